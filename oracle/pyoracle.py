@@ -1,0 +1,239 @@
+"""ctypes bindings for the CPU oracle (oracle/_build/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY -- see oracle/reg_oracle.h.  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+
+
+def build(force=False):
+    """Compile the oracle with gcc (oracle/Makefile)."""
+    if force or not os.path.exists(_LIB_PATH) or _stale():
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+def _stale():
+    t = os.path.getmtime(_LIB_PATH)
+    for f in os.listdir(_HERE):
+        if f.endswith(("_oracle.c", "_oracle.h")):
+            if os.path.getmtime(os.path.join(_HERE, f)) > t:
+                return True
+    return False
+
+
+_lib = None
+
+c_f32p = C.POINTER(C.c_float)
+c_f64p = C.POINTER(C.c_double)
+c_i32p = C.POINTER(C.c_int32)
+c_i64p = C.POINTER(C.c_int64)
+c_u8p = C.POINTER(C.c_uint8)
+
+
+class _OrcLayer(C.Structure):
+    _fields_ = [
+        ("voxel_size", C.c_float), ("voxel_size_inv", C.c_float),
+        ("block_size", C.c_float), ("block_size_inv", C.c_float),
+        ("vps", C.c_int), ("n_blocks", C.c_int),
+        ("block_index", c_i32p), ("distance", c_f32p), ("valid", c_u8p),
+        ("lut_min", C.c_int32 * 3), ("lut_dim", C.c_int32 * 3),
+        ("lut", c_i32p),
+    ]
+
+
+class _OrcRegConfig(C.Structure):
+    _fields_ = [("no_correspondence_cost", C.c_double)]
+
+
+class _Mt(C.Structure):
+    _fields_ = [("mt", C.c_uint32 * 624), ("idx", C.c_int)]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.orc_layer_init.argtypes = [C.POINTER(_OrcLayer), C.c_float, C.c_int, C.c_int,
+                                     c_i32p, c_f32p, c_u8p]
+        L.orc_layer_init.restype = C.c_int
+        L.orc_layer_free.argtypes = [C.POINTER(_OrcLayer)]
+        L.orc_get_voxels_and_q.argtypes = [C.POINTER(_OrcLayer), c_f32p, c_f32p, c_f32p]
+        L.orc_get_voxels_and_q.restype = C.c_int
+        L.orc_relative_transform.argtypes = [c_f64p, c_f64p, c_f32p, c_f32p]
+        L.orc_transform_point.argtypes = [c_f32p, c_f32p, c_f32p, c_f32p]
+        L.orc_pose_jacobian_matrices.argtypes = [C.c_float, C.c_float, c_f64p, c_f64p,
+                                                 c_f32p, c_f32p]
+        L.orc_reg_evaluate.argtypes = [C.POINTER(_OrcLayer), C.POINTER(_OrcRegConfig),
+                                       C.c_int64, c_f32p, c_f32p, c_f32p, c_i64p,
+                                       c_f64p, c_f64p, C.c_int, c_f64p, c_f64p, c_f64p]
+        L.orc_reg_evaluate.restype = C.c_int
+        L.orc_reg_evaluate_normal.argtypes = [C.POINTER(_OrcLayer), C.POINTER(_OrcRegConfig),
+                                              C.c_int64, c_f32p, c_f32p, c_f32p,
+                                              c_f64p, c_f64p, c_f64p, c_f64p, c_f64p]
+        L.orc_reg_evaluate_normal.restype = C.c_int
+        L.orc_mt19937_seed.argtypes = [C.POINTER(_Mt), C.c_uint32]
+        L.orc_mt19937_next.argtypes = [C.POINTER(_Mt)]
+        L.orc_mt19937_next.restype = C.c_uint32
+        L.orc_uniform01.argtypes = [C.POINTER(_Mt)]
+        L.orc_uniform01.restype = C.c_double
+        L.orc_weighted_draw.argtypes = [C.POINTER(_Mt), c_f64p, C.c_int64]
+        L.orc_weighted_draw.restype = C.c_int64
+        L.orc_find_relevant_voxels.argtypes = [C.c_float, C.c_int, C.c_int, c_i32p, c_f32p,
+                                               c_f32p, c_f32p, C.c_double, C.c_double,
+                                               c_f32p, c_f32p, c_f32p]
+        L.orc_find_relevant_voxels.restype = C.c_int64
+        _lib = L
+    return _lib
+
+
+def _p(a, t):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Layer:
+    """voxblox::Layer stand-in: distance + validity per voxel, block-sparse."""
+
+    def __init__(self, voxel_size, vps, block_index, distance, valid):
+        self.block_index = np.ascontiguousarray(block_index, dtype=np.int32).reshape(-1, 3)
+        n = self.block_index.shape[0]
+        self.distance = _f32(distance).reshape(n, vps ** 3)
+        self.valid = np.ascontiguousarray(valid, dtype=np.uint8).reshape(n, vps ** 3)
+        self.voxel_size = float(np.float32(voxel_size))
+        self.vps = int(vps)
+        self._c = _OrcLayer()
+        rc = lib().orc_layer_init(C.byref(self._c), self.voxel_size, self.vps, n,
+                                  _p(self.block_index, c_i32p), _p(self.distance, c_f32p),
+                                  _p(self.valid, c_u8p))
+        if rc != 0:
+            raise MemoryError("orc_layer_init failed")
+
+    def __del__(self):
+        try:
+            lib().orc_layer_free(C.byref(self._c))
+        except Exception:
+            pass
+
+    def voxels_and_q(self, pos):
+        pos = _f32(pos)
+        d = np.zeros(8, np.float32)
+        q = np.zeros(8, np.float32)
+        ok = lib().orc_get_voxels_and_q(C.byref(self._c), _p(pos, c_f32p), _p(d, c_f32p),
+                                        _p(q, c_f32p))
+        return bool(ok), d, q
+
+
+def relative_transform(ref_pose, read_pose):
+    q = np.zeros(4, np.float32)
+    t = np.zeros(3, np.float32)
+    lib().orc_relative_transform(_p(_f64(ref_pose), c_f64p), _p(_f64(read_pose), c_f64p),
+                                 _p(q, c_f32p), _p(t, c_f32p))
+    return q, t
+
+
+def transform_point(q, t, p):
+    out = np.zeros(3, np.float32)
+    lib().orc_transform_point(_p(_f32(q), c_f32p), _p(_f32(t), c_f32p), _p(_f32(p), c_f32p),
+                              _p(out, c_f32p))
+    return out
+
+
+def pose_jacobian_matrices(xi, yi, ref_pose, read_pose):
+    mo = np.zeros(12, np.float32)
+    me = np.zeros(12, np.float32)
+    lib().orc_pose_jacobian_matrices(float(xi), float(yi), _p(_f64(ref_pose), c_f64p),
+                                     _p(_f64(read_pose), c_f64p), _p(mo, c_f32p),
+                                     _p(me, c_f32p))
+    return mo.reshape(3, 4), me.reshape(3, 4)
+
+
+def reg_evaluate(reading, xyz, dist, weight, ref_pose, read_pose, want_jac=True,
+                 want_ref=True, want_read=True, no_correspondence_cost=0.0,
+                 sample_idx=None):
+    """RegistrationCostFunction::Evaluate.  Returns (ok, residuals, jac_ref, jac_read)."""
+    xyz = _f32(xyz).reshape(-1, 3)
+    dist = _f32(dist)
+    weight = _f32(weight)
+    if sample_idx is not None:
+        sample_idx = np.ascontiguousarray(sample_idx, dtype=np.int64)
+        n = sample_idx.shape[0]
+    else:
+        n = xyz.shape[0]
+    res = np.zeros(n, np.float64)
+    jr = np.zeros((n, 4), np.float64) if (want_jac and want_ref) else None
+    je = np.zeros((n, 4), np.float64) if (want_jac and want_read) else None
+    cfg = _OrcRegConfig(no_correspondence_cost)
+    ok = lib().orc_reg_evaluate(C.byref(reading._c), C.byref(cfg), n, _p(xyz, c_f32p),
+                                _p(dist, c_f32p), _p(weight, c_f32p), _p(sample_idx, c_i64p),
+                                _p(_f64(ref_pose), c_f64p), _p(_f64(read_pose), c_f64p),
+                                1 if want_jac else 0, _p(res, c_f64p), _p(jr, c_f64p),
+                                _p(je, c_f64p))
+    return bool(ok), res, jr, je
+
+
+def reg_evaluate_normal(reading, xyz, dist, weight, ref_pose, read_pose,
+                        no_correspondence_cost=0.0):
+    xyz = _f32(xyz).reshape(-1, 3)
+    dist = _f32(dist)
+    weight = _f32(weight)
+    cost = np.zeros(1, np.float64)
+    jtr = np.zeros(8, np.float64)
+    jtj = np.zeros(36, np.float64)
+    cfg = _OrcRegConfig(no_correspondence_cost)
+    ok = lib().orc_reg_evaluate_normal(C.byref(reading._c), C.byref(cfg), xyz.shape[0],
+                                       _p(xyz, c_f32p), _p(dist, c_f32p), _p(weight, c_f32p),
+                                       _p(_f64(ref_pose), c_f64p), _p(_f64(read_pose), c_f64p),
+                                       _p(cost, c_f64p), _p(jtr, c_f64p), _p(jtj, c_f64p))
+    return bool(ok), float(cost[0]), jtr, jtj
+
+
+class Mt19937:
+    def __init__(self, seed=5489):
+        self._g = _Mt()
+        lib().orc_mt19937_seed(C.byref(self._g), seed)
+
+    def next(self):
+        return int(lib().orc_mt19937_next(C.byref(self._g)))
+
+    def uniform01(self):
+        return float(lib().orc_uniform01(C.byref(self._g)))
+
+    def weighted_draw(self, cumulative):
+        cumulative = _f64(cumulative)
+        return int(lib().orc_weighted_draw(C.byref(self._g), _p(cumulative, c_f64p),
+                                           cumulative.shape[0]))
+
+
+def find_relevant_voxels(voxel_size, vps, block_index, tsdf_distance, tsdf_weight,
+                         esdf_distance, min_voxel_weight=1.0, max_voxel_distance=0.3):
+    """VoxgraphSubmap::findRelevantVoxelIndices -> (xyz[n,3], dist[n], weight[n])."""
+    bi = np.ascontiguousarray(block_index, dtype=np.int32).reshape(-1, 3)
+    td = _f32(tsdf_distance)
+    tw = _f32(tsdf_weight)
+    ed = None if esdf_distance is None else _f32(esdf_distance)
+    args = (float(np.float32(voxel_size)), int(vps), bi.shape[0], _p(bi, c_i32p),
+            _p(td, c_f32p), _p(tw, c_f32p), _p(ed, c_f32p), float(min_voxel_weight),
+            float(max_voxel_distance))
+    n = lib().orc_find_relevant_voxels(*args, None, None, None)
+    xyz = np.zeros((n, 3), np.float32)
+    dist = np.zeros(n, np.float32)
+    weight = np.zeros(n, np.float32)
+    lib().orc_find_relevant_voxels(*args, _p(xyz, c_f32p), _p(dist, c_f32p),
+                                   _p(weight, c_f32p))
+    return xyz, dist, weight
