@@ -1,0 +1,231 @@
+/*
+ * voxgraph_amd.h -- C ABI of libvoxgraph_amd.so: voxgraph's two data-parallel
+ * inner loops as hand-written HIP kernels for MI355X (gfx950).
+ *
+ *   REG  : voxgraph::RegistrationCostFunction::Evaluate
+ *          (voxgraph/src/backend/constraint/cost_functions/registration_cost_function.cpp:58-298)
+ *   TSDF : voxblox::FastTsdfIntegrator::integratePointCloud, called at
+ *          voxgraph/src/frontend/measurement_processors/pointcloud_integrator.cpp:83
+ *
+ * Plain C: opaque handles, pointers and sizes, int status codes.  No
+ * exceptions or aborts cross this boundary.  All host pointers are ordinary
+ * (pageable) memory unless a parameter is documented as a DEVICE pointer.
+ * There is no CPU fallback: without a gfx950 device vgx_ctx_create fails with
+ * VGX_ERR_NO_DEVICE and nothing else can be called.
+ *
+ * Reference citations are relative to /root/reference/voxgraph/.
+ * INTEGRATION.md shows the reference-side C++ that binds these entry points.
+ */
+#ifndef VOXGRAPH_AMD_H_
+#define VOXGRAPH_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VGX_API __attribute__((visibility("default")))
+
+/* ---- status codes ------------------------------------------------------ */
+#define VGX_OK 0
+/* Evaluate() would `return false`: summed reference weight == 0
+ * (registration_cost_function.cpp:273).  Outputs are unspecified. */
+#define VGX_EVALUATE_FALSE 1
+#define VGX_ERR_INVALID (-1)     /* bad argument / handle / state            */
+#define VGX_ERR_HIP (-2)         /* a HIP runtime call failed                */
+#define VGX_ERR_NOMEM (-3)       /* host or device allocation failed         */
+#define VGX_ERR_UNSUPPORTED (-4) /* e.g. voxels_per_side not in {8,16}       */
+#define VGX_ERR_NO_DEVICE (-5)   /* no HIP device / not gfx950               */
+
+typedef struct vgx_ctx_s* vgx_ctx;
+typedef struct vgx_submap_s* vgx_submap;
+typedef struct vgx_reg_s* vgx_reg;
+typedef struct vgx_reg_batch_s* vgx_reg_batch;
+
+/* ---- context ----------------------------------------------------------- */
+/* One context per process per GPU (one process per GPU is the multi-GPU
+ * model; constraint shards meet in an RCCL all-reduce issued by the host on
+ * the buffer vgx_reg_batch_evaluate_normal fills). */
+VGX_API int vgx_ctx_create(int device, vgx_ctx* out);
+VGX_API int vgx_ctx_destroy(vgx_ctx ctx);
+/* Human-readable description of the last error on this context (or of the
+ * last failed vgx_ctx_create when ctx == NULL). Never NULL. */
+VGX_API const char* vgx_last_error(vgx_ctx ctx);
+/* Launch all work of this context on an existing hipStream_t (e.g. the
+ * caller's PyTorch stream).  NULL restores the context's own stream. */
+VGX_API int vgx_ctx_set_stream(vgx_ctx ctx, void* hip_stream);
+VGX_API void* vgx_ctx_get_stream(vgx_ctx ctx);
+VGX_API int vgx_ctx_synchronize(vgx_ctx ctx);
+/* hipEvent-based timer on the context's stream (used by bench.py so that
+ * the kernel time is measured on the stream the kernels run on). */
+VGX_API int vgx_ctx_timer_start(vgx_ctx ctx);
+VGX_API int vgx_ctx_timer_stop(vgx_ctx ctx, float* elapsed_ms);
+
+/* ---- submaps ----------------------------------------------------------- */
+/* Stands in for a *finished* voxgraph::VoxgraphSubmap
+ * (include/voxgraph/frontend/submap_collection/voxgraph_submap.h:16): the
+ * TSDF and ESDF voxblox layers (same voxel size and voxels_per_side,
+ * voxgraph_submap.cpp:26-29) plus its cached registration points.  A submap
+ * is immutable once uploaded -- the invariant the reference relies on to
+ * optimise while integrating (voxgraph_mapper.cpp:464-471).
+ *
+ * Layer layout = voxblox's: block b covers block_index[b] * (vps*voxel_size);
+ * per-block arrays hold vps^3 voxels, linear index x + vps*(y + vps*z).
+ * Any of the four voxel arrays may be NULL when that layer is not needed
+ * (REG with use_esdf_distance reads only esdf_*; point extraction reads
+ * tsdf_* and, with use_esdf_distance, esdf_distance).
+ * Distances of valid voxels must be finite. */
+VGX_API int vgx_submap_create(vgx_ctx ctx, int32_t submap_id, float voxel_size,
+                              int32_t voxels_per_side, int32_t n_blocks,
+                              const int32_t* block_index /* [n_blocks][3] */,
+                              const float* tsdf_distance /* [n_blocks][vps^3] */,
+                              const float* tsdf_weight,
+                              const float* esdf_distance,
+                              const uint8_t* esdf_observed,
+                              vgx_submap* out);
+VGX_API int vgx_submap_destroy(vgx_submap submap);
+VGX_API int32_t vgx_submap_id(vgx_submap submap);
+VGX_API int32_t vgx_submap_num_blocks(vgx_submap submap);
+
+/* VoxgraphSubmap::RegistrationPointType (voxgraph_submap.h:65) */
+#define VGX_POINTS_ISOSURFACE 0
+#define VGX_POINTS_VOXELS 1
+
+/* vgx_submap_set_points flags */
+#define VGX_POINTS_KEEP_ORDER 0u
+/* Re-order the points along a Morton curve of their voxel coordinates so a
+ * wavefront's 64 points gather from neighbouring cache lines.  Residual i
+ * then refers to uploaded point order[i] (vgx_submap_point_order); Ceres is
+ * indifferent to residual order, and every residual row still pairs with its
+ * own Jacobian row. */
+#define VGX_POINTS_SORT_MORTON 1u
+
+/* Upload cached registration points (RegistrationPoint,
+ * registration_point.h:6-12): position in the submap frame, distance, weight. */
+VGX_API int vgx_submap_set_points(vgx_submap submap, int32_t point_type,
+                                  int64_t n, const float* xyz /* [n][3] */,
+                                  const float* distance, const float* weight,
+                                  uint32_t flags);
+/* Device-side VoxgraphSubmap::findRelevantVoxelIndices
+ * (voxgraph_submap.cpp:144-201): stream-compacts every TSDF voxel with
+ * weight > min_voxel_weight && |distance| < max_voxel_distance into the
+ * VGX_POINTS_VOXELS set, in block order then (by default) linear-index order.
+ * Needs tsdf_* (and esdf_distance if use_esdf_distance). */
+VGX_API int vgx_submap_extract_voxel_points(vgx_submap submap,
+                                            double min_voxel_weight,
+                                            double max_voxel_distance,
+                                            int32_t use_esdf_distance,
+                                            int64_t* n_points_out);
+VGX_API int64_t vgx_submap_num_points(vgx_submap submap, int32_t point_type);
+/* order[i] = index (in upload / extraction order) of the point residual i uses */
+VGX_API int vgx_submap_point_order(vgx_submap submap, int32_t point_type,
+                                   int64_t* order /* [n] */);
+/* Copy the (re-ordered) device point set back: xyz[n][3], distance, weight. */
+VGX_API int vgx_submap_download_points(vgx_submap submap, int32_t point_type,
+                                       float* xyz, float* distance,
+                                       float* weight);
+/* Drop the raw voxel layers after extraction (keeps the sampling grids). */
+VGX_API int vgx_submap_release_raw_layers(vgx_submap submap);
+
+/* ---- REG: one registration constraint ---------------------------------- */
+/* RegistrationCostFunction::Config (registration_cost_function.h:17-41).
+ * jacobian_evaluation_method is always analytic; visualize_* are ignored. */
+typedef struct vgx_reg_config {
+  int32_t registration_point_type; /* VGX_POINTS_*, default ISOSURFACE (h:20) */
+  float sampling_ratio;            /* -1 disables sampling (h:28)             */
+  double no_correspondence_cost;   /* default 0 (h:32)                        */
+  int32_t use_esdf_distance;       /* default 1 (h:35)                        */
+  uint32_t sampler_seed;           /* std::mt19937 default 5489               */
+} vgx_reg_config;
+VGX_API void vgx_reg_config_default(vgx_reg_config* cfg);
+
+/* new RegistrationCostFunction(reference_submap, reading_submap, config)
+ * (registration_cost_function.cpp:12-56; construction sites
+ * registration_constraint.cpp:33-35, submap_registration_helper.cpp:44-46,
+ * map_evaluation.cpp:143-144).  Cheap: no device allocation proportional to
+ * the point count happens until the first evaluate. */
+VGX_API int vgx_reg_create(vgx_ctx ctx, vgx_submap reference_submap,
+                           vgx_submap reading_submap, const vgx_reg_config* cfg,
+                           vgx_reg* out);
+VGX_API int vgx_reg_destroy(vgx_reg reg);
+/* num_residuals() (registration_cost_function.cpp:45-55) */
+VGX_API int64_t vgx_reg_num_residuals(vgx_reg reg);
+
+/* Drop-in for ceres::CostFunction::Evaluate
+ * (registration_cost_function.h:47-48, .cpp:58-298):
+ *   parameters[0] = ref_pose  {x,y,z,yaw} of the reference (first) submap,
+ *   parameters[1] = read_pose {x,y,z,yaw} of the reading (second) submap,
+ *   residuals[N]; jac_ref / jac_read are jacobians[0] / jacobians[1], each
+ *   [N][4] row-major f64, either or both may be NULL.
+ * All outputs are already scaled by N / sum(w) (.cpp:274-291).
+ * Returns VGX_OK (true), VGX_EVALUATE_FALSE (false) or an error. */
+VGX_API int vgx_reg_evaluate(vgx_reg reg, const double ref_pose[4],
+                             const double read_pose[4], double* residuals,
+                             double* jac_ref, double* jac_read);
+
+/* Same evaluation, results left on the device as f32 (the 88 B/evaluation
+ * form): DEVICE pointers residuals[N], jac_ref[N][4], jac_read[N][4]
+ * (16-byte aligned), either Jacobian may be NULL. Asynchronous on the
+ * context's stream. */
+VGX_API int vgx_reg_evaluate_device_f32(vgx_reg reg, const double ref_pose[4],
+                                        const double read_pose[4],
+                                        void* d_residuals, void* d_jac_ref,
+                                        void* d_jac_read);
+
+/* ---- REG: all constraints of a pose graph in one launch ----------------- */
+/* Mirrors one pass of the Ceres evaluator over every registration residual
+ * block (pose_graph.cpp:101): constraint c links node_pair[c][0] (reference,
+ * first submap) to node_pair[c][1] (reading, second submap).
+ * global_index (nullable) gives each constraint's index in the whole graph
+ * when the constraint list is sharded across processes; n_global is the
+ * unsharded constraint count (== n when global_index == NULL). */
+VGX_API int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs,
+                                 const int32_t* node_pair /* [n][2] */,
+                                 const int32_t* global_index /* [n] or NULL */,
+                                 int32_t n_global, vgx_reg_batch* out);
+VGX_API int vgx_reg_batch_destroy(vgx_reg_batch batch);
+VGX_API int64_t vgx_reg_batch_num_residuals(vgx_reg_batch batch);
+/* row_offset[c] = first row of constraint c in the stacked outputs; [n+1] */
+VGX_API int vgx_reg_batch_row_offsets(vgx_reg_batch batch, int64_t* row_offset);
+
+/* Materialising pass: residual + both Jacobians of every constraint as f32
+ * into DEVICE arrays stacked by row_offset: residuals[R], jac_ref[R][4],
+ * jac_read[R][4].  poses: host [n_nodes][4] f64.  status[c] (host, nullable)
+ * receives VGX_OK / VGX_EVALUATE_FALSE per constraint.  Asynchronous. */
+VGX_API int vgx_reg_batch_evaluate_points(vgx_reg_batch batch,
+                                          const double* poses, int32_t n_nodes,
+                                          void* d_residuals, void* d_jac_ref,
+                                          void* d_jac_read, int32_t* status);
+
+/* Fused pass: no per-point outputs.  Per constraint c, 45 f64:
+ *   [0]      sum r^2
+ *   [1..8]   J^T r      over the stacked parameters [ref(4), read(4)]
+ *   [9..44]  upper triangle of J^T J (row-major, 8x8)
+ * d_normal: DEVICE pointer [n][45] (nullable); normal_host: host [n][45]
+ * (nullable; implies a stream synchronisation).
+ * Deterministic: fixed reduction tree, no atomics. */
+VGX_API int vgx_reg_batch_evaluate_normal(vgx_reg_batch batch,
+                                          const double* poses, int32_t n_nodes,
+                                          void* d_normal, double* normal_host,
+                                          int32_t* status);
+
+/* Scatter-adds this process's [n][45] blocks into the fused buffer every
+ * process all-reduces once per solver evaluation, DEVICE f64:
+ *   [0]                               sum of costs
+ *   [1 .. 4*n_nodes]                  J^T r per node
+ *   [.. + 16*n_nodes]                 diagonal 4x4 blocks of J^T J per node
+ *   [.. + 16*n_global]                off-diagonal 4x4 block (ref rows, read
+ *                                     cols) per constraint, written by exactly
+ *                                     one process
+ * The buffer is zeroed first when `zero_first` != 0. */
+VGX_API int vgx_reg_batch_assemble(vgx_reg_batch batch, const void* d_normal,
+                                   int32_t n_nodes, void* d_fused,
+                                   int32_t zero_first);
+VGX_API int64_t vgx_reg_fused_size(int32_t n_nodes, int32_t n_global);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOXGRAPH_AMD_H_ */

@@ -1,0 +1,71 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every
+symbol include/voxgraph_amd.h declares, and refuses to run without a GPU (no
+fallback).  No compute calls here."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def capi():
+    import __graft_entry__ as g
+    g.build()
+    from voxgraph_amd import capi
+    return capi
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "voxgraph_amd.h")).read()
+    return sorted(set(re.findall(r"VGX_API\s+[\w\s\*]+?\b(vgx_\w+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(capi):
+    lib = capi.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in voxgraph_amd.h but not exported"
+    # and the ctypes table covers the header exactly
+    assert sorted(capi.SIGNATURES) == declared
+
+
+def test_only_c_abi_symbols_are_exported(capi):
+    out = subprocess.check_output(["nm", "-D", "--defined-only", capi.LIB_PATH]).decode()
+    names = [l.split()[-1] for l in out.splitlines() if " T " in l]
+    assert names and all(n.startswith("vgx_") for n in names), [n for n in names
+                                                               if not n.startswith("vgx_")][:5]
+
+
+def test_product_does_not_link_or_reference_the_oracle(capi):
+    out = subprocess.check_output(["ldd", capi.LIB_PATH]).decode()
+    assert "oracle" not in out
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "voxgraph_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in src.lower(), (dirpath, f)
+
+
+def test_no_gpu_means_loud_failure_not_fallback(capi):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(capi.VgxError) as e:
+        capi.Context(0)
+    assert e.value.code == capi.ERR_NO_DEVICE
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_config_defaults_match_reference(capi):
+    """registration_cost_function.h:20-35"""
+    cfg = capi.default_config()
+    assert cfg.registration_point_type == capi.POINTS_ISOSURFACE == 0
+    assert cfg.sampling_ratio == -1
+    assert cfg.no_correspondence_cost == 0
+    assert cfg.use_esdf_distance == 1
+    assert cfg.sampler_seed == 5489
+    assert capi.fused_size(200, 1000) == 1 + 20 * 200 + 16 * 1000

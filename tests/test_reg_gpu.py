@@ -1,0 +1,391 @@
+"""GPU parity tests of the REG path: HIP kernels (through the C ABI) vs the CPU
+oracle on identical seeded inputs.  Tolerance: north_star's 1e-4 relative on
+residuals and Jacobians (tests/helpers.py defines "relative")."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as orc
+from oracle import synth
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from voxgraph_amd import capi
+    return capi
+
+
+@pytest.fixture(scope="module")
+def ctx(capi):
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def cfg1(capi, ctx):
+    """BASELINE config 1: duplicated 64^3 sphere+ground submap."""
+    sm, _ = synth.config1_pair()
+    g = H.gpu_submap(capi, ctx, sm)
+    xyz, dist, w = H.oracle_points(sm)
+    return sm, g, H.oracle_layer(sm), (xyz, dist, w)
+
+
+def _gpu_eval(cf, ref_pose, read_pose, want_ref=True, want_read=True, want_jac=True):
+    n = cf.num_residuals()
+    r = np.full(n, np.nan)
+    jo = np.full((n, 4), np.nan) if (want_jac and want_ref) else None
+    je = np.full((n, 4), np.nan) if (want_jac and want_read) else None
+    ok = cf.Evaluate([ref_pose, read_pose], r, [jo, je] if want_jac else None)
+    return ok, r, jo, je
+
+
+def test_device_extraction_is_bit_exact(capi, ctx, cfg1):
+    """voxgraph_submap.cpp:144-201 on the device == oracle, same order, same bits."""
+    sm, g, _, (xyz, dist, w) = cfg1
+    n = g.extract_voxel_points(1.0, 0.3, True)
+    assert n == len(w)
+    gx, gd, gw = g.download_points(capi.POINTS_VOXELS)
+    assert np.array_equal(gx, xyz) and np.array_equal(gd, dist) and np.array_equal(gw, w)
+    assert np.array_equal(g.point_order(capi.POINTS_VOXELS), np.arange(n))
+    # TSDF-distance variant and a different filter
+    x2, d2, w2 = H.oracle_points(sm, use_esdf=False, min_w=0.5, max_d=0.17)
+    g2 = H.gpu_submap(capi, ctx, sm, 7)
+    assert g2.extract_voxel_points(0.5, 0.17, False) == len(w2)
+    a, b, c = g2.download_points(capi.POINTS_VOXELS)
+    assert np.array_equal(a, x2) and np.array_equal(b, d2) and np.array_equal(c, w2)
+    g2.destroy()
+
+
+def test_evaluate_matches_oracle_on_reference_test_grid(capi, ctx, cfg1):
+    """Drop-in Evaluate vs oracle over the reference's perturbation grid
+    (registration_test_bench.yaml:9-13)."""
+    sm, g, layer, (xyz, dist, w) = cfg1
+    g.extract_voxel_points()
+    cf = capi.RegistrationCostFunction(
+        ctx, g, g, capi.default_config(registration_point_type=capi.POINTS_VOXELS))
+    assert cf.num_residuals() == len(w)
+    worst = 0.0
+    grid = H.test_bench_grid(sm.voxel_size)
+    for k, pert in enumerate(grid[::3] + [np.zeros(4)]):
+        ref_pose = np.array([0.02, -0.01, 0.03, 0.01])
+        read_pose = ref_pose + pert
+        ok, r, jo, je = _gpu_eval(cf, ref_pose, read_pose)
+        ok0, r0, jo0, je0 = orc.reg_evaluate(layer, xyz, dist, w, ref_pose, read_pose)
+        assert ok and ok0
+        worst = max(worst, H.assert_parity(r, r0, f"residual[{k}]"),
+                    H.assert_parity(jo, jo0, f"jac_ref[{k}]"),
+                    H.assert_parity(je, je0, f"jac_read[{k}]"))
+    print("worst relative error over the grid:", worst)
+    cf.destroy()
+
+
+def test_identical_poses_give_exactly_zero_residuals(capi, ctx, cfg1):
+    """Duplicate submap at the same pose: every point is a voxel centre of the
+    reading grid, Delta == 0, so r == (d - d) w == 0 exactly (size-independent)."""
+    sm, g, layer, (xyz, dist, w) = cfg1
+    g.extract_voxel_points()
+    cf = capi.RegistrationCostFunction(
+        ctx, g, g, capi.default_config(registration_point_type=capi.POINTS_VOXELS))
+    ok, r, jo, je = _gpu_eval(cf, np.zeros(4), np.zeros(4))
+    assert ok and np.all(r == 0.0)
+    cf.destroy()
+
+
+def test_morton_order_is_a_permutation_of_the_same_rows(capi, ctx, cfg1):
+    sm, _, layer, (xyz, dist, w) = cfg1
+    g = H.gpu_submap(capi, ctx, sm, 3)
+    g.set_points(capi.POINTS_VOXELS, xyz, dist, w, capi.POINTS_SORT_MORTON)
+    order = g.point_order(capi.POINTS_VOXELS)
+    assert np.array_equal(np.sort(order), np.arange(len(w)))
+    cf = capi.RegistrationCostFunction(
+        ctx, g, g, capi.default_config(registration_point_type=capi.POINTS_VOXELS))
+    ref_pose = np.array([0.05, 0.02, -0.03, 0.04])
+    read_pose = np.array([-0.02, 0.0, 0.01, -0.03])
+    ok, r, jo, je = _gpu_eval(cf, ref_pose, read_pose)
+    ok0, r0, jo0, je0 = orc.reg_evaluate(layer, xyz, dist, w, ref_pose, read_pose)
+    assert ok and ok0
+    H.assert_parity(r, r0[order], "residual")
+    H.assert_parity(jo, jo0[order], "jac_ref")
+    H.assert_parity(je, je0[order], "jac_read")
+    cf.destroy()
+    g.destroy()
+
+
+def test_null_jacobian_blocks_and_no_jacobians(capi, ctx, cfg1):
+    """jacobians == nullptr (.cpp:179) and jacobians[k] == nullptr (.cpp:254,261)."""
+    sm, g, layer, (xyz, dist, w) = cfg1
+    g.extract_voxel_points()
+    cf = capi.RegistrationCostFunction(
+        ctx, g, g, capi.default_config(registration_point_type=capi.POINTS_VOXELS))
+    a, b = np.array([0.03, 0.0, 0.0, 0.02]), np.array([0.0, 0.02, 0.01, 0.0])
+    ok, r_full, jo_full, je_full = _gpu_eval(cf, a, b)
+    ok, r, jo, je = _gpu_eval(cf, a, b, want_jac=False)
+    assert ok and np.array_equal(r, r_full)
+    ok, r, jo, je = _gpu_eval(cf, a, b, want_ref=False)
+    assert ok and jo is None and np.array_equal(je, je_full) and np.array_equal(r, r_full)
+    ok, r, jo, je = _gpu_eval(cf, a, b, want_read=False)
+    assert ok and je is None and np.array_equal(jo, jo_full)
+    cf.destroy()
+
+
+def test_sparse_submap_missing_blocks_and_no_correspondence_cost(capi, ctx):
+    """Missing blocks / unobserved neighbours => w * no_correspondence_cost and zero
+    Jacobian rows (.cpp:164-167,240-243); negative block indices; partial overlap."""
+    sdf = synth.sphere_ground_sdf((0.3, -0.2, 0.1), 1.5, -1.0)
+    ref = synth.make_submap(sdf, 0.1, 16, (-2, -2, -2), (4, 4, 4), trunc=0.3, esdf_max=0.8,
+                            drop_empty_blocks=True)
+    read = synth.make_submap(sdf, 0.1, 16, (-1, -2, -1), (3, 3, 3), trunc=0.3, esdf_max=0.8,
+                             pose=(0.4, 0.1, -0.2, 0.3), drop_empty_blocks=True)
+    assert 0 < ref.n_blocks < 64
+    g_ref, g_read = H.gpu_submap(capi, ctx, ref, 0), H.gpu_submap(capi, ctx, read, 1)
+    xyz, dist, w = H.oracle_points(ref)
+    w = (w * np.random.default_rng(5).uniform(0.2, 1.0, len(w))).astype(F)   # varied weights
+    g_ref.set_points(capi.POINTS_VOXELS, xyz, dist, w)
+    layer = H.oracle_layer(read)
+    cfg = capi.default_config(registration_point_type=capi.POINTS_VOXELS,
+                              no_correspondence_cost=0.37)
+    cf = capi.RegistrationCostFunction(ctx, g_ref, g_read, cfg)
+    ref_pose = np.array([0.0, 0.0, 0.0, 0.0])
+    read_pose = np.array([0.45, 0.05, -0.22, 0.27])
+    ok, r, jo, je = _gpu_eval(cf, ref_pose, read_pose)
+    ok0, r0, jo0, je0 = orc.reg_evaluate(layer, xyz, dist, w, ref_pose, read_pose,
+                                         no_correspondence_cost=0.37)
+    assert ok and ok0
+    no_corr = np.all(jo0 == 0, axis=1) & np.all(je0 == 0, axis=1)
+    assert 0.02 < no_corr.mean() < 0.98, no_corr.mean()
+    assert np.array_equal(np.all(jo == 0, axis=1) & np.all(je == 0, axis=1), no_corr)
+    H.assert_parity(r, r0, "residual")
+    H.assert_parity(jo, jo0, "jac_ref")
+    H.assert_parity(je, je0, "jac_read")
+    for o in (cf, g_ref, g_read):
+        o.destroy()
+
+
+def test_tsdf_distance_mode_and_vps8(capi, ctx):
+    """use_esdf_distance == false samples the TSDF layer, valid iff weight > 0
+    (.cpp:143-153); voxels_per_side 8."""
+    sdf = synth.sphere_ground_sdf((1.0, 1.0, 1.0), 0.8, 0.3)
+    sm = synth.make_submap(sdf, 0.05, 8, (0, 0, 0), (5, 5, 5), trunc=0.15, esdf_max=0.5)
+    g = H.gpu_submap(capi, ctx, sm)
+    xyz, dist, w = H.oracle_points(sm, use_esdf=False, max_d=0.1)
+    assert g.extract_voxel_points(1.0, 0.1, False) == len(w)
+    layer = H.oracle_layer(sm, use_esdf=False)
+    cfg = capi.default_config(registration_point_type=capi.POINTS_VOXELS, use_esdf_distance=0)
+    cf = capi.RegistrationCostFunction(ctx, g, g, cfg)
+    a, b = np.array([0.01, 0.0, 0.02, 0.05]), np.array([0.0, 0.03, 0.0, -0.02])
+    ok, r, jo, je = _gpu_eval(cf, a, b)
+    ok0, r0, jo0, je0 = orc.reg_evaluate(layer, xyz, dist, w, a, b)
+    assert ok and ok0 and np.any(np.all(jo0 == 0, axis=1)) and np.any(jo0 != 0)
+    H.assert_parity(r, r0, "residual")
+    H.assert_parity(jo, jo0, "jac_ref")
+    H.assert_parity(je, je0, "jac_read")
+    cf.destroy()
+    g.destroy()
+
+
+def test_zero_weight_sum_returns_false_and_empty_point_set(capi, ctx, cfg1):
+    """.cpp:273"""
+    sm, _, _, (xyz, dist, w) = cfg1
+    g = H.gpu_submap(capi, ctx, sm, 9)
+    g.set_points(capi.POINTS_VOXELS, xyz[:100], dist[:100], np.zeros(100, F))
+    cf = capi.RegistrationCostFunction(
+        ctx, g, g, capi.default_config(registration_point_type=capi.POINTS_VOXELS))
+    ok, *_ = _gpu_eval(cf, np.zeros(4), np.zeros(4))
+    assert ok is False
+    cf.destroy()
+    g.set_points(capi.POINTS_ISOSURFACE, xyz[:0], dist[:0], w[:0])
+    cf = capi.RegistrationCostFunction(ctx, g, g, capi.default_config())
+    assert cf.num_residuals() == 0
+    assert _gpu_eval(cf, np.zeros(4), np.zeros(4))[0] is False     # sum of no weights == 0
+    cf.destroy()
+    # unfinished submap (no points of the requested type) is an error, not a crash
+    g3 = H.gpu_submap(capi, ctx, sm, 10)
+    with pytest.raises(capi.VgxError):
+        capi.RegistrationCostFunction(ctx, g3, g3, capi.default_config())
+    g3.destroy()
+    g.destroy()
+
+
+def test_sampling_mode_reproduces_the_weighted_sampler_stream(capi, ctx, cfg1):
+    """sampling_ratio != -1 (.cpp:46-50,115-122): default-seeded mt19937, draws
+    proportional to weight, weight := 1; two consecutive Evaluates continue the
+    stream like the reference's mutable sampler."""
+    sm, _, layer, (xyz, dist, w) = cfg1
+    rng = np.random.default_rng(11)
+    w2 = (w * rng.uniform(0.1, 1.0, len(w))).astype(F)
+    for flags in (capi.POINTS_KEEP_ORDER, capi.POINTS_SORT_MORTON):
+        g = H.gpu_submap(capi, ctx, sm, 20)
+        g.set_points(capi.POINTS_VOXELS, xyz, dist, w2, flags)
+        cfg = capi.default_config(registration_point_type=capi.POINTS_VOXELS, sampling_ratio=0.05)
+        cf = capi.RegistrationCostFunction(ctx, g, g, cfg)
+        n = cf.num_residuals()
+        assert n == int(np.float32(0.05) * np.float32(len(w2)))
+        cum = np.cumsum(w2.astype(np.float64))
+        # addItem accumulates sequentially in double (weighted_sampler_inl.h:5-16)
+        acc, cum_seq = 0.0, np.zeros(len(w2))
+        for i, v in enumerate(w2.astype(np.float64)):
+            acc = v if i == 0 else acc + v
+            cum_seq[i] = acc
+        eng = orc.Mt19937(5489)
+        a, b = np.array([0.02, 0.01, 0.0, 0.03]), np.array([0.0, 0.0, 0.02, -0.01])
+        for call in range(2):
+            idx = np.array([eng.weighted_draw(cum_seq) for _ in range(n)], np.int64)
+            ok, r, jo, je = _gpu_eval(cf, a, b)
+            ok0, r0, jo0, je0 = orc.reg_evaluate(layer, xyz, dist, w2, a, b, sample_idx=idx)
+            assert ok and ok0
+            H.assert_parity(r, r0, f"residual call {call}")
+            H.assert_parity(jo, jo0, f"jac_ref call {call}")
+            H.assert_parity(je, je0, f"jac_read call {call}")
+        cf.destroy()
+        g.destroy()
+
+
+def _torch_buf(n, dtype):
+    import torch
+    return torch.full((n,), float("nan"), dtype=dtype, device="cuda:0")
+
+
+def test_device_f32_outputs(capi, ctx, cfg1):
+    """The 88 B/evaluation form: f32 results left on the device."""
+    import torch
+    sm, g, layer, (xyz, dist, w) = cfg1
+    g.extract_voxel_points()
+    cf = capi.RegistrationCostFunction(
+        ctx, g, g, capi.default_config(registration_point_type=capi.POINTS_VOXELS))
+    n = cf.num_residuals()
+    r, jo, je = _torch_buf(n, torch.float32), _torch_buf(4 * n, torch.float32), _torch_buf(4 * n, torch.float32)
+    a, b = np.array([0.03, -0.02, 0.01, 0.02]), np.array([0.0, 0.01, 0.0, -0.02])
+    torch.cuda.synchronize()
+    assert cf.evaluate_device_f32(a, b, r.data_ptr(), jo.data_ptr(), je.data_ptr())
+    ctx.synchronize()
+    ok0, r0, jo0, je0 = orc.reg_evaluate(layer, xyz, dist, w, a, b)
+    H.assert_parity(r.cpu().numpy(), r0, "residual")
+    H.assert_parity(jo.cpu().numpy().reshape(n, 4), jo0, "jac_ref")
+    H.assert_parity(je.cpu().numpy().reshape(n, 4), je0, "jac_read")
+    cf.destroy()
+
+
+@pytest.fixture(scope="module")
+def small_graph(capi, ctx):
+    """4 overlapping submaps of one scene, 5 constraints (both directions of one pair)."""
+    sdf = synth.sphere_ground_sdf((1.6, 1.6, 1.2), 1.0, 0.35)
+    poses_true = [(0, 0, 0, 0), (0.8, 0.1, 0.0, 0.1), (0.1, 0.9, 0.05, -0.15), (0.9, 0.8, 0.0, 0.2)]
+    sms, gs, layers, pts = [], [], [], []
+    for i, p in enumerate(poses_true):
+        sm = synth.make_submap(sdf, 0.1, 16, (0, 0, 0), (2, 2, 2), trunc=0.3, esdf_max=1.0,
+                               pose=p, drop_empty_blocks=True)
+        g = H.gpu_submap(capi, ctx, sm, i)
+        xyz, dist, w = H.oracle_points(sm)
+        g.set_points(capi.POINTS_VOXELS, xyz, dist, w,
+                     capi.POINTS_SORT_MORTON if i % 2 else capi.POINTS_KEEP_ORDER)
+        order = g.point_order(capi.POINTS_VOXELS)
+        sms.append(sm), gs.append(g), layers.append(H.oracle_layer(sm))
+        pts.append((xyz[order], dist[order], w[order]))
+    pairs = [(0, 1), (1, 0), (0, 2), (1, 3), (2, 3)]
+    cfg = capi.default_config(registration_point_type=capi.POINTS_VOXELS)
+    cfs = [capi.RegistrationCostFunction(ctx, gs[a], gs[b], cfg) for a, b in pairs]
+    rng = np.random.default_rng(2)
+    poses = np.array(poses_true, np.float64) + rng.normal(0, 0.03, (4, 4))
+    yield dict(gs=gs, layers=layers, pts=pts, pairs=pairs, cfs=cfs, poses=poses)
+    for o in cfs + gs:
+        o.destroy()
+
+
+def test_batch_points_match_per_constraint_oracle(capi, ctx, small_graph):
+    import torch
+    G = small_graph
+    batch = capi.RegistrationBatch(ctx, G["cfs"], G["pairs"])
+    ro = batch.row_offsets()
+    R = batch.num_residuals()
+    assert ro[-1] == R == sum(cf.num_residuals() for cf in G["cfs"])
+    r, jo, je = _torch_buf(R, torch.float32), _torch_buf(4 * R, torch.float32), _torch_buf(4 * R, torch.float32)
+    torch.cuda.synchronize()
+    status = batch.evaluate_points(G["poses"], r.data_ptr(), jo.data_ptr(), je.data_ptr())
+    ctx.synchronize()
+    assert np.all(status == 0)
+    r, jo, je = r.cpu().numpy(), jo.cpu().numpy().reshape(R, 4), je.cpu().numpy().reshape(R, 4)
+    for c, (a, b) in enumerate(G["pairs"]):
+        xyz, dist, w = G["pts"][a]
+        ok0, r0, jo0, je0 = orc.reg_evaluate(G["layers"][b], xyz, dist, w, G["poses"][a], G["poses"][b])
+        s = slice(ro[c], ro[c + 1])
+        H.assert_parity(r[s], r0, f"residual c{c}")
+        H.assert_parity(jo[s], jo0, f"jac_ref c{c}")
+        H.assert_parity(je[s], je0, f"jac_read c{c}")
+    batch.destroy()
+
+
+def test_batch_normal_equations_and_assembly(capi, ctx, small_graph):
+    import torch
+    G = small_graph
+    n_nodes = 5     # one more node than the batch touches
+    batch = capi.RegistrationBatch(ctx, G["cfs"], G["pairs"])
+    status, normal = batch.evaluate_normal(G["poses"])
+    assert np.all(status == 0)
+    want = np.zeros_like(normal)
+    for c, (a, b) in enumerate(G["pairs"]):
+        xyz, dist, w = G["pts"][a]
+        ok, cost, jtr, jtj = orc.reg_evaluate_normal(G["layers"][b], xyz, dist, w, G["poses"][a], G["poses"][b])
+        want[c] = np.concatenate([[cost], jtr, jtj])
+        scale = np.abs(jtj).max()
+        assert abs(normal[c, 0] - cost) <= 1e-6 * cost
+        assert np.all(np.abs(normal[c, 1:9] - jtr) <= 1e-6 * np.abs(jtr).max() + 1e-12)
+        assert np.all(np.abs(normal[c, 9:] - jtj) <= 1e-6 * scale)
+    # reproducible bit for bit
+    _, normal2 = batch.evaluate_normal(G["poses"])
+    assert np.array_equal(normal, normal2)
+    # assembly into the all-reduce buffer
+    size = capi.fused_size(n_nodes, batch.n_global)
+    fused = torch.full((size,), float("nan"), dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    batch.assemble(n_nodes, fused.data_ptr(), zero_first=True)
+    ctx.synchronize()
+    fused = fused.cpu().numpy()
+    exp = np.zeros(size)
+    iu = np.triu_indices(8)
+    for c, (a, b) in enumerate(G["pairs"]):
+        Hm = np.zeros((8, 8))
+        Hm[iu] = normal[c, 9:]
+        Hm = Hm + np.triu(Hm, 1).T
+        exp[0] += normal[c, 0]
+        for side, node in enumerate((a, b)):
+            exp[1 + 4 * node:1 + 4 * node + 4] += normal[c, 1 + 4 * side:5 + 4 * side]
+            blk = Hm[4 * side:4 * side + 4, 4 * side:4 * side + 4]
+            o = 1 + 4 * n_nodes + 16 * node
+            exp[o:o + 16] += blk.ravel()
+        o = 1 + 20 * n_nodes + 16 * c
+        exp[o:o + 16] = Hm[0:4, 4:8].ravel()
+    np.testing.assert_allclose(fused, exp, rtol=1e-12, atol=1e-9)
+    batch.destroy()
+
+
+def test_sharded_batches_sum_to_the_unsharded_buffer(capi, ctx, small_graph):
+    """Pair-sharding with N logical shards on one device: the
+    per-shard fused buffers add up to the unsharded one."""
+    import torch
+    G = small_graph
+    n_nodes, n = 4, len(G["pairs"])
+    full = capi.RegistrationBatch(ctx, G["cfs"], G["pairs"])
+    size = capi.fused_size(n_nodes, n)
+    buf = torch.zeros(size, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    full.evaluate_normal(G["poses"], to_host=False)
+    full.assemble(n_nodes, buf.data_ptr())
+    ctx.synchronize()
+    want = buf.cpu().numpy()
+    total = np.zeros(size)
+    for shard in ([0, 3], [1, 2, 4]):
+        b = capi.RegistrationBatch(ctx, [G["cfs"][i] for i in shard], [G["pairs"][i] for i in shard],
+                                   global_index=shard, n_global=n)
+        sb = torch.zeros(size, dtype=torch.float64, device="cuda:0")
+        torch.cuda.synchronize()
+        b.evaluate_normal(G["poses"], to_host=False)
+        b.assemble(n_nodes, sb.data_ptr())
+        ctx.synchronize()
+        total += sb.cpu().numpy()
+        b.destroy()
+    np.testing.assert_allclose(total, want, rtol=1e-12, atol=1e-9)
+    full.destroy()

@@ -1,0 +1,317 @@
+"""ctypes view of libvoxgraph_amd.so (include/voxgraph_amd.h).
+
+This module only declares the C ABI and wraps handles; all arithmetic happens in
+the HIP library.  There is no fallback: if the shared object is missing the
+import fails, and without a gfx950 device Context() raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvoxgraph_amd.so")
+
+OK = 0
+EVALUATE_FALSE = 1
+ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_UNSUPPORTED, ERR_NO_DEVICE = -1, -2, -3, -4, -5
+
+POINTS_ISOSURFACE = 0
+POINTS_VOXELS = 1
+POINTS_KEEP_ORDER = 0
+POINTS_SORT_MORTON = 1
+
+NORMAL_SIZE = 45
+
+vp = C.c_void_p
+f32p = C.POINTER(C.c_float)
+f64p = C.POINTER(C.c_double)
+i32p = C.POINTER(C.c_int32)
+i64p = C.POINTER(C.c_int64)
+u8p = C.POINTER(C.c_uint8)
+
+
+class RegConfig(C.Structure):
+    """vgx_reg_config == RegistrationCostFunction::Config (registration_cost_function.h:17-41)."""
+    _fields_ = [("registration_point_type", C.c_int32), ("sampling_ratio", C.c_float),
+                ("no_correspondence_cost", C.c_double), ("use_esdf_distance", C.c_int32),
+                ("sampler_seed", C.c_uint32)]
+
+
+# every symbol include/voxgraph_amd.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "vgx_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+    "vgx_ctx_destroy": (C.c_int, [vp]),
+    "vgx_last_error": (C.c_char_p, [vp]),
+    "vgx_ctx_set_stream": (C.c_int, [vp, vp]),
+    "vgx_ctx_get_stream": (vp, [vp]),
+    "vgx_ctx_synchronize": (C.c_int, [vp]),
+    "vgx_ctx_timer_start": (C.c_int, [vp]),
+    "vgx_ctx_timer_stop": (C.c_int, [vp, f32p]),
+    "vgx_submap_create": (C.c_int, [vp, C.c_int32, C.c_float, C.c_int32, C.c_int32, i32p, f32p,
+                                    f32p, f32p, u8p, C.POINTER(vp)]),
+    "vgx_submap_destroy": (C.c_int, [vp]),
+    "vgx_submap_id": (C.c_int32, [vp]),
+    "vgx_submap_num_blocks": (C.c_int32, [vp]),
+    "vgx_submap_set_points": (C.c_int, [vp, C.c_int32, C.c_int64, f32p, f32p, f32p, C.c_uint32]),
+    "vgx_submap_extract_voxel_points": (C.c_int, [vp, C.c_double, C.c_double, C.c_int32, i64p]),
+    "vgx_submap_num_points": (C.c_int64, [vp, C.c_int32]),
+    "vgx_submap_point_order": (C.c_int, [vp, C.c_int32, i64p]),
+    "vgx_submap_download_points": (C.c_int, [vp, C.c_int32, f32p, f32p, f32p]),
+    "vgx_submap_release_raw_layers": (C.c_int, [vp]),
+    "vgx_reg_config_default": (None, [C.POINTER(RegConfig)]),
+    "vgx_reg_create": (C.c_int, [vp, vp, vp, C.POINTER(RegConfig), C.POINTER(vp)]),
+    "vgx_reg_destroy": (C.c_int, [vp]),
+    "vgx_reg_num_residuals": (C.c_int64, [vp]),
+    "vgx_reg_evaluate": (C.c_int, [vp, f64p, f64p, f64p, f64p, f64p]),
+    "vgx_reg_evaluate_device_f32": (C.c_int, [vp, f64p, f64p, vp, vp, vp]),
+    "vgx_reg_batch_create": (C.c_int, [vp, C.c_int32, C.POINTER(vp), i32p, i32p, C.c_int32,
+                                       C.POINTER(vp)]),
+    "vgx_reg_batch_destroy": (C.c_int, [vp]),
+    "vgx_reg_batch_num_residuals": (C.c_int64, [vp]),
+    "vgx_reg_batch_row_offsets": (C.c_int, [vp, i64p]),
+    "vgx_reg_batch_evaluate_points": (C.c_int, [vp, f64p, C.c_int32, vp, vp, vp, i32p]),
+    "vgx_reg_batch_evaluate_normal": (C.c_int, [vp, f64p, C.c_int32, vp, f64p, i32p]),
+    "vgx_reg_batch_assemble": (C.c_int, [vp, vp, C.c_int32, vp, C.c_int32]),
+    "vgx_reg_fused_size": (C.c_int64, [C.c_int32, C.c_int32]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libvoxgraph_amd.so and bind every declared symbol (loud on failure)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)     # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+class VgxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"vgx error {code}: {msg}")
+        self.code = code
+
+
+def _ptr(a, t):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+def _f32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Context:
+    def __init__(self, device=0):
+        self.lib = load()
+        h = vp()
+        rc = self.lib.vgx_ctx_create(device, C.byref(h))
+        if rc != OK:
+            raise VgxError(rc, self.lib.vgx_last_error(None).decode())
+        self.h = h
+
+    def check(self, rc):
+        if rc < 0:
+            raise VgxError(rc, self.lib.vgx_last_error(self.h).decode())
+        return rc
+
+    def set_stream(self, stream_ptr):
+        self.check(self.lib.vgx_ctx_set_stream(self.h, vp(stream_ptr)))
+
+    def synchronize(self):
+        self.check(self.lib.vgx_ctx_synchronize(self.h))
+
+    def timer_start(self):
+        self.check(self.lib.vgx_ctx_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self.check(self.lib.vgx_ctx_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if self.h:
+            self.lib.vgx_ctx_destroy(self.h)
+            self.h = None
+
+
+class Submap:
+    """A finished VoxgraphSubmap resident on the GPU."""
+
+    def __init__(self, ctx, submap_id, voxel_size, vps, block_index, tsdf_distance=None,
+                 tsdf_weight=None, esdf_distance=None, esdf_observed=None):
+        self.ctx = ctx
+        bi = np.ascontiguousarray(block_index, dtype=np.int32).reshape(-1, 3)
+        td, tw, ed = _f32(tsdf_distance), _f32(tsdf_weight), _f32(esdf_distance)
+        eo = None if esdf_observed is None else np.ascontiguousarray(esdf_observed, np.uint8)
+        h = vp()
+        ctx.check(ctx.lib.vgx_submap_create(ctx.h, submap_id, float(voxel_size), vps, bi.shape[0],
+                                            _ptr(bi, i32p), _ptr(td, f32p), _ptr(tw, f32p),
+                                            _ptr(ed, f32p), _ptr(eo, u8p), C.byref(h)))
+        self.h = h
+
+    def set_points(self, point_type, xyz, distance, weight, flags=POINTS_KEEP_ORDER):
+        xyz = _f32(xyz).reshape(-1, 3)
+        d, w = _f32(distance), _f32(weight)
+        self.ctx.check(self.ctx.lib.vgx_submap_set_points(
+            self.h, point_type, xyz.shape[0], _ptr(xyz, f32p), _ptr(d, f32p), _ptr(w, f32p), flags))
+
+    def extract_voxel_points(self, min_voxel_weight=1.0, max_voxel_distance=0.3,
+                             use_esdf_distance=True):
+        n = C.c_int64()
+        self.ctx.check(self.ctx.lib.vgx_submap_extract_voxel_points(
+            self.h, min_voxel_weight, max_voxel_distance, int(use_esdf_distance), C.byref(n)))
+        return n.value
+
+    def num_points(self, point_type):
+        return self.ctx.lib.vgx_submap_num_points(self.h, point_type)
+
+    def point_order(self, point_type):
+        n = self.num_points(point_type)
+        order = np.zeros(max(n, 0), np.int64)
+        self.ctx.check(self.ctx.lib.vgx_submap_point_order(self.h, point_type, _ptr(order, i64p)))
+        return order
+
+    def download_points(self, point_type):
+        n = self.num_points(point_type)
+        xyz = np.zeros((n, 3), np.float32)
+        d = np.zeros(n, np.float32)
+        w = np.zeros(n, np.float32)
+        self.ctx.check(self.ctx.lib.vgx_submap_download_points(
+            self.h, point_type, _ptr(xyz, f32p), _ptr(d, f32p), _ptr(w, f32p)))
+        return xyz, d, w
+
+    def release_raw_layers(self):
+        self.ctx.check(self.ctx.lib.vgx_submap_release_raw_layers(self.h))
+
+    def destroy(self):
+        if self.h:
+            self.ctx.lib.vgx_submap_destroy(self.h)
+            self.h = None
+
+
+def default_config(**kw):
+    cfg = RegConfig()
+    load().vgx_reg_config_default(C.byref(cfg))
+    for k, v in kw.items():
+        if not hasattr(cfg, k):
+            raise AttributeError(k)
+        setattr(cfg, k, v)
+    return cfg
+
+
+class RegistrationCostFunction:
+    """Mirror of voxgraph::RegistrationCostFunction over the C ABI.
+
+    Evaluate(parameters, residuals, jacobians) follows ceres::CostFunction::Evaluate
+    (registration_cost_function.h:47-48): parameters = [ref_pose[4], read_pose[4]],
+    residuals = f64[N], jacobians = None or [f64[N,4] or None, f64[N,4] or None].
+    Returns True/False like the reference.
+    """
+
+    def __init__(self, ctx, reference_submap, reading_submap, config=None):
+        self.ctx = ctx
+        self.config = config if config is not None else default_config()
+        h = vp()
+        ctx.check(ctx.lib.vgx_reg_create(ctx.h, reference_submap.h, reading_submap.h,
+                                         C.byref(self.config), C.byref(h)))
+        self.h = h
+        self._keep = (reference_submap, reading_submap)
+
+    def num_residuals(self):
+        return self.ctx.lib.vgx_reg_num_residuals(self.h)
+
+    def Evaluate(self, parameters, residuals, jacobians):
+        ref = _f64(parameters[0])
+        read = _f64(parameters[1])
+        jr = je = None
+        if jacobians is not None:
+            jr, je = jacobians[0], jacobians[1]
+        for a in (residuals, jr, je):
+            assert a is None or (a.dtype == np.float64 and a.flags.c_contiguous)
+        rc = self.ctx.check(self.ctx.lib.vgx_reg_evaluate(
+            self.h, _ptr(ref, f64p), _ptr(read, f64p), _ptr(residuals, f64p), _ptr(jr, f64p),
+            _ptr(je, f64p)))
+        return rc == OK
+
+    def evaluate_device_f32(self, ref_pose, read_pose, d_residuals, d_jac_ref, d_jac_read):
+        """Device pointers (ints); asynchronous on the context's stream."""
+        rc = self.ctx.check(self.ctx.lib.vgx_reg_evaluate_device_f32(
+            self.h, _ptr(_f64(ref_pose), f64p), _ptr(_f64(read_pose), f64p), vp(d_residuals),
+            vp(d_jac_ref) if d_jac_ref else None, vp(d_jac_read) if d_jac_read else None))
+        return rc == OK
+
+    def destroy(self):
+        if self.h:
+            self.ctx.lib.vgx_reg_destroy(self.h)
+            self.h = None
+
+
+class RegistrationBatch:
+    """All registration constraints of a pose graph, evaluated in one launch."""
+
+    def __init__(self, ctx, cost_functions, node_pair, global_index=None, n_global=None):
+        self.ctx = ctx
+        self.n = len(cost_functions)
+        arr = (vp * max(self.n, 1))(*[cf.h for cf in cost_functions])
+        np_pair = np.ascontiguousarray(node_pair, dtype=np.int32).reshape(-1, 2)
+        gi = None if global_index is None else np.ascontiguousarray(global_index, np.int32)
+        h = vp()
+        ctx.check(ctx.lib.vgx_reg_batch_create(
+            ctx.h, self.n, arr, _ptr(np_pair, i32p), _ptr(gi, i32p),
+            self.n if n_global is None else n_global, C.byref(h)))
+        self.h = h
+        self.n_global = self.n if n_global is None else n_global
+        self._keep = list(cost_functions)
+
+    def num_residuals(self):
+        return self.ctx.lib.vgx_reg_batch_num_residuals(self.h)
+
+    def row_offsets(self):
+        ro = np.zeros(self.n + 1, np.int64)
+        self.ctx.check(self.ctx.lib.vgx_reg_batch_row_offsets(self.h, _ptr(ro, i64p)))
+        return ro
+
+    def evaluate_points(self, poses, d_residuals, d_jac_ref, d_jac_read):
+        poses = _f64(poses).reshape(-1, 4)
+        status = np.zeros(max(self.n, 1), np.int32)
+        self.ctx.check(self.ctx.lib.vgx_reg_batch_evaluate_points(
+            self.h, _ptr(poses, f64p), poses.shape[0], vp(d_residuals),
+            vp(d_jac_ref) if d_jac_ref else None, vp(d_jac_read) if d_jac_read else None,
+            _ptr(status, i32p)))
+        return status[:self.n]
+
+    def evaluate_normal(self, poses, d_normal=None, to_host=True):
+        poses = _f64(poses).reshape(-1, 4)
+        status = np.zeros(max(self.n, 1), np.int32)
+        host = np.zeros((self.n, NORMAL_SIZE), np.float64) if to_host else None
+        self.ctx.check(self.ctx.lib.vgx_reg_batch_evaluate_normal(
+            self.h, _ptr(poses, f64p), poses.shape[0], vp(d_normal) if d_normal else None,
+            _ptr(host, f64p), _ptr(status, i32p)))
+        return status[:self.n], host
+
+    def assemble(self, n_nodes, d_fused, d_normal=None, zero_first=True):
+        self.ctx.check(self.ctx.lib.vgx_reg_batch_assemble(
+            self.h, vp(d_normal) if d_normal else None, n_nodes, vp(d_fused), int(zero_first)))
+
+    def destroy(self):
+        if self.h:
+            self.ctx.lib.vgx_reg_batch_destroy(self.h)
+            self.h = None
+
+
+def fused_size(n_nodes, n_global):
+    return load().vgx_reg_fused_size(n_nodes, n_global)

@@ -1,0 +1,446 @@
+// Context, submap upload and the apron-brick re-layout kernel.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+#include "vgx_internal.h"
+
+namespace vgx {
+
+static std::mutex g_err_mu;
+static std::string g_global_error = "no error";
+
+void set_global_error(const std::string& msg) {
+  std::lock_guard<std::mutex> lk(g_err_mu);
+  g_global_error = msg;
+}
+
+int set_error(vgx_ctx ctx, int code, const std::string& msg) {
+  if (ctx) {
+    ctx->last_error = msg;
+  } else {
+    set_global_error(msg);
+  }
+  return code;
+}
+
+// ---------------------------------------------------------------------------
+// brickify: voxblox block layout -> apron bricks with NaN validity
+// ---------------------------------------------------------------------------
+// One workgroup per block.  mode 0: valid iff weight > 0 (Interpolator<TsdfVoxel>
+// ::isVoxelValid), mode 1: valid iff observed (Interpolator<EsdfVoxel>) [recalled].
+template <int VPS>
+__global__ __launch_bounds__(256) void brickify_kernel(
+    const int32_t* __restrict__ block_index, const int32_t* __restrict__ lut,
+    int3 lut_min, int3 lut_dim, const float* __restrict__ distance,
+    const float* __restrict__ weight, const uint8_t* __restrict__ observed,
+    float* __restrict__ bricks) {
+  constexpr int B = VPS + 1;
+  constexpr int CELLS = B * B * B;
+  constexpr int VOX = VPS * VPS * VPS;
+  const int b = blockIdx.x;
+  const int bx = block_index[3 * b + 0] - lut_min.x;
+  const int by = block_index[3 * b + 1] - lut_min.y;
+  const int bz = block_index[3 * b + 2] - lut_min.z;
+  float* out = bricks + (size_t)b * CELLS;
+  for (int cell = threadIdx.x; cell < CELLS; cell += blockDim.x) {
+    int cx = cell % B;
+    int cy = (cell / B) % B;
+    int cz = cell / (B * B);
+    int ox = cx == VPS, oy = cy == VPS, oz = cz == VPS;
+    int sx = bx + ox, sy = by + oy, sz = bz + oz;
+    int slot = b;
+    if (ox | oy | oz) {
+      slot = -1;
+      if (sx < lut_dim.x && sy < lut_dim.y && sz < lut_dim.z)
+        slot = lut[sx + lut_dim.x * (sy + lut_dim.y * sz)];
+    }
+    float v = __builtin_nanf("");
+    if (slot >= 0) {
+      int vx = ox ? 0 : cx, vy = oy ? 0 : cy, vz = oz ? 0 : cz;
+      size_t at = (size_t)slot * VOX + vx + VPS * (vy + VPS * vz);
+      bool ok = weight ? (weight[at] > 0.0f) : (observed[at] != 0);
+      if (ok) v = distance[at];
+    }
+    out[cell] = v;
+  }
+}
+
+int launch_brickify(vgx_submap sm, int which) {
+  vgx_ctx ctx = sm->ctx;
+  const float* dist = which == 0 ? sm->d_tsdf_distance : sm->d_esdf_distance;
+  const float* w = which == 0 ? sm->d_tsdf_weight : nullptr;
+  const uint8_t* obs = which == 0 ? nullptr : sm->d_esdf_observed;
+  const int B = sm->vps + 1;
+  size_t bytes = (size_t)sm->n_blocks * B * B * B * sizeof(float);
+  VGX_HIP(ctx, hipMalloc(&sm->grid[which].d_bricks, bytes));
+  int3 mn = make_int3(sm->lut_min[0], sm->lut_min[1], sm->lut_min[2]);
+  int3 dm = make_int3(sm->lut_dim[0], sm->lut_dim[1], sm->lut_dim[2]);
+  if (sm->vps == 16) {
+    hipLaunchKernelGGL(brickify_kernel<16>, dim3(sm->n_blocks), dim3(256), 0, ctx->stream,
+                       sm->d_block_index, sm->d_lut, mn, dm, dist, w, obs,
+                       sm->grid[which].d_bricks);
+  } else {
+    hipLaunchKernelGGL(brickify_kernel<8>, dim3(sm->n_blocks), dim3(256), 0, ctx->stream,
+                       sm->d_block_index, sm->d_lut, mn, dm, dist, w, obs,
+                       sm->grid[which].d_bricks);
+  }
+  VGX_HIP(ctx, hipGetLastError());
+  sm->grid[which].present = true;
+  return VGX_OK;
+}
+
+}  // namespace vgx
+
+using namespace vgx;
+
+vgx::GridDev vgx_submap_s::grid_dev(int which) const {
+  GridDev g;
+  g.bricks = grid[which].d_bricks;
+  g.lut = d_lut;
+  for (int a = 0; a < 3; ++a) {
+    g.lut_min[a] = lut_min[a];
+    g.lut_dim[a] = lut_dim[a];
+  }
+  g.voxel_size = voxel_size;
+  g.voxel_size_inv = voxel_size_inv;
+  g.block_size = block_size;
+  g.block_size_inv = block_size_inv;
+  return g;
+}
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int vgx_ctx_create(int device, vgx_ctx* out) {
+  if (!out) return set_error(nullptr, VGX_ERR_INVALID, "vgx_ctx_create: out == NULL");
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return set_error(nullptr, VGX_ERR_NO_DEVICE,
+                     std::string("vgx_ctx_create: no HIP device (") +
+                         (e != hipSuccess ? hipGetErrorString(e) : "count == 0") +
+                         "); libvoxgraph_amd has no CPU fallback");
+  if (device < 0 || device >= count)
+    return set_error(nullptr, VGX_ERR_INVALID, "vgx_ctx_create: device index out of range");
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+    return set_error(nullptr, VGX_ERR_HIP, "vgx_ctx_create: hipGetDeviceProperties failed");
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+    return set_error(nullptr, VGX_ERR_NO_DEVICE,
+                     std::string("vgx_ctx_create: device is ") + prop.gcnArchName +
+                         ", this library is built for gfx950 only");
+  vgx_ctx ctx = new (std::nothrow) vgx_ctx_s();
+  if (!ctx) return set_error(nullptr, VGX_ERR_NOMEM, "vgx_ctx_create: out of host memory");
+  ctx->device = device;
+  ctx->cu_count = prop.multiProcessorCount;
+  if (hipSetDevice(device) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&ctx->ev_start) != hipSuccess ||
+      hipEventCreate(&ctx->ev_stop) != hipSuccess) {
+    delete ctx;
+    return set_error(nullptr, VGX_ERR_HIP, "vgx_ctx_create: stream/event creation failed");
+  }
+  ctx->stream = ctx->own_stream;
+  ctx->last_error = "no error";
+  *out = ctx;
+  return VGX_OK;
+}
+
+int vgx_ctx_destroy(vgx_ctx ctx) {
+  if (!ctx) return VGX_ERR_INVALID;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+  if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+  return VGX_OK;
+}
+
+const char* vgx_last_error(vgx_ctx ctx) {
+  if (ctx) return ctx->last_error.c_str();
+  static thread_local std::string copy;
+  std::lock_guard<std::mutex> lk(g_err_mu);
+  copy = g_global_error;
+  return copy.c_str();
+}
+
+int vgx_ctx_set_stream(vgx_ctx ctx, void* hip_stream) {
+  if (!ctx) return VGX_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return VGX_OK;
+}
+
+void* vgx_ctx_get_stream(vgx_ctx ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int vgx_ctx_synchronize(vgx_ctx ctx) {
+  if (!ctx) return VGX_ERR_INVALID;
+  VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VGX_OK;
+}
+
+int vgx_ctx_timer_start(vgx_ctx ctx) {
+  if (!ctx) return VGX_ERR_INVALID;
+  VGX_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+  return VGX_OK;
+}
+
+int vgx_ctx_timer_stop(vgx_ctx ctx, float* elapsed_ms) {
+  if (!ctx || !elapsed_ms) return VGX_ERR_INVALID;
+  VGX_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+  VGX_HIP(ctx, hipEventSynchronize(ctx->ev_stop));
+  VGX_HIP(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev_start, ctx->ev_stop));
+  return VGX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// submaps
+// ---------------------------------------------------------------------------
+static int upload(vgx_ctx ctx, const void* src, size_t bytes, void** dst) {
+  *dst = nullptr;
+  if (!src || bytes == 0) return VGX_OK;
+  VGX_HIP(ctx, hipMalloc(dst, bytes));
+  VGX_HIP(ctx, hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return VGX_OK;
+}
+
+int vgx_submap_create(vgx_ctx ctx, int32_t submap_id, float voxel_size, int32_t vps,
+                      int32_t n_blocks, const int32_t* block_index, const float* tsdf_distance,
+                      const float* tsdf_weight, const float* esdf_distance,
+                      const uint8_t* esdf_observed, vgx_submap* out) {
+  if (!ctx || !out) return VGX_ERR_INVALID;
+  *out = nullptr;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!(voxel_size > 0) || n_blocks < 0 || (n_blocks > 0 && !block_index))
+    return set_error(ctx, VGX_ERR_INVALID, "vgx_submap_create: bad voxel_size / n_blocks / block_index");
+  if (vps != 16 && vps != 8)
+    return set_error(ctx, VGX_ERR_UNSUPPORTED, "vgx_submap_create: voxels_per_side must be 8 or 16");
+  if ((tsdf_distance == nullptr) != (tsdf_weight == nullptr) ||
+      (esdf_observed != nullptr && esdf_distance == nullptr))
+    return set_error(ctx, VGX_ERR_INVALID,
+                     "vgx_submap_create: tsdf_distance/tsdf_weight come together; esdf_observed needs esdf_distance");
+  VGX_HIP(ctx, hipSetDevice(ctx->device));
+  vgx_submap sm = new (std::nothrow) vgx_submap_s();
+  if (!sm) return set_error(ctx, VGX_ERR_NOMEM, "vgx_submap_create: out of host memory");
+  sm->ctx = ctx;
+  sm->id = submap_id;
+  sm->vps = vps;
+  sm->n_blocks = n_blocks;
+  // voxblox::Layer / Block constants, f32 [recalled]
+  sm->voxel_size = voxel_size;
+  sm->voxel_size_inv = 1.0f / voxel_size;
+  sm->block_size = (float)vps * voxel_size;
+  sm->block_size_inv = 1.0f / sm->block_size;
+  sm->block_index.assign(block_index, block_index + 3 * (size_t)n_blocks);
+
+  // dense block lookup table over the AABB of the allocated blocks
+  int32_t mn[3] = {0, 0, 0}, mx[3] = {-1, -1, -1};
+  for (int b = 0; b < n_blocks; ++b)
+    for (int a = 0; a < 3; ++a) {
+      int32_t v = block_index[3 * b + a];
+      if (b == 0 || v < mn[a]) mn[a] = v;
+      if (b == 0 || v > mx[a]) mx[a] = v;
+    }
+  size_t total = 1;
+  for (int a = 0; a < 3; ++a) {
+    sm->lut_min[a] = mn[a];
+    sm->lut_dim[a] = mx[a] - mn[a] + 1;
+    total *= (size_t)sm->lut_dim[a];
+    if (total > ((size_t)1 << 28)) {
+      delete sm;
+      return set_error(ctx, VGX_ERR_UNSUPPORTED,
+                       "vgx_submap_create: block AABB exceeds 2^28 cells (dense lookup table)");
+    }
+  }
+  int rc = VGX_OK;
+  if (n_blocks > 0) {
+    std::vector<int32_t> lut(total, -1);
+    for (int b = 0; b < n_blocks; ++b) {
+      size_t ix = (size_t)(block_index[3 * b + 0] - mn[0]);
+      size_t iy = (size_t)(block_index[3 * b + 1] - mn[1]);
+      size_t iz = (size_t)(block_index[3 * b + 2] - mn[2]);
+      lut[ix + (size_t)sm->lut_dim[0] * (iy + (size_t)sm->lut_dim[1] * iz)] = b;
+    }
+    const size_t nvox = (size_t)n_blocks * vps * vps * vps;
+    rc = upload(ctx, lut.data(), total * sizeof(int32_t), (void**)&sm->d_lut);
+    if (rc == VGX_OK) rc = upload(ctx, block_index, 3 * (size_t)n_blocks * sizeof(int32_t), (void**)&sm->d_block_index);
+    if (rc == VGX_OK) rc = upload(ctx, tsdf_distance, nvox * sizeof(float), (void**)&sm->d_tsdf_distance);
+    if (rc == VGX_OK) rc = upload(ctx, tsdf_weight, nvox * sizeof(float), (void**)&sm->d_tsdf_weight);
+    if (rc == VGX_OK) rc = upload(ctx, esdf_distance, nvox * sizeof(float), (void**)&sm->d_esdf_distance);
+    if (rc == VGX_OK) rc = upload(ctx, esdf_observed, nvox * sizeof(uint8_t), (void**)&sm->d_esdf_observed);
+    // the H2D copies above read pageable host memory: finish them before `lut`
+    // and the caller's arrays go away
+    if (rc == VGX_OK && hipStreamSynchronize(ctx->stream) != hipSuccess)
+      rc = set_error(ctx, VGX_ERR_HIP, "vgx_submap_create: H2D upload failed");
+    if (rc == VGX_OK && sm->d_tsdf_distance) rc = launch_brickify(sm, 0);
+    if (rc == VGX_OK && sm->d_esdf_distance && sm->d_esdf_observed) rc = launch_brickify(sm, 1);
+  }
+  if (rc != VGX_OK) {
+    vgx_submap_destroy(sm);
+    return rc;
+  }
+  *out = sm;
+  return VGX_OK;
+}
+
+static void free_points(PointSet& ps) {
+  if (ps.d_xyzd) (void)hipFree(ps.d_xyzd);
+  if (ps.d_weight) (void)hipFree(ps.d_weight);
+  ps = PointSet();
+}
+
+int vgx_submap_release_raw_layers(vgx_submap sm) {
+  if (!sm) return VGX_ERR_INVALID;
+  (void)hipStreamSynchronize(sm->ctx->stream);
+  if (sm->d_tsdf_distance) (void)hipFree(sm->d_tsdf_distance);
+  if (sm->d_tsdf_weight) (void)hipFree(sm->d_tsdf_weight);
+  if (sm->d_esdf_distance) (void)hipFree(sm->d_esdf_distance);
+  if (sm->d_esdf_observed) (void)hipFree(sm->d_esdf_observed);
+  sm->d_tsdf_distance = sm->d_tsdf_weight = sm->d_esdf_distance = nullptr;
+  sm->d_esdf_observed = nullptr;
+  return VGX_OK;
+}
+
+int vgx_submap_destroy(vgx_submap sm) {
+  if (!sm) return VGX_ERR_INVALID;
+  (void)hipSetDevice(sm->ctx->device);
+  vgx_submap_release_raw_layers(sm);
+  if (sm->d_lut) (void)hipFree(sm->d_lut);
+  if (sm->d_block_index) (void)hipFree(sm->d_block_index);
+  for (int k = 0; k < 2; ++k) {
+    if (sm->grid[k].d_bricks) (void)hipFree(sm->grid[k].d_bricks);
+    free_points(sm->points[k]);
+  }
+  delete sm;
+  return VGX_OK;
+}
+
+int32_t vgx_submap_id(vgx_submap sm) { return sm ? sm->id : -1; }
+int32_t vgx_submap_num_blocks(vgx_submap sm) { return sm ? sm->n_blocks : -1; }
+
+// Morton code of non-negative 21-bit voxel coordinates
+static inline uint64_t spread3(uint64_t v) {
+  v &= 0x1fffff;
+  v = (v | v << 32) & 0x1f00000000ffffULL;
+  v = (v | v << 16) & 0x1f0000ff0000ffULL;
+  v = (v | v << 8) & 0x100f00f00f00f00fULL;
+  v = (v | v << 4) & 0x10c30c30c30c30c3ULL;
+  v = (v | v << 2) & 0x1249249249249249ULL;
+  return v;
+}
+
+int vgx_submap_set_points(vgx_submap sm, int32_t point_type, int64_t n, const float* xyz,
+                          const float* distance, const float* weight, uint32_t flags) {
+  if (!sm) return VGX_ERR_INVALID;
+  vgx_ctx ctx = sm->ctx;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (point_type != VGX_POINTS_ISOSURFACE && point_type != VGX_POINTS_VOXELS)
+    return set_error(ctx, VGX_ERR_INVALID, "vgx_submap_set_points: bad point_type");
+  if (n < 0 || n > INT32_MAX || (n > 0 && (!xyz || !distance || !weight)))
+    return set_error(ctx, VGX_ERR_INVALID, "vgx_submap_set_points: bad n or NULL arrays");
+  VGX_HIP(ctx, hipSetDevice(ctx->device));
+  PointSet& ps = sm->points[point_type];
+  (void)hipStreamSynchronize(ctx->stream);
+  free_points(ps);
+  ps.n = n;
+  ps.present = true;
+  // WeightedSampler::addItem (weighted_sampler_inl.h:5-16): cumulative weights
+  // in upload order, accumulated in double
+  ps.cumulative_weight.resize((size_t)n);
+  double acc = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    acc = (i == 0) ? (double)weight[i] : acc + (double)weight[i];
+    ps.cumulative_weight[(size_t)i] = acc;
+  }
+  // summed_reference_weight of the deterministic mode (.cpp:124): same order of
+  // f64 additions as the reference's loop when the order is kept; the Morton
+  // order changes the rounding by O(n eps) only.
+  std::vector<int64_t> order;
+  if ((flags & VGX_POINTS_SORT_MORTON) && n > 1) {
+    std::vector<uint64_t> key((size_t)n);
+    float mnv[3] = {xyz[0], xyz[1], xyz[2]};
+    for (int64_t i = 0; i < n; ++i)
+      for (int a = 0; a < 3; ++a) mnv[a] = std::min(mnv[a], xyz[3 * i + a]);
+    // align the curve to the voxel grid so that 2^k-voxel cells nest in blocks
+    float base[3];
+    for (int a = 0; a < 3; ++a) base[a] = std::floor(mnv[a] * sm->block_size_inv) * sm->block_size;
+    for (int64_t i = 0; i < n; ++i) {
+      uint64_t c[3];
+      for (int a = 0; a < 3; ++a) {
+        double v = std::floor(((double)xyz[3 * i + a] - (double)base[a]) * (double)sm->voxel_size_inv);
+        c[a] = (uint64_t)std::min(std::max(v, 0.0), 2097151.0);
+      }
+      key[(size_t)i] = spread3(c[0]) | (spread3(c[1]) << 1) | (spread3(c[2]) << 2);
+    }
+    order.resize((size_t)n);
+    std::iota(order.begin(), order.end(), (int64_t)0);
+    std::stable_sort(order.begin(), order.end(),
+                     [&](int64_t a, int64_t b) { return key[(size_t)a] < key[(size_t)b]; });
+  }
+  std::vector<float4> h_xyzd((size_t)n);
+  std::vector<float> h_w((size_t)n);
+  double sum_w = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    int64_t s = order.empty() ? i : order[(size_t)i];
+    h_xyzd[(size_t)i] = make_float4(xyz[3 * s], xyz[3 * s + 1], xyz[3 * s + 2], distance[s]);
+    h_w[(size_t)i] = weight[s];
+    sum_w += (double)weight[s];
+  }
+  ps.sum_weight = sum_w;
+  ps.order = order;
+  if (!order.empty()) {
+    ps.inv_order.resize((size_t)n);
+    for (int64_t i = 0; i < n; ++i) ps.inv_order[(size_t)order[(size_t)i]] = (int32_t)i;
+  }
+  if (n > 0) {
+    VGX_HIP(ctx, hipMalloc(&ps.d_xyzd, (size_t)n * sizeof(float4)));
+    VGX_HIP(ctx, hipMalloc(&ps.d_weight, (size_t)n * sizeof(float)));
+    VGX_HIP(ctx, hipMemcpy(ps.d_xyzd, h_xyzd.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice));
+    VGX_HIP(ctx, hipMemcpy(ps.d_weight, h_w.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+  }
+  return VGX_OK;
+}
+
+int64_t vgx_submap_num_points(vgx_submap sm, int32_t point_type) {
+  if (!sm || point_type < 0 || point_type > 1 || !sm->points[point_type].present) return -1;
+  return sm->points[point_type].n;
+}
+
+int vgx_submap_point_order(vgx_submap sm, int32_t point_type, int64_t* order) {
+  if (!sm || point_type < 0 || point_type > 1 || !order) return VGX_ERR_INVALID;
+  const PointSet& ps = sm->points[point_type];
+  if (!ps.present) return set_error(sm->ctx, VGX_ERR_INVALID, "vgx_submap_point_order: no such point set");
+  for (int64_t i = 0; i < ps.n; ++i) order[i] = ps.order.empty() ? i : ps.order[(size_t)i];
+  return VGX_OK;
+}
+
+int vgx_submap_download_points(vgx_submap sm, int32_t point_type, float* xyz, float* distance,
+                               float* weight) {
+  if (!sm || point_type < 0 || point_type > 1) return VGX_ERR_INVALID;
+  vgx_ctx ctx = sm->ctx;
+  const PointSet& ps = sm->points[point_type];
+  if (!ps.present) return set_error(ctx, VGX_ERR_INVALID, "vgx_submap_download_points: no such point set");
+  if (ps.n == 0) return VGX_OK;
+  VGX_HIP(ctx, hipSetDevice(ctx->device));
+  VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<float4> h((size_t)ps.n);
+  VGX_HIP(ctx, hipMemcpy(h.data(), ps.d_xyzd, (size_t)ps.n * sizeof(float4), hipMemcpyDeviceToHost));
+  for (int64_t i = 0; i < ps.n; ++i) {
+    if (xyz) {
+      xyz[3 * i] = h[(size_t)i].x;
+      xyz[3 * i + 1] = h[(size_t)i].y;
+      xyz[3 * i + 2] = h[(size_t)i].z;
+    }
+    if (distance) distance[i] = h[(size_t)i].w;
+  }
+  if (weight) VGX_HIP(ctx, hipMemcpy(weight, ps.d_weight, (size_t)ps.n * sizeof(float), hipMemcpyDeviceToHost));
+  return VGX_OK;
+}
+
+}  // extern "C"

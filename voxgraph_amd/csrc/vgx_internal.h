@@ -1,0 +1,196 @@
+// Internal host/device structures of libvoxgraph_amd.so (gfx950 only).
+#ifndef VGX_INTERNAL_H_
+#define VGX_INTERNAL_H_
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <mutex>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "voxgraph_amd.h"
+
+namespace vgx {
+
+// ---------------------------------------------------------------------------
+// Device-visible descriptors (plain structs, copied by value)
+// ---------------------------------------------------------------------------
+
+// A finished layer re-laid for sampling: one "apron brick" per voxblox block,
+// (vps+1)^3 floats, x fastest.  Cell (i,j,k) of brick b holds voxel (i,j,k) of
+// block b for i,j,k < vps and the first voxel plane of the +x/+y/+z neighbour
+// blocks for index == vps, so the 8 trilinear neighbours of any base voxel of
+// block b live in ONE brick.  Invalid voxels (unobserved / zero weight /
+// missing neighbour block) are stored as NaN: validity travels with the value.
+struct GridDev {
+  const float* bricks;   // [n_blocks][(vps+1)^3]
+  const int32_t* lut;    // dense block lookup [dim.z][dim.y][dim.x] -> brick or -1
+  int32_t lut_min[3];
+  int32_t lut_dim[3];
+  float voxel_size, voxel_size_inv, block_size, block_size_inv;
+};
+
+// Per-evaluation pose data of one constraint, computed on the host in the
+// reference's own f32 arithmetic (registration_cost_function.cpp:69-110).
+struct alignas(16) PosePack {
+  float qw, qz;            // T_reading__reference rotation (yaw-only: x = y = 0)
+  float tx, ty, tz;        // ... translation
+  float cos_e, sin_e;      // cos/sin(yaw_reading)                    (.cpp:91-92)
+  float cos_emo, sin_emo;  // cos/sin(yaw_reading - yaw_reference)    (.cpp:94-96)
+  float dxs, dxc;          // (xe-xo)*sin_e , (xe-xo)*cos_e           (.cpp:225-226)
+  float dys, dyc;          // (ye-yo)*sin_e , (ye-yo)*cos_e
+  float pad[3];
+};
+static_assert(sizeof(PosePack) == 64, "PosePack must stay one 64-byte line");
+
+// Static description of one constraint for the kernels.
+struct alignas(16) ConstraintDev {
+  GridDev grid;             // reading submap's sampling grid
+  const float4* xyzd;       // reference submap's points {x,y,z,distance}
+  const float* weight;      // ... weights
+  const int32_t* sample_idx;  // sampling mode: indices into the point set, else null
+  int64_t n;                // num_residuals
+  int64_t row0;             // first output row (stacked outputs)
+  double factor;            // N / sum(w)                              (.cpp:274)
+  double no_corr_cost;      // config.no_correspondence_cost
+};
+
+// A unit of work: `count` consecutive residuals of one constraint.
+struct Tile {
+  int32_t constraint;
+  int32_t count;
+  int64_t start;  // residual index within the constraint
+};
+
+constexpr int kNormalSize = 45;     // per-constraint fused output (doubles)
+constexpr int kPartialSize = 22;    // 21 unique products + reserved
+
+// ---------------------------------------------------------------------------
+// Host objects behind the opaque handles
+// ---------------------------------------------------------------------------
+struct Context {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  std::mutex mu;
+  std::string last_error;
+  int cu_count = 256;
+};
+
+struct PointSet {
+  int64_t n = 0;
+  float4* d_xyzd = nullptr;
+  float* d_weight = nullptr;
+  double sum_weight = 0;
+  bool present = false;
+  std::vector<int64_t> order;            // order[i] = uploaded index of point i (empty = identity)
+  std::vector<int32_t> inv_order;        // uploaded index -> device index (for sampling)
+  std::vector<double> cumulative_weight; // WeightedSampler::cumulative_item_weights_ (upload order)
+};
+
+struct Grid {
+  float* d_bricks = nullptr;
+  bool present = false;
+};
+
+}  // namespace vgx
+
+struct vgx_ctx_s : vgx::Context {};
+
+struct vgx_submap_s {
+  vgx_ctx ctx = nullptr;
+  int32_t id = 0;
+  float voxel_size = 0, voxel_size_inv = 0, block_size = 0, block_size_inv = 0;
+  int32_t vps = 0;
+  int32_t n_blocks = 0;
+  std::vector<int32_t> block_index;  // host copy [n][3]
+  int32_t* d_block_index = nullptr;
+  int32_t* d_lut = nullptr;
+  int32_t lut_min[3] = {0, 0, 0};
+  int32_t lut_dim[3] = {0, 0, 0};
+  // raw layers (voxblox layout), kept for point extraction
+  float* d_tsdf_distance = nullptr;
+  float* d_tsdf_weight = nullptr;
+  float* d_esdf_distance = nullptr;
+  uint8_t* d_esdf_observed = nullptr;
+  vgx::Grid grid[2];       // [0] TSDF, [1] ESDF sampling grids
+  vgx::PointSet points[2]; // by VGX_POINTS_*
+  vgx::GridDev grid_dev(int which) const;
+};
+
+struct vgx_reg_s {
+  vgx_ctx ctx = nullptr;
+  vgx_submap reference = nullptr;
+  vgx_submap reading = nullptr;
+  vgx_reg_config cfg{};
+  int64_t num_residuals = 0;
+  // sampling mode state: mirrors the WeightedSampler's mutable RNG
+  std::mt19937 rng;
+  std::uniform_real_distribution<double> uniform{0.0, 1.0};
+  int32_t* d_sample_idx = nullptr;
+  std::vector<int32_t> h_sample_idx;
+  // drop-in scratch (f64 outputs staged on the device before the D2H copy)
+  double* d_out = nullptr;
+  int64_t d_out_rows = 0;
+  vgx::Tile* d_tiles = nullptr;
+  int32_t n_tiles = 0;
+  vgx::ConstraintDev* d_desc = nullptr;
+  vgx::PosePack* d_pack = nullptr;
+  bool draw_samples();          // refreshes h_sample_idx / d_sample_idx
+  vgx::ConstraintDev describe() const;
+};
+
+struct vgx_reg_batch_s {
+  vgx_ctx ctx = nullptr;
+  int32_t n = 0;
+  int32_t n_global = 0;
+  std::vector<vgx_reg> regs;
+  std::vector<int32_t> node_pair;     // [n][2]
+  std::vector<int32_t> global_index;  // [n]
+  std::vector<int64_t> row_offset;    // [n+1]
+  std::vector<vgx::Tile> tiles;
+  vgx::ConstraintDev* d_desc = nullptr;
+  vgx::PosePack* d_pack = nullptr;
+  vgx::PosePack* h_pack = nullptr;    // pinned
+  vgx::Tile* d_tiles = nullptr;
+  int32_t* d_tile_first = nullptr;    // [n+1] first tile of each constraint
+  double* d_partials = nullptr;       // [n_tiles][kPartialSize]
+  double* d_normal = nullptr;         // [n][45] (internal, when caller passes none)
+  int32_t* d_node_pair = nullptr;
+  int32_t* d_global_index = nullptr;
+  // fused pass: coarser tiles, and node -> incident (constraint<<1 | side) CSR
+  std::vector<vgx::Tile> reduce_tiles;
+  vgx::Tile* d_reduce_tiles = nullptr;
+  int32_t csr_nodes = 0;
+  int32_t* d_node_first = nullptr;
+  int32_t* d_node_items = nullptr;
+};
+
+// ---------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------
+namespace vgx {
+int set_error(vgx_ctx ctx, int code, const std::string& msg);
+void set_global_error(const std::string& msg);
+
+#define VGX_HIP(ctx, call)                                                      \
+  do {                                                                          \
+    hipError_t e__ = (call);                                                    \
+    if (e__ != hipSuccess)                                                      \
+      return vgx::set_error((ctx), VGX_ERR_HIP,                                 \
+                            std::string(#call) + ": " + hipGetErrorString(e__)); \
+  } while (0)
+
+// kernels' launch wrappers implemented in the .hip files
+int launch_brickify(vgx_submap sm, int which);
+void make_pose_pack(const double ref_pose[4], const double read_pose[4], PosePack* out);
+std::vector<Tile> make_tiles(int32_t constraint, int64_t n, int tile_points);
+constexpr int kBlockThreads = 256;
+constexpr int kPointsPerThread = 4;
+constexpr int kTilePoints = kBlockThreads * kPointsPerThread;
+}  // namespace vgx
+
+#endif

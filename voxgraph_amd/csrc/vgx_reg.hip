@@ -1,0 +1,967 @@
+// REG path: RegistrationCostFunction::Evaluate on gfx950.
+//
+// Reference: voxgraph/src/backend/constraint/cost_functions/
+// registration_cost_function.cpp:58-298 (cited below as RCF:line) and the
+// voxblox interpolator / minkindr semantics restated in SURVEY.md Appendix B.
+//
+// The kernels are HBM/L2-gather bound (88 B per evaluation in the
+// materialising f32 form, 52 B in the fused form, ~200 flop): no MFMA.  Per
+// residual one thread streams a 20-byte point, finds its base voxel with the
+// reference's own f32 floor arithmetic, fetches the 8 trilinear neighbours as
+// four 8-byte loads from ONE apron brick (vgx_internal.h) and either stores
+// residual + two 1x4 Jacobians or accumulates the 21 unique products of
+// [J r]^T [J r].  Floating-point contraction is off so that every floor()
+// decision agrees with the CPU restatement bit for bit.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "vgx_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace vgx {
+
+// ---------------------------------------------------------------------------
+// host: per-evaluation pose pack (RCF:69-110 in the reference's f32 arithmetic)
+// ---------------------------------------------------------------------------
+namespace {
+struct YawQuat {
+  float w, z;
+};
+
+// minkindr RotationQuaternionTemplate<float>::exp for (0,0,psi) [recalled]:
+// double internals (Grassia 1998), narrowed to float.
+YawQuat yaw_exp(float psi) {
+  float nrm = std::sqrt(0.0f * 0.0f + 0.0f * 0.0f + psi * psi);
+  double theta = (double)nrm;
+  double na = theta < std::pow(2.220446049250313e-16, 0.25)
+                  ? 0.5 + (theta * theta) * (1.0 / 48.0)
+                  : std::sin(theta * 0.5) / theta;
+  double ct = std::cos(theta * 0.5);
+  return {(float)ct, (float)((double)psi * na)};
+}
+
+// Eigen _transformVector for a yaw-only quaternion (x = y = 0); the dropped
+// terms are exact zeros.
+void yaw_rotate(YawQuat q, const float v[3], float out[3]) {
+  float uv0 = -(q.z * v[1]);
+  float uv1 = q.z * v[0];
+  uv0 += uv0;
+  uv1 += uv1;
+  float c0 = -(q.z * uv1);
+  float c1 = q.z * uv0;
+  out[0] = v[0] + q.w * uv0 + c0;
+  out[1] = v[1] + q.w * uv1 + c1;
+  out[2] = v[2];
+}
+}  // namespace
+
+void make_pose_pack(const double ref_pose[4], const double read_pose[4], PosePack* out) {
+  std::memset(out, 0, sizeof(*out));
+  // RCF:69-88: f64 parameters narrowed into float Vector6, Transformation::exp
+  float t_ref[3] = {(float)ref_pose[0], (float)ref_pose[1], (float)ref_pose[2]};
+  float t_read[3] = {(float)read_pose[0], (float)read_pose[1], (float)read_pose[2]};
+  float yaw_ref = (float)ref_pose[3], yaw_read = (float)read_pose[3];
+  YawQuat q_ref = yaw_exp(yaw_ref), q_read = yaw_exp(yaw_read);
+  // RCF:109-110: T_mission__reading.inverse() * T_mission__reference
+  YawQuat q_inv = {q_read.w, -q_read.z};
+  float t_inv[3], rt[3];
+  yaw_rotate(q_inv, t_read, t_inv);
+  yaw_rotate(q_inv, t_ref, rt);
+  out->qw = q_inv.w * q_ref.w - q_inv.z * q_ref.z;
+  out->qz = q_inv.w * q_ref.z + q_inv.z * q_ref.w;
+  out->tx = -t_inv[0] + rt[0];
+  out->ty = -t_inv[1] + rt[1];
+  out->tz = -t_inv[2] + rt[2];
+  // RCF:91-100
+  out->cos_e = std::cos(yaw_read);
+  out->sin_e = std::sin(yaw_read);
+  out->cos_emo = std::cos(yaw_read - yaw_ref);
+  out->sin_emo = std::sin(yaw_read - yaw_ref);
+  float dx = t_read[0] - t_ref[0], dy = t_read[1] - t_ref[1];
+  out->dxs = dx * out->sin_e;
+  out->dxc = dx * out->cos_e;
+  out->dys = dy * out->sin_e;
+  out->dyc = dy * out->cos_e;
+}
+
+std::vector<Tile> make_tiles(int32_t constraint, int64_t n, int tile_points) {
+  std::vector<Tile> tiles;
+  for (int64_t s = 0; s < n; s += tile_points) {
+    Tile t;
+    t.constraint = constraint;
+    t.start = s;
+    t.count = (int32_t)std::min<int64_t>(tile_points, n - s);
+    tiles.push_back(t);
+  }
+  return tiles;
+}
+
+// ---------------------------------------------------------------------------
+// device: per-point arithmetic
+// ---------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef f32x2 f32x2u __attribute__((aligned(4)));  // 8-byte load, 4-byte aligned
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Pointers read out of descriptor structs are generic; tell the compiler they
+// are global memory so it emits global_load_* instead of flat_load_*.
+#define VGX_GLOBAL __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ const VGX_GLOBAL T* as_global(const T* p) {
+  return (const VGX_GLOBAL T*)p;
+}
+
+// One axis of Interpolator::setIndexes + getQVector [recalled]: block index,
+// base voxel index and fractional offset, all in the reference's f32 steps.
+template <int VPS>
+__device__ __forceinline__ void locate_axis(float p, const GridDev& g, int& blk, int& vox,
+                                            float& delta) {
+  blk = (int)floorf(p * g.block_size_inv + 1e-6f);
+  float origin = (float)blk * g.block_size;
+  int v = (int)floorf((p - origin) * g.voxel_size_inv + 1e-6f);
+  v = min(max(v, 0), VPS - 1);
+  float centre = origin + ((float)v + 0.5f) * g.voxel_size;
+  if (p - centre < 0.0f) {
+    v--;
+    if (v < 0) {
+      blk--;
+      v += VPS;
+    }
+  }
+  float origin2 = (float)blk * g.block_size;
+  float centre2 = origin2 + ((float)v + 0.5f) * g.voxel_size;
+  delta = (p - centre2) * g.voxel_size_inv;
+  vox = v;
+}
+
+struct PointEval {
+  double r;            // unscaled residual (RCF:161-166)
+  float jo0, jo1, jo2, jo3;  // unscaled d r / d reference pose (RCF:234-236)
+  float je3;           // d r / d reading yaw; je0..2 == -jo0..2 (RCF:223-227)
+};
+
+// RCF:128-268 for one point.  `cell` points at the base voxel inside an apron
+// brick or is null when the base block is missing.
+template <int VPS>
+__device__ __forceinline__ const float* locate_point(const GridDev& g, const PosePack& P, float x,
+                                                     float y, float z, float& Dx, float& Dy,
+                                                     float& Dz) {
+  // T_reading__reference * p (RCF:128-129), Eigen _transformVector, yaw-only
+  float uv0 = -(P.qz * y);
+  float uv1 = P.qz * x;
+  uv0 += uv0;
+  uv1 += uv1;
+  float c0 = -(P.qz * uv1);
+  float c1 = P.qz * uv0;
+  float px = (x + P.qw * uv0 + c0) + P.tx;
+  float py = (y + P.qw * uv1 + c1) + P.ty;
+  float pz = z + P.tz;
+  int bx, by, bz, vx, vy, vz;
+  locate_axis<VPS>(px, g, bx, vx, Dx);
+  locate_axis<VPS>(py, g, by, vy, Dy);
+  locate_axis<VPS>(pz, g, bz, vz, Dz);
+  bx -= g.lut_min[0];
+  by -= g.lut_min[1];
+  bz -= g.lut_min[2];
+  bool inside = (unsigned)bx < (unsigned)g.lut_dim[0] && (unsigned)by < (unsigned)g.lut_dim[1] &&
+                (unsigned)bz < (unsigned)g.lut_dim[2];
+  int slot = -1;
+  if (inside) slot = as_global(g.lut)[bx + g.lut_dim[0] * (by + g.lut_dim[1] * bz)];
+  if (slot < 0) return nullptr;
+  constexpr int B = VPS + 1;
+  return g.bricks + (size_t)slot * (B * B * B) + (vx + B * (vy + B * vz));
+}
+
+template <int VPS>
+__device__ __forceinline__ void load_neighbours(const float* cell, float d[8]) {
+  constexpr int B = VPS + 1;
+  // neighbour k sits at base + (k>>2 & 1, k>>1 & 1, k & 1); x is the
+  // contiguous axis, so (k, k+4) is one 8-byte load
+  f32x2 p0 = *(const VGX_GLOBAL f32x2u*)(cell);
+  f32x2 p1 = *(const VGX_GLOBAL f32x2u*)(cell + B * B);
+  f32x2 p2 = *(const VGX_GLOBAL f32x2u*)(cell + B);
+  f32x2 p3 = *(const VGX_GLOBAL f32x2u*)(cell + B + B * B);
+  d[0] = p0.x; d[4] = p0.y;
+  d[1] = p1.x; d[5] = p1.y;
+  d[2] = p2.x; d[6] = p2.y;
+  d[3] = p3.x; d[7] = p3.y;
+}
+
+__device__ __forceinline__ PointEval eval_point(const float d[8], bool have, float Dx, float Dy,
+                                                float Dz, float inv_f, const PosePack& P, float xi,
+                                                float yi, float d_ref, float w,
+                                                double no_corr_cost, bool want_jac) {
+  PointEval e;
+  // every neighbour valid <=> no NaN among the 8 (apron-brick encoding)
+  float s = ((d[0] + d[1]) + (d[2] + d[3])) + ((d[4] + d[5]) + (d[6] + d[7]));
+  bool ok = have && (s == s);
+  e.jo0 = e.jo1 = e.jo2 = e.jo3 = e.je3 = 0.0f;
+  if (!ok) {
+    e.r = (double)w * no_corr_cost;  // RCF:165-166
+    return e;
+  }
+  // c = interp_table_ * distances^T (registration_cost_function.h:73-81)
+  float c0 = d[0];
+  float c1 = -d[0] + d[4];
+  float c2 = -d[0] + d[2];
+  float c3 = -d[0] + d[1];
+  float c4 = ((d[0] - d[2]) - d[4]) + d[6];
+  float c5 = ((d[0] - d[1]) - d[2]) + d[3];
+  float c6 = ((d[0] - d[1]) - d[4]) + d[5];
+  float c7 = (((((( -d[0] + d[1]) + d[2]) - d[3]) + d[4]) - d[5]) - d[6]) + d[7];
+  // q_vector (Interpolator::getQVector) and RCF:158-159
+  float q4 = Dx * Dy, q5 = Dy * Dz, q6 = Dz * Dx, q7 = Dx * Dy * Dz;
+  float dot = ((((((c0 + Dx * c1) + Dy * c2) + Dz * c3) + q4 * c4) + q5 * c5) + q6 * c6) + q7 * c7;
+  e.r = ((double)d_ref - (double)dot) * (double)w;  // RCF:161-163
+  if (!want_jac) return e;
+  // RCF:183-202: doubles rounded into a float matrix
+  double inv = (double)inv_f, dx = (double)Dx, dy = (double)Dy, dz = (double)Dz;
+  float iDx = (float)(inv * dx), iDy = (float)(inv * dy), iDz = (float)(inv * dz);
+  float iDyDz = (float)(inv * dy * dz), iDxDz = (float)(inv * dx * dz), iDxDy = (float)(inv * dx * dy);
+  // RCF:204-205
+  float g0 = ((c1 * inv_f + c4 * iDy) + c6 * iDz) + c7 * iDyDz;
+  float g1 = ((c2 * inv_f + c4 * iDx) + c5 * iDz) + c7 * iDxDz;
+  float g2 = ((c3 * inv_f + c5 * iDy) + c6 * iDx) + c7 * iDxDy;
+  // RCF:214-239
+  float h0 = -w * g0, h1 = -w * g1, h2 = -w * g2;
+  float mo3 = xi * P.sin_emo - yi * P.cos_emo;
+  float mo7 = xi * P.cos_emo + yi * P.sin_emo;
+  float me3 = ((-xi * P.sin_emo + yi * P.cos_emo) + P.dxs) - P.dyc;
+  float me7 = ((-xi * P.cos_emo - yi * P.sin_emo) + P.dxc) + P.dys;
+  e.jo0 = h0 * P.cos_e + h1 * -P.sin_e;
+  e.jo1 = h0 * P.sin_e + h1 * P.cos_e;
+  e.jo2 = h2;
+  e.jo3 = h0 * mo3 + h1 * mo7;
+  e.je3 = h0 * me3 + h1 * me7;
+  return e;
+}
+
+template <typename T>
+struct Out4;
+template <>
+struct Out4<float> {
+  using type = float4;
+  static __device__ __forceinline__ float4 make(double a, double b, double c, double d) {
+    return make_float4((float)a, (float)b, (float)c, (float)d);
+  }
+};
+template <>
+struct Out4<double> {
+  using type = double4;
+  static __device__ __forceinline__ double4 make(double a, double b, double c, double d) {
+    return make_double4(a, b, c, d);
+  }
+};
+
+// XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch
+// order), so hand each XCD one contiguous range of tiles -- neighbouring tiles
+// gather from neighbouring bricks and share that XCD's L2.
+__device__ __forceinline__ int swizzle_tile(int b, int n_tiles) {
+  int chunk = (n_tiles + 7) >> 3;
+  return (b & 7) * chunk + (b >> 3);
+}
+
+// ---------------------------------------------------------------------------
+// kernel 1: materialise residuals + Jacobians (88 B / evaluation as f32)
+// ---------------------------------------------------------------------------
+template <int VPS, typename OUT, int PPT>
+__global__ __launch_bounds__(kBlockThreads) void reg_eval_points_kernel(
+    const ConstraintDev* __restrict__ cons, const PosePack* __restrict__ packs,
+    const Tile* __restrict__ tiles, int n_tiles, OUT* __restrict__ residuals,
+    typename Out4<OUT>::type* __restrict__ jac_ref, typename Out4<OUT>::type* __restrict__ jac_read) {
+  int t = swizzle_tile(blockIdx.x, n_tiles);
+  if (t >= n_tiles) return;
+  const Tile tile = tiles[t];
+  const ConstraintDev& C = cons[tile.constraint];
+  const PosePack P = packs[tile.constraint];
+  const GridDev g = C.grid;
+  const int32_t* sidx = C.sample_idx;
+  const bool want_jac = (jac_ref != nullptr) | (jac_read != nullptr);
+
+  f32x4 pt[PPT];
+  float w[PPT];
+  const float* cell[PPT];
+  float Dx[PPT], Dy[PPT], Dz[PPT];
+  float d[PPT][8];
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) {
+    int local = j * kBlockThreads + (int)threadIdx.x;
+    bool active = local < tile.count;
+    int64_t i = tile.start + (active ? local : 0);
+    if (sidx) {
+      int32_t s = as_global(sidx)[i];
+      pt[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[s];
+      w[j] = 1.0f;  // RCF:121
+    } else {
+      pt[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[i];
+      w[j] = as_global(C.weight)[i];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < PPT; ++j)
+    cell[j] = locate_point<VPS>(g, P, pt[j].x, pt[j].y, pt[j].z, Dx[j], Dy[j], Dz[j]);
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) {
+    if (cell[j]) {
+      load_neighbours<VPS>(cell[j], d[j]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) d[j][k] = 0.0f;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) {
+    int local = j * kBlockThreads + (int)threadIdx.x;
+    if (local >= tile.count) continue;
+    PointEval e = eval_point(d[j], cell[j] != nullptr, Dx[j], Dy[j], Dz[j], g.voxel_size_inv, P,
+                             pt[j].x, pt[j].y, pt[j].w, w[j], C.no_corr_cost, want_jac);
+    int64_t row = C.row0 + tile.start + local;
+    const double f = C.factor;  // RCF:274-291
+    residuals[row] = (OUT)(e.r * f);
+    if (jac_ref)
+      jac_ref[row] = Out4<OUT>::make((double)e.jo0 * f, (double)e.jo1 * f, (double)e.jo2 * f,
+                                     (double)e.jo3 * f);
+    if (jac_read)
+      jac_read[row] = Out4<OUT>::make((double)-e.jo0 * f, (double)-e.jo1 * f, (double)-e.jo2 * f,
+                                      (double)e.je3 * f);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// kernel 2: fused normal equations (52 B / evaluation, no per-point output)
+// ---------------------------------------------------------------------------
+// u = (jo0, jo1, jo2, jo3, je3, r): [J r]^T [J r] (9x9) is a signed
+// re-arrangement of the 21 unique products of u because je0..2 == -jo0..2.
+constexpr int kReduceIters = 8;  // a reduce tile = kTilePoints * kReduceIters residuals
+
+template <int VPS, int PPT>
+__global__ __launch_bounds__(kBlockThreads) void reg_eval_reduce_kernel(
+    const ConstraintDev* __restrict__ cons, const PosePack* __restrict__ packs,
+    const Tile* __restrict__ tiles, int n_tiles, double* __restrict__ partials) {
+  int t = swizzle_tile(blockIdx.x, n_tiles);
+  if (t >= n_tiles) return;
+  const Tile tile = tiles[t];
+  const ConstraintDev& C = cons[tile.constraint];
+  const PosePack P = packs[tile.constraint];
+  const GridDev g = C.grid;
+  double acc[21];
+#pragma unroll
+  for (int k = 0; k < 21; ++k) acc[k] = 0.0;
+
+  for (int base = 0; base < tile.count; base += kBlockThreads * PPT) {
+    f32x4 pt[PPT];
+    float w[PPT];
+    const float* cell[PPT];
+    float Dx[PPT], Dy[PPT], Dz[PPT];
+    float d[PPT][8];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      int local = base + j * kBlockThreads + (int)threadIdx.x;
+      int64_t i = tile.start + (local < tile.count ? local : 0);
+      pt[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[i];
+      w[j] = as_global(C.weight)[i];
+    }
+#pragma unroll
+    for (int j = 0; j < PPT; ++j)
+      cell[j] = locate_point<VPS>(g, P, pt[j].x, pt[j].y, pt[j].z, Dx[j], Dy[j], Dz[j]);
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      if (cell[j]) {
+        load_neighbours<VPS>(cell[j], d[j]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d[j][k] = 0.0f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      int local = base + j * kBlockThreads + (int)threadIdx.x;
+      if (local >= tile.count) continue;
+      PointEval e = eval_point(d[j], cell[j] != nullptr, Dx[j], Dy[j], Dz[j], g.voxel_size_inv,
+                               P, pt[j].x, pt[j].y, pt[j].w, w[j], C.no_corr_cost, true);
+      double u[6] = {(double)e.jo0, (double)e.jo1, (double)e.jo2, (double)e.jo3, (double)e.je3, e.r};
+      int k = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = a; b < 6; ++b) acc[k++] += u[a] * u[b];
+    }
+  }
+  // wave reduction (64 lanes), then across the 4 waves through LDS: a fixed
+  // tree, so results are bitwise reproducible
+#pragma unroll
+  for (int k = 0; k < 21; ++k) {
+    double v = acc[k];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    acc[k] = v;
+  }
+  __shared__ double lds[kBlockThreads / 64][kPartialSize];
+  int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 21; ++k) lds[wave][k] = acc[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 21) {
+    double v = ((lds[0][threadIdx.x] + lds[1][threadIdx.x]) + lds[2][threadIdx.x]) + lds[3][threadIdx.x];
+    partials[(size_t)t * kPartialSize + threadIdx.x] = v;
+  }
+}
+
+// One wavefront per constraint: sums the constraint's tile partials in tile
+// order and expands the 21 products into [cost, J^T r (8), upper J^T J (36)].
+__global__ __launch_bounds__(64) void reg_finalize_kernel(const ConstraintDev* __restrict__ cons,
+                                                         const int32_t* __restrict__ tile_first,
+                                                         const double* __restrict__ partials,
+                                                         double* __restrict__ normal) {
+  const int c = blockIdx.x;
+  __shared__ double s[21];
+  if (threadIdx.x < 21) {
+    double v = 0.0;
+    for (int t = tile_first[c]; t < tile_first[c + 1]; ++t)
+      v += partials[(size_t)t * kPartialSize + threadIdx.x];
+    s[threadIdx.x] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kNormalSize) {
+    const int map[8] = {0, 1, 2, 3, 0, 1, 2, 4};
+    const double sgn[8] = {1, 1, 1, 1, -1, -1, -1, 1};
+    auto S = [&](int a, int b) {
+      int i = a < b ? a : b, j = a < b ? b : a;
+      return s[i * 6 - (i * (i - 1)) / 2 + (j - i)];
+    };
+    const double f = cons[c].factor;
+    const double f2 = f * f;
+    double v;
+    int k = threadIdx.x;
+    if (k == 0) {
+      v = S(5, 5);
+    } else if (k <= 8) {
+      int p = k - 1;
+      v = sgn[p] * S(map[p], 5);
+    } else {
+      int idx = k - 9, p = 0;
+      while (idx >= 8 - p) {
+        idx -= 8 - p;
+        ++p;
+      }
+      int q = p + idx;
+      v = sgn[p] * sgn[q] * S(map[p], map[q]);
+    }
+    normal[(size_t)c * kNormalSize + k] = v * f2;
+  }
+}
+
+// Deterministic scatter of per-constraint normal blocks into the all-reduce
+// buffer: one thread per output element, looping over incident constraints.
+__global__ void reg_assemble_kernel(const double* __restrict__ normal, int n, int csr_nodes,
+                                    int n_nodes,
+                                    const int32_t* __restrict__ node_pair,
+                                    const int32_t* __restrict__ global_index,
+                                    const int32_t* __restrict__ node_first,
+                                    const int32_t* __restrict__ node_items,
+                                    double* __restrict__ fused, int accumulate) {
+  auto H = [&](const double* nb, int a, int b) {  // upper-triangular lookup
+    int i = a < b ? a : b, j = a < b ? b : a;
+    return nb[9 + i * 8 - (i * (i - 1)) / 2 + (j - i)];
+  };
+  const int64_t n_node_elems = (int64_t)csr_nodes * 20;  // 4 (J^T r) + 16 (diag block)
+  const int64_t n_off = (int64_t)n * 16;
+  int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid == 0) {
+    double v = 0.0;
+    for (int c = 0; c < n; ++c) v += normal[(size_t)c * kNormalSize];
+    fused[0] = accumulate ? fused[0] + v : v;
+  }
+  if (tid < n_node_elems) {
+    int node = (int)(tid / 20), e = (int)(tid % 20);
+    double v = 0.0;
+    for (int it = node_first[node]; it < node_first[node + 1]; ++it) {
+      int item = node_items[it];
+      int c = item >> 1, side = item & 1;
+      const double* nb = normal + (size_t)c * kNormalSize;
+      if (e < 4) {
+        v += nb[1 + 4 * side + e];
+      } else {
+        int k = (e - 4) / 4, l = (e - 4) % 4;
+        v += H(nb, 4 * side + k, 4 * side + l);
+      }
+    }
+    double* dst = e < 4 ? &fused[1 + 4 * (int64_t)node + e]
+                        : &fused[1 + 4 * (int64_t)n_nodes + 16 * (int64_t)node + (e - 4)];
+    *dst = accumulate ? *dst + v : v;
+  } else if (tid < n_node_elems + n_off) {
+    int64_t o = tid - n_node_elems;
+    int c = (int)(o / 16), e = (int)(o % 16);
+    const double* nb = normal + (size_t)c * kNormalSize;
+    int gidx = global_index[c];
+    double* dst = &fused[1 + 20 * (int64_t)n_nodes + 16 * (int64_t)gidx + e];
+    double v = H(nb, e / 4, 4 + e % 4);
+    *dst = accumulate ? *dst + v : v;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// launch helpers
+// ---------------------------------------------------------------------------
+template <typename OUT>
+static void launch_points(vgx_ctx ctx, int vps, const ConstraintDev* d_desc, const PosePack* d_pack,
+                          const Tile* d_tiles, int n_tiles, void* res, void* jr, void* je) {
+  if (n_tiles <= 0) return;
+  dim3 grid(((n_tiles + 7) / 8) * 8), block(kBlockThreads);
+  using O4 = typename Out4<OUT>::type;
+  if (vps == 16)
+    hipLaunchKernelGGL((reg_eval_points_kernel<16, OUT, kPointsPerThread>), grid, block, 0,
+                       ctx->stream, d_desc, d_pack, d_tiles, n_tiles, (OUT*)res, (O4*)jr, (O4*)je);
+  else
+    hipLaunchKernelGGL((reg_eval_points_kernel<8, OUT, kPointsPerThread>), grid, block, 0,
+                       ctx->stream, d_desc, d_pack, d_tiles, n_tiles, (OUT*)res, (O4*)jr, (O4*)je);
+}
+
+}  // namespace vgx
+
+using namespace vgx;
+
+// ---------------------------------------------------------------------------
+// single constraint
+// ---------------------------------------------------------------------------
+vgx::ConstraintDev vgx_reg_s::describe() const {
+  ConstraintDev c;
+  std::memset(&c, 0, sizeof(c));
+  c.grid = reading->grid_dev(cfg.use_esdf_distance ? 1 : 0);
+  const PointSet& ps = reference->points[cfg.registration_point_type];
+  c.xyzd = ps.d_xyzd;
+  c.weight = ps.d_weight;
+  c.sample_idx = d_sample_idx;
+  c.n = num_residuals;
+  c.row0 = 0;
+  // RCF:274: num_residuals / summed_reference_weight; sampled points weigh 1
+  if (cfg.sampling_ratio != -1.0f) {
+    c.factor = 1.0;
+  } else {
+    c.factor = ps.sum_weight != 0 ? (double)num_residuals / ps.sum_weight : 0.0;
+  }
+  c.no_corr_cost = cfg.no_correspondence_cost;
+  return c;
+}
+
+// WeightedSampler::getRandomItem (weighted_sampler_inl.h:18-28), num_residuals
+// draws per Evaluate (RCF:113-122), on the constraint's own engine.
+bool vgx_reg_s::draw_samples() {
+  const PointSet& ps = reference->points[cfg.registration_point_type];
+  h_sample_idx.resize((size_t)num_residuals);
+  const std::vector<double>& cum = ps.cumulative_weight;
+  for (int64_t i = 0; i < num_residuals; ++i) {
+    const double random_number = uniform(rng);
+    const double random_cumulative_weight = random_number * cum.back();
+    auto it = std::upper_bound(cum.begin(), cum.end(), random_cumulative_weight);
+    size_t idx = (size_t)(it - cum.begin());
+    if (idx >= cum.size()) idx = cum.size() - 1;
+    h_sample_idx[(size_t)i] = ps.inv_order.empty() ? (int32_t)idx : ps.inv_order[idx];
+  }
+  return true;
+}
+
+extern "C" {
+
+void vgx_reg_config_default(vgx_reg_config* cfg) {
+  if (!cfg) return;
+  cfg->registration_point_type = VGX_POINTS_ISOSURFACE;
+  cfg->sampling_ratio = -1.0f;
+  cfg->no_correspondence_cost = 0.0;
+  cfg->use_esdf_distance = 1;
+  cfg->sampler_seed = 5489u;
+}
+
+int vgx_reg_create(vgx_ctx ctx, vgx_submap reference, vgx_submap reading, const vgx_reg_config* cfg,
+                   vgx_reg* out) {
+  if (!ctx || !out) return VGX_ERR_INVALID;
+  *out = nullptr;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!reference || !reading || !cfg)
+    return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_create: NULL submap or config");
+  if (reference->ctx != ctx || reading->ctx != ctx)
+    return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_create: submaps belong to another context");
+  if (cfg->registration_point_type != VGX_POINTS_ISOSURFACE &&
+      cfg->registration_point_type != VGX_POINTS_VOXELS)
+    return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_create: bad registration_point_type");
+  const PointSet& ps = reference->points[cfg->registration_point_type];
+  if (!ps.present)
+    return set_error(ctx, VGX_ERR_INVALID,
+                     "vgx_reg_create: reference submap has no registration points of that type "
+                     "(submap not finished)");
+  const int which = cfg->use_esdf_distance ? 1 : 0;
+  if (reading->n_blocks > 0 && !reading->grid[which].present)
+    return set_error(ctx, VGX_ERR_INVALID,
+                     which ? "vgx_reg_create: reading submap has no ESDF layer"
+                           : "vgx_reg_create: reading submap has no TSDF layer");
+  if (reference->vps != reading->vps)
+    return set_error(ctx, VGX_ERR_UNSUPPORTED, "vgx_reg_create: submaps differ in voxels_per_side");
+  vgx_reg r = new (std::nothrow) vgx_reg_s();
+  if (!r) return set_error(ctx, VGX_ERR_NOMEM, "vgx_reg_create: out of host memory");
+  r->ctx = ctx;
+  r->reference = reference;
+  r->reading = reading;
+  r->cfg = *cfg;
+  // RCF:45-55
+  if (cfg->sampling_ratio != -1.0f) {
+    r->num_residuals = (int64_t)(int)(cfg->sampling_ratio * (float)ps.n);
+    if (r->num_residuals < 0) r->num_residuals = 0;
+  } else {
+    r->num_residuals = ps.n;
+  }
+  r->rng.seed(cfg->sampler_seed);
+  if (cfg->sampling_ratio != -1.0f && (int64_t)ps.cumulative_weight.size() != ps.n) {
+    // points extracted on the device: build WeightedSampler's cumulative weights
+    // (weighted_sampler_inl.h:5-16) from the device copy, in extraction order
+    PointSet& mps = reference->points[cfg->registration_point_type];
+    std::vector<float> w((size_t)mps.n);
+    if (mps.n > 0 && (hipStreamSynchronize(ctx->stream) != hipSuccess ||
+                      hipMemcpy(w.data(), mps.d_weight, (size_t)mps.n * sizeof(float),
+                                hipMemcpyDeviceToHost) != hipSuccess)) {
+      delete r;
+      return set_error(ctx, VGX_ERR_HIP, "vgx_reg_create: weight download failed");
+    }
+    mps.cumulative_weight.resize((size_t)mps.n);
+    double acc = 0;
+    for (int64_t i = 0; i < mps.n; ++i) {
+      acc = (i == 0) ? (double)w[0] : acc + (double)w[(size_t)i];
+      mps.cumulative_weight[(size_t)i] = acc;
+    }
+  }
+  if (cfg->sampling_ratio != -1.0f && ps.n == 0) r->num_residuals = 0;
+  *out = r;
+  return VGX_OK;
+}
+
+int vgx_reg_destroy(vgx_reg r) {
+  if (!r) return VGX_ERR_INVALID;
+  (void)hipSetDevice(r->ctx->device);
+  (void)hipStreamSynchronize(r->ctx->stream);
+  if (r->d_sample_idx) (void)hipFree(r->d_sample_idx);
+  if (r->d_out) (void)hipFree(r->d_out);
+  if (r->d_tiles) (void)hipFree(r->d_tiles);
+  if (r->d_desc) (void)hipFree(r->d_desc);
+  if (r->d_pack) (void)hipFree(r->d_pack);
+  delete r;
+  return VGX_OK;
+}
+
+int64_t vgx_reg_num_residuals(vgx_reg r) { return r ? r->num_residuals : -1; }
+
+// Prepares descriptor, tiles, pose pack (and fresh samples) on the device.
+static int reg_prepare(vgx_reg r, const double ref_pose[4], const double read_pose[4]) {
+  vgx_ctx ctx = r->ctx;
+  VGX_HIP(ctx, hipSetDevice(ctx->device));
+  const int64_t n = r->num_residuals;
+  if (!r->d_tiles) {
+    std::vector<Tile> tiles = make_tiles(0, n, kTilePoints);
+    r->n_tiles = (int32_t)tiles.size();
+    if (r->n_tiles > 0) {
+      VGX_HIP(ctx, hipMalloc(&r->d_tiles, tiles.size() * sizeof(Tile)));
+      VGX_HIP(ctx, hipMemcpy(r->d_tiles, tiles.data(), tiles.size() * sizeof(Tile), hipMemcpyHostToDevice));
+    }
+    VGX_HIP(ctx, hipMalloc(&r->d_desc, sizeof(ConstraintDev)));
+    VGX_HIP(ctx, hipMalloc(&r->d_pack, sizeof(PosePack)));
+    if (r->cfg.sampling_ratio != -1.0f && n > 0)
+      VGX_HIP(ctx, hipMalloc(&r->d_sample_idx, (size_t)n * sizeof(int32_t)));
+  }
+  if (r->cfg.sampling_ratio != -1.0f && n > 0) {
+    r->draw_samples();
+    VGX_HIP(ctx, hipMemcpyAsync(r->d_sample_idx, r->h_sample_idx.data(), (size_t)n * sizeof(int32_t),
+                                hipMemcpyHostToDevice, ctx->stream));
+  }
+  ConstraintDev desc = r->describe();
+  PosePack pack;
+  make_pose_pack(ref_pose, read_pose, &pack);
+  VGX_HIP(ctx, hipMemcpyAsync(r->d_desc, &desc, sizeof(desc), hipMemcpyHostToDevice, ctx->stream));
+  VGX_HIP(ctx, hipMemcpyAsync(r->d_pack, &pack, sizeof(pack), hipMemcpyHostToDevice, ctx->stream));
+  // desc / pack / h_sample_idx are pageable host memory: the copies complete
+  // before hipMemcpyAsync returns for pageable sources, but be explicit.
+  VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VGX_OK;
+}
+
+static int reg_status(vgx_reg r) {
+  // RCF:273: summed_reference_weight == 0 -> return false
+  const PointSet& ps = r->reference->points[r->cfg.registration_point_type];
+  double sw = r->cfg.sampling_ratio != -1.0f ? (double)r->num_residuals : ps.sum_weight;
+  return sw == 0 ? VGX_EVALUATE_FALSE : VGX_OK;
+}
+
+int vgx_reg_evaluate(vgx_reg r, const double ref_pose[4], const double read_pose[4],
+                     double* residuals, double* jac_ref, double* jac_read) {
+  if (!r || !ref_pose || !read_pose) return VGX_ERR_INVALID;
+  vgx_ctx ctx = r->ctx;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!residuals) return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_evaluate: residuals == NULL");
+  int rc = reg_prepare(r, ref_pose, read_pose);
+  if (rc != VGX_OK) return rc;
+  if (reg_status(r) == VGX_EVALUATE_FALSE) return VGX_EVALUATE_FALSE;
+  const int64_t n = r->num_residuals;
+  if (n == 0) return VGX_OK;
+  if (r->d_out_rows < n) {
+    if (r->d_out) (void)hipFree(r->d_out);
+    r->d_out = nullptr;
+    VGX_HIP(ctx, hipMalloc(&r->d_out, (size_t)n * 9 * sizeof(double)));
+    r->d_out_rows = n;
+  }
+  double* d_res = r->d_out;
+  double* d_jr = jac_ref ? r->d_out + n : nullptr;
+  double* d_je = jac_read ? r->d_out + 5 * n : nullptr;
+  launch_points<double>(ctx, r->reading->vps, r->d_desc, r->d_pack, r->d_tiles, r->n_tiles, d_res,
+                        d_jr, d_je);
+  VGX_HIP(ctx, hipGetLastError());
+  VGX_HIP(ctx, hipMemcpyAsync(residuals, d_res, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (jac_ref)
+    VGX_HIP(ctx, hipMemcpyAsync(jac_ref, d_jr, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (jac_read)
+    VGX_HIP(ctx, hipMemcpyAsync(jac_read, d_je, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VGX_OK;
+}
+
+int vgx_reg_evaluate_device_f32(vgx_reg r, const double ref_pose[4], const double read_pose[4],
+                                void* d_residuals, void* d_jac_ref, void* d_jac_read) {
+  if (!r || !ref_pose || !read_pose) return VGX_ERR_INVALID;
+  vgx_ctx ctx = r->ctx;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!d_residuals) return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_evaluate_device_f32: residuals == NULL");
+  int rc = reg_prepare(r, ref_pose, read_pose);
+  if (rc != VGX_OK) return rc;
+  if (reg_status(r) == VGX_EVALUATE_FALSE) return VGX_EVALUATE_FALSE;
+  launch_points<float>(ctx, r->reading->vps, r->d_desc, r->d_pack, r->d_tiles, r->n_tiles,
+                       d_residuals, d_jac_ref, d_jac_read);
+  VGX_HIP(ctx, hipGetLastError());
+  return VGX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// batch
+// ---------------------------------------------------------------------------
+int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs, const int32_t* node_pair,
+                         const int32_t* global_index, int32_t n_global, vgx_reg_batch* out) {
+  if (!ctx || !out) return VGX_ERR_INVALID;
+  *out = nullptr;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (n < 0 || (n > 0 && (!regs || !node_pair)))
+    return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_batch_create: bad n / NULL arrays");
+  if (!global_index) n_global = n;
+  if (n_global < n) return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_batch_create: n_global < n");
+  VGX_HIP(ctx, hipSetDevice(ctx->device));
+  int vps = 0;
+  for (int c = 0; c < n; ++c) {
+    if (!regs[c] || regs[c]->ctx != ctx)
+      return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_batch_create: NULL or foreign constraint");
+    if (regs[c]->cfg.sampling_ratio != -1.0f)
+      return set_error(ctx, VGX_ERR_UNSUPPORTED,
+                       "vgx_reg_batch_create: sampling constraints are evaluated one by one "
+                       "(vgx_reg_evaluate); the batch is the deterministic all-points mode");
+    if (node_pair[2 * c] < 0 || node_pair[2 * c + 1] < 0)
+      return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_batch_create: negative node index");
+    if (global_index && (global_index[c] < 0 || global_index[c] >= n_global))
+      return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_batch_create: global_index out of range");
+    if (vps == 0) vps = regs[c]->reading->vps;
+    if (regs[c]->reading->vps != vps)
+      return set_error(ctx, VGX_ERR_UNSUPPORTED, "vgx_reg_batch_create: mixed voxels_per_side");
+  }
+  vgx_reg_batch b = new (std::nothrow) vgx_reg_batch_s();
+  if (!b) return set_error(ctx, VGX_ERR_NOMEM, "vgx_reg_batch_create: out of host memory");
+  vgx_reg_batch ex = b;
+  b->ctx = ctx;
+  b->n = n;
+  b->n_global = n_global;
+  b->regs.assign(regs, regs + n);
+  b->node_pair.assign(node_pair, node_pair + 2 * (size_t)n);
+  b->global_index.resize((size_t)n);
+  for (int c = 0; c < n; ++c) b->global_index[(size_t)c] = global_index ? global_index[c] : c;
+  b->row_offset.assign((size_t)n + 1, 0);
+  std::vector<ConstraintDev> desc((size_t)n);
+  std::vector<int32_t> tile_first((size_t)n + 1, 0);
+  int max_node = -1;
+  for (int c = 0; c < n; ++c) {
+    desc[(size_t)c] = regs[c]->describe();
+    desc[(size_t)c].row0 = b->row_offset[(size_t)c];
+    b->row_offset[(size_t)c + 1] = b->row_offset[(size_t)c] + regs[c]->num_residuals;
+    std::vector<Tile> t = make_tiles(c, regs[c]->num_residuals, kTilePoints);
+    b->tiles.insert(b->tiles.end(), t.begin(), t.end());
+    tile_first[(size_t)c] = (int32_t)ex->reduce_tiles.size();
+    std::vector<Tile> rt = make_tiles(c, regs[c]->num_residuals, kTilePoints * kReduceIters);
+    ex->reduce_tiles.insert(ex->reduce_tiles.end(), rt.begin(), rt.end());
+    max_node = std::max(max_node, std::max(node_pair[2 * c], node_pair[2 * c + 1]));
+  }
+  tile_first[(size_t)n] = (int32_t)ex->reduce_tiles.size();
+  // CSR: node -> (constraint << 1 | side)
+  ex->csr_nodes = max_node + 1;
+  std::vector<int32_t> first((size_t)ex->csr_nodes + 1, 0), items(2 * (size_t)n);
+  for (int c = 0; c < n; ++c)
+    for (int s = 0; s < 2; ++s) first[(size_t)node_pair[2 * c + s] + 1]++;
+  for (int i = 0; i < ex->csr_nodes; ++i) first[(size_t)i + 1] += first[(size_t)i];
+  {
+    std::vector<int32_t> cur(first.begin(), first.end() - 1);
+    for (int c = 0; c < n; ++c)
+      for (int s = 0; s < 2; ++s) items[(size_t)cur[(size_t)node_pair[2 * c + s]]++] = (c << 1) | s;
+  }
+  auto up = [&](const void* src, size_t bytes, void** dst) -> int {
+    *dst = nullptr;
+    if (bytes == 0) return VGX_OK;
+    VGX_HIP(ctx, hipMalloc(dst, bytes));
+    VGX_HIP(ctx, hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    return VGX_OK;
+  };
+  int rc = up(desc.data(), desc.size() * sizeof(ConstraintDev), (void**)&b->d_desc);
+  if (rc == VGX_OK) rc = up(b->tiles.data(), b->tiles.size() * sizeof(Tile), (void**)&b->d_tiles);
+  if (rc == VGX_OK) rc = up(ex->reduce_tiles.data(), ex->reduce_tiles.size() * sizeof(Tile), (void**)&ex->d_reduce_tiles);
+  if (rc == VGX_OK) rc = up(tile_first.data(), tile_first.size() * sizeof(int32_t), (void**)&b->d_tile_first);
+  if (rc == VGX_OK) rc = up(b->node_pair.data(), b->node_pair.size() * sizeof(int32_t), (void**)&b->d_node_pair);
+  if (rc == VGX_OK) rc = up(b->global_index.data(), b->global_index.size() * sizeof(int32_t), (void**)&b->d_global_index);
+  if (rc == VGX_OK) rc = up(first.data(), first.size() * sizeof(int32_t), (void**)&ex->d_node_first);
+  if (rc == VGX_OK) rc = up(items.data(), items.size() * sizeof(int32_t), (void**)&ex->d_node_items);
+  if (rc == VGX_OK && n > 0) {
+    if (hipMalloc(&b->d_pack, (size_t)n * sizeof(PosePack)) != hipSuccess ||
+        hipHostMalloc(&b->h_pack, (size_t)n * sizeof(PosePack)) != hipSuccess ||
+        hipMalloc(&b->d_partials, std::max<size_t>(1, ex->reduce_tiles.size()) * kPartialSize * sizeof(double)) != hipSuccess ||
+        hipMalloc(&b->d_normal, (size_t)n * kNormalSize * sizeof(double)) != hipSuccess)
+      rc = set_error(ctx, VGX_ERR_NOMEM, "vgx_reg_batch_create: device allocation failed");
+  }
+  if (rc != VGX_OK) {
+    vgx_reg_batch_destroy(b);
+    return rc;
+  }
+  *out = b;
+  return VGX_OK;
+}
+
+int vgx_reg_batch_destroy(vgx_reg_batch b) {
+  if (!b) return VGX_ERR_INVALID;
+  (void)hipSetDevice(b->ctx->device);
+  (void)hipStreamSynchronize(b->ctx->stream);
+  if (b->d_node_first) (void)hipFree(b->d_node_first);
+  if (b->d_node_items) (void)hipFree(b->d_node_items);
+  if (b->d_reduce_tiles) (void)hipFree(b->d_reduce_tiles);
+  if (b->d_desc) (void)hipFree(b->d_desc);
+  if (b->d_pack) (void)hipFree(b->d_pack);
+  if (b->h_pack) (void)hipHostFree(b->h_pack);
+  if (b->d_tiles) (void)hipFree(b->d_tiles);
+  if (b->d_tile_first) (void)hipFree(b->d_tile_first);
+  if (b->d_partials) (void)hipFree(b->d_partials);
+  if (b->d_normal) (void)hipFree(b->d_normal);
+  if (b->d_node_pair) (void)hipFree(b->d_node_pair);
+  if (b->d_global_index) (void)hipFree(b->d_global_index);
+  delete b;
+  return VGX_OK;
+}
+
+int64_t vgx_reg_batch_num_residuals(vgx_reg_batch b) { return b ? b->row_offset.back() : -1; }
+
+int vgx_reg_batch_row_offsets(vgx_reg_batch b, int64_t* row_offset) {
+  if (!b || !row_offset) return VGX_ERR_INVALID;
+  std::copy(b->row_offset.begin(), b->row_offset.end(), row_offset);
+  return VGX_OK;
+}
+
+// pose packs for every constraint -> pinned staging -> device
+static int batch_upload_packs(vgx_reg_batch b, const double* poses, int32_t n_nodes, int32_t* status) {
+  vgx_ctx ctx = b->ctx;
+  for (int c = 0; c < b->n; ++c) {
+    int i = b->node_pair[2 * (size_t)c], j = b->node_pair[2 * (size_t)c + 1];
+    if (i >= n_nodes || j >= n_nodes)
+      return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_batch: node index >= n_nodes");
+    make_pose_pack(poses + 4 * (size_t)i, poses + 4 * (size_t)j, &b->h_pack[c]);
+    if (status) status[c] = reg_status(b->regs[(size_t)c]);
+  }
+  if (b->n > 0)
+    VGX_HIP(ctx, hipMemcpyAsync(b->d_pack, b->h_pack, (size_t)b->n * sizeof(PosePack),
+                                hipMemcpyHostToDevice, ctx->stream));
+  return VGX_OK;
+}
+
+int vgx_reg_batch_evaluate_points(vgx_reg_batch b, const double* poses, int32_t n_nodes,
+                                  void* d_residuals, void* d_jac_ref, void* d_jac_read,
+                                  int32_t* status) {
+  if (!b || !poses) return VGX_ERR_INVALID;
+  vgx_ctx ctx = b->ctx;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!d_residuals) return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_batch_evaluate_points: residuals == NULL");
+  VGX_HIP(ctx, hipSetDevice(ctx->device));
+  // the previous evaluation may still be reading the pinned staging buffer
+  VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  int rc = batch_upload_packs(b, poses, n_nodes, status);
+  if (rc != VGX_OK) return rc;
+  if (b->n == 0) return VGX_OK;
+  launch_points<float>(ctx, b->regs[0]->reading->vps, b->d_desc, b->d_pack, b->d_tiles,
+                       (int)b->tiles.size(), d_residuals, d_jac_ref, d_jac_read);
+  VGX_HIP(ctx, hipGetLastError());
+  return VGX_OK;
+}
+
+int vgx_reg_batch_evaluate_normal(vgx_reg_batch b, const double* poses, int32_t n_nodes,
+                                  void* d_normal, double* normal_host, int32_t* status) {
+  if (!b || !poses) return VGX_ERR_INVALID;
+  vgx_ctx ctx = b->ctx;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  vgx_reg_batch ex = b;
+  VGX_HIP(ctx, hipSetDevice(ctx->device));
+  VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  int rc = batch_upload_packs(b, poses, n_nodes, status);
+  if (rc != VGX_OK) return rc;
+  if (b->n == 0) return VGX_OK;
+  double* out = d_normal ? (double*)d_normal : b->d_normal;
+  const int n_tiles = (int)ex->reduce_tiles.size();
+  if (n_tiles > 0) {
+    dim3 grid(((n_tiles + 7) / 8) * 8), block(kBlockThreads);
+    if (b->regs[0]->reading->vps == 16)
+      hipLaunchKernelGGL((reg_eval_reduce_kernel<16, kPointsPerThread>), grid, block, 0, ctx->stream,
+                         b->d_desc, b->d_pack, ex->d_reduce_tiles, n_tiles, b->d_partials);
+    else
+      hipLaunchKernelGGL((reg_eval_reduce_kernel<8, kPointsPerThread>), grid, block, 0, ctx->stream,
+                         b->d_desc, b->d_pack, ex->d_reduce_tiles, n_tiles, b->d_partials);
+    VGX_HIP(ctx, hipGetLastError());
+  }
+  hipLaunchKernelGGL(reg_finalize_kernel, dim3(b->n), dim3(64), 0, ctx->stream, b->d_desc,
+                     b->d_tile_first, b->d_partials, out);
+  VGX_HIP(ctx, hipGetLastError());
+  if (normal_host) {
+    VGX_HIP(ctx, hipMemcpyAsync(normal_host, out, (size_t)b->n * kNormalSize * sizeof(double),
+                                hipMemcpyDeviceToHost, ctx->stream));
+    VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return VGX_OK;
+}
+
+int64_t vgx_reg_fused_size(int32_t n_nodes, int32_t n_global) {
+  if (n_nodes < 0 || n_global < 0) return -1;
+  return 1 + 20 * (int64_t)n_nodes + 16 * (int64_t)n_global;
+}
+
+int vgx_reg_batch_assemble(vgx_reg_batch b, const void* d_normal, int32_t n_nodes, void* d_fused,
+                           int32_t zero_first) {
+  if (!b || !d_fused) return VGX_ERR_INVALID;
+  vgx_ctx ctx = b->ctx;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  vgx_reg_batch ex = b;
+  if (n_nodes < ex->csr_nodes)
+    return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_batch_assemble: n_nodes smaller than the largest node index");
+  VGX_HIP(ctx, hipSetDevice(ctx->device));
+  const double* nb = d_normal ? (const double*)d_normal : b->d_normal;
+  if (zero_first)
+    VGX_HIP(ctx, hipMemsetAsync(d_fused, 0, (size_t)vgx_reg_fused_size(n_nodes, b->n_global) * sizeof(double), ctx->stream));
+  // nodes beyond the batch's CSR have no incident constraints: cover only the
+  // CSR range for node elements, all constraints for the off-diagonal blocks.
+  int64_t work = (int64_t)ex->csr_nodes * 20 + (int64_t)b->n * 16;
+  if (work == 0) work = 1;
+  int threads = 256;
+  int blocks = (int)((work + threads - 1) / threads);
+  // The kernel indexes node elements by the CSR's node count but lays the
+  // buffer out with the caller's n_nodes.
+  hipLaunchKernelGGL(reg_assemble_kernel, dim3(blocks), dim3(threads), 0, ctx->stream, nb, b->n,
+                     ex->csr_nodes, n_nodes, b->d_node_pair, b->d_global_index, ex->d_node_first, ex->d_node_items,
+                     (double*)d_fused, zero_first ? 0 : 1);
+  VGX_HIP(ctx, hipGetLastError());
+  return VGX_OK;
+}
+
+}  // extern "C"
