@@ -1,0 +1,303 @@
+#!/usr/bin/env python3
+"""bench.py -- REG hot path on BASELINE config 3 (200 submaps @ 256^3, pair-sharded).
+
+One "step" = one pass of the registration hot path over the whole pose graph's
+registration constraints: every constraint's residuals and both Jacobians are
+evaluated (materialising f32 form, 88 B/evaluation) by ONE batched
+launch per rank.  Inputs (sampling grids, registration points) are resident in
+HBM before the timed region; the only per-step host->device traffic is the 64-B
+pose pack per constraint.
+
+N > 1: the constraint list is sharded across ranks (greedy LPT by residual
+count), submaps are replicated, no data-path collective is needed
+for this materialising pass; the fixed graph makes this STRONG scaling.  The
+fused pass + RCCL all-reduce of the normal-equation buffer (what a solver
+iteration needs) is timed after the headline region and reported under
+"fused" (it does not contribute to `value`).
+
+  python bench.py --gpus 1 --steps 10 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BYTES_PER_EVAL = 88            # SURVEY.md 8d contract figure (materialising, f32 outputs)
+BYTES_NO_CORR = 56             # an evaluation that finds no reading block: 20 B in, 36 B out
+BYTES_PER_EVAL_FUSED = 52
+
+
+def build_graph(args):
+    """Config 3: grid of submaps over the analytic city scene, constraints between
+    submaps whose cubes overlap."""
+    gw, gh = args.grid
+    rng = np.random.default_rng(args.seed)
+    dims = np.array(args.block_dims, np.int32)
+    extent = dims * 16 * args.voxel_size
+    sx, sy = extent[0] * 0.5, extent[1] / 3.0       # 50 % overlap in x, 2/3 in y
+    true_poses, ids = [], {}
+    for j in range(gh):
+        for i in range(gw):
+            ids[(i, j)] = len(true_poses)
+            true_poses.append([i * sx, j * sy, 0.0, rng.uniform(-0.1, 0.1)])
+    true_poses = np.array(true_poses)
+    pairs = []
+    for j in range(gh):
+        for i in range(gw):
+            for di, dj in ((1, 0), (0, 1), (1, 1), (-1, 1), (0, 2), (1, 2), (-1, 2)):
+                k = (i + di, j + dj)
+                if k in ids:
+                    pairs.append((ids[(i, j)], ids[k]))
+    # initial guess = truth + drift: N(0, 0.3 m), N(0, 0.05 rad); submap 0 fixed
+    poses = true_poses + np.concatenate(
+        [rng.normal(0, args.pose_sigma, (len(true_poses), 3)),
+         rng.normal(0, args.yaw_sigma, (len(true_poses), 1))], axis=1)
+    poses[0] = true_poses[0]
+    return true_poses, poses, np.array(pairs, np.int32)
+
+
+def lpt_shards(weights, n):
+    """Greedy longest-processing-time partition of constraints onto n ranks."""
+    order = np.argsort(-np.asarray(weights), kind="stable")
+    load = np.zeros(n)
+    shard = [[] for _ in range(n)]
+    for c in order:
+        r = int(np.argmin(load))
+        shard[r].append(int(c))
+        load[r] += weights[c]
+    return [sorted(s) for s in shard]
+
+
+def cpu_baseline(capi, ctx, args, true_poses, poses, pairs, seconds):
+    """The CPU oracle ("port") timed on this host on ONE constraint of the same
+    workload, replicated over all host cores (one constraint per task, the
+    reference's parallelism axis, pose_graph.cpp:96)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import pyoracle as orc
+    a, b = int(pairs[0][0]), int(pairs[0][1])
+    subs = {}
+    for k in (a, b):
+        sm = capi.Submap.synth_city(ctx, k, args.voxel_size, 16, args.block_min, args.block_dims,
+                                    args.truncation, args.esdf_max, 10.0, true_poses[k], args.seed)
+        td, tw, ed, eo = sm.download_layers(16)
+        subs[k] = (sm.block_index(), td, tw, ed, eo)
+        sm.destroy()
+    bi, td, tw, ed, eo = subs[a]
+    xyz, dist, w = orc.find_relevant_voxels(args.voxel_size, 16, bi, td, tw, ed)
+    bi, td, tw, ed, eo = subs[b]
+    layer = orc.Layer(args.voxel_size, 16, bi, ed, eo)
+    cores = os.cpu_count() or 1
+    n = len(w)
+
+    def task(_):
+        ok, r, jo, je = orc.reg_evaluate(layer, xyz, dist, w, poses[a], poses[b])
+        return n
+
+    task(0)                                   # page everything in
+    done, t0 = 0, time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        while time.perf_counter() - t0 < seconds:
+            done += sum(ex.map(task, range(cores)))
+    dt = time.perf_counter() - t0
+    return {"value": done / dt / 1e6, "unit": "Mresiduals+Jacobians/s", "cores": cores,
+            "kind": "port",
+            "sample": f"constraint 0 of the same graph ({n} residuals, one 256^3 pair) evaluated "
+                      f"{done // n} times, one evaluation per task on {cores} threads, {dt:.1f} s; "
+                      "oracle/reg_oracle.c (gcc -O2), the reference itself cannot be built here"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--grid", type=int, nargs=2, default=[20, 10], help="submap grid (200 submaps)")
+    ap.add_argument("--block-dims", type=int, nargs=3, default=[16, 16, 16], help="256^3 voxels")
+    ap.add_argument("--block-min", type=int, nargs=3, default=[-8, -8, -4])
+    ap.add_argument("--voxel-size", type=float, default=0.2)
+    ap.add_argument("--truncation", type=float, default=0.6)
+    ap.add_argument("--esdf-max", type=float, default=2.0)
+    ap.add_argument("--pose-sigma", type=float, default=0.3)
+    ap.add_argument("--yaw-sigma", type=float, default=0.05)
+    ap.add_argument("--seed", type=int, default=2)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fused", action="store_true")
+    ap.add_argument("--keep-order", action="store_true", help="extraction order instead of Morton")
+    args = ap.parse_args()
+
+    from voxgraph_amd import capi
+    capi.load()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    ctx = capi.Context(local_rank)
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+
+    true_poses, poses, pairs = build_graph(args)
+    n_sub, n_con = len(true_poses), len(pairs)
+
+    # ---- resident inputs: every rank holds every finished submap -------------
+    t_setup = time.perf_counter()
+    submaps, n_points = [], []
+    for k in range(n_sub):
+        sm = capi.Submap.synth_city(ctx, k, args.voxel_size, 16, args.block_min, args.block_dims,
+                                    args.truncation, args.esdf_max, 10.0, true_poses[k], args.seed)
+        n_points.append(sm.extract_voxel_points(1.0, 0.3, True))      # voxgraph_submap.h:27-28
+        sm.release_raw_layers()
+        submaps.append(sm)
+    ctx.synchronize()
+    setup_s = time.perf_counter() - t_setup
+
+    cfg = capi.default_config(registration_point_type=capi.POINTS_VOXELS)
+    weights = [n_points[a] for a, _ in pairs]
+    mine = lpt_shards(weights, world)[rank]
+    cfs = [capi.RegistrationCostFunction(ctx, submaps[pairs[c][0]], submaps[pairs[c][1]], cfg)
+           for c in mine]
+    batch = capi.RegistrationBatch(ctx, cfs, pairs[mine], global_index=mine, n_global=n_con)
+    R = batch.num_residuals()
+    residuals = torch.empty(R, dtype=torch.float32, device="cuda")
+    jac_ref = torch.empty((R, 4), dtype=torch.float32, device="cuda")
+    jac_read = torch.empty((R, 4), dtype=torch.float32, device="cuda")
+
+    def step():
+        batch.evaluate_points(poses, residuals.data_ptr(), jac_ref.data_ptr(), jac_read.data_ptr())
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    ctx.timer_start()                      # HIP events on the stream the kernel runs on
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    kernel_ms = ctx.timer_stop() / max(args.steps, 1)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    rtot = torch.tensor([float(R)], dtype=torch.float64, device="cuda")
+    kmax = torch.tensor([kernel_ms], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rtot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
+    dt, total_evals, kernel_ms_max = float(tmax.item()), float(rtot.item()), float(kmax.item())
+
+    # correspondences on this rank (for the conservative byte count)
+    with_corr = int((jac_ref.abs().sum(dim=1) > 0).sum().item())
+    checksum = float(residuals.double().pow(2).sum().item())
+
+    # ---- fused pass + all-reduce (solver-iteration form), reported separately --
+    fused = None
+    if not args.no_fused:
+        size = capi.fused_size(n_sub, n_con)
+        buf = torch.zeros(size, dtype=torch.float64, device="cuda")
+
+        def fused_step():
+            batch.evaluate_normal(poses, to_host=False)
+            batch.assemble(n_sub, buf.data_ptr(), zero_first=True)
+            if world > 1:
+                dist.all_reduce(buf)
+
+        for _ in range(2):
+            fused_step()
+        torch.cuda.synchronize()
+        barrier()
+        f0 = time.perf_counter()
+        for _ in range(args.steps):
+            fused_step()
+        torch.cuda.synchronize()
+        barrier()
+        fdt = torch.tensor([time.perf_counter() - f0], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(fdt, op=dist.ReduceOp.MAX)
+        fdt = float(fdt.item())
+        fused = {"value": total_evals * args.steps / fdt / 1e6, "unit": "Mresiduals+Jacobians/s",
+                 "ms_per_step": fdt / args.steps * 1e3,
+                 "algorithmic_GBs": total_evals * args.steps * BYTES_PER_EVAL_FUSED / fdt / 1e9,
+                 "allreduce_bytes": int(size * 8) if world > 1 else 0,
+                 "cost": float(buf[0].item()),
+                 "cost_vs_materialised": None}
+        if world == 1:
+            fused["cost_vs_materialised"] = abs(fused["cost"] - checksum) / max(checksum, 1e-30)
+
+    out = None
+    if rank == 0:
+        value = total_evals * args.steps / dt / 1e6
+        # roofline of the dominant kernel (reg_eval_points_kernel<16,float,4>) on rank 0
+        bytes_contract = R * BYTES_PER_EVAL
+        bytes_conservative = with_corr * BYTES_PER_EVAL + (R - with_corr) * BYTES_NO_CORR
+        achieved = bytes_contract / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            t = json.load(open(tpath))
+            if t.get("residuals_per_launch") == R and t.get("n_gpus") == world:
+                traffic = t.get("hbm_bytes_per_launch")
+        out = {
+            "metric": "Mresiduals+Jacobians/s per GPU; full pose-graph solve ms (200 submaps)",
+            "value": value, "unit": "Mresiduals+Jacobians/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"configs[2]: synthetic {n_sub} submaps @ "
+                                   f"{args.block_dims[0] * 16}x{args.block_dims[1] * 16}x{args.block_dims[2] * 16} voxels "
+                                   f"({args.voxel_size} m), {n_con} overlap constraints, kVoxels points, "
+                                   "all points (sampling_ratio -1), residual + both Jacobians",
+                       "submaps": n_sub, "constraints": n_con,
+                       "residuals_per_step": int(total_evals),
+                       "parallelism": f"pair-sharded x{world} (LPT), submaps replicated",
+                       "point_order": "extraction" if args.keep_order else "extraction (block, linear index)"},
+            "value_per_gpu": value / world,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "reg_eval_points_kernel<16,float,4>",
+                         "kernel_ms": kernel_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
+                         "bytes_per_unit": BYTES_PER_EVAL, "units_per_launch": int(R),
+                         "achieved_conservative": bytes_conservative / (kernel_ms * 1e-3) / 1e9,
+                         "with_correspondence_frac": with_corr / max(R, 1)},
+            "fused": fused,
+            "setup_s": setup_s,
+            "residual_checksum": checksum,
+        }
+    # CPU baseline: rank 0, N = 1 only (bounded sample)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(capi, ctx, args, true_poses, poses, pairs,
+                                           args.cpu_seconds)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -126,8 +126,29 @@ VGX_API int vgx_submap_point_order(vgx_submap submap, int32_t point_type,
 VGX_API int vgx_submap_download_points(vgx_submap submap, int32_t point_type,
                                        float* xyz, float* distance,
                                        float* weight);
+/* Copy the raw voxel layers back ([n_blocks][vps^3] each, any pointer may be
+ * NULL) and the block index list ([n_blocks][3]). */
+VGX_API int vgx_submap_download_layers(vgx_submap submap, float* tsdf_distance,
+                                       float* tsdf_weight, float* esdf_distance,
+                                       uint8_t* esdf_observed);
+VGX_API int vgx_submap_block_index(vgx_submap submap, int32_t* block_index);
 /* Drop the raw voxel layers after extraction (keeps the sampling grids). */
 VGX_API int vgx_submap_release_raw_layers(vgx_submap submap);
+
+/* Benchmark tooling (not part of the reference's interface): fills a dense
+ * block_dims[0..2] cube of blocks starting at block_min with the analytic
+ * "city" scene of oracle/synth.py (ground plane + one box building per 25.6 m
+ * cell, seeded), sampled at the submap's true pose {x,y,z,yaw}, entirely on the
+ * device: TSDF = clamp(d, +-truncation) with weight tsdf_weight where
+ * |d| <= 2*truncation else 0; ESDF = clamp(d, +-esdf_max), observed iff
+ * |d| <= esdf_max.  Builds the ESDF sampling grid (and the TSDF one when
+ * build_tsdf_grid != 0). */
+VGX_API int vgx_synth_city_submap(vgx_ctx ctx, int32_t submap_id, float voxel_size,
+                                  int32_t voxels_per_side, const int32_t block_min[3],
+                                  const int32_t block_dims[3], float truncation,
+                                  float esdf_max, float tsdf_weight,
+                                  const double true_pose[4], uint32_t seed,
+                                  int32_t build_tsdf_grid, vgx_submap* out);
 
 /* ---- REG: one registration constraint ---------------------------------- */
 /* RegistrationCostFunction::Config (registration_cost_function.h:17-41).

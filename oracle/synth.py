@@ -160,7 +160,7 @@ def make_submap(sdf, voxel_size, vps, block_min, block_dims, trunc, pose=(0, 0, 
         rng = np.random.default_rng(seed)
         d = (d + rng.normal(0, noise * voxel_size, d.shape).astype(F)).astype(F)
     tsdf_d = np.clip(d, -F(trunc), F(trunc)).astype(F)
-    tsdf_w = np.where(np.abs(d) <= F(2 * trunc), F(tsdf_weight), F(0)).astype(F)
+    tsdf_w = np.where(np.abs(d) <= F(2) * F(trunc), F(tsdf_weight), F(0)).astype(F)
     esdf_d = np.clip(d, -F(esdf_max), F(esdf_max)).astype(F)
     esdf_o = (np.abs(d) <= F(esdf_max)).astype(np.uint8)
     if drop_empty_blocks:

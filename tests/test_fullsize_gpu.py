@@ -1,0 +1,124 @@
+"""Parity at BASELINE's full size (256^3-voxel submap pairs, config 3 scene):
+size-independent properties plus an oracle check on a random subset of rows."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as orc
+from oracle import synth
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+VS, VPS, TRUNC, ESDF_MAX, SEED = 0.2, 16, 0.6, 2.0, 2
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from voxgraph_amd import capi
+    capi.load()
+    return capi
+
+
+@pytest.fixture(scope="module")
+def ctx(capi):
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def test_device_scene_generator_matches_numpy(capi, ctx):
+    """The bench's on-device city scene == oracle/synth.py, bit for bit (so the
+    CPU oracle and the GPU path can be fed identical grids)."""
+    pose = np.array([12.3, -7.1, 0.4, 0.23])
+    bmin, bdim = (-3, -2, -1), (5, 4, 3)
+    sm = capi.Submap.synth_city(ctx, 0, VS, VPS, bmin, bdim, TRUNC, ESDF_MAX, 10.0, pose, SEED)
+    td, tw, ed, eo = sm.download_layers(VPS)
+    ref = synth.make_submap(synth.city_sdf(SEED), VS, VPS, bmin, bdim, TRUNC, pose, ESDF_MAX)
+    assert np.array_equal(sm.block_index(), ref.block_index)
+    assert np.array_equal(td, ref.tsdf_distance)
+    assert np.array_equal(tw, ref.tsdf_weight)
+    assert np.array_equal(ed, ref.esdf_distance)
+    assert np.array_equal(eo, ref.esdf_observed)
+    assert 0.05 < (tw > 0).mean() < 0.9 and ed.min() < -1.0      # buildings + ground present
+    sm.destroy()
+
+
+@pytest.fixture(scope="module")
+def pair256(capi, ctx):
+    bmin, bdim = (-8, -8, -4), (16, 16, 16)                      # 256^3 voxels, 51.2 m cube
+    poses_true = np.array([[0.0, 0.0, 0.0, 0.05], [25.6, 17.0, 0.0, -0.08]])
+    subs = [capi.Submap.synth_city(ctx, k, VS, VPS, bmin, bdim, TRUNC, ESDF_MAX, 10.0,
+                                   poses_true[k], SEED) for k in range(2)]
+    n = [s.extract_voxel_points(1.0, 0.3, True) for s in subs]
+    assert min(n) > 200_000, n
+    # host copies for the oracle: reading submap 1's ESDF layer, submap 0's points
+    _, _, ed, eo = subs[1].download_layers(VPS)
+    layer = orc.Layer(VS, VPS, subs[1].block_index(), ed, eo)
+    pts = subs[0].download_points(capi.POINTS_VOXELS)
+    for s in subs:
+        s.release_raw_layers()
+    cfg = capi.default_config(registration_point_type=capi.POINTS_VOXELS)
+    cfs = [capi.RegistrationCostFunction(ctx, subs[0], subs[1], cfg),
+           capi.RegistrationCostFunction(ctx, subs[1], subs[0], cfg),
+           capi.RegistrationCostFunction(ctx, subs[0], subs[0], cfg)]
+    yield dict(subs=subs, cfs=cfs, layer=layer, pts=pts, poses_true=poses_true, n=n)
+    for o in cfs + subs:
+        o.destroy()
+
+
+def test_fullsize_subset_matches_oracle(capi, ctx, pair256):
+    P = pair256
+    rng = np.random.default_rng(0)
+    poses = P["poses_true"] + np.array([[0.21, -0.17, 0.08, 0.03], [-0.1, 0.25, -0.05, -0.04]])
+    cf = P["cfs"][0]
+    n = cf.num_residuals()
+    r = np.zeros(n)
+    jo = np.zeros((n, 4))
+    je = np.zeros((n, 4))
+    assert cf.Evaluate([poses[0], poses[1]], r, [jo, je])
+    xyz, dist, w = P["pts"]
+    pick = np.sort(rng.choice(n, 30000, replace=False))
+    # the normalisation factor N / sum(w) uses ALL points: all weights are 10 here
+    ok, r0, jo0, je0 = orc.reg_evaluate(P["layer"], xyz[pick], dist[pick], w[pick], poses[0], poses[1])
+    assert ok and np.all(w == 10.0)
+    corr = np.any(jo0 != 0, axis=1)
+    assert 0.1 < corr.mean() < 0.9                       # partial overlap, both branches taken
+    H.assert_parity(r[pick], r0, "residual")
+    H.assert_parity(jo[pick], jo0, "jac_ref")
+    H.assert_parity(je[pick], je0, "jac_read")
+
+
+def test_fullsize_properties(capi, ctx, pair256):
+    import torch
+    P = pair256
+    poses = np.vstack([P["poses_true"] + np.array([[0.2, 0.1, -0.1, 0.02], [0.0, -0.2, 0.1, -0.03]]),
+                       [[3.0, -2.0, 0.5, 0.4]]])
+    batch = capi.RegistrationBatch(ctx, P["cfs"], [(0, 1), (1, 0), (2, 2)])
+    ro = batch.row_offsets()
+    R = int(ro[-1])
+    r = torch.full((R,), float("nan"), dtype=torch.float32, device="cuda:0")
+    jo = torch.full((R, 4), float("nan"), dtype=torch.float32, device="cuda:0")
+    je = torch.full((R, 4), float("nan"), dtype=torch.float32, device="cuda:0")
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    assert np.all(batch.evaluate_points(poses, r.data_ptr(), jo.data_ptr(), je.data_ptr()) == 0)
+    status, normal = batch.evaluate_normal(poses)
+    torch.cuda.synchronize()
+    assert not torch.isnan(r).any() and not torch.isnan(jo).any() and not torch.isnan(je).any()
+    # (1) a submap registered to itself at one pose: every residual exactly 0
+    self_rows = slice(int(ro[2]), int(ro[3]))
+    assert torch.count_nonzero(r[self_rows]).item() == 0
+    assert normal[2, 0] == 0.0 and np.all(normal[2, 1:9] == 0.0)
+    # (2) J_read[:, :3] == -J_ref[:, :3] row by row (M_read[:, :3] = -M_ref[:, :3])
+    assert torch.equal(je[:, :3], -jo[:, :3])
+    # (3) checksum of checksums: the fused kernel's normal equations equal the
+    #     sums over the materialised rows (two independent kernels)
+    for c in range(2):
+        s = slice(int(ro[c]), int(ro[c + 1]))
+        rc, J = r[s].double(), torch.cat([jo[s], je[s]], dim=1).double()
+        cost, jtr, jtj = float(rc @ rc), (J.T @ rc).cpu().numpy(), (J.T @ J).cpu().numpy()
+        assert abs(normal[c, 0] - cost) <= 2e-6 * cost
+        assert np.all(np.abs(normal[c, 1:9] - jtr) <= 2e-6 * np.abs(jtr).max())
+        assert np.all(np.abs(normal[c, 9:] - jtj[np.triu_indices(8)]) <= 2e-6 * np.abs(jtj).max())
+    ctx.set_stream(None)
+    batch.destroy()

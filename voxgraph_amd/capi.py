@@ -59,6 +59,11 @@ SIGNATURES = {
     "vgx_submap_point_order": (C.c_int, [vp, C.c_int32, i64p]),
     "vgx_submap_download_points": (C.c_int, [vp, C.c_int32, f32p, f32p, f32p]),
     "vgx_submap_release_raw_layers": (C.c_int, [vp]),
+    "vgx_submap_download_layers": (C.c_int, [vp, f32p, f32p, f32p, u8p]),
+    "vgx_submap_block_index": (C.c_int, [vp, i32p]),
+    "vgx_synth_city_submap": (C.c_int, [vp, C.c_int32, C.c_float, C.c_int32, i32p, i32p, C.c_float,
+                                        C.c_float, C.c_float, f64p, C.c_uint32, C.c_int32,
+                                        C.POINTER(vp)]),
     "vgx_reg_config_default": (None, [C.POINTER(RegConfig)]),
     "vgx_reg_create": (C.c_int, [vp, vp, vp, C.POINTER(RegConfig), C.POINTER(vp)]),
     "vgx_reg_destroy": (C.c_int, [vp]),
@@ -79,6 +84,23 @@ SIGNATURES = {
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch wheels bundle their own libamdhip64.so.7 / libhsa-runtime64; two HIP
+    runtimes in one process cannot both open the GPU.  If torch is installed, load
+    ITS runtime first (RTLD_GLOBAL): libvoxgraph_amd.so's DT_NEEDED libamdhip64.so.7
+    then resolves to the same copy by SONAME, and a later `import torch` reuses it."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load():
     """dlopen libvoxgraph_amd.so and bind every declared symbol (loud on failure)."""
     global _lib
@@ -87,6 +109,7 @@ def load():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        _share_hip_runtime_with_torch()
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)     # AttributeError if the symbol is not exported
@@ -162,6 +185,41 @@ class Submap:
                                             _ptr(bi, i32p), _ptr(td, f32p), _ptr(tw, f32p),
                                             _ptr(ed, f32p), _ptr(eo, u8p), C.byref(h)))
         self.h = h
+
+    @classmethod
+    def synth_city(cls, ctx, submap_id, voxel_size, vps, block_min, block_dims, truncation,
+                   esdf_max, tsdf_weight, true_pose, seed, build_tsdf_grid=False):
+        """Benchmark tooling: analytic city scene generated on the device."""
+        self = cls.__new__(cls)
+        self.ctx = ctx
+        bmin = np.ascontiguousarray(block_min, np.int32)
+        bdim = np.ascontiguousarray(block_dims, np.int32)
+        pose = _f64(true_pose)
+        h = vp()
+        ctx.check(ctx.lib.vgx_synth_city_submap(
+            ctx.h, submap_id, float(voxel_size), vps, _ptr(bmin, i32p), _ptr(bdim, i32p),
+            float(truncation), float(esdf_max), float(tsdf_weight), _ptr(pose, f64p), seed,
+            int(build_tsdf_grid), C.byref(h)))
+        self.h = h
+        return self
+
+    def num_blocks(self):
+        return self.ctx.lib.vgx_submap_num_blocks(self.h)
+
+    def block_index(self):
+        bi = np.zeros((self.num_blocks(), 3), np.int32)
+        self.ctx.check(self.ctx.lib.vgx_submap_block_index(self.h, _ptr(bi, i32p)))
+        return bi
+
+    def download_layers(self, vps):
+        n = self.num_blocks()
+        td = np.zeros((n, vps ** 3), np.float32)
+        tw = np.zeros((n, vps ** 3), np.float32)
+        ed = np.zeros((n, vps ** 3), np.float32)
+        eo = np.zeros((n, vps ** 3), np.uint8)
+        self.ctx.check(self.ctx.lib.vgx_submap_download_layers(
+            self.h, _ptr(td, f32p), _ptr(tw, f32p), _ptr(ed, f32p), _ptr(eo, u8p)))
+        return td, tw, ed, eo
 
     def set_points(self, point_type, xyz, distance, weight, flags=POINTS_KEEP_ORDER):
         xyz = _f32(xyz).reshape(-1, 3)

@@ -91,6 +91,41 @@ int launch_brickify(vgx_submap sm, int which) {
   return VGX_OK;
 }
 
+// Dense block lookup table over the AABB of sm->block_index (host copy), uploaded
+// to sm->d_lut.  Stands in for voxblox's unordered_map<BlockIndex, Block::Ptr>.
+int build_block_lut(vgx_submap sm) {
+  vgx_ctx ctx = sm->ctx;
+  const int n_blocks = sm->n_blocks;
+  const int32_t* block_index = sm->block_index.data();
+  int32_t mn[3] = {0, 0, 0}, mx[3] = {-1, -1, -1};
+  for (int b = 0; b < n_blocks; ++b)
+    for (int a = 0; a < 3; ++a) {
+      int32_t v = block_index[3 * b + a];
+      if (b == 0 || v < mn[a]) mn[a] = v;
+      if (b == 0 || v > mx[a]) mx[a] = v;
+    }
+  size_t total = 1;
+  for (int a = 0; a < 3; ++a) {
+    sm->lut_min[a] = mn[a];
+    sm->lut_dim[a] = mx[a] - mn[a] + 1;
+    total *= (size_t)sm->lut_dim[a];
+    if (total > ((size_t)1 << 28))
+      return set_error(ctx, VGX_ERR_UNSUPPORTED,
+                       "submap block AABB exceeds 2^28 cells (dense lookup table)");
+  }
+  if (n_blocks == 0) return VGX_OK;
+  std::vector<int32_t> lut(total, -1);
+  for (int b = 0; b < n_blocks; ++b) {
+    size_t ix = (size_t)(block_index[3 * b + 0] - mn[0]);
+    size_t iy = (size_t)(block_index[3 * b + 1] - mn[1]);
+    size_t iz = (size_t)(block_index[3 * b + 2] - mn[2]);
+    lut[ix + (size_t)sm->lut_dim[0] * (iy + (size_t)sm->lut_dim[1] * iz)] = b;
+  }
+  VGX_HIP(ctx, hipMalloc(&sm->d_lut, total * sizeof(int32_t)));
+  VGX_HIP(ctx, hipMemcpy(sm->d_lut, lut.data(), total * sizeof(int32_t), hipMemcpyHostToDevice));
+  return VGX_OK;
+}
+
 }  // namespace vgx
 
 using namespace vgx;
@@ -239,43 +274,16 @@ int vgx_submap_create(vgx_ctx ctx, int32_t submap_id, float voxel_size, int32_t 
   sm->block_size_inv = 1.0f / sm->block_size;
   sm->block_index.assign(block_index, block_index + 3 * (size_t)n_blocks);
 
-  // dense block lookup table over the AABB of the allocated blocks
-  int32_t mn[3] = {0, 0, 0}, mx[3] = {-1, -1, -1};
-  for (int b = 0; b < n_blocks; ++b)
-    for (int a = 0; a < 3; ++a) {
-      int32_t v = block_index[3 * b + a];
-      if (b == 0 || v < mn[a]) mn[a] = v;
-      if (b == 0 || v > mx[a]) mx[a] = v;
-    }
-  size_t total = 1;
-  for (int a = 0; a < 3; ++a) {
-    sm->lut_min[a] = mn[a];
-    sm->lut_dim[a] = mx[a] - mn[a] + 1;
-    total *= (size_t)sm->lut_dim[a];
-    if (total > ((size_t)1 << 28)) {
-      delete sm;
-      return set_error(ctx, VGX_ERR_UNSUPPORTED,
-                       "vgx_submap_create: block AABB exceeds 2^28 cells (dense lookup table)");
-    }
-  }
-  int rc = VGX_OK;
-  if (n_blocks > 0) {
-    std::vector<int32_t> lut(total, -1);
-    for (int b = 0; b < n_blocks; ++b) {
-      size_t ix = (size_t)(block_index[3 * b + 0] - mn[0]);
-      size_t iy = (size_t)(block_index[3 * b + 1] - mn[1]);
-      size_t iz = (size_t)(block_index[3 * b + 2] - mn[2]);
-      lut[ix + (size_t)sm->lut_dim[0] * (iy + (size_t)sm->lut_dim[1] * iz)] = b;
-    }
+  int rc = build_block_lut(sm);
+  if (rc == VGX_OK && n_blocks > 0) {
     const size_t nvox = (size_t)n_blocks * vps * vps * vps;
-    rc = upload(ctx, lut.data(), total * sizeof(int32_t), (void**)&sm->d_lut);
-    if (rc == VGX_OK) rc = upload(ctx, block_index, 3 * (size_t)n_blocks * sizeof(int32_t), (void**)&sm->d_block_index);
+    rc = upload(ctx, block_index, 3 * (size_t)n_blocks * sizeof(int32_t), (void**)&sm->d_block_index);
     if (rc == VGX_OK) rc = upload(ctx, tsdf_distance, nvox * sizeof(float), (void**)&sm->d_tsdf_distance);
     if (rc == VGX_OK) rc = upload(ctx, tsdf_weight, nvox * sizeof(float), (void**)&sm->d_tsdf_weight);
     if (rc == VGX_OK) rc = upload(ctx, esdf_distance, nvox * sizeof(float), (void**)&sm->d_esdf_distance);
     if (rc == VGX_OK) rc = upload(ctx, esdf_observed, nvox * sizeof(uint8_t), (void**)&sm->d_esdf_observed);
-    // the H2D copies above read pageable host memory: finish them before `lut`
-    // and the caller's arrays go away
+    // the H2D copies above read pageable host memory: finish them before the
+    // caller's arrays go away
     if (rc == VGX_OK && hipStreamSynchronize(ctx->stream) != hipSuccess)
       rc = set_error(ctx, VGX_ERR_HIP, "vgx_submap_create: H2D upload failed");
     if (rc == VGX_OK && sm->d_tsdf_distance) rc = launch_brickify(sm, 0);
@@ -304,6 +312,32 @@ int vgx_submap_release_raw_layers(vgx_submap sm) {
   if (sm->d_esdf_observed) (void)hipFree(sm->d_esdf_observed);
   sm->d_tsdf_distance = sm->d_tsdf_weight = sm->d_esdf_distance = nullptr;
   sm->d_esdf_observed = nullptr;
+  return VGX_OK;
+}
+
+int vgx_submap_download_layers(vgx_submap sm, float* tsdf_distance, float* tsdf_weight,
+                               float* esdf_distance, uint8_t* esdf_observed) {
+  if (!sm) return VGX_ERR_INVALID;
+  vgx_ctx ctx = sm->ctx;
+  VGX_HIP(ctx, hipSetDevice(ctx->device));
+  VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const size_t nvox = (size_t)sm->n_blocks * sm->vps * sm->vps * sm->vps;
+  struct { void* dst; const void* src; size_t bytes; } jobs[4] = {
+      {tsdf_distance, sm->d_tsdf_distance, nvox * sizeof(float)},
+      {tsdf_weight, sm->d_tsdf_weight, nvox * sizeof(float)},
+      {esdf_distance, sm->d_esdf_distance, nvox * sizeof(float)},
+      {esdf_observed, sm->d_esdf_observed, nvox * sizeof(uint8_t)}};
+  for (auto& j : jobs) {
+    if (!j.dst) continue;
+    if (!j.src) return set_error(ctx, VGX_ERR_INVALID, "vgx_submap_download_layers: layer not resident");
+    if (j.bytes) VGX_HIP(ctx, hipMemcpy(j.dst, j.src, j.bytes, hipMemcpyDeviceToHost));
+  }
+  return VGX_OK;
+}
+
+int vgx_submap_block_index(vgx_submap sm, int32_t* block_index) {
+  if (!sm || !block_index) return VGX_ERR_INVALID;
+  std::copy(sm->block_index.begin(), sm->block_index.end(), block_index);
   return VGX_OK;
 }
 

@@ -186,6 +186,7 @@ void set_global_error(const std::string& msg);
 
 // kernels' launch wrappers implemented in the .hip files
 int launch_brickify(vgx_submap sm, int which);
+int build_block_lut(vgx_submap sm);
 void make_pose_pack(const double ref_pose[4], const double read_pose[4], PosePack* out);
 std::vector<Tile> make_tiles(int32_t constraint, int64_t n, int tile_points);
 constexpr int kBlockThreads = 256;

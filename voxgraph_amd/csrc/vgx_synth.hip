@@ -1,0 +1,159 @@
+// Benchmark tooling: the analytic "city" scene of oracle/synth.py, generated on
+// the device so that BASELINE config 3 (200 submaps @ 256^3 = 3.4 G voxels) is
+// practical.  Bit-for-bit mirror of synth.city_sdf / synth.make_submap (checked
+// in tests/test_synth_scene.py).  Not part of the reference's interface.
+#include <cmath>
+
+#include "vgx_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace vgx {
+
+__device__ __forceinline__ uint32_t fmix(uint32_t h) {
+  h ^= h >> 16;
+  h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h;
+}
+
+__device__ __forceinline__ float city_uniform(int ci, int cj, uint32_t seed, uint32_t k) {
+  uint32_t h = ((uint32_t)ci * 73856093u) ^ ((uint32_t)cj * 19349663u) ^ (seed * 83492791u);
+  h = fmix(h + k * 0x9E3779B9u);
+  return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+
+__device__ float city_sdf(float x, float y, float z, uint32_t seed) {
+  const float CELL = 25.6f;
+  int ci0 = (int)floorf(x / CELL), cj0 = (int)floorf(y / CELL);
+  float d = z;
+  for (int di = -1; di <= 1; ++di)
+    for (int dj = -1; dj <= 1; ++dj) {
+      int ci = ci0 + di, cj = cj0 + dj;
+      float u0 = city_uniform(ci, cj, seed, 0), u1 = city_uniform(ci, cj, seed, 1);
+      float u2 = city_uniform(ci, cj, seed, 2), u3 = city_uniform(ci, cj, seed, 3);
+      float u4 = city_uniform(ci, cj, seed, 4);
+      float cx = ((float)ci + 0.5f) * CELL + (u0 - 0.5f) * 6.0f;
+      float cy = ((float)cj + 0.5f) * CELL + (u1 - 0.5f) * 6.0f;
+      float hx = 4.0f + 5.0f * u2, hy = 4.0f + 5.0f * u3;
+      float top = 6.0f + 24.0f * u4;
+      float cz = (top - 10.0f) * 0.5f, hz = (top + 10.0f) * 0.5f;
+      float qx = fabsf(x - cx) - hx, qy = fabsf(y - cy) - hy, qz = fabsf(z - cz) - hz;
+      float ox = fmaxf(qx, 0.0f), oy = fmaxf(qy, 0.0f), oz = fmaxf(qz, 0.0f);
+      float outside = sqrtf(ox * ox + oy * oy + oz * oz);
+      float inside = fminf(fmaxf(qx, fmaxf(qy, qz)), 0.0f);
+      d = fminf(d, outside + inside);
+    }
+  return d;
+}
+
+template <int VPS>
+__global__ __launch_bounds__(256) void synth_city_kernel(
+    const int32_t* __restrict__ block_index, float voxel_size, float block_size, float cos_yaw,
+    float sin_yaw, float tx, float ty, float tz, float trunc, float two_trunc, float esdf_max,
+    float weight, uint32_t seed, float* __restrict__ tsdf_d, float* __restrict__ tsdf_w,
+    float* __restrict__ esdf_d, uint8_t* __restrict__ esdf_obs) {
+  constexpr int VOX = VPS * VPS * VPS;
+  const int b = blockIdx.x;
+  const float ox = (float)block_index[3 * b + 0] * block_size;
+  const float oy = (float)block_index[3 * b + 1] * block_size;
+  const float oz = (float)block_index[3 * b + 2] * block_size;
+  for (int v = threadIdx.x; v < VOX; v += 256) {
+    int ix = v % VPS, iy = (v / VPS) % VPS, iz = v / (VPS * VPS);
+    float px = ox + ((float)ix + 0.5f) * voxel_size;
+    float py = oy + ((float)iy + 0.5f) * voxel_size;
+    float pz = oz + ((float)iz + 0.5f) * voxel_size;
+    float wx = (cos_yaw * px - sin_yaw * py) + tx;
+    float wy = (sin_yaw * px + cos_yaw * py) + ty;
+    float wz = pz + tz;
+    float d = city_sdf(wx, wy, wz, seed);
+    size_t at = (size_t)b * VOX + v;
+    tsdf_d[at] = fminf(fmaxf(d, -trunc), trunc);
+    tsdf_w[at] = fabsf(d) <= two_trunc ? weight : 0.0f;
+    esdf_d[at] = fminf(fmaxf(d, -esdf_max), esdf_max);
+    esdf_obs[at] = fabsf(d) <= esdf_max ? 1 : 0;
+  }
+}
+
+}  // namespace vgx
+
+using namespace vgx;
+
+extern "C" int vgx_synth_city_submap(vgx_ctx ctx, int32_t submap_id, float voxel_size, int32_t vps,
+                                     const int32_t block_min[3], const int32_t block_dims[3],
+                                     float truncation, float esdf_max, float tsdf_weight,
+                                     const double true_pose[4], uint32_t seed,
+                                     int32_t build_tsdf_grid, vgx_submap* out) {
+  if (!ctx || !out || !block_min || !block_dims || !true_pose) return VGX_ERR_INVALID;
+  *out = nullptr;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (vps != 16 && vps != 8)
+    return set_error(ctx, VGX_ERR_UNSUPPORTED, "vgx_synth_city_submap: voxels_per_side must be 8 or 16");
+  int64_t nb64 = (int64_t)block_dims[0] * block_dims[1] * block_dims[2];
+  if (!(voxel_size > 0) || block_dims[0] <= 0 || block_dims[1] <= 0 || block_dims[2] <= 0 || nb64 > (1 << 24))
+    return set_error(ctx, VGX_ERR_INVALID, "vgx_synth_city_submap: bad geometry");
+  VGX_HIP(ctx, hipSetDevice(ctx->device));
+  vgx_submap sm = new (std::nothrow) vgx_submap_s();
+  if (!sm) return set_error(ctx, VGX_ERR_NOMEM, "vgx_synth_city_submap: out of host memory");
+  const int nb = (int)nb64;
+  sm->ctx = ctx;
+  sm->id = submap_id;
+  sm->vps = vps;
+  sm->n_blocks = nb;
+  sm->voxel_size = voxel_size;
+  sm->voxel_size_inv = 1.0f / voxel_size;
+  sm->block_size = (float)vps * voxel_size;
+  sm->block_size_inv = 1.0f / sm->block_size;
+  // same block order as synth.dense_block_index: x slowest, z fastest
+  sm->block_index.resize(3 * (size_t)nb);
+  size_t k = 0;
+  for (int x = 0; x < block_dims[0]; ++x)
+    for (int y = 0; y < block_dims[1]; ++y)
+      for (int z = 0; z < block_dims[2]; ++z) {
+        sm->block_index[k++] = block_min[0] + x;
+        sm->block_index[k++] = block_min[1] + y;
+        sm->block_index[k++] = block_min[2] + z;
+      }
+  int rc = build_block_lut(sm);
+  const size_t nvox = (size_t)nb * vps * vps * vps;
+  if (rc == VGX_OK) {
+    if (hipMalloc(&sm->d_block_index, 3 * (size_t)nb * sizeof(int32_t)) != hipSuccess ||
+        hipMalloc(&sm->d_tsdf_distance, nvox * sizeof(float)) != hipSuccess ||
+        hipMalloc(&sm->d_tsdf_weight, nvox * sizeof(float)) != hipSuccess ||
+        hipMalloc(&sm->d_esdf_distance, nvox * sizeof(float)) != hipSuccess ||
+        hipMalloc(&sm->d_esdf_observed, nvox * sizeof(uint8_t)) != hipSuccess)
+      rc = set_error(ctx, VGX_ERR_NOMEM, "vgx_synth_city_submap: device allocation failed");
+  }
+  if (rc == VGX_OK &&
+      hipMemcpy(sm->d_block_index, sm->block_index.data(), 3 * (size_t)nb * sizeof(int32_t),
+                hipMemcpyHostToDevice) != hipSuccess)
+    rc = set_error(ctx, VGX_ERR_HIP, "vgx_synth_city_submap: block index upload failed");
+  if (rc == VGX_OK) {
+    // synth.pose_apply: F(cos(yaw)), F(sin(yaw)) from double trig
+    float c = (float)std::cos(true_pose[3]), s = (float)std::sin(true_pose[3]);
+    float two_trunc = 2.0f * truncation;
+    if (vps == 16)
+      hipLaunchKernelGGL(synth_city_kernel<16>, dim3(nb), dim3(256), 0, ctx->stream,
+                         sm->d_block_index, sm->voxel_size, sm->block_size, c, s,
+                         (float)true_pose[0], (float)true_pose[1], (float)true_pose[2], truncation,
+                         two_trunc, esdf_max, tsdf_weight, seed, sm->d_tsdf_distance,
+                         sm->d_tsdf_weight, sm->d_esdf_distance, sm->d_esdf_observed);
+    else
+      hipLaunchKernelGGL(synth_city_kernel<8>, dim3(nb), dim3(256), 0, ctx->stream,
+                         sm->d_block_index, sm->voxel_size, sm->block_size, c, s,
+                         (float)true_pose[0], (float)true_pose[1], (float)true_pose[2], truncation,
+                         two_trunc, esdf_max, tsdf_weight, seed, sm->d_tsdf_distance,
+                         sm->d_tsdf_weight, sm->d_esdf_distance, sm->d_esdf_observed);
+    if (hipGetLastError() != hipSuccess) rc = set_error(ctx, VGX_ERR_HIP, "vgx_synth_city_submap: launch failed");
+  }
+  if (rc == VGX_OK && build_tsdf_grid) rc = launch_brickify(sm, 0);
+  if (rc == VGX_OK) rc = launch_brickify(sm, 1);
+  if (rc != VGX_OK) {
+    vgx_submap_destroy(sm);
+    return rc;
+  }
+  *out = sm;
+  return VGX_OK;
+}
