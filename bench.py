@@ -155,7 +155,10 @@ def main():
             dist.barrier()
 
     ctx = capi.Context(local_rank)
-    stream = torch.cuda.current_stream()
+    # one explicit (non-null) stream shared by the HIP library, torch ops and RCCL,
+    # so kernel -> all-reduce ordering is by stream order, not by host syncs
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
 
     true_poses, poses, pairs = build_graph(args)

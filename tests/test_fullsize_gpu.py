@@ -100,7 +100,7 @@ def test_fullsize_properties(capi, ctx, pair256):
     r = torch.full((R,), float("nan"), dtype=torch.float32, device="cuda:0")
     jo = torch.full((R, 4), float("nan"), dtype=torch.float32, device="cuda:0")
     je = torch.full((R, 4), float("nan"), dtype=torch.float32, device="cuda:0")
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
     assert np.all(batch.evaluate_points(poses, r.data_ptr(), jo.data_ptr(), je.data_ptr()) == 0)
     status, normal = batch.evaluate_normal(poses)
     torch.cuda.synchronize()
@@ -120,5 +120,4 @@ def test_fullsize_properties(capi, ctx, pair256):
         assert abs(normal[c, 0] - cost) <= 2e-6 * cost
         assert np.all(np.abs(normal[c, 1:9] - jtr) <= 2e-6 * np.abs(jtr).max())
         assert np.all(np.abs(normal[c, 9:] - jtj[np.triu_indices(8)]) <= 2e-6 * np.abs(jtj).max())
-    ctx.set_stream(None)
     batch.destroy()
