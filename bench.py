@@ -132,6 +132,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused", action="store_true")
+    ap.add_argument("--no-solve", action="store_true")
     ap.add_argument("--keep-order", action="store_true", help="extraction order instead of Morton")
     ap.add_argument("--calibrate", action="store_true",
                     help="PMC calibration: first launch evaluates poses 10 km apart, so every "
@@ -258,6 +259,37 @@ def main():
         if world == 1:
             fused["cost_vs_materialised"] = abs(fused["cost"] - checksum) / max(checksum, 1e-30)
 
+    # ---- metric 2: full pose-graph solve (harness LM, stand-in for ceres::Solve) ---
+    solve = None
+    if not args.no_solve:
+        from harness import lm
+        from harness.backends import GpuBackend
+        info = [1.0, 1.0, 2500.0, 2500.0]                       # voxgraph_mapper.yaml:41-47
+        edges = [lm.RelativePoseEdge.from_poses(k, k + 1, poses[k], poses[k + 1], info)
+                 for k in range(n_sub - 1)]
+        backend = GpuBackend(capi, ctx, batch, n_sub, dist if world > 1 else None)
+        backend(poses)                                           # warm
+        torch.cuda.synchronize()
+        barrier()
+        s0 = time.perf_counter()
+        prob = lm.Problem(backend, n_sub, pairs, edges)
+        x, summ = lm.solve(prob, poses)                          # parameter_tolerance 3e-3
+        torch.cuda.synchronize()
+        barrier()
+        sdt = torch.tensor([time.perf_counter() - s0], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(sdt, op=dist.ReduceOp.MAX)
+
+        def rmse(p):
+            # gauge: submap 0 is fixed at its true pose
+            return float(np.sqrt(((p[:, :3] - true_poses[:, :3]) ** 2).sum(1).mean()))
+        solve = {"ms": float(sdt.item()) * 1e3, "iterations": summ["iterations"],
+                 "evaluations": summ["evaluations"], "termination": summ["termination"],
+                 "initial_cost": summ["initial_cost"], "final_cost": summ["final_cost"],
+                 "position_rmse_m_before": rmse(poses), "position_rmse_m_after": rmse(x),
+                 "solver": "harness/lm.py (LM, dense normal equations on the host; Ceres absent)",
+                 "stop_rule": "parameter_tolerance 3e-3 (pose_graph.cpp:93)"}
+
     out = None
     if rank == 0:
         value = total_evals * args.steps / dt / 1e6
@@ -301,6 +333,7 @@ def main():
                          "traffic_GBs": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None,
                          "with_correspondence_frac": with_corr / max(R, 1)},
             "fused": fused,
+            "solve": solve,
             "setup_s": setup_s,
             "residual_checksum": checksum,
         }

@@ -1,0 +1,164 @@
+"""Levenberg-Marquardt over 4-DoF (x, y, z, yaw) submap poses.
+
+Mirrors what the reference asks of Ceres (voxgraph/src/backend/pose_graph.cpp:85-106):
+trust-region LM, no robust loss (constraint.h:34), first submap constant
+(pose_graph_interface.cpp:30-32), yaw wrapped to [-pi, pi)
+(local_parameterization/normalize_angle.h:11-16), stop on
+parameter_tolerance = 3e-3 (pose_graph.cpp:93) with Ceres' other default
+tolerances.  Relative-pose (odometry / loop-closure) edges restate
+relative_pose_cost_function_inl.h:8-70 with analytic Jacobians.
+
+A "backend" evaluates every registration constraint at the given poses and
+returns the fused normal-equation buffer of SURVEY.md 8e:
+    [cost, J^T r (4 n), diag 4x4 blocks of J^T J (16 n), off-diag blocks (16 m)]
+"""
+import time
+
+import numpy as np
+
+
+def normalize_angle(a):
+    two_pi = 2.0 * np.pi
+    return a - two_pi * np.floor((a + np.pi) / two_pi)
+
+
+class RelativePoseEdge:
+    """RelativePoseCostFunction: residual = sqrt_info * [R(yaw_A)^T (t_B - t_A) - t_obs,
+    normalize(yaw_B - yaw_A - yaw_obs)]."""
+
+    def __init__(self, a, b, t_obs, yaw_obs, information_diag):
+        self.a, self.b = int(a), int(b)
+        self.t_obs = np.asarray(t_obs, np.float64)
+        self.yaw_obs = float(yaw_obs)
+        self.sqrt_info = np.sqrt(np.asarray(information_diag, np.float64))
+
+    @staticmethod
+    def from_poses(a, b, pose_a, pose_b, information_diag):
+        c, s = np.cos(pose_a[3]), np.sin(pose_a[3])
+        d = pose_b[:3] - pose_a[:3]
+        t = np.array([c * d[0] + s * d[1], -s * d[0] + c * d[1], d[2]])
+        return RelativePoseEdge(a, b, t, normalize_angle(pose_b[3] - pose_a[3]), information_diag)
+
+    def evaluate(self, poses):
+        pa, pb = poses[self.a], poses[self.b]
+        c, s = np.cos(pa[3]), np.sin(pa[3])
+        d = pb[:3] - pa[:3]
+        r = np.array([c * d[0] + s * d[1] - self.t_obs[0], -s * d[0] + c * d[1] - self.t_obs[1],
+                      d[2] - self.t_obs[2], normalize_angle(pb[3] - pa[3] - self.yaw_obs)])
+        Ja = np.zeros((4, 4))
+        Jb = np.zeros((4, 4))
+        Rt = np.array([[c, s, 0.0], [-s, c, 0.0], [0.0, 0.0, 1.0]])
+        Ja[:3, :3] = -Rt
+        Jb[:3, :3] = Rt
+        Ja[0, 3] = -s * d[0] + c * d[1]
+        Ja[1, 3] = -c * d[0] - s * d[1]
+        Ja[3, 3] = -1.0
+        Jb[3, 3] = 1.0
+        w = self.sqrt_info
+        return r * w, Ja * w[:, None], Jb * w[:, None]
+
+
+def unpack_fused(buf, n_nodes, pairs):
+    """fused buffer -> (cost, g [4n], H [4n,4n])."""
+    n = n_nodes
+    cost = float(buf[0])
+    g = np.array(buf[1:1 + 4 * n])
+    H = np.zeros((4 * n, 4 * n))
+    diag = buf[1 + 4 * n:1 + 20 * n].reshape(n, 4, 4)
+    for i in range(n):
+        H[4 * i:4 * i + 4, 4 * i:4 * i + 4] = diag[i]
+    off = buf[1 + 20 * n:].reshape(-1, 4, 4)
+    for c, (a, b) in enumerate(pairs):
+        H[4 * a:4 * a + 4, 4 * b:4 * b + 4] += off[c]
+        H[4 * b:4 * b + 4, 4 * a:4 * a + 4] += off[c].T
+    return cost, g, H
+
+
+class Problem:
+    def __init__(self, backend, n_nodes, pairs, edges=(), constant_nodes=(0,)):
+        self.backend = backend
+        self.n = n_nodes
+        self.pairs = [(int(a), int(b)) for a, b in pairs]
+        self.edges = list(edges)
+        free = np.ones(4 * n_nodes, bool)
+        for k in constant_nodes:
+            free[4 * k:4 * k + 4] = False
+        self.free = np.where(free)[0]
+        self.evaluations = 0
+
+    def evaluate(self, poses):
+        """0.5 * sum r^2, gradient J^T r, Gauss-Newton Hessian J^T J (registration + edges)."""
+        buf = self.backend(poses)
+        self.evaluations += 1
+        cost, g, H = unpack_fused(buf, self.n, self.pairs)
+        for e in self.edges:
+            r, Ja, Jb = e.evaluate(poses)
+            cost += float(r @ r)
+            ia, ib = slice(4 * e.a, 4 * e.a + 4), slice(4 * e.b, 4 * e.b + 4)
+            g[ia] += Ja.T @ r
+            g[ib] += Jb.T @ r
+            H[ia, ia] += Ja.T @ Ja
+            H[ib, ib] += Jb.T @ Jb
+            H[ia, ib] += Ja.T @ Jb
+            H[ib, ia] += Jb.T @ Ja
+        return 0.5 * cost, g, H
+
+
+def solve(problem, poses0, parameter_tolerance=3e-3, function_tolerance=1e-6,
+          gradient_tolerance=1e-10, max_iterations=50, max_seconds=4.0,
+          initial_radius=1e4, verbose=False):
+    """Returns (poses, summary).  Ceres-style LM: (H + D^2/radius) step, gain-ratio
+    acceptance, radius update radius / max(1/3, 1 - (2 rho - 1)^3)."""
+    t0 = time.perf_counter()
+    x = np.array(poses0, np.float64).copy()
+    f = problem.free
+    cost, g, H = problem.evaluate(x)
+    radius, decrease = float(initial_radius), 2.0
+    it, reason = 0, "max_iterations"
+    history = [cost]
+    while it < max_iterations:
+        it += 1
+        gf, Hf = g[f], H[np.ix_(f, f)]
+        if np.abs(gf).max() <= gradient_tolerance:
+            reason = "gradient_tolerance"
+            break
+        d2 = np.clip(np.diag(Hf), 1e-6, 1e32)
+        A = Hf + np.diag(d2 / radius)
+        try:
+            step = -np.linalg.solve(A, gf)
+        except np.linalg.LinAlgError:
+            radius /= decrease
+            decrease *= 2
+            continue
+        xf = x.ravel()[f]
+        if np.linalg.norm(step) <= parameter_tolerance * (np.linalg.norm(xf) + parameter_tolerance):
+            reason = "parameter_tolerance"
+            break
+        cand = x.copy().ravel()
+        cand[f] += step
+        cand = cand.reshape(-1, 4)
+        cand[:, 3] = normalize_angle(cand[:, 3])
+        new_cost, new_g, new_H = problem.evaluate(cand)
+        model_decrease = -(gf @ step + 0.5 * step @ (Hf @ step))
+        rho = (cost - new_cost) / model_decrease if model_decrease > 0 else -1.0
+        if verbose:
+            print(f"  it {it}: cost {cost:.6e} -> {new_cost:.6e} rho {rho:.3f} radius {radius:.2e} "
+                  f"|step| {np.linalg.norm(step):.3e}")
+        if rho > 1e-3:
+            rel = abs(cost - new_cost) / max(cost, 1e-300)
+            x, cost, g, H = cand, new_cost, new_g, new_H
+            history.append(cost)
+            radius = min(radius / max(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3), 1e16)
+            decrease = 2.0
+            if rel <= function_tolerance:
+                reason = "function_tolerance"
+                break
+        else:
+            radius /= decrease
+            decrease *= 2.0
+        if time.perf_counter() - t0 > max_seconds:
+            reason = "max_solver_time"
+            break
+    return x, {"iterations": it, "evaluations": problem.evaluations, "termination": reason,
+               "final_cost": cost, "initial_cost": history[0],
+               "seconds": time.perf_counter() - t0}

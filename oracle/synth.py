@@ -172,12 +172,33 @@ def make_submap(sdf, voxel_size, vps, block_min, block_dims, trunc, pose=(0, 0, 
                       np.ascontiguousarray(esdf_d), np.ascontiguousarray(esdf_o), pose)
 
 
-def config1_pair(seed=0):
+def union_sdf(*fs):
+    def f(p):
+        d = fs[0](p)
+        for g in fs[1:]:
+            d = np.minimum(d, g(p))
+        return d.astype(F)
+    return f
+
+
+def sphere_sdf(centre, radius):
+    c = np.asarray(centre, F)
+
+    def f(p):
+        return (np.sqrt(((p - c) ** 2).sum(-1, dtype=F)).astype(F) - F(radius)).astype(F)
+    return f
+
+
+def config1_pair(seed=0, asymmetric=False):
     """BASELINE config 1: two 64^3 submaps (4x4x4 blocks of 16^3, 0.10 m voxels),
     sphere r=2 m centred in the cube + ground plane, trunc 0.3 m, weight 10.
     The reading submap is a duplicate of the reference (test-bench design,
     registration_test_bench.cpp:178-185)."""
     vs, vps = 0.10, 16
     sdf = sphere_ground_sdf((3.2, 3.2, 3.2), 2.0, 0.45)
+    if asymmetric:
+        # sphere + plane is symmetric about the sphere's vertical axis (yaw about it is
+        # unobservable); a second, smaller sphere makes the known-answer solve well posed
+        sdf = union_sdf(sdf, sphere_sdf((1.3, 4.7, 1.2), 0.9))
     ref = make_submap(sdf, vs, vps, (0, 0, 0), (4, 4, 4), trunc=0.3, seed=seed)
     return ref, ref

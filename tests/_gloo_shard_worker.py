@@ -1,0 +1,52 @@
+"""world_size-2 gloo worker for tests/test_harness_cpu.py (CPU only)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import lpt_shards  # noqa: E402
+from harness.backends import assemble_fused  # noqa: E402
+from oracle import pyoracle as orc  # noqa: E402
+from oracle import synth  # noqa: E402
+from tests import helpers as H  # noqa: E402
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    sdf = synth.sphere_ground_sdf((1.6, 1.6, 1.2), 1.0, 0.35)
+    true = [(0, 0, 0, 0), (0.8, 0.1, 0.0, 0.1), (0.1, 0.9, 0.05, -0.15), (0.9, 0.8, 0.0, 0.2)]
+    layers, pts = [], []
+    for p in true:
+        sm = synth.make_submap(sdf, 0.1, 16, (0, 0, 0), (2, 2, 2), 0.3, p, 1.0, drop_empty_blocks=True)
+        layers.append(H.oracle_layer(sm))
+        pts.append(H.oracle_points(sm))
+    pairs = [(0, 1), (1, 0), (0, 2), (1, 3), (2, 3), (0, 3)]
+    poses = np.array(true, np.float64) + np.random.default_rng(3).normal(0, 0.02, (4, 4))
+
+    def normal(c):
+        a, b = pairs[c]
+        ok, cost, jtr, jtj = orc.reg_evaluate_normal(layers[b], *pts[a], poses[a], poses[b])
+        return np.concatenate([[cost], jtr, jtj])
+
+    shards = lpt_shards([len(pts[a][2]) for a, _ in pairs], world)
+    assert sorted(sum(shards, [])) == list(range(len(pairs)))
+    mine = shards[rank]
+    buf = assemble_fused([normal(c) for c in mine], [pairs[c] for c in mine], 4,
+                         n_global=len(pairs), global_index=mine)
+    t = torch.from_numpy(buf)
+    dist.all_reduce(t)
+    full = assemble_fused([normal(c) for c in range(len(pairs))], pairs, 4)
+    np.testing.assert_allclose(t.numpy(), full, rtol=1e-12, atol=1e-12)
+    dist.barrier()
+    if rank == 0:
+        print("SHARD_ALLREDUCE_OK")
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,87 @@
+"""CPU tests of the harness solver and of the N>1 path's host logic (gloo, world 2)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from harness import lm
+from harness.backends import OracleBackend, assemble_fused
+from oracle import pyoracle as orc
+from oracle import synth
+from tests import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_relative_pose_edge_jacobians_by_central_differences():
+    """relative_pose_cost_function_inl.h:8-70 restated with analytic Jacobians."""
+    rng = np.random.default_rng(0)
+    poses = rng.normal(0, 1, (2, 4))
+    e = lm.RelativePoseEdge(0, 1, rng.normal(0, 1, 3), 0.3, [1.0, 1.0, 2500.0, 2500.0])
+    r, Ja, Jb = e.evaluate(poses)
+    for blk, J in ((0, Ja), (1, Jb)):
+        for k in range(4):
+            p = poses.copy(); p[blk, k] += 1e-6
+            m = poses.copy(); m[blk, k] -= 1e-6
+            num = (e.evaluate(p)[0] - e.evaluate(m)[0]) / 2e-6
+            np.testing.assert_allclose(J[:, k], num, rtol=1e-5, atol=1e-5)
+    e2 = lm.RelativePoseEdge.from_poses(0, 1, poses[0], poses[1], [1, 1, 1, 1])
+    assert np.abs(e2.evaluate(poses)[0]).max() < 1e-12
+    assert -np.pi <= lm.normalize_angle(7.0) < np.pi
+
+
+def _config1_problem():
+    sm, _ = synth.config1_pair(asymmetric=True)
+    layer = H.oracle_layer(sm)
+    pts = H.oracle_points(sm)
+    return OracleBackend([layer, layer], [pts, pts], [(0, 1)], 2, threads=1)
+
+
+def test_known_answer_registration_recovers_duplicate_submap():
+    """The reference's test-bench design (registration_test_bench.cpp:178-185,298-319):
+    a duplicated submap perturbed on the yaml's grid must come back to the unperturbed
+    pose.  CPU oracle backend, tight tolerances, < 1 mm / 0.01 deg."""
+    backend = _config1_problem()
+    grid = H.test_bench_grid(0.1)
+    for pert in (grid[0], grid[13 + 27], grid[-1], np.array([0.15, -0.3, 0.15, 0.1])):
+        poses0 = np.array([[0.0, 0, 0, 0], pert])
+        prob = lm.Problem(backend, 2, [(0, 1)])
+        x, s = lm.solve(prob, poses0, parameter_tolerance=1e-9, function_tolerance=1e-14,
+                        max_iterations=60, max_seconds=60)
+        assert np.abs(x[1, :3]).max() < 1e-3, (pert, x[1], s)
+        assert abs(x[1, 3]) < np.deg2rad(0.01), (pert, x[1], s)
+        assert s["final_cost"] <= 1e-6 * s["initial_cost"]
+
+
+def test_assemble_fused_layout_matches_dense_normal_equations():
+    rng = np.random.default_rng(1)
+    pairs = [(0, 1), (1, 2), (0, 2)]
+    normals, Jall = [], []
+    for _ in pairs:
+        J = rng.normal(0, 1, (50, 8)); r = rng.normal(0, 1, 50)
+        Hm = J.T @ J
+        normals.append(np.concatenate([[r @ r], J.T @ r, Hm[np.triu_indices(8)]]))
+        Jall.append((J, r))
+    cost, g, Hd = lm.unpack_fused(assemble_fused(normals, pairs, 3), 3, pairs)
+    Jd = np.zeros((150, 12)); rd = np.zeros(150)
+    for c, ((a, b), (J, r)) in enumerate(zip(pairs, Jall)):
+        Jd[50 * c:50 * c + 50, 4 * a:4 * a + 4] = J[:, :4]
+        Jd[50 * c:50 * c + 50, 4 * b:4 * b + 4] = J[:, 4:]
+        rd[50 * c:50 * c + 50] = r
+    np.testing.assert_allclose(cost, rd @ rd)
+    np.testing.assert_allclose(g, Jd.T @ rd, atol=1e-12)
+    np.testing.assert_allclose(Hd, Jd.T @ Jd, atol=1e-12)
+
+
+def test_pair_sharding_allreduce_world2_gloo():
+    """N > 1 host logic on CPU: two gloo ranks each assemble their LPT shard of the
+    constraints (per-constraint normals from the CPU oracle standing in for the
+    kernel), all-reduce the fused buffer, and must reproduce the unsharded one."""
+    script = os.path.join(ROOT, "tests", "_gloo_shard_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                          "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port",
+                          "29517", script], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "SHARD_ALLREDUCE_OK" in out.stdout
