@@ -18,6 +18,8 @@ class GpuBackend:
         self.batch.assemble(self.n_nodes, self.buf.data_ptr(), zero_first=True)
         if self.dist is not None and self.dist.is_initialized() and self.dist.get_world_size() > 1:
             self.dist.all_reduce(self.buf)
+        # the library may run on its own stream: order the copy after its kernels
+        self.ctx.synchronize()
         self.host.copy_(self.buf, non_blocking=True)
         self.torch.cuda.current_stream().synchronize()
         return self.host.numpy()

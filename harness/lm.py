@@ -59,7 +59,8 @@ class RelativePoseEdge:
 
 
 def unpack_fused(buf, n_nodes, pairs):
-    """fused buffer -> (cost, g [4n], H [4n,4n])."""
+    """fused buffer -> (cost, g [4n], H [4n,4n]).  Reference implementation; Problem
+    uses precomputed scatter indices for the same layout."""
     n = n_nodes
     cost = float(buf[0])
     g = np.array(buf[1:1 + 4 * n])
@@ -74,6 +75,14 @@ def unpack_fused(buf, n_nodes, pairs):
     return cost, g, H
 
 
+def _block_index(rows, cols):
+    """flat indices of the 4x4 blocks (rows[i], cols[i]) in a [4n,4n] matrix -> [m,4,4] r, c"""
+    k = np.arange(4)
+    r = (4 * np.asarray(rows)[:, None, None] + k[None, :, None]) + 0 * k[None, None, :]
+    c = (4 * np.asarray(cols)[:, None, None] + k[None, None, :]) + 0 * k[None, :, None]
+    return r, c
+
+
 class Problem:
     def __init__(self, backend, n_nodes, pairs, edges=(), constant_nodes=(0,)):
         self.backend = backend
@@ -85,23 +94,70 @@ class Problem:
             free[4 * k:4 * k + 4] = False
         self.free = np.where(free)[0]
         self.evaluations = 0
+        n = n_nodes
+        pa = np.array([p[0] for p in self.pairs], np.int64).reshape(-1)
+        pb = np.array([p[1] for p in self.pairs], np.int64).reshape(-1)
+        self._diag_rc = _block_index(np.arange(n), np.arange(n))
+        self._off_rc = _block_index(pa, pb)
+        if self.edges:
+            self._ea = np.array([e.a for e in self.edges])
+            self._eb = np.array([e.b for e in self.edges])
+            self._et = np.array([e.t_obs for e in self.edges])
+            self._eyaw = np.array([e.yaw_obs for e in self.edges])
+            self._ew = np.array([e.sqrt_info for e in self.edges])
+            self._e_aa = _block_index(self._ea, self._ea)
+            self._e_bb = _block_index(self._eb, self._eb)
+            self._e_ab = _block_index(self._ea, self._eb)
+
+    def _edges(self, poses, g, H):
+        """all RelativePoseEdge residuals / Jacobians at once (same arithmetic as
+        RelativePoseEdge.evaluate)"""
+        pa, pb = poses[self._ea], poses[self._eb]
+        c, s = np.cos(pa[:, 3]), np.sin(pa[:, 3])
+        d = pb[:, :3] - pa[:, :3]
+        E = len(self._ea)
+        r = np.stack([c * d[:, 0] + s * d[:, 1] - self._et[:, 0],
+                      -s * d[:, 0] + c * d[:, 1] - self._et[:, 1],
+                      d[:, 2] - self._et[:, 2],
+                      normalize_angle(pb[:, 3] - pa[:, 3] - self._eyaw)], 1) * self._ew
+        Jb = np.zeros((E, 4, 4))
+        Jb[:, 0, 0], Jb[:, 0, 1], Jb[:, 1, 0], Jb[:, 1, 1], Jb[:, 2, 2], Jb[:, 3, 3] = c, s, -s, c, 1, 1
+        Ja = -Jb.copy()
+        Ja[:, 0, 3] = -s * d[:, 0] + c * d[:, 1]
+        Ja[:, 1, 3] = -c * d[:, 0] - s * d[:, 1]
+        Ja *= self._ew[:, :, None]
+        Jb *= self._ew[:, :, None]
+        np.add.at(g.reshape(-1, 4), self._ea, np.einsum("eji,ej->ei", Ja, r))
+        np.add.at(g.reshape(-1, 4), self._eb, np.einsum("eji,ej->ei", Jb, r))
+        np.add.at(H, self._e_aa, np.einsum("eki,ekj->eij", Ja, Ja))
+        np.add.at(H, self._e_bb, np.einsum("eki,ekj->eij", Jb, Jb))
+        ab = np.einsum("eki,ekj->eij", Ja, Jb)
+        np.add.at(H, self._e_ab, ab)
+        np.add.at(H, (self._e_ab[1].transpose(0, 2, 1), self._e_ab[0].transpose(0, 2, 1)),
+                  ab.transpose(0, 2, 1))
+        return float((r * r).sum())
 
     def evaluate(self, poses):
         """0.5 * sum r^2, gradient J^T r, Gauss-Newton Hessian J^T J (registration + edges)."""
-        buf = self.backend(poses)
+        buf = np.asarray(self.backend(poses))
         self.evaluations += 1
-        cost, g, H = unpack_fused(buf, self.n, self.pairs)
-        for e in self.edges:
-            r, Ja, Jb = e.evaluate(poses)
-            cost += float(r @ r)
-            ia, ib = slice(4 * e.a, 4 * e.a + 4), slice(4 * e.b, 4 * e.b + 4)
-            g[ia] += Ja.T @ r
-            g[ib] += Jb.T @ r
-            H[ia, ia] += Ja.T @ Ja
-            H[ib, ib] += Jb.T @ Jb
-            H[ia, ib] += Ja.T @ Jb
-            H[ib, ia] += Jb.T @ Ja
+        n = self.n
+        cost = float(buf[0])
+        g = np.array(buf[1:1 + 4 * n])
+        H = np.zeros((4 * n, 4 * n))
+        H[self._diag_rc] = buf[1 + 4 * n:1 + 20 * n].reshape(n, 4, 4)
+        off = buf[1 + 20 * n:1 + 20 * n + 16 * len(self.pairs)].reshape(-1, 4, 4)
+        np.add.at(H, self._off_rc, off)
+        np.add.at(H, (self._off_rc[1].transpose(0, 2, 1), self._off_rc[0].transpose(0, 2, 1)),
+                  off.transpose(0, 2, 1))
+        if self.edges:
+            cost += self._edges(poses, g, H)
         return 0.5 * cost, g, H
+
+
+def _spd_solve(A, b):
+    from scipy.linalg import cho_factor, cho_solve
+    return cho_solve(cho_factor(A, lower=True, check_finite=False), b, check_finite=False)
 
 
 def solve(problem, poses0, parameter_tolerance=3e-3, function_tolerance=1e-6,
@@ -125,7 +181,7 @@ def solve(problem, poses0, parameter_tolerance=3e-3, function_tolerance=1e-6,
         d2 = np.clip(np.diag(Hf), 1e-6, 1e32)
         A = Hf + np.diag(d2 / radius)
         try:
-            step = -np.linalg.solve(A, gf)
+            step = -_spd_solve(A, gf)
         except np.linalg.LinAlgError:
             radius /= decrease
             decrease *= 2

@@ -85,3 +85,31 @@ def test_pair_sharding_allreduce_world2_gloo():
                           "29517", script], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "SHARD_ALLREDUCE_OK" in out.stdout
+
+
+def test_vectorised_problem_matches_reference_assembly():
+    """Problem.evaluate (scatter indices, batched edges) == unpack_fused + per-edge loop."""
+    rng = np.random.default_rng(7)
+    n, pairs = 5, [(0, 1), (1, 0), (1, 2), (3, 4), (0, 4), (2, 3)]
+    normals = []
+    for _ in pairs:
+        J = rng.normal(0, 1, (30, 8)); r = rng.normal(0, 1, 30)
+        normals.append(np.concatenate([[r @ r], J.T @ r, (J.T @ J)[np.triu_indices(8)]]))
+    buf = assemble_fused(normals, pairs, n)
+    poses = rng.normal(0, 2, (n, 4))
+    edges = [lm.RelativePoseEdge(k, k + 1, rng.normal(0, 1, 3), rng.normal(0, 0.5),
+                                 [1.0, 1.0, 2500.0, 2500.0]) for k in range(n - 1)]
+    prob = lm.Problem(lambda p: buf, n, pairs, edges)
+    cost, g, Hm = prob.evaluate(poses)
+    c0, g0, H0 = lm.unpack_fused(buf, n, pairs)
+    for e in edges:
+        r, Ja, Jb = e.evaluate(poses)
+        c0 += r @ r
+        ia, ib = slice(4 * e.a, 4 * e.a + 4), slice(4 * e.b, 4 * e.b + 4)
+        g0[ia] += Ja.T @ r; g0[ib] += Jb.T @ r
+        H0[ia, ia] += Ja.T @ Ja; H0[ib, ib] += Jb.T @ Jb
+        H0[ia, ib] += Ja.T @ Jb; H0[ib, ia] += Jb.T @ Ja
+    np.testing.assert_allclose(cost, 0.5 * c0, rtol=1e-12)
+    np.testing.assert_allclose(g, g0, rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(Hm, H0, rtol=1e-10, atol=1e-10)
+    assert np.allclose(Hm, Hm.T)
