@@ -237,3 +237,113 @@ def find_relevant_voxels(voxel_size, vps, block_index, tsdf_distance, tsdf_weigh
     lib().orc_find_relevant_voxels(*args, _p(xyz, c_f32p), _p(dist, c_f32p),
                                    _p(weight, c_f32p))
     return xyz, dist, weight
+
+
+# ----------------------------------------------------------------------------
+# TSDF path (oracle/tsdf_oracle.c)
+# ----------------------------------------------------------------------------
+class TsdfConfig(C.Structure):
+    """voxblox::TsdfIntegratorBase::Config [recalled]; same field order as orc_tsdf_config
+    and vgx_tsdf_config."""
+    _fields_ = [("default_truncation_distance", C.c_float), ("max_weight", C.c_float),
+                ("voxel_carving_enabled", C.c_int), ("min_ray_length_m", C.c_float),
+                ("max_ray_length_m", C.c_float), ("use_const_weight", C.c_int),
+                ("allow_clear", C.c_int), ("use_weight_dropoff", C.c_int),
+                ("use_sparsity_compensation_factor", C.c_int),
+                ("sparsity_compensation_factor", C.c_float),
+                ("start_voxel_subsampling_factor", C.c_float),
+                ("max_consecutive_ray_collisions", C.c_int),
+                ("clear_checks_every_n_frames", C.c_int), ("integration_order_mixed", C.c_int)]
+
+
+_tsdf_bound = False
+
+
+def _tsdf_lib():
+    global _tsdf_bound
+    L = lib()
+    if not _tsdf_bound:
+        L.orc_tsdf_config_default.argtypes = [C.POINTER(TsdfConfig)]
+        L.orc_tsdf_layer_create.argtypes = [C.c_float, C.c_int]
+        L.orc_tsdf_layer_create.restype = C.c_void_p
+        L.orc_tsdf_layer_destroy.argtypes = [C.c_void_p]
+        L.orc_tsdf_layer_num_blocks.argtypes = [C.c_void_p]
+        L.orc_tsdf_layer_num_blocks.restype = C.c_int
+        L.orc_tsdf_layer_download.argtypes = [C.c_void_p, c_i32p, c_f32p, c_f32p, c_u8p]
+        L.orc_tsdf_integrator_create.argtypes = [C.POINTER(TsdfConfig), C.c_void_p]
+        L.orc_tsdf_integrator_create.restype = C.c_void_p
+        L.orc_tsdf_integrator_destroy.argtypes = [C.c_void_p]
+        L.orc_tsdf_integrator_set_layer.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_tsdf_integrate.argtypes = [C.c_void_p, c_f32p, c_f32p, c_u8p, C.c_int64, C.c_int]
+        L.orc_tsdf_integrate.restype = C.c_int64
+        _tsdf_bound = True
+    return L
+
+
+def tsdf_config(**kw):
+    cfg = TsdfConfig()
+    _tsdf_lib().orc_tsdf_config_default(C.byref(cfg))
+    for k, v in kw.items():
+        if not hasattr(cfg, k):
+            raise AttributeError(k)
+        setattr(cfg, k, v)
+    return cfg
+
+
+def voxgraph_tsdf_config(**kw):
+    """voxgraph/config/voxgraph_mapper.yaml:21-28 over voxblox's defaults."""
+    base = dict(default_truncation_distance=0.60, max_ray_length_m=16.0, use_const_weight=1,
+                use_weight_dropoff=1, use_sparsity_compensation_factor=1,
+                sparsity_compensation_factor=20.0)
+    base.update(kw)
+    return tsdf_config(**base)
+
+
+class TsdfLayer:
+    def __init__(self, voxel_size, vps=16):
+        self.voxel_size, self.vps = float(np.float32(voxel_size)), vps
+        self.h = _tsdf_lib().orc_tsdf_layer_create(self.voxel_size, vps)
+
+    def num_blocks(self):
+        return _tsdf_lib().orc_tsdf_layer_num_blocks(self.h)
+
+    def download(self):
+        n, nv = self.num_blocks(), self.vps ** 3
+        bi = np.zeros((n, 3), np.int32)
+        d = np.zeros((n, nv), np.float32)
+        w = np.zeros((n, nv), np.float32)
+        rgba = np.zeros((n, nv, 4), np.uint8)
+        _tsdf_lib().orc_tsdf_layer_download(self.h, _p(bi, c_i32p), _p(d, c_f32p), _p(w, c_f32p),
+                                            _p(rgba, c_u8p))
+        return bi, d, w, rgba
+
+    def __del__(self):
+        try:
+            _tsdf_lib().orc_tsdf_layer_destroy(self.h)
+        except Exception:
+            pass
+
+
+class FastTsdfIntegrator:
+    """voxblox::FastTsdfIntegrator(config, layer) / setLayer / integratePointCloud."""
+
+    def __init__(self, config, layer):
+        self.config, self.layer = config, layer
+        self.h = _tsdf_lib().orc_tsdf_integrator_create(C.byref(config), layer.h)
+
+    def setLayer(self, layer):
+        self.layer = layer
+        _tsdf_lib().orc_tsdf_integrator_set_layer(self.h, layer.h)
+
+    def integratePointCloud(self, T_G_C, points_C, colors=None, freespace_points=False):
+        T = _f32(T_G_C)
+        pts = _f32(points_C).reshape(-1, 3)
+        col = None if colors is None else np.ascontiguousarray(colors, np.uint8).reshape(-1, 4)
+        return _tsdf_lib().orc_tsdf_integrate(self.h, _p(T, c_f32p), _p(pts, c_f32p),
+                                              _p(col, c_u8p), pts.shape[0], int(freespace_points))
+
+    def __del__(self):
+        try:
+            _tsdf_lib().orc_tsdf_integrator_destroy(self.h)
+        except Exception:
+            pass

@@ -1,0 +1,403 @@
+/*
+ * oracle/tsdf_oracle.c -- see tsdf_oracle.h.  TEST INFRASTRUCTURE, parity unpinned,
+ * everything [recalled] from voxblox (not vendored in /root/reference).
+ * Build with -ffp-contract=off.
+ */
+#include "tsdf_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+static const float kCoordinateEpsilon = 1e-6f; /* voxblox::kCoordinateEpsilon */
+static const float kFloatEpsilon = 1e-6f;      /* voxblox::kFloatEpsilon */
+static const float kEpsilon = 1e-6f;           /* voxblox::kEpsilon */
+
+void orc_tsdf_config_default(orc_tsdf_config* c) {
+  c->default_truncation_distance = 0.1f;
+  c->max_weight = 10000.0f;
+  c->voxel_carving_enabled = 1;
+  c->min_ray_length_m = 0.1f;
+  c->max_ray_length_m = 5.0f;
+  c->use_const_weight = 0;
+  c->allow_clear = 1;
+  c->use_weight_dropoff = 1;
+  c->use_sparsity_compensation_factor = 0;
+  c->sparsity_compensation_factor = 1.0f;
+  c->start_voxel_subsampling_factor = 2.0f;
+  c->max_consecutive_ray_collisions = 2;
+  c->clear_checks_every_n_frames = 1;
+  c->integration_order_mixed = 1;
+}
+
+/* ---- Layer<TsdfVoxel>: hash map BlockIndex -> block ---------------------- */
+struct orc_tsdf_layer {
+  float voxel_size, voxel_size_inv, block_size, block_size_inv;
+  int vps, vps_inv_shift;
+  size_t nvox;
+  int n_blocks, cap_blocks;
+  int32_t* block_index; /* [cap][3] */
+  float* distance;      /* [cap][nvox] */
+  float* weight;
+  uint8_t* rgba;        /* [cap][nvox][4] */
+  /* open addressing table of slots */
+  int32_t* table;
+  size_t table_size;
+};
+
+static size_t block_hash(int32_t x, int32_t y, int32_t z) {
+  /* voxblox AnyIndexHash: x + y*17191 + z*17191^2 */
+  return (size_t)((int64_t)x + (int64_t)y * 17191 + (int64_t)z * 17191 * 17191);
+}
+
+orc_tsdf_layer* orc_tsdf_layer_create(float voxel_size, int vps) {
+  orc_tsdf_layer* L = (orc_tsdf_layer*)calloc(1, sizeof(*L));
+  L->voxel_size = voxel_size;
+  L->voxel_size_inv = 1.0f / voxel_size;
+  L->vps = vps;
+  L->block_size = (float)vps * voxel_size;
+  L->block_size_inv = 1.0f / L->block_size;
+  L->nvox = (size_t)vps * vps * vps;
+  L->table_size = 1024;
+  L->table = (int32_t*)malloc(L->table_size * sizeof(int32_t));
+  for (size_t i = 0; i < L->table_size; ++i) L->table[i] = -1;
+  return L;
+}
+
+void orc_tsdf_layer_destroy(orc_tsdf_layer* L) {
+  if (!L) return;
+  free(L->block_index);
+  free(L->distance);
+  free(L->weight);
+  free(L->rgba);
+  free(L->table);
+  free(L);
+}
+
+int orc_tsdf_layer_num_blocks(const orc_tsdf_layer* L) { return L->n_blocks; }
+
+void orc_tsdf_layer_download(const orc_tsdf_layer* L, int32_t* block_index, float* distance,
+                             float* weight, uint8_t* rgba) {
+  size_t n = (size_t)L->n_blocks;
+  if (block_index) memcpy(block_index, L->block_index, n * 3 * sizeof(int32_t));
+  if (distance) memcpy(distance, L->distance, n * L->nvox * sizeof(float));
+  if (weight) memcpy(weight, L->weight, n * L->nvox * sizeof(float));
+  if (rgba) memcpy(rgba, L->rgba, n * L->nvox * 4);
+}
+
+static void table_insert(orc_tsdf_layer* L, int slot) {
+  const int32_t* b = &L->block_index[3 * slot];
+  size_t h = block_hash(b[0], b[1], b[2]) & (L->table_size - 1);
+  while (L->table[h] >= 0) h = (h + 1) & (L->table_size - 1);
+  L->table[h] = slot;
+}
+
+/* Layer::allocateBlockPtrByIndex: existing slot or a new zero-initialised block
+ * (TsdfVoxel{distance 0, weight 0, color 0}) */
+static int layer_get_or_allocate(orc_tsdf_layer* L, int32_t x, int32_t y, int32_t z) {
+  size_t h = block_hash(x, y, z) & (L->table_size - 1);
+  while (L->table[h] >= 0) {
+    const int32_t* b = &L->block_index[3 * L->table[h]];
+    if (b[0] == x && b[1] == y && b[2] == z) return L->table[h];
+    h = (h + 1) & (L->table_size - 1);
+  }
+  if (L->n_blocks == L->cap_blocks) {
+    int cap = L->cap_blocks ? 2 * L->cap_blocks : 64;
+    L->block_index = (int32_t*)realloc(L->block_index, (size_t)cap * 3 * sizeof(int32_t));
+    L->distance = (float*)realloc(L->distance, (size_t)cap * L->nvox * sizeof(float));
+    L->weight = (float*)realloc(L->weight, (size_t)cap * L->nvox * sizeof(float));
+    L->rgba = (uint8_t*)realloc(L->rgba, (size_t)cap * L->nvox * 4);
+    L->cap_blocks = cap;
+  }
+  int slot = L->n_blocks++;
+  L->block_index[3 * slot] = x;
+  L->block_index[3 * slot + 1] = y;
+  L->block_index[3 * slot + 2] = z;
+  memset(&L->distance[(size_t)slot * L->nvox], 0, L->nvox * sizeof(float));
+  memset(&L->weight[(size_t)slot * L->nvox], 0, L->nvox * sizeof(float));
+  memset(&L->rgba[(size_t)slot * L->nvox * 4], 0, L->nvox * 4);
+  if ((size_t)L->n_blocks * 2 > L->table_size) {
+    L->table_size *= 2;
+    L->table = (int32_t*)realloc(L->table, L->table_size * sizeof(int32_t));
+    for (size_t i = 0; i < L->table_size; ++i) L->table[i] = -1;
+    for (int s = 0; s < L->n_blocks; ++s) table_insert(L, s);
+  } else {
+    L->table[h] = slot;
+  }
+  return slot;
+}
+
+/* ---- ApproxHashSet<20, 10000, GlobalIndex, LongIndexHash> ---------------- */
+#define ORC_SET_BITS 20
+#define ORC_SET_SIZE (1u << ORC_SET_BITS)
+#define ORC_SET_MASK (ORC_SET_SIZE - 1u)
+#define ORC_FULL_RESET 10000u
+
+typedef struct {
+  uint64_t offset;
+  uint64_t* slots;
+} approx_set;
+
+static void approx_set_init(approx_set* s) {
+  s->offset = 0;
+  s->slots = (uint64_t*)calloc(ORC_SET_SIZE, sizeof(uint64_t));
+  /* the 0 hash would look present in every zeroed slot: poison its slot */
+  s->slots[s->offset & ORC_SET_MASK] = UINT64_MAX;
+}
+
+static void approx_set_reset(approx_set* s) {
+  if (++s->offset >= ORC_FULL_RESET) {
+    memset(s->slots, 0, ORC_SET_SIZE * sizeof(uint64_t));
+    s->offset = 0;
+    s->slots[s->offset & ORC_SET_MASK] = UINT64_MAX;
+  }
+}
+
+/* LongIndexHash: static_cast<unsigned int>(x + y*17191 + z*17191^2) on int64 */
+static uint64_t long_index_hash(const int64_t idx[3]) {
+  int64_t v = idx[0] + idx[1] * 17191 + idx[2] * (int64_t)(17191 * 17191);
+  return (uint64_t)(uint32_t)v;
+}
+
+/* replaceHash: true if the slot did NOT already hold this hash */
+static int approx_set_replace(approx_set* s, const int64_t idx[3]) {
+  uint64_t v = long_index_hash(idx) + s->offset;
+  uint64_t* slot = &s->slots[v & ORC_SET_MASK];
+  uint64_t old = *slot;
+  *slot = v;
+  return old != v;
+}
+
+/* ---- integrator ----------------------------------------------------------- */
+struct orc_tsdf_integrator {
+  orc_tsdf_config cfg;
+  orc_tsdf_layer* layer;
+  approx_set start_set, observed_set;
+  int64_t reset_counter; /* function-static in voxblox */
+};
+
+orc_tsdf_integrator* orc_tsdf_integrator_create(const orc_tsdf_config* cfg, orc_tsdf_layer* layer) {
+  orc_tsdf_integrator* I = (orc_tsdf_integrator*)calloc(1, sizeof(*I));
+  I->cfg = *cfg;
+  I->layer = layer;
+  approx_set_init(&I->start_set);
+  approx_set_init(&I->observed_set);
+  return I;
+}
+
+void orc_tsdf_integrator_destroy(orc_tsdf_integrator* I) {
+  if (!I) return;
+  free(I->start_set.slots);
+  free(I->observed_set.slots);
+  free(I);
+}
+
+void orc_tsdf_integrator_set_layer(orc_tsdf_integrator* I, orc_tsdf_layer* layer) {
+  I->layer = layer;
+}
+
+/* Eigen _transformVector + translation (kindr::minimal transform) */
+static void transform_point(const float T[7], const float v[3], float out[3]) {
+  float w = T[0], x = T[1], y = T[2], z = T[3];
+  float uv[3] = {y * v[2] - z * v[1], z * v[0] - x * v[2], x * v[1] - y * v[0]};
+  uv[0] += uv[0];
+  uv[1] += uv[1];
+  uv[2] += uv[2];
+  float c[3] = {y * uv[2] - z * uv[1], z * uv[0] - x * uv[2], x * uv[1] - y * uv[0]};
+  out[0] = (v[0] + w * uv[0] + c[0]) + T[4];
+  out[1] = (v[1] + w * uv[1] + c[1]) + T[5];
+  out[2] = (v[2] + w * uv[2] + c[2]) + T[6];
+}
+
+static float norm3(const float v[3]) { return sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
+
+static int signum(float x) { return (x > 0.0f) - (x < 0.0f); }
+
+/* updateTsdfVoxel + computeDistance + blendTwoColors */
+static void update_voxel(orc_tsdf_integrator* I, const float origin[3], const float point_G[3],
+                         const int64_t gidx[3], const uint8_t color[4], float weight,
+                         float* v_dist, float* v_weight, uint8_t* v_rgba) {
+  const orc_tsdf_config* c = &I->cfg;
+  const float vs = I->layer->voxel_size;
+  float voxel_center[3], v_voxel_origin[3], v_point_origin[3];
+  for (int a = 0; a < 3; ++a) {
+    /* getCenterPointFromGridIndex: (idx + 0.5) * grid_size, double product -> f32 */
+    voxel_center[a] = (float)(((double)(float)gidx[a] + 0.5) * (double)vs);
+    v_voxel_origin[a] = voxel_center[a] - origin[a];
+    v_point_origin[a] = point_G[a] - origin[a];
+  }
+  float dist_G = norm3(v_point_origin);
+  float dot = v_voxel_origin[0] * v_point_origin[0] + v_voxel_origin[1] * v_point_origin[1] +
+              v_voxel_origin[2] * v_point_origin[2];
+  float dist_G_V = dot / dist_G;
+  float sdf = dist_G - dist_G_V;
+
+  float updated_weight = weight;
+  const float dropoff_epsilon = vs;
+  if (c->use_weight_dropoff && sdf < -dropoff_epsilon) {
+    updated_weight = weight * (c->default_truncation_distance + sdf) /
+                     (c->default_truncation_distance - dropoff_epsilon);
+    updated_weight = fmaxf(updated_weight, 0.0f);
+  }
+  if (c->use_sparsity_compensation_factor) {
+    if (fabsf(sdf) < c->default_truncation_distance)
+      updated_weight *= c->sparsity_compensation_factor;
+  }
+  const float new_weight = *v_weight + updated_weight;
+  if (new_weight < kFloatEpsilon) return;
+  const float new_sdf = (sdf * updated_weight + *v_dist * *v_weight) / new_weight;
+  if (fabsf(sdf) < c->default_truncation_distance) {
+    float first_weight = *v_weight, second_weight = updated_weight;
+    float total = first_weight + second_weight;
+    first_weight /= total;
+    second_weight /= total;
+    for (int k = 0; k < 4; ++k)
+      v_rgba[k] = (uint8_t)roundf((float)v_rgba[k] * first_weight + (float)color[k] * second_weight);
+  }
+  *v_dist = (new_sdf > 0.0f) ? fminf(c->default_truncation_distance, new_sdf)
+                             : fmaxf(-c->default_truncation_distance, new_sdf);
+  *v_weight = fminf(c->max_weight, new_weight);
+}
+
+int64_t orc_tsdf_integrate(orc_tsdf_integrator* I, const float T_G_C[7], const float* points_C,
+                           const uint8_t* rgba, int64_t n, int freespace_points) {
+  const orc_tsdf_config* c = &I->cfg;
+  orc_tsdf_layer* L = I->layer;
+  const int vps = L->vps;
+  const float vsi = L->voxel_size_inv;
+  int64_t updates = 0;
+  static const uint8_t zero_color[4] = {0, 0, 0, 0};
+
+  if ((++I->reset_counter) >= c->clear_checks_every_n_frames) {
+    I->reset_counter = 0;
+    approx_set_reset(&I->start_set);
+    approx_set_reset(&I->observed_set);
+  }
+  /* MixedThreadSafeIndex: 1024-point groups visited round-robin, tail in order */
+  const int64_t step_size = 1024;
+  const int64_t number_of_groups = n / step_size;
+  const float origin[3] = {T_G_C[4], T_G_C[5], T_G_C[6]};
+
+  for (int64_t seq = 0; seq < n; ++seq) {
+    int64_t pi = seq;
+    if (c->integration_order_mixed && seq < number_of_groups * step_size) {
+      int64_t group_num = seq % number_of_groups;
+      int64_t position_in_group = seq / number_of_groups;
+      pi = group_num * step_size + position_in_group;
+    }
+    const float* point_C = &points_C[3 * pi];
+    const uint8_t* color = rgba ? &rgba[4 * pi] : zero_color;
+    /* isPointValid */
+    int is_clearing;
+    const float ray_distance = norm3(point_C);
+    if (ray_distance < c->min_ray_length_m) {
+      continue;
+    } else if (ray_distance > c->max_ray_length_m) {
+      if (c->allow_clear || freespace_points) is_clearing = 1; else continue;
+    } else {
+      is_clearing = freespace_points;
+    }
+    float point_G[3];
+    transform_point(T_G_C, point_C, point_G);
+    /* start-voxel dedup on a grid start_voxel_subsampling_factor times finer */
+    int64_t gidx[3];
+    const float sub_inv = c->start_voxel_subsampling_factor * vsi;
+    for (int a = 0; a < 3; ++a) gidx[a] = (int64_t)floorf(point_G[a] * sub_inv + kCoordinateEpsilon);
+    if (!approx_set_replace(&I->start_set, gidx)) continue;
+
+    /* RayCaster(origin, point_G, is_clearing, carving, max_ray, voxel_size_inv, trunc, false) */
+    float d[3] = {point_G[0] - origin[0], point_G[1] - origin[1], point_G[2] - origin[2]};
+    float len = norm3(d);
+    float unit_ray[3] = {d[0] / len, d[1] / len, d[2] / len};
+    float ray_start[3], ray_end[3];
+    const float trunc = c->default_truncation_distance;
+    if (is_clearing) {
+      float ray_length = fminf(fmaxf(len - trunc, 0.0f), c->max_ray_length_m);
+      for (int a = 0; a < 3; ++a) {
+        ray_end[a] = origin[a] + unit_ray[a] * ray_length;
+        ray_start[a] = c->voxel_carving_enabled ? origin[a] : ray_end[a];
+      }
+    } else {
+      for (int a = 0; a < 3; ++a) {
+        ray_end[a] = point_G[a] + unit_ray[a] * trunc;
+        ray_start[a] = c->voxel_carving_enabled ? origin[a] : (point_G[a] - unit_ray[a] * trunc);
+      }
+    }
+    /* cast_from_origin == false: setupRayCaster(end_scaled, start_scaled) */
+    float start_scaled[3], end_scaled[3];
+    for (int a = 0; a < 3; ++a) {
+      start_scaled[a] = ray_end[a] * vsi;
+      end_scaled[a] = ray_start[a] * vsi;
+    }
+    int64_t curr[3], ray_length_in_steps = 0;
+    int step_sign[3];
+    float t_to_next[3], t_step[3];
+    int bad = 0;
+    for (int a = 0; a < 3; ++a)
+      if (isnan(start_scaled[a]) || isnan(end_scaled[a])) bad = 1;
+    if (bad) continue;
+    for (int a = 0; a < 3; ++a) {
+      curr[a] = (int64_t)floorf(start_scaled[a] + kCoordinateEpsilon);
+      int64_t end_index = (int64_t)floorf(end_scaled[a] + kCoordinateEpsilon);
+      int64_t diff = end_index - curr[a];
+      ray_length_in_steps += diff < 0 ? -diff : diff;
+      float ray_scaled = end_scaled[a] - start_scaled[a];
+      step_sign[a] = signum(ray_scaled);
+      float corrected_step = (float)(step_sign[a] > 0 ? step_sign[a] : 0);
+      float start_scaled_shifted = start_scaled[a] - (float)curr[a];
+      float distance_to_boundary = corrected_step - start_scaled_shifted;
+      /* voxblox divides by ray_scaled unguarded; a component that is exactly 0
+       * never advances here (t = +inf) instead of producing NaN */
+      if (ray_scaled == 0.0f) {
+        t_to_next[a] = INFINITY;
+        t_step[a] = INFINITY;
+      } else {
+        t_to_next[a] = distance_to_boundary / ray_scaled;
+        t_step[a] = (float)step_sign[a] / ray_scaled;
+      }
+    }
+    int64_t consecutive_ray_collisions = 0;
+    for (int64_t current_step = 0; current_step <= ray_length_in_steps; ++current_step) {
+      int64_t v[3] = {curr[0], curr[1], curr[2]};
+      /* advance (minCoeff: first minimum) */
+      int t_min_idx = 0;
+      if (t_to_next[1] < t_to_next[t_min_idx]) t_min_idx = 1;
+      if (t_to_next[2] < t_to_next[t_min_idx]) t_min_idx = 2;
+      curr[t_min_idx] += step_sign[t_min_idx];
+      t_to_next[t_min_idx] += t_step[t_min_idx];
+
+      if (!approx_set_replace(&I->observed_set, v)) {
+        ++consecutive_ray_collisions;
+      } else {
+        consecutive_ray_collisions = 0;
+      }
+      if (consecutive_ray_collisions > c->max_consecutive_ray_collisions) break;
+      /* allocateStorageAndGetVoxelPtr: getBlockIndexFromGlobalVoxelIndex + local index */
+      int32_t b[3], lv[3];
+      for (int a = 0; a < 3; ++a) {
+        int64_t q = v[a] / vps, r = v[a] % vps;
+        if (r < 0) {
+          r += vps;
+          q -= 1;
+        }
+        b[a] = (int32_t)q;
+        lv[a] = (int32_t)r;
+      }
+      int slot = layer_get_or_allocate(L, b[0], b[1], b[2]);
+      size_t lin = (size_t)lv[0] + (size_t)vps * ((size_t)lv[1] + (size_t)vps * (size_t)lv[2]);
+      size_t at = (size_t)slot * L->nvox + lin;
+      /* getVoxelWeight */
+      float weight;
+      if (c->use_const_weight) {
+        weight = 1.0f;
+      } else {
+        float dist_z = fabsf(point_C[2]);
+        weight = dist_z > kEpsilon ? 1.0f / (dist_z * dist_z) : 0.0f;
+      }
+      update_voxel(I, origin, point_G, v, color, weight, &L->distance[at], &L->weight[at],
+                   &L->rgba[4 * at]);
+      ++updates;
+    }
+  }
+  return updates;
+}
