@@ -246,6 +246,70 @@ VGX_API int vgx_reg_batch_assemble(vgx_reg_batch batch, const void* d_normal,
                                    int32_t zero_first);
 VGX_API int64_t vgx_reg_fused_size(int32_t n_nodes, int32_t n_global);
 
+/* ---- TSDF: voxblox::FastTsdfIntegrator ---------------------------------- */
+/* Replaces the integrator voxgraph constructs and drives at
+ * voxgraph/src/frontend/measurement_processors/pointcloud_integrator.cpp:66-83
+ * (`new voxblox::FastTsdfIntegrator(config, layer)`, `setLayer`,
+ * `integratePointCloud(T_submap_sensor, pointcloud, colors)`).  The arithmetic is
+ * voxblox's (not vendored in the reference; restated in oracle/tsdf_oracle.c). */
+typedef struct vgx_tsdf_layer_s* vgx_tsdf_layer;           /* voxblox::Layer<TsdfVoxel> */
+typedef struct vgx_tsdf_integrator_s* vgx_tsdf_integrator; /* voxblox::FastTsdfIntegrator */
+
+/* voxblox::TsdfIntegratorBase::Config (voxblox defaults; voxgraph_mapper.yaml:21-28
+ * overrides truncation 0.60, max ray 16 m, const weight, drop-off, sparsity
+ * compensation 20).  integrator_threads / integration_order_mode /
+ * max_integration_time_s have no meaning on the GPU: every ray is its own thread. */
+typedef struct vgx_tsdf_config {
+  float default_truncation_distance;    /* 0.1   */
+  float max_weight;                     /* 10000 */
+  int32_t voxel_carving_enabled;        /* 1     */
+  float min_ray_length_m;               /* 0.1   */
+  float max_ray_length_m;               /* 5.0   */
+  int32_t use_const_weight;             /* 0     */
+  int32_t allow_clear;                  /* 1     */
+  int32_t use_weight_dropoff;           /* 1     */
+  int32_t use_sparsity_compensation_factor; /* 0 */
+  float sparsity_compensation_factor;   /* 1.0   */
+  float start_voxel_subsampling_factor; /* 2.0   */
+  int32_t max_consecutive_ray_collisions; /* 2   */
+  int32_t clear_checks_every_n_frames;  /* 1     */
+} vgx_tsdf_config;
+VGX_API void vgx_tsdf_config_default(vgx_tsdf_config* cfg);
+
+/* An active (unfinished) submap's TSDF layer, resident on the GPU between scans
+ * (SURVEY.md 3.1).  Blocks are allocated on demand inside the block-coordinate box
+ * [lut_min, lut_min + lut_dim) from a pool of max_blocks blocks (12 B per voxel);
+ * rays leaving the box or exhausting the pool are counted, not integrated there. */
+VGX_API int vgx_tsdf_layer_create(vgx_ctx ctx, float voxel_size, int32_t voxels_per_side,
+                                  const int32_t lut_min[3], const int32_t lut_dim[3],
+                                  int32_t max_blocks, vgx_tsdf_layer* out);
+VGX_API int vgx_tsdf_layer_destroy(vgx_tsdf_layer layer);
+/* allocated blocks; *dropped_updates = voxel updates lost to the box / pool limits */
+VGX_API int vgx_tsdf_layer_stats(vgx_tsdf_layer layer, int32_t* n_blocks,
+                                 int64_t* dropped_updates);
+/* block_index[n][3], distance / weight [n][vps^3], rgba [n][vps^3][4]; any may be NULL */
+VGX_API int vgx_tsdf_layer_download(vgx_tsdf_layer layer, int32_t* block_index,
+                                    float* distance, float* weight, uint8_t* rgba);
+
+VGX_API int vgx_tsdf_integrator_create(vgx_ctx ctx, const vgx_tsdf_config* cfg,
+                                       vgx_tsdf_layer layer, vgx_tsdf_integrator* out);
+VGX_API int vgx_tsdf_integrator_destroy(vgx_tsdf_integrator integrator);
+/* FastTsdfIntegrator::setLayer (pointcloud_integrator.cpp:77) */
+VGX_API int vgx_tsdf_integrator_set_layer(vgx_tsdf_integrator integrator, vgx_tsdf_layer layer);
+/* integratePointCloud(T_G_C, points_C, colors, freespace_points)
+ * (pointcloud_integrator.cpp:83).  T_G_C = {qw,qx,qy,qz, tx,ty,tz} f32
+ * (voxblox::Transformation); points_C [n][3] sensor frame; rgba [n][4] or NULL.
+ * Host pointers; returns after the scan is integrated.  n_updates (nullable)
+ * receives the number of voxel updates performed. */
+VGX_API int vgx_tsdf_integrate(vgx_tsdf_integrator integrator, const float T_G_C[7],
+                               const float* points_C, const uint8_t* rgba, int64_t n,
+                               int32_t freespace_points, int64_t* n_updates);
+/* Same with DEVICE pointers (scan already resident in HBM); asynchronous unless
+ * n_updates != NULL. */
+VGX_API int vgx_tsdf_integrate_device(vgx_tsdf_integrator integrator, const float T_G_C[7],
+                                      const void* d_points_C, const void* d_rgba, int64_t n,
+                                      int32_t freespace_points, int64_t* n_updates);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,19 @@ class RegConfig(C.Structure):
                 ("sampler_seed", C.c_uint32)]
 
 
+class TsdfConfig(C.Structure):
+    """vgx_tsdf_config == voxblox::TsdfIntegratorBase::Config (the fields that matter on a GPU)."""
+    _fields_ = [("default_truncation_distance", C.c_float), ("max_weight", C.c_float),
+                ("voxel_carving_enabled", C.c_int32), ("min_ray_length_m", C.c_float),
+                ("max_ray_length_m", C.c_float), ("use_const_weight", C.c_int32),
+                ("allow_clear", C.c_int32), ("use_weight_dropoff", C.c_int32),
+                ("use_sparsity_compensation_factor", C.c_int32),
+                ("sparsity_compensation_factor", C.c_float),
+                ("start_voxel_subsampling_factor", C.c_float),
+                ("max_consecutive_ray_collisions", C.c_int32),
+                ("clear_checks_every_n_frames", C.c_int32)]
+
+
 # every symbol include/voxgraph_amd.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "vgx_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
@@ -79,6 +92,16 @@ SIGNATURES = {
     "vgx_reg_batch_evaluate_normal": (C.c_int, [vp, f64p, C.c_int32, vp, f64p, i32p]),
     "vgx_reg_batch_assemble": (C.c_int, [vp, vp, C.c_int32, vp, C.c_int32]),
     "vgx_reg_fused_size": (C.c_int64, [C.c_int32, C.c_int32]),
+    "vgx_tsdf_config_default": (None, [C.POINTER(TsdfConfig)]),
+    "vgx_tsdf_layer_create": (C.c_int, [vp, C.c_float, C.c_int32, i32p, i32p, C.c_int32, C.POINTER(vp)]),
+    "vgx_tsdf_layer_destroy": (C.c_int, [vp]),
+    "vgx_tsdf_layer_stats": (C.c_int, [vp, i32p, i64p]),
+    "vgx_tsdf_layer_download": (C.c_int, [vp, i32p, f32p, f32p, u8p]),
+    "vgx_tsdf_integrator_create": (C.c_int, [vp, C.POINTER(TsdfConfig), vp, C.POINTER(vp)]),
+    "vgx_tsdf_integrator_destroy": (C.c_int, [vp]),
+    "vgx_tsdf_integrator_set_layer": (C.c_int, [vp, vp]),
+    "vgx_tsdf_integrate": (C.c_int, [vp, f32p, f32p, u8p, C.c_int64, C.c_int32, i64p]),
+    "vgx_tsdf_integrate_device": (C.c_int, [vp, f32p, vp, vp, C.c_int64, C.c_int32, i64p]),
 }
 
 _lib = None
@@ -373,3 +396,97 @@ class RegistrationBatch:
 
 def fused_size(n_nodes, n_global):
     return load().vgx_reg_fused_size(n_nodes, n_global)
+
+
+# ----------------------------------------------------------------------------
+# TSDF path
+# ----------------------------------------------------------------------------
+def tsdf_config(**kw):
+    cfg = TsdfConfig()
+    load().vgx_tsdf_config_default(C.byref(cfg))
+    for k, v in kw.items():
+        if not hasattr(cfg, k):
+            raise AttributeError(k)
+        setattr(cfg, k, v)
+    return cfg
+
+
+def voxgraph_tsdf_config(**kw):
+    """voxgraph/config/voxgraph_mapper.yaml:21-28 over voxblox's defaults."""
+    base = dict(default_truncation_distance=0.60, max_ray_length_m=16.0, use_const_weight=1,
+                use_weight_dropoff=1, use_sparsity_compensation_factor=1,
+                sparsity_compensation_factor=20.0)
+    base.update(kw)
+    return tsdf_config(**base)
+
+
+class TsdfLayer:
+    """voxblox::Layer<TsdfVoxel> of the active submap, resident on the GPU."""
+
+    def __init__(self, ctx, voxel_size, vps, lut_min, lut_dim, max_blocks):
+        self.ctx, self.vps = ctx, vps
+        mn = np.ascontiguousarray(lut_min, np.int32)
+        dm = np.ascontiguousarray(lut_dim, np.int32)
+        h = vp()
+        ctx.check(ctx.lib.vgx_tsdf_layer_create(ctx.h, float(voxel_size), vps, _ptr(mn, i32p),
+                                                _ptr(dm, i32p), max_blocks, C.byref(h)))
+        self.h = h
+
+    def stats(self):
+        n, d = C.c_int32(), C.c_int64()
+        self.ctx.check(self.ctx.lib.vgx_tsdf_layer_stats(self.h, C.byref(n), C.byref(d)))
+        return n.value, d.value
+
+    def download(self):
+        n, _ = self.stats()
+        nv = self.vps ** 3
+        bi = np.zeros((n, 3), np.int32)
+        d = np.zeros((n, nv), np.float32)
+        w = np.zeros((n, nv), np.float32)
+        rgba = np.zeros((n, nv, 4), np.uint8)
+        self.ctx.check(self.ctx.lib.vgx_tsdf_layer_download(self.h, _ptr(bi, i32p), _ptr(d, f32p),
+                                                            _ptr(w, f32p), _ptr(rgba, u8p)))
+        return bi, d, w, rgba
+
+    def destroy(self):
+        if self.h:
+            self.ctx.lib.vgx_tsdf_layer_destroy(self.h)
+            self.h = None
+
+
+class FastTsdfIntegrator:
+    """Mirror of voxblox::FastTsdfIntegrator as voxgraph drives it
+    (pointcloud_integrator.cpp:66-83): ctor(config, layer), setLayer, integratePointCloud."""
+
+    def __init__(self, ctx, config, layer):
+        self.ctx, self.config, self.layer = ctx, config, layer
+        h = vp()
+        ctx.check(ctx.lib.vgx_tsdf_integrator_create(ctx.h, C.byref(config), layer.h, C.byref(h)))
+        self.h = h
+
+    def setLayer(self, layer):
+        self.ctx.check(self.ctx.lib.vgx_tsdf_integrator_set_layer(self.h, layer.h))
+        self.layer = layer
+
+    def integratePointCloud(self, T_G_C, points_C, colors=None, freespace_points=False):
+        T = _f32(T_G_C)
+        pts = _f32(points_C).reshape(-1, 3)
+        col = None if colors is None else np.ascontiguousarray(colors, np.uint8).reshape(-1, 4)
+        n = C.c_int64()
+        self.ctx.check(self.ctx.lib.vgx_tsdf_integrate(self.h, _ptr(T, f32p), _ptr(pts, f32p),
+                                                       _ptr(col, u8p), pts.shape[0],
+                                                       int(freespace_points), C.byref(n)))
+        return n.value
+
+    def integrate_device(self, T_G_C, d_points, d_rgba, n, freespace_points=False, count=False):
+        T = _f32(T_G_C)
+        out = C.c_int64()
+        self.ctx.check(self.ctx.lib.vgx_tsdf_integrate_device(
+            self.h, _ptr(T, f32p), vp(d_points), vp(d_rgba) if d_rgba else None, n,
+            int(freespace_points), C.byref(out) if count else None))
+        return out.value
+
+    def destroy(self):
+        if self.h:
+            self.ctx.lib.vgx_tsdf_integrator_destroy(self.h)
+            self.h = None
