@@ -115,6 +115,89 @@ def cpu_baseline(capi, ctx, args, true_poses, poses, pairs, seconds):
                       "oracle/reg_oracle.c (gcc -O2), the reference itself cannot be built here"}
 
 
+def _room_points(dirs, origin):
+    """first hit of unit rays from `origin` with the inside of a 10 x 8 x 4 m room"""
+    lo, hi = np.array([-5.0, -4.0, -1.0]) - origin, np.array([5.0, 4.0, 3.0]) - origin
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t = np.where(dirs > 0, hi / dirs, np.where(dirs < 0, lo / dirs, np.inf))
+    return (dirs * t.min(1)[:, None]).astype(np.float32)
+
+
+def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=2):
+    """Second hot path (TSDF): whole scans resident in HBM, one integratePointCloud per
+    scan into the active layer, HIP-event timed.  Two sensor shapes from BASELINE.json:
+    RGB-D 640x480 @ 0.05 m voxels (config 4) and OS1-64-shaped LiDAR 64x1024 @ 0.20 m with
+    the shipped yaml (config 2's integrator settings)."""
+    from oracle import pyoracle as orc
+    out = {}
+    u, v = np.meshgrid((np.arange(640) - 319.5) / 525.0, (np.arange(480) - 239.5) / 525.0)
+    d_rgbd = np.stack([np.ones_like(u), -u, -v], -1).reshape(-1, 3)
+    d_rgbd /= np.linalg.norm(d_rgbd, axis=1, keepdims=True)
+    az = np.linspace(-np.pi, np.pi, 1024, endpoint=False)
+    el = np.deg2rad(np.linspace(-16.6, 16.6, 64))
+    A, E = np.meshgrid(az, el)
+    d_lidar = np.stack([np.cos(E) * np.cos(A), np.cos(E) * np.sin(A), np.sin(E)], -1).reshape(-1, 3)
+    cases = {
+        "rgbd_640x480_0.05m": (d_rgbd, 0.05, dict(default_truncation_distance=0.15, max_ray_length_m=5.0),
+                               (-8, -6, -2), (16, 12, 7)),
+        "lidar_64x1024_0.20m_voxgraph_yaml": (d_lidar, 0.20, dict(
+            default_truncation_distance=0.60, max_ray_length_m=16.0, use_const_weight=1,
+            use_weight_dropoff=1, use_sparsity_compensation_factor=1,
+            sparsity_compensation_factor=20.0), (-3, -3, -2), (6, 6, 4)),
+    }
+    for name, (dirs, vs, kw, bmin, bdim) in cases.items():
+        poses, clouds = [], []
+        for k in range(scans):
+            origin = np.array([-2.0 + 0.15 * k, 0.5 - 0.05 * k, 0.3 + 0.01 * k])
+            yaw = 0.05 * k
+            c, s_ = np.cos(yaw), np.sin(yaw)
+            R = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1.0]])
+            pts_w = _room_points(dirs @ R.T, origin)            # hits, relative to the sensor, world axes
+            pts_c = (pts_w @ R).astype(np.float32)              # sensor frame
+            poses.append(np.array([np.cos(yaw / 2), 0, 0, np.sin(yaw / 2), *origin], np.float32))
+            clouds.append(pts_c)
+        n_pts = clouds[0].shape[0]
+        layer = capi.TsdfLayer(ctx, vs, 16, bmin, bdim, int(np.prod(bdim)))
+        integ = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(**kw), layer)
+        dev = [torch.from_numpy(c_).cuda() for c_ in clouds]
+        torch.cuda.synchronize()
+        integ.integrate_device(poses[0], dev[0].data_ptr(), None, n_pts)        # warm-up scan
+        ctx.synchronize()
+        updates = 0
+        ctx.timer_start()
+        for k in range(1, scans):
+            integ.integrate_device(poses[k], dev[k].data_ptr(), None, n_pts)
+        ms = ctx.timer_stop()
+        # second pass only to count voxel updates (the count needs a sync per scan)
+        layer2 = capi.TsdfLayer(ctx, vs, 16, bmin, bdim, int(np.prod(bdim)))
+        integ.setLayer(layer2)
+        for k in range(scans):
+            u_ = integ.integrate_device(poses[k], dev[k].data_ptr(), None, n_pts, count=True)
+            updates += u_ if k >= 1 else 0
+        n_blocks, dropped = layer.stats()
+        # CPU oracle on a bounded sample (single thread: the restatement is serial)
+        ol = orc.TsdfLayer(vs, 16)
+        oi = orc.FastTsdfIntegrator(orc.tsdf_config(**kw), ol)
+        oi.integratePointCloud(poses[0], clouds[0])
+        t0, cu = time.perf_counter(), 0
+        for k in range(1, 1 + cpu_scans):
+            cu += oi.integratePointCloud(poses[k], clouds[k])
+        cdt = time.perf_counter() - t0
+        timed = scans - 1
+        out[name] = {"points_per_scan": n_pts, "scans_timed": timed, "ms_per_scan": ms / timed,
+                     "Mpoints_per_s": n_pts * timed / ms / 1e3,
+                     "Mvoxel_updates_per_s": updates / ms / 1e3,
+                     "voxel_updates_per_scan": updates / timed, "blocks": n_blocks,
+                     "dropped_updates": dropped,
+                     "algorithmic_GBs": (16.0 * n_pts * timed + 24.0 * updates) / ms / 1e6,
+                     "cpu_baseline": {"Mpoints_per_s": n_pts * cpu_scans / cdt / 1e6,
+                                      "Mvoxel_updates_per_s": cu / cdt / 1e6, "cores": 1,
+                                      "kind": "port", "sample": f"{cpu_scans} scans, oracle/tsdf_oracle.c"}}
+        for o in (integ, layer, layer2):
+            o.destroy()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -133,6 +216,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused", action="store_true")
     ap.add_argument("--no-solve", action="store_true")
+    ap.add_argument("--no-tsdf", action="store_true")
     ap.add_argument("--keep-order", action="store_true", help="extraction order instead of Morton")
     ap.add_argument("--calibrate", action="store_true",
                     help="PMC calibration: first launch evaluates poses 10 km apart, so every "
@@ -352,6 +436,9 @@ def main():
                                            args.cpu_seconds)
     elif rank == 0:
         out["cpu_baseline"] = None
+    # second hot path (does not shard: replicas only) -- rank 0, N = 1
+    if rank == 0 and world == 1 and not args.no_tsdf:
+        out["tsdf"] = tsdf_bench(capi, ctx, torch)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

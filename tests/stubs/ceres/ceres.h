@@ -1,0 +1,26 @@
+// Minimal stand-in for <ceres/ceres.h> (Ceres is not installed in this image): just the
+// ceres::CostFunction surface the adapter in voxgraph_amd/cpp/ touches.  TEST ONLY.
+#ifndef TESTS_STUBS_CERES_CERES_H_
+#define TESTS_STUBS_CERES_CERES_H_
+#include <cstdint>
+#include <vector>
+namespace ceres {
+class CostFunction {
+ public:
+  CostFunction() : num_residuals_(0) {}
+  virtual ~CostFunction() {}
+  virtual bool Evaluate(double const* const* parameters, double* residuals,
+                        double** jacobians) const = 0;
+  const std::vector<int32_t>& parameter_block_sizes() const { return parameter_block_sizes_; }
+  int num_residuals() const { return num_residuals_; }
+
+ protected:
+  std::vector<int32_t>* mutable_parameter_block_sizes() { return &parameter_block_sizes_; }
+  void set_num_residuals(int n) { num_residuals_ = n; }
+
+ private:
+  std::vector<int32_t> parameter_block_sizes_;
+  int num_residuals_;
+};
+}  // namespace ceres
+#endif

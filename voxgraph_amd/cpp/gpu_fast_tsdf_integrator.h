@@ -1,0 +1,83 @@
+// Host-side mirror of voxblox::FastTsdfIntegrator as voxgraph drives it
+// (voxgraph/src/frontend/measurement_processors/pointcloud_integrator.cpp:66-83):
+//   tsdf_integrator_.reset(new voxblox::FastTsdfIntegrator(config, layer_ptr));   :67-69
+//   tsdf_integrator_->setLayer(layer_ptr);                                         :77
+//   tsdf_integrator_->integratePointCloud(T_submap_sensor, pointcloud, colors);    :83
+// No voxblox headers are needed: points are AoS float3 (voxblox::Pointcloud is a
+// std::vector<Eigen::Vector3f>, contiguous 12-byte elements), colours AoS RGBA8
+// (voxblox::Color), the transform is {qw,qx,qy,qz,tx,ty,tz} of voxblox::Transformation.
+#ifndef VOXGRAPH_AMD_CPP_GPU_FAST_TSDF_INTEGRATOR_H_
+#define VOXGRAPH_AMD_CPP_GPU_FAST_TSDF_INTEGRATOR_H_
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+
+#include "voxgraph_amd.h"
+
+namespace voxgraph_amd {
+
+// The active submap's TSDF layer on the GPU (voxblox::Layer<TsdfVoxel> stand-in).
+class GpuTsdfLayer {
+ public:
+  GpuTsdfLayer(vgx_ctx ctx, float voxel_size, int voxels_per_side, const int32_t box_min[3],
+               const int32_t box_dim[3], int32_t max_blocks)
+      : ctx_(ctx) {
+    if (vgx_tsdf_layer_create(ctx, voxel_size, voxels_per_side, box_min, box_dim, max_blocks,
+                              &layer_) != VGX_OK)
+      throw std::runtime_error(std::string("vgx_tsdf_layer_create: ") + vgx_last_error(ctx));
+  }
+  ~GpuTsdfLayer() { vgx_tsdf_layer_destroy(layer_); }
+  GpuTsdfLayer(const GpuTsdfLayer&) = delete;
+  GpuTsdfLayer& operator=(const GpuTsdfLayer&) = delete;
+  vgx_tsdf_layer handle() const { return layer_; }
+  int32_t getNumberOfAllocatedBlocks() const {
+    int32_t n = 0;
+    vgx_tsdf_layer_stats(layer_, &n, nullptr);
+    return n;
+  }
+
+ private:
+  vgx_ctx ctx_;
+  vgx_tsdf_layer layer_ = nullptr;
+};
+
+class GpuFastTsdfIntegrator {
+ public:
+  // voxblox::TsdfIntegratorBase::Config, field for field where it matters on a GPU
+  using Config = vgx_tsdf_config;
+  static Config defaultConfig() {
+    Config c;
+    vgx_tsdf_config_default(&c);
+    return c;
+  }
+
+  GpuFastTsdfIntegrator(vgx_ctx ctx, const Config& config, GpuTsdfLayer* layer) : ctx_(ctx) {
+    if (vgx_tsdf_integrator_create(ctx, &config, layer ? layer->handle() : nullptr, &integ_) != VGX_OK)
+      throw std::runtime_error(std::string("vgx_tsdf_integrator_create: ") + vgx_last_error(ctx));
+  }
+  ~GpuFastTsdfIntegrator() { vgx_tsdf_integrator_destroy(integ_); }
+  GpuFastTsdfIntegrator(const GpuFastTsdfIntegrator&) = delete;
+  GpuFastTsdfIntegrator& operator=(const GpuFastTsdfIntegrator&) = delete;
+
+  void setLayer(GpuTsdfLayer* layer) {
+    if (vgx_tsdf_integrator_set_layer(integ_, layer->handle()) != VGX_OK)
+      throw std::runtime_error("vgx_tsdf_integrator_set_layer failed");
+  }
+
+  // integratePointCloud(T_G_C, points_C, colors, freespace_points = false)
+  void integratePointCloud(const float T_G_C[7], const float* points_C, const uint8_t* colors,
+                           int64_t n_points, bool freespace_points = false) {
+    if (vgx_tsdf_integrate(integ_, T_G_C, points_C, colors, n_points, freespace_points ? 1 : 0,
+                           nullptr) != VGX_OK)
+      throw std::runtime_error(std::string("vgx_tsdf_integrate: ") + vgx_last_error(ctx_));
+  }
+
+ private:
+  vgx_ctx ctx_;
+  vgx_tsdf_integrator integ_ = nullptr;
+};
+
+}  // namespace voxgraph_amd
+
+#endif  // VOXGRAPH_AMD_CPP_GPU_FAST_TSDF_INTEGRATOR_H_
