@@ -162,9 +162,24 @@ def _spd_solve(A, b):
 
 def solve(problem, poses0, parameter_tolerance=3e-3, function_tolerance=1e-6,
           gradient_tolerance=1e-10, max_iterations=50, max_seconds=4.0,
-          initial_radius=1e4, verbose=False):
+          initial_radius=1e4, verbose=False, blas_threads=4):
     """Returns (poses, summary).  Ceres-style LM: (H + D^2/radius) step, gain-ratio
-    acceptance, radius update radius / max(1/3, 1 - (2 rho - 1)^3)."""
+    acceptance, radius update radius / max(1/3, 1 - (2 rho - 1)^3).
+    The dense linear algebra runs on `blas_threads` threads (the reference gives Ceres
+    num_threads = 4, pose_graph.cpp:96; an 800x800 Cholesky on every core of a 256-core
+    host is an order of magnitude slower than on 4)."""
+    try:
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=blas_threads):
+            return _solve(problem, poses0, parameter_tolerance, function_tolerance,
+                          gradient_tolerance, max_iterations, max_seconds, initial_radius, verbose)
+    except ImportError:
+        return _solve(problem, poses0, parameter_tolerance, function_tolerance,
+                      gradient_tolerance, max_iterations, max_seconds, initial_radius, verbose)
+
+
+def _solve(problem, poses0, parameter_tolerance, function_tolerance, gradient_tolerance,
+           max_iterations, max_seconds, initial_radius, verbose):
     t0 = time.perf_counter()
     x = np.array(poses0, np.float64).copy()
     f = problem.free
