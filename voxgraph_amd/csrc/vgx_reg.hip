@@ -14,6 +14,7 @@
 // decision agrees with the CPU restatement bit for bit.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "vgx_internal.h"
@@ -137,6 +138,7 @@ __device__ __forceinline__ void locate_axis(float p, const GridDev& g, int& blk,
 }
 
 struct PointEval {
+  bool ok;             // interp_possible
   double r;            // unscaled residual (RCF:161-166)
   float jo0, jo1, jo2, jo3;  // unscaled d r / d reference pose (RCF:234-236)
   float je3;           // d r / d reading yaw; je0..2 == -jo0..2 (RCF:223-227)
@@ -158,6 +160,19 @@ __device__ __forceinline__ const float* locate_point(const GridDev& g, const Pos
   float px = (x + P.qw * uv0 + c0) + P.tx;
   float py = (y + P.qw * uv1 + c1) + P.ty;
   float pz = z + P.tz;
+  // Coarse reject before the exact (and longer) index arithmetic: the base block is
+  // the block containing p' or its -1 neighbour, so a block index outside
+  // [lut_min, lut_min + lut_dim] on any axis cannot have a correspondence.  Points
+  // of a partially overlapping pair mostly fail here; when a whole wavefront fails,
+  // the compiler's execz branch skips everything below for free.
+  {
+    int cx = (int)floorf(px * g.block_size_inv + 1e-6f) - g.lut_min[0];
+    int cy = (int)floorf(py * g.block_size_inv + 1e-6f) - g.lut_min[1];
+    int cz = (int)floorf(pz * g.block_size_inv + 1e-6f) - g.lut_min[2];
+    if ((unsigned)cx > (unsigned)g.lut_dim[0] || (unsigned)cy > (unsigned)g.lut_dim[1] ||
+        (unsigned)cz > (unsigned)g.lut_dim[2])
+      return nullptr;
+  }
   int bx, by, bz, vx, vy, vz;
   locate_axis<VPS>(px, g, bx, vx, Dx);
   locate_axis<VPS>(py, g, by, vy, Dy);
@@ -197,6 +212,7 @@ __device__ __forceinline__ PointEval eval_point(const float d[8], bool have, flo
   // every neighbour valid <=> no NaN among the 8 (apron-brick encoding)
   float s = ((d[0] + d[1]) + (d[2] + d[3])) + ((d[4] + d[5]) + (d[6] + d[7]));
   bool ok = have && (s == s);
+  e.ok = ok;
   e.jo0 = e.jo1 = e.jo2 = e.jo3 = e.je3 = 0.0f;
   if (!ok) {
     e.r = (double)w * no_corr_cost;  // RCF:165-166
@@ -335,6 +351,7 @@ __global__ __launch_bounds__(kBlockThreads) void reg_eval_points_kernel(
 // u = (jo0, jo1, jo2, jo3, je3, r): [J r]^T [J r] (9x9) is a signed
 // re-arrangement of the 21 unique products of u because je0..2 == -jo0..2.
 constexpr int kReduceIters = 8;  // a reduce tile = kTilePoints * kReduceIters residuals
+constexpr int kReducePointsPerThread = 2;  // measured: 3.72 / 3.29 / 3.41 ms per fused step at 4 / 2 / 1 (profiles/tune_fused.sh)
 
 template <int VPS, int PPT>
 __global__ __launch_bounds__(kBlockThreads) void reg_eval_reduce_kernel(
@@ -381,12 +398,16 @@ __global__ __launch_bounds__(kBlockThreads) void reg_eval_reduce_kernel(
       if (local >= tile.count) continue;
       PointEval e = eval_point(d[j], cell[j] != nullptr, Dx[j], Dy[j], Dz[j], g.voxel_size_inv,
                                P, pt[j].x, pt[j].y, pt[j].w, w[j], C.no_corr_cost, true);
-      double u[6] = {(double)e.jo0, (double)e.jo1, (double)e.jo2, (double)e.jo3, (double)e.je3, e.r};
-      int k = 0;
+      if (e.ok) {
+        double u[6] = {(double)e.jo0, (double)e.jo1, (double)e.jo2, (double)e.jo3, (double)e.je3, e.r};
+        int k = 0;
 #pragma unroll
-      for (int a = 0; a < 6; ++a)
+        for (int a = 0; a < 6; ++a)
 #pragma unroll
-        for (int b = a; b < 6; ++b) acc[k++] += u[a] * u[b];
+          for (int b = a; b < 6; ++b) acc[k++] += u[a] * u[b];
+      } else {
+        acc[20] += e.r * e.r;  // w * no_correspondence_cost, zero Jacobian rows
+      }
     }
   }
   // wave reduction (64 lanes), then across the 4 waves through LDS: a fixed
@@ -411,18 +432,30 @@ __global__ __launch_bounds__(kBlockThreads) void reg_eval_reduce_kernel(
   }
 }
 
-// One wavefront per constraint: sums the constraint's tile partials in tile
-// order and expands the 21 products into [cost, J^T r (8), upper J^T J (36)].
-__global__ __launch_bounds__(64) void reg_finalize_kernel(const ConstraintDev* __restrict__ cons,
-                                                         const int32_t* __restrict__ tile_first,
-                                                         const double* __restrict__ partials,
-                                                         double* __restrict__ normal) {
+// One workgroup per constraint: 12 groups of 21 lanes sum the constraint's tile
+// partials (group g takes tiles g, g+12, ... in order; the 12 group sums are added in
+// group order: a fixed tree) and expand the 21 products into
+// [cost, J^T r (8), upper J^T J (36)].
+__global__ __launch_bounds__(256) void reg_finalize_kernel(const ConstraintDev* __restrict__ cons,
+                                                          const int32_t* __restrict__ tile_first,
+                                                          const double* __restrict__ partials,
+                                                          double* __restrict__ normal) {
   const int c = blockIdx.x;
+  constexpr int G = 12;
+  __shared__ double part[G][21];
   __shared__ double s[21];
+  const int grp = threadIdx.x / 21, k21 = threadIdx.x % 21;
+  if (grp < G) {
+    double v = 0.0;
+    for (int t = tile_first[c] + grp; t < tile_first[c + 1]; t += G)
+      v += partials[(size_t)t * kPartialSize + k21];
+    part[grp][k21] = v;
+  }
+  __syncthreads();
   if (threadIdx.x < 21) {
     double v = 0.0;
-    for (int t = tile_first[c]; t < tile_first[c + 1]; ++t)
-      v += partials[(size_t)t * kPartialSize + threadIdx.x];
+#pragma unroll
+    for (int g = 0; g < G; ++g) v += part[g][threadIdx.x];
     s[threadIdx.x] = v;
   }
   __syncthreads();
@@ -470,12 +503,21 @@ __global__ void reg_assemble_kernel(const double* __restrict__ normal, int n, in
   };
   const int64_t n_node_elems = (int64_t)csr_nodes * 20;  // 4 (J^T r) + 16 (diag block)
   const int64_t n_off = (int64_t)n * 16;
-  int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid == 0) {
+  if (blockIdx.x == gridDim.x - 1) {
+    // the last workgroup only sums the costs: strided partial sums, then a fixed tree
+    __shared__ double part[256];
     double v = 0.0;
-    for (int c = 0; c < n; ++c) v += normal[(size_t)c * kNormalSize];
-    fused[0] = accumulate ? fused[0] + v : v;
+    for (int c = threadIdx.x; c < n; c += 256) v += normal[(size_t)c * kNormalSize];
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+      if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) fused[0] = accumulate ? fused[0] + part[0] : part[0];
+    return;
   }
+  int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (tid < n_node_elems) {
     int node = (int)(tid / 20), e = (int)(tid % 20);
     double v = 0.0;
@@ -913,15 +955,26 @@ int vgx_reg_batch_evaluate_normal(vgx_reg_batch b, const double* poses, int32_t 
   const int n_tiles = (int)ex->reduce_tiles.size();
   if (n_tiles > 0) {
     dim3 grid(((n_tiles + 7) / 8) * 8), block(kBlockThreads);
-    if (b->regs[0]->reading->vps == 16)
-      hipLaunchKernelGGL((reg_eval_reduce_kernel<16, kPointsPerThread>), grid, block, 0, ctx->stream,
-                         b->d_desc, b->d_pack, ex->d_reduce_tiles, n_tiles, b->d_partials);
-    else
-      hipLaunchKernelGGL((reg_eval_reduce_kernel<8, kPointsPerThread>), grid, block, 0, ctx->stream,
-                         b->d_desc, b->d_pack, ex->d_reduce_tiles, n_tiles, b->d_partials);
+    // points per thread per inner iteration: tuning knob (VGX_REDUCE_PPT = 1, 2, 4)
+    static const int ppt = [] {
+      const char* e = getenv("VGX_REDUCE_PPT");
+      int v = e ? atoi(e) : kReducePointsPerThread;
+      return (v == 1 || v == 2 || v == 4) ? v : kReducePointsPerThread;
+    }();
+    const bool v16 = b->regs[0]->reading->vps == 16;
+#define VGX_LAUNCH_REDUCE(VPS, PPT)                                                               \
+  hipLaunchKernelGGL((reg_eval_reduce_kernel<VPS, PPT>), grid, block, 0, ctx->stream, b->d_desc, \
+                     b->d_pack, ex->d_reduce_tiles, n_tiles, b->d_partials)
+    if (v16 && ppt == 4) VGX_LAUNCH_REDUCE(16, 4);
+    else if (v16 && ppt == 2) VGX_LAUNCH_REDUCE(16, 2);
+    else if (v16) VGX_LAUNCH_REDUCE(16, 1);
+    else if (ppt == 4) VGX_LAUNCH_REDUCE(8, 4);
+    else if (ppt == 2) VGX_LAUNCH_REDUCE(8, 2);
+    else VGX_LAUNCH_REDUCE(8, 1);
+#undef VGX_LAUNCH_REDUCE
     VGX_HIP(ctx, hipGetLastError());
   }
-  hipLaunchKernelGGL(reg_finalize_kernel, dim3(b->n), dim3(64), 0, ctx->stream, b->d_desc,
+  hipLaunchKernelGGL(reg_finalize_kernel, dim3(b->n), dim3(256), 0, ctx->stream, b->d_desc,
                      b->d_tile_first, b->d_partials, out);
   VGX_HIP(ctx, hipGetLastError());
   if (normal_host) {
@@ -954,7 +1007,7 @@ int vgx_reg_batch_assemble(vgx_reg_batch b, const void* d_normal, int32_t n_node
   int64_t work = (int64_t)ex->csr_nodes * 20 + (int64_t)b->n * 16;
   if (work == 0) work = 1;
   int threads = 256;
-  int blocks = (int)((work + threads - 1) / threads);
+  int blocks = (int)((work + threads - 1) / threads) + 1;  // + the cost-summing workgroup
   // The kernel indexes node elements by the CSR's node count but lays the
   // buffer out with the caller's n_nodes.
   hipLaunchKernelGGL(reg_assemble_kernel, dim3(blocks), dim3(threads), 0, ctx->stream, nb, b->n,
