@@ -154,7 +154,9 @@ struct vgx_reg_batch_s {
   std::vector<vgx::Tile> tiles;
   vgx::ConstraintDev* d_desc = nullptr;
   vgx::PosePack* d_pack = nullptr;
-  vgx::PosePack* h_pack = nullptr;    // pinned
+  vgx::PosePack* h_pack = nullptr;    // pinned, 2 x n (double-buffered staging)
+  hipEvent_t pack_copied[2] = {nullptr, nullptr};  // H2D of staging half k finished
+  int pack_turn = 0;
   vgx::Tile* d_tiles = nullptr;
   int32_t* d_tile_first = nullptr;    // [n+1] first tile of each constraint
   double* d_partials = nullptr;       // [n_tiles][kPartialSize]

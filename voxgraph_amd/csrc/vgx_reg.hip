@@ -864,7 +864,9 @@ int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs, const int3
   if (rc == VGX_OK) rc = up(items.data(), items.size() * sizeof(int32_t), (void**)&ex->d_node_items);
   if (rc == VGX_OK && n > 0) {
     if (hipMalloc(&b->d_pack, (size_t)n * sizeof(PosePack)) != hipSuccess ||
-        hipHostMalloc(&b->h_pack, (size_t)n * sizeof(PosePack)) != hipSuccess ||
+        hipHostMalloc(&b->h_pack, 2 * (size_t)n * sizeof(PosePack)) != hipSuccess ||
+        hipEventCreateWithFlags(&b->pack_copied[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&b->pack_copied[1], hipEventDisableTiming) != hipSuccess ||
         hipMalloc(&b->d_partials, std::max<size_t>(1, ex->reduce_tiles.size()) * kPartialSize * sizeof(double)) != hipSuccess ||
         hipMalloc(&b->d_normal, (size_t)n * kNormalSize * sizeof(double)) != hipSuccess)
       rc = set_error(ctx, VGX_ERR_NOMEM, "vgx_reg_batch_create: device allocation failed");
@@ -887,6 +889,8 @@ int vgx_reg_batch_destroy(vgx_reg_batch b) {
   if (b->d_desc) (void)hipFree(b->d_desc);
   if (b->d_pack) (void)hipFree(b->d_pack);
   if (b->h_pack) (void)hipHostFree(b->h_pack);
+  for (int k = 0; k < 2; ++k)
+    if (b->pack_copied[k]) (void)hipEventDestroy(b->pack_copied[k]);
   if (b->d_tiles) (void)hipFree(b->d_tiles);
   if (b->d_tile_first) (void)hipFree(b->d_tile_first);
   if (b->d_partials) (void)hipFree(b->d_partials);
@@ -905,19 +909,26 @@ int vgx_reg_batch_row_offsets(vgx_reg_batch b, int64_t* row_offset) {
   return VGX_OK;
 }
 
-// pose packs for every constraint -> pinned staging -> device
+// pose packs for every constraint -> pinned staging (double-buffered) -> device.
+// No stream synchronisation: the host only waits until the H2D copy that last used
+// this staging half has finished, so it prepares evaluation k+1 while k still runs.
 static int batch_upload_packs(vgx_reg_batch b, const double* poses, int32_t n_nodes, int32_t* status) {
   vgx_ctx ctx = b->ctx;
+  if (b->n == 0) return VGX_OK;
+  const int turn = b->pack_turn;
+  b->pack_turn ^= 1;
+  VGX_HIP(ctx, hipEventSynchronize(b->pack_copied[turn]));
+  PosePack* stage = b->h_pack + (size_t)turn * b->n;
   for (int c = 0; c < b->n; ++c) {
     int i = b->node_pair[2 * (size_t)c], j = b->node_pair[2 * (size_t)c + 1];
     if (i >= n_nodes || j >= n_nodes)
       return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_batch: node index >= n_nodes");
-    make_pose_pack(poses + 4 * (size_t)i, poses + 4 * (size_t)j, &b->h_pack[c]);
+    make_pose_pack(poses + 4 * (size_t)i, poses + 4 * (size_t)j, &stage[c]);
     if (status) status[c] = reg_status(b->regs[(size_t)c]);
   }
-  if (b->n > 0)
-    VGX_HIP(ctx, hipMemcpyAsync(b->d_pack, b->h_pack, (size_t)b->n * sizeof(PosePack),
-                                hipMemcpyHostToDevice, ctx->stream));
+  VGX_HIP(ctx, hipMemcpyAsync(b->d_pack, stage, (size_t)b->n * sizeof(PosePack),
+                              hipMemcpyHostToDevice, ctx->stream));
+  VGX_HIP(ctx, hipEventRecord(b->pack_copied[turn], ctx->stream));
   return VGX_OK;
 }
 
@@ -929,8 +940,6 @@ int vgx_reg_batch_evaluate_points(vgx_reg_batch b, const double* poses, int32_t 
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (!d_residuals) return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_batch_evaluate_points: residuals == NULL");
   VGX_HIP(ctx, hipSetDevice(ctx->device));
-  // the previous evaluation may still be reading the pinned staging buffer
-  VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   int rc = batch_upload_packs(b, poses, n_nodes, status);
   if (rc != VGX_OK) return rc;
   if (b->n == 0) return VGX_OK;
@@ -947,7 +956,6 @@ int vgx_reg_batch_evaluate_normal(vgx_reg_batch b, const double* poses, int32_t 
   std::lock_guard<std::mutex> lk(ctx->mu);
   vgx_reg_batch ex = b;
   VGX_HIP(ctx, hipSetDevice(ctx->device));
-  VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   int rc = batch_upload_packs(b, poses, n_nodes, status);
   if (rc != VGX_OK) return rc;
   if (b->n == 0) return VGX_OK;
