@@ -1,0 +1,116 @@
+"""Error conventions of the C ABI on a GPU box: status codes and messages instead of
+aborts (the reference CHECK-fails), bounded resources degrade by counting, not crashing."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import synth
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from voxgraph_amd import capi
+    capi.load()
+    return capi
+
+
+@pytest.fixture(scope="module")
+def ctx(capi):
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def test_invalid_arguments_are_status_codes(capi, ctx):
+    sm, _ = synth.config1_pair()
+    with pytest.raises(capi.VgxError) as e:
+        capi.Submap(ctx, 0, sm.voxel_size, 4, sm.block_index[:1], None, None,
+                    np.zeros((1, 64), F), np.ones((1, 64), np.uint8))
+    assert e.value.code == capi.ERR_UNSUPPORTED and "voxels_per_side" in str(e.value)
+    with pytest.raises(capi.VgxError) as e:
+        capi.Submap(ctx, 0, -1.0, 16, sm.block_index, None, None, sm.esdf_distance, sm.esdf_observed)
+    assert e.value.code == capi.ERR_INVALID
+    with pytest.raises(capi.VgxError):                  # tsdf distance without weight
+        capi.Submap(ctx, 0, sm.voxel_size, 16, sm.block_index, sm.tsdf_distance, None, None, None)
+    g = H.gpu_submap(capi, ctx, sm)
+    with pytest.raises(capi.VgxError):                  # bad point type
+        g.set_points(7, np.zeros((1, 3), F), np.zeros(1, F), np.ones(1, F))
+    g.extract_voxel_points()
+    # a second context's submap cannot be mixed in
+    ctx2 = capi.Context(0)
+    g2 = H.gpu_submap(capi, ctx2, sm)
+    g2.extract_voxel_points()
+    cfg = capi.default_config(registration_point_type=capi.POINTS_VOXELS)
+    with pytest.raises(capi.VgxError) as e:
+        capi.RegistrationCostFunction(ctx, g, g2, cfg)
+    assert e.value.code == capi.ERR_INVALID and "another context" in str(e.value)
+    # TSDF-distance mode needs a TSDF layer on the reading submap
+    only_esdf = capi.Submap(ctx, 5, sm.voxel_size, 16, sm.block_index, None, None,
+                            sm.esdf_distance, sm.esdf_observed)
+    with pytest.raises(capi.VgxError):
+        capi.RegistrationCostFunction(ctx, g, only_esdf, capi.default_config(
+            registration_point_type=capi.POINTS_VOXELS, use_esdf_distance=0))
+    # sampling constraints are not batchable; node indices are checked
+    cf_s = capi.RegistrationCostFunction(ctx, g, g, capi.default_config(
+        registration_point_type=capi.POINTS_VOXELS, sampling_ratio=0.1))
+    with pytest.raises(capi.VgxError) as e:
+        capi.RegistrationBatch(ctx, [cf_s], [(0, 1)])
+    assert e.value.code == capi.ERR_UNSUPPORTED
+    cf = capi.RegistrationCostFunction(ctx, g, g, cfg)
+    batch = capi.RegistrationBatch(ctx, [cf], [(0, 3)])
+    with pytest.raises(capi.VgxError):
+        batch.evaluate_normal(np.zeros((2, 4)))             # node 3 >= n_nodes
+    # NULL residuals
+    rc = ctx.lib.vgx_reg_evaluate(cf.h, np.zeros(4).ctypes.data_as(capi.f64p),
+                                  np.zeros(4).ctypes.data_as(capi.f64p), None, None, None)
+    assert rc == capi.ERR_INVALID
+    assert ctx.lib.vgx_reg_num_residuals(None) == -1
+    for o in (batch, cf, cf_s, only_esdf, g, g2):
+        o.destroy()
+    ctx2.close()
+
+
+def test_empty_submap_and_empty_batch(capi, ctx):
+    empty = capi.Submap(ctx, 1, 0.1, 16, np.zeros((0, 3), np.int32), None, None, None, None)
+    assert empty.extract_voxel_points() == 0
+    sm, _ = synth.config1_pair()
+    g = H.gpu_submap(capi, ctx, sm)
+    n = g.extract_voxel_points()
+    cfg = capi.default_config(registration_point_type=capi.POINTS_VOXELS)
+    # every point falls outside an empty reading submap: all residuals w * ncc, J == 0
+    cf = capi.RegistrationCostFunction(ctx, g, empty, cfg)
+    r, jo, je = np.ones(n), np.ones((n, 4)), np.ones((n, 4))
+    assert cf.Evaluate([np.zeros(4), np.zeros(4)], r, [jo, je])
+    assert np.all(r == 0) and np.all(jo == 0) and np.all(je == 0)
+    b = capi.RegistrationBatch(ctx, [], np.zeros((0, 2), np.int32))
+    assert b.num_residuals() == 0
+    status, normal = b.evaluate_normal(np.zeros((1, 4)))
+    assert normal.shape == (0, 45)
+    for o in (b, cf, g, empty):
+        o.destroy()
+
+
+def test_tsdf_pool_and_box_limits_are_counted(capi, ctx):
+    cfg = capi.tsdf_config(default_truncation_distance=0.3, use_const_weight=1, max_ray_length_m=20)
+    T = np.array([1, 0, 0, 0, 0.05, 0.05, 0.05], F)
+    # box of 2 blocks along x only: the ray leaves it
+    layer = capi.TsdfLayer(ctx, 0.1, 16, (0, 0, 0), (2, 1, 1), 8)
+    integ = capi.FastTsdfIntegrator(ctx, cfg, layer)
+    n = integ.integratePointCloud(T, np.array([[6.0, 0, 0]], F))
+    blocks, dropped = layer.stats()
+    assert blocks == 2 and n == 32 and dropped == 64 - 32
+    # big box, pool of 1 block: the second block cannot be allocated
+    layer2 = capi.TsdfLayer(ctx, 0.1, 16, (-2, -2, -2), (8, 4, 4), 1)
+    integ.setLayer(layer2)
+    n2 = integ.integratePointCloud(T, np.array([[3.0, 0, 0]], F))
+    blocks2, dropped2 = layer2.stats()
+    assert blocks2 == 1 and n2 == 16 and dropped2 == 34 - 16
+    with pytest.raises(capi.VgxError):
+        capi.TsdfLayer(ctx, 0.1, 16, (0, 0, 0), (0, 1, 1), 8)
+    for o in (integ, layer, layer2):
+        o.destroy()
