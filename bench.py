@@ -363,7 +363,9 @@ def main():
             barrier()
             s0 = time.perf_counter()
             prob = lm.Problem(backend, n_sub, pairs, edges)
-            x, summ = lm.solve(prob, poses, **kw)
+            # no wall-clock stop rule here: every rank must take the same number of
+            # evaluations (each one is a collective)
+            x, summ = lm.solve(prob, poses, max_seconds=1e9, **kw)
             torch.cuda.synchronize()
             barrier()
             sdt = torch.tensor([time.perf_counter() - s0], dtype=torch.float64, device="cuda")

@@ -823,6 +823,12 @@ int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs, const int3
   b->row_offset.assign((size_t)n + 1, 0);
   std::vector<ConstraintDev> desc((size_t)n);
   std::vector<int32_t> tile_first((size_t)n + 1, 0);
+  // Fused-pass tile size: each tile ends in a 21 x f64 wave + LDS reduction, so tiles
+  // grow with the batch (8 Ki .. 64 Ki residuals) while keeping >= ~16 K tiles in flight.
+  int64_t total_residuals = 0;
+  for (int c = 0; c < n; ++c) total_residuals += regs[c]->num_residuals;
+  const int reduce_iters =
+      (int)std::min<int64_t>(64, std::max<int64_t>(kReduceIters, total_residuals / ((int64_t)kTilePoints * 16384)));
   int max_node = -1;
   for (int c = 0; c < n; ++c) {
     desc[(size_t)c] = regs[c]->describe();
@@ -831,7 +837,7 @@ int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs, const int3
     std::vector<Tile> t = make_tiles(c, regs[c]->num_residuals, kTilePoints);
     b->tiles.insert(b->tiles.end(), t.begin(), t.end());
     tile_first[(size_t)c] = (int32_t)ex->reduce_tiles.size();
-    std::vector<Tile> rt = make_tiles(c, regs[c]->num_residuals, kTilePoints * kReduceIters);
+    std::vector<Tile> rt = make_tiles(c, regs[c]->num_residuals, kTilePoints * reduce_iters);
     ex->reduce_tiles.insert(ex->reduce_tiles.end(), rt.begin(), rt.end());
     max_node = std::max(max_node, std::max(node_pair[2 * c], node_pair[2 * c + 1]));
   }
