@@ -132,6 +132,28 @@ VGX_API int vgx_submap_download_layers(vgx_submap submap, float* tsdf_distance,
                                        float* tsdf_weight, float* esdf_distance,
                                        uint8_t* esdf_observed);
 VGX_API int vgx_submap_block_index(vgx_submap submap, int32_t* block_index);
+/* Device-side cblox::TsdfEsdfSubmap::generateEsdf() (voxgraph_submap.cpp:86), i.e.
+ * voxblox::EsdfIntegrator::updateFromTsdfLayerBatch [recalled]: TSDF voxels with
+ * weight >= min_weight become observed; |tsdf| < min_distance_m is copied and fixed;
+ * the rest starts at sign * default_distance_m and is lowered by the quasi-Euclidean
+ * 26-neighbour wavefront (steps 1, sqrt2, sqrt3 voxels) from voxels closer than
+ * max_distance_m, never across a sign change.  voxblox runs a bucketed label-correcting
+ * queue that ignores improvements below min_diff_m (1 mm); the GPU relaxes to the exact
+ * fixed point of the same recurrence, so results agree to within a few min_diff_m
+ * (min_diff_m and num_buckets are accepted for layout compatibility and ignored).
+ * Fills the ESDF raw layer from the resident TSDF layer and rebuilds the ESDF sampling
+ * grid.  cfg == NULL uses voxblox's defaults.  sweeps (nullable) = global passes used. */
+typedef struct vgx_esdf_config {
+  float max_distance_m;     /* 2.0   */
+  float min_distance_m;     /* 0.2   */
+  float default_distance_m; /* 2.0   */
+  float min_diff_m;         /* 0.001 (ignored) */
+  float min_weight;         /* 1e-6  */
+  int32_t num_buckets;      /* 20    (ignored) */
+} vgx_esdf_config;
+VGX_API void vgx_esdf_config_default(vgx_esdf_config* cfg);
+VGX_API int vgx_submap_generate_esdf(vgx_submap submap, const vgx_esdf_config* cfg,
+                                     int32_t* sweeps);
 /* Drop the raw voxel layers after extraction (keeps the sampling grids). */
 VGX_API int vgx_submap_release_raw_layers(vgx_submap submap);
 
@@ -309,6 +331,13 @@ VGX_API int vgx_tsdf_integrate(vgx_tsdf_integrator integrator, const float T_G_C
 VGX_API int vgx_tsdf_integrate_device(vgx_tsdf_integrator integrator, const float T_G_C[7],
                                       const void* d_points_C, const void* d_rgba, int64_t n,
                                       int32_t freespace_points, int64_t* n_updates);
+
+/* finishSubmap() hand-off without a host round trip: turns the active layer's blocks
+ * into a (not yet finished) submap holding the raw TSDF layer and its TSDF sampling
+ * grid; follow with vgx_submap_generate_esdf and vgx_submap_extract_voxel_points.  The
+ * layer itself is left untouched (the mapper moves on to a new active submap). */
+VGX_API int vgx_submap_from_tsdf_layer(vgx_ctx ctx, vgx_tsdf_layer layer, int32_t submap_id,
+                                       vgx_submap* out);
 
 #ifdef __cplusplus
 }

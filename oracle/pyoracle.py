@@ -347,3 +347,44 @@ class FastTsdfIntegrator:
             _tsdf_lib().orc_tsdf_integrator_destroy(self.h)
         except Exception:
             pass
+
+
+# ----------------------------------------------------------------------------
+# ESDF generation (oracle/esdf_oracle.c)
+# ----------------------------------------------------------------------------
+class EsdfConfig(C.Structure):
+    """voxblox::EsdfIntegrator::Config defaults [recalled]; same layout as vgx_esdf_config."""
+    _fields_ = [("max_distance_m", C.c_float), ("min_distance_m", C.c_float),
+                ("default_distance_m", C.c_float), ("min_diff_m", C.c_float),
+                ("min_weight", C.c_float), ("num_buckets", C.c_int)]
+
+
+def esdf_config(**kw):
+    cfg = EsdfConfig()
+    L = lib()
+    L.orc_esdf_config_default.argtypes = [C.POINTER(EsdfConfig)]
+    L.orc_esdf_config_default(C.byref(cfg))
+    for k, v in kw.items():
+        if not hasattr(cfg, k):
+            raise AttributeError(k)
+        setattr(cfg, k, v)
+    return cfg
+
+
+def esdf_from_tsdf(voxel_size, vps, block_index, tsdf_distance, tsdf_weight, config=None):
+    """EsdfIntegrator::updateFromTsdfLayerBatch -> (esdf_distance, esdf_observed, n_updates)."""
+    cfg = config or esdf_config()
+    L = lib()
+    L.orc_esdf_from_tsdf_batch.argtypes = [C.POINTER(EsdfConfig), C.c_float, C.c_int, C.c_int,
+                                           c_i32p, c_f32p, c_f32p, c_f32p, c_u8p]
+    L.orc_esdf_from_tsdf_batch.restype = C.c_int64
+    bi = np.ascontiguousarray(block_index, np.int32).reshape(-1, 3)
+    td, tw = _f32(tsdf_distance), _f32(tsdf_weight)
+    ed = np.zeros_like(td)
+    eo = np.zeros(td.shape, np.uint8)
+    n = L.orc_esdf_from_tsdf_batch(C.byref(cfg), float(np.float32(voxel_size)), vps, bi.shape[0],
+                                   _p(bi, c_i32p), _p(td, c_f32p), _p(tw, c_f32p), _p(ed, c_f32p),
+                                   _p(eo, c_u8p))
+    if n < 0:
+        raise MemoryError("orc_esdf_from_tsdf_batch")
+    return ed, eo, n

@@ -2,9 +2,8 @@
 chained on the GPU the way voxgraph chains them:
   scans --TSDF kernel--> active layers --finishSubmap--> finished submaps
         --device point extraction--> registration constraints --REG kernels--> solve.
-ESDF generation is a "next" row; this test stands in for it with the
-TSDF band itself (ESDF := TSDF distance where observed and inside the band), which is what
-voxblox's ESDF integrator fixes before propagating outwards."""
+The finished submap never leaves the device: vgx_submap_from_tsdf_layer ->
+vgx_submap_generate_esdf -> vgx_submap_extract_voxel_points."""
 import numpy as np
 import pytest
 
@@ -68,10 +67,10 @@ def _build_submap(capi, ctx, submap_pose, sensor_poses, submap_id):
         T = np.concatenate([_yaw_q(yaw - submap_pose[3]), t_sc]).astype(F)
         integ.integratePointCloud(T, pts_c)
     assert layer.stats()[1] == 0
-    bi, d, w, _ = layer.download()
-    # finishSubmap stand-in for generateEsdf(): the TSDF band is the fixed part of the ESDF
-    esdf_obs = ((w > 0) & (np.abs(d) < 0.95 * TRUNC)).astype(np.uint8)
-    sm = capi.Submap(ctx, submap_id, VS, VPS, bi, d, w, d, esdf_obs)
+    # finishSubmap() on the device (voxgraph_submap.cpp:84-107): ESDF, then kVoxels points
+    sm = capi.Submap.from_tsdf_layer(ctx, layer, submap_id)
+    assert sm.num_blocks() == layer.stats()[0]
+    sm.generate_esdf(capi.esdf_config(min_distance_m=0.15, max_distance_m=1.0, default_distance_m=1.0))
     n = sm.extract_voxel_points(1.0, 0.2, True)
     for o in (integ, layer):
         o.destroy()

@@ -389,3 +389,47 @@ def test_sharded_batches_sum_to_the_unsharded_buffer(capi, ctx, small_graph):
         b.destroy()
     np.testing.assert_allclose(total, want, rtol=1e-12, atol=1e-9)
     full.destroy()
+
+
+def test_concurrent_evaluate_from_four_threads(capi, ctx, small_graph):
+    """Ceres evaluates distinct residual blocks on 4 threads (pose_graph.cpp:96): concurrent
+    Evaluate calls on distinct cost functions of one context must equal the serial results."""
+    from concurrent.futures import ThreadPoolExecutor
+    G = small_graph
+
+    def run(c):
+        a, b = G["pairs"][c]
+        cf = G["cfs"][c]
+        n = cf.num_residuals()
+        r, jo, je = np.zeros(n), np.zeros((n, 4)), np.zeros((n, 4))
+        assert cf.Evaluate([G["poses"][a], G["poses"][b]], r, [jo, je])
+        return r, jo, je
+
+    serial = [run(c) for c in range(len(G["pairs"]))]
+    with ThreadPoolExecutor(4) as ex:
+        for _ in range(5):
+            par = list(ex.map(run, range(len(G["pairs"]))))
+            for s, p in zip(serial, par):
+                assert all(np.array_equal(x, y) for x, y in zip(s, p))
+
+
+def test_explicit_stream_and_timer(capi, ctx, cfg1):
+    import torch
+    sm, g, layer, (xyz, dist, w) = cfg1
+    g.extract_voxel_points()
+    cf = capi.RegistrationCostFunction(
+        ctx, g, g, capi.default_config(registration_point_type=capi.POINTS_VOXELS))
+    n = cf.num_residuals()
+    stream = torch.cuda.Stream()
+    ctx.set_stream(stream.cuda_stream)
+    assert ctx.lib.vgx_ctx_get_stream(ctx.h) == stream.cuda_stream
+    with torch.cuda.stream(stream):
+        r = torch.zeros(n, dtype=torch.float32, device="cuda:0")
+        ctx.timer_start()
+        assert cf.evaluate_device_f32(np.array([0.05, 0, 0, 0.0]), np.zeros(4), r.data_ptr(), 0, 0)
+        ms = ctx.timer_stop()
+        total = float(r.double().abs().sum())       # ordered after the kernel by the stream
+    ok0, r0, _, _ = orc.reg_evaluate(layer, xyz, dist, w, np.array([0.05, 0, 0, 0.0]), np.zeros(4), False)
+    assert 0 < ms < 1000 and abs(total - np.abs(r0).sum()) < 1e-3 * np.abs(r0).sum()
+    ctx.set_stream(None)
+    cf.destroy()

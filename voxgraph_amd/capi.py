@@ -38,6 +38,13 @@ class RegConfig(C.Structure):
                 ("sampler_seed", C.c_uint32)]
 
 
+class EsdfConfig(C.Structure):
+    """vgx_esdf_config == voxblox::EsdfIntegrator::Config (the fields used in batch mode)."""
+    _fields_ = [("max_distance_m", C.c_float), ("min_distance_m", C.c_float),
+                ("default_distance_m", C.c_float), ("min_diff_m", C.c_float),
+                ("min_weight", C.c_float), ("num_buckets", C.c_int32)]
+
+
 class TsdfConfig(C.Structure):
     """vgx_tsdf_config == voxblox::TsdfIntegratorBase::Config (the fields that matter on a GPU)."""
     _fields_ = [("default_truncation_distance", C.c_float), ("max_weight", C.c_float),
@@ -71,6 +78,9 @@ SIGNATURES = {
     "vgx_submap_num_points": (C.c_int64, [vp, C.c_int32]),
     "vgx_submap_point_order": (C.c_int, [vp, C.c_int32, i64p]),
     "vgx_submap_download_points": (C.c_int, [vp, C.c_int32, f32p, f32p, f32p]),
+    "vgx_esdf_config_default": (None, [C.POINTER(EsdfConfig)]),
+    "vgx_submap_generate_esdf": (C.c_int, [vp, C.POINTER(EsdfConfig), i32p]),
+    "vgx_submap_from_tsdf_layer": (C.c_int, [vp, vp, C.c_int32, C.POINTER(vp)]),
     "vgx_submap_release_raw_layers": (C.c_int, [vp]),
     "vgx_submap_download_layers": (C.c_int, [vp, f32p, f32p, f32p, u8p]),
     "vgx_submap_block_index": (C.c_int, [vp, i32p]),
@@ -225,6 +235,23 @@ class Submap:
             int(build_tsdf_grid), C.byref(h)))
         self.h = h
         return self
+
+    @classmethod
+    def from_tsdf_layer(cls, ctx, layer, submap_id):
+        """finishSubmap() hand-off on the device (no host round trip)."""
+        self = cls.__new__(cls)
+        self.ctx = ctx
+        h = vp()
+        ctx.check(ctx.lib.vgx_submap_from_tsdf_layer(ctx.h, layer.h, submap_id, C.byref(h)))
+        self.h = h
+        return self
+
+    def generate_esdf(self, config=None):
+        """cblox::TsdfEsdfSubmap::generateEsdf() on the device; returns global passes used."""
+        n = C.c_int32()
+        self.ctx.check(self.ctx.lib.vgx_submap_generate_esdf(
+            self.h, C.byref(config) if config is not None else None, C.byref(n)))
+        return n.value
 
     def num_blocks(self):
         return self.ctx.lib.vgx_submap_num_blocks(self.h)
@@ -401,6 +428,16 @@ def fused_size(n_nodes, n_global):
 # ----------------------------------------------------------------------------
 # TSDF path
 # ----------------------------------------------------------------------------
+def esdf_config(**kw):
+    cfg = EsdfConfig()
+    load().vgx_esdf_config_default(C.byref(cfg))
+    for k, v in kw.items():
+        if not hasattr(cfg, k):
+            raise AttributeError(k)
+        setattr(cfg, k, v)
+    return cfg
+
+
 def tsdf_config(**kw):
     cfg = TsdfConfig()
     load().vgx_tsdf_config_default(C.byref(cfg))

@@ -291,6 +291,16 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(TsdfLayerDev L, Tsd
   }
 }
 
+__global__ __launch_bounds__(256) void tsdf_unpack_kernel(const unsigned long long* __restrict__ voxels,
+                                                         size_t n, float* __restrict__ distance,
+                                                         float* __restrict__ weight) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long v = voxels[i];
+  distance[i] = __uint_as_float((unsigned)(v & 0xffffffffull));
+  weight[i] = __uint_as_float((unsigned)(v >> 32));
+}
+
 }  // namespace vgx
 
 using namespace vgx;
@@ -428,6 +438,55 @@ int vgx_tsdf_layer_download(vgx_tsdf_layer L, int32_t* block_index, float* dista
     }
   }
   if (rgba) VGX_HIP(ctx, hipMemcpy(rgba, L->dev.rgba, (size_t)nb * nvox * 4, hipMemcpyDeviceToHost));
+  return VGX_OK;
+}
+
+int vgx_submap_from_tsdf_layer(vgx_ctx ctx, vgx_tsdf_layer L, int32_t submap_id, vgx_submap* out) {
+  if (!ctx || !L || !out || L->ctx != ctx) return VGX_ERR_INVALID;
+  *out = nullptr;
+  int32_t nb = 0;
+  int rc = vgx_tsdf_layer_stats(L, &nb, nullptr);
+  if (rc != VGX_OK) return rc;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  vgx_submap sm = new (std::nothrow) vgx_submap_s();
+  if (!sm) return set_error(ctx, VGX_ERR_NOMEM, "vgx_submap_from_tsdf_layer: out of host memory");
+  const TsdfLayerDev& d = L->dev;
+  sm->ctx = ctx;
+  sm->id = submap_id;
+  sm->vps = d.vps;
+  sm->n_blocks = nb;
+  sm->voxel_size = d.voxel_size;
+  sm->voxel_size_inv = 1.0f / d.voxel_size;
+  sm->block_size = (float)d.vps * d.voxel_size;
+  sm->block_size_inv = 1.0f / sm->block_size;
+  sm->block_index.resize(3 * (size_t)nb);
+  if (nb > 0 && hipMemcpy(sm->block_index.data(), d.block_index, (size_t)nb * 12, hipMemcpyDeviceToHost) != hipSuccess)
+    rc = set_error(ctx, VGX_ERR_HIP, "vgx_submap_from_tsdf_layer: block index download failed");
+  if (rc == VGX_OK) rc = build_block_lut(sm);
+  if (rc == VGX_OK && nb > 0) {
+    const size_t nvox = (size_t)nb * d.vps * d.vps * d.vps;
+    if (hipMalloc(&sm->d_block_index, (size_t)nb * 12) != hipSuccess ||
+        hipMalloc(&sm->d_tsdf_distance, nvox * sizeof(float)) != hipSuccess ||
+        hipMalloc(&sm->d_tsdf_weight, nvox * sizeof(float)) != hipSuccess) {
+      rc = set_error(ctx, VGX_ERR_NOMEM, "vgx_submap_from_tsdf_layer: device allocation failed");
+    } else {
+      hipError_t e = hipMemcpyAsync(sm->d_block_index, d.block_index, (size_t)nb * 12,
+                                    hipMemcpyDeviceToDevice, ctx->stream);
+      if (e == hipSuccess) {
+        hipLaunchKernelGGL(tsdf_unpack_kernel, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0,
+                           ctx->stream, d.voxels, nvox, sm->d_tsdf_distance, sm->d_tsdf_weight);
+        e = hipGetLastError();
+      }
+      if (e != hipSuccess)
+        rc = set_error(ctx, VGX_ERR_HIP, std::string("vgx_submap_from_tsdf_layer: ") + hipGetErrorString(e));
+    }
+    if (rc == VGX_OK) rc = launch_brickify(sm, 0);
+  }
+  if (rc != VGX_OK) {
+    vgx_submap_destroy(sm);
+    return rc;
+  }
+  *out = sm;
   return VGX_OK;
 }
 
