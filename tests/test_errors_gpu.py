@@ -104,13 +104,15 @@ def test_tsdf_pool_and_box_limits_are_counted(capi, ctx):
     n = integ.integratePointCloud(T, np.array([[6.0, 0, 0]], F))
     blocks, dropped = layer.stats()
     assert blocks == 2 and n == 32 and dropped == 64 - 32
-    # big box, pool of 1 block: the second block cannot be allocated
+    # big box, pool of 1 block: rays are cast from the surface towards the sensor, so the
+    # far block (voxels 32, 33) gets the only pool slot and the other two are dropped
     layer2 = capi.TsdfLayer(ctx, 0.1, 16, (-2, -2, -2), (8, 4, 4), 1)
-    integ.setLayer(layer2)
-    n2 = integ.integratePointCloud(T, np.array([[3.0, 0, 0]], F))
+    # (a fresh integrator: the first scan's approximate set would make this ray stop early)
+    integ2 = capi.FastTsdfIntegrator(ctx, cfg, layer2)
+    n2 = integ2.integratePointCloud(T, np.array([[3.0, 0, 0]], F))
     blocks2, dropped2 = layer2.stats()
-    assert blocks2 == 1 and n2 == 16 and dropped2 == 34 - 16
+    assert blocks2 == 1 and n2 == 2 and dropped2 == 34 - 2
     with pytest.raises(capi.VgxError):
         capi.TsdfLayer(ctx, 0.1, 16, (0, 0, 0), (0, 1, 1), 8)
-    for o in (integ, layer, layer2):
+    for o in (integ, integ2, layer, layer2):
         o.destroy()

@@ -83,7 +83,7 @@ def test_scans_to_submaps_to_registration_solve(capi, ctx):
     traj_b = [(-0.2 + 0.2 * k, 0.1 - 0.05 * k, 0.35, 0.4 - 0.1 * k) for k in range(6)]
     sm_a, na = _build_submap(capi, ctx, true[0], traj_a, 0)
     sm_b, nb = _build_submap(capi, ctx, true[1], traj_b, 1)
-    assert na > 20000 and nb > 20000, (na, nb)
+    assert na > 15000 and nb > 15000, (na, nb)
     cfg = capi.default_config(registration_point_type=capi.POINTS_VOXELS)
     cfs = [capi.RegistrationCostFunction(ctx, sm_a, sm_b, cfg),
            capi.RegistrationCostFunction(ctx, sm_b, sm_a, cfg)]
