@@ -367,6 +367,18 @@ __global__ __launch_bounds__(kBlockThreads) void reg_eval_reduce_kernel(
 #pragma unroll
   for (int k = 0; k < 21; ++k) acc[k] = 0.0;
 
+  // The point stream is software-pipelined: iteration k+1's 20-byte points are requested
+  // before iteration k's dependent chain (block lookup -> brick gather -> arithmetic) runs,
+  // so the HBM stream stays in flight through all three latency phases.
+  f32x4 pt_next[PPT];
+  float w_next[PPT];
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) {
+    int local = j * kBlockThreads + (int)threadIdx.x;
+    int64_t i = tile.start + (local < tile.count ? local : 0);
+    pt_next[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[i];
+    w_next[j] = as_global(C.weight)[i];
+  }
   for (int base = 0; base < tile.count; base += kBlockThreads * PPT) {
     f32x4 pt[PPT];
     float w[PPT];
@@ -375,10 +387,17 @@ __global__ __launch_bounds__(kBlockThreads) void reg_eval_reduce_kernel(
     float d[PPT][8];
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
-      int local = base + j * kBlockThreads + (int)threadIdx.x;
-      int64_t i = tile.start + (local < tile.count ? local : 0);
-      pt[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[i];
-      w[j] = as_global(C.weight)[i];
+      pt[j] = pt_next[j];
+      w[j] = w_next[j];
+    }
+    if (base + kBlockThreads * PPT < tile.count) {
+#pragma unroll
+      for (int j = 0; j < PPT; ++j) {
+        int local = base + kBlockThreads * PPT + j * kBlockThreads + (int)threadIdx.x;
+        int64_t i = tile.start + (local < tile.count ? local : 0);
+        pt_next[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[i];
+        w_next[j] = as_global(C.weight)[i];
+      }
     }
 #pragma unroll
     for (int j = 0; j < PPT; ++j)
