@@ -109,6 +109,93 @@ class Problem:
             self._e_bb = _block_index(self._eb, self._eb)
             self._e_ab = _block_index(self._ea, self._eb)
 
+    # ---- reduced, permuted, banded form used by solve() ---------------------------
+    def _prepare_reduced(self):
+        """Index tables for assembling the free-variable normal equations directly in
+        symmetric banded storage (reverse Cuthill-McKee order over the node graph)."""
+        from scipy.sparse import coo_matrix
+        from scipy.sparse.csgraph import reverse_cuthill_mckee
+        n = self.n
+        free_node = np.zeros(n, bool)
+        free_node[np.unique(self.free // 4)] = True
+        pa = np.array([p[0] for p in self.pairs] + [e.a for e in self.edges], np.int64)
+        pb = np.array([p[1] for p in self.pairs] + [e.b for e in self.edges], np.int64)
+        adj = coo_matrix((np.ones(2 * len(pa)), (np.r_[pa, pb], np.r_[pb, pa])), shape=(n, n)).tocsr()
+        order = [int(k) for k in reverse_cuthill_mckee(adj, symmetric_mode=True) if free_node[k]]
+        node_pos = -np.ones(n, np.int64)
+        node_pos[order] = np.arange(len(order))
+        self._nf = 4 * len(order)
+        var_pos = -np.ones(4 * n, np.int64)           # full variable index -> reduced position
+        for k in range(4):
+            var_pos[4 * np.array(order) + k] = 4 * node_pos[order] + k
+        self._var_pos = var_pos
+        self._perm_full = np.argsort(np.where(var_pos >= 0, var_pos, 4 * n))[:self._nf]
+
+        def blocks(rows, cols):
+            r, c = _block_index(rows, cols)
+            return var_pos[r].ravel(), var_pos[c].ravel()
+
+        srcs = [blocks(np.arange(n), np.arange(n))]
+        qa = np.array([p[0] for p in self.pairs], np.int64)
+        qb = np.array([p[1] for p in self.pairs], np.int64)
+        srcs += [blocks(qa, qb), blocks(qb, qa)]
+        if self.edges:
+            srcs += [blocks(self._ea, self._ea), blocks(self._eb, self._eb),
+                     blocks(self._ea, self._eb), blocks(self._eb, self._ea)]
+        R = np.concatenate([x[0] for x in srcs])
+        Cc = np.concatenate([x[1] for x in srcs])
+        self._coo_keep = (R >= 0) & (Cc >= 0)
+        self._coo_r, self._coo_c = R[self._coo_keep], Cc[self._coo_keep]
+        self._u = int(np.abs(self._coo_r - self._coo_c).max()) if len(self._coo_r) else 0
+        upper = self._coo_r <= self._coo_c
+        self._band_sel = upper
+        self._band_flat = (self._u + self._coo_r[upper] - self._coo_c[upper]) * self._nf + self._coo_c[upper]
+
+    def evaluate_reduced(self, poses):
+        """-> (0.5 sum r^2, g_f [nf], (ab [u+1, nf] upper banded J^T J, coo values))"""
+        if not hasattr(self, "_nf"):
+            self._prepare_reduced()
+        buf = np.asarray(self.backend(poses))
+        self.evaluations += 1
+        n, m = self.n, len(self.pairs)
+        cost = float(buf[0])
+        g = np.array(buf[1:1 + 4 * n])
+        off = buf[1 + 20 * n:1 + 20 * n + 16 * m].reshape(m, 4, 4)
+        vals = [buf[1 + 4 * n:1 + 20 * n], off.ravel(), off.transpose(0, 2, 1).ravel()]
+        if self.edges:
+            ecost, eg_a, eg_b, aa, bb, ab = self._edge_terms(poses)
+            cost += ecost
+            np.add.at(g.reshape(-1, 4), self._ea, eg_a)
+            np.add.at(g.reshape(-1, 4), self._eb, eg_b)
+            vals += [aa.ravel(), bb.ravel(), ab.ravel(), ab.transpose(0, 2, 1).ravel()]
+        V = np.concatenate(vals)[self._coo_keep]
+        band = np.bincount(self._band_flat, weights=V[self._band_sel],
+                           minlength=(self._u + 1) * self._nf).reshape(self._u + 1, self._nf)
+        return 0.5 * cost, g[self._perm_full], (band, V)
+
+    def reduced_matvec(self, V, x):
+        return np.bincount(self._coo_r, weights=V * x[self._coo_c], minlength=self._nf)
+
+    def _edge_terms(self, poses):
+        pa, pb = poses[self._ea], poses[self._eb]
+        c, s = np.cos(pa[:, 3]), np.sin(pa[:, 3])
+        d = pb[:, :3] - pa[:, :3]
+        E = len(self._ea)
+        r = np.stack([c * d[:, 0] + s * d[:, 1] - self._et[:, 0],
+                      -s * d[:, 0] + c * d[:, 1] - self._et[:, 1],
+                      d[:, 2] - self._et[:, 2],
+                      normalize_angle(pb[:, 3] - pa[:, 3] - self._eyaw)], 1) * self._ew
+        Jb = np.zeros((E, 4, 4))
+        Jb[:, 0, 0], Jb[:, 0, 1], Jb[:, 1, 0], Jb[:, 1, 1], Jb[:, 2, 2], Jb[:, 3, 3] = c, s, -s, c, 1, 1
+        Ja = -Jb.copy()
+        Ja[:, 0, 3] = -s * d[:, 0] + c * d[:, 1]
+        Ja[:, 1, 3] = -c * d[:, 0] - s * d[:, 1]
+        Ja *= self._ew[:, :, None]
+        Jb *= self._ew[:, :, None]
+        return (float((r * r).sum()), np.einsum("eji,ej->ei", Ja, r), np.einsum("eji,ej->ei", Jb, r),
+                np.einsum("eki,ekj->eij", Ja, Ja), np.einsum("eki,ekj->eij", Jb, Jb),
+                np.einsum("eki,ekj->eij", Ja, Jb))
+
     def _edges(self, poses, g, H):
         """all RelativePoseEdge residuals / Jacobians at once (same arithmetic as
         RelativePoseEdge.evaluate)"""
@@ -180,44 +267,45 @@ def solve(problem, poses0, parameter_tolerance=3e-3, function_tolerance=1e-6,
 
 def _solve(problem, poses0, parameter_tolerance, function_tolerance, gradient_tolerance,
            max_iterations, max_seconds, initial_radius, verbose):
+    from scipy.linalg import solveh_banded
     t0 = time.perf_counter()
     x = np.array(poses0, np.float64).copy()
-    f = problem.free
-    cost, g, H = problem.evaluate(x)
+    cost, gf, (band, V) = problem.evaluate_reduced(x)
+    u, perm = problem._u, problem._perm_full
     radius, decrease = float(initial_radius), 2.0
     it, reason = 0, "max_iterations"
     history = [cost]
     while it < max_iterations:
         it += 1
-        gf, Hf = g[f], H[np.ix_(f, f)]
         if np.abs(gf).max() <= gradient_tolerance:
             reason = "gradient_tolerance"
             break
-        d2 = np.clip(np.diag(Hf), 1e-6, 1e32)
-        A = Hf + np.diag(d2 / radius)
+        d2 = np.clip(band[u], 1e-6, 1e32)
+        A = band.copy()
+        A[u] += d2 / radius
         try:
-            step = -_spd_solve(A, gf)
+            step = -solveh_banded(A, gf, lower=False, check_finite=False)
         except np.linalg.LinAlgError:
             radius /= decrease
             decrease *= 2
             continue
-        xf = x.ravel()[f]
+        xf = x.ravel()[perm]
         if np.linalg.norm(step) <= parameter_tolerance * (np.linalg.norm(xf) + parameter_tolerance):
             reason = "parameter_tolerance"
             break
         cand = x.copy().ravel()
-        cand[f] += step
+        cand[perm] += step
         cand = cand.reshape(-1, 4)
         cand[:, 3] = normalize_angle(cand[:, 3])
-        new_cost, new_g, new_H = problem.evaluate(cand)
-        model_decrease = -(gf @ step + 0.5 * step @ (Hf @ step))
+        new_cost, new_gf, (new_band, new_V) = problem.evaluate_reduced(cand)
+        model_decrease = -(gf @ step + 0.5 * step @ problem.reduced_matvec(V, step))
         rho = (cost - new_cost) / model_decrease if model_decrease > 0 else -1.0
         if verbose:
             print(f"  it {it}: cost {cost:.6e} -> {new_cost:.6e} rho {rho:.3f} radius {radius:.2e} "
                   f"|step| {np.linalg.norm(step):.3e}")
         if rho > 1e-3:
             rel = abs(cost - new_cost) / max(cost, 1e-300)
-            x, cost, g, H = cand, new_cost, new_g, new_H
+            x, cost, gf, band, V = cand, new_cost, new_gf, new_band, new_V
             history.append(cost)
             radius = min(radius / max(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3), 1e16)
             decrease = 2.0

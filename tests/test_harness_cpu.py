@@ -113,3 +113,38 @@ def test_vectorised_problem_matches_reference_assembly():
     np.testing.assert_allclose(g, g0, rtol=1e-10, atol=1e-10)
     np.testing.assert_allclose(Hm, H0, rtol=1e-10, atol=1e-10)
     assert np.allclose(Hm, Hm.T)
+
+
+def test_reduced_banded_form_matches_dense_normal_equations():
+    """evaluate_reduced (RCM order, banded storage) == evaluate (dense) on the free block."""
+    from scipy.linalg import solveh_banded
+    rng = np.random.default_rng(9)
+    n, pairs = 6, [(0, 1), (1, 0), (1, 2), (3, 4), (0, 4), (2, 3), (4, 5), (5, 2)]
+    normals = []
+    for _ in pairs:
+        J = rng.normal(0, 1, (40, 8)); r = rng.normal(0, 1, 40)
+        normals.append(np.concatenate([[r @ r], J.T @ r, (J.T @ J)[np.triu_indices(8)]]))
+    buf = assemble_fused(normals, pairs, n)
+    poses = rng.normal(0, 2, (n, 4))
+    edges = [lm.RelativePoseEdge(k, k + 1, rng.normal(0, 1, 3), rng.normal(0, 0.5),
+                                 [1.0, 1.0, 2500.0, 2500.0]) for k in range(n - 1)]
+    for const in ((0,), (2,), (0, 5)):
+        prob = lm.Problem(lambda p: buf, n, pairs, edges, constant_nodes=const)
+        cost, g, Hd = prob.evaluate(poses)
+        cost2, gf, (band, V) = prob.evaluate_reduced(poses)
+        f = prob._perm_full
+        assert sorted(f) == sorted(prob.free)
+        np.testing.assert_allclose(cost2, cost, rtol=1e-12)
+        np.testing.assert_allclose(gf, g[f], rtol=1e-12, atol=1e-12)
+        Hf = Hd[np.ix_(f, f)]
+        u = prob._u
+        dense_from_band = np.zeros_like(Hf)
+        for i in range(len(f)):
+            for j in range(i, min(len(f), i + u + 1)):
+                dense_from_band[i, j] = dense_from_band[j, i] = band[u + i - j, j]
+        np.testing.assert_allclose(dense_from_band, Hf, rtol=1e-10, atol=1e-9)
+        xv = rng.normal(0, 1, len(f))
+        np.testing.assert_allclose(prob.reduced_matvec(V, xv), Hf @ xv, rtol=1e-10, atol=1e-9)
+        A = band.copy(); A[u] += 10.0
+        np.testing.assert_allclose(solveh_banded(A, gf, lower=False),
+                                   np.linalg.solve(Hf + 10 * np.eye(len(f)), gf), rtol=1e-8, atol=1e-10)
