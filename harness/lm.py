@@ -15,6 +15,15 @@ returns the fused normal-equation buffer of SURVEY.md 8e:
 import time
 
 import numpy as np
+from scipy.linalg import solveh_banded
+from scipy.sparse import coo_matrix
+from scipy.sparse.csgraph import reverse_cuthill_mckee
+
+try:
+    from threadpoolctl import ThreadpoolController
+    _THREADPOOLS = None
+except ImportError:                                   # pragma: no cover
+    ThreadpoolController = None
 
 
 def normalize_angle(a):
@@ -113,8 +122,6 @@ class Problem:
     def _prepare_reduced(self):
         """Index tables for assembling the free-variable normal equations directly in
         symmetric banded storage (reverse Cuthill-McKee order over the node graph)."""
-        from scipy.sparse import coo_matrix
-        from scipy.sparse.csgraph import reverse_cuthill_mckee
         n = self.n
         free_node = np.zeros(n, bool)
         free_node[np.unique(self.free // 4)] = True
@@ -255,19 +262,19 @@ def solve(problem, poses0, parameter_tolerance=3e-3, function_tolerance=1e-6,
     The dense linear algebra runs on `blas_threads` threads (the reference gives Ceres
     num_threads = 4, pose_graph.cpp:96; an 800x800 Cholesky on every core of a 256-core
     host is an order of magnitude slower than on 4)."""
-    try:
-        from threadpoolctl import threadpool_limits
-        with threadpool_limits(limits=blas_threads):
-            return _solve(problem, poses0, parameter_tolerance, function_tolerance,
-                          gradient_tolerance, max_iterations, max_seconds, initial_radius, verbose)
-    except ImportError:
+    global _THREADPOOLS
+    if ThreadpoolController is None:
+        return _solve(problem, poses0, parameter_tolerance, function_tolerance,
+                      gradient_tolerance, max_iterations, max_seconds, initial_radius, verbose)
+    if _THREADPOOLS is None:
+        _THREADPOOLS = ThreadpoolController()         # scans the loaded libraries once
+    with _THREADPOOLS.limit(limits=blas_threads):
         return _solve(problem, poses0, parameter_tolerance, function_tolerance,
                       gradient_tolerance, max_iterations, max_seconds, initial_radius, verbose)
 
 
 def _solve(problem, poses0, parameter_tolerance, function_tolerance, gradient_tolerance,
            max_iterations, max_seconds, initial_radius, verbose):
-    from scipy.linalg import solveh_banded
     t0 = time.perf_counter()
     x = np.array(poses0, np.float64).copy()
     cost, gf, (band, V) = problem.evaluate_reduced(x)
