@@ -433,3 +433,34 @@ def test_explicit_stream_and_timer(capi, ctx, cfg1):
     assert 0 < ms < 1000 and abs(total - np.abs(r0).sum()) < 1e-3 * np.abs(r0).sum()
     ctx.set_stream(None)
     cf.destroy()
+
+
+def test_fused_pass_with_partial_overlap_culling_and_nonzero_no_correspondence_cost(capi, ctx):
+    """Far-apart submaps: most 512-point chunks are culled by their bounding sphere when
+    no_correspondence_cost == 0 (exact), and nothing is culled when it is != 0."""
+    sdf = synth.sphere_ground_sdf((0.3, -0.2, 0.1), 1.5, -1.0)
+    ref = synth.make_submap(sdf, 0.1, 16, (-3, -3, -2), (6, 6, 4), trunc=0.3, esdf_max=0.8)
+    read = synth.make_submap(sdf, 0.1, 16, (0, -1, -1), (3, 3, 3), trunc=0.3, esdf_max=0.8,
+                             pose=(0.4, 0.1, -0.2, 0.3))
+    g_ref, g_read = H.gpu_submap(capi, ctx, ref, 0), H.gpu_submap(capi, ctx, read, 1)
+    n = g_ref.extract_voxel_points()
+    xyz, dist, w = H.oracle_points(ref)
+    layer = H.oracle_layer(read)
+    poses = np.array([[0.0, 0.0, 0.0, 0.0], [0.45, 0.05, -0.22, 0.27]])
+    for ncc in (0.0, 0.37):
+        cfg = capi.default_config(registration_point_type=capi.POINTS_VOXELS, no_correspondence_cost=ncc)
+        cf = capi.RegistrationCostFunction(ctx, g_ref, g_read, cfg)
+        batch = capi.RegistrationBatch(ctx, [cf], [(0, 1)])
+        status, normal = batch.evaluate_normal(poses)
+        ok, cost, jtr, jtj = orc.reg_evaluate_normal(layer, xyz, dist, w, poses[0], poses[1],
+                                                     no_correspondence_cost=ncc)
+        ok2, r0, jo0, _ = orc.reg_evaluate(layer, xyz, dist, w, poses[0], poses[1],
+                                           no_correspondence_cost=ncc)
+        assert ok and 0.05 < np.any(jo0 != 0, axis=1).mean() < 0.6     # mostly outside
+        assert abs(normal[0, 0] - cost) <= 1e-6 * cost
+        assert np.all(np.abs(normal[0, 1:9] - jtr) <= 1e-6 * np.abs(jtr).max())
+        assert np.all(np.abs(normal[0, 9:] - jtj) <= 1e-6 * np.abs(jtj).max())
+        batch.destroy()
+        cf.destroy()
+    g_ref.destroy()
+    g_read.destroy()

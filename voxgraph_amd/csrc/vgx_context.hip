@@ -91,6 +91,49 @@ int launch_brickify(vgx_submap sm, int which) {
   return VGX_OK;
 }
 
+// Bounding sphere of every kChunkPoints consecutive registration points (one
+// wavefront per chunk).  The fused REG pass tests a chunk's sphere against the reading
+// grid's box before it requests the chunk's points at all.
+__global__ __launch_bounds__(64) void chunk_bounds_kernel(const float4* __restrict__ xyzd, long long n,
+                                                         float4* __restrict__ bounds) {
+  const long long first = (long long)blockIdx.x * kChunkPoints;
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (long long i = first + threadIdx.x; i < first + kChunkPoints && i < n; i += 64) {
+    float4 p = xyzd[i];
+    mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
+    mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
+    mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      mn[a] = fminf(mn[a], __shfl_xor(mn[a], off, 64));
+      mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off, 64));
+    }
+  if (threadIdx.x == 0) {
+    float hx = 0.5f * (mx[0] - mn[0]), hy = 0.5f * (mx[1] - mn[1]), hz = 0.5f * (mx[2] - mn[2]);
+    // radius rounded up generously: the test it feeds is conservative anyway
+    float r = sqrtf(hx * hx + hy * hy + hz * hz) * 1.0001f + 1e-4f;
+    bounds[blockIdx.x] = make_float4(0.5f * (mx[0] + mn[0]), 0.5f * (mx[1] + mn[1]),
+                                     0.5f * (mx[2] + mn[2]), r);
+  }
+}
+
+int build_chunk_bounds(vgx_ctx ctx, PointSet& ps) {
+  if (ps.d_chunk_bounds) {
+    (void)hipFree(ps.d_chunk_bounds);
+    ps.d_chunk_bounds = nullptr;
+  }
+  if (ps.n <= 0) return VGX_OK;
+  const long long chunks = (ps.n + kChunkPoints - 1) / kChunkPoints;
+  VGX_HIP(ctx, hipMalloc(&ps.d_chunk_bounds, (size_t)chunks * sizeof(float4)));
+  hipLaunchKernelGGL(chunk_bounds_kernel, dim3((unsigned)chunks), dim3(64), 0, ctx->stream, ps.d_xyzd,
+                     (long long)ps.n, ps.d_chunk_bounds);
+  VGX_HIP(ctx, hipGetLastError());
+  return VGX_OK;
+}
+
 // Dense block lookup table over the AABB of sm->block_index (host copy), uploaded
 // to sm->d_lut.  Stands in for voxblox's unordered_map<BlockIndex, Block::Ptr>.
 int build_block_lut(vgx_submap sm) {
@@ -300,6 +343,7 @@ int vgx_submap_create(vgx_ctx ctx, int32_t submap_id, float voxel_size, int32_t 
 static void free_points(PointSet& ps) {
   if (ps.d_xyzd) (void)hipFree(ps.d_xyzd);
   if (ps.d_weight) (void)hipFree(ps.d_weight);
+  if (ps.d_chunk_bounds) (void)hipFree(ps.d_chunk_bounds);
   ps = PointSet();
 }
 
@@ -438,7 +482,7 @@ int vgx_submap_set_points(vgx_submap sm, int32_t point_type, int64_t n, const fl
     VGX_HIP(ctx, hipMemcpy(ps.d_xyzd, h_xyzd.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice));
     VGX_HIP(ctx, hipMemcpy(ps.d_weight, h_w.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
   }
-  return VGX_OK;
+  return build_chunk_bounds(ctx, ps);
 }
 
 int64_t vgx_submap_num_points(vgx_submap sm, int32_t point_type) {

@@ -124,6 +124,7 @@ extern "C" int vgx_submap_extract_voxel_points(vgx_submap sm, double min_voxel_w
   VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (ps.d_xyzd) (void)hipFree(ps.d_xyzd);
   if (ps.d_weight) (void)hipFree(ps.d_weight);
+  if (ps.d_chunk_bounds) (void)hipFree(ps.d_chunk_bounds);
   ps = PointSet();
   ps.present = true;
   const int nb = sm->n_blocks;
@@ -192,6 +193,7 @@ extern "C" int vgx_submap_extract_voxel_points(vgx_submap sm, double min_voxel_w
   (void)hipFree(d_counts);
   (void)hipFree(d_wsum);
   (void)hipFree(d_offsets);
+  if (rc == VGX_OK) rc = build_chunk_bounds(ctx, ps);
   if (rc == VGX_OK && n_points_out) *n_points_out = ps.n;
   return rc;
 }

@@ -51,6 +51,7 @@ struct alignas(16) ConstraintDev {
   const float4* xyzd;       // reference submap's points {x,y,z,distance}
   const float* weight;      // ... weights
   const int32_t* sample_idx;  // sampling mode: indices into the point set, else null
+  const float4* chunk_bounds; // bounding spheres of consecutive kChunkPoints-point chunks
   int64_t n;                // num_residuals
   int64_t row0;             // first output row (stacked outputs)
   double factor;            // N / sum(w)                              (.cpp:274)
@@ -64,6 +65,7 @@ struct Tile {
   int64_t start;  // residual index within the constraint
 };
 
+constexpr int kChunkPoints = 512;   // culling granule of the fused pass (= 256 threads x 2)
 constexpr int kNormalSize = 45;     // per-constraint fused output (doubles)
 constexpr int kPartialSize = 22;    // 21 unique products + reserved
 
@@ -84,6 +86,7 @@ struct PointSet {
   int64_t n = 0;
   float4* d_xyzd = nullptr;
   float* d_weight = nullptr;
+  float4* d_chunk_bounds = nullptr;  // per kChunkPoints points: bounding sphere {cx,cy,cz,r}
   double sum_weight = 0;
   bool present = false;
   std::vector<int64_t> order;            // order[i] = uploaded index of point i (empty = identity)
@@ -189,6 +192,7 @@ void set_global_error(const std::string& msg);
 // kernels' launch wrappers implemented in the .hip files
 int launch_brickify(vgx_submap sm, int which);
 int build_block_lut(vgx_submap sm);
+int build_chunk_bounds(vgx_ctx ctx, PointSet& ps);
 void make_pose_pack(const double ref_pose[4], const double read_pose[4], PosePack* out);
 std::vector<Tile> make_tiles(int32_t constraint, int64_t n, int tile_points);
 constexpr int kBlockThreads = 256;

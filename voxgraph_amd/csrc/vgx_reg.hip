@@ -353,16 +353,39 @@ __global__ __launch_bounds__(kBlockThreads) void reg_eval_points_kernel(
 constexpr int kReduceIters = 8;  // a reduce tile = kTilePoints * kReduceIters residuals
 constexpr int kReducePointsPerThread = 2;  // measured: 3.72 / 3.29 / 3.41 ms per fused step at 4 / 2 / 1 (profiles/tune_fused.sh)
 
+// True when no point inside the sphere (centre in the reference frame) can have a
+// correspondence in grid g under pose pack P: the base block of p' is the block of p'
+// or its -1 neighbour, so p' must lie in [lut_min * bs, (lut_min + lut_dim + 1) * bs);
+// one voxel of slack covers the f32 rounding of the transformed centre.
+__device__ __forceinline__ bool chunk_outside(const GridDev& g, const PosePack& P, float4 sph) {
+  float uv0 = -(P.qz * sph.y), uv1 = P.qz * sph.x;
+  uv0 += uv0;
+  uv1 += uv1;
+  float cx = (sph.x + P.qw * uv0 - P.qz * uv1) + P.tx;
+  float cy = (sph.y + P.qw * uv1 + P.qz * uv0) + P.ty;
+  float cz = sph.z + P.tz;
+  float r = sph.w + g.voxel_size;
+  float lox = (float)g.lut_min[0] * g.block_size, hix = (float)(g.lut_min[0] + g.lut_dim[0] + 1) * g.block_size;
+  float loy = (float)g.lut_min[1] * g.block_size, hiy = (float)(g.lut_min[1] + g.lut_dim[1] + 1) * g.block_size;
+  float loz = (float)g.lut_min[2] * g.block_size, hiz = (float)(g.lut_min[2] + g.lut_dim[2] + 1) * g.block_size;
+  return cx + r < lox || cx - r > hix || cy + r < loy || cy - r > hiy || cz + r < loz || cz - r > hiz;
+}
+
 template <int VPS, int PPT>
 __global__ __launch_bounds__(kBlockThreads) void reg_eval_reduce_kernel(
     const ConstraintDev* __restrict__ cons, const PosePack* __restrict__ packs,
     const Tile* __restrict__ tiles, int n_tiles, double* __restrict__ partials) {
+  static_assert(kBlockThreads * PPT == kChunkPoints, "one inner iteration == one culling chunk");
   int t = swizzle_tile(blockIdx.x, n_tiles);
   if (t >= n_tiles) return;
   const Tile tile = tiles[t];
   const ConstraintDev& C = cons[tile.constraint];
   const PosePack P = packs[tile.constraint];
   const GridDev g = C.grid;
+  // Chunks that cannot overlap the reading grid are skipped without touching their
+  // points (exact: such points only add w * no_correspondence_cost, which must be 0).
+  const float4* bounds = (C.no_corr_cost == 0.0 && C.chunk_bounds) ? C.chunk_bounds : nullptr;
+  const long long chunk0 = tile.start / kChunkPoints;  // tiles start on chunk boundaries
   double acc[21];
 #pragma unroll
   for (int k = 0; k < 21; ++k) acc[k] = 0.0;
@@ -372,33 +395,42 @@ __global__ __launch_bounds__(kBlockThreads) void reg_eval_reduce_kernel(
   // so the HBM stream stays in flight through all three latency phases.
   f32x4 pt_next[PPT];
   float w_next[PPT];
+  bool live_next = !(bounds && chunk_outside(g, P, bounds[chunk0]));
+  if (live_next) {
 #pragma unroll
-  for (int j = 0; j < PPT; ++j) {
-    int local = j * kBlockThreads + (int)threadIdx.x;
-    int64_t i = tile.start + (local < tile.count ? local : 0);
-    pt_next[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[i];
-    w_next[j] = as_global(C.weight)[i];
+    for (int j = 0; j < PPT; ++j) {
+      int local = j * kBlockThreads + (int)threadIdx.x;
+      int64_t i = tile.start + (local < tile.count ? local : 0);
+      pt_next[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[i];
+      w_next[j] = as_global(C.weight)[i];
+    }
   }
-  for (int base = 0; base < tile.count; base += kBlockThreads * PPT) {
+  for (int base = 0, it = 0; base < tile.count; base += kChunkPoints, ++it) {
     f32x4 pt[PPT];
     float w[PPT];
     const float* cell[PPT];
     float Dx[PPT], Dy[PPT], Dz[PPT];
     float d[PPT][8];
+    const bool live = live_next;
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
       pt[j] = pt_next[j];
       w[j] = w_next[j];
     }
-    if (base + kBlockThreads * PPT < tile.count) {
+    live_next = false;
+    if (base + kChunkPoints < tile.count) {
+      live_next = !(bounds && chunk_outside(g, P, bounds[chunk0 + it + 1]));
+      if (live_next) {
 #pragma unroll
-      for (int j = 0; j < PPT; ++j) {
-        int local = base + kBlockThreads * PPT + j * kBlockThreads + (int)threadIdx.x;
-        int64_t i = tile.start + (local < tile.count ? local : 0);
-        pt_next[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[i];
-        w_next[j] = as_global(C.weight)[i];
+        for (int j = 0; j < PPT; ++j) {
+          int local = base + kChunkPoints + j * kBlockThreads + (int)threadIdx.x;
+          int64_t i = tile.start + (local < tile.count ? local : 0);
+          pt_next[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[i];
+          w_next[j] = as_global(C.weight)[i];
+        }
       }
     }
+    if (!live) continue;
 #pragma unroll
     for (int j = 0; j < PPT; ++j)
       cell[j] = locate_point<VPS>(g, P, pt[j].x, pt[j].y, pt[j].z, Dx[j], Dy[j], Dz[j]);
@@ -597,6 +629,7 @@ vgx::ConstraintDev vgx_reg_s::describe() const {
   c.xyzd = ps.d_xyzd;
   c.weight = ps.d_weight;
   c.sample_idx = d_sample_idx;
+  c.chunk_bounds = ps.d_chunk_bounds;
   c.n = num_residuals;
   c.row0 = 0;
   // RCF:274: num_residuals / summed_reference_weight; sampled points weigh 1
@@ -988,23 +1021,12 @@ int vgx_reg_batch_evaluate_normal(vgx_reg_batch b, const double* poses, int32_t 
   const int n_tiles = (int)ex->reduce_tiles.size();
   if (n_tiles > 0) {
     dim3 grid(((n_tiles + 7) / 8) * 8), block(kBlockThreads);
-    // points per thread per inner iteration: tuning knob (VGX_REDUCE_PPT = 1, 2, 4)
-    static const int ppt = [] {
-      const char* e = getenv("VGX_REDUCE_PPT");
-      int v = e ? atoi(e) : kReducePointsPerThread;
-      return (v == 1 || v == 2 || v == 4) ? v : kReducePointsPerThread;
-    }();
-    const bool v16 = b->regs[0]->reading->vps == 16;
-#define VGX_LAUNCH_REDUCE(VPS, PPT)                                                               \
-  hipLaunchKernelGGL((reg_eval_reduce_kernel<VPS, PPT>), grid, block, 0, ctx->stream, b->d_desc, \
-                     b->d_pack, ex->d_reduce_tiles, n_tiles, b->d_partials)
-    if (v16 && ppt == 4) VGX_LAUNCH_REDUCE(16, 4);
-    else if (v16 && ppt == 2) VGX_LAUNCH_REDUCE(16, 2);
-    else if (v16) VGX_LAUNCH_REDUCE(16, 1);
-    else if (ppt == 4) VGX_LAUNCH_REDUCE(8, 4);
-    else if (ppt == 2) VGX_LAUNCH_REDUCE(8, 2);
-    else VGX_LAUNCH_REDUCE(8, 1);
-#undef VGX_LAUNCH_REDUCE
+    if (b->regs[0]->reading->vps == 16)
+      hipLaunchKernelGGL((reg_eval_reduce_kernel<16, kReducePointsPerThread>), grid, block, 0,
+                         ctx->stream, b->d_desc, b->d_pack, ex->d_reduce_tiles, n_tiles, b->d_partials);
+    else
+      hipLaunchKernelGGL((reg_eval_reduce_kernel<8, kReducePointsPerThread>), grid, block, 0,
+                         ctx->stream, b->d_desc, b->d_pack, ex->d_reduce_tiles, n_tiles, b->d_partials);
     VGX_HIP(ctx, hipGetLastError());
   }
   hipLaunchKernelGGL(reg_finalize_kernel, dim3(b->n), dim3(256), 0, ctx->stream, b->d_desc,
