@@ -351,6 +351,7 @@ __global__ __launch_bounds__(kBlockThreads) void reg_eval_points_kernel(
 // u = (jo0, jo1, jo2, jo3, je3, r): [J r]^T [J r] (9x9) is a signed
 // re-arrangement of the 21 unique products of u because je0..2 == -jo0..2.
 constexpr int kReduceIters = 8;  // a reduce tile = kTilePoints * kReduceIters residuals
+constexpr int kMaxReduceIters = 64;
 constexpr int kReducePointsPerThread = 2;  // measured: 3.72 / 3.29 / 3.41 ms per fused step at 4 / 2 / 1 (profiles/tune_fused.sh)
 
 // True when no point inside the sphere (centre in the reference frame) can have a
@@ -386,6 +387,13 @@ __global__ __launch_bounds__(kBlockThreads) void reg_eval_reduce_kernel(
   // points (exact: such points only add w * no_correspondence_cost, which must be 0).
   const float4* bounds = (C.no_corr_cost == 0.0 && C.chunk_bounds) ? C.chunk_bounds : nullptr;
   const long long chunk0 = tile.start / kChunkPoints;  // tiles start on chunk boundaries
+  // one flag per chunk of this tile, decided up front by one thread each (a tile holds
+  // at most kMaxReduceIters * 2 chunks): the main loop then never waits on a bounds load
+  __shared__ unsigned char s_live[kMaxReduceIters * 2];
+  const int n_chunks = (tile.count + kChunkPoints - 1) / kChunkPoints;
+  if ((int)threadIdx.x < n_chunks)
+    s_live[threadIdx.x] = !(bounds && chunk_outside(g, P, bounds[chunk0 + threadIdx.x]));
+  __syncthreads();
   double acc[21];
 #pragma unroll
   for (int k = 0; k < 21; ++k) acc[k] = 0.0;
@@ -395,7 +403,7 @@ __global__ __launch_bounds__(kBlockThreads) void reg_eval_reduce_kernel(
   // so the HBM stream stays in flight through all three latency phases.
   f32x4 pt_next[PPT];
   float w_next[PPT];
-  bool live_next = !(bounds && chunk_outside(g, P, bounds[chunk0]));
+  bool live_next = s_live[0] != 0;
   if (live_next) {
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
@@ -419,7 +427,7 @@ __global__ __launch_bounds__(kBlockThreads) void reg_eval_reduce_kernel(
     }
     live_next = false;
     if (base + kChunkPoints < tile.count) {
-      live_next = !(bounds && chunk_outside(g, P, bounds[chunk0 + it + 1]));
+      live_next = s_live[it + 1] != 0;
       if (live_next) {
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
@@ -880,7 +888,7 @@ int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs, const int3
   int64_t total_residuals = 0;
   for (int c = 0; c < n; ++c) total_residuals += regs[c]->num_residuals;
   const int reduce_iters =
-      (int)std::min<int64_t>(64, std::max<int64_t>(kReduceIters, total_residuals / ((int64_t)kTilePoints * 16384)));
+      (int)std::min<int64_t>(kMaxReduceIters, std::max<int64_t>(kReduceIters, total_residuals / ((int64_t)kTilePoints * 16384)));
   int max_node = -1;
   for (int c = 0; c < n; ++c) {
     desc[(size_t)c] = regs[c]->describe();
