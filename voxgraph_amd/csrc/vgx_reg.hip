@@ -282,7 +282,31 @@ __device__ __forceinline__ int swizzle_tile(int b, int n_tiles) {
 // ---------------------------------------------------------------------------
 // kernel 1: materialise residuals + Jacobians (88 B / evaluation as f32)
 // ---------------------------------------------------------------------------
-template <int VPS, typename OUT, int PPT>
+// Registration points are read exactly once per constraint evaluation: stream them with
+// the non-temporal hint (A/B switch VGX_NT_LOADS, compile-time default below).
+template <bool NT, typename T>
+__device__ __forceinline__ T load_stream(const VGX_GLOBAL T* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p); else return *p;
+}
+
+// Output rows are written once and never re-read by this kernel: with NT the stores
+// carry the non-temporal hint so the 36 B/row write stream does not evict the bricks
+// and block tables the gathers re-use from L2.
+template <bool NT, typename T>
+__device__ __forceinline__ void store_out(T* p, T v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v;
+}
+template <bool NT>
+__device__ __forceinline__ void store_out4(float4* p, float4 v) {
+  f32x4 x = {v.x, v.y, v.z, v.w};
+  if constexpr (NT) __builtin_nontemporal_store(x, reinterpret_cast<f32x4*>(p)); else *p = v;
+}
+template <bool NT>
+__device__ __forceinline__ void store_out4(double4* p, double4 v) {
+  *p = v;  // drop-in f64 path: followed by a D2H copy, keep it cacheable
+}
+
+template <int VPS, typename OUT, int PPT, bool NT, bool NTL>
 __global__ __launch_bounds__(kBlockThreads) void reg_eval_points_kernel(
     const ConstraintDev* __restrict__ cons, const PosePack* __restrict__ packs,
     const Tile* __restrict__ tiles, int n_tiles, OUT* __restrict__ residuals,
@@ -311,8 +335,8 @@ __global__ __launch_bounds__(kBlockThreads) void reg_eval_points_kernel(
       pt[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[s];
       w[j] = 1.0f;  // RCF:121
     } else {
-      pt[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[i];
-      w[j] = as_global(C.weight)[i];
+      pt[j] = load_stream<NTL>(as_global(reinterpret_cast<const f32x4*>(C.xyzd)) + i);
+      w[j] = load_stream<NTL>(as_global(C.weight) + i);
     }
   }
 #pragma unroll
@@ -335,13 +359,13 @@ __global__ __launch_bounds__(kBlockThreads) void reg_eval_points_kernel(
                              pt[j].x, pt[j].y, pt[j].w, w[j], C.no_corr_cost, want_jac);
     int64_t row = C.row0 + tile.start + local;
     const double f = C.factor;  // RCF:274-291
-    residuals[row] = (OUT)(e.r * f);
+    store_out<NT>(&residuals[row], (OUT)(e.r * f));
     if (jac_ref)
-      jac_ref[row] = Out4<OUT>::make((double)e.jo0 * f, (double)e.jo1 * f, (double)e.jo2 * f,
-                                     (double)e.jo3 * f);
+      store_out4<NT>(&jac_ref[row], Out4<OUT>::make((double)e.jo0 * f, (double)e.jo1 * f,
+                                                    (double)e.jo2 * f, (double)e.jo3 * f));
     if (jac_read)
-      jac_read[row] = Out4<OUT>::make((double)-e.jo0 * f, (double)-e.jo1 * f, (double)-e.jo2 * f,
-                                      (double)e.je3 * f);
+      store_out4<NT>(&jac_read[row], Out4<OUT>::make((double)-e.jo0 * f, (double)-e.jo1 * f,
+                                                     (double)-e.jo2 * f, (double)e.je3 * f));
   }
 }
 
@@ -351,6 +375,8 @@ __global__ __launch_bounds__(kBlockThreads) void reg_eval_points_kernel(
 // u = (jo0, jo1, jo2, jo3, je3, r): [J r]^T [J r] (9x9) is a signed
 // re-arrangement of the 21 unique products of u because je0..2 == -jo0..2.
 constexpr int kReduceIters = 8;  // a reduce tile = kTilePoints * kReduceIters residuals
+constexpr bool kNonTemporalLoads = false;  // A/B: VGX_NT_LOADS=1
+constexpr bool kNonTemporalStores = true;  // measured 6.08 -> 5.40 ms (profiles/ab_nt.sh, VGX_NT_STORES=0/1)
 constexpr int kMaxReduceIters = 64;
 constexpr int kReducePointsPerThread = 2;  // measured: 3.72 / 3.29 / 3.41 ms per fused step at 4 / 2 / 1 (profiles/tune_fused.sh)
 
@@ -372,7 +398,7 @@ __device__ __forceinline__ bool chunk_outside(const GridDev& g, const PosePack& 
   return cx + r < lox || cx - r > hix || cy + r < loy || cy - r > hiy || cz + r < loz || cz - r > hiz;
 }
 
-template <int VPS, int PPT>
+template <int VPS, int PPT, bool NTL>
 __global__ __launch_bounds__(kBlockThreads) void reg_eval_reduce_kernel(
     const ConstraintDev* __restrict__ cons, const PosePack* __restrict__ packs,
     const Tile* __restrict__ tiles, int n_tiles, double* __restrict__ partials) {
@@ -409,8 +435,8 @@ __global__ __launch_bounds__(kBlockThreads) void reg_eval_reduce_kernel(
     for (int j = 0; j < PPT; ++j) {
       int local = j * kBlockThreads + (int)threadIdx.x;
       int64_t i = tile.start + (local < tile.count ? local : 0);
-      pt_next[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[i];
-      w_next[j] = as_global(C.weight)[i];
+      pt_next[j] = load_stream<NTL>(as_global(reinterpret_cast<const f32x4*>(C.xyzd)) + i);
+      w_next[j] = load_stream<NTL>(as_global(C.weight) + i);
     }
   }
   for (int base = 0, it = 0; base < tile.count; base += kChunkPoints, ++it) {
@@ -433,8 +459,8 @@ __global__ __launch_bounds__(kBlockThreads) void reg_eval_reduce_kernel(
         for (int j = 0; j < PPT; ++j) {
           int local = base + kChunkPoints + j * kBlockThreads + (int)threadIdx.x;
           int64_t i = tile.start + (local < tile.count ? local : 0);
-          pt_next[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[i];
-          w_next[j] = as_global(C.weight)[i];
+          pt_next[j] = load_stream<NTL>(as_global(reinterpret_cast<const f32x4*>(C.xyzd)) + i);
+          w_next[j] = load_stream<NTL>(as_global(C.weight) + i);
         }
       }
     }
@@ -614,12 +640,27 @@ static void launch_points(vgx_ctx ctx, int vps, const ConstraintDev* d_desc, con
   if (n_tiles <= 0) return;
   dim3 grid(((n_tiles + 7) / 8) * 8), block(kBlockThreads);
   using O4 = typename Out4<OUT>::type;
-  if (vps == 16)
-    hipLaunchKernelGGL((reg_eval_points_kernel<16, OUT, kPointsPerThread>), grid, block, 0,
-                       ctx->stream, d_desc, d_pack, d_tiles, n_tiles, (OUT*)res, (O4*)jr, (O4*)je);
-  else
-    hipLaunchKernelGGL((reg_eval_points_kernel<8, OUT, kPointsPerThread>), grid, block, 0,
-                       ctx->stream, d_desc, d_pack, d_tiles, n_tiles, (OUT*)res, (O4*)jr, (O4*)je);
+  static const bool nt = [] {
+    const char* e = getenv("VGX_NT_STORES");
+    return e ? atoi(e) != 0 : kNonTemporalStores;
+  }();
+  static const bool ntl = [] {
+    const char* e = getenv("VGX_NT_LOADS");
+    return e ? atoi(e) != 0 : kNonTemporalLoads;
+  }();
+#define VGX_LAUNCH_POINTS(VPS, NT, NTL)                                                             \
+  hipLaunchKernelGGL((reg_eval_points_kernel<VPS, OUT, kPointsPerThread, NT, NTL>), grid, block, 0, \
+                     ctx->stream, d_desc, d_pack, d_tiles, n_tiles, (OUT*)res, (O4*)jr, (O4*)je)
+  if (vps == 16) {
+    if (nt && ntl) VGX_LAUNCH_POINTS(16, true, true);
+    else if (nt) VGX_LAUNCH_POINTS(16, true, false);
+    else if (ntl) VGX_LAUNCH_POINTS(16, false, true);
+    else VGX_LAUNCH_POINTS(16, false, false);
+  } else {
+    if (nt) VGX_LAUNCH_POINTS(8, true, kNonTemporalLoads);
+    else VGX_LAUNCH_POINTS(8, false, kNonTemporalLoads);
+  }
+#undef VGX_LAUNCH_POINTS
 }
 
 }  // namespace vgx
@@ -1029,12 +1070,19 @@ int vgx_reg_batch_evaluate_normal(vgx_reg_batch b, const double* poses, int32_t 
   const int n_tiles = (int)ex->reduce_tiles.size();
   if (n_tiles > 0) {
     dim3 grid(((n_tiles + 7) / 8) * 8), block(kBlockThreads);
-    if (b->regs[0]->reading->vps == 16)
-      hipLaunchKernelGGL((reg_eval_reduce_kernel<16, kReducePointsPerThread>), grid, block, 0,
-                         ctx->stream, b->d_desc, b->d_pack, ex->d_reduce_tiles, n_tiles, b->d_partials);
-    else
-      hipLaunchKernelGGL((reg_eval_reduce_kernel<8, kReducePointsPerThread>), grid, block, 0,
-                         ctx->stream, b->d_desc, b->d_pack, ex->d_reduce_tiles, n_tiles, b->d_partials);
+    static const bool ntl = [] {
+      const char* e = getenv("VGX_NT_LOADS");
+      return e ? atoi(e) != 0 : kNonTemporalLoads;
+    }();
+#define VGX_LAUNCH_REDUCE(VPS, NTL)                                                                 \
+  hipLaunchKernelGGL((reg_eval_reduce_kernel<VPS, kReducePointsPerThread, NTL>), grid, block, 0,   \
+                     ctx->stream, b->d_desc, b->d_pack, ex->d_reduce_tiles, n_tiles, b->d_partials)
+    if (b->regs[0]->reading->vps == 16) {
+      if (ntl) VGX_LAUNCH_REDUCE(16, true); else VGX_LAUNCH_REDUCE(16, false);
+    } else {
+      if (ntl) VGX_LAUNCH_REDUCE(8, true); else VGX_LAUNCH_REDUCE(8, false);
+    }
+#undef VGX_LAUNCH_REDUCE
     VGX_HIP(ctx, hipGetLastError());
   }
   hipLaunchKernelGGL(reg_finalize_kernel, dim3(b->n), dim3(256), 0, ctx->stream, b->d_desc,
