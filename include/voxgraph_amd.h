@@ -118,6 +118,18 @@ VGX_API int vgx_submap_extract_voxel_points(vgx_submap submap,
                                             double max_voxel_distance,
                                             int32_t use_esdf_distance,
                                             int64_t* n_points_out);
+/* Device-side VoxgraphSubmap::findIsosurfaceVertices (voxgraph_submap.cpp:203-243), the
+ * VGX_POINTS_ISOSURFACE set the shipped "explicit_to_implicit" method registers with:
+ * zero crossings of the TSDF along the edges of every fully observed dual cell (all 8
+ * corner voxels with weight > min_weight: voxblox MeshIntegrator), merged per
+ * 0.5-voxel cell (MeshLayer::getConnectedMesh(mesh, 0.5 * voxel_size)), each carrying the
+ * trilinearly interpolated TSDF distance and weight (Interpolator::getVoxel).  Which of
+ * several vertices in one cell survives is implementation-defined in the reference
+ * (unordered_map order); here it is the first in (block, linear index, axis) order.
+ * Needs the raw TSDF layer.  Also records the blocks that contain vertices
+ * (isosurface_blocks_, voxgraph_submap.cpp:237-240). */
+VGX_API int vgx_submap_extract_isosurface_points(vgx_submap submap, double min_voxel_weight,
+                                                 int64_t* n_points_out);
 VGX_API int64_t vgx_submap_num_points(vgx_submap submap, int32_t point_type);
 /* order[i] = index (in upload / extraction order) of the point residual i uses */
 VGX_API int vgx_submap_point_order(vgx_submap submap, int32_t point_type,

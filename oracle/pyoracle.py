@@ -388,3 +388,24 @@ def esdf_from_tsdf(voxel_size, vps, block_index, tsdf_distance, tsdf_weight, con
     if n < 0:
         raise MemoryError("orc_esdf_from_tsdf_batch")
     return ed, eo, n
+
+
+# ----------------------------------------------------------------------------
+# isosurface registration points (oracle/iso_oracle.c)
+# ----------------------------------------------------------------------------
+def isosurface_points(voxel_size, vps, block_index, tsdf_distance, tsdf_weight, min_weight=1.0):
+    """VoxgraphSubmap::findIsosurfaceVertices -> (xyz[n,3], distance[n], weight[n])."""
+    L = lib()
+    L.orc_isosurface_points.argtypes = [C.c_float, C.c_int, C.c_int, c_i32p, c_f32p, c_f32p,
+                                        C.c_float, c_f32p, c_f32p, c_f32p]
+    L.orc_isosurface_points.restype = C.c_int64
+    bi = np.ascontiguousarray(block_index, np.int32).reshape(-1, 3)
+    td, tw = _f32(tsdf_distance), _f32(tsdf_weight)
+    args = (float(np.float32(voxel_size)), vps, bi.shape[0], _p(bi, c_i32p), _p(td, c_f32p),
+            _p(tw, c_f32p), float(min_weight))
+    n = L.orc_isosurface_points(*args, None, None, None)
+    if n < 0:
+        raise MemoryError("orc_isosurface_points")
+    xyz, d, w = np.zeros((n, 3), np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    L.orc_isosurface_points(*args, _p(xyz, c_f32p), _p(d, c_f32p), _p(w, c_f32p))
+    return xyz, d, w

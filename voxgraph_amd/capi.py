@@ -75,6 +75,7 @@ SIGNATURES = {
     "vgx_submap_num_blocks": (C.c_int32, [vp]),
     "vgx_submap_set_points": (C.c_int, [vp, C.c_int32, C.c_int64, f32p, f32p, f32p, C.c_uint32]),
     "vgx_submap_extract_voxel_points": (C.c_int, [vp, C.c_double, C.c_double, C.c_int32, i64p]),
+    "vgx_submap_extract_isosurface_points": (C.c_int, [vp, C.c_double, i64p]),
     "vgx_submap_num_points": (C.c_int64, [vp, C.c_int32]),
     "vgx_submap_point_order": (C.c_int, [vp, C.c_int32, i64p]),
     "vgx_submap_download_points": (C.c_int, [vp, C.c_int32, f32p, f32p, f32p]),
@@ -282,6 +283,12 @@ class Submap:
         n = C.c_int64()
         self.ctx.check(self.ctx.lib.vgx_submap_extract_voxel_points(
             self.h, min_voxel_weight, max_voxel_distance, int(use_esdf_distance), C.byref(n)))
+        return n.value
+
+    def extract_isosurface_points(self, min_voxel_weight=1.0):
+        n = C.c_int64()
+        self.ctx.check(self.ctx.lib.vgx_submap_extract_isosurface_points(
+            self.h, min_voxel_weight, C.byref(n)))
         return n.value
 
     def num_points(self, point_type):

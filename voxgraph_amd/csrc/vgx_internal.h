@@ -121,6 +121,7 @@ struct vgx_submap_s {
   uint8_t* d_esdf_observed = nullptr;
   vgx::Grid grid[2];       // [0] TSDF, [1] ESDF sampling grids
   vgx::PointSet points[2]; // by VGX_POINTS_*
+  std::vector<int32_t> isosurface_blocks;  // block slots holding isosurface vertices (VSM:237-240)
   vgx::GridDev grid_dev(int which) const;
 };
 
