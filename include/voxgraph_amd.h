@@ -280,6 +280,26 @@ VGX_API int vgx_reg_batch_assemble(vgx_reg_batch batch, const void* d_normal,
                                    int32_t zero_first);
 VGX_API int64_t vgx_reg_fused_size(int32_t n_nodes, int32_t n_global);
 
+/* ---- overlap detection (callers' side of REG) -------------------------- */
+/* VoxgraphSubmap::getSubmapFrameSurfaceObb (voxgraph_submap.cpp:280-321): box around the
+ * kVoxels registration voxels (centres -+ half a voxel), submap frame.  Needs the
+ * VGX_POINTS_VOXELS set.  Returns VGX_ERR_INVALID when the set is empty. */
+VGX_API int vgx_submap_surface_obb(vgx_submap submap, float min_xyz[3], float max_xyz[3]);
+/* VoxgraphSubmap::getMissionFrameSurfaceAabb = BoundingBox::getAabbFromObbAndPose
+ * (bounding_box.cpp:28-42) for a 4-DoF pose {x,y,z,yaw}. */
+VGX_API int vgx_submap_mission_surface_aabb(vgx_submap submap, const double pose[4],
+                                            float min_xyz[3], float max_xyz[3]);
+/* PoseGraphInterface::updateOverlappingSubmapList (pose_graph_interface.cpp:109-147) over
+ * VoxgraphSubmap::overlapsWith (voxgraph_submap.cpp:245-278): all pairs i < j whose
+ * mission-frame surface AABBs intersect and for which at least one isosurface block
+ * centre of submap i, carried into submap j's frame, falls in an allocated block of j.
+ * The AABB stage runs on the host, the block stage is one launch over the surviving pairs.
+ * Needs both point sets on every submap.  pairs: [max_pairs][2] indices into `submaps`,
+ * in the reference's loop order. */
+VGX_API int vgx_find_overlapping_pairs(vgx_ctx ctx, int32_t n, const vgx_submap* submaps,
+                                       const double* poses /* [n][4] */, int32_t* pairs,
+                                       int32_t max_pairs, int32_t* n_pairs);
+
 /* ---- TSDF: voxblox::FastTsdfIntegrator ---------------------------------- */
 /* Replaces the integrator voxgraph constructs and drives at
  * voxgraph/src/frontend/measurement_processors/pointcloud_integrator.cpp:66-83

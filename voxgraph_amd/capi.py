@@ -103,6 +103,9 @@ SIGNATURES = {
     "vgx_reg_batch_evaluate_normal": (C.c_int, [vp, f64p, C.c_int32, vp, f64p, i32p]),
     "vgx_reg_batch_assemble": (C.c_int, [vp, vp, C.c_int32, vp, C.c_int32]),
     "vgx_reg_fused_size": (C.c_int64, [C.c_int32, C.c_int32]),
+    "vgx_submap_surface_obb": (C.c_int, [vp, f32p, f32p]),
+    "vgx_submap_mission_surface_aabb": (C.c_int, [vp, f64p, f32p, f32p]),
+    "vgx_find_overlapping_pairs": (C.c_int, [vp, C.c_int32, C.POINTER(vp), f64p, i32p, C.c_int32, i32p]),
     "vgx_tsdf_config_default": (None, [C.POINTER(TsdfConfig)]),
     "vgx_tsdf_layer_create": (C.c_int, [vp, C.c_float, C.c_int32, i32p, i32p, C.c_int32, C.POINTER(vp)]),
     "vgx_tsdf_layer_destroy": (C.c_int, [vp]),
@@ -291,6 +294,17 @@ class Submap:
             self.h, min_voxel_weight, C.byref(n)))
         return n.value
 
+    def surface_obb(self):
+        mn, mx = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        self.ctx.check(self.ctx.lib.vgx_submap_surface_obb(self.h, _ptr(mn, f32p), _ptr(mx, f32p)))
+        return mn, mx
+
+    def mission_surface_aabb(self, pose):
+        mn, mx = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        self.ctx.check(self.ctx.lib.vgx_submap_mission_surface_aabb(
+            self.h, _ptr(_f64(pose), f64p), _ptr(mn, f32p), _ptr(mx, f32p)))
+        return mn, mx
+
     def num_points(self, point_type):
         return self.ctx.lib.vgx_submap_num_points(self.h, point_type)
 
@@ -426,6 +440,19 @@ class RegistrationBatch:
         if self.h:
             self.ctx.lib.vgx_reg_batch_destroy(self.h)
             self.h = None
+
+
+def find_overlapping_pairs(ctx, submaps, poses, max_pairs=None):
+    """PoseGraphInterface::updateOverlappingSubmapList -> [(i, j)] with i < j."""
+    n = len(submaps)
+    arr = (vp * max(n, 1))(*[s.h for s in submaps])
+    poses = _f64(poses).reshape(-1, 4)
+    max_pairs = n * (n - 1) // 2 if max_pairs is None else max_pairs
+    pairs = np.zeros((max(max_pairs, 1), 2), np.int32)
+    k = C.c_int32()
+    ctx.check(ctx.lib.vgx_find_overlapping_pairs(ctx.h, n, arr, _ptr(poses, f64p), _ptr(pairs, i32p),
+                                                 max_pairs, C.byref(k)))
+    return [tuple(int(x) for x in p) for p in pairs[:k.value]]
 
 
 def fused_size(n_nodes, n_global):

@@ -95,7 +95,8 @@ int launch_brickify(vgx_submap sm, int which) {
 // wavefront per chunk).  The fused REG pass tests a chunk's sphere against the reading
 // grid's box before it requests the chunk's points at all.
 __global__ __launch_bounds__(64) void chunk_bounds_kernel(const float4* __restrict__ xyzd, long long n,
-                                                         float4* __restrict__ bounds) {
+                                                         float4* __restrict__ bounds,
+                                                         float* __restrict__ chunk_minmax) {
   const long long first = (long long)blockIdx.x * kChunkPoints;
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
   for (long long i = first + threadIdx.x; i < first + kChunkPoints && i < n; i += 64) {
@@ -117,6 +118,11 @@ __global__ __launch_bounds__(64) void chunk_bounds_kernel(const float4* __restri
     float r = sqrtf(hx * hx + hy * hy + hz * hz) * 1.0001f + 1e-4f;
     bounds[blockIdx.x] = make_float4(0.5f * (mx[0] + mn[0]), 0.5f * (mx[1] + mn[1]),
                                      0.5f * (mx[2] + mn[2]), r);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      chunk_minmax[6 * blockIdx.x + a] = mn[a];
+      chunk_minmax[6 * blockIdx.x + 3 + a] = mx[a];
+    }
   }
 }
 
@@ -128,9 +134,26 @@ int build_chunk_bounds(vgx_ctx ctx, PointSet& ps) {
   if (ps.n <= 0) return VGX_OK;
   const long long chunks = (ps.n + kChunkPoints - 1) / kChunkPoints;
   VGX_HIP(ctx, hipMalloc(&ps.d_chunk_bounds, (size_t)chunks * sizeof(float4)));
+  float* d_minmax = nullptr;
+  VGX_HIP(ctx, hipMalloc(&d_minmax, (size_t)chunks * 6 * sizeof(float)));
   hipLaunchKernelGGL(chunk_bounds_kernel, dim3((unsigned)chunks), dim3(64), 0, ctx->stream, ps.d_xyzd,
-                     (long long)ps.n, ps.d_chunk_bounds);
-  VGX_HIP(ctx, hipGetLastError());
+                     (long long)ps.n, ps.d_chunk_bounds, d_minmax);
+  // exact AABB of the point positions (feeds getSubmapFrameSurfaceObb for kVoxels points)
+  std::vector<float> mm((size_t)chunks * 6);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(mm.data(), d_minmax, mm.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_minmax);
+  if (e != hipSuccess) return set_error(ctx, VGX_ERR_HIP, std::string("chunk bounds: ") + hipGetErrorString(e));
+  for (int a = 0; a < 3; ++a) {
+    ps.aabb_min[a] = mm[(size_t)a];
+    ps.aabb_max[a] = mm[3 + (size_t)a];
+  }
+  for (long long c = 1; c < chunks; ++c)
+    for (int a = 0; a < 3; ++a) {
+      ps.aabb_min[a] = std::min(ps.aabb_min[a], mm[(size_t)c * 6 + a]);
+      ps.aabb_max[a] = std::max(ps.aabb_max[a], mm[(size_t)c * 6 + 3 + a]);
+    }
   return VGX_OK;
 }
 
@@ -391,6 +414,7 @@ int vgx_submap_destroy(vgx_submap sm) {
   vgx_submap_release_raw_layers(sm);
   if (sm->d_lut) (void)hipFree(sm->d_lut);
   if (sm->d_block_index) (void)hipFree(sm->d_block_index);
+  if (sm->d_iso_block_index) (void)hipFree(sm->d_iso_block_index);
   for (int k = 0; k < 2; ++k) {
     if (sm->grid[k].d_bricks) (void)hipFree(sm->grid[k].d_bricks);
     free_points(sm->points[k]);

@@ -87,6 +87,7 @@ struct PointSet {
   float4* d_xyzd = nullptr;
   float* d_weight = nullptr;
   float4* d_chunk_bounds = nullptr;  // per kChunkPoints points: bounding sphere {cx,cy,cz,r}
+  float aabb_min[3] = {0, 0, 0}, aabb_max[3] = {0, 0, 0};  // of the point positions (n > 0)
   double sum_weight = 0;
   bool present = false;
   std::vector<int64_t> order;            // order[i] = uploaded index of point i (empty = identity)
@@ -122,6 +123,7 @@ struct vgx_submap_s {
   vgx::Grid grid[2];       // [0] TSDF, [1] ESDF sampling grids
   vgx::PointSet points[2]; // by VGX_POINTS_*
   std::vector<int32_t> isosurface_blocks;  // block slots holding isosurface vertices (VSM:237-240)
+  int32_t* d_iso_block_index = nullptr;    // [isosurface_blocks.size()][3]
   vgx::GridDev grid_dev(int which) const;
 };
 

@@ -329,6 +329,10 @@ extern "C" int vgx_submap_extract_isosurface_points(vgx_submap sm, double min_vo
   ps = PointSet();
   ps.present = true;
   sm->isosurface_blocks.clear();
+  if (sm->d_iso_block_index) {
+    (void)hipFree(sm->d_iso_block_index);
+    sm->d_iso_block_index = nullptr;
+  }
   if (n_points_out) *n_points_out = 0;
   const int nb = sm->n_blocks;
   if (nb == 0) return VGX_OK;
@@ -430,6 +434,14 @@ extern "C" int vgx_submap_extract_isosurface_points(vgx_submap sm, double min_vo
   if (d_offsets) (void)hipFree(d_offsets);
   if (d_has) (void)hipFree(d_has);
   if (rc == VGX_OK) rc = build_chunk_bounds(ctx, ps);
+  if (rc == VGX_OK && !sm->isosurface_blocks.empty()) {
+    std::vector<int32_t> ib(3 * sm->isosurface_blocks.size());
+    for (size_t k = 0; k < sm->isosurface_blocks.size(); ++k)
+      for (int a = 0; a < 3; ++a) ib[3 * k + a] = sm->block_index[3 * (size_t)sm->isosurface_blocks[k] + a];
+    if (hipMalloc(&sm->d_iso_block_index, ib.size() * 4) != hipSuccess ||
+        hipMemcpy(sm->d_iso_block_index, ib.data(), ib.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+      rc = set_error(ctx, VGX_ERR_NOMEM, "vgx_submap_extract_isosurface_points: block list upload failed");
+  }
   if (rc == VGX_OK && n_points_out) *n_points_out = ps.n;
   return rc;
 }
