@@ -800,7 +800,7 @@ static int reg_prepare(vgx_reg r, const double ref_pose[4], const double read_po
   vgx_ctx ctx = r->ctx;
   VGX_HIP(ctx, hipSetDevice(ctx->device));
   const int64_t n = r->num_residuals;
-  if (!r->d_tiles) {
+  if (!r->d_desc) {
     std::vector<Tile> tiles = make_tiles(0, n, kTilePoints);
     r->n_tiles = (int32_t)tiles.size();
     if (r->n_tiles > 0) {
