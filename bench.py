@@ -198,6 +198,25 @@ def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=2):
     return out
 
 
+def finish_bench(capi, ctx, args, true_poses):
+    """finishSubmap() on the device for one 256^3 submap of the bench scene (HIP-event
+    timed): ESDF from TSDF, kVoxels and kIsosurfacePoints extraction."""
+    sm = capi.Submap.synth_city(ctx, 0, args.voxel_size, 16, args.block_min, args.block_dims,
+                                args.truncation, args.esdf_max, 10.0, true_poses[0], args.seed)
+    out = {}
+    for name, fn in (("generate_esdf_ms", lambda: sm.generate_esdf()),
+                     ("extract_voxel_points_ms", lambda: sm.extract_voxel_points(1.0, 0.3, True)),
+                     ("extract_isosurface_points_ms", lambda: sm.extract_isosurface_points(1.0))):
+        fn()
+        ctx.synchronize()
+        ctx.timer_start()
+        r = fn()
+        out[name] = ctx.timer_stop()
+        out[name.replace("_ms", "_result")] = int(r)
+    sm.destroy()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -444,6 +463,7 @@ def main():
     # second hot path (does not shard: replicas only) -- rank 0, N = 1
     if rank == 0 and world == 1 and not args.no_tsdf:
         out["tsdf"] = tsdf_bench(capi, ctx, torch)
+        out["finish_submap"] = finish_bench(capi, ctx, args, true_poses)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -141,10 +141,6 @@ struct vgx_reg_s {
   // drop-in scratch (f64 outputs staged on the device before the D2H copy)
   double* d_out = nullptr;
   int64_t d_out_rows = 0;
-  vgx::Tile* d_tiles = nullptr;
-  int32_t n_tiles = 0;
-  vgx::ConstraintDev* d_desc = nullptr;
-  vgx::PosePack* d_pack = nullptr;
   bool draw_samples();          // refreshes h_sample_idx / d_sample_idx
   vgx::ConstraintDev describe() const;
 };

@@ -307,15 +307,9 @@ __device__ __forceinline__ void store_out4(double4* p, double4 v) {
 }
 
 template <int VPS, typename OUT, int PPT, bool NT, bool NTL>
-__global__ __launch_bounds__(kBlockThreads) void reg_eval_points_kernel(
-    const ConstraintDev* __restrict__ cons, const PosePack* __restrict__ packs,
-    const Tile* __restrict__ tiles, int n_tiles, OUT* __restrict__ residuals,
+__device__ __forceinline__ void reg_eval_points_body(
+    const ConstraintDev& C, const PosePack& P, const Tile& tile, OUT* __restrict__ residuals,
     typename Out4<OUT>::type* __restrict__ jac_ref, typename Out4<OUT>::type* __restrict__ jac_read) {
-  int t = swizzle_tile(blockIdx.x, n_tiles);
-  if (t >= n_tiles) return;
-  const Tile tile = tiles[t];
-  const ConstraintDev& C = cons[tile.constraint];
-  const PosePack P = packs[tile.constraint];
   const GridDev g = C.grid;
   const int32_t* sidx = C.sample_idx;
   const bool want_jac = (jac_ref != nullptr) | (jac_read != nullptr);
@@ -367,6 +361,35 @@ __global__ __launch_bounds__(kBlockThreads) void reg_eval_points_kernel(
       store_out4<NT>(&jac_read[row], Out4<OUT>::make((double)-e.jo0 * f, (double)-e.jo1 * f,
                                                      (double)-e.jo2 * f, (double)e.je3 * f));
   }
+}
+
+// batched form: descriptors, pose packs and tiles live in device memory
+template <int VPS, typename OUT, int PPT, bool NT, bool NTL>
+__global__ __launch_bounds__(kBlockThreads) void reg_eval_points_kernel(
+    const ConstraintDev* __restrict__ cons, const PosePack* __restrict__ packs,
+    const Tile* __restrict__ tiles, int n_tiles, OUT* __restrict__ residuals,
+    typename Out4<OUT>::type* __restrict__ jac_ref, typename Out4<OUT>::type* __restrict__ jac_read) {
+  int t = swizzle_tile(blockIdx.x, n_tiles);
+  if (t >= n_tiles) return;
+  const Tile tile = tiles[t];
+  reg_eval_points_body<VPS, OUT, PPT, NT, NTL>(cons[tile.constraint], packs[tile.constraint], tile,
+                                               residuals, jac_ref, jac_read);
+}
+
+// drop-in form (one constraint per Evaluate): descriptor and pose pack travel as kernel
+// arguments and tiles are implicit, so an Evaluate needs no host->device copy at all
+template <int VPS, typename OUT, int PPT, bool NT, bool NTL>
+__global__ __launch_bounds__(kBlockThreads) void reg_eval_points_single_kernel(
+    ConstraintDev C, PosePack P, int n_tiles, OUT* __restrict__ residuals,
+    typename Out4<OUT>::type* __restrict__ jac_ref, typename Out4<OUT>::type* __restrict__ jac_read) {
+  int t = swizzle_tile(blockIdx.x, n_tiles);
+  if (t >= n_tiles) return;
+  Tile tile;
+  tile.constraint = 0;
+  tile.start = (int64_t)t * (kBlockThreads * PPT);
+  int64_t left = C.n - tile.start;
+  tile.count = (int32_t)(left < kBlockThreads * PPT ? left : kBlockThreads * PPT);
+  reg_eval_points_body<VPS, OUT, PPT, NT, NTL>(C, P, tile, residuals, jac_ref, jac_read);
 }
 
 // ---------------------------------------------------------------------------
@@ -663,6 +686,28 @@ static void launch_points(vgx_ctx ctx, int vps, const ConstraintDev* d_desc, con
 #undef VGX_LAUNCH_POINTS
 }
 
+
+template <typename OUT>
+static void launch_points_single(vgx_ctx ctx, int vps, const ConstraintDev& desc, const PosePack& pack,
+                                 void* res, void* jr, void* je) {
+  const int n_tiles = (int)((desc.n + kTilePoints - 1) / kTilePoints);
+  if (n_tiles <= 0) return;
+  dim3 grid(((n_tiles + 7) / 8) * 8), block(kBlockThreads);
+  using O4 = typename Out4<OUT>::type;
+  static const bool nt = [] {
+    const char* e = getenv("VGX_NT_STORES");
+    return e ? atoi(e) != 0 : kNonTemporalStores;
+  }();
+#define VGX_LAUNCH_SINGLE(VPS, NT)                                                                  \
+  hipLaunchKernelGGL((reg_eval_points_single_kernel<VPS, OUT, kPointsPerThread, NT, kNonTemporalLoads>), \
+                     grid, block, 0, ctx->stream, desc, pack, n_tiles, (OUT*)res, (O4*)jr, (O4*)je)
+  if (vps == 16 && nt) VGX_LAUNCH_SINGLE(16, true);
+  else if (vps == 16) VGX_LAUNCH_SINGLE(16, false);
+  else if (nt) VGX_LAUNCH_SINGLE(8, true);
+  else VGX_LAUNCH_SINGLE(8, false);
+#undef VGX_LAUNCH_SINGLE
+}
+
 }  // namespace vgx
 
 using namespace vgx;
@@ -786,45 +831,27 @@ int vgx_reg_destroy(vgx_reg r) {
   (void)hipStreamSynchronize(r->ctx->stream);
   if (r->d_sample_idx) (void)hipFree(r->d_sample_idx);
   if (r->d_out) (void)hipFree(r->d_out);
-  if (r->d_tiles) (void)hipFree(r->d_tiles);
-  if (r->d_desc) (void)hipFree(r->d_desc);
-  if (r->d_pack) (void)hipFree(r->d_pack);
   delete r;
   return VGX_OK;
 }
 
 int64_t vgx_reg_num_residuals(vgx_reg r) { return r ? r->num_residuals : -1; }
 
-// Prepares descriptor, tiles, pose pack (and fresh samples) on the device.
-static int reg_prepare(vgx_reg r, const double ref_pose[4], const double read_pose[4]) {
+// Fresh samples for sampling mode (the only per-Evaluate upload of the drop-in path:
+// descriptor and pose pack travel as kernel arguments).
+static int reg_prepare(vgx_reg r) {
   vgx_ctx ctx = r->ctx;
   VGX_HIP(ctx, hipSetDevice(ctx->device));
   const int64_t n = r->num_residuals;
-  if (!r->d_desc) {
-    std::vector<Tile> tiles = make_tiles(0, n, kTilePoints);
-    r->n_tiles = (int32_t)tiles.size();
-    if (r->n_tiles > 0) {
-      VGX_HIP(ctx, hipMalloc(&r->d_tiles, tiles.size() * sizeof(Tile)));
-      VGX_HIP(ctx, hipMemcpy(r->d_tiles, tiles.data(), tiles.size() * sizeof(Tile), hipMemcpyHostToDevice));
-    }
-    VGX_HIP(ctx, hipMalloc(&r->d_desc, sizeof(ConstraintDev)));
-    VGX_HIP(ctx, hipMalloc(&r->d_pack, sizeof(PosePack)));
-    if (r->cfg.sampling_ratio != -1.0f && n > 0)
-      VGX_HIP(ctx, hipMalloc(&r->d_sample_idx, (size_t)n * sizeof(int32_t)));
-  }
   if (r->cfg.sampling_ratio != -1.0f && n > 0) {
+    if (!r->d_sample_idx) VGX_HIP(ctx, hipMalloc(&r->d_sample_idx, (size_t)n * sizeof(int32_t)));
+    // the previous Evaluate's kernel may still read the old indices
+    VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     r->draw_samples();
     VGX_HIP(ctx, hipMemcpyAsync(r->d_sample_idx, r->h_sample_idx.data(), (size_t)n * sizeof(int32_t),
                                 hipMemcpyHostToDevice, ctx->stream));
+    VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
-  ConstraintDev desc = r->describe();
-  PosePack pack;
-  make_pose_pack(ref_pose, read_pose, &pack);
-  VGX_HIP(ctx, hipMemcpyAsync(r->d_desc, &desc, sizeof(desc), hipMemcpyHostToDevice, ctx->stream));
-  VGX_HIP(ctx, hipMemcpyAsync(r->d_pack, &pack, sizeof(pack), hipMemcpyHostToDevice, ctx->stream));
-  // desc / pack / h_sample_idx are pageable host memory: the copies complete
-  // before hipMemcpyAsync returns for pageable sources, but be explicit.
-  VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return VGX_OK;
 }
 
@@ -841,11 +868,14 @@ int vgx_reg_evaluate(vgx_reg r, const double ref_pose[4], const double read_pose
   vgx_ctx ctx = r->ctx;
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (!residuals) return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_evaluate: residuals == NULL");
-  int rc = reg_prepare(r, ref_pose, read_pose);
+  int rc = reg_prepare(r);
   if (rc != VGX_OK) return rc;
   if (reg_status(r) == VGX_EVALUATE_FALSE) return VGX_EVALUATE_FALSE;
   const int64_t n = r->num_residuals;
   if (n == 0) return VGX_OK;
+  const ConstraintDev desc = r->describe();
+  PosePack pack;
+  make_pose_pack(ref_pose, read_pose, &pack);
   if (r->d_out_rows < n) {
     if (r->d_out) (void)hipFree(r->d_out);
     r->d_out = nullptr;
@@ -855,8 +885,7 @@ int vgx_reg_evaluate(vgx_reg r, const double ref_pose[4], const double read_pose
   double* d_res = r->d_out;
   double* d_jr = jac_ref ? r->d_out + n : nullptr;
   double* d_je = jac_read ? r->d_out + 5 * n : nullptr;
-  launch_points<double>(ctx, r->reading->vps, r->d_desc, r->d_pack, r->d_tiles, r->n_tiles, d_res,
-                        d_jr, d_je);
+  launch_points_single<double>(ctx, r->reading->vps, desc, pack, d_res, d_jr, d_je);
   VGX_HIP(ctx, hipGetLastError());
   VGX_HIP(ctx, hipMemcpyAsync(residuals, d_res, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   if (jac_ref)
@@ -873,11 +902,13 @@ int vgx_reg_evaluate_device_f32(vgx_reg r, const double ref_pose[4], const doubl
   vgx_ctx ctx = r->ctx;
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (!d_residuals) return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_evaluate_device_f32: residuals == NULL");
-  int rc = reg_prepare(r, ref_pose, read_pose);
+  int rc = reg_prepare(r);
   if (rc != VGX_OK) return rc;
   if (reg_status(r) == VGX_EVALUATE_FALSE) return VGX_EVALUATE_FALSE;
-  launch_points<float>(ctx, r->reading->vps, r->d_desc, r->d_pack, r->d_tiles, r->n_tiles,
-                       d_residuals, d_jac_ref, d_jac_read);
+  PosePack pack;
+  make_pose_pack(ref_pose, read_pose, &pack);
+  launch_points_single<float>(ctx, r->reading->vps, r->describe(), pack, d_residuals, d_jac_ref,
+                              d_jac_read);
   VGX_HIP(ctx, hipGetLastError());
   return VGX_OK;
 }
