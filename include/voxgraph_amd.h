@@ -280,6 +280,16 @@ VGX_API int vgx_reg_batch_assemble(vgx_reg_batch batch, const void* d_normal,
                                    int32_t zero_first);
 VGX_API int64_t vgx_reg_fused_size(int32_t n_nodes, int32_t n_global);
 
+/* Host-side helper for solvers that want residual blocks (Ceres), not normal equations:
+ * turns one constraint's 45-number block N = [J r]^T [J r] into a 9-residual block with
+ * the same normal equations, r_c[9] and J_c[9][8] row-major (J_c^T J_c = J^T J,
+ * J_c^T r_c = J^T r, r_c^T r_c = r^T r), via a symmetric eigen-decomposition
+ * N = V L V^T, [J_c | r_c] = sqrt(max(L, 0)) V^T.  Exact for least squares without a robust
+ * loss, which is how the reference adds registration constraints
+ * (registration_constraint.cpp:10, constraint.h:34).  Pure host arithmetic. */
+VGX_API int vgx_reg_compress_normal(const double normal[45], double residuals9[9],
+                                    double jacobian9x8[72]);
+
 /* ---- overlap detection (callers' side of REG) -------------------------- */
 /* VoxgraphSubmap::getSubmapFrameSurfaceObb (voxgraph_submap.cpp:280-321): box around the
  * kVoxels registration voxels (centres -+ half a voxel), submap frame.  Needs the

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "gpu_fast_tsdf_integrator.h"
+#include "gpu_registration_batch.h"
 #include "gpu_registration_cost_function.h"
 
 static int fail(const char* what) {
@@ -90,6 +91,50 @@ int main() {
     double* jac1[2] = {nullptr, je.data()};
     if (!base.Evaluate(params, r2.data(), jac1) || r2 != r) return fail("null block");
     std::printf("REG adapter ok: %d residuals, worst |dr|/(wF) = %.2e\n", N, worst);
+    // ---- batched Ceres path: EvaluationCallback + 9-residual compressed block -----------
+    voxgraph_amd::GpuRegistrationBatch batch(ctx);
+    ceres::CostFunction* block = batch.AddConstraint(cost.handle(), ref_pose, read_pose);
+    ceres::CostFunction* block2 = batch.AddConstraint(cost.handle(), read_pose, ref_pose);
+    batch.Finalize();
+    ceres::EvaluationCallback& cb = batch;
+    cb.PrepareForEvaluation(true, true);
+    double rc[9], jc0[36], jc1[36];
+    double* jcs[2] = {jc0, jc1};
+    if (block->num_residuals() != 9 || !block->Evaluate(params, rc, jcs)) return fail("compressed block");
+    double cost_full = 0, cost_c = 0, g_full[8] = {0}, g_c[8] = {0};
+    for (int i = 0; i < N; ++i) {
+      cost_full += r[i] * r[i];
+      for (int k2 = 0; k2 < 4; ++k2) {
+        g_full[k2] += jo[4 * i + k2] * r[i];
+        g_full[4 + k2] += je[4 * i + k2] * r[i];
+      }
+    }
+    for (int m = 0; m < 9; ++m) {
+      cost_c += rc[m] * rc[m];
+      for (int k2 = 0; k2 < 4; ++k2) {
+        g_c[k2] += jc0[4 * m + k2] * rc[m];
+        g_c[4 + k2] += jc1[4 * m + k2] * rc[m];
+      }
+    }
+    if (std::fabs(cost_c - cost_full) > 1e-6 * cost_full) return fail("compressed cost");
+    for (int k2 = 0; k2 < 8; ++k2)
+      if (std::fabs(g_c[k2] - g_full[k2]) > 1e-6 * (std::fabs(g_full[k2]) + 1e-3 * cost_full))
+        return fail("compressed gradient");
+    // moving a pose and re-preparing changes the block; without new_evaluation_point it is cached
+    double before = rc[8];
+    read_pose[0] += 0.05;
+    cb.PrepareForEvaluation(false, false);
+    block->Evaluate(params, rc, nullptr);
+    if (rc[8] != before) return fail("cache");
+    cb.PrepareForEvaluation(false, true);
+    block->Evaluate(params, rc, nullptr);
+    double c2 = 0;
+    for (int m = 0; m < 9; ++m) c2 += rc[m] * rc[m];
+    if (std::fabs(c2 - cost_c) < 1e-9 * cost_c) return fail("re-evaluation");
+    read_pose[0] -= 0.05;
+    std::printf("batched Ceres path ok: cost %.6f == %.6f\n", cost_c, cost_full);
+    delete block;
+    delete block2;
   }
   // ---- TSDF adapter: one ray through an empty layer -----------------------------------
   {

@@ -22,5 +22,19 @@ class CostFunction {
   std::vector<int32_t> parameter_block_sizes_;
   int num_residuals_;
 };
+template <int kNumResiduals, int N0, int N1>
+class SizedCostFunction : public CostFunction {
+ public:
+  SizedCostFunction() {
+    set_num_residuals(kNumResiduals);
+    mutable_parameter_block_sizes()->push_back(N0);
+    mutable_parameter_block_sizes()->push_back(N1);
+  }
+};
+class EvaluationCallback {
+ public:
+  virtual ~EvaluationCallback() {}
+  virtual void PrepareForEvaluation(bool evaluate_jacobians, bool new_evaluation_point) = 0;
+};
 }  // namespace ceres
 #endif

@@ -464,3 +464,22 @@ def test_fused_pass_with_partial_overlap_culling_and_nonzero_no_correspondence_c
         cf.destroy()
     g_ref.destroy()
     g_read.destroy()
+
+
+def test_compressed_blocks_reproduce_the_normal_equations(capi, ctx, small_graph):
+    """vgx_reg_compress_normal: 9 residuals per constraint with the same J^T J, J^T r, r^T r
+    (what voxgraph_amd/cpp/gpu_registration_batch.h hands to Ceres)."""
+    G = small_graph
+    batch = capi.RegistrationBatch(ctx, G["cfs"], G["pairs"])
+    _, normal = batch.evaluate_normal(G["poses"])
+    iu = np.triu_indices(8)
+    for nb in normal:
+        r, J = capi.compress_normal(nb)
+        Hm = np.zeros((8, 8))
+        Hm[iu] = nb[9:]
+        Hm = Hm + np.triu(Hm, 1).T
+        scale = np.abs(Hm).max()
+        assert np.abs(J.T @ J - Hm).max() <= 1e-10 * scale
+        assert np.abs(J.T @ r - nb[1:9]).max() <= 1e-10 * max(np.abs(nb[1:9]).max(), 1e-300) + 1e-12 * scale
+        assert abs(r @ r - nb[0]) <= 1e-10 * nb[0]
+    batch.destroy()

@@ -103,6 +103,7 @@ SIGNATURES = {
     "vgx_reg_batch_evaluate_normal": (C.c_int, [vp, f64p, C.c_int32, vp, f64p, i32p]),
     "vgx_reg_batch_assemble": (C.c_int, [vp, vp, C.c_int32, vp, C.c_int32]),
     "vgx_reg_fused_size": (C.c_int64, [C.c_int32, C.c_int32]),
+    "vgx_reg_compress_normal": (C.c_int, [f64p, f64p, f64p]),
     "vgx_submap_surface_obb": (C.c_int, [vp, f32p, f32p]),
     "vgx_submap_mission_surface_aabb": (C.c_int, [vp, f64p, f32p, f32p]),
     "vgx_find_overlapping_pairs": (C.c_int, [vp, C.c_int32, C.POINTER(vp), f64p, i32p, C.c_int32, i32p]),
@@ -453,6 +454,16 @@ def find_overlapping_pairs(ctx, submaps, poses, max_pairs=None):
     ctx.check(ctx.lib.vgx_find_overlapping_pairs(ctx.h, n, arr, _ptr(poses, f64p), _ptr(pairs, i32p),
                                                  max_pairs, C.byref(k)))
     return [tuple(int(x) for x in p) for p in pairs[:k.value]]
+
+
+def compress_normal(normal45):
+    """45-number normal block -> (r_c[9], J_c[9,8]) with identical normal equations."""
+    nb = _f64(normal45)
+    r, J = np.zeros(9), np.zeros((9, 8))
+    rc = load().vgx_reg_compress_normal(_ptr(nb, f64p), _ptr(r, f64p), _ptr(J, f64p))
+    if rc != OK:
+        raise VgxError(rc, "vgx_reg_compress_normal")
+    return r, J
 
 
 def fused_size(n_nodes, n_global):

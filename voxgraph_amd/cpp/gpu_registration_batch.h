@@ -1,0 +1,129 @@
+// Batched Ceres integration: every registration residual block of a pose graph is
+// evaluated by ONE GPU launch per solver evaluation instead of one launch + 72 B/residual
+// of PCIe traffic per block.
+//
+//   voxgraph_amd::GpuRegistrationBatch batch(gpu_ctx);
+//   // registration_constraint.cpp:33-42, for every registration constraint:
+//   problem->AddResidualBlock(batch.AddConstraint(reg_handle, pose_first, pose_second),
+//                             nullptr, pose_first, pose_second);
+//   batch.Finalize();
+//   ceres_options.evaluation_callback = &batch;      // next to pose_graph.cpp:93-97
+//   ceres::Solve(ceres_options, problem, &summary);  // pose_graph.cpp:101, unchanged
+//
+// Each constraint appears to Ceres as a 9-residual block [J_c | r_c] with exactly the
+// normal equations of its N-residual original (vgx_reg_compress_normal): legitimate
+// because the reference attaches no robust loss to registration constraints
+// (registration_constraint.cpp:10, constraint.h:34).
+#ifndef VOXGRAPH_AMD_CPP_GPU_REGISTRATION_BATCH_H_
+#define VOXGRAPH_AMD_CPP_GPU_REGISTRATION_BATCH_H_
+
+#include <ceres/ceres.h>
+
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "voxgraph_amd.h"
+
+namespace voxgraph_amd {
+
+class GpuRegistrationBatch : public ceres::EvaluationCallback {
+ public:
+  explicit GpuRegistrationBatch(vgx_ctx ctx) : ctx_(ctx) {}
+  ~GpuRegistrationBatch() override {
+    if (batch_) vgx_reg_batch_destroy(batch_);
+  }
+  GpuRegistrationBatch(const GpuRegistrationBatch&) = delete;
+  GpuRegistrationBatch& operator=(const GpuRegistrationBatch&) = delete;
+
+  // One registration constraint.  pose_* are the parameter blocks Ceres optimises
+  // ({x,y,z,yaw} doubles, Pose4D::optimizationVectorData()); the returned cost function
+  // is handed to Problem::AddResidualBlock (which takes ownership by default).
+  ceres::CostFunction* AddConstraint(vgx_reg reg, const double* pose_reference,
+                                     const double* pose_reading) {
+    if (batch_) throw std::logic_error("GpuRegistrationBatch: AddConstraint after Finalize");
+    regs_.push_back(reg);
+    node_pair_.push_back(NodeIndex(pose_reference));
+    node_pair_.push_back(NodeIndex(pose_reading));
+    const int c = static_cast<int>(regs_.size()) - 1;
+    return new Block(this, c);
+  }
+
+  void Finalize() {
+    const int n = static_cast<int>(regs_.size());
+    if (vgx_reg_batch_create(ctx_, n, regs_.data(), node_pair_.data(), nullptr, n, &batch_) != VGX_OK)
+      throw std::runtime_error(std::string("vgx_reg_batch_create: ") + vgx_last_error(ctx_));
+    normal_.assign(static_cast<size_t>(n) * 45, 0.0);
+    status_.assign(static_cast<size_t>(n), 0);
+    compressed_r_.assign(static_cast<size_t>(n) * 9, 0.0);
+    compressed_j_.assign(static_cast<size_t>(n) * 72, 0.0);
+    poses_.assign(nodes_.size() * 4, 0.0);
+  }
+
+  // ceres::EvaluationCallback: the user's parameter blocks already hold the point to
+  // evaluate when this is called.
+  void PrepareForEvaluation(bool /*evaluate_jacobians*/, bool new_evaluation_point) override {
+    if (!batch_) throw std::logic_error("GpuRegistrationBatch: Finalize() was not called");
+    if (!new_evaluation_point && valid_) return;
+    for (size_t k = 0; k < nodes_.size(); ++k) std::memcpy(&poses_[4 * k], nodes_[k], 4 * sizeof(double));
+    if (vgx_reg_batch_evaluate_normal(batch_, poses_.data(), static_cast<int32_t>(nodes_.size()),
+                                      nullptr, normal_.data(), status_.data()) != VGX_OK)
+      throw std::runtime_error(std::string("vgx_reg_batch_evaluate_normal: ") + vgx_last_error(ctx_));
+    for (size_t c = 0; c < regs_.size(); ++c)
+      vgx_reg_compress_normal(&normal_[45 * c], &compressed_r_[9 * c], &compressed_j_[72 * c]);
+    valid_ = true;
+  }
+
+  int num_constraints() const { return static_cast<int>(regs_.size()); }
+
+ private:
+  // The 9-residual stand-in for one RegistrationCostFunction.
+  class Block : public ceres::SizedCostFunction<9, 4, 4> {
+   public:
+    Block(const GpuRegistrationBatch* owner, int index) : owner_(owner), index_(index) {}
+    bool Evaluate(double const* const* /*parameters*/, double* residuals,
+                  double** jacobians) const override {
+      const GpuRegistrationBatch& o = *owner_;
+      if (!o.valid_) return false;
+      if (o.status_[static_cast<size_t>(index_)] == VGX_EVALUATE_FALSE) return false;  // .cpp:273
+      std::memcpy(residuals, &o.compressed_r_[9 * static_cast<size_t>(index_)], 9 * sizeof(double));
+      if (jacobians) {
+        const double* J = &o.compressed_j_[72 * static_cast<size_t>(index_)];
+        for (int side = 0; side < 2; ++side)
+          if (jacobians[side])
+            for (int m = 0; m < 9; ++m)
+              std::memcpy(&jacobians[side][4 * m], &J[8 * m + 4 * side], 4 * sizeof(double));
+      }
+      return true;
+    }
+
+   private:
+    const GpuRegistrationBatch* owner_;
+    int index_;
+  };
+
+  int32_t NodeIndex(const double* pose) {
+    auto it = node_of_.find(pose);
+    if (it != node_of_.end()) return it->second;
+    const int32_t k = static_cast<int32_t>(nodes_.size());
+    nodes_.push_back(pose);
+    node_of_[pose] = k;
+    return k;
+  }
+
+  vgx_ctx ctx_;
+  vgx_reg_batch batch_ = nullptr;
+  std::vector<vgx_reg> regs_;
+  std::vector<int32_t> node_pair_;
+  std::vector<const double*> nodes_;
+  std::map<const double*, int32_t> node_of_;
+  std::vector<double> poses_, normal_, compressed_r_, compressed_j_;
+  std::vector<int32_t> status_;
+  bool valid_ = false;
+};
+
+}  // namespace voxgraph_amd
+
+#endif  // VOXGRAPH_AMD_CPP_GPU_REGISTRATION_BATCH_H_
