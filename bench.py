@@ -253,12 +253,18 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # under torch.distributed.run (RANK set) the RCCL group is always created, also for
+    # one rank, so the collective code path below is the one that runs at every N
+    use_dist = world > 1 or "RANK" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     ctx = capi.Context(local_rank)
@@ -318,7 +324,7 @@ def main():
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     rtot = torch.tensor([float(R)], dtype=torch.float64, device="cuda")
     kmax = torch.tensor([kernel_ms], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(rtot, op=dist.ReduceOp.SUM)
         dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
@@ -337,7 +343,7 @@ def main():
         def fused_step():
             batch.evaluate_normal(poses, to_host=False)
             batch.assemble(n_sub, buf.data_ptr(), zero_first=True)
-            if world > 1:
+            if use_dist:
                 dist.all_reduce(buf)
 
         for _ in range(2):
@@ -350,13 +356,13 @@ def main():
         torch.cuda.synchronize()
         barrier()
         fdt = torch.tensor([time.perf_counter() - f0], dtype=torch.float64, device="cuda")
-        if world > 1:
+        if use_dist:
             dist.all_reduce(fdt, op=dist.ReduceOp.MAX)
         fdt = float(fdt.item())
         fused = {"value": total_evals * args.steps / fdt / 1e6, "unit": "Mresiduals+Jacobians/s",
                  "ms_per_step": fdt / args.steps * 1e3,
                  "algorithmic_GBs": total_evals * args.steps * BYTES_PER_EVAL_FUSED / fdt / 1e9,
-                 "allreduce_bytes": int(size * 8) if world > 1 else 0,
+                 "allreduce_bytes": int(size * 8) if use_dist else 0,
                  "cost": float(buf[0].item()),
                  "cost_vs_materialised": None}
         if world == 1:
@@ -370,7 +376,7 @@ def main():
         info = [1.0, 1.0, 2500.0, 2500.0]                       # voxgraph_mapper.yaml:41-47
         edges = [lm.RelativePoseEdge.from_poses(k, k + 1, poses[k], poses[k + 1], info)
                  for k in range(n_sub - 1)]
-        backend = GpuBackend(capi, ctx, batch, n_sub, dist if world > 1 else None)
+        backend = GpuBackend(capi, ctx, batch, n_sub, dist if use_dist else None)
         backend(poses)                                           # warm
 
         def rmse(p):
@@ -391,7 +397,7 @@ def main():
             torch.cuda.synchronize()
             barrier()
             sdt = torch.tensor([time.perf_counter() - s0], dtype=torch.float64, device="cuda")
-            if world > 1:
+            if use_dist:
                 dist.all_reduce(sdt, op=dist.ReduceOp.MAX)
             return {"ms": float(sdt.item()) * 1e3, "iterations": summ["iterations"],
                     "evaluations": summ["evaluations"], "termination": summ["termination"],
@@ -466,7 +472,7 @@ def main():
         out["finish_submap"] = finish_bench(capi, ctx, args, true_poses)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -16,7 +16,7 @@ class GpuBackend:
     def __call__(self, poses):
         self.batch.evaluate_normal(poses, to_host=False)
         self.batch.assemble(self.n_nodes, self.buf.data_ptr(), zero_first=True)
-        if self.dist is not None and self.dist.is_initialized() and self.dist.get_world_size() > 1:
+        if self.dist is not None and self.dist.is_initialized():
             self.dist.all_reduce(self.buf)
         # the library may run on its own stream: order the copy after its kernels
         self.ctx.synchronize()
