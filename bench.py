@@ -108,7 +108,14 @@ def cpu_baseline(capi, ctx, args, true_poses, poses, pairs, seconds):
         while time.perf_counter() - t0 < seconds:
             done += sum(ex.map(task, range(cores)))
     dt = time.perf_counter() - t0
+    # the reference's own setting: Ceres num_threads = 4 (pose_graph.cpp:96)
+    done4, t4 = 0, time.perf_counter()
+    with ThreadPoolExecutor(4) as ex:
+        while time.perf_counter() - t4 < max(2.0, seconds / 4):
+            done4 += sum(ex.map(task, range(4)))
+    dt4 = time.perf_counter() - t4
     return {"value": done / dt / 1e6, "unit": "Mresiduals+Jacobians/s", "cores": cores,
+            "value_4_threads": done4 / dt4 / 1e6,
             "kind": "port",
             "sample": f"constraint 0 of the same graph ({n} residuals, one 256^3 pair) evaluated "
                       f"{done // n} times, one evaluation per task on {cores} threads, {dt:.1f} s; "
