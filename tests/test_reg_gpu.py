@@ -483,3 +483,66 @@ def test_compressed_blocks_reproduce_the_normal_equations(capi, ctx, small_graph
         assert np.abs(J.T @ r - nb[1:9]).max() <= 1e-10 * max(np.abs(nb[1:9]).max(), 1e-300) + 1e-12 * scale
         assert abs(r @ r - nb[0]) <= 1e-10 * nb[0]
     batch.destroy()
+
+
+def test_randomised_configurations_match_oracle(capi, ctx):
+    """25 seeded random set-ups: sparse random block sets (negative indices), both vps, voxel
+    sizes from 2 cm to 50 cm, poses hundreds of metres from the origin and yaw across the
+    +-pi wrap, random weights, unobserved voxels, both distance layers, both output forms."""
+    worst = 0.0
+    for seed in range(25):
+        rng = np.random.default_rng(1000 + seed)
+        vps = 16 if seed % 3 else 8
+        vs = float(rng.choice([0.02, 0.05, 0.1, 0.2, 0.5]))
+        bdim = tuple(int(x) for x in rng.integers(2, 5, 3))
+        bmin = tuple(int(x) for x in rng.integers(-6, 3, 3))
+        extent = np.array(bdim) * vps * vs
+        centre = (np.array(bmin) * vps * vs) + extent * rng.uniform(0.3, 0.7, 3)
+        sdf = synth.union_sdf(synth.sphere_sdf(centre, 0.3 * extent.min()),
+                              synth.plane_sdf((0.1, -0.2, 0.97), float(np.array([0.1, -0.2, 0.97]) @ centre) - 0.2 * extent.min()))
+        trunc = 3 * vs
+        sm = synth.make_submap(sdf, vs, vps, bmin, bdim, trunc=trunc, esdf_max=6 * vs, noise=0.02, seed=seed)
+        keep = rng.random(sm.n_blocks) < 0.8                      # random missing blocks
+        keep[0] = True
+        for name in ("block_index", "tsdf_distance", "tsdf_weight", "esdf_distance", "esdf_observed"):
+            setattr(sm, name, np.ascontiguousarray(getattr(sm, name)[keep]))
+        sm.esdf_observed[rng.random(sm.esdf_observed.shape) < 0.01] = 0    # unobserved speckles
+        use_esdf = bool(seed % 2)
+        g = H.gpu_submap(capi, ctx, sm, seed)
+        xyz, dist, w = H.oracle_points(sm, use_esdf=use_esdf, max_d=1.0 * trunc)
+        if len(w) < 50:
+            g.destroy()
+            continue
+        w = (w * rng.uniform(0.2, 1.0, len(w))).astype(F)
+        flags = capi.POINTS_SORT_MORTON if seed % 4 == 0 else capi.POINTS_KEEP_ORDER
+        g.set_points(capi.POINTS_VOXELS, xyz, dist, w, flags)
+        order = g.point_order(capi.POINTS_VOXELS)
+        layer = H.oracle_layer(sm, use_esdf=use_esdf)
+        cfg = capi.default_config(registration_point_type=capi.POINTS_VOXELS,
+                                  use_esdf_distance=int(use_esdf),
+                                  no_correspondence_cost=float(rng.choice([0.0, 0.0, 0.3])))
+        cf = capi.RegistrationCostFunction(ctx, g, g, cfg)
+        base = np.r_[rng.uniform(-400, 400, 2), rng.uniform(-20, 20), rng.uniform(-3.14, 3.14)]
+        ref_pose = base
+        d_yaw = rng.uniform(-0.3, 0.3)
+        read_pose = base + np.r_[rng.normal(0, 2 * vs, 3), d_yaw]
+        if seed % 5 == 0:
+            ref_pose = ref_pose.copy(); ref_pose[3] = 3.13; read_pose[3] = -3.12   # across the wrap
+        ok, r, jo, je = _gpu_eval(cf, ref_pose, read_pose)
+        ok0, r0, jo0, je0 = orc.reg_evaluate(layer, xyz, dist, w, ref_pose, read_pose,
+                                             no_correspondence_cost=cfg.no_correspondence_cost)
+        assert ok == ok0
+        if not ok:
+            continue
+        worst = max(worst, H.assert_parity(r, r0[order], f"residual seed {seed}"),
+                    H.assert_parity(jo, jo0[order], f"jac_ref seed {seed}"),
+                    H.assert_parity(je, je0[order], f"jac_read seed {seed}"))
+        batch = capi.RegistrationBatch(ctx, [cf], [(0, 1)])
+        _, normal = batch.evaluate_normal(np.vstack([ref_pose, read_pose]))
+        okn, cost, jtr, jtj = orc.reg_evaluate_normal(layer, xyz, dist, w, ref_pose, read_pose,
+                                                      no_correspondence_cost=cfg.no_correspondence_cost)
+        assert abs(normal[0, 0] - cost) <= 1e-6 * max(cost, 1e-12)
+        assert np.all(np.abs(normal[0, 9:] - jtj) <= 1e-6 * max(np.abs(jtj).max(), 1e-12))
+        for o in (batch, cf, g):
+            o.destroy()
+    print("randomised configurations: worst relative error", worst)
