@@ -231,3 +231,47 @@ def test_full_scan_with_shipped_config_agrees_statistically(capi, ctx):
     assert np.abs(gD[sl] - true)[sel].max() < 0.75 * vs
     for o in (gi, gl):
         o.destroy()
+
+
+def test_randomised_single_ray_sequences_are_bit_exact(capi, ctx):
+    """six random integrator configurations (vps 8/16, voxel 5-30 cm, carving on/off, constant or
+    1/z^2 weights, drop-off, sparsity compensation, low max_weight, freespace points), 60 rays
+    each, one ray per scan: GPU == oracle in every voxel, bit for bit."""
+    for seed in range(6):
+        rng = np.random.default_rng(500 + seed)
+        vps = 8 if seed % 2 else 16
+        vs = float(rng.choice([0.05, 0.1, 0.2, 0.3]))
+        kw = dict(default_truncation_distance=float(rng.uniform(2, 4) * vs),
+                  max_ray_length_m=float(rng.uniform(20, 60) * vs),
+                  min_ray_length_m=float(rng.uniform(0.5, 2) * vs),
+                  voxel_carving_enabled=int(rng.integers(0, 2)), use_const_weight=int(rng.integers(0, 2)),
+                  use_weight_dropoff=int(rng.integers(0, 2)),
+                  use_sparsity_compensation_factor=int(rng.integers(0, 2)),
+                  sparsity_compensation_factor=float(rng.uniform(1, 30)),
+                  allow_clear=int(rng.integers(0, 2)), max_weight=float(rng.choice([3.0, 50.0, 10000.0])),
+                  max_consecutive_ray_collisions=int(rng.integers(0, 4)),
+                  start_voxel_subsampling_factor=float(rng.choice([1.0, 2.0, 4.0])))
+        ocfg, gcfg = _both_cfg(capi, **kw)
+        ol = orc.TsdfLayer(vs, vps)
+        oi = orc.FastTsdfIntegrator(ocfg, ol)
+        half = int(np.ceil(80 * vs / (vps * vs))) + 2
+        gl = capi.TsdfLayer(ctx, vs, vps, (-half,) * 3, (2 * half,) * 3, 4096)
+        gi = capi.FastTsdfIntegrator(ctx, gcfg, gl)
+        for k in range(60):
+            ax = rng.normal(0, 1, 3); ax /= np.linalg.norm(ax)
+            ang = rng.uniform(-3, 3)
+            T = np.r_[np.cos(ang / 2), np.sin(ang / 2) * ax, rng.uniform(-2, 2, 3) * vs * 5].astype(F)
+            dirv = rng.normal(0, 1, 3); dirv /= np.linalg.norm(dirv)
+            p = (dirv * rng.uniform(0.2, 70.0) * vs).astype(F)[None]
+            col = rng.integers(0, 256, (1, 4)).astype(np.uint8)
+            free = bool(rng.random() < 0.15)
+            a = oi.integratePointCloud(T, p, col, free)
+            b = gi.integratePointCloud(T, p, col, free)
+            assert a == b, (seed, k, a, b)
+        assert gl.stats()[1] == 0
+        O, G = _as_dict(*ol.download(), vps), _as_dict(*gl.download(), vps)
+        assert O.keys() == G.keys(), seed
+        bad = [k for k in O if O[k] != G[k]]
+        assert not bad, (seed, len(bad), bad[:2], [O[k] for k in bad[:2]], [G[k] for k in bad[:2]])
+        for o in (gi, gl):
+            o.destroy()
