@@ -271,10 +271,16 @@ struct Out4<double> {
   }
 };
 
-// XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch
-// order), so hand each XCD one contiguous range of tiles -- neighbouring tiles
-// gather from neighbouring bricks and share that XCD's L2.
+// Optional XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch
+// order), so each XCD could be handed one contiguous range of tiles to keep
+// neighbouring bricks in one L2.  MEASURED SLOWER here (5.24-5.55 ms vs 5.03-5.31 ms for
+// the materialising kernel, 2.66 vs 2.54 ms fused; profiles/ab_swizzle.sh): the kernels
+// are HBM-stream bound, the gathers already hit in L2/MALL, and eight XCDs streaming eight
+// distant address ranges is worse for the memory system than one interleaved front.
+// Default: off (identity mapping); VGX_XCD_SWIZZLE=1 re-enables it for experiments.
+__constant__ int g_xcd_swizzle = 0;
 __device__ __forceinline__ int swizzle_tile(int b, int n_tiles) {
+  if (!g_xcd_swizzle) return b;
   int chunk = (n_tiles + 7) >> 3;
   return (b & 7) * chunk + (b >> 3);
 }
@@ -657,10 +663,24 @@ __global__ void reg_assemble_kernel(const double* __restrict__ normal, int n, in
 // ---------------------------------------------------------------------------
 // launch helpers
 // ---------------------------------------------------------------------------
+// one-time application of the VGX_XCD_SWIZZLE experiment switch
+static void apply_swizzle_env() {
+  static const bool done = [] {
+    const char* e = getenv("VGX_XCD_SWIZZLE");
+    if (e) {
+      int v = atoi(e) != 0;
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_xcd_swizzle), &v, sizeof(int));
+    }
+    return true;
+  }();
+  (void)done;
+}
+
 template <typename OUT>
 static void launch_points(vgx_ctx ctx, int vps, const ConstraintDev* d_desc, const PosePack* d_pack,
                           const Tile* d_tiles, int n_tiles, void* res, void* jr, void* je) {
   if (n_tiles <= 0) return;
+  apply_swizzle_env();
   dim3 grid(((n_tiles + 7) / 8) * 8), block(kBlockThreads);
   using O4 = typename Out4<OUT>::type;
   static const bool nt = [] {
@@ -1099,6 +1119,7 @@ int vgx_reg_batch_evaluate_normal(vgx_reg_batch b, const double* poses, int32_t 
   if (b->n == 0) return VGX_OK;
   double* out = d_normal ? (double*)d_normal : b->d_normal;
   const int n_tiles = (int)ex->reduce_tiles.size();
+  apply_swizzle_env();
   if (n_tiles > 0) {
     dim3 grid(((n_tiles + 7) / 8) * 8), block(kBlockThreads);
     static const bool ntl = [] {
