@@ -407,6 +407,9 @@ constexpr int kReduceIters = 8;  // a reduce tile = kTilePoints * kReduceIters r
 constexpr bool kNonTemporalLoads = false;  // A/B: VGX_NT_LOADS=1
 constexpr bool kNonTemporalStores = true;  // measured 6.08 -> 5.40 ms (profiles/ab_nt.sh, VGX_NT_STORES=0/1)
 constexpr int kMaxReduceIters = 64;
+// 120 VGPRs -> 4 waves/SIMD.  Forcing 5 or 6 (launch_bounds) spills the 21 f64
+// accumulators: measured 7.8 / 13.0 ms per fused step against 2.45 ms.
+constexpr int kReduceWavesPerSimd = 4;
 constexpr int kReducePointsPerThread = 2;  // measured: 3.72 / 3.29 / 3.41 ms per fused step at 4 / 2 / 1 (profiles/tune_fused.sh)
 
 // True when no point inside the sphere (centre in the reference frame) can have a
@@ -427,8 +430,8 @@ __device__ __forceinline__ bool chunk_outside(const GridDev& g, const PosePack& 
   return cx + r < lox || cx - r > hix || cy + r < loy || cy - r > hiy || cz + r < loz || cz - r > hiz;
 }
 
-template <int VPS, int PPT, bool NTL>
-__global__ __launch_bounds__(kBlockThreads) void reg_eval_reduce_kernel(
+template <int VPS, int PPT, bool NTL, int WAVES>
+__global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_kernel(
     const ConstraintDev* __restrict__ cons, const PosePack* __restrict__ packs,
     const Tile* __restrict__ tiles, int n_tiles, double* __restrict__ partials) {
   static_assert(kBlockThreads * PPT == kChunkPoints, "one inner iteration == one culling chunk");
@@ -1127,8 +1130,9 @@ int vgx_reg_batch_evaluate_normal(vgx_reg_batch b, const double* poses, int32_t 
       return e ? atoi(e) != 0 : kNonTemporalLoads;
     }();
 #define VGX_LAUNCH_REDUCE(VPS, NTL)                                                                 \
-  hipLaunchKernelGGL((reg_eval_reduce_kernel<VPS, kReducePointsPerThread, NTL>), grid, block, 0,   \
-                     ctx->stream, b->d_desc, b->d_pack, ex->d_reduce_tiles, n_tiles, b->d_partials)
+  hipLaunchKernelGGL((reg_eval_reduce_kernel<VPS, kReducePointsPerThread, NTL, kReduceWavesPerSimd>), \
+                     grid, block, 0, ctx->stream, b->d_desc, b->d_pack, ex->d_reduce_tiles, n_tiles, \
+                     b->d_partials)
     if (b->regs[0]->reading->vps == 16) {
       if (ntl) VGX_LAUNCH_REDUCE(16, true); else VGX_LAUNCH_REDUCE(16, false);
     } else {
