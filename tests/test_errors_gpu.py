@@ -116,3 +116,41 @@ def test_tsdf_pool_and_box_limits_are_counted(capi, ctx):
         capi.TsdfLayer(ctx, 0.1, 16, (0, 0, 0), (0, 1, 1), 8)
     for o in (integ, integ2, layer, layer2):
         o.destroy()
+
+
+def test_create_destroy_cycles_do_not_leak_device_memory(capi, ctx):
+    import torch
+    sm, _ = synth.config1_pair(asymmetric=True)
+
+    def cycle():
+        g = H.gpu_submap(capi, ctx, sm)
+        g.generate_esdf()
+        g.extract_voxel_points()
+        g.extract_isosurface_points()
+        cfg = capi.default_config(registration_point_type=capi.POINTS_VOXELS)
+        cf = capi.RegistrationCostFunction(ctx, g, g, cfg)
+        cs = capi.RegistrationCostFunction(ctx, g, g, capi.default_config(sampling_ratio=0.1))
+        n = cf.num_residuals()
+        r = np.zeros(n)
+        cf.Evaluate([np.zeros(4), np.array([0.01, 0, 0, 0.0])], r, None)
+        r2 = np.zeros(cs.num_residuals())
+        cs.Evaluate([np.zeros(4), np.zeros(4)], r2, None)
+        b = capi.RegistrationBatch(ctx, [cf, cf], [(0, 1), (1, 0)])
+        b.evaluate_normal(np.zeros((2, 4)))
+        pairs = capi.find_overlapping_pairs(ctx, [g, g], np.zeros((2, 4)))
+        layer = capi.TsdfLayer(ctx, 0.1, 16, (-2, -2, -2), (4, 4, 4), 64)
+        integ = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(), layer)
+        integ.integratePointCloud(np.array([1, 0, 0, 0, 0, 0, 0], F), np.array([[1.0, 0.2, 0.1]], F))
+        s2 = capi.Submap.from_tsdf_layer(ctx, layer, 3)
+        for o in (s2, integ, layer, b, cs, cf, g):
+            o.destroy()
+        return pairs
+
+    cycle()
+    ctx.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(10):
+        cycle()
+    ctx.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 8 << 20, (free0, free1)
