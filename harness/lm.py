@@ -328,3 +328,25 @@ def _solve(problem, poses0, parameter_tolerance, function_tolerance, gradient_to
     return x, {"iterations": it, "evaluations": problem.evaluations, "termination": reason,
                "final_cost": cost, "initial_cost": history[0],
                "seconds": time.perf_counter() - t0}
+
+
+def zero_registration_backend(n_nodes, n_constraints):
+    """Backend for `exclude_registration_constraints = true` (pose_graph.cpp:74-83)."""
+    buf = np.zeros(1 + 20 * n_nodes + 16 * n_constraints)
+    return lambda poses: buf
+
+
+def optimize_two_stage(backend, n_nodes, pairs, edges, poses0, new_loop_closures, **solve_kw):
+    """PoseGraphInterface::optimize (pose_graph_interface.cpp:177-198): when new loop
+    closures were added, first optimise WITHOUT the registration constraints (odometry +
+    loop closures only, :182-188), then run the full problem from that result (:191)."""
+    poses = np.array(poses0, np.float64)
+    summaries = []
+    if new_loop_closures:
+        pre = Problem(zero_registration_backend(n_nodes, len(pairs)), n_nodes, pairs, edges)
+        poses, s = solve(pre, poses, **solve_kw)
+        summaries.append(s)
+    full = Problem(backend, n_nodes, pairs, edges)
+    poses, s = solve(full, poses, **solve_kw)
+    summaries.append(s)
+    return poses, summaries

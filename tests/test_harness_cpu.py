@@ -148,3 +148,37 @@ def test_reduced_banded_form_matches_dense_normal_equations():
         A = band.copy(); A[u] += 10.0
         np.testing.assert_allclose(solveh_banded(A, gf, lower=False),
                                    np.linalg.solve(Hf + 10 * np.eye(len(f)), gf), rtol=1e-8, atol=1e-10)
+
+
+def test_two_stage_optimise_with_loop_closure_pulls_in_accumulated_drift():
+    """BASELINE config 5 in miniature (pose_graph_interface.cpp:177-198): a loop of submaps
+    with odometry drift far outside the registration basin; the loop-closure edge alone
+    (stage 1, registration excluded) brings the chain back, stage 2 refines with
+    registration (CPU oracle backend)."""
+    sdf = synth.union_sdf(synth.sphere_ground_sdf((1.6, 1.6, 1.2), 1.0, 0.35),
+                          synth.sphere_sdf((0.6, 2.4, 0.8), 0.5))
+    n = 6
+    ang = np.linspace(0, 2 * np.pi, n, endpoint=False)
+    true = np.stack([0.5 * np.cos(ang) - 0.5, 0.5 * np.sin(ang), 0.02 * np.arange(n), 0.1 * np.sin(ang)], 1)
+    true[0] = 0
+    layers, pts = [], []
+    for p in true:
+        sm = synth.make_submap(sdf, 0.1, 16, (0, 0, 0), (2, 2, 2), 0.3, p, 1.0, drop_empty_blocks=True)
+        layers.append(H.oracle_layer(sm))
+        pts.append(H.oracle_points(sm))
+    pairs = [(k, (k + 1) % n) for k in range(n)]
+    # odometry: true relative motion plus a bias that accumulates around the loop
+    info_odo, info_lc = [1.0, 1.0, 2500.0, 2500.0], [100.0, 100.0, 2500.0, 2500.0]
+    poses0 = true.copy()
+    for k in range(1, n):
+        poses0[k] = poses0[k - 1] + (true[k] - true[k - 1]) + np.array([0.12, -0.08, 0.0, 0.03])
+    edges = [lm.RelativePoseEdge.from_poses(k, k + 1, poses0[k], poses0[k + 1], info_odo) for k in range(n - 1)]
+    edges.append(lm.RelativePoseEdge.from_poses(n - 1, 0, true[n - 1], true[0], info_lc))   # the loop closure
+    backend = OracleBackend(layers, pts, pairs, n)
+    kw = dict(parameter_tolerance=1e-8, function_tolerance=1e-10, max_iterations=60, max_seconds=120)
+    drift0 = np.abs(poses0[:, :2] - true[:, :2]).max()
+    assert drift0 > 0.4                                   # well outside the 0.3 m band
+    x2, summ = lm.optimize_two_stage(backend, n, pairs, edges, poses0, True, **kw)
+    assert len(summ) == 2
+    e2 = np.abs(x2[:, :3] - true[:, :3]).max()
+    assert e2 < 0.05 and e2 < 0.2 * drift0, (e2, drift0)
