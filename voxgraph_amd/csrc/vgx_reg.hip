@@ -204,6 +204,48 @@ __device__ __forceinline__ void load_neighbours(const float* cell, float d[8]) {
   d[3] = p3.x; d[7] = p3.y;
 }
 
+// Branch-free two-stage form of locate_point + load_neighbours used by the kernels: all
+// lanes compute clamped, always-valid addresses, so the block-table loads of every point
+// a thread owns issue back to back, then all brick gathers issue back to back (one memory
+// round trip each instead of one per point behind divergent branches).  `have` says
+// whether the gathered values mean anything.
+struct Located {
+  int lut_index;   // clamped index into the block table
+  int cell_off;    // offset of the base voxel inside a brick
+  bool inside;     // base block index within the table's box
+  float Dx, Dy, Dz;
+};
+
+template <int VPS>
+__device__ __forceinline__ Located locate_stage1(const GridDev& g, const PosePack& P, float x, float y,
+                                                 float z) {
+  float uv0 = -(P.qz * y);
+  float uv1 = P.qz * x;
+  uv0 += uv0;
+  uv1 += uv1;
+  float c0 = -(P.qz * uv1);
+  float c1 = P.qz * uv0;
+  float px = (x + P.qw * uv0 + c0) + P.tx;
+  float py = (y + P.qw * uv1 + c1) + P.ty;
+  float pz = z + P.tz;
+  Located L;
+  int bx, by, bz, vx, vy, vz;
+  locate_axis<VPS>(px, g, bx, vx, L.Dx);
+  locate_axis<VPS>(py, g, by, vy, L.Dy);
+  locate_axis<VPS>(pz, g, bz, vz, L.Dz);
+  bx -= g.lut_min[0];
+  by -= g.lut_min[1];
+  bz -= g.lut_min[2];
+  L.inside = (unsigned)bx < (unsigned)g.lut_dim[0] && (unsigned)by < (unsigned)g.lut_dim[1] &&
+             (unsigned)bz < (unsigned)g.lut_dim[2];
+  int cx = min(max(bx, 0), g.lut_dim[0] - 1), cy = min(max(by, 0), g.lut_dim[1] - 1),
+      cz = min(max(bz, 0), g.lut_dim[2] - 1);
+  L.lut_index = cx + g.lut_dim[0] * (cy + g.lut_dim[1] * cz);
+  constexpr int B = VPS + 1;
+  L.cell_off = vx + B * (vy + B * vz);
+  return L;
+}
+
 __device__ __forceinline__ PointEval eval_point(const float d[8], bool have, float Dx, float Dy,
                                                 float Dz, float inv_f, const PosePack& P, float xi,
                                                 float yi, float d_ref, float w,
@@ -339,23 +381,40 @@ __device__ __forceinline__ void reg_eval_points_body(
       w[j] = load_stream<NTL>(as_global(C.weight) + i);
     }
   }
-#pragma unroll
-  for (int j = 0; j < PPT; ++j)
-    cell[j] = locate_point<VPS>(g, P, pt[j].x, pt[j].y, pt[j].z, Dx[j], Dy[j], Dz[j]);
+  // stage 1: exact base voxel of every point (registers only)
+  Located loc[PPT];
+  bool have[PPT];
+  const bool grid_empty = g.bricks == nullptr;  // reading submap without blocks
 #pragma unroll
   for (int j = 0; j < PPT; ++j) {
-    if (cell[j]) {
-      load_neighbours<VPS>(cell[j], d[j]);
-    } else {
+    loc[j] = locate_stage1<VPS>(g, P, pt[j].x, pt[j].y, pt[j].z);
+    Dx[j] = loc[j].Dx;
+    Dy[j] = loc[j].Dy;
+    Dz[j] = loc[j].Dz;
+    have[j] = false;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) d[j][k] = 0.0f;
+    for (int k = 0; k < 8; ++k) d[j][k] = 0.0f;
+    cell[j] = nullptr;
+  }
+  if (!grid_empty) {
+    // stage 2: all block-table loads, then all brick gathers
+    int slot[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) slot[j] = as_global(g.lut)[loc[j].lut_index];
+    constexpr int CELLS = (VPS + 1) * (VPS + 1) * (VPS + 1);
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      have[j] = loc[j].inside && slot[j] >= 0;
+      cell[j] = g.bricks + (size_t)(have[j] ? slot[j] : 0) * CELLS + loc[j].cell_off;
     }
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) load_neighbours<VPS>(cell[j], d[j]);
   }
 #pragma unroll
   for (int j = 0; j < PPT; ++j) {
     int local = j * kBlockThreads + (int)threadIdx.x;
     if (local >= tile.count) continue;
-    PointEval e = eval_point(d[j], cell[j] != nullptr, Dx[j], Dy[j], Dz[j], g.voxel_size_inv, P,
+    PointEval e = eval_point(d[j], have[j], Dx[j], Dy[j], Dz[j], g.voxel_size_inv, P,
                              pt[j].x, pt[j].y, pt[j].w, w[j], C.no_corr_cost, want_jac);
     int64_t row = C.row0 + tile.start + local;
     const double f = C.factor;  // RCF:274-291
@@ -497,23 +556,37 @@ __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_kernel(
       }
     }
     if (!live) continue;
-#pragma unroll
-    for (int j = 0; j < PPT; ++j)
-      cell[j] = locate_point<VPS>(g, P, pt[j].x, pt[j].y, pt[j].z, Dx[j], Dy[j], Dz[j]);
+    Located loc[PPT];
+    bool have[PPT];
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
-      if (cell[j]) {
-        load_neighbours<VPS>(cell[j], d[j]);
-      } else {
+      loc[j] = locate_stage1<VPS>(g, P, pt[j].x, pt[j].y, pt[j].z);
+      Dx[j] = loc[j].Dx;
+      Dy[j] = loc[j].Dy;
+      Dz[j] = loc[j].Dz;
+      have[j] = false;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) d[j][k] = 0.0f;
+      for (int k = 0; k < 8; ++k) d[j][k] = 0.0f;
+      cell[j] = nullptr;
+    }
+    if (g.bricks != nullptr) {
+      int slot[PPT];
+#pragma unroll
+      for (int j = 0; j < PPT; ++j) slot[j] = as_global(g.lut)[loc[j].lut_index];
+      constexpr int CELLS = (VPS + 1) * (VPS + 1) * (VPS + 1);
+#pragma unroll
+      for (int j = 0; j < PPT; ++j) {
+        have[j] = loc[j].inside && slot[j] >= 0;
+        cell[j] = g.bricks + (size_t)(have[j] ? slot[j] : 0) * CELLS + loc[j].cell_off;
       }
+#pragma unroll
+      for (int j = 0; j < PPT; ++j) load_neighbours<VPS>(cell[j], d[j]);
     }
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
       int local = base + j * kBlockThreads + (int)threadIdx.x;
       if (local >= tile.count) continue;
-      PointEval e = eval_point(d[j], cell[j] != nullptr, Dx[j], Dy[j], Dz[j], g.voxel_size_inv,
+      PointEval e = eval_point(d[j], have[j], Dx[j], Dy[j], Dz[j], g.voxel_size_inv,
                                P, pt[j].x, pt[j].y, pt[j].w, w[j], C.no_corr_cost, true);
       if (e.ok) {
         double u[6] = {(double)e.jo0, (double)e.jo1, (double)e.jo2, (double)e.jo3, (double)e.je3, e.r};
