@@ -154,3 +154,32 @@ def test_create_destroy_cycles_do_not_leak_device_memory(capi, ctx):
     ctx.synchronize()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < 8 << 20, (free0, free1)
+
+
+def test_large_sparse_block_extent_and_table_limit(capi, ctx):
+    """A submap whose blocks span a huge box still works through the dense block table up
+    to 2^28 cells; beyond that the upload is refused with UNSUPPORTED (no silent hashing)."""
+    plane = synth.plane_sdf((0, 0, 1), 0.05)
+    sm = synth.make_submap(plane, 0.1, 16, (0, 0, -1), (2, 1, 2), trunc=100.0, esdf_max=100.0)
+    # move the second x-block 500 blocks away (800 m): 501 x 1 x 2 table cells, both blocks usable
+    bi = sm.block_index.copy()
+    far = bi[:, 0] == 1
+    bi[far, 0] = 500
+    # the ESDF values of the moved blocks no longer match their position; re-evaluate the plane
+    centres = synth.voxel_centres(sm.voxel_size, 16, bi)
+    ed = (centres[..., 2] - np.float32(0.05)).astype(F)
+    g = capi.Submap(ctx, 0, sm.voxel_size, 16, bi, None, None, ed, np.ones_like(sm.esdf_observed))
+    xyz = np.array([[0.8, 0.8, 0.2], [800.8, 0.8, -0.3], [400.0, 0.8, 0.0]], F)   # near, far, gap
+    g.set_points(capi.POINTS_ISOSURFACE, xyz, np.zeros(3, F), np.ones(3, F))
+    cf = capi.RegistrationCostFunction(ctx, g, g, capi.default_config())
+    r, jo, je = np.zeros(3), np.zeros((3, 4)), np.zeros((3, 4))
+    assert cf.Evaluate([np.zeros(4), np.zeros(4)], r, [jo, je])
+    np.testing.assert_allclose(r[:2], [-(0.2 - 0.05), -(-0.3 - 0.05)], atol=1e-5)
+    assert r[2] == 0 and np.all(jo[2] == 0)                     # in the gap: no block, no correspondence
+    np.testing.assert_allclose(jo[:2, 2], [-1.0, -1.0], atol=1e-4)
+    cf.destroy()
+    g.destroy()
+    bi2 = np.array([[0, 0, 0], [1 << 12, 1 << 12, 1 << 6]], np.int32)    # 2^30 cells
+    with pytest.raises(capi.VgxError) as e:
+        capi.Submap(ctx, 1, 0.1, 16, bi2, None, None, np.zeros((2, 4096), F), np.ones((2, 4096), np.uint8))
+    assert e.value.code == capi.ERR_UNSUPPORTED
