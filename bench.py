@@ -259,6 +259,8 @@ def main():
     ap.add_argument("--no-fused", action="store_true")
     ap.add_argument("--no-solve", action="store_true")
     ap.add_argument("--no-tsdf", action="store_true")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="also run the config-2 stand-in (30-submap LiDAR session, harness/pipeline.py)")
     ap.add_argument("--keep-order", action="store_true", help="extraction order instead of Morton")
     ap.add_argument("--calibrate", action="store_true",
                     help="PMC calibration: first launch evaluates poses 10 km apart, so every "
@@ -493,6 +495,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_tsdf:
         out["tsdf"] = tsdf_bench(capi, ctx, torch)
         out["finish_submap"] = finish_bench(capi, ctx, args, true_poses)
+    if rank == 0 and world == 1 and args.pipeline:
+        from harness import pipeline
+        out["pipeline_config2"] = pipeline.run(capi, ctx, torch)
     if rank == 0:
         print(json.dumps(out))
     if use_dist:

@@ -1,0 +1,126 @@
+"""BASELINE config 2 stand-in (the Arche bag cannot be downloaded here): a LiDAR session
+through the analytic city, run the way voxgraph runs it, with every data-parallel stage on
+the device:
+
+  per scan      vgx_tsdf_integrate_device            (VoxgraphMapper::pointcloudCallback, voxgraph_mapper.cpp:248-250)
+  per submap    from_tsdf_layer -> generate_esdf -> extract_{voxel,isosurface}_points   (finishSubmap, voxgraph_submap.cpp:84-107)
+  per new map   vgx_find_overlapping_pairs, registration constraints rebuilt            (pose_graph_interface.cpp:149-175)
+  per new map   pose-graph solve: fused REG pass + harness LM                            (pose_graph.cpp:85-106)
+
+Measurement / test infrastructure (uses harness.lm, torch for device buffers)."""
+import time
+
+import numpy as np
+
+from . import lm
+from .backends import GpuBackend
+
+
+def _inv_compose(pose_a, pose_b):
+    """T_a^-1 * T_b for 4-DoF poses -> (quaternion wxyz, translation) as f32 T_G_C array."""
+    ca, sa = np.cos(pose_a[3]), np.sin(pose_a[3])
+    d = np.asarray(pose_b[:3]) - np.asarray(pose_a[:3])
+    t = np.array([ca * d[0] + sa * d[1], -sa * d[0] + ca * d[1], d[2]])
+    yaw = pose_b[3] - pose_a[3]
+    return np.array([np.cos(yaw / 2), 0, 0, np.sin(yaw / 2), *t], np.float32)
+
+
+def run(capi, ctx, torch, n_submaps=30, scans_per_submap=20, n_az=1024, n_el=64, voxel_size=0.2,
+        step_m=1.0, seed=1, drift_sigma=(0.12, 0.008), solve_kw=None, verbose=False):
+    rng = np.random.default_rng(seed)
+    cfg = capi.voxgraph_tsdf_config()                         # voxgraph_mapper.yaml:21-28
+    el_span = np.deg2rad(33.2)                                # OS1-64
+    half = n_submaps // 2
+    # out along the street y = 0 (always free in the city scene), back along y = 3 m
+    sensor_poses = []
+    for k in range(n_submaps * scans_per_submap):
+        s = k * step_m
+        leg = half * scans_per_submap * step_m
+        if s < leg:
+            sensor_poses.append([s, 0.0, 2.0, 0.02 * np.sin(0.05 * s)])
+        else:
+            sensor_poses.append([2 * leg - s, 3.0, 2.0, np.pi + 0.02 * np.sin(0.05 * s)])
+    sensor_poses = np.array(sensor_poses)
+    bs = 16 * voxel_size
+    reach = 16.0 + scans_per_submap * step_m
+    nb_xy = int(np.ceil(reach / bs)) + 1
+    box_min, box_dim = (-nb_xy, -nb_xy, -2), (2 * nb_xy, 2 * nb_xy, 7)
+    pts = torch.empty((n_az * n_el, 3), dtype=torch.float32, device="cuda")
+    submaps, true_poses = [], []
+    t_integrate = t_finish = 0.0
+    n_updates_total = 0
+    stats = []
+    for m in range(n_submaps):
+        first = m * scans_per_submap
+        P = sensor_poses[first].copy()
+        P[2] = 0.0                                            # submap origin on the ground under the sensor
+        true_poses.append(P)
+        layer = capi.TsdfLayer(ctx, voxel_size, 16, box_min, box_dim, int(np.prod(box_dim)))
+        integ = capi.FastTsdfIntegrator(ctx, cfg, layer)
+        for j in range(first, first + scans_per_submap):
+            capi.synth_city_scan(ctx, sensor_poses[j], n_az, n_el, el_span, 40.0, 2, pts.data_ptr())
+            ctx.synchronize()
+            ctx.timer_start()
+            integ.integrate_device(_inv_compose(P, sensor_poses[j]), pts.data_ptr(), None, n_az * n_el)
+            t_integrate += ctx.timer_stop()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        sm = capi.Submap.from_tsdf_layer(ctx, layer, m)
+        sm.generate_esdf()
+        nv = sm.extract_voxel_points(1.0, 0.3, True)
+        ni = sm.extract_isosurface_points(1.0)
+        sm.release_raw_layers()
+        ctx.synchronize()
+        t_finish += time.perf_counter() - t0
+        stats.append((layer.stats()[0], nv, ni, layer.stats()[1]))
+        integ.destroy()
+        layer.destroy()
+        submaps.append(sm)
+    true_poses = np.array(true_poses)
+    # odometry drift accumulates along the trajectory
+    est = true_poses.copy()
+    drift = np.zeros(4)
+    for m in range(1, n_submaps):
+        drift += np.r_[rng.normal(0, drift_sigma[0], 2), 0.2 * rng.normal(0, drift_sigma[0]),
+                       rng.normal(0, drift_sigma[1])]
+        est[m] = true_poses[m] + drift
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    pairs = capi.find_overlapping_pairs(ctx, submaps, est)
+    t_overlap = time.perf_counter() - t0
+    rcfg = capi.default_config(registration_point_type=capi.POINTS_VOXELS)
+    cfs = [capi.RegistrationCostFunction(ctx, submaps[a], submaps[b], rcfg) for a, b in pairs]
+    batch = capi.RegistrationBatch(ctx, cfs, pairs)
+    info = [1.0, 1.0, 2500.0, 2500.0]                          # voxgraph_mapper.yaml:41-47
+    edges = [lm.RelativePoseEdge.from_poses(k, k + 1, est[k], est[k + 1], info) for k in range(n_submaps - 1)]
+    backend = GpuBackend(capi, ctx, batch, n_submaps)
+    kw = dict(parameter_tolerance=1e-8, max_seconds=1e9)
+    kw.update(solve_kw or {})
+    lm.solve(lm.Problem(backend, n_submaps, pairs, edges), est, **kw)      # warm
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    x, summ = lm.solve(lm.Problem(backend, n_submaps, pairs, edges), est, **kw)
+    t_solve = time.perf_counter() - t0
+
+    def rmse(p):
+        return float(np.sqrt(((p[:, :2] - true_poses[:, :2]) ** 2).sum(1).mean()))
+    n_scans = n_submaps * scans_per_submap
+    out = {"submaps": n_submaps, "scans": n_scans, "points_per_scan": n_az * n_el,
+           "tsdf_integrate_ms_per_scan": t_integrate / n_scans,
+           "tsdf_Mpoints_per_s": n_az * n_el * n_scans / t_integrate / 1e3,
+           "finish_submap_ms": t_finish / n_submaps * 1e3,
+           "blocks_per_submap": float(np.mean([s[0] for s in stats])),
+           "voxel_points_per_submap": float(np.mean([s[1] for s in stats])),
+           "isosurface_points_per_submap": float(np.mean([s[2] for s in stats])),
+           "dropped_updates": int(sum(s[3] for s in stats)),
+           "overlapping_pairs": len(pairs), "overlap_detection_ms": t_overlap * 1e3,
+           "registration_residuals": int(batch.num_residuals()),
+           "solve_ms": t_solve * 1e3, "solve_evaluations": summ["evaluations"],
+           "solve_termination": summ["termination"],
+           "xy_rmse_m_before": rmse(est), "xy_rmse_m_after": rmse(x),
+           "sensor_time_s_at_10Hz": n_scans / 10.0}
+    if verbose:
+        print(out)
+    for o in [batch] + cfs + submaps:
+        o.destroy()
+    return out

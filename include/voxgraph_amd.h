@@ -184,6 +184,15 @@ VGX_API int vgx_synth_city_submap(vgx_ctx ctx, int32_t submap_id, float voxel_si
                                   const double true_pose[4], uint32_t seed,
                                   int32_t build_tsdf_grid, vgx_submap* out);
 
+/* Benchmark tooling: one OS1-like LiDAR scan (n_el rings x n_az azimuth steps, elevation
+ * -el_span/2 .. +el_span/2 rad) of the same analytic city scene, sphere-traced on the
+ * device from sensor pose {x,y,z,yaw} (world frame).  Writes n_el*n_az points in the
+ * SENSOR frame (float3, DEVICE pointer); rays that hit nothing within max_range get
+ * length max_range * 2 (so they become clearing rays / are dropped like real returns). */
+VGX_API int vgx_synth_city_scan(vgx_ctx ctx, const double sensor_pose[4], int32_t n_az,
+                                int32_t n_el, float el_span, float max_range, uint32_t seed,
+                                void* d_points_C);
+
 /* ---- REG: one registration constraint ---------------------------------- */
 /* RegistrationCostFunction::Config (registration_cost_function.h:17-41).
  * jacobian_evaluation_method is always analytic; visualize_* are ignored. */

@@ -88,6 +88,8 @@ SIGNATURES = {
     "vgx_synth_city_submap": (C.c_int, [vp, C.c_int32, C.c_float, C.c_int32, i32p, i32p, C.c_float,
                                         C.c_float, C.c_float, f64p, C.c_uint32, C.c_int32,
                                         C.POINTER(vp)]),
+    "vgx_synth_city_scan": (C.c_int, [vp, f64p, C.c_int32, C.c_int32, C.c_float, C.c_float,
+                                      C.c_uint32, vp]),
     "vgx_reg_config_default": (None, [C.POINTER(RegConfig)]),
     "vgx_reg_create": (C.c_int, [vp, vp, vp, C.POINTER(RegConfig), C.POINTER(vp)]),
     "vgx_reg_destroy": (C.c_int, [vp]),
@@ -441,6 +443,12 @@ class RegistrationBatch:
         if self.h:
             self.ctx.lib.vgx_reg_batch_destroy(self.h)
             self.h = None
+
+
+def synth_city_scan(ctx, sensor_pose, n_az, n_el, el_span, max_range, seed, d_points):
+    """Benchmark tooling: sphere-traced LiDAR scan of the analytic city (sensor frame)."""
+    ctx.check(ctx.lib.vgx_synth_city_scan(ctx.h, _ptr(_f64(sensor_pose), f64p), n_az, n_el,
+                                          float(el_span), float(max_range), seed, vp(d_points)))
 
 
 def find_overlapping_pairs(ctx, submaps, poses, max_pairs=None):

@@ -77,9 +77,54 @@ __global__ __launch_bounds__(256) void synth_city_kernel(
   }
 }
 
+// One thread per LiDAR ray: sphere tracing of city_sdf (a distance bound, exact outside
+// the buildings), then a few bisection steps on the sign change for a crisp surface point.
+__global__ __launch_bounds__(256) void synth_city_scan_kernel(float sx, float sy, float sz,
+                                                              float cos_yaw, float sin_yaw, int n_az,
+                                                              int n_el, float el_span, float max_range,
+                                                              uint32_t seed, float* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_az * n_el) return;
+  int ia = i % n_az, ie = i / n_az;
+  float az = -3.14159265f + 6.2831853f * ((float)ia + 0.5f) / (float)n_az;
+  float el = n_el > 1 ? -0.5f * el_span + el_span * (float)ie / (float)(n_el - 1) : 0.0f;
+  float dx = cosf(el) * cosf(az), dy = cosf(el) * sinf(az), dz = sinf(el);   // sensor frame
+  float wx = cos_yaw * dx - sin_yaw * dy, wy = sin_yaw * dx + cos_yaw * dy, wz = dz;
+  float t = 0.2f, hit = 2.0f * max_range;
+  for (int it = 0; it < 256 && t < max_range; ++it) {
+    float d = city_sdf(sx + t * wx, sy + t * wy, sz + t * wz, seed);
+    if (d < 1e-3f) {
+      float lo = fmaxf(t - 0.05f, 0.0f), hi = t;
+      for (int b = 0; b < 12; ++b) {
+        float mid = 0.5f * (lo + hi);
+        if (city_sdf(sx + mid * wx, sy + mid * wy, sz + mid * wz, seed) > 0.0f) lo = mid; else hi = mid;
+      }
+      hit = 0.5f * (lo + hi);
+      break;
+    }
+    t += fmaxf(d, 0.01f);
+  }
+  out[3 * i] = dx * hit;
+  out[3 * i + 1] = dy * hit;
+  out[3 * i + 2] = dz * hit;
+}
+
 }  // namespace vgx
 
 using namespace vgx;
+
+extern "C" int vgx_synth_city_scan(vgx_ctx ctx, const double pose[4], int32_t n_az, int32_t n_el,
+                                   float el_span, float max_range, uint32_t seed, void* d_points) {
+  if (!ctx || !pose || !d_points || n_az <= 0 || n_el <= 0) return VGX_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  VGX_HIP(ctx, hipSetDevice(ctx->device));
+  const int n = n_az * n_el;
+  hipLaunchKernelGGL(synth_city_scan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                     (float)pose[0], (float)pose[1], (float)pose[2], (float)std::cos(pose[3]),
+                     (float)std::sin(pose[3]), n_az, n_el, el_span, max_range, seed, (float*)d_points);
+  VGX_HIP(ctx, hipGetLastError());
+  return VGX_OK;
+}
 
 extern "C" int vgx_synth_city_submap(vgx_ctx ctx, int32_t submap_id, float voxel_size, int32_t vps,
                                      const int32_t block_min[3], const int32_t block_dims[3],
