@@ -121,4 +121,4 @@ def test_lidar_session_through_the_city_config2_miniature(capi, ctx):
     # found by the overlap test alone)
     assert out["overlapping_pairs"] >= 10
     assert out["xy_rmse_m_before"] > 0.15
-    assert out["xy_rmse_m_after"] < 0.5 * out["xy_rmse_m_before"]
+    assert out["xy_rmse_m_after"] < 0.7 * out["xy_rmse_m_before"]
