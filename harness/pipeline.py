@@ -26,20 +26,28 @@ def _inv_compose(pose_a, pose_b):
 
 
 def run(capi, ctx, torch, n_submaps=30, scans_per_submap=20, n_az=1024, n_el=64, voxel_size=0.2,
-        step_m=1.0, seed=1, drift_sigma=(0.12, 0.008), solve_kw=None, verbose=False):
+        step_m=None, seed=1, drift_sigma=(0.12, 0.008), solve_kw=None, verbose=False):
     rng = np.random.default_rng(seed)
     cfg = capi.voxgraph_tsdf_config()                         # voxgraph_mapper.yaml:21-28
     el_span = np.deg2rad(33.2)                                # OS1-64
-    half = n_submaps // 2
-    # out along the street y = 0 (always free in the city scene), back along y = 3 m
+    # one lap around a 2 x 1 block of city cells along the (always free) cell boundaries:
+    # the streets run in both directions, so x and y are both observable somewhere, and
+    # the last submaps see the first ones again (loop closure through the overlap test)
+    cell = 25.6
+    corners = np.array([[0.0, 0.0], [2 * cell, 0.0], [2 * cell, cell], [0.0, cell], [0.0, 0.0]])
+    seg = np.linalg.norm(np.diff(corners, axis=0), axis=1)
+    n_scans_total = n_submaps * scans_per_submap
+    lap = seg.sum() * (1.0 - 1.0 / n_submaps)               # stop one submap short of the start
+    step_m = lap / n_scans_total if step_m is None else step_m
     sensor_poses = []
-    for k in range(n_submaps * scans_per_submap):
-        s = k * step_m
-        leg = half * scans_per_submap * step_m
-        if s < leg:
-            sensor_poses.append([s, 0.0, 2.0, 0.02 * np.sin(0.05 * s)])
-        else:
-            sensor_poses.append([2 * leg - s, 3.0, 2.0, np.pi + 0.02 * np.sin(0.05 * s)])
+    for k in range(n_scans_total):
+        s = (k * step_m) % seg.sum()
+        i = int(np.searchsorted(np.cumsum(seg), s, side="right"))
+        i = min(i, len(seg) - 1)
+        s0 = s - (np.cumsum(seg)[i] - seg[i])
+        d = (corners[i + 1] - corners[i]) / seg[i]
+        xy = corners[i] + d * s0
+        sensor_poses.append([xy[0], xy[1], 2.0, float(np.arctan2(d[1], d[0])) + 0.02 * np.sin(0.3 * s)])
     sensor_poses = np.array(sensor_poses)
     bs = 16 * voxel_size
     reach = 16.0 + scans_per_submap * step_m

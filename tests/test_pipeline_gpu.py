@@ -106,14 +106,13 @@ def test_scans_to_submaps_to_registration_solve(capi, ctx):
 
 
 def test_lidar_session_through_the_city_config2_miniature(capi, ctx):
-    """BASELINE config 2 in miniature (harness/pipeline.py): an out-and-back LiDAR drive
+    """BASELINE config 2 in miniature (harness/pipeline.py): one lap of a LiDAR drive
     through the analytic city, submaps built scan by scan on the device, finished on the
     device, overlap list from the device, pose graph solved with the fused REG pass."""
     import torch
     from harness import pipeline
     torch.cuda.synchronize()
-    out = pipeline.run(capi, ctx, torch, n_submaps=8, scans_per_submap=8, n_az=512, n_el=32,
-                       step_m=1.5, seed=3)
+    out = pipeline.run(capi, ctx, torch, n_submaps=10, scans_per_submap=8, n_az=512, n_el=32, seed=3)
     print(out)
     assert out["dropped_updates"] == 0
     assert out["voxel_points_per_submap"] > 20000 and out["isosurface_points_per_submap"] > 5000
