@@ -118,6 +118,6 @@ def test_lidar_session_through_the_city_config2_miniature(capi, ctx):
     assert out["voxel_points_per_submap"] > 20000 and out["isosurface_points_per_submap"] > 5000
     # consecutive submaps overlap, and the return leg overlaps the outbound leg (loop closures
     # found by the overlap test alone)
-    assert out["overlapping_pairs"] >= 10
-    assert out["xy_rmse_m_before"] > 0.15
-    assert out["xy_rmse_m_after"] < 0.7 * out["xy_rmse_m_before"]
+    assert out["overlapping_pairs_final"] >= 10
+    assert out["xy_rmse_m_odometry_only"] > 0.15
+    assert out["xy_rmse_m_optimised"] < 0.7 * out["xy_rmse_m_odometry_only"]
