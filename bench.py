@@ -277,6 +277,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # VGX_BENCH_DRYRUN=gloo: every rank on cuda:0 with the gloo backend, to walk the N>1
+    # code path on a one-GPU box (profiles/README.md); never used for reported numbers
+    dryrun = os.environ.get("VGX_BENCH_DRYRUN", "")
+    if dryrun:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     # under torch.distributed.run (RANK set) the RCCL group is always created, also for
     # one rank, so the collective code path below is the one that runs at every N
@@ -286,7 +291,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dryrun:
+            dist.init_process_group(dryrun)
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     def barrier():
         if use_dist:
@@ -461,7 +469,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if not dryrun else f"synthetic (DRY RUN: all ranks on one GPU, {dryrun})",
             "config": {"workload": f"configs[2]: synthetic {n_sub} submaps @ "
                                    f"{args.block_dims[0] * 16}x{args.block_dims[1] * 16}x{args.block_dims[2] * 16} voxels "
                                    f"({args.voxel_size} m), {n_con} overlap constraints, kVoxels points, "

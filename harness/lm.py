@@ -268,7 +268,13 @@ def solve(problem, poses0, parameter_tolerance=3e-3, function_tolerance=1e-6,
                       gradient_tolerance, max_iterations, max_seconds, initial_radius, verbose)
     if _THREADPOOLS is None:
         _THREADPOOLS = ThreadpoolController()         # scans the loaded libraries once
-    with _THREADPOOLS.limit(limits=blas_threads):
+    # only ever LOWER a pool: an OpenBLAS that initialised with one thread (OMP_NUM_THREADS=1,
+    # which torch.distributed.run exports) segfaults when raised to four afterwards
+    limits = {}
+    for lib in _THREADPOOLS.info():
+        api = lib["user_api"]
+        limits[api] = min(limits.get(api, blas_threads), max(1, int(lib["num_threads"])))
+    with _THREADPOOLS.limit(limits=limits):
         return _solve(problem, poses0, parameter_tolerance, function_tolerance,
                       gradient_tolerance, max_iterations, max_seconds, initial_radius, verbose)
 

@@ -182,3 +182,24 @@ def test_two_stage_optimise_with_loop_closure_pulls_in_accumulated_drift():
     assert len(summ) == 2
     e2 = np.abs(x2[:, :3] - true[:, :3]).max()
     assert e2 < 0.05 and e2 < 0.2 * drift0, (e2, drift0)
+
+
+def test_solve_survives_single_thread_blas_environment():
+    """torch.distributed.run exports OMP_NUM_THREADS=1; an OpenBLAS that starts with one thread
+    crashes if a thread-pool limit later RAISES it (seen at N=2 on the GPU box).  lm.solve must
+    only ever lower the pools."""
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import torch, numpy as np\n"
+        "from harness import lm\n"
+        "n = 60; rng = np.random.default_rng(0)\n"
+        "true = np.c_[np.arange(n) * 2.0, rng.normal(0, 0.1, (n, 3))]\n"
+        "edges = [lm.RelativePoseEdge.from_poses(k, k + 1, true[k], true[k + 1], [1, 1, 2500, 2500])\n"
+        "         for k in range(n - 1)]\n"
+        "prob = lm.Problem(lm.zero_registration_backend(n, 0), n, np.zeros((0, 2), np.int64), edges)\n"
+        "x, s = lm.solve(prob, true + rng.normal(0, 0.05, true.shape), parameter_tolerance=1e-10)\n"
+        "assert s['final_cost'] < 1e-12, s\n"
+        "print('SOLVED')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "SOLVED" in r.stdout, (r.returncode, r.stderr[-2000:])
