@@ -1,0 +1,114 @@
+"""ctypes view of oracle/_ref/libref_reg.so: the REFERENCE's own
+voxgraph::RegistrationCostFunction (registration_cost_function.cpp compiled from
+/root/reference against the stand-in headers of oracle/ref_shims; see its README).
+
+TEST INFRASTRUCTURE.  Only tests/ and tests/golden/make_ref_golden.py import this.
+`available()` is False wherever the library was not built (it can only be built where
+/root/reference exists; the built .so travels to the GPU box with the snapshot)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_ref", "libref_reg.so")
+_LIB = None
+
+POINTS_ISOSURFACE, POINTS_VOXELS = 0, 1
+
+
+def build():
+    """(Re)build when the reference sources are present; no-op otherwise."""
+    subprocess.run(["make", "-s", "-C", _HERE, "ref"], check=True)
+    return os.path.exists(_SO)
+
+
+def available():
+    return os.path.exists(_SO)
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        lib = C.CDLL(_SO)
+        vp, f32p, f64p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double)
+        lib.refreg_submap_create.restype = vp
+        lib.refreg_submap_create.argtypes = [C.c_uint32, f64p, C.c_float, C.c_int32, C.c_int32,
+                                             C.POINTER(C.c_int32), f32p, f32p, f32p,
+                                             C.POINTER(C.c_uint8)]
+        lib.refreg_submap_destroy.argtypes = [vp]
+        lib.refreg_submap_add_points.argtypes = [vp, C.c_int32, C.c_int64, f32p, f32p, f32p]
+        lib.refreg_cost_create.restype = vp
+        lib.refreg_cost_create.argtypes = [vp, vp, C.c_int32, C.c_float, C.c_double, C.c_int32]
+        lib.refreg_cost_destroy.argtypes = [vp]
+        lib.refreg_cost_num_residuals.restype = C.c_int32
+        lib.refreg_cost_num_residuals.argtypes = [vp]
+        lib.refreg_cost_evaluate.restype = C.c_int32
+        lib.refreg_cost_evaluate.argtypes = [vp, f64p, f64p, C.c_int32, f64p, f64p, f64p]
+        _LIB = lib
+    return _LIB
+
+
+def _ptr(a, t):
+    return None if a is None else a.ctypes.data_as(C.POINTER(t))
+
+
+class Submap:
+    """A finished submap as the reference cost function sees it (shim VoxgraphSubmap)."""
+
+    def __init__(self, submap_id, pose, voxel_size, vps, block_index, tsdf_distance, tsdf_weight,
+                 esdf_distance=None, esdf_observed=None):
+        bi = np.ascontiguousarray(block_index, np.int32).reshape(-1, 3)
+        td = np.ascontiguousarray(tsdf_distance, np.float32).ravel()
+        tw = np.ascontiguousarray(tsdf_weight, np.float32).ravel()
+        ed = None if esdf_distance is None else np.ascontiguousarray(esdf_distance, np.float32).ravel()
+        eo = None if esdf_observed is None else np.ascontiguousarray(esdf_observed, np.uint8).ravel()
+        pose = np.ascontiguousarray(pose, np.float64)
+        self._h = _lib().refreg_submap_create(int(submap_id), _ptr(pose, C.c_double), float(voxel_size),
+                                              int(vps), bi.shape[0], _ptr(bi, C.c_int32),
+                                              _ptr(td, C.c_float), _ptr(tw, C.c_float),
+                                              _ptr(ed, C.c_float), _ptr(eo, C.c_uint8))
+
+    def add_points(self, point_type, xyz, distance, weight):
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(distance, np.float32)
+        w = np.ascontiguousarray(weight, np.float32)
+        _lib().refreg_submap_add_points(self._h, int(point_type), xyz.shape[0], _ptr(xyz, C.c_float),
+                                        _ptr(d, C.c_float), _ptr(w, C.c_float))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib().refreg_submap_destroy(self._h)
+            self._h = None
+
+
+class RegistrationCostFunction:
+    """voxgraph::RegistrationCostFunction(reference_submap, reading_submap, config)."""
+
+    def __init__(self, reference, reading, point_type=POINTS_VOXELS, sampling_ratio=-1.0,
+                 no_correspondence_cost=0.0, use_esdf_distance=True):
+        self._keep = (reference, reading)
+        self._h = _lib().refreg_cost_create(reference._h, reading._h, int(point_type),
+                                            float(sampling_ratio), float(no_correspondence_cost),
+                                            int(bool(use_esdf_distance)))
+
+    def num_residuals(self):
+        return int(_lib().refreg_cost_num_residuals(self._h))
+
+    def Evaluate(self, ref_pose, read_pose, want_jac=True, want_ref=True, want_read=True):
+        n = self.num_residuals()
+        r = np.zeros(n, np.float64)
+        j0 = np.zeros((n, 4), np.float64) if (want_jac and want_ref) else None
+        j1 = np.zeros((n, 4), np.float64) if (want_jac and want_read) else None
+        a = np.ascontiguousarray(ref_pose, np.float64)
+        b = np.ascontiguousarray(read_pose, np.float64)
+        ok = _lib().refreg_cost_evaluate(self._h, _ptr(a, C.c_double), _ptr(b, C.c_double),
+                                         1 if want_jac else 0, _ptr(r, C.c_double),
+                                         _ptr(j0, C.c_double), _ptr(j1, C.c_double))
+        return bool(ok), r, j0, j1
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib().refreg_cost_destroy(self._h)
+            self._h = None

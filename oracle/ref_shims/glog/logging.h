@@ -1,0 +1,34 @@
+// CHECK* macros standing in for glog.  TEST INFRASTRUCTURE (oracle/ref_shims/README.md).
+#ifndef ORACLE_REF_SHIMS_GLOG_LOGGING_H_
+#define ORACLE_REF_SHIMS_GLOG_LOGGING_H_
+#include <cstdio>
+#include <cstdlib>
+#include <sstream>
+namespace ref_shims {
+class CheckFailure {
+ public:
+  CheckFailure(const char* file, int line, const char* what) {
+    s_ << file << ":" << line << " CHECK failed: " << what << " ";
+  }
+  [[noreturn]] ~CheckFailure() {
+    std::fprintf(stderr, "%s\n", s_.str().c_str());
+    std::abort();
+  }
+  std::ostream& stream() { return s_; }
+
+ private:
+  std::ostringstream s_;
+};
+}  // namespace ref_shims
+#define CHECK(cond) \
+  if (cond) {       \
+  } else            \
+    ::ref_shims::CheckFailure(__FILE__, __LINE__, #cond).stream()
+#define CHECK_EQ(a, b) CHECK((a) == (b))
+#define CHECK_NE(a, b) CHECK((a) != (b))
+#define CHECK_LE(a, b) CHECK((a) <= (b))
+#define CHECK_LT(a, b) CHECK((a) < (b))
+#define CHECK_GE(a, b) CHECK((a) >= (b))
+#define CHECK_GT(a, b) CHECK((a) > (b))
+#define CHECK_NOTNULL(p) (p)
+#endif

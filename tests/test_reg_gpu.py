@@ -546,3 +546,41 @@ def test_randomised_configurations_match_oracle(capi, ctx):
         for o in (batch, cf, g):
             o.destroy()
     print("randomised configurations: worst relative error", worst)
+
+
+# ------------------------------------------------ reference-source golden -----
+@pytest.mark.parametrize("case,use_esdf,no_corr,ratio", [
+    ("esdf_all", True, 0.0, -1.0), ("tsdf_nocorr", False, 0.7, -1.0), ("esdf_sampled", True, 0.0, 0.05)])
+def test_hip_path_matches_the_reference_source_golden(capi, ctx, golden_dir, case, use_esdf, no_corr, ratio):
+    """tests/golden/ref_reg_config1.npz holds outputs of the REFERENCE's own
+    registration_cost_function.cpp (compiled against oracle/ref_shims, see
+    tests/golden/make_ref_golden.py).  The HIP path, through the C ABI with device-side point
+    extraction, must match them to the contract's 1e-4 -- and does so bit for bit."""
+    import hashlib
+    import os
+    gold = np.load(os.path.join(golden_dir, "ref_reg_config1.npz"))
+    ref, read = synth.config1_pair(seed=0, asymmetric=True)
+    g_ref, g_read = H.gpu_submap(capi, ctx, ref, 30), H.gpu_submap(capi, ctx, read, 31)
+    n_pts = g_ref.extract_voxel_points(1.0, 0.3, use_esdf)
+    cfg = capi.default_config(registration_point_type=capi.POINTS_VOXELS, sampling_ratio=ratio,
+                              no_correspondence_cost=no_corr, use_esdf_distance=int(use_esdf))
+    cf = capi.RegistrationCostFunction(ctx, g_ref, g_read, cfg)
+    n = cf.num_residuals()
+    assert n == int(gold[f"{case}_num_residuals"]) and n <= n_pts
+    base, stride = gold["base_pose"], int(gold["stride"])
+    exact = 0
+    for k, pert in enumerate(gold["perturbations"]):    # successive calls continue the sampler stream
+        ok, r, jo, je = _gpu_eval(cf, base, base + pert)
+        assert ok
+        key = f"{case}_{k}"
+        H.assert_parity(r[::stride], gold[key + "_r"], key + " residual")
+        H.assert_parity(jo[::stride], gold[key + "_jref"], key + " jac_ref")
+        H.assert_parity(je[::stride], gold[key + "_jread"], key + " jac_read")
+        assert int((np.abs(jo).sum(1) > 0).sum()) == int(gold[key + "_corr"])
+        assert abs(0.5 * (r * r).sum() - float(gold[key + "_cost"])) <= 1e-9 * float(gold[key + "_cost"])
+        sha = [hashlib.sha256(np.ascontiguousarray(x).tobytes()).hexdigest() for x in (r, jo, je)]
+        exact += int(sha == list(gold[key + "_sha"]))
+    print(f"{case}: {exact}/{len(gold['perturbations'])} evaluations bit-identical to the reference source")
+    assert exact == len(gold["perturbations"])
+    for o in (cf, g_ref, g_read):
+        o.destroy()
