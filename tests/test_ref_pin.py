@@ -24,7 +24,7 @@ F = np.float32
 
 
 def _digest(a):
-    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    return hashlib.sha256(np.ascontiguousarray(np.asarray(a) + 0.0).tobytes()).hexdigest()   # -0 == +0
 
 
 @pytest.fixture(scope="module")
