@@ -1,6 +1,6 @@
 /*
  * oracle/reg_oracle.c -- CPU restatement of the REG path.  TEST INFRASTRUCTURE.
- * See reg_oracle.h for the usage rule and the "parity unpinned" statement.
+ * See reg_oracle.h for the usage rule and the parity status (pinned / unpinned parts).
  *
  * Build with -ffp-contract=off: the reference is compiled without FMA
  * contraction guarantees and its precision map is

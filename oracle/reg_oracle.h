@@ -5,18 +5,24 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * link or call this.  The product (libvoxgraph_amd.so) never does.
  *
- * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures
- * for this path, and it cannot be built here (Eigen, Ceres, voxblox, cblox,
- * minkindr, ROS absent).  What *is* pinned:
- *   - the two 3x4 pose-Jacobian matrices, against vectors generated from the
- *     reference's own sympy derivation voxgraph/scripts/jacobians_xyz_yaw.py
+ * PARITY STATUS: pinned to the reference's own source for everything voxgraph
+ * owns; unpinned for what voxblox / minkindr own.
+ *   - oracle/_ref/libref_reg.so is /root/reference's registration_cost_function.cpp
+ *     (+ its weighted_sampler / registration_point headers) compiled, from where it
+ *     lies, against the stand-in headers of oracle/ref_shims (Eigen, glog, minkindr,
+ *     voxblox, Ceres, ROS are absent from this image).  This file reproduces its
+ *     residuals and Jacobians value for value (tests/test_ref_pin.py, live and
+ *     through the committed fixture tests/golden/ref_reg_config1.npz).
+ *   - the two 3x4 pose-Jacobian matrices also match vectors generated from the
+ *     reference's sympy derivation voxgraph/scripts/jacobians_xyz_yaw.py
  *     (tests/golden/jacobians_xyz_yaw.json, made by tests/golden/make_golden.py)
- *   - the mt19937 stream, against the C++ standard's known answer
- *     (10000th draw of a default-seeded engine == 4123659995)
- *   - interpolation + analytic Jacobians, against closed forms (plane) and
- *     central differences.
- * Everything tagged [recalled] restates un-vendored dependencies (voxblox,
- * minkindr) from knowledge of their public sources.
+ *   - the mt19937 stream matches the C++ standard's known answer
+ *   - interpolation + analytic Jacobians match closed forms (plane) and central
+ *     differences.
+ * PARITY UNPINNED for everything tagged [recalled]: the un-vendored dependencies
+ * (voxblox grid + interpolator, minkindr transformation) are restated from
+ * knowledge of their public sources, here AND in the shims the reference source is
+ * compiled against; the reference ships no tests or fixtures that would pin them.
  */
 #ifndef VOXGRAPH_AMD_ORACLE_REG_ORACLE_H_
 #define VOXGRAPH_AMD_ORACLE_REG_ORACLE_H_
