@@ -48,7 +48,7 @@ def test_product_does_not_link_or_reference_the_oracle(capi):
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 for token in ("import oracle", "from oracle", "liboracle", "orc_", "pyoracle",
-                              "reg_oracle.h"):
+                              "reg_oracle.h", "ref_shims", "libref_reg", "refreg_", "ref_reg"):
                     assert token not in src, (dirpath, f, token)
 
 
