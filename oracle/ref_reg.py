@@ -1,5 +1,6 @@
 """ctypes view of oracle/_ref/libref_reg.so: the REFERENCE's own
-voxgraph::RegistrationCostFunction (registration_cost_function.cpp compiled from
+voxgraph::RegistrationCostFunction, voxgraph::VoxgraphSubmap and voxgraph::BoundingBox
+(registration_cost_function.cpp, voxgraph_submap.cpp, bounding_box.cpp compiled from
 /root/reference against the stand-in headers of oracle/ref_shims; see its README).
 
 TEST INFRASTRUCTURE.  Only tests/ and tests/golden/make_ref_golden.py import this.
@@ -33,12 +34,25 @@ def _lib():
     if _LIB is None:
         lib = C.CDLL(_SO)
         vp, f32p, f64p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double)
+        i32p = C.POINTER(C.c_int32)
         lib.refreg_submap_create.restype = vp
         lib.refreg_submap_create.argtypes = [C.c_uint32, f64p, C.c_float, C.c_int32, C.c_int32,
-                                             C.POINTER(C.c_int32), f32p, f32p, f32p,
-                                             C.POINTER(C.c_uint8)]
+                                             i32p, f32p, f32p, f32p, C.POINTER(C.c_uint8),
+                                             C.c_double, C.c_double, C.c_int32]
         lib.refreg_submap_destroy.argtypes = [vp]
-        lib.refreg_submap_add_points.argtypes = [vp, C.c_int32, C.c_int64, f32p, f32p, f32p]
+        lib.refreg_submap_set_pose.argtypes = [vp, f64p]
+        lib.refreg_submap_block_order.restype = C.c_int32
+        lib.refreg_submap_block_order.argtypes = [vp, i32p]
+        lib.refreg_submap_num_points.restype = C.c_int64
+        lib.refreg_submap_num_points.argtypes = [vp, C.c_int32]
+        lib.refreg_submap_get_points.argtypes = [vp, C.c_int32, f32p, f32p, f32p]
+        lib.refreg_submap_set_points.argtypes = [vp, C.c_int32, C.c_int64, f32p, f32p, f32p]
+        lib.refreg_submap_isosurface_blocks.restype = C.c_int32
+        lib.refreg_submap_isosurface_blocks.argtypes = [vp, i32p]
+        lib.refreg_submap_surface_obb.argtypes = [vp, f32p]
+        lib.refreg_submap_mission_surface_aabb.argtypes = [vp, f32p]
+        lib.refreg_submap_overlaps_with.restype = C.c_int32
+        lib.refreg_submap_overlaps_with.argtypes = [vp, vp]
         lib.refreg_cost_create.restype = vp
         lib.refreg_cost_create.argtypes = [vp, vp, C.c_int32, C.c_float, C.c_double, C.c_int32]
         lib.refreg_cost_destroy.argtypes = [vp]
@@ -55,10 +69,13 @@ def _ptr(a, t):
 
 
 class Submap:
-    """A finished submap as the reference cost function sees it (shim VoxgraphSubmap)."""
+    """The reference's VoxgraphSubmap, constructed from a TSDF layer, ESDF voxels injected,
+    then finishSubmap() (voxgraph_submap.cpp:84-107): surface OBB, findRelevantVoxelIndices,
+    findIsosurfaceVertices with the given registration filter (voxgraph_submap.h:26-30)."""
 
     def __init__(self, submap_id, pose, voxel_size, vps, block_index, tsdf_distance, tsdf_weight,
-                 esdf_distance=None, esdf_observed=None):
+                 esdf_distance=None, esdf_observed=None, min_voxel_weight=1.0, max_voxel_distance=0.3,
+                 use_esdf_distance=True):
         bi = np.ascontiguousarray(block_index, np.int32).reshape(-1, 3)
         td = np.ascontiguousarray(tsdf_distance, np.float32).ravel()
         tw = np.ascontiguousarray(tsdf_weight, np.float32).ravel()
@@ -68,14 +85,56 @@ class Submap:
         self._h = _lib().refreg_submap_create(int(submap_id), _ptr(pose, C.c_double), float(voxel_size),
                                               int(vps), bi.shape[0], _ptr(bi, C.c_int32),
                                               _ptr(td, C.c_float), _ptr(tw, C.c_float),
-                                              _ptr(ed, C.c_float), _ptr(eo, C.c_uint8))
+                                              _ptr(ed, C.c_float), _ptr(eo, C.c_uint8),
+                                              float(min_voxel_weight), float(max_voxel_distance),
+                                              int(bool(use_esdf_distance)))
 
-    def add_points(self, point_type, xyz, distance, weight):
+    def set_pose(self, pose):
+        pose = np.ascontiguousarray(pose, np.float64)
+        _lib().refreg_submap_set_pose(self._h, _ptr(pose, C.c_double))
+
+    def block_order(self):
+        """Layer::getAllAllocatedBlocks order (hash-map order: what the reference iterates in)."""
+        n = _lib().refreg_submap_block_order(self._h, None)
+        out = np.zeros((n, 3), np.int32)
+        _lib().refreg_submap_block_order(self._h, _ptr(out, C.c_int32))
+        return out
+
+    def points(self, point_type):
+        n = int(_lib().refreg_submap_num_points(self._h, int(point_type)))
+        xyz, d, w = np.zeros((n, 3), np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+        if n:
+            _lib().refreg_submap_get_points(self._h, int(point_type), _ptr(xyz, C.c_float),
+                                            _ptr(d, C.c_float), _ptr(w, C.c_float))
+        return xyz, d, w
+
+    def set_points(self, point_type, xyz, distance, weight):
+        """Replace a sampler's contents (addItem(point, weight) per point, as the reference fills it)."""
         xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
         d = np.ascontiguousarray(distance, np.float32)
         w = np.ascontiguousarray(weight, np.float32)
-        _lib().refreg_submap_add_points(self._h, int(point_type), xyz.shape[0], _ptr(xyz, C.c_float),
+        _lib().refreg_submap_set_points(self._h, int(point_type), xyz.shape[0], _ptr(xyz, C.c_float),
                                         _ptr(d, C.c_float), _ptr(w, C.c_float))
+
+    def isosurface_blocks(self):
+        n = _lib().refreg_submap_isosurface_blocks(self._h, None)
+        out = np.zeros((n, 3), np.int32)
+        if n:
+            _lib().refreg_submap_isosurface_blocks(self._h, _ptr(out, C.c_int32))
+        return out
+
+    def surface_obb(self):
+        out = np.zeros(6, np.float32)
+        _lib().refreg_submap_surface_obb(self._h, _ptr(out, C.c_float))
+        return out[:3].copy(), out[3:].copy()
+
+    def mission_surface_aabb(self):
+        out = np.zeros(6, np.float32)
+        _lib().refreg_submap_mission_surface_aabb(self._h, _ptr(out, C.c_float))
+        return out[:3].copy(), out[3:].copy()
+
+    def overlapsWith(self, other):
+        return bool(_lib().refreg_submap_overlaps_with(self._h, other._h))
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -100,6 +100,18 @@ class QuatTransformationTemplate {
     return v;
   }
   const Rotation& getRotation() const { return q_; }
+  Eigen::Matrix<Scalar, 4, 4> getTransformationMatrix() const {
+    Eigen::Matrix<Scalar, 4, 4> m;
+    for (int c = 0; c < 3; ++c) {
+      Position e;
+      e[c] = Scalar(1);
+      const Position col = q_.rotate(e);
+      for (int r = 0; r < 3; ++r) m(r, c) = col[r];
+      m(c, 3) = t_[c];
+    }
+    m(3, 3) = Scalar(1);
+    return m;
+  }
   const Position& getPosition() const { return t_; }
   QuatTransformationTemplate inverse() const {
     const Rotation qi = q_.inverse();

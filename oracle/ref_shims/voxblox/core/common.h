@@ -3,8 +3,10 @@
 #define ORACLE_REF_SHIMS_VOXBLOX_CORE_COMMON_H_
 #include <cmath>
 #include <cstdint>
+#include <iostream>
 #include <memory>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include <Eigen/Core>
@@ -34,6 +36,10 @@ inline AnyIndex getGridIndexFromPoint(const Point& p, const FloatingPoint grid_s
   for (int a = 0; a < 3; ++a) idx[a] = static_cast<int>(std::floor(p[a] * grid_size_inv + kCoordinateEpsilon));
   return idx;
 }
+template <typename IndexType>
+inline IndexType getGridIndexFromPoint(const Point& p, const FloatingPoint grid_size_inv) {
+  return getGridIndexFromPoint(p, grid_size_inv);
+}
 // (idx + 0.5) * grid_size: the sum and product are formed in double (the 0.5 literal)
 inline Point getCenterPointFromGridIndex(const AnyIndex& idx, FloatingPoint grid_size) {
   return Point(static_cast<FloatingPoint>((static_cast<FloatingPoint>(idx[0]) + 0.5) * grid_size),
@@ -53,5 +59,8 @@ struct AnyIndexEqual {
     return a[0] == b[0] && a[1] == b[1] && a[2] == b[2];
   }
 };
+typedef std::unordered_set<AnyIndex, AnyIndexHash, AnyIndexEqual> IndexSet;
+template <typename T>
+using AlignedVector = std::vector<T>;
 }  // namespace voxblox
 #endif

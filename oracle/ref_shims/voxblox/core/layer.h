@@ -14,6 +14,18 @@ class Layer {
     block_size_ = voxel_size_ * vps_;
     block_size_inv_ = 1.0 / block_size_;
   }
+  // deep copy, as voxblox's Layer copy constructor
+  Layer(const Layer& o)
+      : voxel_size_(o.voxel_size_), voxel_size_inv_(o.voxel_size_inv_), block_size_(o.block_size_),
+        block_size_inv_(o.block_size_inv_), vps_(o.vps_) {
+    for (const auto& kv : o.blocks_) blocks_.emplace(kv.first, std::make_shared<BlockType>(*kv.second));
+  }
+  bool hasBlock(const BlockIndex& index) const { return blocks_.count(index) > 0; }
+  const BlockType& getBlockByIndex(const BlockIndex& index) const {
+    auto it = blocks_.find(index);
+    CHECK(it != blocks_.end()) << "block does not exist";
+    return *it->second;
+  }
   FloatingPoint voxel_size() const { return voxel_size_; }
   FloatingPoint voxel_size_inv() const { return voxel_size_inv_; }
   FloatingPoint block_size() const { return block_size_; }

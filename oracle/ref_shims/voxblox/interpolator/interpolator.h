@@ -13,6 +13,23 @@ class Interpolator {
  public:
   explicit Interpolator(const Layer<VoxelType>* layer) : layer_(layer) {}
 
+  // getVoxel(pos, &voxel, interpolate = true): every field trilinearly interpolated with the
+  // same q-vector / B_1 table; without interpolation, the voxel containing pos
+  bool getVoxel(const Point& pos, VoxelType* voxel, bool interpolate = false) const {
+    if (!interpolate) {
+      typename Layer<VoxelType>::BlockType::ConstPtr block =
+          layer_->getBlockPtrByIndex(layer_->computeBlockIndexFromCoordinates(pos));
+      if (!block) return false;
+      *voxel = block->getVoxelByVoxelIndex(block->computeTruncatedVoxelIndexFromCoordinates(pos));
+      return true;
+    }
+    const VoxelType* voxels[8];
+    InterpVector q;
+    if (!getVoxelsAndQVector(pos, voxels, &q)) return false;
+    *voxel = interpVoxel(q, voxels);
+    return true;
+  }
+
   // the eight voxels surrounding `pos` (neighbour k sits at base + (k>>2&1, k>>1&1, k&1))
   // and q = [1, dx, dy, dz, dx dy, dy dz, dz dx, dx dy dz] relative to the base voxel's centre;
   // false as soon as a block is missing or a voxel is not valid
@@ -51,6 +68,30 @@ class Interpolator {
   }
 
  private:
+  static InterpTable table() {
+    return (InterpTable() << 1, 0, 0, 0, 0, 0, 0, 0,    -1, 0, 0, 0, 1, 0, 0, 0,   -1, 0, 1, 0, 0, 0, 0, 0,
+            -1, 1, 0, 0, 0, 0, 0, 0,   1, 0, -1, 0, -1, 0, 1, 0,   1, -1, -1, 1, 0, 0, 0, 0,
+            1, -1, 0, 0, -1, 1, 0, 0,  -1, 1, 1, -1, 1, -1, -1, 1).finished();
+  }
+  static TsdfVoxel interpVoxel(const InterpVector& q, const TsdfVoxel** voxels) {
+    InterpVector d, w;
+    for (int i = 0; i < 8; ++i) {
+      d[i] = voxels[i]->distance;
+      w[i] = voxels[i]->weight;
+    }
+    TsdfVoxel out;
+    out.distance = q * (table() * d.transpose());
+    out.weight = q * (table() * w.transpose());
+    return out;
+  }
+  static EsdfVoxel interpVoxel(const InterpVector& q, const EsdfVoxel** voxels) {
+    InterpVector d;
+    for (int i = 0; i < 8; ++i) d[i] = voxels[i]->distance;
+    EsdfVoxel out;
+    out.distance = q * (table() * d.transpose());
+    out.observed = true;
+    return out;
+  }
   // block containing pos (must exist) and the voxel whose centre is the lower corner of the
   // interpolation cell; stepping below index 0 moves to the previous block
   bool setIndexes(const Point& pos, BlockIndex* block_index, VoxelIndex* base) const {

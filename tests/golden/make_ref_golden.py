@@ -49,9 +49,37 @@ CASES = [
 ]
 
 
+def submap_scene():
+    """tests/golden/ref_submap_scene.npz: the reference's finishSubmap() products, boxes and overlap
+    list for the 7-submap scene of tests/test_ref_submap_pin.py (digests + block orders + boxes)."""
+    from tests.test_ref_submap_pin import scene_submaps
+    out, refs = {}, []
+    for k, (i, sm, pose) in enumerate(scene_submaps()):
+        R = ref_reg.Submap(i, pose, sm.voxel_size, sm.vps, sm.block_index, sm.tsdf_distance, sm.tsdf_weight,
+                           sm.esdf_distance, sm.esdf_observed)
+        refs.append(R)
+        out[f"s{k}_id"] = np.int64(i)
+        out[f"s{k}_pose"] = pose
+        out[f"s{k}_block_order"] = R.block_order()
+        for name, t in (("voxels", ref_reg.POINTS_VOXELS), ("iso", ref_reg.POINTS_ISOSURFACE)):
+            xyz, d, w = R.points(t)
+            out[f"s{k}_{name}_n"] = np.int64(len(w))
+            out[f"s{k}_{name}_sha"] = np.array([digest(xyz), digest(d), digest(w)])
+        out[f"s{k}_iso_blocks"] = np.unique(R.isosurface_blocks(), axis=0)
+        out[f"s{k}_obb"] = np.concatenate(R.surface_obb())
+        out[f"s{k}_aabb"] = np.concatenate(R.mission_surface_aabb())
+    out["n_submaps"] = np.int64(len(refs))
+    out["pairs"] = np.array([(a, b) for a in range(len(refs)) for b in range(a + 1, len(refs))
+                             if refs[a].overlapsWith(refs[b])], np.int64)
+    path = os.path.join(ROOT, "tests", "golden", "ref_submap_scene.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes;", len(out["pairs"]), "overlapping pairs")
+
+
 def main():
     if not ref_reg.build():
         raise SystemExit("oracle/_ref/libref_reg.so could not be built (no /root/reference?)")
+    submap_scene()
     ref, read, pts = inputs()
     out = {"stride": np.int64(STRIDE), "base_pose": BASE, "perturbations": np.array(PERTURBATIONS)}
     for name, arr in (("ref_tsdf", ref.tsdf_distance), ("ref_esdf", ref.esdf_distance),
@@ -62,7 +90,7 @@ def main():
         xyz, d, w = pts[use_esdf]
         R = ref_reg.Submap(0, ref.pose, ref.voxel_size, ref.vps, ref.block_index, ref.tsdf_distance,
                            ref.tsdf_weight, ref.esdf_distance, ref.esdf_observed)
-        R.add_points(ref_reg.POINTS_VOXELS, xyz, d, w)
+        R.set_points(ref_reg.POINTS_VOXELS, xyz, d, w)
         E = ref_reg.Submap(1, read.pose, read.voxel_size, read.vps, read.block_index,
                            read.tsdf_distance, read.tsdf_weight, read.esdf_distance, read.esdf_observed)
         cf = ref_reg.RegistrationCostFunction(R, E, ref_reg.POINTS_VOXELS, **kw)

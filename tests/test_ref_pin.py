@@ -96,7 +96,7 @@ def _ref_pair(scene, use_esdf, point_type=ref_reg.POINTS_VOXELS, points=None):
     xyz, d, w = points if points is not None else pts[use_esdf]
     R = ref_reg.Submap(0, ref.pose, ref.voxel_size, ref.vps, ref.block_index, ref.tsdf_distance,
                        ref.tsdf_weight, ref.esdf_distance, ref.esdf_observed)
-    R.add_points(point_type, xyz, d, w)
+    R.set_points(point_type, xyz, d, w)
     E = ref_reg.Submap(1, read.pose, read.voxel_size, read.vps, read.block_index, read.tsdf_distance,
                        read.tsdf_weight, read.esdf_distance, read.esdf_observed)
     return R, E, (xyz, d, w)
