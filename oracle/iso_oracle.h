@@ -5,7 +5,9 @@
  * ("explicit_to_implicit", voxgraph/config/voxgraph_mapper.yaml:35).
  * TEST INFRASTRUCTURE ONLY (usage rule in reg_oracle.h).
  *
- * PARITY UNPINNED.  The reference builds these points from three voxblox pieces that are
+ * PARITY: the part voxgraph owns (interpolated distance/weight per vertex, CHECK_LE, block set) is
+ * pinned to the reference's own voxgraph_submap.cpp (tests/test_ref_submap_pin.py, oracle/_ref);
+ * the vertex positions are UNPINNED.  The reference builds these points from three voxblox pieces that are
  * not vendored: MeshIntegrator::generateMesh (marching cubes over the dual cells of the
  * TSDF, a cell is meshed iff all 8 corner voxels have weight > min_weight),
  * MeshLayer::getConnectedMesh(mesh, 0.5 * voxel_size) (vertices whose coordinates round to

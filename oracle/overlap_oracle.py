@@ -5,8 +5,10 @@
   VoxgraphSubmap::overlapsWith               voxgraph_submap.cpp:245-278
   PoseGraphInterface::updateOverlappingSubmapList  voxgraph/src/frontend/pose_graph_interface/pose_graph_interface.cpp:109-147
 
-This part of the path is in the reference itself (no un-vendored arithmetic except the
-f32 rigid transform, taken from oracle/reg_oracle.c); still unpinned by any reference test.
+This part of the path is in the reference itself (no un-vendored arithmetic except the f32 rigid
+transform, taken from oracle/reg_oracle.c).  Pinned: tests/test_ref_submap_pin.py runs the
+reference's own voxgraph_submap.cpp / bounding_box.cpp (oracle/_ref, compiled against
+oracle/ref_shims) and these functions reproduce its boxes and overlap decisions exactly.
 """
 import numpy as np
 
