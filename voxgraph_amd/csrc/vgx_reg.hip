@@ -469,6 +469,9 @@ constexpr int kMaxReduceIters = 64;
 // 120 VGPRs -> 4 waves/SIMD.  Forcing 5 or 6 (launch_bounds) spills the 21 f64
 // accumulators: measured 7.8 / 13.0 ms per fused step against 2.45 ms.
 constexpr int kReduceWavesPerSimd = 4;
+// The loop is VALU-bound (~310 VALU instructions per point, profiles/README.md "fused kernel"):
+// fused multiply-adds for the 21 f64 accumulations took 2.23 -> 2.11 ms; a branch-free variant
+// (masked lanes carried through the FMAs) needed 144 VGPRs: 2.43 ms at 3 waves/SIMD, 2.94 ms spilling at 4.
 constexpr int kReducePointsPerThread = 2;  // measured: 3.72 / 3.29 / 3.41 ms per fused step at 4 / 2 / 1 (profiles/tune_fused.sh)
 
 // True when no point inside the sphere (centre in the reference frame) can have a
@@ -594,9 +597,9 @@ __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_kernel(
 #pragma unroll
         for (int a = 0; a < 6; ++a)
 #pragma unroll
-          for (int b = a; b < 6; ++b) acc[k++] += u[a] * u[b];
+          for (int b = a; b < 6; ++b, ++k) acc[k] = __builtin_fma(u[a], u[b], acc[k]);
       } else {
-        acc[20] += e.r * e.r;  // w * no_correspondence_cost, zero Jacobian rows
+        acc[20] = __builtin_fma(e.r, e.r, acc[20]);  // w * no_correspondence_cost, zero Jacobian rows
       }
     }
   }
