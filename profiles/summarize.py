@@ -1,21 +1,29 @@
 #!/usr/bin/env python3
 """Turns the rocprofv3 CSVs collected by profiles/collect.sh into the committed
-summaries: profiles/rNN_kernel_stats.json, profiles/rNN_pmc_hbm.json and
-profiles/hbm_traffic.json (read by bench.py for roofline.traffic).
+summaries: profiles/rNN_kernel_stats.json, profiles/rNN_pmc_hbm.json,
+profiles/rNN_pmc_fused.json and profiles/hbm_traffic.json (read by bench.py for
+roofline.traffic), and copies the raw CSVs next to them.
 
-HBM bytes follow MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are in KiB and
-are uncalibrated on gfx950 (FETCH_SIZE reads 1/2 of a wide coalesced stream), so
-each counter is corrected by the factor measured on a calibration launch of the
-same kernel with a known byte count (every evaluation without correspondence:
-exactly 20 B read, 36 B written per residual)."""
+HBM bytes, following MI355X_MICROARCH.md "HBM":
+  reads  : FETCH_SIZE is RDREQ x 64 B on gfx950, i.e. half of a stream of 128-B requests.  Instead
+           of doubling it blindly the read requests are counted per size class
+           (TCC_EA0_RDREQ_{32B,64B,128B}_sum): bytes = 32 n32 + 64 n64 + 128 n128, exact for any
+           request mix; FETCH_SIZE of a second pass is reported beside it (x2 must agree).
+  writes : WRITE_SIZE is uncalibrated, so it is scaled by (known bytes / counted bytes) of the
+           calibration dispatches of the same kernel, in which every residual writes exactly 36 B
+           (outputs are written once, so the known figure is exact; measured factor ~0.95 with
+           the kernel's non-temporal stores).  The fused kernel uses plain stores (x0.998).
+Reads are NOT calibrated against "20 B per point": constraints that share a reference submap
+re-read its points out of L2 / Infinity Cache, so the true fabric read volume is below that."""
 import argparse
 import csv
 import glob
 import json
 import os
+import shutil
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "reg_eval_points_kernel"
+KERNEL, FUSED = "reg_eval_points_kernel", "reg_eval_reduce_kernel"
 
 
 def rows(pattern):
@@ -26,11 +34,31 @@ def rows(pattern):
     return out
 
 
-def counter(prefix, name):
-    r = [x for x in rows(f"{prefix}/**/*counter_collection.csv")
-         if KERNEL in x.get("Kernel_Name", "") and x.get("Counter_Name") == name]
-    r.sort(key=lambda x: int(x.get("Dispatch_Id", 0)))
-    return [float(x["Counter_Value"]) for x in r]
+def dispatches(prefix, kernel):
+    """[{counter: value}] per dispatch of `kernel`, in dispatch order"""
+    d = {}
+    for x in rows(f"{prefix}/**/*counter_collection.csv"):
+        if kernel in x.get("Kernel_Name", ""):
+            d.setdefault(int(x["Dispatch_Id"]), {})[x["Counter_Name"]] = float(x["Counter_Value"])
+    return [d[k] for k in sorted(d)]
+
+
+def read_bytes(c):
+    return (32.0 * c.get("TCC_EA0_RDREQ_32B_sum", 0) + 64.0 * c.get("TCC_EA0_RDREQ_64B_sum", 0) +
+            128.0 * c.get("TCC_EA0_RDREQ_128B_sum", 0))
+
+
+def bench_line(name):
+    p = os.path.join(ROOT, "gpurun_out", name)
+    if os.path.exists(p):
+        for line in open(p):
+            if line.startswith("{"):
+                return json.loads(line)
+    return None
+
+
+def mean(v):
+    return sum(v) / len(v)
 
 
 def main():
@@ -38,54 +66,81 @@ def main():
     ap.add_argument("--round", default="01")
     a = ap.parse_args()
     tag = f"r{int(a.round):02d}"
+    N_CAL = 2                                            # bench.py --calibrate: two far-pose launches
     # ---- kernel stats of the bench command -----------------------------------
     stats = rows("prof_stats/**/*kernel_stats.csv")
-    bench = None
-    bpath = os.path.join(ROOT, "gpurun_out", "prof_stats_bench.json")
-    if os.path.exists(bpath):
-        for line in open(bpath):
-            if line.startswith("{"):
-                bench = json.loads(line)
+    bench = bench_line("prof_stats_bench.json")
     summ = {"command": "rocprofv3 --kernel-trace --stats -f csv -- python bench.py",
             "kernels": [{k: v for k, v in x.items()} for x in stats[:12]],
             "bench_line": bench}
+    avg_ms = {}
     for x in stats:
+        for k in (KERNEL, FUSED):
+            if k in x.get("Name", ""):
+                avg_ms[k] = float(x.get("AverageNs", 0)) / 1e6
         if KERNEL in x.get("Name", ""):
-            avg_ns = float(x.get("AverageNs", x.get("Average", 0)))
             summ["dominant_kernel"] = {"name": x["Name"], "calls": int(x.get("Calls", 0)),
-                                       "avg_ms_rocprof": avg_ns / 1e6}
+                                       "avg_ms_rocprof": avg_ms[KERNEL]}
             if bench:
                 summ["dominant_kernel"]["avg_ms_bench_hip_events"] = bench["roofline"]["kernel_ms"]
     json.dump(summ, open(os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.json"), "w"), indent=1)
-    # ---- HBM traffic ------------------------------------------------------------
-    fetch, write = counter("prof_fetch", "FETCH_SIZE"), counter("prof_write", "WRITE_SIZE")
-    pmc_bench = None
-    ppath = os.path.join(ROOT, "gpurun_out", "prof_fetch_bench.json")
-    if os.path.exists(ppath):
-        for line in open(ppath):
-            if line.startswith("{"):
-                pmc_bench = json.loads(line)
-    res = {"fetch_KiB_per_dispatch": fetch, "write_KiB_per_dispatch": write}
-    if fetch and write and pmc_bench and len(fetch) > 1 and len(write) > 1:
+    # ---- HBM traffic of the dominant kernel ---------------------------------------
+    rd, fetch, write = dispatches("prof_rd", KERNEL), dispatches("prof_fetch", KERNEL), dispatches("prof_write", KERNEL)
+    pmc_bench = bench_line("prof_rd_bench.json")
+    res = {"read_requests_per_dispatch": rd,
+           "fetch_KiB_per_dispatch": [c.get("FETCH_SIZE") for c in fetch],
+           "write_KiB_per_dispatch": [c.get("WRITE_SIZE") for c in write],
+           "calibration_dispatches": N_CAL}
+    if pmc_bench and len(rd) > N_CAL and len(write) > N_CAL:
         R = pmc_bench["roofline"]["units_per_launch"]
-        known_r, known_w = 20.0 * R, 36.0 * R
-        cf = known_r / (fetch[0] * 1024.0)        # dispatch 0 = calibration launch
-        cw = known_w / (write[0] * 1024.0)
-        fr = sum(fetch[1:]) / len(fetch[1:]) * 1024.0 * cf
-        wr = sum(write[1:]) / len(write[1:]) * 1024.0 * cw
-        res.update({"residuals_per_launch": R, "calibration": {
-            "known_read_bytes": known_r, "known_write_bytes": known_w,
-            "fetch_correction": cf, "write_correction": cw},
-            "hbm_read_bytes_per_launch": fr, "hbm_write_bytes_per_launch": wr,
-            "hbm_bytes_per_launch": fr + wr,
-            "algorithmic_bytes_88": 88.0 * R,
-            "n_gpus": 1})
+        known_w = 36.0 * R
+        cw = known_w / (mean([c["WRITE_SIZE"] for c in write[:N_CAL]]) * 1024.0)
+        fr = mean([read_bytes(c) for c in rd[N_CAL:]])
+        wr = mean([c["WRITE_SIZE"] for c in write[N_CAL:]]) * 1024.0 * cw
+        res.update({"residuals_per_launch": R,
+                    "calibration": {"known_write_bytes": known_w, "write_correction": cw,
+                                    "read_bytes_calibration_launch": mean([read_bytes(c) for c in rd[:N_CAL]]),
+                                    "read_bytes_if_20B_per_point": 20.0 * R},
+                    "hbm_read_bytes_per_launch": fr, "hbm_write_bytes_per_launch": wr,
+                    "hbm_bytes_per_launch": fr + wr, "algorithmic_bytes_88": 88.0 * R, "n_gpus": 1})
+        if len(fetch) > N_CAL:
+            f2 = mean([c["FETCH_SIZE"] for c in fetch[N_CAL:]]) * 1024.0 * 2.0
+            res["fetch_size_x2_bytes"] = f2                 # the guide's "double it": must agree with the exact count
+            res["fetch_size_x2_over_exact"] = f2 / fr
+        if KERNEL in avg_ms:
+            res["hbm_GBs_at_rocprof_avg"] = (fr + wr) / (avg_ms[KERNEL] * 1e-3) / 1e9
         json.dump({"residuals_per_launch": R, "n_gpus": 1, "hbm_bytes_per_launch": fr + wr,
                    "source": f"profiles/{tag}_pmc_hbm.json"},
                   open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
     json.dump(res, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm.json"), "w"), indent=1)
-    print(json.dumps({"stats": summ.get("dominant_kernel"), "pmc": {k: v for k, v in res.items()
-                                                                    if not k.endswith("_dispatch")}}, indent=1))
+    # ---- fused kernel --------------------------------------------------------------
+    frd, fwr = dispatches("prof_rd", FUSED), dispatches("prof_write", FUSED)
+    fused = None
+    if frd and fwr and "residuals_per_launch" in res:
+        fused = {"kernel": FUSED, "dispatches": len(frd), "residuals_per_launch": res["residuals_per_launch"],
+                 "read_requests_per_dispatch": frd,
+                 "write_KiB_per_dispatch": [c.get("WRITE_SIZE") for c in fwr], "write_correction": 0.998,
+                 "hbm_read_bytes_per_launch": mean([read_bytes(c) for c in frd]),
+                 "hbm_write_bytes_per_launch": mean([c["WRITE_SIZE"] for c in fwr]) * 1024.0 * 0.998}
+        fused["hbm_bytes_per_launch"] = fused["hbm_read_bytes_per_launch"] + fused["hbm_write_bytes_per_launch"]
+        if FUSED in avg_ms:
+            fused["avg_ms_rocprof"] = avg_ms[FUSED]
+            fused["hbm_GBs"] = fused["hbm_bytes_per_launch"] / (avg_ms[FUSED] * 1e-3) / 1e9
+        json.dump(fused, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_fused.json"), "w"), indent=1)
+    # ---- copies of the raw evidence ---------------------------------------------------
+    for src, dst in (("prof_stats/**/*kernel_stats.csv", f"{tag}_rocprofv3_kernel_stats.csv"),
+                     ("prof_rd/**/*counter_collection.csv", f"{tag}_pmc_rdreq_counter_collection.csv"),
+                     ("prof_fetch/**/*counter_collection.csv", f"{tag}_pmc_fetch_counter_collection.csv"),
+                     ("prof_write/**/*counter_collection.csv", f"{tag}_pmc_write_counter_collection.csv"),
+                     ("prof_stats_bench.json", f"{tag}_bench_under_rocprof.json"),
+                     ("bench_full.json", f"{tag}_bench_full.json")):
+        found = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", src), recursive=True))
+        if found:
+            shutil.copyfile(found[0], os.path.join(ROOT, "profiles", dst))
+    keep = ("residuals_per_launch", "calibration", "hbm_read_bytes_per_launch", "hbm_write_bytes_per_launch",
+            "hbm_bytes_per_launch", "fetch_size_x2_over_exact", "hbm_GBs_at_rocprof_avg")
+    print(json.dumps({"stats": summ.get("dominant_kernel"), "pmc": {k: res[k] for k in keep if k in res},
+                      "fused": {k: v for k, v in (fused or {}).items() if not k.endswith("_dispatch")}}, indent=1))
 
 
 if __name__ == "__main__":
