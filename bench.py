@@ -114,12 +114,51 @@ def cpu_baseline(capi, ctx, args, true_poses, poses, pairs, seconds):
         while time.perf_counter() - t4 < max(2.0, seconds / 4):
             done4 += sum(ex.map(task, range(4)))
     dt4 = time.perf_counter() - t4
-    return {"value": done / dt / 1e6, "unit": "Mresiduals+Jacobians/s", "cores": cores,
-            "value_4_threads": done4 / dt4 / 1e6,
-            "kind": "port",
-            "sample": f"constraint 0 of the same graph ({n} residuals, one 256^3 pair) evaluated "
-                      f"{done // n} times, one evaluation per task on {cores} threads, {dt:.1f} s; "
-                      "oracle/reg_oracle.c (gcc -O2), the reference itself cannot be built here"}
+    out = {"value": done / dt / 1e6, "unit": "Mresiduals+Jacobians/s", "cores": cores,
+           "value_4_threads": done4 / dt4 / 1e6,
+           "kind": "port",
+           "sample": f"constraint 0 of the same graph ({n} residuals, one 256^3 pair) evaluated "
+                     f"{done // n} times, one evaluation per task on {cores} threads, {dt:.1f} s; "
+                     "oracle/reg_oracle.c (gcc -O2)"}
+    # The reference's OWN RegistrationCostFunction::Evaluate (oracle/_ref: its source compiled
+    # against stand-in headers, hashed-block voxblox layer included), when the prebuilt library
+    # travelled here: same constraint, same poses, its results checked against the port's.
+    try:
+        from oracle import ref_reg
+        if ref_reg.available():
+            subs_ref = {}
+            for k in (a, b):
+                bi, td, tw, ed, eo = subs[k]
+                subs_ref[k] = ref_reg.Submap(k, true_poses[k], args.voxel_size, 16, bi, td, tw, ed, eo)
+            # the reference walks its hash map in its own block order: same point SET, so compare sorted
+            cf0 = ref_reg.RegistrationCostFunction(subs_ref[a], subs_ref[b])
+            ok_r, r_ref, _, _ = cf0.Evaluate(poses[a], poses[b])
+            ok_p, r_port, _, _ = orc.reg_evaluate(layer, xyz, dist, w, poses[a], poses[b])
+            same = bool(ok_r and ok_p and np.array_equal(np.sort(r_ref), np.sort(r_port)))
+            n_thr = min(cores, 64)
+            cfs = [ref_reg.RegistrationCostFunction(subs_ref[a], subs_ref[b]) for _ in range(n_thr)]
+
+            def ref_task(i):
+                cfs[i].Evaluate(poses[a], poses[b])
+                return cfs[i].num_residuals()
+
+            def timed(threads, budget):
+                cnt, t = 0, time.perf_counter()
+                with ThreadPoolExecutor(threads) as ex:
+                    while time.perf_counter() - t < budget:
+                        cnt += sum(ex.map(ref_task, range(threads)))
+                return cnt / (time.perf_counter() - t) / 1e6
+            out["reference_source"] = {
+                "kind": "reference", "unit": "Mresiduals+Jacobians/s",
+                "value": timed(n_thr, max(2.0, seconds / 3)), "cores": n_thr,
+                "value_4_threads": timed(4, max(2.0, seconds / 6)),
+                "residuals_equal_to_port": same,
+                "sample": "the same constraint through /root/reference's registration_cost_function.cpp, "
+                          "compiled (g++ -O2) against oracle/ref_shims (hashed 16^3 blocks of 12/20-byte "
+                          "voxels behind shared_ptr, minimal Eigen); one cost function per thread"}
+    except Exception as e:                                    # the checker must never sink the bench
+        out["reference_source"] = {"error": repr(e)}
+    return out
 
 
 def _room_points(dirs, origin):
