@@ -1,0 +1,105 @@
+// VoxgraphSubmap -> vgx_submap upload glue: the piece a voxgraph maintainer adds next to
+// VoxgraphSubmap::finishSubmap (voxgraph_submap.cpp:84-107) so that the registration cost function
+// built at registration_constraint.cpp:33-35 can be the GPU one (gpu_registration_cost_function.h).
+//
+// Header-only templates written against the public API of voxgraph / cblox / voxblox, so this file
+// needs none of their headers itself:
+//   SubmapT  = voxgraph::VoxgraphSubmap   getID(), getTsdfMap().getTsdfLayer(), getEsdfMap().getEsdfLayer(),
+//                                         getRegistrationPoints(RegistrationPointType)
+//   layers   = voxblox::Layer<Voxel>      voxel_size(), voxels_per_side(), getAllAllocatedBlocks(),
+//                                         getBlockByIndex(), getBlockPtrByIndex()
+//   blocks   = voxblox::Block<Voxel>      getVoxelByLinearIndex()
+//   sampler  = voxgraph::WeightedSampler<RegistrationPoint>   size(), operator[]
+// It is compiled and run against the reference's own classes in tests (oracle/ref_driver/dropin_check.cpp).
+#ifndef VOXGRAPH_AMD_CPP_VOXGRAPH_SUBMAP_BRIDGE_H_
+#define VOXGRAPH_AMD_CPP_VOXGRAPH_SUBMAP_BRIDGE_H_
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+#include "voxgraph_amd.h"
+
+namespace voxgraph_amd {
+namespace detail {
+template <typename F>
+struct ListArgument;
+template <typename C, typename L>
+struct ListArgument<void (C::*)(L*) const> {
+  typedef L type;
+};
+}  // namespace detail
+
+// Copies one registration-point set (voxgraph_submap.h:66-69) in the sampler's own order, so that
+// residual i of the GPU cost function is residual i of the reference's (and weighted sampling
+// draws the same items).
+template <typename SubmapT, typename PointTypeT>
+void UploadRegistrationPoints(vgx_ctx ctx, const SubmapT& submap, PointTypeT point_type,
+                              int32_t vgx_point_type, vgx_submap out) {
+  const auto& sampler = submap.getRegistrationPoints(point_type);
+  const size_t n = sampler.size();
+  std::vector<float> xyz(3 * n), distance(n), weight(n);
+  for (size_t i = 0; i < n; ++i) {
+    const auto& p = sampler[static_cast<int>(i)];  // RegistrationPoint (registration_point.h:6-12)
+    xyz[3 * i + 0] = p.position.x();
+    xyz[3 * i + 1] = p.position.y();
+    xyz[3 * i + 2] = p.position.z();
+    distance[i] = p.distance;
+    weight[i] = p.weight;
+  }
+  const int rc = vgx_submap_set_points(out, vgx_point_type, static_cast<int64_t>(n), xyz.data(),
+                                       distance.data(), weight.data(), VGX_POINTS_KEEP_ORDER);
+  if (rc != VGX_OK) throw std::runtime_error(std::string("vgx_submap_set_points: ") + vgx_last_error(ctx));
+}
+
+// Uploads a FINISHED submap: both layers (block by block, voxblox linear voxel order) and both
+// cached registration-point sets.  The returned handle is immutable and independent of `submap`.
+template <typename SubmapT>
+vgx_submap UploadFinishedSubmap(vgx_ctx ctx, const SubmapT& submap) {
+  const auto& tsdf = submap.getTsdfMap().getTsdfLayer();
+  const auto& esdf = submap.getEsdfMap().getEsdfLayer();
+  const size_t vps = tsdf.voxels_per_side();
+  const size_t vox = vps * vps * vps;
+  // voxblox::BlockIndexList, named through Layer::getAllAllocatedBlocks(BlockIndexList*) const
+  using LayerT = typename std::decay<decltype(tsdf)>::type;
+  typename detail::ListArgument<decltype(&LayerT::getAllAllocatedBlocks)>::type block_list;
+  tsdf.getAllAllocatedBlocks(&block_list);
+  const size_t nb = block_list.size();
+  std::vector<int32_t> block_index(3 * nb);
+  std::vector<float> tsdf_distance(nb * vox), tsdf_weight(nb * vox), esdf_distance(nb * vox);
+  std::vector<uint8_t> esdf_observed(nb * vox);
+  for (size_t b = 0; b < nb; ++b) {
+    for (int a = 0; a < 3; ++a) block_index[3 * b + a] = block_list[b][a];
+    const auto& tb = tsdf.getBlockByIndex(block_list[b]);
+    const auto eb = esdf.getBlockPtrByIndex(block_list[b]);  // may be absent: nothing observed there
+    for (size_t i = 0; i < vox; ++i) {
+      const auto& tv = tb.getVoxelByLinearIndex(i);
+      tsdf_distance[b * vox + i] = tv.distance;
+      tsdf_weight[b * vox + i] = tv.weight;
+      if (eb) {
+        const auto& ev = eb->getVoxelByLinearIndex(i);
+        esdf_distance[b * vox + i] = ev.distance;
+        esdf_observed[b * vox + i] = ev.observed ? 1 : 0;
+      } else {
+        esdf_distance[b * vox + i] = 0.0f;
+        esdf_observed[b * vox + i] = 0;
+      }
+    }
+  }
+  vgx_submap out = nullptr;
+  const int rc = vgx_submap_create(ctx, static_cast<int32_t>(submap.getID()), tsdf.voxel_size(),
+                                   static_cast<int32_t>(vps), static_cast<int32_t>(nb), block_index.data(),
+                                   tsdf_distance.data(), tsdf_weight.data(), esdf_distance.data(),
+                                   esdf_observed.data(), &out);
+  if (rc != VGX_OK) throw std::runtime_error(std::string("vgx_submap_create: ") + vgx_last_error(ctx));
+  using PointType = typename SubmapT::RegistrationPointType;
+  UploadRegistrationPoints(ctx, submap, PointType::kVoxels, VGX_POINTS_VOXELS, out);
+  UploadRegistrationPoints(ctx, submap, PointType::kIsosurfacePoints, VGX_POINTS_ISOSURFACE, out);
+  return out;
+}
+
+}  // namespace voxgraph_amd
+#endif  // VOXGRAPH_AMD_CPP_VOXGRAPH_SUBMAP_BRIDGE_H_
