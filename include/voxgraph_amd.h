@@ -201,7 +201,12 @@ typedef struct vgx_reg_config {
   float sampling_ratio;            /* -1 disables sampling (h:28)             */
   double no_correspondence_cost;   /* default 0 (h:32)                        */
   int32_t use_esdf_distance;       /* default 1 (h:35)                        */
-  uint32_t sampler_seed;           /* std::mt19937 default 5489               */
+  uint32_t sampler_seed;           /* 0 (default): draw from the reference submap's own
+                                    * sampler stream -- one default-seeded (5489)
+                                    * std::mt19937 per point set, advanced by every cost
+                                    * function sampling that set, as WeightedSampler does
+                                    * (weighted_sampler.h:36-39).  != 0: a private engine
+                                    * seeded with this value                              */
 } vgx_reg_config;
 VGX_API void vgx_reg_config_default(vgx_reg_config* cfg);
 

@@ -93,6 +93,9 @@ struct PointSet {
   std::vector<int64_t> order;            // order[i] = uploaded index of point i (empty = identity)
   std::vector<int32_t> inv_order;        // uploaded index -> device index (for sampling)
   std::vector<double> cumulative_weight; // WeightedSampler::cumulative_item_weights_ (upload order)
+  // WeightedSampler's mutable engine (weighted_sampler.h:36-39): ONE default-seeded std::mt19937 per
+  // point set, shared by every cost function that samples this set (vgx_reg_config.sampler_seed == 0)
+  std::mt19937 rng;
 };
 
 struct Grid {
@@ -133,7 +136,7 @@ struct vgx_reg_s {
   vgx_submap reading = nullptr;
   vgx_reg_config cfg{};
   int64_t num_residuals = 0;
-  // sampling mode state: mirrors the WeightedSampler's mutable RNG
+  // sampling mode state: a private engine when cfg.sampler_seed != 0, else the point set's
   std::mt19937 rng;
   std::uniform_real_distribution<double> uniform{0.0, 1.0};
   int32_t* d_sample_idx = nullptr;

@@ -836,13 +836,16 @@ vgx::ConstraintDev vgx_reg_s::describe() const {
 }
 
 // WeightedSampler::getRandomItem (weighted_sampler_inl.h:18-28), num_residuals
-// draws per Evaluate (RCF:113-122), on the constraint's own engine.
+// draws per Evaluate (RCF:113-122).  The engine is the reference submap's point-set engine, as in
+// the reference (every cost function built on a submap advances the same stream), unless the
+// caller asked for a private, separately seeded one.
 bool vgx_reg_s::draw_samples() {
-  const PointSet& ps = reference->points[cfg.registration_point_type];
+  PointSet& ps = reference->points[cfg.registration_point_type];
+  std::mt19937& engine = cfg.sampler_seed != 0u ? rng : ps.rng;
   h_sample_idx.resize((size_t)num_residuals);
   const std::vector<double>& cum = ps.cumulative_weight;
   for (int64_t i = 0; i < num_residuals; ++i) {
-    const double random_number = uniform(rng);
+    const double random_number = uniform(engine);
     const double random_cumulative_weight = random_number * cum.back();
     auto it = std::upper_bound(cum.begin(), cum.end(), random_cumulative_weight);
     size_t idx = (size_t)(it - cum.begin());
@@ -860,7 +863,7 @@ void vgx_reg_config_default(vgx_reg_config* cfg) {
   cfg->sampling_ratio = -1.0f;
   cfg->no_correspondence_cost = 0.0;
   cfg->use_esdf_distance = 1;
-  cfg->sampler_seed = 5489u;
+  cfg->sampler_seed = 0u;  // share the reference submap's sampler stream (weighted_sampler.h:36-39)
 }
 
 int vgx_reg_create(vgx_ctx ctx, vgx_submap reference, vgx_submap reading, const vgx_reg_config* cfg,
@@ -900,7 +903,7 @@ int vgx_reg_create(vgx_ctx ctx, vgx_submap reference, vgx_submap reading, const 
   } else {
     r->num_residuals = ps.n;
   }
-  r->rng.seed(cfg->sampler_seed);
+  if (cfg->sampler_seed != 0u) r->rng.seed(cfg->sampler_seed);
   if (cfg->sampling_ratio != -1.0f && (int64_t)ps.cumulative_weight.size() != ps.n) {
     // points extracted on the device: build WeightedSampler's cumulative weights
     // (weighted_sampler_inl.h:5-16) from the device copy, in extraction order
