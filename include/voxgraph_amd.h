@@ -395,6 +395,71 @@ VGX_API int vgx_tsdf_integrate_device(vgx_tsdf_integrator integrator, const floa
 VGX_API int vgx_submap_from_tsdf_layer(vgx_ctx ctx, vgx_tsdf_layer layer, int32_t submap_id,
                                        vgx_submap* out);
 
+/* ---------------------------------------------------------------------------
+ * Saved maps: cblox submap-collection files and voxblox layer files.
+ *
+ * voxgraph saves its map with SubmapCollection::saveToFile (voxgraph_mapper.cpp:412-417)
+ * and reads collections back with cblox::io::LoadSubmapCollection<VoxgraphSubmap>
+ * (registration_test_bench.cpp:173-175 -> VoxgraphSubmap::LoadFromStream,
+ * voxgraph_submap.cpp:398-415).  The container is a sequence of length-prefixed
+ * protobuf messages (varint32 size, then the message):
+ *   collection : SubmapCollectionProto, then per submap a SubmapProto header followed by
+ *                its TSDF BlockProtos and (TsdfEsdfSubmap) its ESDF BlockProtos
+ *   layer file : varint32 message count, LayerProto, BlockProtos   (voxblox::io::SaveLayer)
+ * This is a hand-written wire-format reader/writer (protobuf is not a dependency).
+ * [recalled] The message schemas live in un-vendored voxblox / cblox and could not be
+ * checked against a real file in this environment; they are isolated in one table
+ * (voxgraph_amd/csrc/vgx_mapfile_schema.h).  Unknown fields are skipped, packed and
+ * unpacked repeated encodings are both accepted.
+ * Host-only (no device needed) except vgx_map_file_load_submap.
+ * ------------------------------------------------------------------------- */
+typedef struct vgx_map_file_s* vgx_map_file;
+#define VGX_FILE_CBLOX_COLLECTION 0
+#define VGX_FILE_VOXBLOX_LAYER 1
+typedef struct vgx_map_file_submap_info {
+  int64_t id;              /* SubmapProto.id (0 for a layer file)                       */
+  double T_M_S[7];         /* submap pose {qw,qx,qy,qz, tx,ty,tz} (identity for a layer) */
+  double voxel_size;
+  int32_t voxels_per_side;
+  int32_t n_tsdf_blocks;
+  int32_t n_esdf_blocks;   /* 0 when the file holds no ESDF for this submap              */
+  int32_t layer_is_esdf;   /* layer files only: LayerProto.type == "esdf"                */
+} vgx_map_file_submap_info;
+/* Indexes the file (headers and message offsets; voxel payloads are decoded on read). */
+VGX_API int vgx_map_file_open(const char* path, int32_t format, vgx_map_file* out);
+VGX_API int vgx_map_file_close(vgx_map_file file);
+/* Last error of this file handle (or of the last failed open when file == NULL). */
+VGX_API const char* vgx_map_file_last_error(vgx_map_file file);
+VGX_API int32_t vgx_map_file_num_submaps(vgx_map_file file);
+VGX_API int vgx_map_file_get_submap_info(vgx_map_file file, int32_t index, vgx_map_file_submap_info* info);
+/* Decodes submap `index` into caller arrays (any may be NULL): TSDF blocks in file order
+ * (block_index [n_tsdf][3], distance / weight / rgba [n_tsdf][vps^3]), and the ESDF values
+ * of the SAME blocks (esdf_distance, esdf_observed [n_tsdf][vps^3]; blocks without an ESDF
+ * counterpart read distance 0 / observed 0) -- the layout vgx_submap_create takes. */
+VGX_API int vgx_map_file_read_submap(vgx_map_file file, int32_t index, int32_t* block_index,
+                                     float* tsdf_distance, float* tsdf_weight, uint8_t* tsdf_rgba,
+                                     float* esdf_distance, uint8_t* esdf_observed);
+/* read + vgx_submap_create: the device-side counterpart of VoxgraphSubmap::LoadFromStream.
+ * The submap is NOT finished: follow with vgx_submap_generate_esdf (if the file has no ESDF)
+ * and the extract calls, as finishSubmap() does after loading. */
+VGX_API int vgx_map_file_load_submap(vgx_ctx ctx, vgx_map_file file, int32_t index, vgx_submap* out);
+/* Writer (round trips, and saving maps built on the device).  One entry per submap;
+ * esdf_* may be NULL (TSDF-only submap). */
+typedef struct vgx_map_file_submap_data {
+  int64_t id;
+  double T_M_S[7];
+  int32_t n_blocks;
+  const int32_t* block_index;     /* [n][3] */
+  const float* tsdf_distance;     /* [n][vps^3] */
+  const float* tsdf_weight;
+  const uint8_t* tsdf_rgba;       /* [n][vps^3][4] or NULL */
+  const float* esdf_distance;     /* or NULL */
+  const uint8_t* esdf_observed;
+} vgx_map_file_submap_data;
+VGX_API int vgx_map_file_write(const char* path, int32_t format, double voxel_size,
+                               int32_t voxels_per_side, int32_t n_submaps,
+                               const vgx_map_file_submap_data* submaps);
+
 #ifdef __cplusplus
 }
 #endif

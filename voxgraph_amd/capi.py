@@ -45,6 +45,19 @@ class EsdfConfig(C.Structure):
                 ("min_weight", C.c_float), ("num_buckets", C.c_int32)]
 
 
+class MapFileSubmapInfo(C.Structure):
+    _fields_ = [("id", C.c_int64), ("T_M_S", C.c_double * 7), ("voxel_size", C.c_double),
+                ("voxels_per_side", C.c_int32), ("n_tsdf_blocks", C.c_int32),
+                ("n_esdf_blocks", C.c_int32), ("layer_is_esdf", C.c_int32)]
+
+
+class MapFileSubmapData(C.Structure):
+    _fields_ = [("id", C.c_int64), ("T_M_S", C.c_double * 7), ("n_blocks", C.c_int32),
+                ("block_index", C.POINTER(C.c_int32)), ("tsdf_distance", C.POINTER(C.c_float)),
+                ("tsdf_weight", C.POINTER(C.c_float)), ("tsdf_rgba", C.POINTER(C.c_uint8)),
+                ("esdf_distance", C.POINTER(C.c_float)), ("esdf_observed", C.POINTER(C.c_uint8))]
+
+
 class TsdfConfig(C.Structure):
     """vgx_tsdf_config == voxblox::TsdfIntegratorBase::Config (the fields that matter on a GPU)."""
     _fields_ = [("default_truncation_distance", C.c_float), ("max_weight", C.c_float),
@@ -119,6 +132,15 @@ SIGNATURES = {
     "vgx_tsdf_integrator_set_layer": (C.c_int, [vp, vp]),
     "vgx_tsdf_integrate": (C.c_int, [vp, f32p, f32p, u8p, C.c_int64, C.c_int32, i64p]),
     "vgx_tsdf_integrate_device": (C.c_int, [vp, f32p, vp, vp, C.c_int64, C.c_int32, i64p]),
+    "vgx_map_file_open": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(vp)]),
+    "vgx_map_file_close": (C.c_int, [vp]),
+    "vgx_map_file_last_error": (C.c_char_p, [vp]),
+    "vgx_map_file_num_submaps": (C.c_int32, [vp]),
+    "vgx_map_file_get_submap_info": (C.c_int, [vp, C.c_int32, C.POINTER(MapFileSubmapInfo)]),
+    "vgx_map_file_read_submap": (C.c_int, [vp, C.c_int32, i32p, f32p, f32p, u8p, f32p, u8p]),
+    "vgx_map_file_load_submap": (C.c_int, [vp, vp, C.c_int32, C.POINTER(vp)]),
+    "vgx_map_file_write": (C.c_int, [C.c_char_p, C.c_int32, C.c_double, C.c_int32, C.c_int32,
+                                     C.POINTER(MapFileSubmapData)]),
 }
 
 _lib = None
@@ -580,3 +602,86 @@ class FastTsdfIntegrator:
         if self.h:
             self.ctx.lib.vgx_tsdf_integrator_destroy(self.h)
             self.h = None
+
+
+# ------------------------------------------------------------------ saved maps
+FILE_CBLOX_COLLECTION, FILE_VOXBLOX_LAYER = 0, 1
+
+
+class MapFile:
+    """A cblox submap-collection file (voxgraph's save_to_file) or a voxblox layer file.
+    Host-only except load_submap()."""
+
+    def __init__(self, path, fmt=FILE_CBLOX_COLLECTION):
+        self.lib = load()
+        h = vp()
+        rc = self.lib.vgx_map_file_open(os.fsencode(path), fmt, C.byref(h))
+        if rc != 0:
+            raise VgxError(rc, self.lib.vgx_map_file_last_error(None).decode())
+        self.h = h
+
+    def _check(self, rc):
+        if rc != 0:
+            raise VgxError(rc, self.lib.vgx_map_file_last_error(self.h).decode())
+
+    def __len__(self):
+        return int(self.lib.vgx_map_file_num_submaps(self.h))
+
+    def info(self, i):
+        info = MapFileSubmapInfo()
+        self._check(self.lib.vgx_map_file_get_submap_info(self.h, i, C.byref(info)))
+        return info
+
+    def read_submap(self, i, want_rgba=False):
+        """-> dict(block_index, tsdf_distance, tsdf_weight, [tsdf_rgba], esdf_distance, esdf_observed)"""
+        info = self.info(i)
+        nb, vox = info.n_tsdf_blocks, info.voxels_per_side ** 3
+        out = dict(block_index=np.zeros((nb, 3), np.int32), tsdf_distance=np.zeros((nb, vox), np.float32),
+                   tsdf_weight=np.zeros((nb, vox), np.float32),
+                   tsdf_rgba=np.zeros((nb, vox, 4), np.uint8) if want_rgba else None,
+                   esdf_distance=np.zeros((nb, vox), np.float32), esdf_observed=np.zeros((nb, vox), np.uint8))
+        self._check(self.lib.vgx_map_file_read_submap(
+            self.h, i, _ptr(out["block_index"], i32p), _ptr(out["tsdf_distance"], f32p),
+            _ptr(out["tsdf_weight"], f32p), _ptr(out["tsdf_rgba"], u8p),
+            _ptr(out["esdf_distance"], f32p), _ptr(out["esdf_observed"], u8p)))
+        return out
+
+    def load_submap(self, ctx, i):
+        """VoxgraphSubmap::LoadFromStream onto the device (not yet finished)."""
+        sm = Submap.__new__(Submap)
+        sm.ctx = ctx
+        h = vp()
+        self._check(self.lib.vgx_map_file_load_submap(ctx.h, self.h, i, C.byref(h)))
+        sm.h = h
+        return sm
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.vgx_map_file_close(self.h)
+            self.h = None
+
+    __del__ = close
+
+
+def write_map_file(path, fmt, voxel_size, vps, submaps):
+    """submaps: list of dict(id, T_M_S[7], block_index, tsdf_distance, tsdf_weight,
+    tsdf_rgba=None, esdf_distance=None, esdf_observed=None)"""
+    lib = load()
+    arr = (MapFileSubmapData * len(submaps))()
+    keep = []
+    for k, s in enumerate(submaps):
+        bi = np.ascontiguousarray(s["block_index"], np.int32).reshape(-1, 3)
+        td, tw = _f32(s["tsdf_distance"]), _f32(s["tsdf_weight"])
+        rgba = None if s.get("tsdf_rgba") is None else np.ascontiguousarray(s["tsdf_rgba"], np.uint8)
+        ed = _f32(s.get("esdf_distance"))
+        eo = None if s.get("esdf_observed") is None else np.ascontiguousarray(s["esdf_observed"], np.uint8)
+        keep += [bi, td, tw, rgba, ed, eo]
+        arr[k].id = int(s.get("id", k))
+        for a, v in enumerate(s.get("T_M_S", (1, 0, 0, 0, 0, 0, 0))):
+            arr[k].T_M_S[a] = float(v)
+        arr[k].n_blocks = bi.shape[0]
+        arr[k].block_index, arr[k].tsdf_distance, arr[k].tsdf_weight = _ptr(bi, i32p), _ptr(td, f32p), _ptr(tw, f32p)
+        arr[k].tsdf_rgba, arr[k].esdf_distance, arr[k].esdf_observed = _ptr(rgba, u8p), _ptr(ed, f32p), _ptr(eo, u8p)
+    rc = lib.vgx_map_file_write(os.fsencode(path), fmt, float(voxel_size), int(vps), len(submaps), arr)
+    if rc != 0:
+        raise VgxError(rc, lib.vgx_map_file_last_error(None).decode())
