@@ -14,6 +14,7 @@
 // HBM-latency / atomic bound: 16 B per input point + 24 B per voxel update
 // (SURVEY.md 8d); no MFMA.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -159,6 +160,131 @@ __device__ __forceinline__ void update_voxel(const TsdfLayerDev& L, const vgx_ts
   }
 }
 
+// ---------------------------------------------------------------------------
+// Software-pipelined voxel updates.  updateTsdfVoxel is a chain of dependent memory round trips
+// (load {d,w} -> CAS {d,w} -> load colour -> CAS colour), and the ray walk adds the approximate
+// set's exchange in front of it: up to five L2 round trips per DDA step, and the scan's kernel time
+// is the LONGEST ray's chain.  A ray never visits a voxel twice, so the update of voxel k-1 does
+// not depend on the walk's step k: the walk keeps three updates in flight, one per stage,
+//   stage 1: load {d,w} and colour      (voxel k-1)
+//   stage 2: CAS {d,w}                  (voxel k-2, expected value from its stage 1)
+//   stage 3: CAS colour                 (voxel k-3, blend weight from its stage 2)
+// and issues them together with step k's exchange: one round trip per step.  Values loaded a step
+// earlier may be stale when another ray got in between; the CAS then fails and is retried, exactly
+// as in the unpipelined loop.  Per ray the updates are still applied in walk order.
+struct PendingUpdate {
+  size_t at = 0;
+  float sdf = 0.0f, w = 0.0f, old_w = 0.0f;
+  unsigned long long expected = 0ull;
+  uint32_t expected_color = 0u;
+  bool active = false, blend = false;
+};
+
+// geometry of updateTsdfVoxel + computeDistance (same operations as update_voxel)
+__device__ __forceinline__ PendingUpdate make_update(const TsdfLayerDev& L, const vgx_tsdf_config& c,
+                                                     size_t at, float ox, float oy, float oz, float gx,
+                                                     float gy, float gz, int vx, int vy, int vz,
+                                                     float weight) {
+  PendingUpdate u;
+  const float vs = L.voxel_size;
+  float cx = ((float)vx + 0.5f) * vs, cy = ((float)vy + 0.5f) * vs, cz = ((float)vz + 0.5f) * vs;
+  float vvx = cx - ox, vvy = cy - oy, vvz = cz - oz;
+  float vpx = gx - ox, vpy = gy - oy, vpz = gz - oz;
+  float dist_G = norm3(vpx, vpy, vpz);
+  float dot = (vvx * vpx + vvy * vpy) + vvz * vpz;
+  float dist_G_V = dot / dist_G;
+  float sdf = dist_G - dist_G_V;
+  float updated_weight = weight;
+  const float trunc = c.default_truncation_distance;
+  if (c.use_weight_dropoff && sdf < -vs) {
+    updated_weight = weight * (trunc + sdf) / (trunc - vs);
+    updated_weight = fmaxf(updated_weight, 0.0f);
+  }
+  if (c.use_sparsity_compensation_factor && fabsf(sdf) < trunc)
+    updated_weight *= c.sparsity_compensation_factor;
+  u.at = at;
+  u.sdf = sdf;
+  u.w = updated_weight;
+  u.blend = fabsf(sdf) < trunc;
+  u.active = true;
+  return u;
+}
+
+__device__ __forceinline__ unsigned long long blended_voxel(const vgx_tsdf_config& c, const PendingUpdate& u,
+                                                            unsigned long long old, bool* skip) {
+  const float trunc = c.default_truncation_distance;
+  float d = __uint_as_float((unsigned)(old & 0xffffffffull));
+  float old_w = __uint_as_float((unsigned)(old >> 32));
+  float new_weight = old_w + u.w;
+  *skip = new_weight < 1e-6f;  // kFloatEpsilon: updateTsdfVoxel returns without touching the voxel
+  float new_sdf = (u.sdf * u.w + d * old_w) / new_weight;
+  float nd = (new_sdf > 0.0f) ? fminf(trunc, new_sdf) : fmaxf(-trunc, new_sdf);
+  float nw = fminf(c.max_weight, new_weight);
+  return pack_voxel(nd, nw);
+}
+
+__device__ __forceinline__ uint32_t blended_color(uint32_t oc, uint32_t color, float old_w, float w) {
+  float total = old_w + w;
+  float fw = old_w / total, sw = w / total;
+  uint32_t nc = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float a = (float)((oc >> (8 * k)) & 0xffu), b = (float)((color >> (8 * k)) & 0xffu);
+    nc |= ((uint32_t)(uint8_t)roundf(a * fw + b * sw)) << (8 * k);
+  }
+  return nc;
+}
+
+// One pipeline beat: issues every stage's memory operation, then consumes the results and
+// shifts.  `s1` enters with an address only; leaves through s2 and s3.
+__device__ __forceinline__ void pipeline_beat(const TsdfLayerDev& L, const vgx_tsdf_config& c, uint32_t color,
+                                              PendingUpdate& s1, PendingUpdate& s2, PendingUpdate& s3) {
+  // ---- issue ----
+  unsigned long long e1 = 0ull, prev2 = 0ull, want2 = 0ull;
+  uint32_t ec1 = 0u, prevc3 = 0u, wantc3 = 0u;
+  bool skip2 = false;
+  if (s1.active) {
+    e1 = __hip_atomic_load(&L.voxels[s1.at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (s1.blend) ec1 = __hip_atomic_load(&L.rgba[s1.at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (s2.active) {
+    want2 = blended_voxel(c, s2, s2.expected, &skip2);
+    if (!skip2) prev2 = atomicCAS(&L.voxels[s2.at], s2.expected, want2);
+  }
+  const bool do3 = s3.active && s3.blend;
+  if (do3) {
+    wantc3 = blended_color(s3.expected_color, color, s3.old_w, s3.w);
+    prevc3 = atomicCAS(&L.rgba[s3.at], s3.expected_color, wantc3);
+  }
+  // ---- consume ----
+  if (do3) {
+    uint32_t oc = s3.expected_color;
+    while (prevc3 != oc) {  // another ray blended in between: retry on what it left
+      oc = prevc3;
+      prevc3 = atomicCAS(&L.rgba[s3.at], oc, blended_color(oc, color, s3.old_w, s3.w));
+    }
+  }
+  if (s2.active) {
+    unsigned long long old = s2.expected;
+    while (!skip2 && prev2 != old) {
+      old = prev2;
+      want2 = blended_voxel(c, s2, old, &skip2);
+      if (!skip2) prev2 = atomicCAS(&L.voxels[s2.at], old, want2);
+    }
+    s2.old_w = __uint_as_float((unsigned)(old >> 32));  // the weight this update saw
+    if (skip2) s2.active = false;                        // no colour blend either
+  }
+  if (s1.active) {
+    s1.expected = e1;
+    s1.expected_color = ec1;
+  }
+  // ---- shift ----
+  s3 = s2;
+  s2 = s1;
+  s1.active = false;
+}
+
+template <bool PIPELINED>
 __global__ __launch_bounds__(256) void tsdf_integrate_kernel(TsdfLayerDev L, TsdfIntegratorDev I,
                                                             float qw, float qx, float qy, float qz,
                                                             float tx, float ty, float tz,
@@ -249,6 +375,7 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(TsdfLayerDev L, Tsd
           int collisions = 0;
           const int vps = L.vps, shift = L.vps_shift, mask = vps - 1;
           int last_b[3] = {INT32_MIN, INT32_MIN, INT32_MIN}, last_slot = -1;
+          PendingUpdate s1, s2, s3;
           for (long long step = 0; step <= steps; ++step) {
             int vx = curr[0], vy = curr[1], vz = curr[2];
             int m = 0;
@@ -258,7 +385,13 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(TsdfLayerDev L, Tsd
             curr[0] += m == 0 ? sign[0] : 0; curr[1] += m == 1 ? sign[1] : 0; curr[2] += m == 2 ? sign[2] : 0;
             t_next[0] += m == 0 ? t_step[0] : 0.0f; t_next[1] += m == 1 ? t_step[1] : 0.0f;
             t_next[2] += m == 2 ? t_step[2] : 0.0f;
-            if (!approx_replace(I.observed_set, I.observed_offset, vx, vy, vz)) ++collisions; else collisions = 0;
+            // ApproxHashSet::replaceHash, issued first; its result is consumed after the pending
+            // updates of the previous voxels have been issued as well
+            unsigned int h = (unsigned int)vx + (unsigned int)vy * 17191u + (unsigned int)vz * 295530481u;
+            unsigned long long v = (unsigned long long)h + I.observed_offset;
+            unsigned long long seen = atomicExch(&I.observed_set[v & kSetMask], v);
+            if (PIPELINED) pipeline_beat(L, c, color, s1, s2, s3);
+            if (seen == v) ++collisions; else collisions = 0;
             if (collisions > c.max_consecutive_ray_collisions) break;
             int bx = vx >> shift, by = vy >> shift, bz = vz >> shift;  // floor division (vps = 2^shift)
             if (bx != last_b[0] || by != last_b[1] || bz != last_b[2]) {
@@ -272,8 +405,16 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(TsdfLayerDev L, Tsd
             }
             size_t at = (size_t)last_slot * ((size_t)vps * vps * vps) +
                         (size_t)((vx & mask) + vps * ((vy & mask) + vps * (vz & mask)));
-            update_voxel(L, c, at, tx, ty, tz, gx, gy, gz, vx, vy, vz, color, weight);
+            if (PIPELINED)
+              s1 = make_update(L, c, at, tx, ty, tz, gx, gy, gz, vx, vy, vz, weight);
+            else
+              update_voxel(L, c, at, tx, ty, tz, gx, gy, gz, vx, vy, vz, color, weight);
             ++my_updates;
+          }
+          if (PIPELINED) {  // drain
+            pipeline_beat(L, c, color, s1, s2, s3);
+            pipeline_beat(L, c, color, s1, s2, s3);
+            pipeline_beat(L, c, color, s1, s2, s3);
           }
         }
       }
@@ -569,9 +710,18 @@ int vgx_tsdf_integrate_device(vgx_tsdf_integrator I, const float T[7], const voi
   if (n_updates) VGX_HIP(ctx, hipMemsetAsync(I->dev.n_updates, 0, 8, ctx->stream));
   if (n > 0) {
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
-    hipLaunchKernelGGL(tsdf_integrate_kernel, grid, block, 0, ctx->stream, I->layer->dev, I->dev,
-                       T[0], T[1], T[2], T[3], T[4], T[5], T[6], (const float*)d_points,
-                       (const uint32_t*)d_rgba, (long long)n, (int)freespace);
+    static const bool pipelined = [] {
+      const char* e = getenv("VGX_TSDF_PIPELINED");  // A/B switch (profiles/ab_tsdf.sh)
+      return e ? atoi(e) != 0 : true;
+    }();
+    if (pipelined)
+      hipLaunchKernelGGL(tsdf_integrate_kernel<true>, grid, block, 0, ctx->stream, I->layer->dev, I->dev,
+                         T[0], T[1], T[2], T[3], T[4], T[5], T[6], (const float*)d_points,
+                         (const uint32_t*)d_rgba, (long long)n, (int)freespace);
+    else
+      hipLaunchKernelGGL(tsdf_integrate_kernel<false>, grid, block, 0, ctx->stream, I->layer->dev, I->dev,
+                         T[0], T[1], T[2], T[3], T[4], T[5], T[6], (const float*)d_points,
+                         (const uint32_t*)d_rgba, (long long)n, (int)freespace);
     VGX_HIP(ctx, hipGetLastError());
   }
   if (n_updates) {
