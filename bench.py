@@ -29,6 +29,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the host driver only supports dmabuf IPC: without this RCCL's peer mapping fails with
+# "hipIpcGetMemHandle: invalid argument" (already exported on the GPU boxes; kept for safety)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_EVAL = 88            # SURVEY.md 8d contract figure (materialising, f32 outputs)
