@@ -144,6 +144,13 @@ struct vgx_reg_s {
   // drop-in scratch (f64 outputs staged on the device before the D2H copy)
   double* d_out = nullptr;
   int64_t d_out_rows = 0;
+  // Drop-in Evaluate calls arrive from several Ceres threads (pose_graph.cpp:96), each on its own
+  // cost function.  Every cost function therefore has its own stream: the context lock is held
+  // only while work is enqueued (ordered after the context stream through `order`), and the wait
+  // for kernel + device->host copies happens outside it, so calls on distinct cost functions overlap.
+  hipStream_t stream = nullptr;
+  hipEvent_t order = nullptr;
+  std::mutex mu;                // two threads on the SAME cost function are serialised
   bool draw_samples();          // refreshes h_sample_idx / d_sample_idx
   vgx::ConstraintDev describe() const;
 };

@@ -787,7 +787,7 @@ static void launch_points(vgx_ctx ctx, int vps, const ConstraintDev* d_desc, con
 
 
 template <typename OUT>
-static void launch_points_single(vgx_ctx ctx, int vps, const ConstraintDev& desc, const PosePack& pack,
+static void launch_points_single(hipStream_t stream, int vps, const ConstraintDev& desc, const PosePack& pack,
                                  void* res, void* jr, void* je) {
   const int n_tiles = (int)((desc.n + kTilePoints - 1) / kTilePoints);
   if (n_tiles <= 0) return;
@@ -799,7 +799,7 @@ static void launch_points_single(vgx_ctx ctx, int vps, const ConstraintDev& desc
   }();
 #define VGX_LAUNCH_SINGLE(VPS, NT)                                                                  \
   hipLaunchKernelGGL((reg_eval_points_single_kernel<VPS, OUT, kPointsPerThread, NT, kNonTemporalLoads>), \
-                     grid, block, 0, ctx->stream, desc, pack, n_tiles, (OUT*)res, (O4*)jr, (O4*)je)
+                     grid, block, 0, stream, desc, pack, n_tiles, (OUT*)res, (O4*)jr, (O4*)je)
   if (vps == 16 && nt) VGX_LAUNCH_SINGLE(16, true);
   else if (vps == 16) VGX_LAUNCH_SINGLE(16, false);
   else if (nt) VGX_LAUNCH_SINGLE(8, true);
@@ -923,6 +923,12 @@ int vgx_reg_create(vgx_ctx ctx, vgx_submap reference, vgx_submap reading, const 
     }
   }
   if (cfg->sampling_ratio != -1.0f && ps.n == 0) r->num_residuals = 0;
+  if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&r->order, hipEventDisableTiming) != hipSuccess) {
+    if (r->stream) (void)hipStreamDestroy(r->stream);
+    delete r;
+    return set_error(ctx, VGX_ERR_HIP, "vgx_reg_create: stream / event creation failed");
+  }
   *out = r;
   return VGX_OK;
 }
@@ -931,6 +937,11 @@ int vgx_reg_destroy(vgx_reg r) {
   if (!r) return VGX_ERR_INVALID;
   (void)hipSetDevice(r->ctx->device);
   (void)hipStreamSynchronize(r->ctx->stream);
+  if (r->stream) {
+    (void)hipStreamSynchronize(r->stream);
+    (void)hipStreamDestroy(r->stream);
+  }
+  if (r->order) (void)hipEventDestroy(r->order);
   if (r->d_sample_idx) (void)hipFree(r->d_sample_idx);
   if (r->d_out) (void)hipFree(r->d_out);
   delete r;
@@ -968,33 +979,49 @@ int vgx_reg_evaluate(vgx_reg r, const double ref_pose[4], const double read_pose
                      double* residuals, double* jac_ref, double* jac_read) {
   if (!r || !ref_pose || !read_pose) return VGX_ERR_INVALID;
   vgx_ctx ctx = r->ctx;
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  if (!residuals) return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_evaluate: residuals == NULL");
-  int rc = reg_prepare(r);
-  if (rc != VGX_OK) return rc;
-  if (reg_status(r) == VGX_EVALUATE_FALSE) return VGX_EVALUATE_FALSE;
-  const int64_t n = r->num_residuals;
-  if (n == 0) return VGX_OK;
-  const ConstraintDev desc = r->describe();
-  PosePack pack;
-  make_pose_pack(ref_pose, read_pose, &pack);
-  if (r->d_out_rows < n) {
-    if (r->d_out) (void)hipFree(r->d_out);
-    r->d_out = nullptr;
-    VGX_HIP(ctx, hipMalloc(&r->d_out, (size_t)n * 9 * sizeof(double)));
-    r->d_out_rows = n;
+  std::lock_guard<std::mutex> own(r->mu);
+  int64_t n = 0;
+  {
+    // launch under the context lock ...
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!residuals) return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_evaluate: residuals == NULL");
+    int rc = reg_prepare(r);
+    if (rc != VGX_OK) return rc;
+    if (reg_status(r) == VGX_EVALUATE_FALSE) return VGX_EVALUATE_FALSE;
+    n = r->num_residuals;
+    if (n == 0) return VGX_OK;
+    const ConstraintDev desc = r->describe();
+    PosePack pack;
+    make_pose_pack(ref_pose, read_pose, &pack);
+    if (r->d_out_rows < n) {
+      if (r->d_out) (void)hipFree(r->d_out);
+      r->d_out = nullptr;
+      VGX_HIP(ctx, hipMalloc(&r->d_out, (size_t)n * 9 * sizeof(double)));
+      r->d_out_rows = n;
+    }
+    double* d_res = r->d_out;
+    double* d_jr = jac_ref ? r->d_out + n : nullptr;
+    double* d_je = jac_read ? r->d_out + 5 * n : nullptr;
+    // everything already enqueued on the context stream (uploads, extraction, sample indices)
+    // happens before this evaluation
+    VGX_HIP(ctx, hipEventRecord(r->order, ctx->stream));
+    VGX_HIP(ctx, hipStreamWaitEvent(r->stream, r->order, 0));
+    launch_points_single<double>(r->stream, r->reading->vps, desc, pack, d_res, d_jr, d_je);
+    VGX_HIP(ctx, hipGetLastError());
   }
+  // ... and copy + wait outside it (copies into pageable host memory block their caller): other
+  // cost functions' evaluations proceed meanwhile
   double* d_res = r->d_out;
-  double* d_jr = jac_ref ? r->d_out + n : nullptr;
-  double* d_je = jac_read ? r->d_out + 5 * n : nullptr;
-  launch_points_single<double>(ctx, r->reading->vps, desc, pack, d_res, d_jr, d_je);
-  VGX_HIP(ctx, hipGetLastError());
-  VGX_HIP(ctx, hipMemcpyAsync(residuals, d_res, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  if (jac_ref)
-    VGX_HIP(ctx, hipMemcpyAsync(jac_ref, d_jr, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  if (jac_read)
-    VGX_HIP(ctx, hipMemcpyAsync(jac_read, d_je, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  hipError_t e = hipMemcpyAsync(residuals, d_res, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, r->stream);
+  if (e == hipSuccess && jac_ref)
+    e = hipMemcpyAsync(jac_ref, d_res + n, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost, r->stream);
+  if (e == hipSuccess && jac_read)
+    e = hipMemcpyAsync(jac_read, d_res + 5 * n, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost, r->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
+  if (e != hipSuccess) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return set_error(ctx, VGX_ERR_HIP, std::string("vgx_reg_evaluate: ") + hipGetErrorString(e));
+  }
   return VGX_OK;
 }
 
@@ -1009,7 +1036,7 @@ int vgx_reg_evaluate_device_f32(vgx_reg r, const double ref_pose[4], const doubl
   if (reg_status(r) == VGX_EVALUATE_FALSE) return VGX_EVALUATE_FALSE;
   PosePack pack;
   make_pose_pack(ref_pose, read_pose, &pack);
-  launch_points_single<float>(ctx, r->reading->vps, r->describe(), pack, d_residuals, d_jac_ref,
+  launch_points_single<float>(ctx->stream, r->reading->vps, r->describe(), pack, d_residuals, d_jac_ref,
                               d_jac_read);
   VGX_HIP(ctx, hipGetLastError());
   return VGX_OK;
