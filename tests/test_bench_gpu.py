@@ -1,0 +1,50 @@
+"""bench.py end to end on a miniature graph: the N = 1 line carries every object the contract asks
+for, and the N = 2 code path (sharding, all-reduce, collective-per-evaluation solve) is walked on
+ONE GPU with the gloo backend (VGX_BENCH_DRYRUN, see profiles/README.md) -- the real RCCL runs are
+the driver's."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--grid", "4", "3", "--block-dims", "4", "4", "4", "--block-min", "-2", "-2", "-1",
+         "--steps", "2", "--warmup", "1", "--no-tsdf"]
+
+pytestmark = pytest.mark.gpu
+
+
+def _line(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_has_the_contract_fields():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--cpu-seconds", "1"] + SMALL,
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _line(r.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"])
+    assert d["value"] > 0 and d["solve"]["position_rmse_m_after"] < d["solve"]["position_rmse_m_before"]
+    assert d["fused"]["cost_vs_materialised"] < 1e-6
+
+
+def test_two_rank_path_dry_run_on_one_gpu():
+    env = dict(os.environ, VGX_BENCH_DRYRUN="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 2 and "DRY RUN" in d["data"] and d["cpu_baseline"] is None
+    assert d["fused"]["allreduce_bytes"] > 0
+    # the sharded solve converges like the single-rank one
+    assert d["solve"]["position_rmse_m_after"] < 0.5 * d["solve"]["position_rmse_m_before"]
