@@ -469,7 +469,8 @@ constexpr int kMaxReduceIters = 64;
 // 120 VGPRs -> 4 waves/SIMD.  Forcing 5 or 6 (launch_bounds) spills the 21 f64
 // accumulators: measured 7.8 / 13.0 ms per fused step against 2.45 ms.
 constexpr int kReduceWavesPerSimd = 4;
-// The loop is VALU-bound (~310 VALU instructions per point, profiles/README.md "fused kernel"):
+// ~310 VALU instructions per point; VALU issue is about half of the kernel time, the rest is latency
+// that 4 waves/SIMD cannot hide (SQ counters, profiles/README.md "Fused kernel"):
 // fused multiply-adds for the 21 f64 accumulations took 2.23 -> 2.11 ms; a branch-free variant
 // (masked lanes carried through the FMAs) needed 144 VGPRs: 2.43 ms at 3 waves/SIMD, 2.94 ms spilling at 4.
 constexpr int kReducePointsPerThread = 2;  // measured: 3.72 / 3.29 / 3.41 ms per fused step at 4 / 2 / 1 (profiles/tune_fused.sh)
