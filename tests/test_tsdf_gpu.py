@@ -323,3 +323,43 @@ def test_rgbd_fullsize_scan_invariants(capi, ctx):
     assert np.percentile(diff, 99) < 1e-4 and diff.max() <= 2 * trunc
     for o in (gi, gl):
         o.destroy()
+
+
+def test_degenerate_point_clouds(capi, ctx):
+    """empty cloud, points at the sensor origin, too close, beyond the maximum range with and
+    without allow_clear, freespace_points, and non-finite coordinates: no crash, no hang, and the
+    finite cases equal the oracle bit for bit"""
+    vs, vps = 0.1, 16
+    T = np.array([1, 0, 0, 0, 0.05, -0.02, 0.03], F)
+    for allow_clear in (0, 1):
+        ocfg, gcfg = _both_cfg(capi, default_truncation_distance=0.3, max_ray_length_m=3.0, min_ray_length_m=0.2,
+                               allow_clear=allow_clear, use_const_weight=0)
+        ol = orc.TsdfLayer(vs, vps)
+        oi = orc.FastTsdfIntegrator(ocfg, ol)
+        gl = capi.TsdfLayer(ctx, vs, vps, (-4, -4, -4), (8, 8, 8), 512)
+        gi = capi.FastTsdfIntegrator(ctx, gcfg, gl)
+        scans = [np.zeros((0, 3), F),                                            # empty
+                 np.zeros((1, 3), F),                                            # at the origin: ray length 0
+                 np.array([[0.1, 0.0, 0.0]], F),                                 # closer than min_ray_length_m
+                 np.array([[0.2, 0.0, 0.0]], F),                                 # exactly min_ray_length_m
+                 np.array([[3.0, 0.0, 0.0]], F),                                 # exactly max_ray_length_m
+                 np.array([[0.0, 3.5, 0.5]], F),                                 # beyond it: clearing ray or dropped
+                 np.array([[1.0, 1.0, 0.0]], F)]                                 # an ordinary point, for contrast
+        for k, pts in enumerate(scans):
+            for freespace in (False, True):
+                a = oi.integratePointCloud(T, pts, None, freespace)
+                b = gi.integratePointCloud(T, pts, None, freespace)
+                assert a == b, (allow_clear, k, freespace, a, b)
+        obi, od, ow, oc = ol.download()
+        gbi, gd, gw, gc = gl.download()
+        assert set(map(tuple, obi)) == set(map(tuple, gbi)) and len(obi) > 0
+        O, G = _as_dict(obi, od, ow, oc, vps), _as_dict(gbi, gd, gw, gc, vps)
+        assert all(O[k][0] == G[k][0] and O[k][1] == G[k][1] for k in O)
+        # non-finite coordinates never reach the layer (the reference would index with floor(NaN))
+        before = gl.download()
+        bad = np.array([[np.nan, 0, 1], [np.inf, 1, 1], [1, -np.inf, 0], [np.nan, np.nan, np.nan]], F)
+        assert gi.integratePointCloud(T, bad, None) == 0
+        after = gl.download()
+        assert all(np.array_equal(x, y) for x, y in zip(before, after))
+        for o in (gi, gl):
+            o.destroy()
