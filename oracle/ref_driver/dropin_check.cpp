@@ -120,11 +120,11 @@ int main() {
   Worst worst;
   for (int point_type = 0; point_type < 2; ++point_type)
     for (int use_esdf = 0; use_esdf < 2; ++use_esdf)
-      for (int sampled = 0; sampled < 2; ++sampled) {
+      for (int sampled = 0; sampled < 3; ++sampled) {
         RegistrationCostFunction::Config rc;
         rc.registration_point_type = static_cast<VoxgraphSubmap::RegistrationPointType>(point_type);
         rc.use_esdf_distance = use_esdf != 0;
-        rc.sampling_ratio = sampled ? 0.2f : -1.0f;
+        rc.sampling_ratio = sampled == 0 ? -1.0f : (sampled == 1 ? 0.2f : 1.5f);  // all / down- / up-sampling
         rc.no_correspondence_cost = use_esdf ? 0.0 : 0.4;
         voxgraph_amd::GpuRegistrationCostFunction::Config gc;
         gc.registration_point_type = point_type;
