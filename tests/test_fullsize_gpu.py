@@ -121,3 +121,46 @@ def test_fullsize_properties(capi, ctx, pair256):
         assert np.all(np.abs(normal[c, 1:9] - jtr) <= 2e-6 * np.abs(jtr).max())
         assert np.all(np.abs(normal[c, 9:] - jtj[np.triu_indices(8)]) <= 2e-6 * np.abs(jtj).max())
     batch.destroy()
+
+
+def test_fullsize_pair_against_the_reference_source(capi, ctx):
+    """BASELINE's full size against the REFERENCE'S OWN cost function (oracle/_ref, see
+    tests/test_ref_pin.py): a 256^3 pair of the config-3 scene, finished by the reference's
+    finishSubmap(), uploaded block for block in the reference's own iteration order; all ~3.4e5
+    residuals and both Jacobian blocks must be equal value for value."""
+    from oracle import ref_reg
+    if not ref_reg.available():
+        pytest.skip("oracle/_ref/libref_reg.so not built (needs /root/reference)")
+    bmin, bdim = (-8, -8, -4), (16, 16, 16)
+    poses_true = np.array([[0.0, 0.0, 0.0, 0.05], [25.6, 17.0, 0.0, -0.08]])
+    refs, gpus = [], []
+    for k in range(2):
+        dev = capi.Submap.synth_city(ctx, k, VS, VPS, bmin, bdim, TRUNC, ESDF_MAX, 10.0, poses_true[k], SEED)
+        td, tw, ed, eo = dev.download_layers(VPS)
+        bi = dev.block_index()
+        dev.destroy()
+        R = ref_reg.Submap(k, poses_true[k], VS, VPS, bi, td, tw, ed, eo)
+        order = R.block_order()
+        lut = {tuple(b): i for i, b in enumerate(bi.tolist())}
+        perm = np.array([lut[tuple(b)] for b in order.tolist()])
+        pick = lambda a: np.ascontiguousarray(np.asarray(a).reshape(len(bi), -1)[perm])
+        g = capi.Submap(ctx, k, VS, VPS, order, pick(td), pick(tw), pick(ed), pick(eo))
+        assert g.extract_voxel_points(1.0, 0.3, True) == len(R.points(ref_reg.POINTS_VOXELS)[2])
+        refs.append(R)
+        gpus.append(g)
+    rx, rd, rw = refs[0].points(ref_reg.POINTS_VOXELS)
+    gx, gd, gw = gpus[0].download_points(capi.POINTS_VOXELS)
+    assert np.array_equal(rx, gx) and np.array_equal(rd, gd) and np.array_equal(rw, gw)   # device extraction
+    cf_ref = ref_reg.RegistrationCostFunction(refs[0], refs[1])
+    cf_gpu = capi.RegistrationCostFunction(ctx, gpus[0], gpus[1],
+                                           capi.default_config(registration_point_type=capi.POINTS_VOXELS))
+    n = cf_gpu.num_residuals()
+    assert n == cf_ref.num_residuals() > 200_000
+    poses = poses_true + np.array([[0.21, -0.17, 0.08, 0.03], [-0.1, 0.25, -0.05, -0.04]])
+    ok, r0, a0, b0 = cf_ref.Evaluate(poses[0], poses[1])
+    r, jo, je = np.zeros(n), np.zeros((n, 4)), np.zeros((n, 4))
+    assert ok and cf_gpu.Evaluate([poses[0], poses[1]], r, [jo, je])
+    assert int((np.abs(a0).sum(1) > 0).sum()) > 50_000
+    assert np.array_equal(r, r0) and np.array_equal(jo, a0) and np.array_equal(je, b0)
+    for o in [cf_gpu] + gpus:
+        o.destroy()
