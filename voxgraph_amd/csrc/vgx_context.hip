@@ -134,8 +134,9 @@ int build_chunk_bounds(vgx_ctx ctx, PointSet& ps) {
   if (ps.n <= 0) return VGX_OK;
   const long long chunks = (ps.n + kChunkPoints - 1) / kChunkPoints;
   VGX_HIP(ctx, hipMalloc(&ps.d_chunk_bounds, (size_t)chunks * sizeof(float4)));
-  float* d_minmax = nullptr;
-  VGX_HIP(ctx, hipMalloc(&d_minmax, (size_t)chunks * 6 * sizeof(float)));
+  DeviceScratch s_minmax;
+  VGX_HIP(ctx, s_minmax.alloc((size_t)chunks * 6 * sizeof(float)));
+  float* d_minmax = s_minmax.as<float>();
   hipLaunchKernelGGL(chunk_bounds_kernel, dim3((unsigned)chunks), dim3(64), 0, ctx->stream, ps.d_xyzd,
                      (long long)ps.n, ps.d_chunk_bounds, d_minmax);
   // exact AABB of the point positions (feeds getSubmapFrameSurfaceObb for kVoxels points)
@@ -143,7 +144,6 @@ int build_chunk_bounds(vgx_ctx ctx, PointSet& ps) {
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(mm.data(), d_minmax, mm.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  (void)hipFree(d_minmax);
   if (e != hipSuccess) return set_error(ctx, VGX_ERR_HIP, std::string("chunk bounds: ") + hipGetErrorString(e));
   for (int a = 0; a < 3; ++a) {
     ps.aabb_min[a] = mm[(size_t)a];

@@ -166,8 +166,9 @@ int vgx_submap_generate_esdf(vgx_submap sm, const vgx_esdf_config* cfg_in, int32
   VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (!sm->d_esdf_distance) VGX_HIP(ctx, hipMalloc(&sm->d_esdf_distance, nvox * sizeof(float)));
   if (!sm->d_esdf_observed) VGX_HIP(ctx, hipMalloc(&sm->d_esdf_observed, nvox));
-  int* d_changed = nullptr;
-  VGX_HIP(ctx, hipMalloc(&d_changed, sizeof(int)));
+  DeviceScratch s_changed;
+  VGX_HIP(ctx, s_changed.alloc(sizeof(int)));
+  int* d_changed = s_changed.as<int>();
   hipLaunchKernelGGL(esdf_init_kernel, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, ctx->stream,
                      sm->d_tsdf_distance, sm->d_tsdf_weight, nvox, cfg.min_weight, cfg.min_distance_m,
                      cfg.default_distance_m, sm->d_esdf_distance, sm->d_esdf_observed);
@@ -202,7 +203,6 @@ int vgx_submap_generate_esdf(vgx_submap sm, const vgx_esdf_config* cfg_in, int32
     ++passes;
     if (!h_changed) break;
   }
-  (void)hipFree(d_changed);
   if (rc != VGX_OK) return rc;
   if (sweeps_out) *sweeps_out = passes;
   // (re)build the ESDF sampling grid

@@ -132,12 +132,13 @@ extern "C" int vgx_submap_extract_voxel_points(vgx_submap sm, double min_voxel_w
     if (n_points_out) *n_points_out = 0;
     return VGX_OK;
   }
-  int32_t* d_counts = nullptr;
-  double* d_wsum = nullptr;
-  int64_t* d_offsets = nullptr;
-  VGX_HIP(ctx, hipMalloc(&d_counts, (size_t)nb * sizeof(int32_t)));
-  VGX_HIP(ctx, hipMalloc(&d_wsum, (size_t)nb * sizeof(double)));
-  VGX_HIP(ctx, hipMalloc(&d_offsets, ((size_t)nb + 1) * sizeof(int64_t)));
+  DeviceScratch s_counts, s_wsum, s_offsets;
+  VGX_HIP(ctx, s_counts.alloc((size_t)nb * sizeof(int32_t)));
+  VGX_HIP(ctx, s_wsum.alloc((size_t)nb * sizeof(double)));
+  VGX_HIP(ctx, s_offsets.alloc(((size_t)nb + 1) * sizeof(int64_t)));
+  int32_t* d_counts = s_counts.as<int32_t>();
+  double* d_wsum = s_wsum.as<double>();
+  int64_t* d_offsets = s_offsets.as<int64_t>();
   if (sm->vps == 16)
     hipLaunchKernelGGL(extract_count_kernel<16>, dim3(nb), dim3(256), 0, ctx->stream,
                        sm->d_tsdf_distance, sm->d_tsdf_weight, min_voxel_weight,
@@ -190,9 +191,6 @@ extern "C" int vgx_submap_extract_voxel_points(vgx_submap sm, double min_voxel_w
       if (e != hipSuccess) rc = set_error(ctx, VGX_ERR_HIP, std::string("extract: ") + hipGetErrorString(e));
     }
   }
-  (void)hipFree(d_counts);
-  (void)hipFree(d_wsum);
-  (void)hipFree(d_offsets);
   if (rc == VGX_OK) rc = build_chunk_bounds(ctx, ps);
   if (rc == VGX_OK && n_points_out) *n_points_out = ps.n;
   return rc;

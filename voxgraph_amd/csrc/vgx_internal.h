@@ -188,6 +188,22 @@ struct vgx_reg_batch_s {
 // ---------------------------------------------------------------------------
 namespace vgx {
 int set_error(vgx_ctx ctx, int code, const std::string& msg);
+
+// Scope-bound device scratch: freed on every exit path (the VGX_HIP macro returns early).
+struct DeviceScratch {
+  void* p = nullptr;
+  DeviceScratch() = default;
+  DeviceScratch(const DeviceScratch&) = delete;
+  DeviceScratch& operator=(const DeviceScratch&) = delete;
+  ~DeviceScratch() {
+    if (p) (void)hipFree(p);
+  }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
+  template <typename T>
+  T* as() const {
+    return static_cast<T*>(p);
+  }
+};
 void set_global_error(const std::string& msg);
 
 #define VGX_HIP(ctx, call)                                                      \
