@@ -112,7 +112,8 @@ def test_lidar_session_through_the_city_config2_miniature(capi, ctx):
     import torch
     from harness import pipeline
     torch.cuda.synchronize()
-    out = pipeline.run(capi, ctx, torch, n_submaps=10, scans_per_submap=8, n_az=512, n_el=32, seed=3)
+    out = pipeline.run(capi, ctx, torch, n_submaps=10, scans_per_submap=8, n_az=512, n_el=32, seed=3,
+                       isosurface_points=False)      # kVoxels: the steadier mode on this miniature
     print(out)
     assert out["dropped_updates"] == 0
     assert out["voxel_points_per_submap"] > 20000 and out["isosurface_points_per_submap"] > 5000
