@@ -258,6 +258,13 @@ int vgx_ctx_destroy(vgx_ctx ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+  for (int k = 0; k < Context::kEvalStreams; ++k) {
+    if (ctx->eval_stream[k]) {
+      (void)hipStreamSynchronize(ctx->eval_stream[k]);
+      (void)hipStreamDestroy(ctx->eval_stream[k]);
+    }
+    if (ctx->eval_order[k]) (void)hipEventDestroy(ctx->eval_order[k]);
+  }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
   return VGX_OK;

@@ -80,6 +80,13 @@ struct Context {
   std::mutex mu;
   std::string last_error;
   int cu_count = 256;
+  // Streams for the drop-in Evaluate path, handed to cost functions round robin (created on first
+  // use, under `mu`): constructing a cost function must stay cheap -- voxgraph rebuilds every
+  // registration constraint before each solve (pose_graph_interface.cpp:149-175).
+  static constexpr int kEvalStreams = 8;
+  hipStream_t eval_stream[kEvalStreams] = {};
+  hipEvent_t eval_order[kEvalStreams] = {};
+  unsigned next_eval_stream = 0;
 };
 
 struct PointSet {
@@ -145,11 +152,10 @@ struct vgx_reg_s {
   double* d_out = nullptr;
   int64_t d_out_rows = 0;
   // Drop-in Evaluate calls arrive from several Ceres threads (pose_graph.cpp:96), each on its own
-  // cost function.  Every cost function therefore has its own stream: the context lock is held
+  // cost function.  Every cost function therefore evaluates on one of the context's evaluation streams: the context lock is held
   // only while work is enqueued (ordered after the context stream through `order`), and the wait
   // for kernel + device->host copies happens outside it, so calls on distinct cost functions overlap.
-  hipStream_t stream = nullptr;
-  hipEvent_t order = nullptr;
+  int eval_slot = -1;           // index into Context::eval_stream, assigned at the first Evaluate
   std::mutex mu;                // two threads on the SAME cost function are serialised
   bool draw_samples();          // refreshes h_sample_idx / d_sample_idx
   vgx::ConstraintDev describe() const;

@@ -924,12 +924,6 @@ int vgx_reg_create(vgx_ctx ctx, vgx_submap reference, vgx_submap reading, const 
     }
   }
   if (cfg->sampling_ratio != -1.0f && ps.n == 0) r->num_residuals = 0;
-  if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&r->order, hipEventDisableTiming) != hipSuccess) {
-    if (r->stream) (void)hipStreamDestroy(r->stream);
-    delete r;
-    return set_error(ctx, VGX_ERR_HIP, "vgx_reg_create: stream / event creation failed");
-  }
   *out = r;
   return VGX_OK;
 }
@@ -938,11 +932,7 @@ int vgx_reg_destroy(vgx_reg r) {
   if (!r) return VGX_ERR_INVALID;
   (void)hipSetDevice(r->ctx->device);
   (void)hipStreamSynchronize(r->ctx->stream);
-  if (r->stream) {
-    (void)hipStreamSynchronize(r->stream);
-    (void)hipStreamDestroy(r->stream);
-  }
-  if (r->order) (void)hipEventDestroy(r->order);
+  if (r->eval_slot >= 0) (void)hipStreamSynchronize(r->ctx->eval_stream[r->eval_slot]);
   if (r->d_sample_idx) (void)hipFree(r->d_sample_idx);
   if (r->d_out) (void)hipFree(r->d_out);
   delete r;
@@ -982,6 +972,7 @@ int vgx_reg_evaluate(vgx_reg r, const double ref_pose[4], const double read_pose
   vgx_ctx ctx = r->ctx;
   std::lock_guard<std::mutex> own(r->mu);
   int64_t n = 0;
+  hipStream_t stream = nullptr;
   {
     // launch under the context lock ...
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -1003,22 +994,31 @@ int vgx_reg_evaluate(vgx_reg r, const double ref_pose[4], const double read_pose
     double* d_res = r->d_out;
     double* d_jr = jac_ref ? r->d_out + n : nullptr;
     double* d_je = jac_read ? r->d_out + 5 * n : nullptr;
+    if (r->eval_slot < 0) {
+      const int k = (int)(ctx->next_eval_stream++ % (unsigned)Context::kEvalStreams);
+      if (!ctx->eval_stream[k]) {
+        VGX_HIP(ctx, hipStreamCreateWithFlags(&ctx->eval_stream[k], hipStreamNonBlocking));
+        VGX_HIP(ctx, hipEventCreateWithFlags(&ctx->eval_order[k], hipEventDisableTiming));
+      }
+      r->eval_slot = k;
+    }
+    stream = ctx->eval_stream[r->eval_slot];
     // everything already enqueued on the context stream (uploads, extraction, sample indices)
     // happens before this evaluation
-    VGX_HIP(ctx, hipEventRecord(r->order, ctx->stream));
-    VGX_HIP(ctx, hipStreamWaitEvent(r->stream, r->order, 0));
-    launch_points_single<double>(r->stream, r->reading->vps, desc, pack, d_res, d_jr, d_je);
+    VGX_HIP(ctx, hipEventRecord(ctx->eval_order[r->eval_slot], ctx->stream));
+    VGX_HIP(ctx, hipStreamWaitEvent(stream, ctx->eval_order[r->eval_slot], 0));
+    launch_points_single<double>(stream, r->reading->vps, desc, pack, d_res, d_jr, d_je);
     VGX_HIP(ctx, hipGetLastError());
   }
   // ... and copy + wait outside it (copies into pageable host memory block their caller): other
   // cost functions' evaluations proceed meanwhile
   double* d_res = r->d_out;
-  hipError_t e = hipMemcpyAsync(residuals, d_res, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, r->stream);
+  hipError_t e = hipMemcpyAsync(residuals, d_res, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, stream);
   if (e == hipSuccess && jac_ref)
-    e = hipMemcpyAsync(jac_ref, d_res + n, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost, r->stream);
+    e = hipMemcpyAsync(jac_ref, d_res + n, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost, stream);
   if (e == hipSuccess && jac_read)
-    e = hipMemcpyAsync(jac_read, d_res + 5 * n, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost, r->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
+    e = hipMemcpyAsync(jac_read, d_res + 5 * n, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
   if (e != hipSuccess) {
     std::lock_guard<std::mutex> lk(ctx->mu);
     return set_error(ctx, VGX_ERR_HIP, std::string("vgx_reg_evaluate: ") + hipGetErrorString(e));
