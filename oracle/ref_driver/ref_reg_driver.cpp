@@ -23,6 +23,7 @@
 #include "voxgraph/frontend/submap_collection/voxgraph_submap.h"
 #undef private
 #include "voxgraph/backend/constraint/cost_functions/registration_cost_function.h"
+#include "voxgraph/backend/constraint/cost_functions/relative_pose_cost_function.h"
 
 using voxgraph::RegistrationCostFunction;
 using voxgraph::RegistrationPoint;
@@ -210,6 +211,28 @@ int32_t refreg_cost_evaluate(void* cost, const double ref_pose[4], const double 
                                                         want_jacobians ? jacobians : nullptr)
              ? 1
              : 0;
+}
+
+
+// voxgraph::RelativePoseCostFunction (odometry and loop-closure edges,
+// relative_pose_cost_function{.h,_inl.h}, normalize_angle.h): residuals of the functor with
+// T = double, created through the reference's own Create().  observed = {x, y, z, yaw} of the
+// measured relative pose; sqrt_information = 4x4 row-major.  observed_out (nullable) receives the
+// values the functor actually stores: float translation widened to double, float yaw from log().
+int32_t refreg_relative_pose_residual(const double observed[4], const double* sqrt_information,
+                                      const double pose_a[4], const double pose_b[4],
+                                      double residuals[4], double observed_out[4]) {
+  const voxblox::Transformation T_obs = pose_from(observed);
+  voxgraph::Constraint::InformationMatrix info;
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) info(r, c) = sqrt_information[4 * r + c];
+  if (observed_out) {
+    for (int a = 0; a < 3; ++a) observed_out[a] = static_cast<double>(T_obs.getPosition()[a]);
+    observed_out[3] = static_cast<double>(T_obs.log()[5]);
+  }
+  std::unique_ptr<ceres::CostFunction> cost(voxgraph::RelativePoseCostFunction::Create(T_obs, info));
+  const double* parameters[2] = {pose_a, pose_b};
+  return cost->Evaluate(parameters, residuals, nullptr) ? 1 : 0;
 }
 
 }  // extern "C"

@@ -60,6 +60,8 @@ def _lib():
         lib.refreg_cost_num_residuals.argtypes = [vp]
         lib.refreg_cost_evaluate.restype = C.c_int32
         lib.refreg_cost_evaluate.argtypes = [vp, f64p, f64p, C.c_int32, f64p, f64p, f64p]
+        lib.refreg_relative_pose_residual.restype = C.c_int32
+        lib.refreg_relative_pose_residual.argtypes = [f64p, f64p, f64p, f64p, f64p, f64p]
         _LIB = lib
     return _LIB
 
@@ -171,3 +173,15 @@ class RegistrationCostFunction:
         if getattr(self, "_h", None):
             _lib().refreg_cost_destroy(self._h)
             self._h = None
+
+
+def relative_pose_residual(observed_xyz_yaw, sqrt_information, pose_a, pose_b):
+    """voxgraph::RelativePoseCostFunction (T = double) -> (residuals[4], observed values as stored)."""
+    obs = np.ascontiguousarray(observed_xyz_yaw, np.float64)
+    info = np.ascontiguousarray(sqrt_information, np.float64).reshape(4, 4)
+    a, b = np.ascontiguousarray(pose_a, np.float64), np.ascontiguousarray(pose_b, np.float64)
+    r, stored = np.zeros(4), np.zeros(4)
+    ok = _lib().refreg_relative_pose_residual(_ptr(obs, C.c_double), _ptr(info, C.c_double), _ptr(a, C.c_double),
+                                              _ptr(b, C.c_double), _ptr(r, C.c_double), _ptr(stored, C.c_double))
+    assert ok
+    return r, stored

@@ -31,4 +31,5 @@ class CheckFailure {
 #define CHECK_GE(a, b) CHECK((a) >= (b))
 #define CHECK_GT(a, b) CHECK((a) > (b))
 #define CHECK_NOTNULL(p) (p)
+#define CHECK_NEAR(a, b, margin) CHECK(((a) - (b)) <= (margin) && ((b) - (a)) <= (margin))
 #endif

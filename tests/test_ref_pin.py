@@ -177,3 +177,24 @@ def test_live_reference_sampler_stream_and_zero_weight(scene):
     ok1 = cf0.Evaluate(a, b)[0]
     ok2 = orc.reg_evaluate(layer, xyz[:100], d[:100], np.zeros(100, F), a, b)[0]
     assert ok1 is False and ok2 is False
+
+
+@needs_ref
+def test_harness_relative_pose_edge_is_the_reference_functor():
+    """harness/lm.py's odometry / loop-closure edge against the reference's RelativePoseCostFunction
+    (relative_pose_cost_function_inl.h + normalize_angle.h, T = double, built through its own
+    Create()): with the registration cost pinned too, the stand-in solver minimises voxgraph's
+    objective itself; only the solver differs from Ceres."""
+    from harness import lm
+    rng = np.random.default_rng(4)
+    worst = 0.0
+    for trial in range(200):
+        observed = np.r_[rng.uniform(-8, 8, 3), rng.uniform(-3.0, 3.0)]
+        info_diag = rng.choice([1.0, 2500.0, 0.25, 100.0], 4)                 # voxgraph_mapper.yaml:41-47 style
+        a = np.r_[rng.uniform(-50, 50, 3), rng.uniform(-3.1, 3.1)]
+        b = np.r_[a[:3] + rng.uniform(-9, 9, 3), rng.uniform(-3.1, 3.1)]    # CHECK_NEAR(yaw, 0, pi) holds
+        r_ref, stored = ref_reg.relative_pose_residual(observed, np.diag(np.sqrt(info_diag)), a, b)
+        edge = lm.RelativePoseEdge(0, 1, stored[:3], stored[3], info_diag)
+        r, _, _ = edge.evaluate(np.array([a, b]))
+        worst = max(worst, float(np.abs(r - r_ref).max() / max(1.0, np.abs(r_ref).max())))
+    assert worst < 1e-12, worst
