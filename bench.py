@@ -309,6 +309,16 @@ def main():
                          "evaluation reads exactly 20 B and writes exactly 36 B (profiles/README.md)")
     args = ap.parse_args()
 
+    lib_path = os.path.join(ROOT, "voxgraph_amd", "lib", "libvoxgraph_amd.so")
+    if not os.path.exists(lib_path):            # checkout without the (git-ignored) built library
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+            import __graft_entry__
+            __graft_entry__.build()
+        else:
+            t_wait = time.time()
+            while not os.path.exists(lib_path) and time.time() - t_wait < 900:
+                time.sleep(1.0)
+            time.sleep(2.0)                      # let the linker finish writing
     from voxgraph_amd import capi
     capi.load()
     import torch
