@@ -144,51 +144,6 @@ struct PointEval {
   float je3;           // d r / d reading yaw; je0..2 == -jo0..2 (RCF:223-227)
 };
 
-// RCF:128-268 for one point.  `cell` points at the base voxel inside an apron
-// brick or is null when the base block is missing.
-template <int VPS>
-__device__ __forceinline__ const float* locate_point(const GridDev& g, const PosePack& P, float x,
-                                                     float y, float z, float& Dx, float& Dy,
-                                                     float& Dz) {
-  // T_reading__reference * p (RCF:128-129), Eigen _transformVector, yaw-only
-  float uv0 = -(P.qz * y);
-  float uv1 = P.qz * x;
-  uv0 += uv0;
-  uv1 += uv1;
-  float c0 = -(P.qz * uv1);
-  float c1 = P.qz * uv0;
-  float px = (x + P.qw * uv0 + c0) + P.tx;
-  float py = (y + P.qw * uv1 + c1) + P.ty;
-  float pz = z + P.tz;
-  // Coarse reject before the exact (and longer) index arithmetic: the base block is
-  // the block containing p' or its -1 neighbour, so a block index outside
-  // [lut_min, lut_min + lut_dim] on any axis cannot have a correspondence.  Points
-  // of a partially overlapping pair mostly fail here; when a whole wavefront fails,
-  // the compiler's execz branch skips everything below for free.
-  {
-    int cx = (int)floorf(px * g.block_size_inv + 1e-6f) - g.lut_min[0];
-    int cy = (int)floorf(py * g.block_size_inv + 1e-6f) - g.lut_min[1];
-    int cz = (int)floorf(pz * g.block_size_inv + 1e-6f) - g.lut_min[2];
-    if ((unsigned)cx > (unsigned)g.lut_dim[0] || (unsigned)cy > (unsigned)g.lut_dim[1] ||
-        (unsigned)cz > (unsigned)g.lut_dim[2])
-      return nullptr;
-  }
-  int bx, by, bz, vx, vy, vz;
-  locate_axis<VPS>(px, g, bx, vx, Dx);
-  locate_axis<VPS>(py, g, by, vy, Dy);
-  locate_axis<VPS>(pz, g, bz, vz, Dz);
-  bx -= g.lut_min[0];
-  by -= g.lut_min[1];
-  bz -= g.lut_min[2];
-  bool inside = (unsigned)bx < (unsigned)g.lut_dim[0] && (unsigned)by < (unsigned)g.lut_dim[1] &&
-                (unsigned)bz < (unsigned)g.lut_dim[2];
-  int slot = -1;
-  if (inside) slot = as_global(g.lut)[bx + g.lut_dim[0] * (by + g.lut_dim[1] * bz)];
-  if (slot < 0) return nullptr;
-  constexpr int B = VPS + 1;
-  return g.bricks + (size_t)slot * (B * B * B) + (vx + B * (vy + B * vz));
-}
-
 template <int VPS>
 __device__ __forceinline__ void load_neighbours(const float* cell, float d[8]) {
   constexpr int B = VPS + 1;
@@ -204,7 +159,7 @@ __device__ __forceinline__ void load_neighbours(const float* cell, float d[8]) {
   d[3] = p3.x; d[7] = p3.y;
 }
 
-// Branch-free two-stage form of locate_point + load_neighbours used by the kernels: all
+// Branch-free two-stage point location + load_neighbours used by the kernels: all
 // lanes compute clamped, always-valid addresses, so the block-table loads of every point
 // a thread owns issue back to back, then all brick gathers issue back to back (one memory
 // round trip each instead of one per point behind divergent branches).  `have` says
