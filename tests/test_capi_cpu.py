@@ -71,3 +71,16 @@ def test_config_defaults_match_reference(capi):
     assert cfg.use_esdf_distance == 1
     assert cfg.sampler_seed == 0          # the submap's shared sampler stream, as WeightedSampler
     assert capi.fused_size(200, 1000) == 1 + 20 * 200 + 16 * 1000
+
+
+def test_header_is_plain_c(tmp_path):
+    """the boundary is a C ABI: include/voxgraph_amd.h must compile as C99 (no C++ism, no torch /
+    Ceres / Eigen types) and as C++"""
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "voxgraph_amd.h"\nint main(void) { vgx_reg_config c; vgx_tsdf_config t; '
+                   'vgx_map_file_submap_info i; (void)c; (void)t; (void)i; return 0; }\n')
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", inc,
+                           "-fsyntax-only", str(src)])
+    subprocess.check_call(["g++", "-std=c++14", "-Wall", "-Wextra", "-Werror", "-I", inc, "-x", "c++",
+                           "-fsyntax-only", str(src)])
