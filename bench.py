@@ -552,6 +552,18 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(capi, ctx, args, true_poses, poses, pairs,
                                            args.cpu_seconds)
+        # metric 2 on the CPU, DERIVED (not run: it would take minutes): the converged solve's
+        # evaluation count x this graph's residuals / the measured CPU evaluation rates
+        if solve:
+            cb = out["cpu_baseline"]
+            work = solve["evaluations"] * total_evals / 1e6          # M evaluations in the solve
+            est = {"evaluations": solve["evaluations"],
+                   "port_all_cores_s": work / cb["value"], "port_4_threads_s": work / cb["value_4_threads"],
+                   "note": "derived from the measured rates above; excludes the host linear algebra"}
+            rs = cb.get("reference_source") or {}
+            if rs.get("value_4_threads"):
+                est["reference_source_4_threads_s"] = work / rs["value_4_threads"]
+            cb["solve_estimate"] = est
     elif rank == 0:
         out["cpu_baseline"] = None
     # second hot path (does not shard: replicas only) -- rank 0, N = 1
