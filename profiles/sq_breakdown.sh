@@ -1,5 +1,5 @@
 #!/bin/bash
-# Where the wave cycles of the two REG kernels go (SQ counters, one pass; units = quad-cycles per
+# Where the wave cycles of the two REG kernels and of the TSDF kernel go (SQ counters, one pass; units = quad-cycles per
 # MI355X_MICROARCH.md): ACTIVE_INST_* = issuing, WAIT_ANY = parked on s_waitcnt/barrier,
 # WAIT_INST_ANY = issue stall.  WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES.
 set -u
@@ -8,8 +8,8 @@ OUT=$REPO/gpurun_out
 export TMPDIR=/tmp
 cd /tmp
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES \
-    --kernel-trace -f csv --kernel-include-regex "reg_eval_points_kernel|reg_eval_reduce" \
-    -d $OUT/prof_sq -o sq -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-solve --no-tsdf \
+    --kernel-trace -f csv --kernel-include-regex "reg_eval_points_kernel|reg_eval_reduce|tsdf_integrate" \
+    -d $OUT/prof_sq -o sq -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-solve \
     > /dev/null 2> $OUT/prof_sq.err
 cd $REPO
 python - <<'PY'
@@ -17,7 +17,7 @@ import csv, glob, json, collections
 d = collections.OrderedDict()
 for f in glob.glob("gpurun_out/prof_sq/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = "fused" if "reduce" in r["Kernel_Name"] else "materialising"
+        k = "fused" if "reduce" in r["Kernel_Name"] else ("tsdf_integrate" if "tsdf" in r["Kernel_Name"] else "materialising")
         d.setdefault(k, collections.defaultdict(list))[r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {}
 for k, c in d.items():
