@@ -59,6 +59,16 @@ void UploadRegistrationPoints(vgx_ctx ctx, const SubmapT& submap, PointTypeT poi
 // cached registration-point sets.  The returned handle is immutable and independent of `submap`.
 template <typename SubmapT>
 vgx_submap UploadFinishedSubmap(vgx_ctx ctx, const SubmapT& submap) {
+  // The registration cost function is 4-DoF: the reference CHECKs that both submaps' Z axes are
+  // gravity aligned when it is constructed (registration_cost_function.cpp:25-36, a signed compare
+  // of roll and pitch against 1e-6).  The GPU cost function never sees the 6-DoF pose, so the same
+  // guard sits here.
+  {
+    const auto T_vec = submap.getPose().log();
+    if (!(T_vec[3] < 1e-6 && T_vec[4] < 1e-6))
+      throw std::runtime_error("UploadFinishedSubmap: submap " + std::to_string(submap.getID()) +
+                               " has non-zero roll / pitch; submap Z axes must be gravity aligned");
+  }
   const auto& tsdf = submap.getTsdfMap().getTsdfLayer();
   const auto& esdf = submap.getEsdfMap().getEsdfLayer();
   const size_t vps = tsdf.voxels_per_side();
