@@ -572,8 +572,8 @@ def main():
         out["finish_submap"] = finish_bench(capi, ctx, args, true_poses)
     if rank == 0 and world == 1 and args.pipeline:
         from harness import pipeline
-        # SURVEY.md 8d config 2 asks for 100 scans per submap; 20 are used, see harness/pipeline.py
-        out["pipeline_config2"] = pipeline.run(capi, ctx, torch, n_submaps=30, scans_per_submap=20)
+        # 30 submaps, 10 Hz, 10 s per submap = 100 scans per submap
+        out["pipeline_config2"] = pipeline.run(capi, ctx, torch, n_submaps=30, scans_per_submap=100)
     if rank == 0:
         print(json.dumps(out))
     if use_dist:

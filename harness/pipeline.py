@@ -8,25 +8,27 @@ the device:
   per new map   pose-graph solve: fused REG pass + harness LM                            (pose_graph.cpp:85-106)
 
 Registration mode.  The stand-in registers isosurface points (the shipped "explicit_to_implicit",
-voxgraph_mapper.yaml:35) against the reading submap's TSDF distance (use_esdf_distance = false).
-Measured on this synthetic session (30 submaps, xy RMSE against ground truth, odometry only 0.88 m):
+voxgraph_mapper.yaml:35) in BOTH directions of every overlapping pair, as
+PoseGraph::addRegistrationConstraint does for that point type (pose_graph.cpp:62-71), against the
+reading submap's TSDF distance (use_esdf_distance = false).  Measured on this synthetic session (30
+submaps, xy RMSE against ground truth; odometry only: 0.88 m):
 
-  20 scans per submap     start at truth -> stays within    start from drifted odometry ->
-    kIsosurface, TSDF        0.12 m                            0.21 m
-    kVoxels,     TSDF        0.30 m                            0.31-0.38 m
-    kIsosurface, ESDF        0.34 m                            0.80 m
-    kVoxels,     ESDF        0.89 m                            1.08 m
-  100 scans per submap    kIsosurface/TSDF stays within 0.11 m of the truth when started there, but no
-                          mode improves on the odometry when started from the drifted poses.
+                                   20 scans / submap            100 scans / submap
+                                   from truth   from drift      from truth   from drift
+    kIsosurface mirrored, TSDF       0.26 m       0.33 m          0.27 m       0.33 m
+    kIsosurface mirrored, ESDF       0.41 m       0.75 m          0.67 m       0.69 m
+    kIsosurface one-way,  TSDF       0.12 m       0.21 m          0.11 m       1.10 m
+    kVoxels,              TSDF       0.30 m       0.31-0.38 m     0.98 m       1.12 m
+    kVoxels,              ESDF       0.89 m       1.08 m          6.6 m        1.49 m
 
-The reconstructed surfaces themselves are accurate (isosurface vertices lie within 1-4 cm of the
-analytic scene, ground and walls alike), so the sensitivity is in the registration cost of these
-partially observed synthetic submaps -- SDF values away from the zero crossing (projective TSDF at
-grazing incidence, the ESDF's 2 m default in observed free space next to surfaces only the other
-submap saw) -- and in the basin of the harness solver, not in the kernels: every mode is
-parity-tested against the oracle and against the reference source.  The throughput figures do not
-depend on it.  bench.py --pipeline therefore runs 20 scans per submap (60 s of sensor time) instead
-of SURVEY.md's 100.
+("from truth": the optimiser is started at the ground truth and the figure is how far it drifts;
+"from drift": started from the drifted odometry.)  The reconstructed surfaces themselves are accurate
+(isosurface vertices lie within 1-4 cm of the analytic scene, ground and walls alike); the biases
+come from SDF values away from the zero crossing on these partially observed street-canyon submaps
+(projective TSDF at grazing incidence, walls eroded by grazing rays of the neighbouring submap, the
+ESDF's 2 m default in observed free space next to surfaces only the other submap saw) and the
+mirrored constraints are what makes the optimisation robust to them -- not a property of the
+kernels: every mode is parity-tested against the oracle and against the reference source.
 
 Measurement / test infrastructure (uses harness.lm, torch for device buffers)."""
 import time
@@ -144,6 +146,10 @@ def run(capi, ctx, torch, n_submaps=30, scans_per_submap=20, n_az=1024, n_el=64,
         t_overlap += time.perf_counter() - t0
         if not pairs:
             continue
+        if isosurface_points:
+            # PoseGraph::addRegistrationConstraint mirrors every kIsosurfacePoints constraint
+            # (pose_graph.cpp:62-71): B's surface points are also registered against A
+            pairs = pairs + [(b, a) for a, b in pairs]
         cfs = [capi.RegistrationCostFunction(ctx, submaps[a], submaps[b], rcfg) for a, b in pairs]
         batch = capi.RegistrationBatch(ctx, cfs, pairs)
         edges = [lm.RelativePoseEdge(k, k + 1, odom[k][:3], odom[k][3], info) for k in range(m)]
