@@ -48,4 +48,29 @@ for T in (1, 2, 4, 8):
                          "Mresiduals_per_s": done * N / dt / 1e6}
 ref_r = bufs[0][0].copy()
 assert all(np.array_equal(bufs[i][0], ref_r) for i in range(NCF))
+
+# the shipped configuration: sampling_ratio 0.05 (voxgraph_mapper.yaml:34) -- tiny evaluations whose
+# cost is the call itself (host-side draws, one small upload, launch, small copies back)
+scfg = capi.default_config(registration_point_type=capi.POINTS_VOXELS, sampling_ratio=0.05)
+scfs = [capi.RegistrationCostFunction(ctx, a, b, scfg) for _ in range(NCF)]
+NS = scfs[0].num_residuals()
+sbufs = [(np.zeros(NS), np.zeros((NS, 4)), np.zeros((NS, 4))) for _ in range(NCF)]
+
+
+def swork(i, reps):
+    r, j0, j1 = sbufs[i]
+    for _ in range(reps):
+        scfs[i].Evaluate([pa, pb], r, [j0, j1])
+    return reps
+
+
+out["sampled_0.05"] = {"residuals_per_evaluate": NS, "threads": {}}
+for T in (1, 4):
+    with ThreadPoolExecutor(T) as ex:
+        list(ex.map(lambda i: swork(i, 5), range(T)))
+        t0 = time.perf_counter()
+        done = sum(ex.map(lambda i: swork(i, 300), range(T)))
+        dt = time.perf_counter() - t0
+    out["sampled_0.05"]["threads"][T] = {"evaluations_per_s": done / dt, "us_per_evaluation": dt / done * 1e6,
+                                          "Mresiduals_per_s": done * NS / dt / 1e6}
 print(json.dumps(out, indent=1))

@@ -258,12 +258,16 @@ int vgx_ctx_destroy(vgx_ctx ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
-  for (int k = 0; k < Context::kEvalStreams; ++k) {
-    if (ctx->eval_stream[k]) {
-      (void)hipStreamSynchronize(ctx->eval_stream[k]);
-      (void)hipStreamDestroy(ctx->eval_stream[k]);
+  for (int k = 0; k < Context::kEvalSlots; ++k) {
+    Context::EvalSlot& sl = ctx->eval_slot[k];
+    if (sl.stream) {
+      (void)hipStreamSynchronize(sl.stream);
+      (void)hipStreamDestroy(sl.stream);
     }
-    if (ctx->eval_order[k]) (void)hipEventDestroy(ctx->eval_order[k]);
+    if (sl.order) (void)hipEventDestroy(sl.order);
+    if (sl.d_out) (void)hipFree(sl.d_out);
+    if (sl.d_raw) (void)hipFree(sl.d_raw);
+    if (sl.h_raw) (void)hipHostFree(sl.h_raw);
   }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -374,6 +378,8 @@ static void free_points(PointSet& ps) {
   if (ps.d_xyzd) (void)hipFree(ps.d_xyzd);
   if (ps.d_weight) (void)hipFree(ps.d_weight);
   if (ps.d_chunk_bounds) (void)hipFree(ps.d_chunk_bounds);
+  if (ps.d_cumulative) (void)hipFree(ps.d_cumulative);
+  if (ps.d_inv_order) (void)hipFree(ps.d_inv_order);
   ps = PointSet();
 }
 

@@ -6,6 +6,7 @@
 
 #include <cstdint>
 #include <mutex>
+#include <condition_variable>
 #include <random>
 #include <string>
 #include <vector>
@@ -50,7 +51,13 @@ struct alignas(16) ConstraintDev {
   GridDev grid;             // reading submap's sampling grid
   const float4* xyzd;       // reference submap's points {x,y,z,distance}
   const float* weight;      // ... weights
-  const int32_t* sample_idx;  // sampling mode: indices into the point set, else null
+  // sampling mode (else all null): per residual two raw std::mt19937 outputs; the kernel turns
+  // them into the WeightedSampler draw itself (generate_canonical -> * total -> upper_bound on the
+  // cumulative weights -> optional Morton permutation), bit for bit what the host code did
+  const uint32_t* sample_raw;
+  const double* cumulative;   // [n_points] WeightedSampler::cumulative_item_weights_
+  const int32_t* inv_order;   // uploaded index -> device index, or null
+  int64_t n_points;
   const float4* chunk_bounds; // bounding spheres of consecutive kChunkPoints-point chunks
   int64_t n;                // num_residuals
   int64_t row0;             // first output row (stacked outputs)
@@ -80,13 +87,25 @@ struct Context {
   std::mutex mu;
   std::string last_error;
   int cu_count = 256;
-  // Streams for the drop-in Evaluate path, handed to cost functions round robin (created on first
-  // use, under `mu`): constructing a cost function must stay cheap -- voxgraph rebuilds every
-  // registration constraint before each solve (pose_graph_interface.cpp:149-175).
-  static constexpr int kEvalStreams = 8;
-  hipStream_t eval_stream[kEvalStreams] = {};
-  hipEvent_t eval_order[kEvalStreams] = {};
-  unsigned next_eval_stream = 0;
+  // Evaluation slots of the drop-in Evaluate path.  A call takes a free slot for its duration
+  // (stream, ordering event, device staging for the f64 outputs, pinned + device staging for the
+  // sampler's engine outputs -- all grown on demand and reused), so constructing a cost function
+  // allocates nothing: voxgraph rebuilds every registration constraint before each solve
+  // (pose_graph_interface.cpp:149-175).  Ceres uses 4 threads (pose_graph.cpp:96); with 8 slots a
+  // caller practically never waits.
+  struct EvalSlot {
+    hipStream_t stream = nullptr;
+    hipEvent_t order = nullptr;
+    double* d_out = nullptr;
+    int64_t out_rows = 0;
+    uint32_t* d_raw = nullptr;
+    uint32_t* h_raw = nullptr;
+    int64_t raw_cap = 0;
+    bool busy = false;
+  };
+  static constexpr int kEvalSlots = 8;
+  EvalSlot eval_slot[kEvalSlots];
+  std::condition_variable slot_free;
 };
 
 struct PointSet {
@@ -100,6 +119,8 @@ struct PointSet {
   std::vector<int64_t> order;            // order[i] = uploaded index of point i (empty = identity)
   std::vector<int32_t> inv_order;        // uploaded index -> device index (for sampling)
   std::vector<double> cumulative_weight; // WeightedSampler::cumulative_item_weights_ (upload order)
+  double* d_cumulative = nullptr;        // device copy, made when a sampling cost function is created
+  int32_t* d_inv_order = nullptr;        // device copy of inv_order (Morton-sorted sets only)
   // WeightedSampler's mutable engine (weighted_sampler.h:36-39): ONE default-seeded std::mt19937 per
   // point set, shared by every cost function that samples this set (vgx_reg_config.sampler_seed == 0)
   std::mt19937 rng;
@@ -146,18 +167,14 @@ struct vgx_reg_s {
   // sampling mode state: a private engine when cfg.sampler_seed != 0, else the point set's
   std::mt19937 rng;
   std::uniform_real_distribution<double> uniform{0.0, 1.0};
-  int32_t* d_sample_idx = nullptr;
-  std::vector<int32_t> h_sample_idx;
-  // drop-in scratch (f64 outputs staged on the device before the D2H copy)
-  double* d_out = nullptr;
-  int64_t d_out_rows = 0;
+  // vgx_reg_evaluate_device_f32 in sampling mode only (it does not wait for its kernel, so it
+  // cannot borrow a slot): own staging for the engine outputs, allocated at first use
+  uint32_t* d_sample_raw = nullptr;
+  uint32_t* h_sample_raw = nullptr;
   // Drop-in Evaluate calls arrive from several Ceres threads (pose_graph.cpp:96), each on its own
-  // cost function.  Every cost function therefore evaluates on one of the context's evaluation streams: the context lock is held
-  // only while work is enqueued (ordered after the context stream through `order`), and the wait
-  // for kernel + device->host copies happens outside it, so calls on distinct cost functions overlap.
-  int eval_slot = -1;           // index into Context::eval_stream, assigned at the first Evaluate
+  // cost function; each call borrows one of the context's evaluation slots (Context::EvalSlot).
   std::mutex mu;                // two threads on the SAME cost function are serialised
-  bool draw_samples();          // refreshes h_sample_idx / d_sample_idx
+  void draw_raw(uint32_t* out); // 2 engine outputs per residual
   vgx::ConstraintDev describe() const;
 };
 

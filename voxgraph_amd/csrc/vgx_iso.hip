@@ -326,6 +326,8 @@ extern "C" int vgx_submap_extract_isosurface_points(vgx_submap sm, double min_vo
   if (ps.d_xyzd) (void)hipFree(ps.d_xyzd);
   if (ps.d_weight) (void)hipFree(ps.d_weight);
   if (ps.d_chunk_bounds) (void)hipFree(ps.d_chunk_bounds);
+  if (ps.d_cumulative) (void)hipFree(ps.d_cumulative);
+  if (ps.d_inv_order) (void)hipFree(ps.d_inv_order);
   ps = PointSet();
   ps.present = true;
   sm->isosurface_blocks.clear();

@@ -309,12 +309,38 @@ __device__ __forceinline__ void store_out4(double4* p, double4 v) {
   *p = v;  // drop-in f64 path: followed by a D2H copy, keep it cacheable
 }
 
+// WeightedSampler::getRandomItem (weighted_sampler_inl.h:18-28) for residual i, from the two raw
+// std::mt19937 outputs the host drew for it.  std::uniform_real_distribution<double>(0, 1) is
+// libstdc++'s generate_canonical<double, 53>: (first + second * 2^32) / 2^64 with the first output
+// as the LOW part, the sum rounded once to double, and 1.0 mapped to the largest double below it.
+// Every operation is an IEEE f64 operation or an exact scaling, so this is the host's arithmetic.
+__device__ __forceinline__ int32_t weighted_draw(const ConstraintDev& C, int64_t i) {
+  const double lo = (double)as_global(C.sample_raw)[2 * i];
+  const double hi = (double)as_global(C.sample_raw)[2 * i + 1];
+  double u = (lo + hi * 4294967296.0) / 18446744073709551616.0;
+  if (u >= 1.0) u = 0x1.fffffffffffffp-1;  // std::nextafter(1.0, 0.0)
+  const double* cum = C.cumulative;
+  const double target = u * as_global(cum)[C.n_points - 1];  // random_number * cumulative.back()
+  int64_t first = 0, len = C.n_points;                       // std::upper_bound
+  while (len > 0) {
+    const int64_t half = len >> 1;
+    if (!(target < as_global(cum)[first + half])) {
+      first += half + 1;
+      len -= half + 1;
+    } else {
+      len = half;
+    }
+  }
+  if (first >= C.n_points) first = C.n_points - 1;
+  return C.inv_order ? as_global(C.inv_order)[first] : (int32_t)first;
+}
+
 template <int VPS, typename OUT, int PPT, bool NT, bool NTL>
 __device__ __forceinline__ void reg_eval_points_body(
     const ConstraintDev& C, const PosePack& P, const Tile& tile, OUT* __restrict__ residuals,
     typename Out4<OUT>::type* __restrict__ jac_ref, typename Out4<OUT>::type* __restrict__ jac_read) {
   const GridDev g = C.grid;
-  const int32_t* sidx = C.sample_idx;
+  const bool sampled = C.sample_raw != nullptr;
   const bool want_jac = (jac_ref != nullptr) | (jac_read != nullptr);
 
   f32x4 pt[PPT];
@@ -327,8 +353,8 @@ __device__ __forceinline__ void reg_eval_points_body(
     int local = j * kBlockThreads + (int)threadIdx.x;
     bool active = local < tile.count;
     int64_t i = tile.start + (active ? local : 0);
-    if (sidx) {
-      int32_t s = as_global(sidx)[i];
+    if (sampled) {
+      int32_t s = weighted_draw(C, i);
       pt[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[s];
       w[j] = 1.0f;  // RCF:121
     } else {
@@ -777,7 +803,12 @@ vgx::ConstraintDev vgx_reg_s::describe() const {
   const PointSet& ps = reference->points[cfg.registration_point_type];
   c.xyzd = ps.d_xyzd;
   c.weight = ps.d_weight;
-  c.sample_idx = d_sample_idx;
+  if (cfg.sampling_ratio != -1.0f) {
+    c.sample_raw = d_sample_raw;  // callers that stage elsewhere overwrite this
+    c.cumulative = ps.d_cumulative;
+    c.inv_order = ps.d_inv_order;
+    c.n_points = ps.n;
+  }
   c.chunk_bounds = ps.d_chunk_bounds;
   c.n = num_residuals;
   c.row0 = 0;
@@ -791,24 +822,17 @@ vgx::ConstraintDev vgx_reg_s::describe() const {
   return c;
 }
 
-// WeightedSampler::getRandomItem (weighted_sampler_inl.h:18-28), num_residuals
-// draws per Evaluate (RCF:113-122).  The engine is the reference submap's point-set engine, as in
-// the reference (every cost function built on a submap advances the same stream), unless the
-// caller asked for a private, separately seeded one.
-bool vgx_reg_s::draw_samples() {
+// The engine outputs of one Evaluate: num_residuals draws of WeightedSampler::getRandomItem
+// (weighted_sampler_inl.h:18-28, RCF:113-122) consume two 32-bit outputs each.  The engine is the
+// reference submap's point-set engine, as in the reference (every cost function built on a submap
+// advances the same stream), unless the caller asked for a private, separately seeded one.  Only
+// the cheap sequential part stays on the host (~2 ns per output); the draw itself -- canonical
+// double, scaling, binary search over the cumulative weights -- runs in the kernel.
+void vgx_reg_s::draw_raw(uint32_t* out) {
   PointSet& ps = reference->points[cfg.registration_point_type];
   std::mt19937& engine = cfg.sampler_seed != 0u ? rng : ps.rng;
-  h_sample_idx.resize((size_t)num_residuals);
-  const std::vector<double>& cum = ps.cumulative_weight;
-  for (int64_t i = 0; i < num_residuals; ++i) {
-    const double random_number = uniform(engine);
-    const double random_cumulative_weight = random_number * cum.back();
-    auto it = std::upper_bound(cum.begin(), cum.end(), random_cumulative_weight);
-    size_t idx = (size_t)(it - cum.begin());
-    if (idx >= cum.size()) idx = cum.size() - 1;
-    h_sample_idx[(size_t)i] = ps.inv_order.empty() ? (int32_t)idx : ps.inv_order[idx];
-  }
-  return true;
+  const int64_t m = 2 * num_residuals;
+  for (int64_t k = 0; k < m; ++k) out[k] = (uint32_t)engine();
 }
 
 extern "C" {
@@ -879,6 +903,26 @@ int vgx_reg_create(vgx_ctx ctx, vgx_submap reference, vgx_submap reading, const 
     }
   }
   if (cfg->sampling_ratio != -1.0f && ps.n == 0) r->num_residuals = 0;
+  if (cfg->sampling_ratio != -1.0f && ps.n > 0) {
+    PointSet& mps = reference->points[cfg->registration_point_type];
+    hipError_t e = hipSuccess;
+    if (!mps.d_cumulative) {
+      e = hipMalloc(&mps.d_cumulative, (size_t)mps.n * sizeof(double));
+      if (e == hipSuccess)
+        e = hipMemcpy(mps.d_cumulative, mps.cumulative_weight.data(), (size_t)mps.n * sizeof(double),
+                      hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess && !mps.inv_order.empty() && !mps.d_inv_order) {
+      e = hipMalloc(&mps.d_inv_order, (size_t)mps.n * sizeof(int32_t));
+      if (e == hipSuccess)
+        e = hipMemcpy(mps.d_inv_order, mps.inv_order.data(), (size_t)mps.n * sizeof(int32_t),
+                      hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) {
+      delete r;
+      return set_error(ctx, VGX_ERR_HIP, std::string("vgx_reg_create: sampler tables: ") + hipGetErrorString(e));
+    }
+  }
   *out = r;
   return VGX_OK;
 }
@@ -887,32 +931,13 @@ int vgx_reg_destroy(vgx_reg r) {
   if (!r) return VGX_ERR_INVALID;
   (void)hipSetDevice(r->ctx->device);
   (void)hipStreamSynchronize(r->ctx->stream);
-  if (r->eval_slot >= 0) (void)hipStreamSynchronize(r->ctx->eval_stream[r->eval_slot]);
-  if (r->d_sample_idx) (void)hipFree(r->d_sample_idx);
-  if (r->d_out) (void)hipFree(r->d_out);
+  if (r->d_sample_raw) (void)hipFree(r->d_sample_raw);
+  if (r->h_sample_raw) (void)hipHostFree(r->h_sample_raw);
   delete r;
   return VGX_OK;
 }
 
 int64_t vgx_reg_num_residuals(vgx_reg r) { return r ? r->num_residuals : -1; }
-
-// Fresh samples for sampling mode (the only per-Evaluate upload of the drop-in path:
-// descriptor and pose pack travel as kernel arguments).
-static int reg_prepare(vgx_reg r) {
-  vgx_ctx ctx = r->ctx;
-  VGX_HIP(ctx, hipSetDevice(ctx->device));
-  const int64_t n = r->num_residuals;
-  if (r->cfg.sampling_ratio != -1.0f && n > 0) {
-    if (!r->d_sample_idx) VGX_HIP(ctx, hipMalloc(&r->d_sample_idx, (size_t)n * sizeof(int32_t)));
-    // the previous Evaluate's kernel may still read the old indices
-    VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    r->draw_samples();
-    VGX_HIP(ctx, hipMemcpyAsync(r->d_sample_idx, r->h_sample_idx.data(), (size_t)n * sizeof(int32_t),
-                                hipMemcpyHostToDevice, ctx->stream));
-    VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  }
-  return VGX_OK;
-}
 
 static int reg_status(vgx_reg r) {
   // RCF:273: summed_reference_weight == 0 -> return false
@@ -921,61 +946,99 @@ static int reg_status(vgx_reg r) {
   return sw == 0 ? VGX_EVALUATE_FALSE : VGX_OK;
 }
 
+namespace {
+// Borrows an evaluation slot (must be called with ctx->mu held through `lk`); returns its index.
+int acquire_slot(vgx_ctx ctx, std::unique_lock<std::mutex>& lk) {
+  for (;;) {
+    for (int k = 0; k < Context::kEvalSlots; ++k)
+      if (!ctx->eval_slot[k].busy) {
+        ctx->eval_slot[k].busy = true;
+        return k;
+      }
+    ctx->slot_free.wait(lk);
+  }
+}
+struct SlotLease {  // gives the slot back on every exit path; declare it BEFORE the context
+                    // lock so that it is destroyed after the lock has been released
+  vgx_ctx ctx;
+  int k;
+  ~SlotLease() {
+    if (k < 0) return;
+    {
+      std::lock_guard<std::mutex> lk(ctx->mu);
+      ctx->eval_slot[k].busy = false;
+    }
+    ctx->slot_free.notify_one();
+  }
+};
+}  // namespace
+
 int vgx_reg_evaluate(vgx_reg r, const double ref_pose[4], const double read_pose[4],
                      double* residuals, double* jac_ref, double* jac_read) {
   if (!r || !ref_pose || !read_pose) return VGX_ERR_INVALID;
   vgx_ctx ctx = r->ctx;
   std::lock_guard<std::mutex> own(r->mu);
-  int64_t n = 0;
-  hipStream_t stream = nullptr;
-  {
-    // launch under the context lock ...
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    if (!residuals) return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_evaluate: residuals == NULL");
-    int rc = reg_prepare(r);
-    if (rc != VGX_OK) return rc;
-    if (reg_status(r) == VGX_EVALUATE_FALSE) return VGX_EVALUATE_FALSE;
-    n = r->num_residuals;
-    if (n == 0) return VGX_OK;
-    const ConstraintDev desc = r->describe();
-    PosePack pack;
-    make_pose_pack(ref_pose, read_pose, &pack);
-    if (r->d_out_rows < n) {
-      if (r->d_out) (void)hipFree(r->d_out);
-      r->d_out = nullptr;
-      VGX_HIP(ctx, hipMalloc(&r->d_out, (size_t)n * 9 * sizeof(double)));
-      r->d_out_rows = n;
-    }
-    double* d_res = r->d_out;
-    double* d_jr = jac_ref ? r->d_out + n : nullptr;
-    double* d_je = jac_read ? r->d_out + 5 * n : nullptr;
-    if (r->eval_slot < 0) {
-      const int k = (int)(ctx->next_eval_stream++ % (unsigned)Context::kEvalStreams);
-      if (!ctx->eval_stream[k]) {
-        VGX_HIP(ctx, hipStreamCreateWithFlags(&ctx->eval_stream[k], hipStreamNonBlocking));
-        VGX_HIP(ctx, hipEventCreateWithFlags(&ctx->eval_order[k], hipEventDisableTiming));
-      }
-      r->eval_slot = k;
-    }
-    stream = ctx->eval_stream[r->eval_slot];
-    // everything already enqueued on the context stream (uploads, extraction, sample indices)
-    // happens before this evaluation
-    VGX_HIP(ctx, hipEventRecord(ctx->eval_order[r->eval_slot], ctx->stream));
-    VGX_HIP(ctx, hipStreamWaitEvent(stream, ctx->eval_order[r->eval_slot], 0));
-    launch_points_single<double>(stream, r->reading->vps, desc, pack, d_res, d_jr, d_je);
-    VGX_HIP(ctx, hipGetLastError());
+  const int64_t n = r->num_residuals;
+  SlotLease lease{ctx, -1};
+  std::unique_lock<std::mutex> lk(ctx->mu);  // launch under the context lock ...
+  if (!residuals) return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_evaluate: residuals == NULL");
+  if (n == 0) return reg_status(r);
+  const int k = acquire_slot(ctx, lk);
+  lease.k = k;
+  Context::EvalSlot& sl = ctx->eval_slot[k];
+  VGX_HIP(ctx, hipSetDevice(ctx->device));
+  if (!sl.stream) {
+    VGX_HIP(ctx, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+    VGX_HIP(ctx, hipEventCreateWithFlags(&sl.order, hipEventDisableTiming));
   }
+  if (sl.out_rows < n) {
+    if (sl.d_out) (void)hipFree(sl.d_out);
+    sl.d_out = nullptr;
+    sl.out_rows = 0;
+    VGX_HIP(ctx, hipMalloc(&sl.d_out, (size_t)n * 9 * sizeof(double)));
+    sl.out_rows = n;
+  }
+  const bool sampled = r->cfg.sampling_ratio != -1.0f;
+  if (sampled && sl.raw_cap < 2 * n) {
+    if (sl.d_raw) (void)hipFree(sl.d_raw);
+    if (sl.h_raw) (void)hipHostFree(sl.h_raw);
+    sl.d_raw = nullptr;
+    sl.h_raw = nullptr;
+    sl.raw_cap = 0;
+    VGX_HIP(ctx, hipMalloc(&sl.d_raw, (size_t)n * 2 * sizeof(uint32_t)));
+    VGX_HIP(ctx, hipHostMalloc((void**)&sl.h_raw, (size_t)n * 2 * sizeof(uint32_t), hipHostMallocDefault));
+    sl.raw_cap = 2 * n;
+  }
+  PosePack pack;
+  make_pose_pack(ref_pose, read_pose, &pack);
+  double* d_res = sl.d_out;
+  double* d_jr = jac_ref ? sl.d_out + n : nullptr;
+  double* d_je = jac_read ? sl.d_out + 5 * n : nullptr;
+  // everything already enqueued on the context stream (uploads, extraction) happens before this
+  VGX_HIP(ctx, hipEventRecord(sl.order, ctx->stream));
+  VGX_HIP(ctx, hipStreamWaitEvent(sl.stream, sl.order, 0));
+  ConstraintDev desc = r->describe();
+  if (sampled) {
+    // this Evaluate's engine outputs (drawn under the lock: the engine is shared)
+    r->draw_raw(sl.h_raw);
+    VGX_HIP(ctx, hipMemcpyAsync(sl.d_raw, sl.h_raw, (size_t)n * 2 * sizeof(uint32_t), hipMemcpyHostToDevice,
+                                sl.stream));
+    desc.sample_raw = sl.d_raw;
+  }
+  if (reg_status(r) == VGX_EVALUATE_FALSE) return VGX_EVALUATE_FALSE;
+  launch_points_single<double>(sl.stream, r->reading->vps, desc, pack, d_res, d_jr, d_je);
+  VGX_HIP(ctx, hipGetLastError());
+  lk.unlock();
   // ... and copy + wait outside it (copies into pageable host memory block their caller): other
   // cost functions' evaluations proceed meanwhile
-  double* d_res = r->d_out;
-  hipError_t e = hipMemcpyAsync(residuals, d_res, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, stream);
+  hipError_t e = hipMemcpyAsync(residuals, d_res, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, sl.stream);
   if (e == hipSuccess && jac_ref)
-    e = hipMemcpyAsync(jac_ref, d_res + n, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost, stream);
+    e = hipMemcpyAsync(jac_ref, d_res + n, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost, sl.stream);
   if (e == hipSuccess && jac_read)
-    e = hipMemcpyAsync(jac_read, d_res + 5 * n, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost, stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    e = hipMemcpyAsync(jac_read, d_res + 5 * n, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost, sl.stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(sl.stream);
   if (e != hipSuccess) {
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    lk.lock();
     return set_error(ctx, VGX_ERR_HIP, std::string("vgx_reg_evaluate: ") + hipGetErrorString(e));
   }
   return VGX_OK;
@@ -987,8 +1050,20 @@ int vgx_reg_evaluate_device_f32(vgx_reg r, const double ref_pose[4], const doubl
   vgx_ctx ctx = r->ctx;
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (!d_residuals) return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_evaluate_device_f32: residuals == NULL");
-  int rc = reg_prepare(r);
-  if (rc != VGX_OK) return rc;
+  // this entry point does not wait for its kernel: in sampling mode the previous call's upload of
+  // the engine outputs must have left the pinned staging buffer before it is refilled
+  VGX_HIP(ctx, hipSetDevice(ctx->device));
+  const int64_t n = r->num_residuals;
+  if (r->cfg.sampling_ratio != -1.0f && n > 0) {
+    VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!r->d_sample_raw) {
+      VGX_HIP(ctx, hipMalloc(&r->d_sample_raw, (size_t)n * 2 * sizeof(uint32_t)));
+      VGX_HIP(ctx, hipHostMalloc((void**)&r->h_sample_raw, (size_t)n * 2 * sizeof(uint32_t), hipHostMallocDefault));
+    }
+    r->draw_raw(r->h_sample_raw);
+    VGX_HIP(ctx, hipMemcpyAsync(r->d_sample_raw, r->h_sample_raw, (size_t)n * 2 * sizeof(uint32_t),
+                                hipMemcpyHostToDevice, ctx->stream));
+  }
   if (reg_status(r) == VGX_EVALUATE_FALSE) return VGX_EVALUATE_FALSE;
   PosePack pack;
   make_pose_pack(ref_pose, read_pose, &pack);
