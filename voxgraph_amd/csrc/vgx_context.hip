@@ -268,6 +268,7 @@ int vgx_ctx_destroy(vgx_ctx ctx) {
     if (sl.d_out) (void)hipFree(sl.d_out);
     if (sl.d_raw) (void)hipFree(sl.d_raw);
     if (sl.h_raw) (void)hipHostFree(sl.h_raw);
+    if (sl.h_out) (void)hipHostFree(sl.h_out);
   }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;

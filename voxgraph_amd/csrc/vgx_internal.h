@@ -101,9 +101,11 @@ struct Context {
     uint32_t* d_raw = nullptr;
     uint32_t* h_raw = nullptr;
     int64_t raw_cap = 0;
+    double* h_out = nullptr;   // pinned, kSmallOutputBytes: small evaluations come back in ONE copy
     bool busy = false;
   };
   static constexpr int kEvalSlots = 8;
+  static constexpr size_t kSmallOutputBytes = 1u << 20;
   EvalSlot eval_slot[kEvalSlots];
   std::condition_variable slot_free;
 };

@@ -990,6 +990,7 @@ int vgx_reg_evaluate(vgx_reg r, const double ref_pose[4], const double read_pose
   if (!sl.stream) {
     VGX_HIP(ctx, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
     VGX_HIP(ctx, hipEventCreateWithFlags(&sl.order, hipEventDisableTiming));
+    VGX_HIP(ctx, hipHostMalloc((void**)&sl.h_out, Context::kSmallOutputBytes, hipHostMallocDefault));
   }
   if (sl.out_rows < n) {
     if (sl.d_out) (void)hipFree(sl.d_out);
@@ -1029,14 +1030,28 @@ int vgx_reg_evaluate(vgx_reg r, const double ref_pose[4], const double read_pose
   launch_points_single<double>(sl.stream, r->reading->vps, desc, pack, d_res, d_jr, d_je);
   VGX_HIP(ctx, hipGetLastError());
   lk.unlock();
-  // ... and copy + wait outside it (copies into pageable host memory block their caller): other
-  // cost functions' evaluations proceed meanwhile
-  hipError_t e = hipMemcpyAsync(residuals, d_res, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, sl.stream);
-  if (e == hipSuccess && jac_ref)
-    e = hipMemcpyAsync(jac_ref, d_res + n, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost, sl.stream);
-  if (e == hipSuccess && jac_read)
-    e = hipMemcpyAsync(jac_read, d_res + 5 * n, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost, sl.stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(sl.stream);
+  // ... and copy + wait outside it: other cost functions' evaluations proceed meanwhile.  Small
+  // outputs (the shipped sampled configuration: a few thousand residuals) come back in one copy
+  // into the slot's pinned buffer and are scattered by the host; large ones go straight into the
+  // caller's (pageable) arrays, three copies that block their caller.
+  hipError_t e = hipSuccess;
+  const size_t out_bytes = (size_t)n * 9 * sizeof(double);
+  if (out_bytes <= Context::kSmallOutputBytes && sl.h_out) {
+    e = hipMemcpyAsync(sl.h_out, d_res, out_bytes, hipMemcpyDeviceToHost, sl.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(sl.stream);
+    if (e == hipSuccess) {
+      std::memcpy(residuals, sl.h_out, (size_t)n * sizeof(double));
+      if (jac_ref) std::memcpy(jac_ref, sl.h_out + n, (size_t)n * 4 * sizeof(double));
+      if (jac_read) std::memcpy(jac_read, sl.h_out + 5 * n, (size_t)n * 4 * sizeof(double));
+    }
+  } else {
+    e = hipMemcpyAsync(residuals, d_res, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, sl.stream);
+    if (e == hipSuccess && jac_ref)
+      e = hipMemcpyAsync(jac_ref, d_res + n, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost, sl.stream);
+    if (e == hipSuccess && jac_read)
+      e = hipMemcpyAsync(jac_read, d_res + 5 * n, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost, sl.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(sl.stream);
+  }
   if (e != hipSuccess) {
     lk.lock();
     return set_error(ctx, VGX_ERR_HIP, std::string("vgx_reg_evaluate: ") + hipGetErrorString(e));
