@@ -246,7 +246,7 @@ int build_chunk_bounds(vgx_ctx ctx, PointSet& ps);
 void make_pose_pack(const double ref_pose[4], const double read_pose[4], PosePack* out);
 std::vector<Tile> make_tiles(int32_t constraint, int64_t n, int tile_points);
 constexpr int kBlockThreads = 256;
-constexpr int kPointsPerThread = 4;
+constexpr int kPointsPerThread = 4;  // measured 5.09-5.28 / 5.06-5.12 / 5.77-5.79 ms at 2 / 4 / 8 (config 3)
 constexpr int kTilePoints = kBlockThreads * kPointsPerThread;
 }  // namespace vgx
 
