@@ -237,6 +237,16 @@ def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=2):
         first_updates = integ4.integrate_device(poses[0], dev[0].data_ptr(), None, n_pts, count=True)
         for o in (integ3, integ4, layer3, layer4):
             o.destroy()
+        # the drop-in call itself: host pointers (pageable), PCIe upload included, returns when done
+        layer5 = capi.TsdfLayer(ctx, vs, 16, bmin, bdim, int(np.prod(bdim)))
+        integ5 = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(**kw), layer5)
+        integ5.integratePointCloud(poses[0], clouds[0])
+        h0 = time.perf_counter()
+        for k in range(1, scans):
+            integ5.integratePointCloud(poses[k], clouds[k])
+        host_ms = (time.perf_counter() - h0) * 1e3 / (scans - 1)
+        for o in (integ5, layer5):
+            o.destroy()
         # CPU oracle on a bounded sample (single thread: the restatement is serial)
         ol = orc.TsdfLayer(vs, 16)
         oi = orc.FastTsdfIntegrator(orc.tsdf_config(**kw), ol)
@@ -252,6 +262,9 @@ def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=2):
                      "voxel_updates_per_scan": updates / timed, "blocks": n_blocks,
                      "dropped_updates": dropped,
                      "algorithmic_GBs": (16.0 * n_pts * timed + 24.0 * updates) / ms / 1e6,
+                     "host_pointer_call": {"ms_per_scan": host_ms, "Mpoints_per_s": n_pts / host_ms / 1e3,
+                                           "note": "vgx_tsdf_integrate: pageable host points, PCIe upload and "
+                                                   "completion wait included"},
                      "first_scan": {"ms": first_ms, "voxel_updates": first_updates,
                                     "Mvoxel_updates_per_s": first_updates / first_ms / 1e3,
                                     "algorithmic_GBs": (16.0 * n_pts + 24.0 * first_updates) / first_ms / 1e6},
