@@ -18,6 +18,30 @@ def pytest_configure(config):
         __graft_entry__.build()
 
 
+def _gfx950_present():
+    """True when a gfx950 device can be opened (asked of the product library, not of torch)."""
+    try:
+        from voxgraph_amd import capi
+        capi.Context(0).close()
+        return True
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    # plain `pytest` on a host without an MI355X: skip the gpu-marked tests instead of erroring
+    # (`-m gpu` on a GPU box and `-m "not gpu"` here are unaffected)
+    markexpr = (config.getoption("markexpr", "") or "").strip()
+    if markexpr == "gpu":
+        return          # the GPU tests were asked for by name: without a device they must fail loudly
+    gpu_items = [it for it in items if "gpu" in it.keywords]
+    if not gpu_items or _gfx950_present():
+        return
+    skip = pytest.mark.skip(reason="needs an MI355X (gfx950): vgx_ctx_create found no device")
+    for it in gpu_items:
+        it.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")

@@ -40,6 +40,14 @@ def test_single_gpu_line_has_the_contract_fields(single):
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"])
     assert d["value"] > 0 and d["solve"]["position_rmse_m_after"] < d["solve"]["position_rmse_m_before"]
     assert d["fused"]["cost_vs_materialised"] < 1e-6
+    # every reported bandwidth is at or below the HBM peak (accounting)
+    fo = d["roofline_full_overlap"]
+    assert fo["with_correspondence_frac"] > 0.9 and 0 < fo["frac"] <= 1.0
+    assert fo["fused"]["cost_vs_materialised"] < 1e-6
+    for f in (d["fused"], fo["fused"]):
+        assert 0 < f["algorithmic_GBs"] <= d["roofline"]["peak"]
+        assert f["with_correspondence"] <= f["loaded_after_culling"] <= f["evaluations"]
+    assert d["config"]["passes_per_step"] == 10 and d["value_with_correspondence"] <= d["value"]
 
 
 def test_two_rank_path_dry_run_on_one_gpu(single):
@@ -52,7 +60,7 @@ def test_two_rank_path_dry_run_on_one_gpu(single):
     assert d["n_gpus"] == 2 and "DRY RUN" in d["data"] and d["cpu_baseline"] is None
     assert d["fused"]["allreduce_bytes"] > 0
     # the sharded solve is the single-rank solve: same evaluations, same answer
-    assert d["config"]["residuals_per_step"] == single["config"]["residuals_per_step"]
+    assert d["config"]["residuals_per_pass"] == single["config"]["residuals_per_pass"]
     for k in ("iterations", "evaluations", "termination"):
         assert d["solve"][k] == single["solve"][k], k
     assert abs(d["solve"]["final_cost"] - single["solve"]["final_cost"]) <= 1e-9 * single["solve"]["final_cost"]

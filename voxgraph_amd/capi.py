@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvoxgraph_amd.so")
+# VGX_LIB: an alternative build of the same library (A/B scripts under profiles/ only)
+LIB_PATH = os.environ.get("VGX_LIB") or os.path.join(_HERE, "lib", "libvoxgraph_amd.so")
 
 OK = 0
 EVALUATE_FALSE = 1
@@ -116,6 +117,7 @@ SIGNATURES = {
     "vgx_reg_batch_row_offsets": (C.c_int, [vp, i64p]),
     "vgx_reg_batch_evaluate_points": (C.c_int, [vp, f64p, C.c_int32, vp, vp, vp, i32p]),
     "vgx_reg_batch_evaluate_normal": (C.c_int, [vp, f64p, C.c_int32, vp, f64p, i32p]),
+    "vgx_reg_batch_count_live": (C.c_int, [vp, f64p, C.c_int32, i64p]),
     "vgx_reg_batch_assemble": (C.c_int, [vp, vp, C.c_int32, vp, C.c_int32]),
     "vgx_reg_fused_size": (C.c_int64, [C.c_int32, C.c_int32]),
     "vgx_reg_compress_normal": (C.c_int, [f64p, f64p, f64p]),
@@ -456,6 +458,14 @@ class RegistrationBatch:
             self.h, _ptr(poses, f64p), poses.shape[0], vp(d_normal) if d_normal else None,
             _ptr(host, f64p), _ptr(status, i32p)))
         return status[:self.n], host
+
+    def count_live(self, poses):
+        """residuals whose points the fused pass reads at these poses (chunk culling applied)"""
+        poses = _f64(poses).reshape(-1, 4)
+        n = C.c_int64()
+        self.ctx.check(self.ctx.lib.vgx_reg_batch_count_live(self.h, _ptr(poses, f64p), poses.shape[0],
+                                                             C.byref(n)))
+        return n.value
 
     def assemble(self, n_nodes, d_fused, d_normal=None, zero_first=True):
         self.ctx.check(self.ctx.lib.vgx_reg_batch_assemble(

@@ -42,7 +42,8 @@ struct alignas(16) PosePack {
   float cos_emo, sin_emo;  // cos/sin(yaw_reading - yaw_reference)    (.cpp:94-96)
   float dxs, dxc;          // (xe-xo)*sin_e , (xe-xo)*cos_e           (.cpp:225-226)
   float dys, dyc;          // (ye-yo)*sin_e , (ye-yo)*cos_e
-  float pad[3];
+  float k1, k2;            // dxs - dyc , dxc + dys (lean fused kernel)
+  float pad;
 };
 static_assert(sizeof(PosePack) == 64, "PosePack must stay one 64-byte line");
 

@@ -85,6 +85,9 @@ void make_pose_pack(const double ref_pose[4], const double read_pose[4], PosePac
   out->dxc = dx * out->cos_e;
   out->dys = dy * out->sin_e;
   out->dyc = dy * out->cos_e;
+  // lean fused kernel only (the exact kernels keep the reference's association, RCF:225-226)
+  out->k1 = out->dxs - out->dyc;
+  out->k2 = out->dxc + out->dys;
 }
 
 std::vector<Tile> make_tiles(int32_t constraint, int64_t n, int tile_points) {
@@ -454,6 +457,7 @@ constexpr int kReduceWavesPerSimd = 4;
 // that 4 waves/SIMD cannot hide (SQ counters, profiles/README.md "Fused kernel"):
 // fused multiply-adds for the 21 f64 accumulations took 2.23 -> 2.11 ms; a branch-free variant
 // (masked lanes carried through the FMAs) needed 144 VGPRs: 2.43 ms at 3 waves/SIMD, 2.94 ms spilling at 4.
+constexpr int kFusedVariantDefault = 422;  // lean kernel: 4 waves/SIMD, 2 points/thread, f32 accumulators
 constexpr int kReducePointsPerThread = 2;  // measured: 3.72 / 3.29 / 3.41 ms per fused step at 4 / 2 / 1 (profiles/tune_fused.sh)
 
 // True when no point inside the sphere (centre in the reference frame) can have a
@@ -605,6 +609,211 @@ __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_kernel(
     double v = ((lds[0][threadIdx.x] + lds[1][threadIdx.x]) + lds[2][threadIdx.x]) + lds[3][threadIdx.x];
     partials[(size_t)t * kPartialSize + threadIdx.x] = v;
   }
+}
+
+// ---------------------------------------------------------------------------
+// kernel 2b: fused normal equations, lean form (the default)
+// ---------------------------------------------------------------------------
+// The materialising kernel reproduces the reference's f32 operation order so that every output
+// value can be compared with the reference bit for bit.  The fused pass has no per-point output to
+// compare: its 45 sums per constraint are checked against the materialised sums to 1e-6.  It
+// therefore keeps ONLY the discontinuous part of the reference's arithmetic exact -- the rigid
+// transform and Interpolator::setIndexes/getQVector (locate_stage1: which cell a point falls in,
+// and its fractional offsets, bit for bit) -- and evaluates everything that is a smooth function of
+// (8 neighbours, offsets) in the cheapest association:
+//   * trilinear value and gradient as 7 + 6 nested lerps with FMAs (22 VALU instead of the
+//     interp_table_ product, q-vector and three 4-term gradient rows: ~78),
+//   * the f64 detour of RCF:183-202 (doubles rounded into a float matrix) stays in f32,
+//   * validity from the interpolated value itself: every neighbour enters it, so it is NaN exactly
+//     when a neighbour is the NaN sentinel,
+//   * -w/voxel_size folded into one scale, (dxs - dyc) and (dxc + dys) precomputed per constraint.
+// Each of these differs from the reference's rounding by a few f32 ulp per point (relative 1e-7),
+// unbiased, so the sums agree to ~1e-9; what would NOT average out -- a point assigned to the
+// neighbouring cell -- cannot happen because locate_stage1 is shared with the exact kernel.
+// ACC = float keeps the 21 running products in f32 per thread across a tile (<= 2 * kMaxReduceIters
+// terms), widened to f64 for the wave / workgroup / constraint reduction: half the accumulator
+// registers and no f64 FMA in the loop.  Fixed order throughout => bitwise reproducible.
+__device__ __forceinline__ bool eval_point_lean(const float d[8], bool have, float Dx, float Dy, float Dz,
+                                                float inv_f, const PosePack& P, float xi, float yi,
+                                                float d_ref, float w, float u[6]) {
+#pragma clang fp contract(fast)
+  // neighbour k = 4 x + 2 y + z
+  const float a0 = d[4] - d[0], a1 = d[5] - d[1], a2 = d[6] - d[2], a3 = d[7] - d[3];
+  const float v0 = Dx * a0 + d[0], v1 = Dx * a1 + d[1], v2 = Dx * a2 + d[2], v3 = Dx * a3 + d[3];
+  const float b0 = v2 - v0, b1 = v3 - v1;
+  const float u0 = Dy * b0 + v0, u1 = Dy * b1 + v1;
+  const float ax0 = Dy * (a2 - a0) + a0, ax1 = Dy * (a3 - a1) + a1;
+  const float gz = u1 - u0;
+  const float val = Dz * gz + u0;
+  const float gx = Dz * (ax1 - ax0) + ax0;
+  const float gy = Dz * (b1 - b0) + b0;
+  const float s = -w * inv_f;
+  const float h0 = s * gx, h1 = s * gy, h2 = s * gz;
+  const float mo3 = xi * P.sin_emo - yi * P.cos_emo;
+  const float mo7 = xi * P.cos_emo + yi * P.sin_emo;
+  u[0] = h0 * P.cos_e - h1 * P.sin_e;
+  u[1] = h0 * P.sin_e + h1 * P.cos_e;
+  u[2] = h2;
+  u[3] = h0 * mo3 + h1 * mo7;
+  u[4] = h0 * (P.k1 - mo3) + h1 * (P.k2 - mo7);
+  u[5] = (d_ref - val) * w;
+  return have && (val == val);  // NaN sentinel among the neighbours <=> NaN value
+}
+
+template <typename ACC>
+__device__ __forceinline__ void accumulate21(ACC acc[21], const float u[6]) {
+#pragma clang fp contract(fast)
+  ACC x[6];
+#pragma unroll
+  for (int a = 0; a < 6; ++a) x[a] = (ACC)u[a];
+  int k = 0;
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int b = a; b < 6; ++b, ++k) acc[k] = x[a] * x[b] + acc[k];
+}
+
+template <int VPS, int PPT, typename ACC, int WAVES>
+__global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_kernel(
+    const ConstraintDev* __restrict__ cons, const PosePack* __restrict__ packs,
+    const Tile* __restrict__ tiles, int n_tiles, double* __restrict__ partials) {
+  constexpr int kIterPoints = kBlockThreads * PPT;
+  static_assert(kChunkPoints % kIterPoints == 0, "an inner iteration never straddles a culling chunk");
+  const int t = blockIdx.x;
+  if (t >= n_tiles) return;
+  const Tile tile = tiles[t];
+  const ConstraintDev& C = cons[tile.constraint];
+  const PosePack P = packs[tile.constraint];
+  const GridDev g = C.grid;
+  const bool count_misses = C.no_corr_cost != 0.0;
+  const float4* bounds = (!count_misses && C.chunk_bounds) ? C.chunk_bounds : nullptr;
+  const long long chunk0 = tile.start / kChunkPoints;  // tiles start on chunk boundaries
+  __shared__ unsigned char s_live[kMaxReduceIters * 2];
+  const int n_chunks = (tile.count + kChunkPoints - 1) / kChunkPoints;
+  if ((int)threadIdx.x < n_chunks)
+    s_live[threadIdx.x] = !(bounds && chunk_outside(g, P, bounds[chunk0 + threadIdx.x]));
+  __syncthreads();
+  ACC acc[21];
+#pragma unroll
+  for (int k = 0; k < 21; ++k) acc[k] = (ACC)0;
+  const float nc = (float)C.no_corr_cost;
+  const bool grid_empty = g.bricks == nullptr;
+
+  f32x4 pt_next[PPT];
+  float w_next[PPT];
+  bool live_next = s_live[0] != 0;
+  if (live_next) {
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      int local = j * kBlockThreads + (int)threadIdx.x;
+      int64_t i = tile.start + (local < tile.count ? local : 0);
+      pt_next[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[i];
+      w_next[j] = as_global(C.weight)[i];
+    }
+  }
+  for (int base = 0; base < tile.count; base += kIterPoints) {
+    f32x4 pt[PPT];
+    float w[PPT];
+    const bool live = live_next;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      pt[j] = pt_next[j];
+      w[j] = w_next[j];
+    }
+    live_next = false;
+    if (base + kIterPoints < tile.count) {
+      live_next = s_live[(base + kIterPoints) / kChunkPoints] != 0;
+      if (live_next) {
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+          int local = base + kIterPoints + j * kBlockThreads + (int)threadIdx.x;
+          int64_t i = tile.start + (local < tile.count ? local : 0);
+          pt_next[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[i];
+          w_next[j] = as_global(C.weight)[i];
+        }
+      }
+    }
+    if (!live) continue;
+    Located loc[PPT];
+    bool have[PPT];
+    float d[PPT][8];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      loc[j] = locate_stage1<VPS>(g, P, pt[j].x, pt[j].y, pt[j].z);
+      have[j] = false;
+    }
+    if (!grid_empty) {
+      int slot[PPT];
+#pragma unroll
+      for (int j = 0; j < PPT; ++j) slot[j] = as_global(g.lut)[loc[j].lut_index];
+      constexpr int CELLS = (VPS + 1) * (VPS + 1) * (VPS + 1);
+#pragma unroll
+      for (int j = 0; j < PPT; ++j) {
+        have[j] = loc[j].inside && slot[j] >= 0;
+        // 32-bit offsets: a grid holds < 2^31 floats (4096 bricks of 17^3 = 20 M)
+        const unsigned off = (unsigned)(have[j] ? slot[j] : 0) * (unsigned)CELLS + (unsigned)loc[j].cell_off;
+        load_neighbours<VPS>(g.bricks + off, d[j]);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < PPT; ++j)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d[j][k] = 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      const int local = base + j * kBlockThreads + (int)threadIdx.x;
+      // branch-free: lanes without a correspondence carry zeros (or the miss cost) through the FMAs
+      float u[6];
+      const bool in_range = local < tile.count;
+      const bool ok = eval_point_lean(d[j], have[j], loc[j].Dx, loc[j].Dy, loc[j].Dz, g.voxel_size_inv, P,
+                                      pt[j].x, pt[j].y, pt[j].w, w[j], u) && in_range;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) u[k] = ok ? u[k] : 0.0f;
+      // RCF:165-166: w * no_correspondence_cost with zero Jacobian rows
+      u[5] = ok ? u[5] : ((count_misses && in_range) ? w[j] * nc : 0.0f);
+      accumulate21<ACC>(acc, u);
+    }
+  }
+  double accd[21];
+#pragma unroll
+  for (int k = 0; k < 21; ++k) {
+    double v = (double)acc[k];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    accd[k] = v;
+  }
+  __shared__ double lds[kBlockThreads / 64][kPartialSize];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 21; ++k) lds[wave][k] = accd[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 21) {
+    double v = ((lds[0][threadIdx.x] + lds[1][threadIdx.x]) + lds[2][threadIdx.x]) + lds[3][threadIdx.x];
+    partials[(size_t)t * kPartialSize + threadIdx.x] = v;
+  }
+}
+
+// Residuals the fused pass actually touches at these poses: the points of every chunk that
+// survives the bounding-sphere test (the rest cost no memory traffic at all).  One thread per chunk.
+__global__ void reg_count_live_kernel(const ConstraintDev* __restrict__ cons, const PosePack* __restrict__ packs,
+                                      int n_cons, unsigned long long* __restrict__ live) {
+  const int c = blockIdx.x;
+  if (c >= n_cons) return;
+  const ConstraintDev& C = cons[c];
+  const PosePack P = packs[c];
+  const long long n_chunks = (C.n + kChunkPoints - 1) / kChunkPoints;
+  unsigned long long mine = 0;
+  const bool cull = C.no_corr_cost == 0.0 && C.chunk_bounds && C.sample_raw == nullptr;
+  for (long long k = threadIdx.x; k < n_chunks; k += blockDim.x) {
+    const long long pts = (k + 1) * kChunkPoints <= C.n ? kChunkPoints : C.n - k * kChunkPoints;
+    if (!cull || !chunk_outside(C.grid, P, C.chunk_bounds[k])) mine += (unsigned long long)pts;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off, 64);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(live, mine);
 }
 
 // One workgroup per constraint: 12 groups of 21 lanes sum the constraint's tile
@@ -1275,7 +1484,39 @@ int vgx_reg_batch_evaluate_normal(vgx_reg_batch b, const double* poses, int32_t 
   double* out = d_normal ? (double*)d_normal : b->d_normal;
   const int n_tiles = (int)ex->reduce_tiles.size();
   apply_swizzle_env();
-  if (n_tiles > 0) {
+  // Fused-kernel variant (A/B switch, profiles/ab_fused2.sh): 0 = round-1 kernel (reference
+  // operation order, f64 accumulators), otherwise the lean kernel, encoded as
+  // 100 * waves_per_simd + 10 * points_per_thread + (1 = f64 accumulators, 2 = f32 accumulators)
+  static const int variant = [] {
+    const char* e = getenv("VGX_FUSED_KERNEL");
+    return e ? atoi(e) : kFusedVariantDefault;
+  }();
+  if (n_tiles > 0 && variant != 0) {
+    dim3 grid(n_tiles), block(kBlockThreads);
+    const int vps = b->regs[0]->reading->vps;
+#define VGX_LAUNCH_LEAN(VPS, PPT, ACC, W)                                                             \
+  hipLaunchKernelGGL((reg_eval_reduce_lean_kernel<VPS, PPT, ACC, W>), grid, block, 0, ctx->stream,  \
+                     b->d_desc, b->d_pack, ex->d_reduce_tiles, n_tiles, b->d_partials)
+#define VGX_LEAN_CASE(CODE, PPT, ACC, W)                                  \
+  case CODE:                                                              \
+    if (vps == 16) VGX_LAUNCH_LEAN(16, PPT, ACC, W);                      \
+    else VGX_LAUNCH_LEAN(8, PPT, ACC, W);                                 \
+    break
+    switch (variant) {
+      VGX_LEAN_CASE(421, 2, double, 4);
+      VGX_LEAN_CASE(422, 2, float, 4);
+      VGX_LEAN_CASE(522, 2, float, 5);
+      VGX_LEAN_CASE(622, 2, float, 6);
+      VGX_LEAN_CASE(612, 1, float, 6);
+      VGX_LEAN_CASE(812, 1, float, 8);
+      VGX_LEAN_CASE(511, 1, double, 5);
+      default:
+        return set_error(ctx, VGX_ERR_INVALID, "VGX_FUSED_KERNEL: unknown variant");
+    }
+#undef VGX_LEAN_CASE
+#undef VGX_LAUNCH_LEAN
+    VGX_HIP(ctx, hipGetLastError());
+  } else if (n_tiles > 0) {
     dim3 grid(((n_tiles + 7) / 8) * 8), block(kBlockThreads);
     static const bool ntl = [] {
       const char* e = getenv("VGX_NT_LOADS");
@@ -1301,6 +1542,28 @@ int vgx_reg_batch_evaluate_normal(vgx_reg_batch b, const double* poses, int32_t 
                                 hipMemcpyDeviceToHost, ctx->stream));
     VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
+  return VGX_OK;
+}
+
+int vgx_reg_batch_count_live(vgx_reg_batch b, const double* poses, int32_t n_nodes, int64_t* live_residuals) {
+  if (!b || !poses || !live_residuals) return VGX_ERR_INVALID;
+  vgx_ctx ctx = b->ctx;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  *live_residuals = 0;
+  VGX_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = batch_upload_packs(b, poses, n_nodes, nullptr);
+  if (rc != VGX_OK) return rc;
+  if (b->n == 0) return VGX_OK;
+  DeviceScratch counter;
+  VGX_HIP(ctx, counter.alloc(sizeof(unsigned long long)));
+  VGX_HIP(ctx, hipMemsetAsync(counter.p, 0, sizeof(unsigned long long), ctx->stream));
+  hipLaunchKernelGGL(reg_count_live_kernel, dim3(b->n), dim3(256), 0, ctx->stream, b->d_desc, b->d_pack, b->n,
+                     counter.as<unsigned long long>());
+  VGX_HIP(ctx, hipGetLastError());
+  unsigned long long v = 0;
+  VGX_HIP(ctx, hipMemcpyAsync(&v, counter.p, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
+  VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *live_residuals = (int64_t)v;
   return VGX_OK;
 }
 
