@@ -315,6 +315,8 @@ def main():
                     help="full-overlap workload: perturbed duplicates per submap (config 3 has ~6 "
                          "constraints per reference submap)")
     ap.add_argument("--no-full-overlap", action="store_true")
+    ap.add_argument("--no-shipped", action="store_true",
+                    help="skip the shipped-yaml evaluation (isosurface points, sampling_ratio 0.05, mirrored)")
     ap.add_argument("--grid", type=int, nargs=2, default=[20, 10], help="submap grid (200 submaps)")
     ap.add_argument("--block-dims", type=int, nargs=3, default=[16, 16, 16], help="256^3 voxels")
     ap.add_argument("--block-min", type=int, nargs=3, default=[-8, -8, -4])
@@ -391,11 +393,13 @@ def main():
 
     # ---- resident inputs: every rank holds every finished submap -------------
     t_setup = time.perf_counter()
-    submaps, n_points = [], []
+    submaps, n_points, n_iso = [], [], []
     for k in range(n_sub):
         sm = capi.Submap.synth_city(ctx, k, args.voxel_size, 16, args.block_min, args.block_dims,
                                     args.truncation, args.esdf_max, 10.0, true_poses[k], args.seed)
         n_points.append(sm.extract_voxel_points(1.0, 0.3, True))      # voxgraph_submap.h:27-28
+        if not args.no_shipped:
+            n_iso.append(sm.extract_isosurface_points(1.0))            # finishSubmap(), voxgraph_submap.cpp:97
         sm.release_raw_layers()
         submaps.append(sm)
     ctx.synchronize()
@@ -565,6 +569,53 @@ def main():
             fused_fo = fused_bench(fo["batch"], fo["poses"], len(fo["poses"]), fo["n"],
                                    fo_out["with_corr_total"], fo_out["R_total"], fo_cost)
 
+    # ---- the reference's SHIPPED configuration (voxgraph_mapper.yaml:34-35): explicit_to_implicit =
+    # isosurface points, sampling_ratio 0.05, both directions of every pair (pose_graph.cpp:62-71),
+    # ESDF distance (registration_cost_function.h:35) -- one solver evaluation = one fused batched pass;
+    # the per-point-set std::mt19937 streams are generated on the device (mt_generate_kernel)
+    shipped = None
+    if not args.no_shipped and not args.no_fused:
+        cfg_s = capi.default_config(registration_point_type=capi.POINTS_ISOSURFACE, sampling_ratio=0.05)
+        shard = lpt_shards([n_iso[a] + n_iso[b] for a, b in pairs], world)[rank]
+        pairs_s = [(int(a), int(b)) for c in shard for a, b in (pairs[c], pairs[c][::-1])]
+        gidx_s = [2 * c + k for c in shard for k in (0, 1)]
+        cfs_s = [capi.RegistrationCostFunction(ctx, submaps[a], submaps[b], cfg_s) for a, b in pairs_s]
+        batch_s = capi.RegistrationBatch(ctx, cfs_s, pairs_s, global_index=gidx_s, n_global=2 * n_con)
+        buf_s = torch.zeros(capi.fused_size(n_sub, 2 * n_con), dtype=torch.float64, device="cuda")
+
+        def shipped_step():
+            batch_s.evaluate_normal(poses, to_host=False)
+            batch_s.assemble(n_sub, buf_s.data_ptr(), zero_first=True)
+            if use_dist:
+                dist.all_reduce(buf_s)
+
+        for _ in range(2):
+            shipped_step()
+        torch.cuda.synchronize()
+        barrier()
+        n_s = max(args.steps, 1)
+        s0 = time.perf_counter()
+        for _ in range(n_s):
+            shipped_step()
+        torch.cuda.synchronize()
+        barrier()
+        sdt = torch.tensor([time.perf_counter() - s0], dtype=torch.float64, device="cuda")
+        rs = torch.tensor([float(batch_s.num_residuals())], dtype=torch.float64, device="cuda")
+        if use_dist:
+            dist.all_reduce(sdt, op=dist.ReduceOp.MAX)
+            dist.all_reduce(rs, op=dist.ReduceOp.SUM)
+        shipped = {"config": "registration_method explicit_to_implicit (isosurface points), sampling_ratio 0.05, "
+                             "mirrored constraints, ESDF distance (voxgraph_mapper.yaml:34-35, pose_graph.cpp:62-71)",
+                   "constraints": 2 * n_con, "residuals_per_evaluation": float(rs.item()),
+                   "isosurface_points_per_submap": float(np.mean(n_iso)),
+                   "ms_per_evaluation": float(sdt.item()) / n_s * 1e3,
+                   "Mresiduals_per_s": float(rs.item()) * n_s / float(sdt.item()) / 1e6,
+                   "cost": float(buf_s[0].item()),
+                   "what": "one solver evaluation: device mt19937 streams + fused normal equations of every "
+                           "constraint + assembly" + (" + RCCL all-reduce" if use_dist else "")}
+        for o in [batch_s] + cfs_s:
+            o.destroy()
+
     # ---- metric 2: full pose-graph solve (harness LM, stand-in for ceres::Solve) ---
     solve = None
     if not args.no_solve:
@@ -669,6 +720,7 @@ def main():
                          "traffic_GBs": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None,
                          "with_correspondence_frac": with_corr / max(R, 1)},
             "fused": fused,
+            "shipped_config": shipped,
             "solve": solve,
             "setup_s": setup_s,
             "residual_checksum": checksum,

@@ -1,5 +1,6 @@
 // Context, submap upload and the apron-brick re-layout kernel.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <numeric>
@@ -194,6 +195,39 @@ int build_block_lut(vgx_submap sm) {
 
 }  // namespace vgx
 
+namespace vgx {
+void reset_point_set(PointSet& ps) {
+  static std::atomic<uint64_t> next_version{1};
+  if (ps.d_xyzd) (void)hipFree(ps.d_xyzd);
+  if (ps.d_weight) (void)hipFree(ps.d_weight);
+  if (ps.d_chunk_bounds) (void)hipFree(ps.d_chunk_bounds);
+  if (ps.d_cumulative) (void)hipFree(ps.d_cumulative);
+  if (ps.d_inv_order) (void)hipFree(ps.d_inv_order);
+  if (ps.rng.d_state) (void)hipFree(ps.rng.d_state);
+  ps = PointSet();
+  // cost functions and batches built on the old points notice the change (they hold raw device
+  // pointers into the arrays freed above)
+  ps.version = next_version.fetch_add(1);
+}
+
+int engine_to_host(vgx_ctx ctx, SamplerEngine& e) {
+  if (!e.on_device) return VGX_OK;
+  VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  VGX_HIP(ctx, hipMemcpy(&e.host, e.d_state, sizeof(Mt19937), hipMemcpyDeviceToHost));
+  e.on_device = false;
+  return VGX_OK;
+}
+
+int engine_to_device(vgx_ctx ctx, SamplerEngine& e) {
+  if (e.on_device) return VGX_OK;
+  if (!e.d_state) VGX_HIP(ctx, hipMalloc(&e.d_state, sizeof(Mt19937)));
+  // pageable source: the copy has left the host buffer when the call returns
+  VGX_HIP(ctx, hipMemcpyAsync(e.d_state, &e.host, sizeof(Mt19937), hipMemcpyHostToDevice, ctx->stream));
+  e.on_device = true;
+  return VGX_OK;
+}
+}  // namespace vgx
+
 using namespace vgx;
 
 vgx::GridDev vgx_submap_s::grid_dev(int which) const {
@@ -375,14 +409,6 @@ int vgx_submap_create(vgx_ctx ctx, int32_t submap_id, float voxel_size, int32_t 
   return VGX_OK;
 }
 
-static void free_points(PointSet& ps) {
-  if (ps.d_xyzd) (void)hipFree(ps.d_xyzd);
-  if (ps.d_weight) (void)hipFree(ps.d_weight);
-  if (ps.d_chunk_bounds) (void)hipFree(ps.d_chunk_bounds);
-  if (ps.d_cumulative) (void)hipFree(ps.d_cumulative);
-  if (ps.d_inv_order) (void)hipFree(ps.d_inv_order);
-  ps = PointSet();
-}
 
 int vgx_submap_release_raw_layers(vgx_submap sm) {
   if (!sm) return VGX_ERR_INVALID;
@@ -431,7 +457,7 @@ int vgx_submap_destroy(vgx_submap sm) {
   if (sm->d_iso_block_index) (void)hipFree(sm->d_iso_block_index);
   for (int k = 0; k < 2; ++k) {
     if (sm->grid[k].d_bricks) (void)hipFree(sm->grid[k].d_bricks);
-    free_points(sm->points[k]);
+    reset_point_set(sm->points[k]);
   }
   delete sm;
   return VGX_OK;
@@ -463,9 +489,8 @@ int vgx_submap_set_points(vgx_submap sm, int32_t point_type, int64_t n, const fl
   VGX_HIP(ctx, hipSetDevice(ctx->device));
   PointSet& ps = sm->points[point_type];
   (void)hipStreamSynchronize(ctx->stream);
-  free_points(ps);
+  reset_point_set(ps);
   ps.n = n;
-  ps.present = true;
   // WeightedSampler::addItem (weighted_sampler_inl.h:5-16): cumulative weights
   // in upload order, accumulated in double
   ps.cumulative_weight.resize((size_t)n);
@@ -520,7 +545,9 @@ int vgx_submap_set_points(vgx_submap sm, int32_t point_type, int64_t n, const fl
     VGX_HIP(ctx, hipMemcpy(ps.d_xyzd, h_xyzd.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice));
     VGX_HIP(ctx, hipMemcpy(ps.d_weight, h_w.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
   }
-  return build_chunk_bounds(ctx, ps);
+  const int rc = build_chunk_bounds(ctx, ps);
+  ps.present = rc == VGX_OK;  // only a completely built set is offered to cost functions
+  return rc;
 }
 
 int64_t vgx_submap_num_points(vgx_submap sm, int32_t point_type) {

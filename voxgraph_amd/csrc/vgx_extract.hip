@@ -122,15 +122,10 @@ extern "C" int vgx_submap_extract_voxel_points(vgx_submap sm, double min_voxel_w
   VGX_HIP(ctx, hipSetDevice(ctx->device));
   PointSet& ps = sm->points[VGX_POINTS_VOXELS];
   VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (ps.d_xyzd) (void)hipFree(ps.d_xyzd);
-  if (ps.d_weight) (void)hipFree(ps.d_weight);
-  if (ps.d_chunk_bounds) (void)hipFree(ps.d_chunk_bounds);
-  if (ps.d_cumulative) (void)hipFree(ps.d_cumulative);
-  if (ps.d_inv_order) (void)hipFree(ps.d_inv_order);
-  ps = PointSet();
-  ps.present = true;
+  reset_point_set(ps);
   const int nb = sm->n_blocks;
   if (nb == 0) {
+    ps.present = true;
     if (n_points_out) *n_points_out = 0;
     return VGX_OK;
   }
@@ -195,5 +190,7 @@ extern "C" int vgx_submap_extract_voxel_points(vgx_submap sm, double min_voxel_w
   }
   if (rc == VGX_OK) rc = build_chunk_bounds(ctx, ps);
   if (rc == VGX_OK && n_points_out) *n_points_out = ps.n;
+  // the set is offered to cost functions only once every allocation and kernel has succeeded
+  if (rc == VGX_OK) ps.present = true; else reset_point_set(ps);
   return rc;
 }

@@ -111,8 +111,50 @@ struct Context {
   std::condition_variable slot_free;
 };
 
+// std::mt19937 (the engine of WeightedSampler, weighted_sampler.h:36-39) with its state in the
+// open: the standard fixes the algorithm completely (seed 5489 -> 10000th output 4123659995), so
+// this IS std::mt19937's stream, and the state can travel between the host and the device.
+struct Mt19937 {
+  static constexpr int kN = 624;
+  uint32_t mt[kN];
+  uint32_t idx = kN;  // next unread word of mt; kN = twist first (std::mt19937 after seed())
+  Mt19937() { seed(5489u); }
+  void seed(uint32_t s) {
+    mt[0] = s;
+    for (int i = 1; i < kN; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+    idx = kN;
+  }
+  void twist() {
+    for (int k = 0; k < kN; ++k) {
+      uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % kN] & 0x7fffffffu);
+      mt[k] = mt[(k + 397) % kN] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    idx = 0;
+  }
+  uint32_t operator()() {
+    if (idx >= (uint32_t)kN) twist();
+    uint32_t y = mt[idx++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+  }
+};
+static_assert(sizeof(Mt19937) == 625 * 4, "Mt19937 is copied to the device as 625 words");
+
+// A sampler engine that lives wherever it was advanced last: the drop-in Evaluate draws on the
+// host (a few thousand outputs per call), the batched passes generate whole streams on the device
+// (mt_generate_kernel).  Exactly one copy is current at any time.
+struct SamplerEngine {
+  Mt19937 host;
+  uint32_t* d_state = nullptr;  // 625 words, allocated at first device use
+  bool on_device = false;       // the device copy is the current one
+};
+
 struct PointSet {
   int64_t n = 0;
+  uint64_t version = 0;  // bumped whenever the points are replaced (cost functions remember theirs)
   float4* d_xyzd = nullptr;
   float* d_weight = nullptr;
   float4* d_chunk_bounds = nullptr;  // per kChunkPoints points: bounding sphere {cx,cy,cz,r}
@@ -126,7 +168,7 @@ struct PointSet {
   int32_t* d_inv_order = nullptr;        // device copy of inv_order (Morton-sorted sets only)
   // WeightedSampler's mutable engine (weighted_sampler.h:36-39): ONE default-seeded std::mt19937 per
   // point set, shared by every cost function that samples this set (vgx_reg_config.sampler_seed == 0)
-  std::mt19937 rng;
+  SamplerEngine rng;
 };
 
 struct Grid {
@@ -167,9 +209,9 @@ struct vgx_reg_s {
   vgx_submap reading = nullptr;
   vgx_reg_config cfg{};
   int64_t num_residuals = 0;
+  uint64_t points_version = 0;  // PointSet::version of the reference points at construction
   // sampling mode state: a private engine when cfg.sampler_seed != 0, else the point set's
-  std::mt19937 rng;
-  std::uniform_real_distribution<double> uniform{0.0, 1.0};
+  vgx::SamplerEngine rng;
   // vgx_reg_evaluate_device_f32 in sampling mode only (it does not wait for its kernel, so it
   // cannot borrow a slot): own staging for the engine outputs, allocated at first use
   uint32_t* d_sample_raw = nullptr;
@@ -177,7 +219,10 @@ struct vgx_reg_s {
   // Drop-in Evaluate calls arrive from several Ceres threads (pose_graph.cpp:96), each on its own
   // cost function; each call borrows one of the context's evaluation slots (Context::EvalSlot).
   std::mutex mu;                // two threads on the SAME cost function are serialised
-  void draw_raw(uint32_t* out); // 2 engine outputs per residual
+  int draw_raw(uint32_t* out);  // 2 engine outputs per residual, drawn on the host
+  vgx::SamplerEngine& engine(); // the stream this cost function samples from
+  bool sampling() const { return cfg.sampling_ratio != -1.0f; }
+  bool points_current() const;  // the reference submap still holds the points this was built on
   vgx::ConstraintDev describe() const;
 };
 
@@ -207,6 +252,18 @@ struct vgx_reg_batch_s {
   int32_t csr_nodes = 0;
   int32_t* d_node_first = nullptr;
   int32_t* d_node_items = nullptr;
+  // sampling constraints (sampling_ratio != -1): one stream job per distinct engine, in order of
+  // first appearance; the engine's constraints consume consecutive ranges of its stream in
+  // constraint order, as successive Evaluate calls on one thread would (RCF:113-122)
+  struct StreamJob {
+    vgx::SamplerEngine* engine;
+    int64_t offset;   // first word in d_raw
+    int64_t count;    // words generated per evaluation
+  };
+  std::vector<StreamJob> stream_jobs;
+  uint32_t* d_raw = nullptr;       // all engine outputs of one evaluation
+  void* d_stream_jobs = nullptr;   // device copy of {state*, out*, count} per job
+  bool any_sampling = false;
 };
 
 // ---------------------------------------------------------------------------
@@ -244,6 +301,11 @@ void set_global_error(const std::string& msg);
 int launch_brickify(vgx_submap sm, int which);
 int build_block_lut(vgx_submap sm);
 int build_chunk_bounds(vgx_ctx ctx, PointSet& ps);
+// frees a point set's device arrays and leaves it empty (present = false) with a new version
+void reset_point_set(PointSet& ps);
+// sampler engines: make the host / the device copy the current one (ctx->mu held)
+int engine_to_host(vgx_ctx ctx, SamplerEngine& e);
+int engine_to_device(vgx_ctx ctx, SamplerEngine& e);
 void make_pose_pack(const double ref_pose[4], const double read_pose[4], PosePack* out);
 std::vector<Tile> make_tiles(int32_t constraint, int64_t n, int tile_points);
 constexpr int kBlockThreads = 256;

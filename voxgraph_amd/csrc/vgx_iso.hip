@@ -323,13 +323,7 @@ extern "C" int vgx_submap_extract_isosurface_points(vgx_submap sm, double min_vo
   VGX_HIP(ctx, hipSetDevice(ctx->device));
   VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   PointSet& ps = sm->points[VGX_POINTS_ISOSURFACE];
-  if (ps.d_xyzd) (void)hipFree(ps.d_xyzd);
-  if (ps.d_weight) (void)hipFree(ps.d_weight);
-  if (ps.d_chunk_bounds) (void)hipFree(ps.d_chunk_bounds);
-  if (ps.d_cumulative) (void)hipFree(ps.d_cumulative);
-  if (ps.d_inv_order) (void)hipFree(ps.d_inv_order);
-  ps = PointSet();
-  ps.present = true;
+  reset_point_set(ps);
   sm->isosurface_blocks.clear();
   if (sm->d_iso_block_index) {
     (void)hipFree(sm->d_iso_block_index);
@@ -337,7 +331,10 @@ extern "C" int vgx_submap_extract_isosurface_points(vgx_submap sm, double min_vo
   }
   if (n_points_out) *n_points_out = 0;
   const int nb = sm->n_blocks;
-  if (nb == 0) return VGX_OK;
+  if (nb == 0) {
+    ps.present = true;
+    return VGX_OK;
+  }
 
   IsoParams p{};
   p.block_index = sm->d_block_index;
@@ -445,5 +442,7 @@ extern "C" int vgx_submap_extract_isosurface_points(vgx_submap sm, double min_vo
       rc = set_error(ctx, VGX_ERR_NOMEM, "vgx_submap_extract_isosurface_points: block list upload failed");
   }
   if (rc == VGX_OK && n_points_out) *n_points_out = ps.n;
+  // the set is offered to cost functions only once every allocation and kernel has succeeded
+  if (rc == VGX_OK) ps.present = true; else reset_point_set(ps);
   return rc;
 }

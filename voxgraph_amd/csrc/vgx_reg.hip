@@ -686,7 +686,10 @@ __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_ker
   const PosePack P = packs[tile.constraint];
   const GridDev g = C.grid;
   const bool count_misses = C.no_corr_cost != 0.0;
-  const float4* bounds = (!count_misses && C.chunk_bounds) ? C.chunk_bounds : nullptr;
+  // sampling mode (RCF:113-122): residual i uses the point its weighted draw selects, with weight
+  // 1; draws are scattered over the whole set, so there is nothing to cull
+  const bool sampled = C.sample_raw != nullptr;
+  const float4* bounds = (!count_misses && !sampled && C.chunk_bounds) ? C.chunk_bounds : nullptr;
   const long long chunk0 = tile.start / kChunkPoints;  // tiles start on chunk boundaries
   __shared__ unsigned char s_live[kMaxReduceIters * 2];
   const int n_chunks = (tile.count + kChunkPoints - 1) / kChunkPoints;
@@ -707,8 +710,13 @@ __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_ker
     for (int j = 0; j < PPT; ++j) {
       int local = j * kBlockThreads + (int)threadIdx.x;
       int64_t i = tile.start + (local < tile.count ? local : 0);
-      pt_next[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[i];
-      w_next[j] = as_global(C.weight)[i];
+      if (sampled) {
+        pt_next[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[weighted_draw(C, i)];
+        w_next[j] = 1.0f;  // RCF:121
+      } else {
+        pt_next[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[i];
+        w_next[j] = as_global(C.weight)[i];
+      }
     }
   }
   for (int base = 0; base < tile.count; base += kIterPoints) {
@@ -728,8 +736,13 @@ __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_ker
         for (int j = 0; j < PPT; ++j) {
           int local = base + kIterPoints + j * kBlockThreads + (int)threadIdx.x;
           int64_t i = tile.start + (local < tile.count ? local : 0);
-          pt_next[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[i];
-          w_next[j] = as_global(C.weight)[i];
+          if (sampled) {
+            pt_next[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[weighted_draw(C, i)];
+            w_next[j] = 1.0f;
+          } else {
+            pt_next[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[i];
+            w_next[j] = as_global(C.weight)[i];
+          }
         }
       }
     }
@@ -794,6 +807,73 @@ __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_ker
     double v = ((lds[0][threadIdx.x] + lds[1][threadIdx.x]) + lds[2][threadIdx.x]) + lds[3][threadIdx.x];
     partials[(size_t)t * kPartialSize + threadIdx.x] = v;
   }
+}
+
+// ---------------------------------------------------------------------------
+// std::mt19937 streams on the device (sampling mode of the batched passes)
+// ---------------------------------------------------------------------------
+// One workgroup per engine: the 624-word state sits in LDS, each "twist" (the only sequential
+// part of the generator) runs as three data-parallel phases -- mt[k] depends on the OLD mt[k],
+// mt[k+1] and on mt[(k+397) % 624], which is old for k < 227 and already renewed afterwards, so
+// [0,227), [227,454), [454,623) and the last word can each be computed in one step -- and the
+// tempered outputs are written 256 at a time.  Bit for bit the stream Mt19937::operator() (and
+// std::mt19937) produces; the state is left where the host engine can pick it up again.
+struct StreamJobDev {
+  uint32_t* state;  // Mt19937: 624 words + index
+  uint32_t* out;
+  long long count;
+};
+
+__device__ __forceinline__ uint32_t mt_twist_word(uint32_t cur, uint32_t next, uint32_t far) {
+  const uint32_t y = (cur & 0x80000000u) | (next & 0x7fffffffu);
+  return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+
+__global__ __launch_bounds__(256) void mt_generate_kernel(const StreamJobDev* __restrict__ jobs) {
+  constexpr int N = Mt19937::kN, M = 397;
+  const StreamJobDev job = jobs[blockIdx.x];
+  __shared__ uint32_t mt[N];
+  const int tid = threadIdx.x;
+  for (int k = tid; k < N; k += 256) mt[k] = job.state[k];
+  uint32_t idx = job.state[N];  // uniform
+  __syncthreads();
+  long long produced = 0;
+  while (produced < job.count) {
+    if (idx >= (uint32_t)N) {
+      uint32_t nv = 0;
+      if (tid < N - M) nv = mt_twist_word(mt[tid], mt[tid + 1], mt[tid + M]);
+      __syncthreads();
+      if (tid < N - M) mt[tid] = nv;
+      __syncthreads();
+      if (tid < N - M) nv = mt_twist_word(mt[N - M + tid], mt[N - M + tid + 1], mt[tid]);
+      __syncthreads();
+      if (tid < N - M) mt[N - M + tid] = nv;
+      __syncthreads();
+      constexpr int C0 = 2 * (N - M);  // 454
+      if (tid < N - 1 - C0) nv = mt_twist_word(mt[C0 + tid], mt[C0 + tid + 1], mt[C0 + tid - (N - M)]);
+      __syncthreads();
+      if (tid < N - 1 - C0) mt[C0 + tid] = nv;
+      __syncthreads();
+      if (tid == 0) mt[N - 1] = mt_twist_word(mt[N - 1], mt[0], mt[M - 1]);
+      __syncthreads();
+      idx = 0;
+    }
+    const long long left = job.count - produced;
+    const int take = (int)(left < (long long)(N - idx) ? left : (long long)(N - idx));
+    for (int t = tid; t < take; t += 256) {
+      uint32_t y = mt[idx + t];
+      y ^= y >> 11;
+      y ^= (y << 7) & 0x9d2c5680u;
+      y ^= (y << 15) & 0xefc60000u;
+      y ^= y >> 18;
+      job.out[produced + t] = y;
+    }
+    idx += (uint32_t)take;
+    produced += take;
+  }
+  __syncthreads();
+  for (int k = tid; k < N; k += 256) job.state[k] = mt[k];
+  if (tid == 0) job.state[N] = idx;
 }
 
 // Residuals the fused pass actually touches at these poses: the points of every chunk that
@@ -1037,11 +1117,22 @@ vgx::ConstraintDev vgx_reg_s::describe() const {
 // advances the same stream), unless the caller asked for a private, separately seeded one.  Only
 // the cheap sequential part stays on the host (~2 ns per output); the draw itself -- canonical
 // double, scaling, binary search over the cumulative weights -- runs in the kernel.
-void vgx_reg_s::draw_raw(uint32_t* out) {
-  PointSet& ps = reference->points[cfg.registration_point_type];
-  std::mt19937& engine = cfg.sampler_seed != 0u ? rng : ps.rng;
+vgx::SamplerEngine& vgx_reg_s::engine() {
+  return cfg.sampler_seed != 0u ? rng : reference->points[cfg.registration_point_type].rng;
+}
+
+bool vgx_reg_s::points_current() const {
+  const PointSet& ps = reference->points[cfg.registration_point_type];
+  return ps.present && ps.version == points_version;
+}
+
+int vgx_reg_s::draw_raw(uint32_t* out) {
+  SamplerEngine& e = engine();
+  int rc = engine_to_host(ctx, e);  // a batched pass may have advanced the stream on the device
+  if (rc != VGX_OK) return rc;
   const int64_t m = 2 * num_residuals;
-  for (int64_t k = 0; k < m; ++k) out[k] = (uint32_t)engine();
+  for (int64_t k = 0; k < m; ++k) out[k] = e.host();
+  return VGX_OK;
 }
 
 extern "C" {
@@ -1085,6 +1176,7 @@ int vgx_reg_create(vgx_ctx ctx, vgx_submap reference, vgx_submap reading, const 
   r->reference = reference;
   r->reading = reading;
   r->cfg = *cfg;
+  r->points_version = ps.version;
   // RCF:45-55
   if (cfg->sampling_ratio != -1.0f) {
     r->num_residuals = (int64_t)(int)(cfg->sampling_ratio * (float)ps.n);
@@ -1092,7 +1184,7 @@ int vgx_reg_create(vgx_ctx ctx, vgx_submap reference, vgx_submap reading, const 
   } else {
     r->num_residuals = ps.n;
   }
-  if (cfg->sampler_seed != 0u) r->rng.seed(cfg->sampler_seed);
+  if (cfg->sampler_seed != 0u) r->rng.host.seed(cfg->sampler_seed);
   if (cfg->sampling_ratio != -1.0f && (int64_t)ps.cumulative_weight.size() != ps.n) {
     // points extracted on the device: build WeightedSampler's cumulative weights
     // (weighted_sampler_inl.h:5-16) from the device copy, in extraction order
@@ -1142,6 +1234,7 @@ int vgx_reg_destroy(vgx_reg r) {
   (void)hipStreamSynchronize(r->ctx->stream);
   if (r->d_sample_raw) (void)hipFree(r->d_sample_raw);
   if (r->h_sample_raw) (void)hipHostFree(r->h_sample_raw);
+  if (r->rng.d_state) (void)hipFree(r->rng.d_state);
   delete r;
   return VGX_OK;
 }
@@ -1191,6 +1284,10 @@ int vgx_reg_evaluate(vgx_reg r, const double ref_pose[4], const double read_pose
   SlotLease lease{ctx, -1};
   std::unique_lock<std::mutex> lk(ctx->mu);  // launch under the context lock ...
   if (!residuals) return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_evaluate: residuals == NULL");
+  if (!r->points_current())
+    return set_error(ctx, VGX_ERR_INVALID,
+                     "vgx_reg_evaluate: the reference submap's registration points were replaced after "
+                     "this cost function was created");
   if (n == 0) return reg_status(r);
   const int k = acquire_slot(ctx, lk);
   lease.k = k;
@@ -1230,7 +1327,8 @@ int vgx_reg_evaluate(vgx_reg r, const double ref_pose[4], const double read_pose
   ConstraintDev desc = r->describe();
   if (sampled) {
     // this Evaluate's engine outputs (drawn under the lock: the engine is shared)
-    r->draw_raw(sl.h_raw);
+    const int rc_draw = r->draw_raw(sl.h_raw);
+    if (rc_draw != VGX_OK) return rc_draw;
     VGX_HIP(ctx, hipMemcpyAsync(sl.d_raw, sl.h_raw, (size_t)n * 2 * sizeof(uint32_t), hipMemcpyHostToDevice,
                                 sl.stream));
     desc.sample_raw = sl.d_raw;
@@ -1274,6 +1372,10 @@ int vgx_reg_evaluate_device_f32(vgx_reg r, const double ref_pose[4], const doubl
   vgx_ctx ctx = r->ctx;
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (!d_residuals) return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_evaluate_device_f32: residuals == NULL");
+  if (!r->points_current())
+    return set_error(ctx, VGX_ERR_INVALID,
+                     "vgx_reg_evaluate_device_f32: the reference submap's registration points were replaced "
+                     "after this cost function was created");
   // this entry point does not wait for its kernel: in sampling mode the previous call's upload of
   // the engine outputs must have left the pinned staging buffer before it is refilled
   VGX_HIP(ctx, hipSetDevice(ctx->device));
@@ -1284,7 +1386,8 @@ int vgx_reg_evaluate_device_f32(vgx_reg r, const double ref_pose[4], const doubl
       VGX_HIP(ctx, hipMalloc(&r->d_sample_raw, (size_t)n * 2 * sizeof(uint32_t)));
       VGX_HIP(ctx, hipHostMalloc((void**)&r->h_sample_raw, (size_t)n * 2 * sizeof(uint32_t), hipHostMallocDefault));
     }
-    r->draw_raw(r->h_sample_raw);
+    const int rc_draw = r->draw_raw(r->h_sample_raw);
+    if (rc_draw != VGX_OK) return rc_draw;
     VGX_HIP(ctx, hipMemcpyAsync(r->d_sample_raw, r->h_sample_raw, (size_t)n * 2 * sizeof(uint32_t),
                                 hipMemcpyHostToDevice, ctx->stream));
   }
@@ -1314,10 +1417,10 @@ int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs, const int3
   for (int c = 0; c < n; ++c) {
     if (!regs[c] || regs[c]->ctx != ctx)
       return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_batch_create: NULL or foreign constraint");
-    if (regs[c]->cfg.sampling_ratio != -1.0f)
-      return set_error(ctx, VGX_ERR_UNSUPPORTED,
-                       "vgx_reg_batch_create: sampling constraints are evaluated one by one "
-                       "(vgx_reg_evaluate); the batch is the deterministic all-points mode");
+    if (!regs[c]->points_current())
+      return set_error(ctx, VGX_ERR_INVALID,
+                       "vgx_reg_batch_create: a reference submap's registration points were replaced after "
+                       "its cost function was created");
     if (node_pair[2 * c] < 0 || node_pair[2 * c + 1] < 0)
       return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_batch_create: negative node index");
     if (global_index && (global_index[c] < 0 || global_index[c] >= n_global))
@@ -1358,6 +1461,54 @@ int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs, const int3
     max_node = std::max(max_node, std::max(node_pair[2 * c], node_pair[2 * c + 1]));
   }
   tile_first[(size_t)n] = (int32_t)ex->reduce_tiles.size();
+  // Sampling constraints: group by engine (order of first appearance).  One evaluation of the
+  // batch is one Evaluate of every constraint in list order, so the constraints of an engine
+  // consume consecutive ranges of its stream, 2 words per residual (RCF:113-122).
+  {
+    std::vector<int> job_of((size_t)n, -1);
+    for (int c = 0; c < n; ++c) {
+      if (!regs[c]->sampling() || regs[c]->num_residuals == 0) continue;
+      SamplerEngine* e = &regs[c]->engine();
+      int j = 0;
+      while (j < (int)b->stream_jobs.size() && b->stream_jobs[(size_t)j].engine != e) ++j;
+      if (j == (int)b->stream_jobs.size()) b->stream_jobs.push_back({e, 0, 0});
+      job_of[(size_t)c] = j;
+      b->stream_jobs[(size_t)j].count += 2 * regs[c]->num_residuals;
+    }
+    int64_t total = 0;
+    for (auto& j : b->stream_jobs) {
+      j.offset = total;
+      total += j.count;
+    }
+    b->any_sampling = total > 0;
+    if (b->any_sampling) {
+      if (hipMalloc(&b->d_raw, (size_t)total * sizeof(uint32_t)) != hipSuccess) {
+        vgx_reg_batch_destroy(b);
+        return set_error(ctx, VGX_ERR_NOMEM, "vgx_reg_batch_create: sampler stream buffer allocation failed");
+      }
+      std::vector<int64_t> used(b->stream_jobs.size(), 0);
+      for (int c = 0; c < n; ++c) {
+        const int j = job_of[(size_t)c];
+        if (j < 0) continue;
+        desc[(size_t)c].sample_raw = b->d_raw + b->stream_jobs[(size_t)j].offset + used[(size_t)j];
+        used[(size_t)j] += 2 * regs[c]->num_residuals;
+      }
+      std::vector<StreamJobDev> jd(b->stream_jobs.size());
+      for (size_t j = 0; j < jd.size(); ++j) {
+        SamplerEngine* e = b->stream_jobs[j].engine;
+        if (!e->d_state && hipMalloc(&e->d_state, sizeof(Mt19937)) != hipSuccess) {
+          vgx_reg_batch_destroy(b);
+          return set_error(ctx, VGX_ERR_NOMEM, "vgx_reg_batch_create: sampler state allocation failed");
+        }
+        jd[j] = {e->d_state, b->d_raw + b->stream_jobs[j].offset, (long long)b->stream_jobs[j].count};
+      }
+      if (hipMalloc(&b->d_stream_jobs, jd.size() * sizeof(StreamJobDev)) != hipSuccess ||
+          hipMemcpy(b->d_stream_jobs, jd.data(), jd.size() * sizeof(StreamJobDev), hipMemcpyHostToDevice) != hipSuccess) {
+        vgx_reg_batch_destroy(b);
+        return set_error(ctx, VGX_ERR_NOMEM, "vgx_reg_batch_create: sampler job table upload failed");
+      }
+    }
+  }
   // CSR: node -> (constraint << 1 | side)
   ex->csr_nodes = max_node + 1;
   std::vector<int32_t> first((size_t)ex->csr_nodes + 1, 0), items(2 * (size_t)n);
@@ -1405,6 +1556,8 @@ int vgx_reg_batch_destroy(vgx_reg_batch b) {
   if (!b) return VGX_ERR_INVALID;
   (void)hipSetDevice(b->ctx->device);
   (void)hipStreamSynchronize(b->ctx->stream);
+  if (b->d_raw) (void)hipFree(b->d_raw);
+  if (b->d_stream_jobs) (void)hipFree(b->d_stream_jobs);
   if (b->d_node_first) (void)hipFree(b->d_node_first);
   if (b->d_node_items) (void)hipFree(b->d_node_items);
   if (b->d_reduce_tiles) (void)hipFree(b->d_reduce_tiles);
@@ -1428,6 +1581,26 @@ int64_t vgx_reg_batch_num_residuals(vgx_reg_batch b) { return b ? b->row_offset.
 int vgx_reg_batch_row_offsets(vgx_reg_batch b, int64_t* row_offset) {
   if (!b || !row_offset) return VGX_ERR_INVALID;
   std::copy(b->row_offset.begin(), b->row_offset.end(), row_offset);
+  return VGX_OK;
+}
+
+// Start of one batched evaluation: the registration points every constraint was built on must still
+// be there, and in sampling mode this evaluation's engine outputs are generated on the device.
+static int batch_begin(vgx_reg_batch b) {
+  vgx_ctx ctx = b->ctx;
+  for (vgx_reg r : b->regs)
+    if (!r->points_current())
+      return set_error(ctx, VGX_ERR_INVALID,
+                       "vgx_reg_batch: a reference submap's registration points were replaced after the "
+                       "batch was created");
+  if (!b->any_sampling) return VGX_OK;
+  for (auto& j : b->stream_jobs) {
+    int rc = engine_to_device(ctx, *j.engine);
+    if (rc != VGX_OK) return rc;
+  }
+  hipLaunchKernelGGL(mt_generate_kernel, dim3((unsigned)b->stream_jobs.size()), dim3(256), 0, ctx->stream,
+                     (const StreamJobDev*)b->d_stream_jobs);
+  VGX_HIP(ctx, hipGetLastError());
   return VGX_OK;
 }
 
@@ -1462,7 +1635,8 @@ int vgx_reg_batch_evaluate_points(vgx_reg_batch b, const double* poses, int32_t 
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (!d_residuals) return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_batch_evaluate_points: residuals == NULL");
   VGX_HIP(ctx, hipSetDevice(ctx->device));
-  int rc = batch_upload_packs(b, poses, n_nodes, status);
+  int rc = batch_begin(b);
+  if (rc == VGX_OK) rc = batch_upload_packs(b, poses, n_nodes, status);
   if (rc != VGX_OK) return rc;
   if (b->n == 0) return VGX_OK;
   launch_points<float>(ctx, b->regs[0]->reading->vps, b->d_desc, b->d_pack, b->d_tiles,
@@ -1478,7 +1652,8 @@ int vgx_reg_batch_evaluate_normal(vgx_reg_batch b, const double* poses, int32_t 
   std::lock_guard<std::mutex> lk(ctx->mu);
   vgx_reg_batch ex = b;
   VGX_HIP(ctx, hipSetDevice(ctx->device));
-  int rc = batch_upload_packs(b, poses, n_nodes, status);
+  int rc = batch_begin(b);
+  if (rc == VGX_OK) rc = batch_upload_packs(b, poses, n_nodes, status);
   if (rc != VGX_OK) return rc;
   if (b->n == 0) return VGX_OK;
   double* out = d_normal ? (double*)d_normal : b->d_normal;
@@ -1491,6 +1666,8 @@ int vgx_reg_batch_evaluate_normal(vgx_reg_batch b, const double* poses, int32_t 
     const char* e = getenv("VGX_FUSED_KERNEL");
     return e ? atoi(e) : kFusedVariantDefault;
   }();
+  if (n_tiles > 0 && variant == 0 && b->any_sampling)
+    return set_error(ctx, VGX_ERR_UNSUPPORTED, "VGX_FUSED_KERNEL=0 (the round-1 kernel) has no sampling mode");
   if (n_tiles > 0 && variant != 0) {
     dim3 grid(n_tiles), block(kBlockThreads);
     const int vps = b->regs[0]->reading->vps;
