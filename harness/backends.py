@@ -12,13 +12,23 @@ class GpuBackend:
         self.buf = torch.zeros(capi.fused_size(n_nodes, batch.n_global), dtype=torch.float64,
                                device="cuda")
         self.host = torch.zeros_like(self.buf, device="cpu").pin_memory()
+        # the zero-fill above ran on torch's stream; the library writes the buffer on ITS stream
+        torch.cuda.current_stream().synchronize()
+
+    def _library_stream_is_torchs(self):
+        return self.ctx.get_stream() == self.torch.cuda.current_stream().cuda_stream
 
     def __call__(self, poses):
         self.batch.evaluate_normal(poses, to_host=False)
         self.batch.assemble(self.n_nodes, self.buf.data_ptr(), zero_first=True)
         if self.dist is not None and self.dist.is_initialized():
+            # the all-reduce is ordered after torch's current stream; the assembly ran on the
+            # library's stream.  Same stream (ctx.set_stream(torch's), as bench.py does): stream
+            # order suffices.  Otherwise the buffer must be complete before RCCL reads it.
+            if not self._library_stream_is_torchs():
+                self.ctx.synchronize()
             self.dist.all_reduce(self.buf)
-        # the library may run on its own stream: order the copy after its kernels
+        # order the copy after the library's kernels (no-op wait when everything is drained)
         self.ctx.synchronize()
         self.host.copy_(self.buf, non_blocking=True)
         self.torch.cuda.current_stream().synchronize()

@@ -218,6 +218,10 @@ class Context:
     def set_stream(self, stream_ptr):
         self.check(self.lib.vgx_ctx_set_stream(self.h, vp(stream_ptr)))
 
+    def get_stream(self):
+        """the hipStream_t (as an int) the library launches on"""
+        return int(self.lib.vgx_ctx_get_stream(self.h) or 0)
+
     def synchronize(self):
         self.check(self.lib.vgx_ctx_synchronize(self.h))
 
