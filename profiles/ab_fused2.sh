@@ -1,6 +1,6 @@
 #!/bin/bash
 # Interleaved A/B of the fused-kernel variants (VGX_FUSED_KERNEL, see vgx_reg.hip) and of the
-# -fno-slp-vectorize build of the library (make SUFFIX=_noslp EXTRA=-fno-slp-vectorize), on one box:
+# -fslp-vectorize build of the library (make SUFFIX=_slp EXTRA=-fslp-vectorize), on one box:
 #   gpurun -- 'bash profiles/ab_fused2.sh'
 # Prints one line per (library, variant): fused ms per solver evaluation on config 3 and on the
 # full-overlap workload, its agreement with the materialised sums, and the materialising kernel's
@@ -16,7 +16,7 @@ print("fused %.3f ms (stream %.3f, rel.err %.1e) | fused full-overlap %.3f ms (r
  f["ms_per_step"],f["stream_ms_per_step"],f["cost_vs_materialised"],fo["fused"]["ms_per_step"],fo["fused"]["cost_vs_materialised"],
  d["roofline"]["kernel_ms"],fo["kernel_ms"]))'
 for round in 1 2; do
-  for lib in libvoxgraph_amd.so libvoxgraph_amd_noslp.so; do
+  for lib in libvoxgraph_amd.so libvoxgraph_amd_slp.so; do
     [ -f $REPO/voxgraph_amd/lib/$lib ] || continue
     for v in ${VARIANTS:-0 421 422 522 622 612 812}; do
       printf "round %s %-26s VGX_FUSED_KERNEL=%-4s " $round $lib $v

@@ -55,12 +55,12 @@ def test_invalid_arguments_are_status_codes(capi, ctx):
     with pytest.raises(capi.VgxError):
         capi.RegistrationCostFunction(ctx, g, only_esdf, capi.default_config(
             registration_point_type=capi.POINTS_VOXELS, use_esdf_distance=0))
-    # sampling constraints are not batchable; node indices are checked
+    # sampling constraints batch too (tests/test_batch_sampling_gpu.py); node indices are checked
     cf_s = capi.RegistrationCostFunction(ctx, g, g, capi.default_config(
         registration_point_type=capi.POINTS_VOXELS, sampling_ratio=0.1))
-    with pytest.raises(capi.VgxError) as e:
-        capi.RegistrationBatch(ctx, [cf_s], [(0, 1)])
-    assert e.value.code == capi.ERR_UNSUPPORTED
+    bs = capi.RegistrationBatch(ctx, [cf_s], [(0, 1)])
+    assert bs.num_residuals() == cf_s.num_residuals() > 0
+    bs.destroy()
     cf = capi.RegistrationCostFunction(ctx, g, g, cfg)
     batch = capi.RegistrationBatch(ctx, [cf], [(0, 3)])
     with pytest.raises(capi.VgxError):

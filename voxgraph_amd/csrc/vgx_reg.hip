@@ -457,7 +457,11 @@ constexpr int kReduceWavesPerSimd = 4;
 // that 4 waves/SIMD cannot hide (SQ counters, profiles/README.md "Fused kernel"):
 // fused multiply-adds for the 21 f64 accumulations took 2.23 -> 2.11 ms; a branch-free variant
 // (masked lanes carried through the FMAs) needed 144 VGPRs: 2.43 ms at 3 waves/SIMD, 2.94 ms spilling at 4.
-constexpr int kFusedVariantDefault = 422;  // lean kernel: 4 waves/SIMD, 2 points/thread, f32 accumulators
+constexpr int kFusedVariantDefault = 622;  // lean kernel: 6 waves/SIMD (80 VGPRs), 2 points/thread, f32 accumulators
+#ifndef VGX_BALLOT_SKIP
+#define VGX_BALLOT_SKIP 1
+#endif
+constexpr bool kBallotSkip = VGX_BALLOT_SKIP != 0;
 constexpr int kReducePointsPerThread = 2;  // measured: 3.72 / 3.29 / 3.41 ms per fused step at 4 / 2 / 1 (profiles/tune_fused.sh)
 
 // True when no point inside the sphere (centre in the reference frame) can have a
@@ -760,9 +764,17 @@ __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_ker
 #pragma unroll
       for (int j = 0; j < PPT; ++j) slot[j] = as_global(g.lut)[loc[j].lut_index];
       constexpr int CELLS = (VPS + 1) * (VPS + 1) * (VPS + 1);
+      bool any = false;
 #pragma unroll
       for (int j = 0; j < PPT; ++j) {
         have[j] = loc[j].inside && slot[j] >= 0;
+        any |= have[j];
+      }
+      // a wavefront none of whose points found a reading block (the part of a live chunk that
+      // sticks out of the reading grid) has nothing to gather or accumulate
+      if (kBallotSkip && !count_misses && __builtin_amdgcn_ballot_w64(any) == 0ull) continue;
+#pragma unroll
+      for (int j = 0; j < PPT; ++j) {
         // 32-bit offsets: a grid holds < 2^31 floats (4096 bricks of 17^3 = 20 M)
         const unsigned off = (unsigned)(have[j] ? slot[j] : 0) * (unsigned)CELLS + (unsigned)loc[j].cell_off;
         load_neighbours<VPS>(g.bricks + off, d[j]);
