@@ -78,15 +78,11 @@ def build_graph(args):
 
 
 def lpt_shards(weights, n):
-    """Greedy longest-processing-time partition of constraints onto n ranks."""
-    order = np.argsort(-np.asarray(weights), kind="stable")
-    load = np.zeros(n)
-    shard = [[] for _ in range(n)]
-    for c in order:
-        r = int(np.argmin(load))
-        shard[r].append(int(c))
-        load[r] += weights[c]
-    return [sorted(s) for s in shard]
+    """Greedy longest-processing-time partition of constraints onto n ranks: the library's own
+    placement (vgx_lpt_shards), the one the in-process multi-GPU component uses."""
+    from voxgraph_amd import capi
+    shard_of = capi.lpt_shards(weights, n)
+    return [[int(c) for c in np.nonzero(shard_of == r)[0]] for r in range(n)]
 
 
 def cpu_baseline(capi, ctx, args, true_poses, poses, pairs, seconds):

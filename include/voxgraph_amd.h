@@ -43,6 +43,7 @@ typedef struct vgx_ctx_s* vgx_ctx;
 typedef struct vgx_submap_s* vgx_submap;
 typedef struct vgx_reg_s* vgx_reg;
 typedef struct vgx_reg_batch_s* vgx_reg_batch;
+typedef struct vgx_reg_multi_s* vgx_reg_multi;
 
 /* ---- context ----------------------------------------------------------- */
 /* One context per process per GPU (one process per GPU is the multi-GPU
@@ -310,6 +311,34 @@ VGX_API int64_t vgx_reg_fused_size(int32_t n_nodes, int32_t n_global);
  * (registration_constraint.cpp:10, constraint.h:34).  Pure host arithmetic. */
 VGX_API int vgx_reg_compress_normal(const double normal[45], double residuals9[9],
                                     double jacobian9x8[72]);
+
+/* ---- REG on several GPUs of one process --------------------------------- */
+/* voxgraph is one process (voxgraph_mapping_node.cpp:6-26); given the poses its registration
+ * constraints are independent, so the list is pair-sharded over N contexts -- one per
+ * GPU, every finished submap uploaded to each -- and each solver evaluation ends in ONE reduction.
+ *
+ * vgx_lpt_shards: greedy longest-processing-time partition; weight[c] = the constraint's residual
+ * count (keep both directions of a mirrored pair together by giving them one entry).  Create each
+ * constraint's cost function on the context of its shard, then hand the whole list over:
+ * vgx_reg_multi_create sorts the constraints by owning context, builds one vgx_reg_batch per
+ * context and starts one host thread per context.  Contexts may share a device (testing). */
+VGX_API int vgx_lpt_shards(int32_t n, const int64_t* weight, int32_t n_shards, int32_t* shard_of /* [n] */);
+VGX_API int vgx_reg_multi_create(int32_t n_ctx, const vgx_ctx* ctxs, int32_t n, const vgx_reg* regs,
+                                 const int32_t* node_pair /* [n][2] */, vgx_reg_multi* out);
+VGX_API int vgx_reg_multi_destroy(vgx_reg_multi multi);
+VGX_API int32_t vgx_reg_multi_num_shards(vgx_reg_multi multi);
+VGX_API int vgx_reg_multi_shard_of(vgx_reg_multi multi, int32_t* shard_of /* [n] */);
+/* One solver evaluation: every context runs vgx_reg_batch_evaluate_normal + vgx_reg_batch_assemble on
+ * its share concurrently (own thread, own stream); context 0 then sums the per-context buffers in
+ * context order, reading the other GPUs' buffers through xGMI peer mappings, and returns the fused
+ * buffer of vgx_reg_batch_assemble's layout (vgx_reg_fused_size(n_nodes, n) doubles) to the host.
+ * Fixed-order sum of deterministic partial buffers: bitwise reproducible.  status: [n], nullable. */
+VGX_API int vgx_reg_multi_evaluate_fused(vgx_reg_multi multi, const double* poses, int32_t n_nodes,
+                                         double* fused_host, int32_t* status);
+/* The same pass for solvers that want residual blocks (Ceres through vgx_reg_compress_normal): the
+ * [n][45] normal blocks in the caller's constraint order; needs no reduction at all. */
+VGX_API int vgx_reg_multi_evaluate_normal(vgx_reg_multi multi, const double* poses, int32_t n_nodes,
+                                          double* normal_host /* [n][45] */, int32_t* status);
 
 /* ---- overlap detection (callers' side of REG) -------------------------- */
 /* VoxgraphSubmap::getSubmapFrameSurfaceObb (voxgraph_submap.cpp:280-321): box around the

@@ -8,6 +8,7 @@
 
 #include "gpu_fast_tsdf_integrator.h"
 #include "gpu_registration_batch.h"
+#include "gpu_registration_batch_multi.h"
 #include "gpu_registration_cost_function.h"
 
 static int fail(const char* what) {
@@ -133,6 +134,56 @@ int main() {
     if (std::fabs(c2 - cost_c) < 1e-9 * cost_c) return fail("re-evaluation");
     read_pose[0] -= 0.05;
     std::printf("batched Ceres path ok: cost %.6f == %.6f\n", cost_c, cost_full);
+    // ---- the same two constraints sharded over two contexts (one device here; one per GPU
+    // in production): identical 9-residual blocks, and the fused buffer of the in-process sum
+    {
+      vgx_ctx ctx_b = nullptr;
+      if (vgx_ctx_create(0, &ctx_b) != VGX_OK) return fail("second context");
+      vgx_submap sm_b = nullptr;
+      if (vgx_submap_create(ctx_b, 0, vs, vps, nb, block_index.data(), tsdf.data(), w.data(), esdf.data(),
+                            obs.data(), &sm_b) != VGX_OK ||
+          vgx_submap_set_points(sm_b, VGX_POINTS_ISOSURFACE, N, xyz.data(), dist.data(), wt.data(),
+                                VGX_POINTS_KEEP_ORDER) != VGX_OK)
+        return fail(vgx_last_error(ctx_b));
+      voxgraph_amd::GpuRegistrationCostFunction cost_b(ctx_b, sm_b, sm_b, config);
+      std::vector<vgx_ctx> gpus = {ctx, ctx_b};
+      voxgraph_amd::GpuRegistrationBatchMulti multi(gpus);
+      std::vector<int32_t> plan = multi.PlanShards({N, N});
+      if (plan.size() != 2 || plan[0] == plan[1]) return fail("LPT plan");
+      ceres::CostFunction* m1 = multi.AddConstraint(plan[0] == 0 ? cost.handle() : cost_b.handle(), ref_pose, read_pose);
+      ceres::CostFunction* m2 = multi.AddConstraint(plan[1] == 0 ? cost.handle() : cost_b.handle(), read_pose, ref_pose);
+      multi.Finalize();
+      ceres::EvaluationCallback& mcb = multi;
+      mcb.PrepareForEvaluation(true, true);
+      cb.PrepareForEvaluation(true, true);
+      double r_s[9], r_m[9], j_s0[36], j_s1[36], j_m0[36], j_m1[36];
+      double* js[2] = {j_s0, j_s1};
+      double* jm[2] = {j_m0, j_m1};
+      if (!block->Evaluate(params, r_s, js) || !m1->Evaluate(params, r_m, jm)) return fail("multi block");
+      for (int q = 0; q < 9; ++q)
+        if (r_s[q] != r_m[q]) return fail("multi block differs from the single-GPU block");
+      for (int q = 0; q < 36; ++q)
+        if (j_s0[q] != j_m0[q] || j_s1[q] != j_m1[q]) return fail("multi Jacobian differs");
+      if (!block2->Evaluate(params, r_s, nullptr) || !m2->Evaluate(params, r_m, nullptr)) return fail("multi block 2");
+      for (int q = 0; q < 9; ++q)
+        if (r_s[q] != r_m[q]) return fail("multi block 2 differs");
+      double two_poses[8];
+      for (int q = 0; q < 4; ++q) {
+        two_poses[q] = ref_pose[q];
+        two_poses[4 + q] = read_pose[q];
+      }
+      std::vector<double> fused = multi.EvaluateFused(two_poses, 2);
+      double c_m = 0;
+      for (int q = 0; q < 9; ++q) c_m += r_m[q] * r_m[q];
+      // fused[0] = cost of both constraints; constraint 1's cost is cost_full (same residuals)
+      if (fused.size() != 1 + 20 * 2 + 16 * 2 || std::fabs(fused[0] - (cost_full + c_m)) > 1e-6 * fused[0])
+        return fail("multi fused cost");
+      std::printf("multi-context Ceres path ok: fused cost %.6f over 2 contexts\n", fused[0]);
+      delete m1;
+      delete m2;
+      // multi and cost_b go at scope exit; the submap and the second context outlive them
+      // (process exit reclaims them: this is a smoke test)
+    }
     delete block;
     delete block2;
   }

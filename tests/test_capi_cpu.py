@@ -84,3 +84,22 @@ def test_header_is_plain_c(tmp_path):
                            "-fsyntax-only", str(src)])
     subprocess.check_call(["g++", "-std=c++14", "-Wall", "-Wextra", "-Werror", "-I", inc, "-x", "c++",
                            "-fsyntax-only", str(src)])
+
+
+def test_lpt_shards_is_the_greedy_longest_processing_time_partition(capi):
+    """vgx_lpt_shards (pure host arithmetic): the placement bench.py, the in-process multi-GPU
+    component and a maintainer's own code share.  Against a direct restatement of the rule."""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    for n, k in ((0, 3), (1, 4), (50, 8), (1176, 8), (7, 1)):
+        w = rng.integers(1, 500000, n)
+        got = capi.lpt_shards(w, k)
+        order = np.argsort(-w, kind="stable")
+        load, want = np.zeros(k, np.int64), np.zeros(n, np.int32)
+        for c in order:
+            r = int(np.argmin(load))
+            want[c] = r
+            load[r] += w[c]
+        assert np.array_equal(got, want)
+        if n >= k:
+            assert load.max() - load.min() <= w.max()

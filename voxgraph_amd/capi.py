@@ -120,6 +120,13 @@ SIGNATURES = {
     "vgx_reg_batch_count_live": (C.c_int, [vp, f64p, C.c_int32, i64p]),
     "vgx_reg_batch_assemble": (C.c_int, [vp, vp, C.c_int32, vp, C.c_int32]),
     "vgx_reg_fused_size": (C.c_int64, [C.c_int32, C.c_int32]),
+    "vgx_lpt_shards": (C.c_int, [C.c_int32, i64p, C.c_int32, i32p]),
+    "vgx_reg_multi_create": (C.c_int, [C.c_int32, C.POINTER(vp), C.c_int32, C.POINTER(vp), i32p, C.POINTER(vp)]),
+    "vgx_reg_multi_destroy": (C.c_int, [vp]),
+    "vgx_reg_multi_num_shards": (C.c_int32, [vp]),
+    "vgx_reg_multi_shard_of": (C.c_int, [vp, i32p]),
+    "vgx_reg_multi_evaluate_fused": (C.c_int, [vp, f64p, C.c_int32, f64p, i32p]),
+    "vgx_reg_multi_evaluate_normal": (C.c_int, [vp, f64p, C.c_int32, f64p, i32p]),
     "vgx_reg_compress_normal": (C.c_int, [f64p, f64p, f64p]),
     "vgx_submap_surface_obb": (C.c_int, [vp, f32p, f32p]),
     "vgx_submap_mission_surface_aabb": (C.c_int, [vp, f64p, f32p, f32p]),
@@ -478,6 +485,57 @@ class RegistrationBatch:
     def destroy(self):
         if self.h:
             self.ctx.lib.vgx_reg_batch_destroy(self.h)
+            self.h = None
+
+
+def lpt_shards(weights, n_shards):
+    """vgx_lpt_shards: shard index per constraint (greedy longest-processing-time)."""
+    w = np.ascontiguousarray(weights, np.int64)
+    out = np.zeros(len(w), np.int32)
+    rc = load().vgx_lpt_shards(len(w), _ptr(w, i64p), int(n_shards), _ptr(out, i32p))
+    if rc != OK:
+        raise VgxError(rc, "vgx_lpt_shards")
+    return out
+
+
+class RegistrationMulti:
+    """vgx_reg_multi: the constraint list sharded over several contexts of this process."""
+
+    def __init__(self, ctxs, cost_functions, node_pair):
+        self.ctxs, self.n = list(ctxs), len(cost_functions)
+        carr = (vp * len(self.ctxs))(*[c.h for c in self.ctxs])
+        rarr = (vp * max(self.n, 1))(*[cf.h for cf in cost_functions])
+        np_pair = np.ascontiguousarray(node_pair, dtype=np.int32).reshape(-1, 2)
+        h = vp()
+        self.ctxs[0].check(self.ctxs[0].lib.vgx_reg_multi_create(len(self.ctxs), carr, self.n, rarr,
+                                                                 _ptr(np_pair, i32p), C.byref(h)))
+        self.h = h
+        self._keep = list(cost_functions)
+
+    def shard_of(self):
+        out = np.zeros(max(self.n, 1), np.int32)
+        self.ctxs[0].check(self.ctxs[0].lib.vgx_reg_multi_shard_of(self.h, _ptr(out, i32p)))
+        return out[:self.n]
+
+    def evaluate_fused(self, poses):
+        poses = _f64(poses).reshape(-1, 4)
+        out = np.zeros(fused_size(poses.shape[0], self.n))
+        status = np.zeros(max(self.n, 1), np.int32)
+        self.ctxs[0].check(self.ctxs[0].lib.vgx_reg_multi_evaluate_fused(
+            self.h, _ptr(poses, f64p), poses.shape[0], _ptr(out, f64p), _ptr(status, i32p)))
+        return out, status[:self.n]
+
+    def evaluate_normal(self, poses):
+        poses = _f64(poses).reshape(-1, 4)
+        out = np.zeros((self.n, NORMAL_SIZE))
+        status = np.zeros(max(self.n, 1), np.int32)
+        self.ctxs[0].check(self.ctxs[0].lib.vgx_reg_multi_evaluate_normal(
+            self.h, _ptr(poses, f64p), poses.shape[0], _ptr(out, f64p), _ptr(status, i32p)))
+        return out, status[:self.n]
+
+    def destroy(self):
+        if self.h:
+            self.ctxs[0].lib.vgx_reg_multi_destroy(self.h)
             self.h = None
 
 

@@ -29,48 +29,18 @@
 
 namespace voxgraph_amd {
 
-class GpuRegistrationBatch : public ceres::EvaluationCallback {
+// What the single- and multi-GPU callbacks share: the constraint list, the pose-block -> node
+// numbering, the [n][45] normal blocks of the last evaluation and their 9-residual stand-ins.
+// A derived class only says how the normal blocks are produced (EvaluateNormals).
+class GpuRegistrationBlocks : public ceres::EvaluationCallback {
  public:
-  explicit GpuRegistrationBatch(vgx_ctx ctx) : ctx_(ctx) {}
-  ~GpuRegistrationBatch() override {
-    if (batch_) vgx_reg_batch_destroy(batch_);
-  }
-  GpuRegistrationBatch(const GpuRegistrationBatch&) = delete;
-  GpuRegistrationBatch& operator=(const GpuRegistrationBatch&) = delete;
-
-  // One registration constraint.  pose_* are the parameter blocks Ceres optimises
-  // ({x,y,z,yaw} doubles, Pose4D::optimizationVectorData()); the returned cost function
-  // is handed to Problem::AddResidualBlock (which takes ownership by default).
-  ceres::CostFunction* AddConstraint(vgx_reg reg, const double* pose_reference,
-                                     const double* pose_reading) {
-    if (batch_) throw std::logic_error("GpuRegistrationBatch: AddConstraint after Finalize");
-    regs_.push_back(reg);
-    node_pair_.push_back(NodeIndex(pose_reference));
-    node_pair_.push_back(NodeIndex(pose_reading));
-    const int c = static_cast<int>(regs_.size()) - 1;
-    return new Block(this, c);
-  }
-
-  void Finalize() {
-    const int n = static_cast<int>(regs_.size());
-    if (vgx_reg_batch_create(ctx_, n, regs_.data(), node_pair_.data(), nullptr, n, &batch_) != VGX_OK)
-      throw std::runtime_error(std::string("vgx_reg_batch_create: ") + vgx_last_error(ctx_));
-    normal_.assign(static_cast<size_t>(n) * 45, 0.0);
-    status_.assign(static_cast<size_t>(n), 0);
-    compressed_r_.assign(static_cast<size_t>(n) * 9, 0.0);
-    compressed_j_.assign(static_cast<size_t>(n) * 72, 0.0);
-    poses_.assign(nodes_.size() * 4, 0.0);
-  }
-
   // ceres::EvaluationCallback: the user's parameter blocks already hold the point to
   // evaluate when this is called.
   void PrepareForEvaluation(bool /*evaluate_jacobians*/, bool new_evaluation_point) override {
-    if (!batch_) throw std::logic_error("GpuRegistrationBatch: Finalize() was not called");
+    if (!finalized_) throw std::logic_error("GpuRegistrationBatch: Finalize() was not called");
     if (!new_evaluation_point && valid_) return;
     for (size_t k = 0; k < nodes_.size(); ++k) std::memcpy(&poses_[4 * k], nodes_[k], 4 * sizeof(double));
-    if (vgx_reg_batch_evaluate_normal(batch_, poses_.data(), static_cast<int32_t>(nodes_.size()),
-                                      nullptr, normal_.data(), status_.data()) != VGX_OK)
-      throw std::runtime_error(std::string("vgx_reg_batch_evaluate_normal: ") + vgx_last_error(ctx_));
+    EvaluateNormals(poses_.data(), static_cast<int32_t>(nodes_.size()), normal_.data(), status_.data());
     for (size_t c = 0; c < regs_.size(); ++c)
       vgx_reg_compress_normal(&normal_[45 * c], &compressed_r_[9 * c], &compressed_j_[72 * c]);
     valid_ = true;
@@ -78,14 +48,38 @@ class GpuRegistrationBatch : public ceres::EvaluationCallback {
 
   int num_constraints() const { return static_cast<int>(regs_.size()); }
 
+ protected:
+  virtual void EvaluateNormals(const double* poses, int32_t n_nodes, double* normal, int32_t* status) = 0;
+
+  ceres::CostFunction* AddBlock(vgx_reg reg, const double* pose_reference, const double* pose_reading) {
+    if (finalized_) throw std::logic_error("GpuRegistrationBatch: AddConstraint after Finalize");
+    regs_.push_back(reg);
+    node_pair_.push_back(NodeIndex(pose_reference));
+    node_pair_.push_back(NodeIndex(pose_reading));
+    return new Block(this, static_cast<int>(regs_.size()) - 1);
+  }
+
+  void FinalizeBlocks() {
+    const size_t n = regs_.size();
+    normal_.assign(n * 45, 0.0);
+    status_.assign(n, 0);
+    compressed_r_.assign(n * 9, 0.0);
+    compressed_j_.assign(n * 72, 0.0);
+    poses_.assign(nodes_.size() * 4, 0.0);
+    finalized_ = true;
+  }
+
+  std::vector<vgx_reg> regs_;
+  std::vector<int32_t> node_pair_;
+
  private:
   // The 9-residual stand-in for one RegistrationCostFunction.
   class Block : public ceres::SizedCostFunction<9, 4, 4> {
    public:
-    Block(const GpuRegistrationBatch* owner, int index) : owner_(owner), index_(index) {}
+    Block(const GpuRegistrationBlocks* owner, int index) : owner_(owner), index_(index) {}
     bool Evaluate(double const* const* /*parameters*/, double* residuals,
                   double** jacobians) const override {
-      const GpuRegistrationBatch& o = *owner_;
+      const GpuRegistrationBlocks& o = *owner_;
       if (!o.valid_) return false;
       if (o.status_[static_cast<size_t>(index_)] == VGX_EVALUATE_FALSE) return false;  // .cpp:273
       std::memcpy(residuals, &o.compressed_r_[9 * static_cast<size_t>(index_)], 9 * sizeof(double));
@@ -100,7 +94,7 @@ class GpuRegistrationBatch : public ceres::EvaluationCallback {
     }
 
    private:
-    const GpuRegistrationBatch* owner_;
+    const GpuRegistrationBlocks* owner_;
     int index_;
   };
 
@@ -113,15 +107,47 @@ class GpuRegistrationBatch : public ceres::EvaluationCallback {
     return k;
   }
 
-  vgx_ctx ctx_;
-  vgx_reg_batch batch_ = nullptr;
-  std::vector<vgx_reg> regs_;
-  std::vector<int32_t> node_pair_;
   std::vector<const double*> nodes_;
   std::map<const double*, int32_t> node_of_;
   std::vector<double> poses_, normal_, compressed_r_, compressed_j_;
   std::vector<int32_t> status_;
+  bool finalized_ = false;
   bool valid_ = false;
+};
+
+// One GPU.
+class GpuRegistrationBatch : public GpuRegistrationBlocks {
+ public:
+  explicit GpuRegistrationBatch(vgx_ctx ctx) : ctx_(ctx) {}
+  ~GpuRegistrationBatch() override {
+    if (batch_) vgx_reg_batch_destroy(batch_);
+  }
+  GpuRegistrationBatch(const GpuRegistrationBatch&) = delete;
+  GpuRegistrationBatch& operator=(const GpuRegistrationBatch&) = delete;
+
+  // One registration constraint.  pose_* are the parameter blocks Ceres optimises
+  // ({x,y,z,yaw} doubles, Pose4D::optimizationVectorData()); the returned cost function
+  // is handed to Problem::AddResidualBlock (which takes ownership by default).
+  ceres::CostFunction* AddConstraint(vgx_reg reg, const double* pose_reference, const double* pose_reading) {
+    return AddBlock(reg, pose_reference, pose_reading);
+  }
+
+  void Finalize() {
+    const int n = static_cast<int>(regs_.size());
+    if (vgx_reg_batch_create(ctx_, n, regs_.data(), node_pair_.data(), nullptr, n, &batch_) != VGX_OK)
+      throw std::runtime_error(std::string("vgx_reg_batch_create: ") + vgx_last_error(ctx_));
+    FinalizeBlocks();
+  }
+
+ protected:
+  void EvaluateNormals(const double* poses, int32_t n_nodes, double* normal, int32_t* status) override {
+    if (vgx_reg_batch_evaluate_normal(batch_, poses, n_nodes, nullptr, normal, status) != VGX_OK)
+      throw std::runtime_error(std::string("vgx_reg_batch_evaluate_normal: ") + vgx_last_error(ctx_));
+  }
+
+ private:
+  vgx_ctx ctx_;
+  vgx_reg_batch batch_ = nullptr;
 };
 
 }  // namespace voxgraph_amd

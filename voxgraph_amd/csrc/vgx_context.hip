@@ -17,8 +17,11 @@ void set_global_error(const std::string& msg) {
   g_global_error = msg;
 }
 
+// Errors are recorded from any thread (Ceres evaluates on 4, pose_graph.cpp:96), with or without
+// the context lock held, so the message has its own small lock.
 int set_error(vgx_ctx ctx, int code, const std::string& msg) {
   if (ctx) {
+    std::lock_guard<std::mutex> lk(ctx->err_mu);
     ctx->last_error = msg;
   } else {
     set_global_error(msg);
@@ -310,10 +313,15 @@ int vgx_ctx_destroy(vgx_ctx ctx) {
 }
 
 const char* vgx_last_error(vgx_ctx ctx) {
-  if (ctx) return ctx->last_error.c_str();
+  // a per-thread copy: the returned pointer stays valid while other threads record new errors
   static thread_local std::string copy;
-  std::lock_guard<std::mutex> lk(g_err_mu);
-  copy = g_global_error;
+  if (ctx) {
+    std::lock_guard<std::mutex> lk(ctx->err_mu);
+    copy = ctx->last_error;
+  } else {
+    std::lock_guard<std::mutex> lk(g_err_mu);
+    copy = g_global_error;
+  }
   return copy.c_str();
 }
 

@@ -86,6 +86,7 @@ struct Context {
   hipStream_t stream = nullptr;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   std::mutex mu;
+  std::mutex err_mu;       // guards last_error only (set_error is called with and without `mu`)
   std::string last_error;
   int cu_count = 256;
   // Evaluation slots of the drop-in Evaluate path.  A call takes a free slot for its duration

@@ -1,0 +1,330 @@
+// Multi-GPU REG inside ONE process: voxgraph is a single process
+// (voxgraph/src/voxgraph_mapping_node.cpp:6-26) whose Ceres solve evaluates every registration
+// residual block per iteration (pose_graph.cpp:85-106).  Given the pose vector the constraints are
+// independent, so the constraint list is pair-sharded over N contexts (one per GPU, submaps
+// replicated); each context runs the fused pass on its share from its own host thread and its
+// own stream, and the shares meet in ONE reduction per solver evaluation:
+//
+//     worker k : vgx_reg_batch_evaluate_normal -> vgx_reg_batch_assemble -> event
+//     context 0: waits for the K events, sums the K fused buffers IN CONTEXT ORDER (peer-mapped
+//                reads over xGMI, ~180 KB each for 200 submaps / 1176 constraints) -> host
+//
+// The sum is a fixed-order sum of deterministic partial buffers: bitwise reproducible, unlike an
+// all-reduce whose ring order depends on the communicator.  The same sharding with one process
+// per GPU and an RCCL all-reduce (what bench.py's torchrun launch does) uses the same entry
+// points underneath (vgx_lpt_shards, vgx_reg_batch_*).
+#include <algorithm>
+#include <condition_variable>
+#include <cstring>
+#include <memory>
+#include <numeric>
+#include <thread>
+
+#include "vgx_internal.h"
+
+namespace vgx {
+
+constexpr int kMaxShards = 16;
+
+struct SumArgs {
+  const double* src[kMaxShards];
+  int n_src;
+};
+
+// out[i] = src[0][i] + src[1][i] + ... in that order
+__global__ void multi_sum_kernel(SumArgs a, long long n, double* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double v = a.src[0][i];
+  for (int k = 1; k < a.n_src; ++k) v += a.src[k][i];
+  out[i] = v;
+}
+
+}  // namespace vgx
+
+using namespace vgx;
+
+struct vgx_reg_multi_s {
+  struct Shard {
+    vgx_ctx ctx = nullptr;
+    vgx_reg_batch batch = nullptr;
+    std::vector<int32_t> global;   // global constraint index of local constraint c
+    std::vector<int32_t> status;   // per local constraint
+    double* d_fused = nullptr;     // this shard's assembled buffer
+    double* h_normal = nullptr;    // pinned [n_local][45]
+    int64_t fused_cap = 0;
+    hipEvent_t done = nullptr;
+    int rc = VGX_OK;
+    std::thread th;
+  };
+  std::vector<std::unique_ptr<Shard>> shards;
+  int32_t n = 0;                   // global constraint count
+  std::vector<int32_t> shard_of;   // [n]
+  // job hand-off to the worker threads
+  std::mutex mu;
+  std::condition_variable go, finished;
+  uint64_t generation = 0;
+  int pending = 0;
+  bool quit = false;
+  int mode = 0;                    // 0 fused, 1 per-constraint normal blocks to the host
+  const double* poses = nullptr;
+  int32_t n_nodes = 0;
+  // reduction on shard 0
+  double* d_sum = nullptr;
+  double* h_sum = nullptr;         // pinned
+  int64_t sum_cap = 0;
+  std::mutex call_mu;              // one evaluation at a time
+};
+
+static void run_shard(vgx_reg_multi_s* m, vgx_reg_multi_s::Shard& s) {
+  s.rc = VGX_OK;
+  const int32_t nl = (int32_t)s.global.size();
+  if (m->mode == 0) {
+    s.rc = vgx_reg_batch_evaluate_normal(s.batch, m->poses, m->n_nodes, nullptr, nullptr,
+                                         nl ? s.status.data() : nullptr);
+    if (s.rc == VGX_OK) s.rc = vgx_reg_batch_assemble(s.batch, nullptr, m->n_nodes, s.d_fused, 1);
+    if (s.rc == VGX_OK && (hipSetDevice(s.ctx->device) != hipSuccess ||
+                           hipEventRecord(s.done, s.ctx->stream) != hipSuccess))
+      s.rc = VGX_ERR_HIP;
+  } else {
+    s.rc = vgx_reg_batch_evaluate_normal(s.batch, m->poses, m->n_nodes, nullptr, nl ? s.h_normal : nullptr,
+                                         nl ? s.status.data() : nullptr);
+  }
+}
+
+static void worker_loop(vgx_reg_multi_s* m, int k) {
+  uint64_t seen = 0;
+  vgx_reg_multi_s::Shard& s = *m->shards[(size_t)k];
+  (void)hipSetDevice(s.ctx->device);
+  for (;;) {
+    {
+      std::unique_lock<std::mutex> lk(m->mu);
+      m->go.wait(lk, [&] { return m->quit || m->generation != seen; });
+      if (m->quit) return;
+      seen = m->generation;
+    }
+    run_shard(m, s);
+    {
+      std::lock_guard<std::mutex> lk(m->mu);
+      if (--m->pending == 0) m->finished.notify_all();
+    }
+  }
+}
+
+static int dispatch(vgx_reg_multi_s* m, int mode, const double* poses, int32_t n_nodes) {
+  {
+    std::lock_guard<std::mutex> lk(m->mu);
+    m->mode = mode;
+    m->poses = poses;
+    m->n_nodes = n_nodes;
+    m->pending = (int)m->shards.size();
+    ++m->generation;
+  }
+  m->go.notify_all();
+  std::unique_lock<std::mutex> lk(m->mu);
+  m->finished.wait(lk, [&] { return m->pending == 0; });
+  for (auto& s : m->shards)
+    if (s->rc != VGX_OK) return s->rc;
+  return VGX_OK;
+}
+
+extern "C" {
+
+int vgx_lpt_shards(int32_t n, const int64_t* weight, int32_t n_shards, int32_t* shard_of) {
+  if (n < 0 || n_shards <= 0 || (n > 0 && (!weight || !shard_of))) return VGX_ERR_INVALID;
+  // greedy longest-processing-time: heaviest constraint first onto the least loaded shard
+  // (ties: lower constraint index first, lower shard index first)
+  std::vector<int32_t> order((size_t)n);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return weight[a] > weight[b]; });
+  std::vector<int64_t> load((size_t)n_shards, 0);
+  for (int32_t c : order) {
+    int best = 0;
+    for (int k = 1; k < n_shards; ++k)
+      if (load[(size_t)k] < load[(size_t)best]) best = k;
+    shard_of[c] = best;
+    load[(size_t)best] += weight[c];
+  }
+  return VGX_OK;
+}
+
+int vgx_reg_multi_destroy(vgx_reg_multi m) {
+  if (!m) return VGX_ERR_INVALID;
+  {
+    std::lock_guard<std::mutex> lk(m->mu);
+    m->quit = true;
+  }
+  m->go.notify_all();
+  for (auto& s : m->shards)
+    if (s->th.joinable()) s->th.join();
+  for (auto& s : m->shards) {
+    (void)hipSetDevice(s->ctx->device);
+    if (s->batch) vgx_reg_batch_destroy(s->batch);
+    if (s->d_fused) (void)hipFree(s->d_fused);
+    if (s->h_normal) (void)hipHostFree(s->h_normal);
+    if (s->done) (void)hipEventDestroy(s->done);
+  }
+  if (!m->shards.empty()) (void)hipSetDevice(m->shards[0]->ctx->device);
+  if (m->d_sum) (void)hipFree(m->d_sum);
+  if (m->h_sum) (void)hipHostFree(m->h_sum);
+  delete m;
+  return VGX_OK;
+}
+
+int vgx_reg_multi_create(int32_t n_ctx, const vgx_ctx* ctxs, int32_t n, const vgx_reg* regs,
+                         const int32_t* node_pair, vgx_reg_multi* out) {
+  if (!out) return VGX_ERR_INVALID;
+  *out = nullptr;
+  if (n_ctx <= 0 || n_ctx > kMaxShards || !ctxs || n < 0 || (n > 0 && (!regs || !node_pair))) return VGX_ERR_INVALID;
+  for (int k = 0; k < n_ctx; ++k)
+    if (!ctxs[k]) return VGX_ERR_INVALID;
+  vgx_ctx ctx0 = ctxs[0];
+  vgx_reg_multi m = new (std::nothrow) vgx_reg_multi_s();
+  if (!m) return set_error(ctx0, VGX_ERR_NOMEM, "vgx_reg_multi_create: out of host memory");
+  m->n = n;
+  m->shard_of.assign((size_t)n, -1);
+  for (int k = 0; k < n_ctx; ++k) {
+    m->shards.emplace_back(new vgx_reg_multi_s::Shard());
+    m->shards.back()->ctx = ctxs[k];
+  }
+  // a constraint runs on the context its cost function (and therefore its two submaps) lives on
+  for (int c = 0; c < n; ++c) {
+    int k = 0;
+    while (k < n_ctx && (!regs[c] || regs[c]->ctx != ctxs[k])) ++k;
+    if (k == n_ctx) {
+      vgx_reg_multi_destroy(m);
+      return set_error(ctx0, VGX_ERR_INVALID, "vgx_reg_multi_create: a constraint belongs to none of the contexts");
+    }
+    m->shard_of[(size_t)c] = k;
+    m->shards[(size_t)k]->global.push_back(c);
+  }
+  int rc = VGX_OK;
+  for (int k = 0; k < n_ctx && rc == VGX_OK; ++k) {
+    vgx_reg_multi_s::Shard& s = *m->shards[(size_t)k];
+    const int32_t nl = (int32_t)s.global.size();
+    std::vector<vgx_reg> r((size_t)nl);
+    std::vector<int32_t> np(2 * (size_t)nl);
+    for (int32_t c = 0; c < nl; ++c) {
+      r[(size_t)c] = regs[s.global[(size_t)c]];
+      np[2 * (size_t)c] = node_pair[2 * (size_t)s.global[(size_t)c]];
+      np[2 * (size_t)c + 1] = node_pair[2 * (size_t)s.global[(size_t)c] + 1];
+    }
+    rc = vgx_reg_batch_create(s.ctx, nl, r.data(), np.data(), s.global.data(), n, &s.batch);
+    if (rc != VGX_OK) {
+      set_error(ctx0, rc, std::string("vgx_reg_multi_create: shard batch: ") + vgx_last_error(s.ctx));
+      break;
+    }
+    s.status.assign((size_t)nl, 0);
+    if (hipSetDevice(s.ctx->device) != hipSuccess ||
+        hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess ||
+        (nl > 0 && hipHostMalloc((void**)&s.h_normal, (size_t)nl * kNormalSize * sizeof(double), hipHostMallocDefault) != hipSuccess))
+      rc = set_error(ctx0, VGX_ERR_HIP, "vgx_reg_multi_create: event / pinned buffer creation failed");
+    // shard 0 reads the other shards' buffers directly (xGMI peer mapping)
+    if (rc == VGX_OK && k > 0 && s.ctx->device != ctx0->device) {
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, ctx0->device, s.ctx->device) != hipSuccess || !can) {
+        rc = set_error(ctx0, VGX_ERR_UNSUPPORTED, "vgx_reg_multi_create: device 0 cannot peer-map another shard's device");
+      } else {
+        (void)hipSetDevice(ctx0->device);
+        hipError_t e = hipDeviceEnablePeerAccess(s.ctx->device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+          rc = set_error(ctx0, VGX_ERR_HIP, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+        (void)hipGetLastError();
+      }
+    }
+  }
+  if (rc != VGX_OK) {
+    vgx_reg_multi_destroy(m);
+    return rc;
+  }
+  for (int k = 0; k < n_ctx; ++k) m->shards[(size_t)k]->th = std::thread(worker_loop, m, k);
+  *out = m;
+  return VGX_OK;
+}
+
+int32_t vgx_reg_multi_num_shards(vgx_reg_multi m) { return m ? (int32_t)m->shards.size() : -1; }
+
+int vgx_reg_multi_shard_of(vgx_reg_multi m, int32_t* shard_of) {
+  if (!m || !shard_of) return VGX_ERR_INVALID;
+  std::copy(m->shard_of.begin(), m->shard_of.end(), shard_of);
+  return VGX_OK;
+}
+
+int vgx_reg_multi_evaluate_fused(vgx_reg_multi m, const double* poses, int32_t n_nodes, double* fused_host,
+                                 int32_t* status) {
+  if (!m || !poses || !fused_host || n_nodes <= 0) return VGX_ERR_INVALID;
+  std::lock_guard<std::mutex> call(m->call_mu);
+  vgx_ctx ctx0 = m->shards[0]->ctx;
+  const int64_t size = vgx_reg_fused_size(n_nodes, m->n);
+  // (re)size the per-shard buffers and the reduction buffers
+  for (auto& sp : m->shards) {
+    vgx_reg_multi_s::Shard& s = *sp;
+    if (s.fused_cap >= size) continue;
+    VGX_HIP(ctx0, hipSetDevice(s.ctx->device));
+    VGX_HIP(ctx0, hipStreamSynchronize(s.ctx->stream));
+    if (s.d_fused) (void)hipFree(s.d_fused);
+    s.d_fused = nullptr;
+    s.fused_cap = 0;
+    VGX_HIP(ctx0, hipMalloc(&s.d_fused, (size_t)size * sizeof(double)));
+    s.fused_cap = size;
+  }
+  VGX_HIP(ctx0, hipSetDevice(ctx0->device));
+  if (m->sum_cap < size) {
+    VGX_HIP(ctx0, hipStreamSynchronize(ctx0->stream));
+    if (m->d_sum) (void)hipFree(m->d_sum);
+    if (m->h_sum) (void)hipHostFree(m->h_sum);
+    m->d_sum = nullptr;
+    m->h_sum = nullptr;
+    m->sum_cap = 0;
+    VGX_HIP(ctx0, hipMalloc(&m->d_sum, (size_t)size * sizeof(double)));
+    VGX_HIP(ctx0, hipHostMalloc((void**)&m->h_sum, (size_t)size * sizeof(double), hipHostMallocDefault));
+    m->sum_cap = size;
+  }
+  int rc = dispatch(m, 0, poses, n_nodes);
+  if (rc != VGX_OK) {
+    for (auto& s : m->shards)
+      if (s->rc != VGX_OK) return set_error(ctx0, s->rc, std::string("vgx_reg_multi: shard failed: ") + vgx_last_error(s->ctx));
+    return rc;
+  }
+  // one reduction per solver evaluation, on shard 0's stream, in shard order
+  VGX_HIP(ctx0, hipSetDevice(ctx0->device));
+  SumArgs a{};
+  a.n_src = (int)m->shards.size();
+  for (int k = 0; k < a.n_src; ++k) {
+    a.src[k] = m->shards[(size_t)k]->d_fused;
+    if (k > 0) VGX_HIP(ctx0, hipStreamWaitEvent(ctx0->stream, m->shards[(size_t)k]->done, 0));
+  }
+  hipLaunchKernelGGL(multi_sum_kernel, dim3((unsigned)((size + 255) / 256)), dim3(256), 0, ctx0->stream, a,
+                     (long long)size, m->d_sum);
+  VGX_HIP(ctx0, hipGetLastError());
+  VGX_HIP(ctx0, hipMemcpyAsync(m->h_sum, m->d_sum, (size_t)size * sizeof(double), hipMemcpyDeviceToHost, ctx0->stream));
+  VGX_HIP(ctx0, hipStreamSynchronize(ctx0->stream));
+  std::memcpy(fused_host, m->h_sum, (size_t)size * sizeof(double));
+  if (status)
+    for (auto& s : m->shards)
+      for (size_t c = 0; c < s->global.size(); ++c) status[s->global[c]] = s->status[c];
+  return VGX_OK;
+}
+
+int vgx_reg_multi_evaluate_normal(vgx_reg_multi m, const double* poses, int32_t n_nodes, double* normal_host,
+                                  int32_t* status) {
+  if (!m || !poses || !normal_host || n_nodes <= 0) return VGX_ERR_INVALID;
+  std::lock_guard<std::mutex> call(m->call_mu);
+  vgx_ctx ctx0 = m->shards[0]->ctx;
+  int rc = dispatch(m, 1, poses, n_nodes);
+  if (rc != VGX_OK) {
+    for (auto& s : m->shards)
+      if (s->rc != VGX_OK) return set_error(ctx0, s->rc, std::string("vgx_reg_multi: shard failed: ") + vgx_last_error(s->ctx));
+    return rc;
+  }
+  // no collective: every shard hands its own constraints' blocks back
+  for (auto& s : m->shards)
+    for (size_t c = 0; c < s->global.size(); ++c) {
+      std::memcpy(normal_host + (size_t)s->global[c] * kNormalSize, s->h_normal + c * kNormalSize,
+                  kNormalSize * sizeof(double));
+      if (status) status[s->global[c]] = s->status[c];
+    }
+  return VGX_OK;
+}
+
+}  // extern "C"
