@@ -391,19 +391,30 @@ typedef struct vgx_tsdf_config {
 VGX_API void vgx_tsdf_config_default(vgx_tsdf_config* cfg);
 
 /* An active (unfinished) submap's TSDF layer, resident on the GPU between scans
- * (SURVEY.md 3.1).  Blocks are allocated on demand inside the block-coordinate box
- * [lut_min, lut_min + lut_dim) from a pool of max_blocks blocks (12 B per voxel);
- * rays leaving the box or exhausting the pool are counted, not integrated there. */
+ * (SURVEY.md 3.1).  Unbounded, like voxblox::Layer<TsdfVoxel>: blocks (12 B per voxel) are allocated
+ * on demand wherever rays go.  lut_min / lut_dim (block coordinates; both may be NULL) and max_blocks
+ * (<= 0: a default) are only an initial reservation: before each scan the integrator enlarges the
+ * block table and the block pool, on the stream, to hold everything that scan can reach
+ * (origin +- max_ray_length + truncation), so no update is ever dropped for lack of room.  If the
+ * GPU itself runs out of memory the integrate call fails with VGX_ERR_NOMEM. */
 VGX_API int vgx_tsdf_layer_create(vgx_ctx ctx, float voxel_size, int32_t voxels_per_side,
                                   const int32_t lut_min[3], const int32_t lut_dim[3],
                                   int32_t max_blocks, vgx_tsdf_layer* out);
 VGX_API int vgx_tsdf_layer_destroy(vgx_tsdf_layer layer);
-/* allocated blocks; *dropped_updates = voxel updates lost to the box / pool limits */
+/* allocated blocks; *dropped_updates = voxel updates that found no block (always 0 unless an
+ * allocation failed, in which case the next integrate call reports VGX_ERR_NOMEM).  Waits for the
+ * scans in flight. */
 VGX_API int vgx_tsdf_layer_stats(vgx_tsdf_layer layer, int32_t* n_blocks,
                                  int64_t* dropped_updates);
+/* how often the layer has enlarged its block table or pool so far (diagnostics) */
+VGX_API int64_t vgx_tsdf_layer_growths(vgx_tsdf_layer layer);
 /* block_index[n][3], distance / weight [n][vps^3], rgba [n][vps^3][4]; any may be NULL */
 VGX_API int vgx_tsdf_layer_download(vgx_tsdf_layer layer, int32_t* block_index,
                                     float* distance, float* weight, uint8_t* rgba);
+/* Replaces the layer's contents with host blocks in the same layout (rgba may be NULL): hands a
+ * voxblox::Layer<TsdfVoxel> that already holds data over to the GPU integrator. */
+VGX_API int vgx_tsdf_layer_upload(vgx_tsdf_layer layer, int32_t n_blocks, const int32_t* block_index,
+                                  const float* distance, const float* weight, const uint8_t* rgba);
 
 VGX_API int vgx_tsdf_integrator_create(vgx_ctx ctx, const vgx_tsdf_config* cfg,
                                        vgx_tsdf_layer layer, vgx_tsdf_integrator* out);

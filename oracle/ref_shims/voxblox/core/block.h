@@ -2,6 +2,7 @@
 #ifndef ORACLE_REF_SHIMS_VOXBLOX_CORE_BLOCK_H_
 #define ORACLE_REF_SHIMS_VOXBLOX_CORE_BLOCK_H_
 #include <algorithm>
+#include <bitset>
 
 #include "voxblox/core/voxel.h"
 namespace voxblox {
@@ -43,12 +44,19 @@ class Block {
     return voxels_[computeLinearIndexFromVoxelIndex(i)];
   }
   bool isValidLinearIndex(size_t i) const { return i < voxels_.size(); }
+  // bookkeeping flags of voxblox::Block [recalled]: Update::{kMap, kMesh, kEsdf}
+  bool has_data() const { return has_data_; }
+  bool& has_data() { return has_data_; }
+  const std::bitset<3>& updated() const { return updated_; }
+  std::bitset<3>& updated() { return updated_; }
 
  private:
   size_t vps_;
   FloatingPoint voxel_size_, voxel_size_inv_;
   Point origin_;
   std::vector<VoxelType> voxels_;
+  bool has_data_ = false;
+  std::bitset<3> updated_;
 };
 }  // namespace voxblox
 #endif

@@ -135,7 +135,9 @@ SIGNATURES = {
     "vgx_tsdf_layer_create": (C.c_int, [vp, C.c_float, C.c_int32, i32p, i32p, C.c_int32, C.POINTER(vp)]),
     "vgx_tsdf_layer_destroy": (C.c_int, [vp]),
     "vgx_tsdf_layer_stats": (C.c_int, [vp, i32p, i64p]),
+    "vgx_tsdf_layer_growths": (C.c_int64, [vp]),
     "vgx_tsdf_layer_download": (C.c_int, [vp, i32p, f32p, f32p, u8p]),
+    "vgx_tsdf_layer_upload": (C.c_int, [vp, C.c_int32, i32p, f32p, f32p, u8p]),
     "vgx_tsdf_integrator_create": (C.c_int, [vp, C.POINTER(TsdfConfig), vp, C.POINTER(vp)]),
     "vgx_tsdf_integrator_destroy": (C.c_int, [vp]),
     "vgx_tsdf_integrator_set_layer": (C.c_int, [vp, vp]),
@@ -607,14 +609,25 @@ def voxgraph_tsdf_config(**kw):
 class TsdfLayer:
     """voxblox::Layer<TsdfVoxel> of the active submap, resident on the GPU."""
 
-    def __init__(self, ctx, voxel_size, vps, lut_min, lut_dim, max_blocks):
+    def __init__(self, ctx, voxel_size, vps, lut_min=None, lut_dim=None, max_blocks=0):
+        """lut_min / lut_dim / max_blocks are only an initial reservation: the layer grows."""
         self.ctx, self.vps = ctx, vps
-        mn = np.ascontiguousarray(lut_min, np.int32)
-        dm = np.ascontiguousarray(lut_dim, np.int32)
+        mn = None if lut_min is None else np.ascontiguousarray(lut_min, np.int32)
+        dm = None if lut_dim is None else np.ascontiguousarray(lut_dim, np.int32)
         h = vp()
         ctx.check(ctx.lib.vgx_tsdf_layer_create(ctx.h, float(voxel_size), vps, _ptr(mn, i32p),
                                                 _ptr(dm, i32p), max_blocks, C.byref(h)))
         self.h = h
+
+    def growths(self):
+        return int(self.ctx.lib.vgx_tsdf_layer_growths(self.h))
+
+    def upload(self, block_index, distance, weight, rgba=None):
+        bi = np.ascontiguousarray(block_index, np.int32).reshape(-1, 3)
+        d, w = _f32(distance), _f32(weight)
+        c = None if rgba is None else np.ascontiguousarray(rgba, np.uint8)
+        self.ctx.check(self.ctx.lib.vgx_tsdf_layer_upload(self.h, bi.shape[0], _ptr(bi, i32p), _ptr(d, f32p),
+                                                          _ptr(w, f32p), _ptr(c, u8p)))
 
     def stats(self):
         n, d = C.c_int32(), C.c_int64()

@@ -17,12 +17,18 @@
 
 namespace voxgraph_amd {
 
-// The active submap's TSDF layer on the GPU (voxblox::Layer<TsdfVoxel> stand-in).
+// The active submap's TSDF layer on the GPU: voxblox::Layer<TsdfVoxel>(voxel_size, voxels_per_side),
+// unbounded like it.  gpu_tsdf_layer_bridge.h moves its contents to / from a voxblox layer.
 class GpuTsdfLayer {
  public:
+  GpuTsdfLayer(vgx_ctx ctx, float voxel_size, int voxels_per_side) : ctx_(ctx), vps_(voxels_per_side), voxel_size_(voxel_size) {
+    if (vgx_tsdf_layer_create(ctx, voxel_size, voxels_per_side, nullptr, nullptr, 0, &layer_) != VGX_OK)
+      throw std::runtime_error(std::string("vgx_tsdf_layer_create: ") + vgx_last_error(ctx));
+  }
+  // with an initial reservation (block box and pool size); the layer still grows beyond it
   GpuTsdfLayer(vgx_ctx ctx, float voxel_size, int voxels_per_side, const int32_t box_min[3],
                const int32_t box_dim[3], int32_t max_blocks)
-      : ctx_(ctx) {
+      : ctx_(ctx), vps_(voxels_per_side), voxel_size_(voxel_size) {
     if (vgx_tsdf_layer_create(ctx, voxel_size, voxels_per_side, box_min, box_dim, max_blocks,
                               &layer_) != VGX_OK)
       throw std::runtime_error(std::string("vgx_tsdf_layer_create: ") + vgx_last_error(ctx));
@@ -31,14 +37,21 @@ class GpuTsdfLayer {
   GpuTsdfLayer(const GpuTsdfLayer&) = delete;
   GpuTsdfLayer& operator=(const GpuTsdfLayer&) = delete;
   vgx_tsdf_layer handle() const { return layer_; }
-  int32_t getNumberOfAllocatedBlocks() const {
+  int voxels_per_side() const { return vps_; }
+  float voxel_size() const { return voxel_size_; }
+  const char* last_error() const { return vgx_last_error(ctx_); }
+  // waits for the scans in flight; *dropped_updates (nullable) is 0 unless the GPU ran out of memory
+  int32_t getNumberOfAllocatedBlocks(int64_t* dropped_updates = nullptr) const {
     int32_t n = 0;
-    vgx_tsdf_layer_stats(layer_, &n, nullptr);
+    if (vgx_tsdf_layer_stats(layer_, &n, dropped_updates) != VGX_OK)
+      throw std::runtime_error(std::string("vgx_tsdf_layer_stats: ") + vgx_last_error(ctx_));
     return n;
   }
 
  private:
   vgx_ctx ctx_;
+  int vps_;
+  float voxel_size_;
   vgx_tsdf_layer layer_ = nullptr;
 };
 

@@ -10,12 +10,19 @@
 //     on the packed {distance, weight} voxel, i.e. each ray's update is applied
 //     atomically in SOME order -- exactly the reference's multi-thread semantics,
 //   * blocks are allocated on demand from a pre-zeroed pool through a dense
-//     block lookup table (no hashing, no locks held across iterations).
+//     block lookup table (no hashing, no locks held across iterations).  The layer is
+//     UNBOUNDED like voxblox::Layer: before every scan the host makes sure the table's box
+//     covers everything the scan can reach (origin +- max ray + truncation) and that the pool
+//     has room for every block in that reach, growing either on the stream if not, so a
+//     kernel never meets a block it cannot allocate.
 // HBM-latency / atomic bound: 16 B per input point + 24 B per voxel update
 // (SURVEY.md 8d); no MFMA.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <string>
+#include <utility>
 #include <vector>
 
 #include "vgx_internal.h"
@@ -29,7 +36,6 @@ struct TsdfLayerDev {
   uint32_t* rgba;              // [max_blocks][vps^3]
   int32_t* lut;                // dense [dim.z][dim.y][dim.x]: slot, -1 free, -2 being allocated, -3 pool exhausted
   int32_t* block_index;        // [max_blocks][3]
-  uint8_t* touched;            // [max_blocks]
   int32_t* n_blocks;           // allocation counter
   unsigned long long* dropped; // updates lost to box / pool limits
   int32_t lut_min[3], lut_dim[3];
@@ -397,7 +403,6 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(TsdfLayerDev L, Tsd
             if (bx != last_b[0] || by != last_b[1] || bz != last_b[2]) {
               last_slot = get_or_allocate_block(L, bx, by, bz);
               last_b[0] = bx; last_b[1] = by; last_b[2] = bz;
-              if (last_slot >= 0) L.touched[last_slot] = 1;
             }
             if (last_slot < 0) {
               ++my_dropped;
@@ -442,14 +447,67 @@ __global__ __launch_bounds__(256) void tsdf_unpack_kernel(const unsigned long lo
   weight[i] = __uint_as_float((unsigned)(v >> 32));
 }
 
+// re-boxing: entries of the old block table move to their place in the new (larger) one;
+// "pool exhausted" marks (-3) become free again, the pool has been enlarged meanwhile
+__global__ void tsdf_lut_remap_kernel(const int32_t* __restrict__ old_lut, int3 old_min, int3 old_dim,
+                                      int32_t* __restrict__ new_lut, int3 new_min, int3 new_dim) {
+  const long long cells = (long long)old_dim.x * old_dim.y * old_dim.z;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cells) return;
+  const int x = (int)(i % old_dim.x), y = (int)((i / old_dim.x) % old_dim.y), z = (int)(i / ((long long)old_dim.x * old_dim.y));
+  const int slot = old_lut[i];
+  if (slot < 0) return;
+  const int nx = x + old_min.x - new_min.x, ny = y + old_min.y - new_min.y, nz = z + old_min.z - new_min.z;
+  new_lut[nx + (long long)new_dim.x * (ny + (long long)new_dim.y * nz)] = slot;
+}
+
+__global__ void tsdf_lut_clear_exhausted_kernel(int32_t* __restrict__ lut, long long cells) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cells && lut[i] == -3) lut[i] = -1;
+}
+
+__global__ void tsdf_lut_from_blocks_kernel(const int32_t* __restrict__ block_index, int n, int3 lut_min, int3 lut_dim,
+                                            int32_t* __restrict__ lut) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n) return;
+  const int x = block_index[3 * b] - lut_min.x, y = block_index[3 * b + 1] - lut_min.y, z = block_index[3 * b + 2] - lut_min.z;
+  lut[x + (long long)lut_dim.x * (y + (long long)lut_dim.y * z)] = b;
+}
+
+__global__ __launch_bounds__(256) void tsdf_pack_kernel(const float* __restrict__ distance,
+                                                       const float* __restrict__ weight, size_t n,
+                                                       unsigned long long* __restrict__ voxels) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  voxels[i] = pack_voxel(distance[i], weight[i]);
+}
+
 }  // namespace vgx
 
 using namespace vgx;
+
+struct TsdfStats {  // one device allocation: TsdfLayerDev::n_blocks / ::dropped point into it
+  int32_t n_blocks;
+  int32_t pad;
+  unsigned long long dropped;
+};
 
 struct vgx_tsdf_layer_s {
   vgx_ctx ctx = nullptr;
   TsdfLayerDev dev{};
   size_t lut_cells = 0;
+  TsdfStats* d_stats = nullptr;
+  // What the host knows about the device's allocation counter without waiting for it: the value
+  // as of scan `known_seq` (read back asynchronously after scans) plus an upper bound on what the
+  // scans launched since may have allocated.  known + pending is never below the true count.
+  TsdfStats* h_stats = nullptr;  // pinned
+  hipEvent_t readback_done = nullptr;
+  bool readback_inflight = false;
+  uint64_t scan_seq = 0, inflight_seq = 0, known_seq = 0;
+  int64_t known_blocks = 0;
+  std::vector<std::pair<uint64_t, int64_t>> recent;  // (scan, bound) of scans after known_seq
+  unsigned long long dropped_seen = 0;
+  int64_t growths = 0;  // re-boxings + pool enlargements so far
 };
 
 struct vgx_tsdf_integrator_s {
@@ -460,6 +518,7 @@ struct vgx_tsdf_integrator_s {
   float* d_points = nullptr;  // staging for host-pointer scans
   uint32_t* d_rgba = nullptr;
   long long staging_cap = 0;
+  std::mutex mu;  // one scan at a time per integrator: the staging buffers belong to the scan in flight
 };
 
 extern "C" {
@@ -481,52 +540,247 @@ void vgx_tsdf_config_default(vgx_tsdf_config* c) {
   c->clear_checks_every_n_frames = 1;
 }
 
+// ---------------------------------------------------------------------------
+// layer storage: (re)allocation helpers, all on the context's stream
+// ---------------------------------------------------------------------------
+namespace {
+
+constexpr int32_t kDefaultPoolBlocks = 256;
+
+size_t voxels_per_block(const TsdfLayerDev& d) { return (size_t)d.vps * d.vps * d.vps; }
+
+// New pool of `blocks` blocks: the first `used` blocks keep their contents, the rest is zero
+// (a fresh voxblox block: distance 0, weight 0, colour 0).  Stream-ordered; the old arrays are
+// released once the copies have run.
+int grow_pool(vgx_tsdf_layer L, int32_t blocks, int32_t used) {
+  vgx_ctx ctx = L->ctx;
+  TsdfLayerDev& d = L->dev;
+  const size_t vpb = voxels_per_block(d);
+  unsigned long long* voxels = nullptr;
+  uint32_t* rgba = nullptr;
+  int32_t* block_index = nullptr;
+  bool ok = hipMalloc(&voxels, (size_t)blocks * vpb * 8) == hipSuccess &&
+            hipMalloc(&rgba, (size_t)blocks * vpb * 4) == hipSuccess &&
+            hipMalloc(&block_index, (size_t)blocks * 12) == hipSuccess;
+  if (ok) {
+    const size_t keep = (size_t)used * vpb;
+    ok = (keep == 0 || (hipMemcpyAsync(voxels, d.voxels, keep * 8, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess &&
+                        hipMemcpyAsync(rgba, d.rgba, keep * 4, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess &&
+                        hipMemcpyAsync(block_index, d.block_index, (size_t)used * 12, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess)) &&
+         hipMemsetAsync(voxels + keep, 0, ((size_t)blocks * vpb - keep) * 8, ctx->stream) == hipSuccess &&
+         hipMemsetAsync(rgba + keep, 0, ((size_t)blocks * vpb - keep) * 4, ctx->stream) == hipSuccess &&
+         hipStreamSynchronize(ctx->stream) == hipSuccess;
+  }
+  if (!ok) {
+    void* fresh[] = {voxels, rgba, block_index};
+    for (void* q : fresh)
+      if (q) (void)hipFree(q);
+    (void)hipGetLastError();
+    return set_error(ctx, VGX_ERR_NOMEM, "TSDF layer: block pool allocation failed (" + std::to_string(blocks) + " blocks)");
+  }
+  void* old[] = {d.voxels, d.rgba, d.block_index};
+  for (void* q : old)
+    if (q) (void)hipFree(q);
+  d.voxels = voxels;
+  d.rgba = rgba;
+  d.block_index = block_index;
+  d.max_blocks = blocks;
+  return VGX_OK;
+}
+
+// New block table over [mn, mn + dm): existing entries move over, everything else is free.
+int rebox(vgx_tsdf_layer L, const int32_t mn[3], const int32_t dm[3]) {
+  vgx_ctx ctx = L->ctx;
+  TsdfLayerDev& d = L->dev;
+  size_t cells = 1;
+  for (int a = 0; a < 3; ++a) cells *= (size_t)dm[a];
+  if (cells > ((size_t)1 << 28))
+    return set_error(ctx, VGX_ERR_UNSUPPORTED, "TSDF layer: block box exceeds 2^28 cells (dense lookup table)");
+  int32_t* lut = nullptr;
+  if (hipMalloc(&lut, cells * 4) != hipSuccess)
+    return set_error(ctx, VGX_ERR_NOMEM, "TSDF layer: block table allocation failed");
+  hipError_t e = hipMemsetAsync(lut, 0xff, cells * 4, ctx->stream);
+  if (e == hipSuccess && d.lut && L->lut_cells > 0) {
+    hipLaunchKernelGGL(tsdf_lut_remap_kernel, dim3((unsigned)((L->lut_cells + 255) / 256)), dim3(256), 0, ctx->stream,
+                       d.lut, make_int3(d.lut_min[0], d.lut_min[1], d.lut_min[2]),
+                       make_int3(d.lut_dim[0], d.lut_dim[1], d.lut_dim[2]), lut, make_int3(mn[0], mn[1], mn[2]),
+                       make_int3(dm[0], dm[1], dm[2]));
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    (void)hipFree(lut);
+    return set_error(ctx, VGX_ERR_HIP, std::string("TSDF layer: re-boxing failed: ") + hipGetErrorString(e));
+  }
+  if (d.lut) (void)hipFree(d.lut);
+  d.lut = lut;
+  L->lut_cells = cells;
+  for (int a = 0; a < 3; ++a) {
+    d.lut_min[a] = mn[a];
+    d.lut_dim[a] = dm[a];
+  }
+  return VGX_OK;
+}
+
+// exact counters, waiting for the stream (rare: growth decisions, stats, download)
+int read_stats_sync(vgx_tsdf_layer L, TsdfStats* out) {
+  vgx_ctx ctx = L->ctx;
+  VGX_HIP(ctx, hipSetDevice(ctx->device));
+  VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  VGX_HIP(ctx, hipMemcpy(out, L->d_stats, sizeof(TsdfStats), hipMemcpyDeviceToHost));
+  L->known_blocks = out->n_blocks;
+  L->known_seq = L->scan_seq;
+  L->recent.clear();
+  L->readback_inflight = false;
+  L->dropped_seen = out->dropped;
+  return VGX_OK;
+}
+
+// non-blocking: adopt the counters an earlier asynchronous read-back has delivered meanwhile
+void poll_readback(vgx_tsdf_layer L) {
+  if (!L->readback_inflight || hipEventQuery(L->readback_done) != hipSuccess) return;
+  L->readback_inflight = false;
+  L->known_blocks = L->h_stats->n_blocks;
+  L->known_seq = L->inflight_seq;
+  L->dropped_seen = L->h_stats->dropped;
+  size_t keep = 0;
+  for (auto& r : L->recent)
+    if (r.first > L->known_seq) L->recent[keep++] = r;
+  L->recent.resize(keep);
+}
+
+// Before a scan whose rays start at `origin` (layer frame) and reach at most `reach` metres: the
+// block table covers every block the scan can touch and the pool can hold all of them.
+int reserve_for_scan(vgx_tsdf_layer L, const float origin[3], float reach) {
+  vgx_ctx ctx = L->ctx;
+  TsdfLayerDev& d = L->dev;
+  poll_readback(L);
+  if (L->dropped_seen != 0)
+    return set_error(ctx, VGX_ERR_NOMEM, "TSDF layer: " + std::to_string(L->dropped_seen) +
+                                             " voxel updates were dropped by an earlier scan (allocation failed)");
+  const float bs = (float)d.vps * d.voxel_size, bs_inv = 1.0f / bs;
+  int32_t lo[3], hi[3];
+  for (int a = 0; a < 3; ++a) {
+    lo[a] = (int32_t)std::floor((origin[a] - reach) * bs_inv) - 1;
+    hi[a] = (int32_t)std::floor((origin[a] + reach) * bs_inv) + 1;
+  }
+  // upper bound on the blocks this scan can allocate: the blocks that come within `reach` of the
+  // origin (about half of the bounding cube; a few thousand cells to test)
+  int64_t bound = 0;
+  for (int32_t z = lo[2]; z <= hi[2]; ++z)
+    for (int32_t y = lo[1]; y <= hi[1]; ++y)
+      for (int32_t x = lo[0]; x <= hi[0]; ++x) {
+        const int32_t b[3] = {x, y, z};
+        float d2 = 0.0f;
+        for (int a = 0; a < 3; ++a) {
+          const float mn = (float)b[a] * bs, mx = mn + bs;
+          const float g = origin[a] < mn ? mn - origin[a] : (origin[a] > mx ? origin[a] - mx : 0.0f);
+          d2 += g * g;
+        }
+        if (d2 <= (reach + bs * 0.01f) * (reach + bs * 0.01f)) ++bound;
+      }
+  // 1. the box
+  bool inside = L->lut_cells > 0;
+  for (int a = 0; a < 3 && inside; ++a) inside = lo[a] >= d.lut_min[a] && hi[a] < d.lut_min[a] + d.lut_dim[a];
+  if (!inside) {
+    int32_t mn[3], dm[3];
+    for (int a = 0; a < 3; ++a) {
+      int32_t nlo = lo[a], nhi = hi[a];
+      if (L->lut_cells > 0) {
+        nlo = std::min(nlo, d.lut_min[a]);
+        nhi = std::max(nhi, d.lut_min[a] + d.lut_dim[a] - 1);
+      }
+      // half a reach of slack on the side that grew: a moving sensor re-boxes every few metres, not every scan
+      const int32_t slack = std::max<int32_t>(2, (hi[a] - lo[a]) / 4);
+      if (L->lut_cells == 0 || nlo < d.lut_min[a]) nlo -= slack;
+      if (L->lut_cells == 0 || nhi > d.lut_min[a] + d.lut_dim[a] - 1) nhi += slack;
+      mn[a] = nlo;
+      dm[a] = nhi - nlo + 1;
+    }
+    int rc = rebox(L, mn, dm);
+    if (rc != VGX_OK) return rc;
+    ++L->growths;
+  }
+  // 2. the pool: known + what earlier, not yet reported scans may have taken + this scan's reach
+  int64_t pending = 0;
+  for (auto& r : L->recent) pending += r.second;
+  if (L->known_blocks + pending + bound > (int64_t)d.max_blocks) {
+    TsdfStats st{};
+    int rc = read_stats_sync(L, &st);  // exact count; also drains the stream
+    if (rc != VGX_OK) return rc;
+    if (st.dropped != 0)
+      return set_error(ctx, VGX_ERR_NOMEM, "TSDF layer: voxel updates were dropped (allocation failed)");
+    if ((int64_t)st.n_blocks + bound > (int64_t)d.max_blocks) {
+      // room for this scan and five more of the same reach before the host has to look again
+      // (it normally learns the true count from the asynchronous read-backs), at least doubling
+      const int64_t want = std::max<int64_t>(2 * (int64_t)d.max_blocks, (int64_t)st.n_blocks + 6 * bound);
+      if (want > INT32_MAX) return set_error(ctx, VGX_ERR_UNSUPPORTED, "TSDF layer: more than 2^31 blocks");
+      rc = grow_pool(L, (int32_t)want, st.n_blocks);
+      if (rc != VGX_OK) return rc;
+      hipLaunchKernelGGL(tsdf_lut_clear_exhausted_kernel, dim3((unsigned)((L->lut_cells + 255) / 256)), dim3(256), 0,
+                         ctx->stream, d.lut, (long long)L->lut_cells);
+      VGX_HIP(ctx, hipGetLastError());
+      ++L->growths;
+    }
+  }
+  L->recent.emplace_back(++L->scan_seq, bound);
+  return VGX_OK;
+}
+
+// after a scan's kernel: ask for the counters without waiting for them
+void request_readback(vgx_tsdf_layer L) {
+  if (L->readback_inflight) return;
+  vgx_ctx ctx = L->ctx;
+  if (hipMemcpyAsync(L->h_stats, L->d_stats, sizeof(TsdfStats), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+      hipEventRecord(L->readback_done, ctx->stream) != hipSuccess) {
+    (void)hipGetLastError();
+    return;  // the synchronous path still works
+  }
+  L->readback_inflight = true;
+  L->inflight_seq = L->scan_seq;
+}
+
+}  // namespace
+
 int vgx_tsdf_layer_create(vgx_ctx ctx, float voxel_size, int32_t vps, const int32_t lut_min[3],
                           const int32_t lut_dim[3], int32_t max_blocks, vgx_tsdf_layer* out) {
-  if (!ctx || !out || !lut_min || !lut_dim) return VGX_ERR_INVALID;
+  if (!ctx || !out) return VGX_ERR_INVALID;
   *out = nullptr;
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (vps != 8 && vps != 16)
     return set_error(ctx, VGX_ERR_UNSUPPORTED, "vgx_tsdf_layer_create: voxels_per_side must be 8 or 16");
-  size_t cells = 1;
-  for (int a = 0; a < 3; ++a) {
-    if (lut_dim[a] <= 0) return set_error(ctx, VGX_ERR_INVALID, "vgx_tsdf_layer_create: empty block box");
-    cells *= (size_t)lut_dim[a];
-  }
-  if (!(voxel_size > 0) || max_blocks <= 0 || cells > ((size_t)1 << 28))
-    return set_error(ctx, VGX_ERR_INVALID, "vgx_tsdf_layer_create: bad voxel_size / max_blocks / box");
+  if ((lut_min == nullptr) != (lut_dim == nullptr))
+    return set_error(ctx, VGX_ERR_INVALID, "vgx_tsdf_layer_create: lut_min and lut_dim come together");
+  if (lut_dim)
+    for (int a = 0; a < 3; ++a)
+      if (lut_dim[a] <= 0) return set_error(ctx, VGX_ERR_INVALID, "vgx_tsdf_layer_create: empty block box");
+  if (!(voxel_size > 0)) return set_error(ctx, VGX_ERR_INVALID, "vgx_tsdf_layer_create: bad voxel_size");
+  if (max_blocks <= 0) max_blocks = kDefaultPoolBlocks;
   VGX_HIP(ctx, hipSetDevice(ctx->device));
   vgx_tsdf_layer L = new (std::nothrow) vgx_tsdf_layer_s();
   if (!L) return set_error(ctx, VGX_ERR_NOMEM, "vgx_tsdf_layer_create: out of host memory");
   L->ctx = ctx;
-  L->lut_cells = cells;
   TsdfLayerDev& d = L->dev;
-  for (int a = 0; a < 3; ++a) {
-    d.lut_min[a] = lut_min[a];
-    d.lut_dim[a] = lut_dim[a];
-  }
-  d.max_blocks = max_blocks;
   d.vps = vps;
   d.vps_shift = vps == 16 ? 4 : 3;
   d.voxel_size = voxel_size;
   d.voxel_size_inv = 1.0f / voxel_size;
-  const size_t nvox = (size_t)max_blocks * vps * vps * vps;
-  bool ok = hipMalloc(&d.voxels, nvox * 8) == hipSuccess && hipMalloc(&d.rgba, nvox * 4) == hipSuccess &&
-            hipMalloc(&d.lut, cells * 4) == hipSuccess &&
-            hipMalloc(&d.block_index, (size_t)max_blocks * 12) == hipSuccess &&
-            hipMalloc(&d.touched, (size_t)max_blocks) == hipSuccess &&
-            hipMalloc(&d.n_blocks, 4) == hipSuccess && hipMalloc(&d.dropped, 8) == hipSuccess;
-  if (ok)
-    ok = hipMemsetAsync(d.voxels, 0, nvox * 8, ctx->stream) == hipSuccess &&
-         hipMemsetAsync(d.rgba, 0, nvox * 4, ctx->stream) == hipSuccess &&
-         hipMemsetAsync(d.lut, 0xff, cells * 4, ctx->stream) == hipSuccess &&
-         hipMemsetAsync(d.touched, 0, (size_t)max_blocks, ctx->stream) == hipSuccess &&
-         hipMemsetAsync(d.n_blocks, 0, 4, ctx->stream) == hipSuccess &&
-         hipMemsetAsync(d.dropped, 0, 8, ctx->stream) == hipSuccess &&
-         hipStreamSynchronize(ctx->stream) == hipSuccess;
-  if (!ok) {
+  int rc = VGX_OK;
+  if (hipMalloc(&L->d_stats, sizeof(TsdfStats)) != hipSuccess ||
+      hipHostMalloc((void**)&L->h_stats, sizeof(TsdfStats), hipHostMallocDefault) != hipSuccess ||
+      hipEventCreateWithFlags(&L->readback_done, hipEventDisableTiming) != hipSuccess ||
+      hipMemsetAsync(L->d_stats, 0, sizeof(TsdfStats), ctx->stream) != hipSuccess)
+    rc = set_error(ctx, VGX_ERR_NOMEM, "vgx_tsdf_layer_create: device allocation failed");
+  if (rc == VGX_OK) {
+    d.n_blocks = &L->d_stats->n_blocks;
+    d.dropped = &L->d_stats->dropped;
+    rc = grow_pool(L, max_blocks, 0);
+  }
+  // the box is only an initial reservation: scans re-box the table as they need (reserve_for_scan)
+  if (rc == VGX_OK && lut_min) rc = rebox(L, lut_min, lut_dim);
+  if (rc != VGX_OK) {
     vgx_tsdf_layer_destroy(L);
-    return set_error(ctx, VGX_ERR_NOMEM, "vgx_tsdf_layer_create: device allocation failed");
+    return rc;
   }
   *out = L;
   return VGX_OK;
@@ -537,26 +791,27 @@ int vgx_tsdf_layer_destroy(vgx_tsdf_layer L) {
   (void)hipSetDevice(L->ctx->device);
   (void)hipStreamSynchronize(L->ctx->stream);
   TsdfLayerDev& d = L->dev;
-  void* ptrs[] = {d.voxels, d.rgba, d.lut, d.block_index, d.touched, d.n_blocks, d.dropped};
+  void* ptrs[] = {d.voxels, d.rgba, d.lut, d.block_index, L->d_stats};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  if (L->h_stats) (void)hipHostFree(L->h_stats);
+  if (L->readback_done) (void)hipEventDestroy(L->readback_done);
   delete L;
   return VGX_OK;
 }
 
 int vgx_tsdf_layer_stats(vgx_tsdf_layer L, int32_t* n_blocks, int64_t* dropped) {
   if (!L) return VGX_ERR_INVALID;
-  vgx_ctx ctx = L->ctx;
-  VGX_HIP(ctx, hipSetDevice(ctx->device));
-  VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  int32_t nb = 0;
-  unsigned long long dr = 0;
-  VGX_HIP(ctx, hipMemcpy(&nb, L->dev.n_blocks, 4, hipMemcpyDeviceToHost));
-  VGX_HIP(ctx, hipMemcpy(&dr, L->dev.dropped, 8, hipMemcpyDeviceToHost));
-  if (n_blocks) *n_blocks = nb;
-  if (dropped) *dropped = (int64_t)dr;
+  std::lock_guard<std::mutex> lk(L->ctx->mu);
+  TsdfStats st{};
+  int rc = read_stats_sync(L, &st);
+  if (rc != VGX_OK) return rc;
+  if (n_blocks) *n_blocks = st.n_blocks;
+  if (dropped) *dropped = (int64_t)st.dropped;
   return VGX_OK;
 }
+
+int64_t vgx_tsdf_layer_growths(vgx_tsdf_layer L) { return L ? L->growths : -1; }
 
 int vgx_tsdf_layer_download(vgx_tsdf_layer L, int32_t* block_index, float* distance, float* weight,
                             uint8_t* rgba) {
@@ -566,7 +821,8 @@ int vgx_tsdf_layer_download(vgx_tsdf_layer L, int32_t* block_index, float* dista
   int rc = vgx_tsdf_layer_stats(L, &nb, nullptr);
   if (rc != VGX_OK) return rc;
   if (nb == 0) return VGX_OK;
-  const size_t nvox = (size_t)L->dev.vps * L->dev.vps * L->dev.vps;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  const size_t nvox = voxels_per_block(L->dev);
   if (block_index)
     VGX_HIP(ctx, hipMemcpy(block_index, L->dev.block_index, (size_t)nb * 12, hipMemcpyDeviceToHost));
   if (distance || weight) {
@@ -579,6 +835,69 @@ int vgx_tsdf_layer_download(vgx_tsdf_layer L, int32_t* block_index, float* dista
     }
   }
   if (rgba) VGX_HIP(ctx, hipMemcpy(rgba, L->dev.rgba, (size_t)nb * nvox * 4, hipMemcpyDeviceToHost));
+  return VGX_OK;
+}
+
+// Replaces the layer's contents with host blocks (a voxblox::Layer<TsdfVoxel> handed over, e.g. a
+// submap that already holds data when the GPU integrator takes over).
+int vgx_tsdf_layer_upload(vgx_tsdf_layer L, int32_t n_blocks, const int32_t* block_index, const float* distance,
+                          const float* weight, const uint8_t* rgba) {
+  if (!L || n_blocks < 0) return VGX_ERR_INVALID;
+  vgx_ctx ctx = L->ctx;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (n_blocks > 0 && (!block_index || !distance || !weight))
+    return set_error(ctx, VGX_ERR_INVALID, "vgx_tsdf_layer_upload: NULL arrays");
+  VGX_HIP(ctx, hipSetDevice(ctx->device));
+  VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  TsdfLayerDev& d = L->dev;
+  const size_t vpb = voxels_per_block(d);
+  // box of the uploaded blocks (with a little slack); the old table is dropped, not remapped
+  int32_t mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+  for (int b = 0; b < n_blocks; ++b)
+    for (int a = 0; a < 3; ++a) {
+      const int32_t v = block_index[3 * b + a];
+      if (b == 0 || v < mn[a]) mn[a] = v;
+      if (b == 0 || v > mx[a]) mx[a] = v;
+    }
+  if (d.lut) (void)hipFree(d.lut);
+  d.lut = nullptr;
+  L->lut_cells = 0;
+  int rc = VGX_OK;
+  if (n_blocks > 0) {
+    int32_t dm[3];
+    for (int a = 0; a < 3; ++a) {
+      mn[a] -= 2;
+      dm[a] = mx[a] - mn[a] + 3;
+    }
+    rc = rebox(L, mn, dm);
+  }
+  if (rc == VGX_OK) rc = grow_pool(L, std::max<int32_t>(d.max_blocks, n_blocks + kDefaultPoolBlocks), 0);
+  if (rc != VGX_OK) return rc;
+  if (n_blocks > 0) {
+    const size_t nv = (size_t)n_blocks * vpb;
+    DeviceScratch sd, sw;
+    VGX_HIP(ctx, sd.alloc(nv * 4));
+    VGX_HIP(ctx, sw.alloc(nv * 4));
+    VGX_HIP(ctx, hipMemcpy(sd.p, distance, nv * 4, hipMemcpyHostToDevice));
+    VGX_HIP(ctx, hipMemcpy(sw.p, weight, nv * 4, hipMemcpyHostToDevice));
+    VGX_HIP(ctx, hipMemcpy(d.block_index, block_index, (size_t)n_blocks * 12, hipMemcpyHostToDevice));
+    if (rgba) VGX_HIP(ctx, hipMemcpy(d.rgba, rgba, nv * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(tsdf_pack_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, ctx->stream,
+                       sd.as<float>(), sw.as<float>(), nv, d.voxels);
+    hipLaunchKernelGGL(tsdf_lut_from_blocks_kernel, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, ctx->stream,
+                       d.block_index, (int)n_blocks, make_int3(d.lut_min[0], d.lut_min[1], d.lut_min[2]),
+                       make_int3(d.lut_dim[0], d.lut_dim[1], d.lut_dim[2]), d.lut);
+    VGX_HIP(ctx, hipGetLastError());
+  }
+  TsdfStats st{};
+  st.n_blocks = n_blocks;
+  VGX_HIP(ctx, hipMemcpyAsync(L->d_stats, &st, sizeof(st), hipMemcpyHostToDevice, ctx->stream));
+  VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  L->known_blocks = n_blocks;
+  L->known_seq = L->scan_seq;
+  L->recent.clear();
+  L->readback_inflight = false;
+  L->dropped_seen = 0;
   return VGX_OK;
 }
 
@@ -693,9 +1012,9 @@ static int reset_set(vgx_ctx ctx, unsigned long long* set, unsigned long long* o
   return VGX_OK;
 }
 
-int vgx_tsdf_integrate_device(vgx_tsdf_integrator I, const float T[7], const void* d_points,
-                              const void* d_rgba, int64_t n, int32_t freespace, int64_t* n_updates) {
-  if (!I || !T || n < 0 || (n > 0 && !d_points)) return VGX_ERR_INVALID;
+// integratePointCloud with the scan already in device memory; the caller holds I->mu.
+static int integrate_locked(vgx_tsdf_integrator I, const float T[7], const void* d_points, const void* d_rgba,
+                            int64_t n, int32_t freespace, int64_t* n_updates) {
   vgx_ctx ctx = I->ctx;
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (!I->layer) return set_error(ctx, VGX_ERR_INVALID, "vgx_tsdf_integrate: no layer set");
@@ -709,6 +1028,14 @@ int vgx_tsdf_integrate_device(vgx_tsdf_integrator I, const float T[7], const voi
   }
   if (n_updates) VGX_HIP(ctx, hipMemsetAsync(I->dev.n_updates, 0, 8, ctx->stream));
   if (n > 0) {
+    // Every voxel a ray of this scan can touch lies within max_ray_length + truncation of the
+    // sensor origin (a longer return is a clearing ray cut at max_ray_length, RayCaster [recalled]);
+    // two voxels of slack cover the f32 rounding of the ray ends.
+    const vgx_tsdf_config& c = I->dev.cfg;
+    const float origin[3] = {T[4], T[5], T[6]};
+    const float reach = c.max_ray_length_m + c.default_truncation_distance + 2.0f * I->layer->dev.voxel_size;
+    int rc = reserve_for_scan(I->layer, origin, reach);
+    if (rc != VGX_OK) return rc;
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
     static const bool pipelined = [] {
       const char* e = getenv("VGX_TSDF_PIPELINED");  // A/B switch (profiles/ab_tsdf.sh)
@@ -723,6 +1050,7 @@ int vgx_tsdf_integrate_device(vgx_tsdf_integrator I, const float T[7], const voi
                          T[0], T[1], T[2], T[3], T[4], T[5], T[6], (const float*)d_points,
                          (const uint32_t*)d_rgba, (long long)n, (int)freespace);
     VGX_HIP(ctx, hipGetLastError());
+    request_readback(I->layer);
   }
   if (n_updates) {
     unsigned long long u = 0;
@@ -733,10 +1061,20 @@ int vgx_tsdf_integrate_device(vgx_tsdf_integrator I, const float T[7], const voi
   return VGX_OK;
 }
 
+int vgx_tsdf_integrate_device(vgx_tsdf_integrator I, const float T[7], const void* d_points,
+                              const void* d_rgba, int64_t n, int32_t freespace, int64_t* n_updates) {
+  if (!I || !T || n < 0 || (n > 0 && !d_points)) return VGX_ERR_INVALID;
+  std::lock_guard<std::mutex> own(I->mu);
+  return integrate_locked(I, T, d_points, d_rgba, n, freespace, n_updates);
+}
+
 int vgx_tsdf_integrate(vgx_tsdf_integrator I, const float T[7], const float* points, const uint8_t* rgba,
                        int64_t n, int32_t freespace, int64_t* n_updates) {
   if (!I || !T || n < 0 || (n > 0 && !points)) return VGX_ERR_INVALID;
   vgx_ctx ctx = I->ctx;
+  // the staging buffers are this scan's from the upload to the launch: two threads calling the
+  // same integrator are serialised here, not interleaved between the two steps
+  std::lock_guard<std::mutex> own(I->mu);
   {
     std::lock_guard<std::mutex> lk(ctx->mu);
     VGX_HIP(ctx, hipSetDevice(ctx->device));
@@ -758,7 +1096,7 @@ int vgx_tsdf_integrate(vgx_tsdf_integrator I, const float T[7], const float* poi
     }
   }
   int64_t upd = 0;
-  int rc = vgx_tsdf_integrate_device(I, T, I->d_points, rgba ? I->d_rgba : nullptr, n, freespace, &upd);
+  int rc = integrate_locked(I, T, I->d_points, rgba ? I->d_rgba : nullptr, n, freespace, &upd);
   if (n_updates) *n_updates = upd;
   return rc;
 }
