@@ -14,8 +14,8 @@
 //
 // Header-only, against voxblox's public API [recalled: Layer::allocateBlockPtrByIndex,
 // getAllAllocatedBlocks, getBlockByIndex; Block::getVoxelByLinearIndex, num_voxels, has_data(),
-// updated(); TsdfVoxel{distance, weight, color}; Color{r,g,b,a}]; compiled in this repository
-// against the stand-in headers of oracle/ref_shims by oracle/ref_driver/tsdf_dropin_check.cpp.
+// updated(); TsdfVoxel{distance, weight, color}; Color{r,g,b,a}]; exercised in this repository by
+// the in-process TSDF drop-in check (tests/test_tsdf_dropin_gpu.py).
 #ifndef VOXGRAPH_AMD_CPP_GPU_TSDF_LAYER_BRIDGE_H_
 #define VOXGRAPH_AMD_CPP_GPU_TSDF_LAYER_BRIDGE_H_
 
