@@ -211,45 +211,70 @@ def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=2):
             poses.append(np.array([np.cos(yaw / 2), 0, 0, np.sin(yaw / 2), *origin], np.float32))
             clouds.append(pts_c)
         n_pts = clouds[0].shape[0]
-        layer = capi.TsdfLayer(ctx, vs, 16, bmin, bdim, int(np.prod(bdim)))
+        reach = kw["max_ray_length_m"] + kw["default_truncation_distance"] + 2 * vs
+
+        def new_layer():
+            # unbounded layer; room for the whole sweep is reserved up front so that no timed
+            # scan pays for an enlargement (scans would reserve for themselves otherwise)
+            lay = capi.TsdfLayer(ctx, vs, 16)
+            for k in (0, scans - 1):
+                lay.reserve(poses[k][4:7], reach)
+            return lay
+
+        layer = new_layer()
         integ = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(**kw), layer)
         dev = [torch.from_numpy(c_).cuda() for c_ in clouds]
         torch.cuda.synchronize()
         integ.integrate_device(poses[0], dev[0].data_ptr(), None, n_pts)        # warm-up scan
         ctx.synchronize()
+        g0 = layer.growths()
         updates = 0
         ctx.timer_start()
         for k in range(1, scans):
             integ.integrate_device(poses[k], dev[k].data_ptr(), None, n_pts)
         ms = ctx.timer_stop()
-        # second pass only to count voxel updates (the count needs a sync per scan)
-        layer2 = capi.TsdfLayer(ctx, vs, 16, bmin, bdim, int(np.prod(bdim)))
+        grew = layer.growths() - g0
+        # second pass: voxel updates per scan (the count needs a sync per scan) and, with the stream
+        # drained around every launch, the duration of each scan's kernel by itself (HIP events)
+        layer2 = new_layer()
         integ.setLayer(layer2)
+        kernel_ms = 0.0
+        for k in range(scans):
+            ctx.synchronize()
+            ctx.timer_start()
+            integ.integrate_device(poses[k], dev[k].data_ptr(), None, n_pts)
+            t_k = ctx.timer_stop()
+            kernel_ms += t_k if k >= 1 else 0.0
+        kernel_ms /= (scans - 1)
+        layer2b = new_layer()
+        integ.setLayer(layer2b)
         for k in range(scans):
             u_ = integ.integrate_device(poses[k], dev[k].data_ptr(), None, n_pts, count=True)
             updates += u_ if k >= 1 else 0
         n_blocks, dropped = layer.stats()
         # heaviest case: the first scan into an empty layer with a fresh integrator (no
         # previously observed voxels: every ray runs to its early-out or to the sensor)
-        layer3 = capi.TsdfLayer(ctx, vs, 16, bmin, bdim, int(np.prod(bdim)))
+        layer3 = new_layer()
         integ3 = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(**kw), layer3)
         ctx.synchronize()
         ctx.timer_start()
         integ3.integrate_device(poses[0], dev[0].data_ptr(), None, n_pts)
         first_ms = ctx.timer_stop()
-        layer4 = capi.TsdfLayer(ctx, vs, 16, bmin, bdim, int(np.prod(bdim)))
+        layer4 = new_layer()
         integ4 = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(**kw), layer4)
         first_updates = integ4.integrate_device(poses[0], dev[0].data_ptr(), None, n_pts, count=True)
-        for o in (integ3, integ4, layer3, layer4):
+        for o in (integ3, integ4, layer3, layer4, layer2b):
             o.destroy()
-        # the drop-in call itself: host pointers (pageable), PCIe upload included, returns when done
-        layer5 = capi.TsdfLayer(ctx, vs, 16, bmin, bdim, int(np.prod(bdim)))
+        # the drop-in call itself: host pointers (pageable), PCIe upload included, returns when done;
+        # layer created the way voxblox creates one (no reservation at all)
+        layer5 = capi.TsdfLayer(ctx, vs, 16)
         integ5 = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(**kw), layer5)
         integ5.integratePointCloud(poses[0], clouds[0])
         h0 = time.perf_counter()
         for k in range(1, scans):
             integ5.integratePointCloud(poses[k], clouds[k])
         host_ms = (time.perf_counter() - h0) * 1e3 / (scans - 1)
+        host_growths = layer5.growths()
         for o in (integ5, layer5):
             o.destroy()
         # CPU oracle on a bounded sample (single thread: the restatement is serial)
@@ -261,15 +286,27 @@ def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=2):
             cu += oi.integratePointCloud(poses[k], clouds[k])
         cdt = time.perf_counter() - t0
         timed = scans - 1
+        alg_bytes_scan = 16.0 * n_pts + 24.0 * updates / timed
         out[name] = {"points_per_scan": n_pts, "scans_timed": timed, "ms_per_scan": ms / timed,
                      "Mpoints_per_s": n_pts * timed / ms / 1e3,
                      "Mvoxel_updates_per_s": updates / ms / 1e3,
                      "voxel_updates_per_scan": updates / timed, "blocks": n_blocks,
-                     "dropped_updates": dropped,
-                     "algorithmic_GBs": (16.0 * n_pts * timed + 24.0 * updates) / ms / 1e6,
+                     "dropped_updates": dropped, "layer_enlargements_in_timed_region": grew,
+                     "algorithmic_GBs": alg_bytes_scan * timed / ms / 1e6,
+                     # the TSDF kernel is latency bound (one dependent L2 round trip per DDA step of
+                     # the longest ray), nowhere near the HBM roofline: reported for completeness
+                     "roofline": {"bound": "hbm", "kernel": "tsdf_integrate_kernel<true>",
+                                  "kernel_ms": kernel_ms,
+                                  "kernel_ms_how": "HIP events around each scan's launch, stream drained before",
+                                  "bytes_per_launch": alg_bytes_scan,
+                                  "achieved": alg_bytes_scan / kernel_ms / 1e6, "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": alg_bytes_scan / kernel_ms / 1e6 / HBM_PEAK_GBS,
+                                  "back_to_back_ms_per_scan": ms / timed,
+                                  "back_to_back_over_kernel": (ms / timed) / kernel_ms},
                      "host_pointer_call": {"ms_per_scan": host_ms, "Mpoints_per_s": n_pts / host_ms / 1e3,
-                                           "note": "vgx_tsdf_integrate: pageable host points, PCIe upload and "
-                                                   "completion wait included"},
+                                           "layer_enlargements": host_growths,
+                                           "note": "vgx_tsdf_integrate into an unreserved layer: pageable host "
+                                                   "points, PCIe upload, enlargements and completion wait included"},
                      "first_scan": {"ms": first_ms, "voxel_updates": first_updates,
                                     "Mvoxel_updates_per_s": first_updates / first_ms / 1e3,
                                     "algorithmic_GBs": (16.0 * n_pts + 24.0 * first_updates) / first_ms / 1e6},

@@ -406,6 +406,10 @@ VGX_API int vgx_tsdf_layer_destroy(vgx_tsdf_layer layer);
  * scans in flight. */
 VGX_API int vgx_tsdf_layer_stats(vgx_tsdf_layer layer, int32_t* n_blocks,
                                  int64_t* dropped_updates);
+/* Optional: make room NOW for scans taken from around `origin` (layer frame) that reach up to
+ * reach_m metres (max_ray_length + truncation), so that the first scans there do not pay for the
+ * enlargement.  Scans reserve for themselves anyway. */
+VGX_API int vgx_tsdf_layer_reserve(vgx_tsdf_layer layer, const float origin[3], float reach_m);
 /* how often the layer has enlarged its block table or pool so far (diagnostics) */
 VGX_API int64_t vgx_tsdf_layer_growths(vgx_tsdf_layer layer);
 /* block_index[n][3], distance / weight [n][vps^3], rgba [n][vps^3][4]; any may be NULL */

@@ -135,6 +135,7 @@ SIGNATURES = {
     "vgx_tsdf_layer_create": (C.c_int, [vp, C.c_float, C.c_int32, i32p, i32p, C.c_int32, C.POINTER(vp)]),
     "vgx_tsdf_layer_destroy": (C.c_int, [vp]),
     "vgx_tsdf_layer_stats": (C.c_int, [vp, i32p, i64p]),
+    "vgx_tsdf_layer_reserve": (C.c_int, [vp, f32p, C.c_float]),
     "vgx_tsdf_layer_growths": (C.c_int64, [vp]),
     "vgx_tsdf_layer_download": (C.c_int, [vp, i32p, f32p, f32p, u8p]),
     "vgx_tsdf_layer_upload": (C.c_int, [vp, C.c_int32, i32p, f32p, f32p, u8p]),
@@ -621,6 +622,10 @@ class TsdfLayer:
 
     def growths(self):
         return int(self.ctx.lib.vgx_tsdf_layer_growths(self.h))
+
+    def reserve(self, origin, reach_m):
+        o = _f32(origin)
+        self.ctx.check(self.ctx.lib.vgx_tsdf_layer_reserve(self.h, _ptr(o, f32p), float(reach_m)))
 
     def upload(self, block_index, distance, weight, rgba=None):
         bi = np.ascontiguousarray(block_index, np.int32).reshape(-1, 3)

@@ -711,9 +711,10 @@ int reserve_for_scan(vgx_tsdf_layer L, const float origin[3], float reach) {
     if (st.dropped != 0)
       return set_error(ctx, VGX_ERR_NOMEM, "TSDF layer: voxel updates were dropped (allocation failed)");
     if ((int64_t)st.n_blocks + bound > (int64_t)d.max_blocks) {
-      // room for this scan and five more of the same reach before the host has to look again
-      // (it normally learns the true count from the asynchronous read-backs), at least doubling
-      const int64_t want = std::max<int64_t>(2 * (int64_t)d.max_blocks, (int64_t)st.n_blocks + 6 * bound);
+      // room for this scan and fifteen more of the same reach queued behind it before the host has
+      // to wait for the true count (at sensor rates it learns it from the asynchronous read-backs
+      // long before), at least doubling.  48 KB per block: ~1 GB for 16 m LiDAR rays at 0.2 m.
+      const int64_t want = std::max<int64_t>(2 * (int64_t)d.max_blocks, (int64_t)st.n_blocks + 16 * bound);
       if (want > INT32_MAX) return set_error(ctx, VGX_ERR_UNSUPPORTED, "TSDF layer: more than 2^31 blocks");
       rc = grow_pool(L, (int32_t)want, st.n_blocks);
       if (rc != VGX_OK) return rc;
@@ -812,6 +813,16 @@ int vgx_tsdf_layer_stats(vgx_tsdf_layer L, int32_t* n_blocks, int64_t* dropped) 
 }
 
 int64_t vgx_tsdf_layer_growths(vgx_tsdf_layer L) { return L ? L->growths : -1; }
+
+int vgx_tsdf_layer_reserve(vgx_tsdf_layer L, const float origin[3], float reach_m) {
+  if (!L || !origin || !(reach_m >= 0)) return VGX_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(L->ctx->mu);
+  VGX_HIP(L->ctx, hipSetDevice(L->ctx->device));
+  int rc = reserve_for_scan(L, origin, reach_m);
+  // nothing was launched: the bound just booked must not count as a scan in flight
+  if (rc == VGX_OK && !L->recent.empty()) L->recent.pop_back();
+  return rc;
+}
 
 int vgx_tsdf_layer_download(vgx_tsdf_layer L, int32_t* block_index, float* distance, float* weight,
                             uint8_t* rgba) {
