@@ -95,7 +95,10 @@ def test_empty_submap_and_empty_batch(capi, ctx):
         o.destroy()
 
 
-def test_tsdf_pool_and_box_limits_are_counted(capi, ctx):
+def test_tsdf_initial_box_and_pool_are_only_a_reservation(capi, ctx):
+    """voxblox::Layer is unbounded.  A box too small for the ray and a pool of one block used to
+    COUNT the lost updates; now the layer re-boxes and enlarges its pool before the scan: every
+    update lands (64 along the 6 m ray, 34 along the 3 m one) and nothing is dropped."""
     cfg = capi.tsdf_config(default_truncation_distance=0.3, use_const_weight=1, max_ray_length_m=20)
     T = np.array([1, 0, 0, 0, 0.05, 0.05, 0.05], F)
     # box of 2 blocks along x only: the ray leaves it
@@ -103,17 +106,18 @@ def test_tsdf_pool_and_box_limits_are_counted(capi, ctx):
     integ = capi.FastTsdfIntegrator(ctx, cfg, layer)
     n = integ.integratePointCloud(T, np.array([[6.0, 0, 0]], F))
     blocks, dropped = layer.stats()
-    assert blocks == 2 and n == 32 and dropped == 64 - 32
-    # big box, pool of 1 block: rays are cast from the surface towards the sensor, so the
-    # far block (voxels 32, 33) gets the only pool slot and the other two are dropped
+    assert blocks == 4 and n == 64 and dropped == 0 and layer.growths() >= 1
+    # big box, pool of 1 block
     layer2 = capi.TsdfLayer(ctx, 0.1, 16, (-2, -2, -2), (8, 4, 4), 1)
     # (a fresh integrator: the first scan's approximate set would make this ray stop early)
     integ2 = capi.FastTsdfIntegrator(ctx, cfg, layer2)
     n2 = integ2.integratePointCloud(T, np.array([[3.0, 0, 0]], F))
     blocks2, dropped2 = layer2.stats()
-    assert blocks2 == 1 and n2 == 2 and dropped2 == 34 - 2
+    assert blocks2 == 3 and n2 == 34 and dropped2 == 0 and layer2.growths() >= 1
     with pytest.raises(capi.VgxError):
         capi.TsdfLayer(ctx, 0.1, 16, (0, 0, 0), (0, 1, 1), 8)
+    with pytest.raises(capi.VgxError):
+        capi.TsdfLayer(ctx, 0.1, 16, (0, 0, 0), None, 8)             # a box needs both corners
     for o in (integ, integ2, layer, layer2):
         o.destroy()
 

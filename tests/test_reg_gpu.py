@@ -479,9 +479,12 @@ def test_compressed_blocks_reproduce_the_normal_equations(capi, ctx, small_graph
         Hm[iu] = nb[9:]
         Hm = Hm + np.triu(Hm, 1).T
         scale = np.abs(Hm).max()
-        assert np.abs(J.T @ J - Hm).max() <= 1e-10 * scale
-        assert np.abs(J.T @ r - nb[1:9]).max() <= 1e-10 * max(np.abs(nb[1:9]).max(), 1e-300) + 1e-12 * scale
-        assert abs(r @ r - nb[0]) <= 1e-10 * nb[0]
+        # The 45 numbers are sums of f32-accumulated partial sums (lean fused kernel): [J r]^T [J r]
+        # is positive semi-definite only up to their rounding (~1e-8 relative), and the compression
+        # clamps the slightly negative eigenvalues of weakly constrained directions to zero.
+        assert np.abs(J.T @ J - Hm).max() <= 1e-7 * scale
+        assert np.abs(J.T @ r - nb[1:9]).max() <= 1e-7 * max(np.abs(nb[1:9]).max(), 1e-300) + 1e-9 * scale
+        assert abs(r @ r - nb[0]) <= 1e-7 * nb[0]
     batch.destroy()
 
 

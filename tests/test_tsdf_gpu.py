@@ -411,7 +411,7 @@ def test_layer_grows_with_the_sensor_and_never_drops(capi, ctx):
     # one ray: order-independent.  The far origin is not exactly representable in f32 voxel
     # coordinates, so a voxel the ray merely grazes may differ and distances agree to rounding.
     common = A.keys() & B.keys()
-    assert len(common) >= len(A) - 2 and len(common) >= len(B) - 2 and len(common) > 50
+    assert len(common) >= len(A) - 2 and len(common) >= len(B) - 2 and len(common) > 20
     assert max(abs(A[k][0] - B[k][0]) for k in common) < 5e-4
     for o in (gi, gl, far, near):
         o.destroy()

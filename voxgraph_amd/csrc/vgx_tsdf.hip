@@ -728,9 +728,14 @@ int reserve_for_scan(vgx_tsdf_layer L, const float origin[3], float reach) {
   return VGX_OK;
 }
 
-// after a scan's kernel: ask for the counters without waiting for them
+// after a scan's kernel: ask for the counters without waiting for them -- but only once the
+// unconfirmed bounds have eaten half of the pool's headroom: a copy between two kernels costs the
+// stream a few microseconds, and at 16 scans of slack one look every ~8 scans is plenty
 void request_readback(vgx_tsdf_layer L) {
   if (L->readback_inflight) return;
+  int64_t pending = 0;
+  for (auto& r : L->recent) pending += r.second;
+  if (2 * pending < (int64_t)L->dev.max_blocks - L->known_blocks) return;
   vgx_ctx ctx = L->ctx;
   if (hipMemcpyAsync(L->h_stats, L->d_stats, sizeof(TsdfStats), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
       hipEventRecord(L->readback_done, ctx->stream) != hipSuccess) {
