@@ -1,0 +1,43 @@
+/*
+ * voxgraph_amd_bench.h -- benchmark / test tooling exported by libvoxgraph_amd.so that is NOT part
+ * of the drop-in boundary (include/voxgraph_amd.h): synthetic scenes generated on the device so that
+ * bench.py and the tests can fill 200 submaps of 256^3 voxels without a host round trip.  Nothing in
+ * the reference corresponds to these entry points and an integration never calls them.
+ */
+#ifndef VOXGRAPH_AMD_BENCH_H_
+#define VOXGRAPH_AMD_BENCH_H_
+
+#include "voxgraph_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Fills a dense
+ * block_dims[0..2] cube of blocks starting at block_min with the analytic
+ * "city" scene of oracle/synth.py (ground plane + one box building per 25.6 m
+ * cell, seeded), sampled at the submap's true pose {x,y,z,yaw}, entirely on the
+ * device: TSDF = clamp(d, +-truncation) with weight tsdf_weight where
+ * |d| <= 2*truncation else 0; ESDF = clamp(d, +-esdf_max), observed iff
+ * |d| <= esdf_max.  Builds the ESDF sampling grid (and the TSDF one when
+ * build_tsdf_grid != 0). */
+VGX_API int vgx_synth_city_submap(vgx_ctx ctx, int32_t submap_id, float voxel_size,
+                                  int32_t voxels_per_side, const int32_t block_min[3],
+                                  const int32_t block_dims[3], float truncation,
+                                  float esdf_max, float tsdf_weight,
+                                  const double true_pose[4], uint32_t seed,
+                                  int32_t build_tsdf_grid, vgx_submap* out);
+
+/* One OS1-like LiDAR scan (n_el rings x n_az azimuth steps, elevation
+ * -el_span/2 .. +el_span/2 rad) of the same analytic city scene, sphere-traced on the
+ * device from sensor pose {x,y,z,yaw} (world frame).  Writes n_el*n_az points in the
+ * SENSOR frame (float3, DEVICE pointer); rays that hit nothing within max_range get
+ * length max_range * 2 (so they become clearing rays / are dropped like real returns). */
+VGX_API int vgx_synth_city_scan(vgx_ctx ctx, const double sensor_pose[4], int32_t n_az,
+                                int32_t n_el, float el_span, float max_range, uint32_t seed,
+                                void* d_points_C);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOXGRAPH_AMD_BENCH_H_ */

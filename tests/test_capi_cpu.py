@@ -18,8 +18,8 @@ def capi():
     return capi
 
 
-def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "voxgraph_amd.h")).read()
+def _declared_symbols(headers=("voxgraph_amd.h", "voxgraph_amd_bench.h")):
+    text = "".join(open(os.path.join(ROOT, "include", h)).read() for h in headers)
     return sorted(set(re.findall(r"VGX_API\s+[\w\s\*]+?\b(vgx_\w+)\s*\(", text)))
 
 
@@ -29,8 +29,12 @@ def test_library_exports_every_declared_symbol(capi):
     assert len(declared) >= 30
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in voxgraph_amd.h but not exported"
-    # and the ctypes table covers the header exactly
+    # and the ctypes table covers the headers exactly
     assert sorted(capi.SIGNATURES) == declared
+    # benchmark tooling lives in its own header, not in the drop-in boundary
+    boundary = _declared_symbols(("voxgraph_amd.h",))
+    assert not [n for n in boundary if "synth" in n]
+    assert sorted(set(declared) - set(boundary)) == ["vgx_synth_city_scan", "vgx_synth_city_submap"]
 
 
 def test_only_c_abi_symbols_are_exported(capi):
@@ -77,7 +81,7 @@ def test_header_is_plain_c(tmp_path):
     """the boundary is a C ABI: include/voxgraph_amd.h must compile as C99 (no C++ism, no torch /
     Ceres / Eigen types) and as C++"""
     src = tmp_path / "hdr.c"
-    src.write_text('#include "voxgraph_amd.h"\nint main(void) { vgx_reg_config c; vgx_tsdf_config t; '
+    src.write_text('#include "voxgraph_amd.h"\n#include "voxgraph_amd_bench.h"\nint main(void) { vgx_reg_config c; vgx_tsdf_config t; '
                    'vgx_map_file_submap_info i; (void)c; (void)t; (void)i; return 0; }\n')
     inc = os.path.join(ROOT, "include")
     subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", inc,

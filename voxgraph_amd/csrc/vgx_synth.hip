@@ -5,6 +5,7 @@
 #include <cmath>
 
 #include "vgx_internal.h"
+#include "voxgraph_amd_bench.h"
 
 #pragma clang fp contract(off)
 
