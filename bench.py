@@ -337,6 +337,136 @@ def finish_bench(capi, ctx, args, true_poses):
     return out
 
 
+def config5_bench(capi, ctx, torch, dist, use_dist, rank, world, args):
+    """BASELINE configs[4]: 1000 submaps @ 128^3 on a loop (serpentine) trajectory, odometry edges
+    with accumulated drift, 20 injected loop-closure relative-pose edges
+    (PoseGraphInterface::addLoopClosureMeasurement, pose_graph_interface.cpp:68-92) and the
+    reference's two-stage optimisation (PoseGraphInterface::optimize, :177-198: loop closures are
+    new, so first optimise WITHOUT the registration constraints, then with all of them).
+    Constraints pair-sharded over the ranks; one all-reduce per solver evaluation."""
+    from harness import lm
+    from harness.backends import GpuBackend
+    n_lanes, per_lane = args.config5_grid
+    n = n_lanes * per_lane
+    rng = np.random.default_rng(4)                                 # SURVEY.md 8d: seed 4
+    vs, dims, bmin = 0.2, (8, 8, 8), (-4, -4, -2)                   # 128^3 voxels, 25.6 m cubes
+    dx, dy = 12.8, 19.2                                             # 50 % overlap along a lane, 25 % across
+
+    def idx(lane, q):                                               # path index of x-position q in a lane
+        return lane * per_lane + (q if lane % 2 == 0 else per_lane - 1 - q)
+    true = np.zeros((n, 4))
+    for lane in range(n_lanes):
+        for q in range(per_lane):
+            true[idx(lane, q)] = [q * dx, lane * dy, 0.0, rng.uniform(-0.1, 0.1)]
+    pairs = [(i, i + 1) for i in range(n - 1)]
+    for lane in range(n_lanes - 1):
+        for q in range(per_lane):
+            for dq in (-1, 0, 1):
+                if 0 <= q + dq < per_lane:
+                    a, b = idx(lane, q), idx(lane + 1, q + dq)
+                    if abs(a - b) > 1:
+                        pairs.append((min(a, b), max(a, b)))
+    pairs = np.array(sorted(set(pairs)), np.int32)
+
+    def between(pa, pb):
+        c, s_ = np.cos(pa[3]), np.sin(pa[3])
+        d = pb[:3] - pa[:3]
+        return np.array([c * d[0] + s_ * d[1], -s_ * d[0] + c * d[1], d[2], lm.normalize_angle(pb[3] - pa[3])])
+
+    def compose(pose, delta):
+        c, s_ = np.cos(pose[3]), np.sin(pose[3])
+        return np.array([pose[0] + c * delta[0] - s_ * delta[1], pose[1] + s_ * delta[0] + c * delta[1],
+                         pose[2] + delta[2], lm.normalize_angle(pose[3] + delta[3])])
+    # odometry: good in z and yaw (the yaml's information 2500 = sigma 0.02), drifting in x, y
+    sig = np.array([0.02, 0.02, 0.002, 1e-4])
+    info_odo = [1.0, 1.0, 2500.0, 2500.0]                            # voxgraph_mapper.yaml:41-47
+    info_lc = [100.0, 100.0, 2500.0, 2500.0]                         # not in the yaml (template is zero): 0.1 m
+    poses0 = true[:1].copy()
+    edges = []
+    for k in range(n - 1):
+        delta = between(true[k], true[k + 1]) + rng.normal(0, sig)
+        edges.append(lm.RelativePoseEdge(k, k + 1, delta[:3], delta[3], info_odo))
+        poses0 = np.vstack([poses0, compose(poses0[k], delta)])
+    n_lc = 20
+    for j in range(n_lc):
+        lane = 1 + (j * (n_lanes - 1)) // n_lc
+        q = (7 * j + 3) % per_lane
+        a, b = idx(lane - 1, q), idx(lane, q)
+        delta = between(true[a], true[b]) + rng.normal(0, [0.05, 0.05, 0.01, 0.002])
+        edges.append(lm.RelativePoseEdge(a, b, delta[:3], delta[3], info_lc))
+
+    t0 = time.perf_counter()
+    submaps, n_points = [], []
+    for k in range(n):
+        sm = capi.Submap.synth_city(ctx, k, vs, 16, bmin, dims, args.truncation, args.esdf_max, 10.0,
+                                    true[k], args.seed)
+        n_points.append(sm.extract_voxel_points(1.0, 0.3, True))
+        sm.release_raw_layers()
+        submaps.append(sm)
+    ctx.synchronize()
+    setup_s = time.perf_counter() - t0
+    cfg = capi.default_config(registration_point_type=capi.POINTS_VOXELS)
+    mine = lpt_shards([n_points[a] for a, _ in pairs], world)[rank]
+    cfs = [capi.RegistrationCostFunction(ctx, submaps[pairs[c][0]], submaps[pairs[c][1]], cfg) for c in mine]
+    batch = capi.RegistrationBatch(ctx, cfs, pairs[mine], global_index=mine, n_global=len(pairs))
+    backend = GpuBackend(capi, ctx, batch, n, dist if use_dist else None)
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+
+    def rmse(p):
+        return float(np.sqrt(((p[:, :3] - true[:, :3]) ** 2).sum(1).mean()))
+    kw = dict(parameter_tolerance=1e-10, max_seconds=1e9)            # Ceres-default function_tolerance decides
+    lm.optimize_two_stage(backend, n, pairs, edges, poses0, True, **kw)      # untimed warm-up
+    torch.cuda.synchronize()
+    barrier()
+    s0 = time.perf_counter()
+    x, summaries = lm.optimize_two_stage(backend, n, pairs, edges, poses0, True, **kw)
+    torch.cuda.synchronize()
+    barrier()
+    sdt = torch.tensor([time.perf_counter() - s0], dtype=torch.float64, device="cuda")
+    # stage 1 alone, for the intermediate error
+    x1, _ = lm.solve(lm.Problem(lm.zero_registration_backend(n, len(pairs)), n, pairs, edges), poses0, **kw)
+    # one fused evaluation of every registration constraint at the initial guess, timed by itself
+    for _ in range(2):
+        backend(poses0)
+    torch.cuda.synchronize()
+    barrier()
+    e0 = time.perf_counter()
+    for _ in range(10):
+        backend(poses0)
+    torch.cuda.synchronize()
+    barrier()
+    edt = torch.tensor([(time.perf_counter() - e0) / 10], dtype=torch.float64, device="cuda")
+    rs = torch.tensor([float(batch.num_residuals())], dtype=torch.float64, device="cuda")
+    if use_dist:
+        dist.all_reduce(sdt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(edt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rs, op=dist.ReduceOp.SUM)
+    out = {"workload": f"configs[4]: {n} submaps @ 128^3 (0.2 m) on a serpentine loop trajectory "
+                       f"({n_lanes} lanes x {per_lane}), {len(pairs)} registration constraints (kVoxels, all points), "
+                       f"{n - 1} odometry edges with accumulated drift, {n_lc} injected loop-closure edges; "
+                       "two-stage optimisation (pose_graph_interface.cpp:177-198)",
+           "submaps": n, "registration_constraints": int(len(pairs)), "loop_closures": n_lc,
+           "residuals_per_evaluation": float(rs.item()),
+           "solve_ms": float(sdt.item()) * 1e3,
+           "stage1_without_registration": {k: summaries[0][k] for k in ("iterations", "evaluations", "termination")},
+           "stage2_all_constraints": {k: summaries[1][k] for k in ("iterations", "evaluations", "termination",
+                                                                  "initial_cost", "final_cost")},
+           "registration_evaluation_ms": float(edt.item()) * 1e3,
+           "position_rmse_m_odometry": rmse(poses0), "position_rmse_m_after_stage1": rmse(x1),
+           "position_rmse_m_after": rmse(x),
+           "stop_rule": "function_tolerance 1e-6 (Ceres default) in both stages, parameter_tolerance off",
+           "parallelism": f"pair-sharded x{world} (LPT), submaps replicated, one all-reduce of "
+                          f"{capi.fused_size(n, len(pairs)) * 8} B per evaluation",
+           "setup_s": setup_s,
+           "solver": "harness/lm.py (LM, banded Cholesky on the host; Ceres absent)"}
+    for o in [batch] + cfs + submaps:
+        o.destroy()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -365,7 +495,13 @@ def main():
     ap.add_argument("--no-solve", action="store_true")
     ap.add_argument("--no-tsdf", action="store_true")
     ap.add_argument("--pipeline", action="store_true",
-                    help="also run the config-2 stand-in (30-submap LiDAR session, harness/pipeline.py)")
+                    help="run the config-2 stand-in at full length (30 submaps x 100 scans, harness/pipeline.py) "
+                         "instead of the bounded one (10 submaps x 30 scans) the default line carries")
+    ap.add_argument("--no-config2", action="store_true")
+    ap.add_argument("--no-config5", action="store_true")
+    ap.add_argument("--config", type=int, default=3, choices=[3, 5],
+                    help="5: only BASELINE configs[4] (1000 submaps @ 128^3, loop closures, two-stage solve)")
+    ap.add_argument("--config5-grid", type=int, nargs=2, default=[25, 40], help="lanes x submaps per lane")
     ap.add_argument("--calibrate", action="store_true",
                     help="PMC calibration: first launch evaluates poses 10 km apart, so every "
                          "evaluation reads exactly 20 B and writes exactly 36 B (profiles/README.md)")
@@ -420,6 +556,17 @@ def main():
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
+
+    if args.config == 5:
+        c5 = config5_bench(capi, ctx, torch, dist, use_dist, rank, world, args)
+        if rank == 0:
+            print(json.dumps({"metric": "full pose-graph solve ms (1000 submaps, two-stage)", "value": c5["solve_ms"],
+                              "unit": "ms", "n_gpus": world, "higher_is_better": False, "scaling": "strong",
+                              "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": c5}))
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     true_poses, poses, pairs = build_graph(args)
     n_sub, n_con = len(true_poses), len(pairs)
@@ -802,10 +949,24 @@ def main():
     if rank == 0 and world == 1 and not args.no_tsdf:
         out["tsdf"] = tsdf_bench(capi, ctx, torch)
         out["finish_submap"] = finish_bench(capi, ctx, args, true_poses)
-    if rank == 0 and world == 1 and args.pipeline:
+    # config 5 (every rank takes part: its constraints are sharded like config 3's)
+    if not args.no_config5:
+        for o in [batch] + cfs + ([fo["batch"]] + cfs_fo if fo else []) + submaps:
+            o.destroy()                                            # make room: config 5 brings its own 1000 submaps
+        del residuals, jac_ref, jac_read
+        torch.cuda.empty_cache()
+        c5 = config5_bench(capi, ctx, torch, dist, use_dist, rank, world, args)
+        if rank == 0:
+            out["config5"] = c5
+    if rank == 0 and world == 1 and not args.no_config2:
         from harness import pipeline
-        # 30 submaps, 10 Hz, 10 s per submap = 100 scans per submap
-        out["pipeline_config2"] = pipeline.run(capi, ctx, torch, n_submaps=30, scans_per_submap=100)
+        # 30 submaps, 10 Hz, 10 s per submap = 100 scans per submap; the
+        # default line carries a bounded cut of the same session (10 submaps x 30 scans)
+        full = args.pipeline
+        out["pipeline_config2"] = pipeline.run(capi, ctx, torch, n_submaps=30 if full else 10,
+                                               scans_per_submap=100 if full else 30)
+        out["pipeline_config2"]["cut"] = "full: 30 submaps x 100 scans" if full else \
+            "bounded: 10 submaps x 30 scans of the 30 x 100 session (python bench.py --pipeline runs all of it)"
     if rank == 0:
         print(json.dumps(out))
     if use_dist:

@@ -11,7 +11,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SMALL = ["--grid", "4", "3", "--block-dims", "4", "4", "4", "--block-min", "-2", "-2", "-1",
-         "--steps", "2", "--warmup", "1", "--no-tsdf"]
+         "--steps", "2", "--warmup", "1", "--no-tsdf", "--config5-grid", "3", "5"]
 
 pytestmark = pytest.mark.gpu
 
@@ -48,6 +48,17 @@ def test_single_gpu_line_has_the_contract_fields(single):
         assert 0 < f["algorithmic_GBs"] <= d["roofline"]["peak"]
         assert f["with_correspondence"] <= f["loaded_after_culling"] <= f["evaluations"]
     assert d["config"]["passes_per_step"] == 10 and d["value_with_correspondence"] <= d["value"]
+    # the shipped yaml's configuration (sampled, mirrored isosurface constraints) in one batched pass
+    assert d["shipped_config"]["constraints"] == 2 * d["config"]["constraints"]
+    assert d["shipped_config"]["ms_per_evaluation"] > 0 and d["shipped_config"]["cost"] > 0
+    # configs[4] in miniature: loop closures + two-stage optimisation improve on the odometry
+    c5 = d["config5"]
+    assert c5["submaps"] == 15 and c5["loop_closures"] == 20 and c5["solve_ms"] > 0
+    assert c5["position_rmse_m_after"] < c5["position_rmse_m_odometry"]
+    assert c5["stage1_without_registration"]["evaluations"] >= 1
+    # configs[1] stand-in, bounded cut
+    c2 = d["pipeline_config2"]
+    assert c2["submaps"] == 10 and c2["dropped_updates"] == 0 and c2["solves"] == 9
 
 
 def test_two_rank_path_dry_run_on_one_gpu(single):
@@ -66,3 +77,7 @@ def test_two_rank_path_dry_run_on_one_gpu(single):
     assert abs(d["solve"]["final_cost"] - single["solve"]["final_cost"]) <= 1e-9 * single["solve"]["final_cost"]
     assert abs(d["solve"]["position_rmse_m_after"] - single["solve"]["position_rmse_m_after"]) < 1e-7
     assert abs(d["fused"]["cost"] - single["fused"]["cost"]) <= 1e-9 * single["fused"]["cost"]
+    # config 5 sharded over two ranks is the single-rank solve
+    for k in ("stage1_without_registration", "stage2_all_constraints"):
+        assert d["config5"][k]["iterations"] == single["config5"][k]["iterations"], k
+    assert abs(d["config5"]["position_rmse_m_after"] - single["config5"]["position_rmse_m_after"]) < 1e-7
