@@ -73,10 +73,6 @@ def run(capi, ctx, torch, n_submaps=30, scans_per_submap=20, n_az=1024, n_el=64,
         xy = corners[i] + d * s0
         sensor_poses.append([xy[0], xy[1], 2.0, float(np.arctan2(d[1], d[0])) + 0.02 * np.sin(0.3 * s)])
     sensor_poses = np.array(sensor_poses)
-    bs = 16 * voxel_size
-    reach = 16.0 + scans_per_submap * step_m
-    nb_xy = int(np.ceil(reach / bs)) + 1
-    box_min, box_dim = (-nb_xy, -nb_xy, -2), (2 * nb_xy, 2 * nb_xy, 7)
     pts = torch.empty((n_az * n_el, 3), dtype=torch.float32, device="cuda")
     submaps, true_poses = [], []
     t_integrate = t_finish = 0.0
@@ -87,7 +83,11 @@ def run(capi, ctx, torch, n_submaps=30, scans_per_submap=20, n_az=1024, n_el=64,
         P = sensor_poses[first].copy()
         P[2] = 0.0                                            # submap origin on the ground under the sensor
         true_poses.append(P)
-        layer = capi.TsdfLayer(ctx, voxel_size, 16, box_min, box_dim, int(np.prod(box_dim)))
+        # voxblox::Layer semantics: no box, no pool size; room for the stretch this submap will
+        # cover is reserved up front so that no timed scan pays for an enlargement
+        layer = capi.TsdfLayer(ctx, voxel_size, 16)
+        for j in (first, first + scans_per_submap - 1):
+            layer.reserve(_inv_compose(P, sensor_poses[j])[4:7], 16.0 + 0.6 + 2 * voxel_size)
         integ = capi.FastTsdfIntegrator(ctx, cfg, layer)
         for j in range(first, first + scans_per_submap):
             capi.synth_city_scan(ctx, sensor_poses[j], n_az, n_el, el_span, 40.0, 2, pts.data_ptr())
