@@ -48,15 +48,11 @@ def _inv_compose(pose_a, pose_b):
     return np.array([np.cos(yaw / 2), 0, 0, np.sin(yaw / 2), *t], np.float32)
 
 
-def run(capi, ctx, torch, n_submaps=30, scans_per_submap=20, n_az=1024, n_el=64, voxel_size=0.2,
-        step_m=None, seed=1, drift_sigma=(0.12, 0.008), solve_kw=None, verbose=False,
-        use_esdf_distance=False, isosurface_points=True):
-    rng = np.random.default_rng(seed)
-    cfg = capi.voxgraph_tsdf_config()                         # voxgraph_mapper.yaml:21-28
-    el_span = np.deg2rad(33.2)                                # OS1-64
-    # one lap around a 2 x 1 block of city cells along the (always free) cell boundaries:
-    # the streets run in both directions, so x and y are both observable somewhere, and
-    # the last submaps see the first ones again (loop closure through the overlap test)
+def session_sensor_poses(n_submaps, scans_per_submap, step_m=None):
+    """Sensor poses {x, y, z, yaw} of the session: one lap around a 2 x 1 block of city cells along
+    the (always free) cell boundaries: the streets run in both directions, so x and y are both
+    observable somewhere, and the last submaps see the first ones again (loop closure through the
+    overlap test)."""
     cell = 25.6
     corners = np.array([[0.0, 0.0], [2 * cell, 0.0], [2 * cell, cell], [0.0, cell], [0.0, 0.0]])
     seg = np.linalg.norm(np.diff(corners, axis=0), axis=1)
@@ -72,7 +68,17 @@ def run(capi, ctx, torch, n_submaps=30, scans_per_submap=20, n_az=1024, n_el=64,
         d = (corners[i + 1] - corners[i]) / seg[i]
         xy = corners[i] + d * s0
         sensor_poses.append([xy[0], xy[1], 2.0, float(np.arctan2(d[1], d[0])) + 0.02 * np.sin(0.3 * s)])
-    sensor_poses = np.array(sensor_poses)
+    return np.array(sensor_poses)
+
+
+def run(capi, ctx, torch, n_submaps=30, scans_per_submap=20, n_az=1024, n_el=64, voxel_size=0.2,
+        step_m=None, seed=1, drift_sigma=(0.12, 0.008), solve_kw=None, verbose=False,
+        use_esdf_distance=False, isosurface_points=True):
+    rng = np.random.default_rng(seed)
+    cfg = capi.voxgraph_tsdf_config()                         # voxgraph_mapper.yaml:21-28
+    el_span = np.deg2rad(33.2)                                # OS1-64
+    sensor_poses = session_sensor_poses(n_submaps, scans_per_submap, step_m)
+    n_scans_total = len(sensor_poses)
     pts = torch.empty((n_az * n_el, 3), dtype=torch.float32, device="cuda")
     submaps, true_poses = [], []
     t_integrate = t_finish = 0.0
