@@ -74,8 +74,11 @@ def test_esdf_matches_oracle_and_is_an_exact_fixed_point(capi, ctx):
     assert np.array_equal(ed[fixed], sm.tsdf_distance[fixed])
     diff = np.abs(ed - od)[oo.astype(bool)]
     print("ESDF GPU vs oracle: max", diff.max(), "p99", np.percentile(diff, 99), "passes", passes)
-    # the oracle ignores improvements below min_diff_m = 1 mm per hop; the GPU does not
-    assert diff.max() < 0.02 and np.all(np.abs(ed) <= np.abs(od) + 1e-6)
+    # the oracle (voxblox's queue) ignores improvements below min_diff_m = 1 mm; the GPU result is
+    # the exact fixed point: equal to f32 rounding almost everywhere, within ~2 min_diff_m where
+    # the queue stopped early, never above it (measured on LiDAR-built submaps:
+    # profiles/r02_chain_compare_*.json, max 1.8 mm, p99 1e-7)
+    assert diff.max() < 2.5e-3 and np.percentile(diff, 99) < 1e-5 and np.all(np.abs(ed) <= np.abs(od) + 1e-6)
     err, n_free = _check_fixed_point(sm.block_index, sm.tsdf_distance, ed, eo, sm.voxel_size, sm.vps)
     assert n_free > 10000 and err < 1e-6, err
     # unobserved TSDF voxels stay unobserved; the sampling grid was rebuilt and is usable
@@ -101,7 +104,7 @@ def test_esdf_sparse_blocks_and_sign_separation(capi, ctx):
                                    orc.esdf_config(max_distance_m=1.0, default_distance_m=1.0,
                                                    min_distance_m=0.15))
     assert np.array_equal(eo, oo)
-    assert np.abs(ed - od)[oo.astype(bool)].max() < 0.02
+    assert np.abs(ed - od)[oo.astype(bool)].max() < 2.5e-3
     obs = oo.astype(bool)
     assert np.array_equal(np.sign(ed[obs]), np.sign(sm.tsdf_distance[obs]))
     err, _ = _check_fixed_point(sm.block_index, sm.tsdf_distance, ed, eo, sm.voxel_size, sm.vps, 0.15, 1.0, 1.0)
