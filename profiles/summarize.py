@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Turns the rocprofv3 CSVs collected by profiles/collect.sh into the committed
-summaries: profiles/rNN_kernel_stats.json, profiles/rNN_pmc_hbm.json,
-profiles/rNN_pmc_fused.json and profiles/hbm_traffic.json (read by bench.py for
-roofline.traffic), and copies the raw CSVs next to them.
+"""Turns the rocprofv3 CSVs collected by profiles/collect.sh into the committed summaries:
+profiles/rNN_kernel_stats.json (per kernel AND per workload: dispatches are grouped by grid size),
+profiles/rNN_pmc_hbm.json, profiles/rNN_pmc_fused.json, profiles/rNN_sq_breakdown.json and
+profiles/hbm_traffic.json (read by bench.py for roofline.traffic), and copies the raw CSVs.
 
 HBM bytes, following MI355X_MICROARCH.md "HBM":
   reads  : FETCH_SIZE is RDREQ x 64 B on gfx950, i.e. half of a stream of 128-B requests.  Instead
@@ -16,6 +16,7 @@ HBM bytes, following MI355X_MICROARCH.md "HBM":
 Reads are NOT calibrated against "20 B per point": constraints that share a reference submap
 re-read its points out of L2 / Infinity Cache, so the true fabric read volume is below that."""
 import argparse
+import collections
 import csv
 import glob
 import json
@@ -23,7 +24,7 @@ import os
 import shutil
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL, FUSED = "reg_eval_points_kernel", "reg_eval_reduce_kernel"
+KERNEL, FUSED, TSDF = "reg_eval_points_kernel", "reg_eval_reduce", "tsdf_integrate_kernel"
 
 
 def rows(pattern):
@@ -35,11 +36,12 @@ def rows(pattern):
 
 
 def dispatches(prefix, kernel):
-    """[{counter: value}] per dispatch of `kernel`, in dispatch order"""
+    """[{counter: value, "grid": n}] per dispatch of `kernel`, in dispatch order"""
     d = {}
     for x in rows(f"{prefix}/**/*counter_collection.csv"):
         if kernel in x.get("Kernel_Name", ""):
-            d.setdefault(int(x["Dispatch_Id"]), {})[x["Counter_Name"]] = float(x["Counter_Value"])
+            e = d.setdefault(int(x["Dispatch_Id"]), {"grid": int(x["Grid_Size"])})
+            e[x["Counter_Name"]] = float(x["Counter_Value"])
     return [d[k] for k in sorted(d)]
 
 
@@ -58,75 +60,161 @@ def bench_line(name):
 
 
 def mean(v):
-    return sum(v) / len(v)
+    v = list(v)
+    return sum(v) / len(v) if v else None
+
+
+def by_grid(trace, kernel):
+    """kernel-trace rows of one kernel grouped per grid size, in order of first appearance:
+    [(grid, [duration_ns, ...])]"""
+    g = collections.OrderedDict()
+    for x in trace:
+        if kernel in x.get("Kernel_Name", ""):
+            g.setdefault(int(x["Grid_Size_X"]), []).append(int(x["End_Timestamp"]) - int(x["Start_Timestamp"]))
+    return list(g.items())
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--round", default="01")
+    ap.add_argument("--round", default="02")
     a = ap.parse_args()
     tag = f"r{int(a.round):02d}"
     N_CAL = 2                                            # bench.py --calibrate: two far-pose launches
-    # ---- kernel stats of the bench command -----------------------------------
+    # ---- kernel stats of the bench command, per workload -------------------------------------
     stats = rows("prof_stats/**/*kernel_stats.csv")
+    trace = rows("prof_stats/**/*kernel_trace.csv")
     bench = bench_line("prof_stats_bench.json")
-    summ = {"command": "rocprofv3 --kernel-trace --stats -f csv -- python bench.py",
-            "kernels": [{k: v for k, v in x.items()} for x in stats[:12]],
-            "bench_line": bench}
-    avg_ms = {}
-    for x in stats:
-        for k in (KERNEL, FUSED):
-            if k in x.get("Name", ""):
-                avg_ms[k] = float(x.get("AverageNs", 0)) / 1e6
-        if KERNEL in x.get("Name", ""):
-            summ["dominant_kernel"] = {"name": x["Name"], "calls": int(x.get("Calls", 0)),
-                                       "avg_ms_rocprof": avg_ms[KERNEL]}
-            if bench:
-                summ["dominant_kernel"]["avg_ms_bench_hip_events"] = bench["roofline"]["kernel_ms"]
+    summ = {"command": "rocprofv3 --kernel-trace --stats -f csv -- python bench.py --gpus 1 --steps 20 --warmup 5",
+            "kernels": [{k: v for k, v in x.items()} for x in stats[:14]],
+            "bench_line": bench, "per_workload": {}}
+    pw = summ["per_workload"]
+
+    def entry(durs, hip_ms=None, **extra):
+        e = {"calls": len(durs), "avg_ms_rocprof": mean(durs) / 1e6, "min_ms": min(durs) / 1e6, "max_ms": max(durs) / 1e6}
+        if hip_ms is not None:
+            e["avg_ms_bench_hip_events"] = hip_ms
+            e["rocprof_over_hip_events"] = e["avg_ms_rocprof"] / hip_ms
+        e.update(extra)
+        return e
+    pts = by_grid(trace, KERNEL)
+    if bench and len(pts) >= 1:
+        pw["config3_points"] = entry(pts[0][1], bench["roofline"]["kernel_ms"], grid=pts[0][0])
+    if bench and len(pts) >= 2 and bench.get("roofline_full_overlap"):
+        pw["full_overlap_points"] = entry(pts[1][1], bench["roofline_full_overlap"]["kernel_ms"], grid=pts[1][0])
+    red = by_grid(trace, FUSED)
+    names = ["config3_fused", "full_overlap_fused", "shipped_config_fused", "config5_fused"]
+    for (grid, durs), nm in zip(red, names):
+        pw[nm] = entry(durs, grid=grid)
+    if bench and "config3_fused" in pw:
+        pw["config3_fused"]["bench_stream_ms_per_step_incl_finalize_assemble"] = bench["fused"]["stream_ms_per_step"]
+    ts = by_grid(trace, TSDF)
+    if bench and bench.get("tsdf"):
+        for (grid, durs) in ts:
+            for name, v in bench["tsdf"].items():
+                if (v["points_per_scan"] + 255) // 256 * 256 == grid:
+                    e = pw.setdefault("tsdf_" + name, {"grid": grid, "calls": 0, "durs": []})
+                    e["durs"] += durs
+        for k in [k for k in pw if k.startswith("tsdf_")]:
+            durs = pw[k].pop("durs")
+            # steady-state scans only: the first scan of every fresh layer walks every ray to the sensor
+            steady = sorted(durs)[:max(1, int(0.8 * len(durs)))]
+            pw[k] = entry(steady, bench["tsdf"][k[5:]]["roofline"]["kernel_ms"], grid=pw[k]["grid"],
+                          note="fastest 80 % of the dispatches (steady-state scans; first scans into empty layers excluded)",
+                          back_to_back_ms_per_scan=bench["tsdf"][k[5:]]["ms_per_scan"])
+            pw[k]["back_to_back_over_rocprof_kernel"] = pw[k]["back_to_back_ms_per_scan"] / pw[k]["avg_ms_rocprof"]
     json.dump(summ, open(os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.json"), "w"), indent=1)
-    # ---- HBM traffic of the dominant kernel ---------------------------------------
+    # ---- HBM traffic of the dominant kernel, both workloads ---------------------------------------
     rd, fetch, write = dispatches("prof_rd", KERNEL), dispatches("prof_fetch", KERNEL), dispatches("prof_write", KERNEL)
     pmc_bench = bench_line("prof_rd_bench.json")
-    res = {"read_requests_per_dispatch": rd,
-           "fetch_KiB_per_dispatch": [c.get("FETCH_SIZE") for c in fetch],
-           "write_KiB_per_dispatch": [c.get("WRITE_SIZE") for c in write],
-           "calibration_dispatches": N_CAL}
+    res = {"calibration_dispatches": N_CAL}
+    traffic = {}
     if pmc_bench and len(rd) > N_CAL and len(write) > N_CAL:
+        main_grid = rd[0]["grid"]
         R = pmc_bench["roofline"]["units_per_launch"]
         known_w = 36.0 * R
-        cw = known_w / (mean([c["WRITE_SIZE"] for c in write[:N_CAL]]) * 1024.0)
-        fr = mean([read_bytes(c) for c in rd[N_CAL:]])
-        wr = mean([c["WRITE_SIZE"] for c in write[N_CAL:]]) * 1024.0 * cw
-        res.update({"residuals_per_launch": R,
-                    "calibration": {"known_write_bytes": known_w, "write_correction": cw,
-                                    "read_bytes_calibration_launch": mean([read_bytes(c) for c in rd[:N_CAL]]),
-                                    "read_bytes_if_20B_per_point": 20.0 * R},
-                    "hbm_read_bytes_per_launch": fr, "hbm_write_bytes_per_launch": wr,
-                    "hbm_bytes_per_launch": fr + wr, "algorithmic_bytes_88": 88.0 * R, "n_gpus": 1})
-        if len(fetch) > N_CAL:
-            f2 = mean([c["FETCH_SIZE"] for c in fetch[N_CAL:]]) * 1024.0 * 2.0
-            res["fetch_size_x2_bytes"] = f2                 # the guide's "double it": must agree with the exact count
-            res["fetch_size_x2_over_exact"] = f2 / fr
-        if KERNEL in avg_ms:
-            res["hbm_GBs_at_rocprof_avg"] = (fr + wr) / (avg_ms[KERNEL] * 1e-3) / 1e9
-        json.dump({"residuals_per_launch": R, "n_gpus": 1, "hbm_bytes_per_launch": fr + wr,
-                   "source": f"profiles/{tag}_pmc_hbm.json"},
-                  open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
+        cw = known_w / (mean(c["WRITE_SIZE"] for c in write[:N_CAL]) * 1024.0)
+        res["calibration"] = {"known_write_bytes": known_w, "write_correction": cw,
+                              "read_bytes_calibration_launch": mean(read_bytes(c) for c in rd[:N_CAL]),
+                              "read_bytes_if_20B_per_point": 20.0 * R}
+        groups = {"config3": (lambda c: c["grid"] == main_grid, R, pmc_bench["roofline"]["kernel_ms"])}
+        fo = pmc_bench.get("roofline_full_overlap")
+        if fo:
+            groups["full_overlap"] = (lambda c: c["grid"] != main_grid, fo["units_per_launch"], fo["kernel_ms"])
+        for name, (sel, units, hip_ms) in groups.items():
+            r_ = [c for c in rd[N_CAL:] if sel(c)]
+            w_ = [c for c in write[N_CAL:] if sel(c)]
+            f_ = [c for c in fetch[N_CAL:] if sel(c)]
+            if not r_ or not w_:
+                continue
+            fr = mean(read_bytes(c) for c in r_)
+            wr = mean(c["WRITE_SIZE"] for c in w_) * 1024.0 * cw
+            e = {"dispatches": len(r_), "residuals_per_launch": units, "hbm_read_bytes_per_launch": fr,
+                 "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": fr + wr,
+                 "algorithmic_bytes_88": 88.0 * units, "traffic_over_algorithmic_88": (fr + wr) / (88.0 * units),
+                 "kernel_ms_under_pmc_hip_events": hip_ms,
+                 "hbm_GBs_at_pmc_run_kernel_ms": (fr + wr) / (hip_ms * 1e-3) / 1e9}
+            if f_:
+                e["fetch_size_x2_over_exact"] = mean(c["FETCH_SIZE"] for c in f_) * 1024.0 * 2.0 / fr
+            key = name + "_points"
+            if key in pw:
+                e["hbm_GBs_at_rocprof_avg"] = (fr + wr) / (pw[key]["avg_ms_rocprof"] * 1e-3) / 1e9
+            res[name] = e
+            traffic[name] = e
+        if "config3" in traffic:
+            t = {"residuals_per_launch": traffic["config3"]["residuals_per_launch"], "n_gpus": 1,
+                 "hbm_bytes_per_launch": traffic["config3"]["hbm_bytes_per_launch"], "source": f"profiles/{tag}_pmc_hbm.json"}
+            if "full_overlap" in traffic:
+                t["full_overlap"] = {"residuals_per_launch": traffic["full_overlap"]["residuals_per_launch"],
+                                     "hbm_bytes_per_launch": traffic["full_overlap"]["hbm_bytes_per_launch"]}
+            json.dump(t, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
     json.dump(res, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm.json"), "w"), indent=1)
-    # ---- fused kernel --------------------------------------------------------------
+    # ---- fused kernel, both workloads --------------------------------------------------------------
     frd, fwr = dispatches("prof_rd", FUSED), dispatches("prof_write", FUSED)
-    fused = None
-    if frd and fwr and "residuals_per_launch" in res:
-        fused = {"kernel": FUSED, "dispatches": len(frd), "residuals_per_launch": res["residuals_per_launch"],
-                 "read_requests_per_dispatch": frd,
-                 "write_KiB_per_dispatch": [c.get("WRITE_SIZE") for c in fwr], "write_correction": 0.998,
-                 "hbm_read_bytes_per_launch": mean([read_bytes(c) for c in frd]),
-                 "hbm_write_bytes_per_launch": mean([c["WRITE_SIZE"] for c in fwr]) * 1024.0 * 0.998}
-        fused["hbm_bytes_per_launch"] = fused["hbm_read_bytes_per_launch"] + fused["hbm_write_bytes_per_launch"]
-        if FUSED in avg_ms:
-            fused["avg_ms_rocprof"] = avg_ms[FUSED]
-            fused["hbm_GBs"] = fused["hbm_bytes_per_launch"] / (avg_ms[FUSED] * 1e-3) / 1e9
+    fused = {}
+    if frd and fwr and pmc_bench:
+        g0 = frd[0]["grid"]
+        for name, sel, fb in (("config3", lambda c: c["grid"] == g0, pmc_bench.get("fused")),
+                              ("full_overlap", lambda c: c["grid"] != g0,
+                               (pmc_bench.get("roofline_full_overlap") or {}).get("fused"))):
+            r_ = [c for c in frd if sel(c)]
+            w_ = [c for c in fwr if sel(c)]
+            if not r_ or not w_ or not fb:
+                continue
+            e = {"kernel": "reg_eval_reduce_lean_kernel", "dispatches": len(r_),
+                 "hbm_read_bytes_per_launch": mean(read_bytes(c) for c in r_),
+                 "hbm_write_bytes_per_launch": mean(c["WRITE_SIZE"] for c in w_) * 1024.0 * 0.998,
+                 "algorithmic_bytes_per_step": fb["algorithmic_bytes_per_step"],
+                 "evaluations": fb["evaluations"], "with_correspondence": fb["with_correspondence"],
+                 "loaded_after_culling": fb["loaded_after_culling"]}
+            e["hbm_bytes_per_launch"] = e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]
+            e["traffic_over_algorithmic"] = e["hbm_bytes_per_launch"] / e["algorithmic_bytes_per_step"]
+            key = name + "_fused"
+            if key in pw:
+                e["avg_ms_rocprof"] = pw[key]["avg_ms_rocprof"]
+                e["hbm_GBs_at_rocprof_avg"] = e["hbm_bytes_per_launch"] / (e["avg_ms_rocprof"] * 1e-3) / 1e9
+                e["hbm_time_ms_at_8TBs"] = e["hbm_bytes_per_launch"] / 8e12 * 1e3
+                e["frac_of_hbm_time"] = e["hbm_time_ms_at_8TBs"] / e["avg_ms_rocprof"]
+            fused[name] = e
         json.dump(fused, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_fused.json"), "w"), indent=1)
+    # ---- SQ wave-cycle breakdown ---------------------------------------------------------------------
+    d = collections.OrderedDict()
+    for r in rows("prof_sq/**/*counter_collection.csv"):
+        kn = r["Kernel_Name"]
+        k = "fused" if "reduce" in kn else ("tsdf_integrate" if "tsdf" in kn else "materialising")
+        d.setdefault((k, int(r["Grid_Size"])), collections.defaultdict(list))[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    sq = {}
+    for (k, grid), c in d.items():
+        m = {n: sum(v) / len(v) for n, v in c.items()}
+        wc = m.get("SQ_WAVE_CYCLES", 0) or 1
+        sq[f"{k}@grid{grid}"] = {"dispatches": len(next(iter(c.values()))), **m,
+                                 "frac_wait_any": m.get("SQ_WAIT_ANY", 0) / wc,
+                                 "frac_wait_inst_any": m.get("SQ_WAIT_INST_ANY", 0) / wc,
+                                 "frac_active_inst_any": m.get("SQ_ACTIVE_INST_ANY", 0) / wc,
+                                 "frac_active_inst_valu": m.get("SQ_ACTIVE_INST_VALU", 0) / wc,
+                                 "valu_insts_per_wave": m.get("SQ_INSTS_VALU", 0) / (m.get("SQ_WAVES", 0) or 1),
+                                 "salu_insts_per_wave": m.get("SQ_INSTS_SALU", 0) / (m.get("SQ_WAVES", 0) or 1)}
+    if sq:
+        json.dump(sq, open(os.path.join(ROOT, "profiles", f"{tag}_sq_breakdown.json"), "w"), indent=1)
     # ---- copies of the raw evidence ---------------------------------------------------
     for src, dst in (("prof_stats/**/*kernel_stats.csv", f"{tag}_rocprofv3_kernel_stats.csv"),
                      ("prof_rd/**/*counter_collection.csv", f"{tag}_pmc_rdreq_counter_collection.csv"),
@@ -137,10 +225,19 @@ def main():
         found = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", src), recursive=True))
         if found:
             shutil.copyfile(found[0], os.path.join(ROOT, "profiles", dst))
-    keep = ("residuals_per_launch", "calibration", "hbm_read_bytes_per_launch", "hbm_write_bytes_per_launch",
-            "hbm_bytes_per_launch", "fetch_size_x2_over_exact", "hbm_GBs_at_rocprof_avg")
-    print(json.dumps({"stats": summ.get("dominant_kernel"), "pmc": {k: res[k] for k in keep if k in res},
-                      "fused": {k: v for k, v in (fused or {}).items() if not k.endswith("_dispatch")}}, indent=1))
+    # the per-dispatch kernel trace is large: keep the REG / TSDF kernels' rows only
+    keep_rows = [x for x in trace if any(k in x.get("Kernel_Name", "") for k in (KERNEL, FUSED, TSDF, "reg_finalize", "reg_assemble", "mt_generate"))]
+    if keep_rows:
+        with open(os.path.join(ROOT, "profiles", f"{tag}_rocprofv3_kernel_trace_reg_tsdf.csv"), "w", newline="") as fh:
+            cols = ["Kernel_Name", "Dispatch_Id", "Start_Timestamp", "End_Timestamp", "Grid_Size_X", "VGPR_Count", "SGPR_Count", "LDS_Block_Size"]
+            w = csv.DictWriter(fh, fieldnames=cols, extrasaction="ignore")
+            w.writeheader()
+            for x in keep_rows:
+                x = dict(x)
+                x["Kernel_Name"] = x["Kernel_Name"].split("(")[0][-60:]
+                w.writerow(x)
+    print(json.dumps({"per_workload": pw, "pmc": {k: v for k, v in res.items() if k in ("config3", "full_overlap", "calibration")},
+                      "fused": fused}, indent=1))
 
 
 if __name__ == "__main__":
