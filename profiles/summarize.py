@@ -107,7 +107,10 @@ def main():
         pw[nm] = entry(durs, grid=grid)
     if bench and "config3_fused" in pw:
         pw["config3_fused"]["bench_stream_ms_per_step_incl_finalize_assemble"] = bench["fused"]["stream_ms_per_step"]
-    ts = by_grid(trace, TSDF)
+    # the bench's own TSDF section only: the config-2 session that follows integrates scans of the
+    # same size (synth_city_scan_kernel marks where it starts)
+    cut = next((i for i, x in enumerate(trace) if "synth_city_scan" in x.get("Kernel_Name", "")), len(trace))
+    ts = by_grid(trace[:cut], TSDF)
     if bench and bench.get("tsdf"):
         for (grid, durs) in ts:
             for name, v in bench["tsdf"].items():

@@ -205,6 +205,7 @@ void reset_point_set(PointSet& ps) {
   if (ps.d_weight) (void)hipFree(ps.d_weight);
   if (ps.d_chunk_bounds) (void)hipFree(ps.d_chunk_bounds);
   if (ps.d_cumulative) (void)hipFree(ps.d_cumulative);
+  if (ps.d_search_lut) (void)hipFree(ps.d_search_lut);
   if (ps.d_inv_order) (void)hipFree(ps.d_inv_order);
   if (ps.rng.d_state) (void)hipFree(ps.rng.d_state);
   ps = PointSet();

@@ -325,6 +325,13 @@ __device__ __forceinline__ int32_t weighted_draw(const ConstraintDev& C, int64_t
   const double* cum = C.cumulative;
   const double target = u * as_global(cum)[C.n_points - 1];  // random_number * cumulative.back()
   int64_t first = 0, len = C.n_points;                       // std::upper_bound
+  if (C.search_lut) {
+    // u in [k / K, (k + 1) / K)  =>  the bound lies in [lut[k], lut[k + 1]] (monotonicity of u * total
+    // and of upper_bound); searching that sub-range returns exactly what the full search returns
+    const int k = (int)(u * (double)kSearchBuckets);
+    first = as_global(C.search_lut)[k];
+    len = as_global(C.search_lut)[k + 1] - first;
+  }
   while (len > 0) {
     const int64_t half = len >> 1;
     if (!(target < as_global(cum)[first + half])) {
@@ -1107,6 +1114,7 @@ vgx::ConstraintDev vgx_reg_s::describe() const {
   if (cfg.sampling_ratio != -1.0f) {
     c.sample_raw = d_sample_raw;  // callers that stage elsewhere overwrite this
     c.cumulative = ps.d_cumulative;
+    c.search_lut = ps.d_search_lut;
     c.inv_order = ps.d_inv_order;
     c.n_points = ps.n;
   }
@@ -1224,6 +1232,19 @@ int vgx_reg_create(vgx_ctx ctx, vgx_submap reference, vgx_submap reading, const 
       if (e == hipSuccess)
         e = hipMemcpy(mps.d_cumulative, mps.cumulative_weight.data(), (size_t)mps.n * sizeof(double),
                       hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess && !mps.d_search_lut) {
+      // lut[k] = upper_bound(cumulative, (k / K) * total), k = 0 .. K, in the draw's own f64 arithmetic
+      std::vector<int32_t> lut((size_t)kSearchBuckets + 1);
+      const std::vector<double>& cum = mps.cumulative_weight;
+      const double total = cum.back();
+      for (int k = 0; k <= kSearchBuckets; ++k) {
+        const double target = ((double)k / (double)kSearchBuckets) * total;
+        lut[(size_t)k] = (int32_t)(std::upper_bound(cum.begin(), cum.end(), target) - cum.begin());
+      }
+      e = hipMalloc(&mps.d_search_lut, lut.size() * sizeof(int32_t));
+      if (e == hipSuccess)
+        e = hipMemcpy(mps.d_search_lut, lut.data(), lut.size() * sizeof(int32_t), hipMemcpyHostToDevice);
     }
     if (e == hipSuccess && !mps.inv_order.empty() && !mps.d_inv_order) {
       e = hipMalloc(&mps.d_inv_order, (size_t)mps.n * sizeof(int32_t));
