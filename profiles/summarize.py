@@ -110,21 +110,26 @@ def main():
     # the bench's own TSDF section only: the config-2 session that follows integrates scans of the
     # same size (synth_city_scan_kernel marks where it starts)
     cut = next((i for i, x in enumerate(trace) if "synth_city_scan" in x.get("Kernel_Name", "")), len(trace))
-    ts = by_grid(trace[:cut], TSDF)
     if bench and bench.get("tsdf"):
-        for (grid, durs) in ts:
-            for name, v in bench["tsdf"].items():
-                if (v["points_per_scan"] + 255) // 256 * 256 == grid:
-                    e = pw.setdefault("tsdf_" + name, {"grid": grid, "calls": 0, "durs": []})
-                    e["durs"] += durs
-        for k in [k for k in pw if k.startswith("tsdf_")]:
-            durs = pw[k].pop("durs")
-            # steady-state scans only: the first scan of every fresh layer walks every ray to the sensor
-            steady = sorted(durs)[:max(1, int(0.8 * len(durs)))]
-            pw[k] = entry(steady, bench["tsdf"][k[5:]]["roofline"]["kernel_ms"], grid=pw[k]["grid"],
-                          note="fastest 80 % of the dispatches (steady-state scans; first scans into empty layers excluded)",
-                          back_to_back_ms_per_scan=bench["tsdf"][k[5:]]["ms_per_scan"])
-            pw[k]["back_to_back_over_rocprof_kernel"] = pw[k]["back_to_back_ms_per_scan"] / pw[k]["avg_ms_rocprof"]
+        for name, v in bench["tsdf"].items():
+            grid = (v["points_per_scan"] + 255) // 256 * 256
+            t = [(int(x["Start_Timestamp"]), int(x["End_Timestamp"])) for x in trace[:cut]
+                 if TSDF in x.get("Kernel_Name", "") and int(x["Grid_Size_X"]) == grid]
+            n_timed = v["scans_timed"]
+            if len(t) < 1 + n_timed:
+                continue
+            # tsdf_bench's first pass over this sensor: one warm-up scan, then the timed back-to-back scans
+            timed = t[1:1 + n_timed]
+            ksum = sum(e - s_ for s_, e in timed)
+            span = timed[-1][1] - timed[0][0]
+            pw["tsdf_" + name] = {
+                "grid": grid, "calls": n_timed, "what": "the back-to-back scans bench.py times (first pass, after the warm-up scan)",
+                "avg_kernel_ms_rocprof": ksum / n_timed / 1e6,
+                "span_ms_per_scan_rocprof": span / n_timed / 1e6,
+                "scan_wall_over_kernel_time": span / ksum,
+                "gaps_us": [round((timed[i + 1][0] - timed[i][1]) / 1e3, 1) for i in range(n_timed - 1)],
+                "back_to_back_ms_per_scan_bench_hip_events": v["ms_per_scan"],
+                "isolated_kernel_ms_bench_hip_events": v["roofline"]["kernel_ms"]}
     json.dump(summ, open(os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.json"), "w"), indent=1)
     # ---- HBM traffic of the dominant kernel, both workloads ---------------------------------------
     rd, fetch, write = dispatches("prof_rd", KERNEL), dispatches("prof_fetch", KERNEL), dispatches("prof_write", KERNEL)
