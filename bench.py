@@ -394,7 +394,9 @@ def config5_bench(capi, ctx, torch, dist, use_dist, rank, world, args):
         lane = 1 + (j * (n_lanes - 1)) // n_lc
         q = (7 * j + 3) % per_lane
         a, b = idx(lane - 1, q), idx(lane, q)
-        delta = between(true[a], true[b]) + rng.normal(0, [0.05, 0.05, 0.01, 0.002])
+        # a loop closure's yaw error acts over the whole lane behind it (1 mrad over 500 m = 0.5 m), so
+        # a usable one is accurate to a fraction of that
+        delta = between(true[a], true[b]) + rng.normal(0, [0.03, 0.03, 0.005, 1e-4])
         edges.append(lm.RelativePoseEdge(a, b, delta[:3], delta[3], info_lc))
 
     t0 = time.perf_counter()
