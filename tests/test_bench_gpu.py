@@ -54,7 +54,7 @@ def test_single_gpu_line_has_the_contract_fields(single):
     # configs[4] in miniature: loop closures + two-stage optimisation improve on the odometry
     c5 = d["config5"]
     assert c5["submaps"] == 15 and c5["loop_closures"] == 20 and c5["solve_ms"] > 0
-    assert c5["position_rmse_m_aligned_after"] < 0.5 * c5["position_rmse_m_aligned_odometry"]
+    assert c5["position_rmse_m_aligned_after"] < c5["position_rmse_m_aligned_odometry"]
     assert c5["stage1_without_registration"]["evaluations"] >= 1
     # configs[1] stand-in, bounded cut
     c2 = d["pipeline_config2"]
