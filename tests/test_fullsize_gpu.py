@@ -162,5 +162,32 @@ def test_fullsize_pair_against_the_reference_source(capi, ctx):
     assert ok and cf_gpu.Evaluate([poses[0], poses[1]], r, [jo, je])
     assert int((np.abs(a0).sum(1) > 0).sum()) > 50_000
     assert np.array_equal(r, r0) and np.array_equal(jo, a0) and np.array_equal(je, b0)
-    for o in [cf_gpu] + gpus:
+    # The shipped configuration at full size: both directions of the pair sampled at 5 %
+    # (voxgraph_mapper.yaml:34) plus a second A->B constraint that shares A's sampler engine, in ONE
+    # batched launch with the std::mt19937 streams generated on the device, against the reference's
+    # cost functions called in the same order; two evaluations (the streams continue).
+    import torch
+    assert gpus[1].extract_voxel_points(1.0, 0.3, True) == len(refs[1].points(ref_reg.POINTS_VOXELS)[2])
+    pairs = [(0, 1), (1, 0), (0, 1)]
+    cfg_s = capi.default_config(registration_point_type=capi.POINTS_VOXELS, sampling_ratio=0.05)
+    cfs = [capi.RegistrationCostFunction(ctx, gpus[a], gpus[b], cfg_s) for a, b in pairs]
+    ref_cfs = [ref_reg.RegistrationCostFunction(refs[a], refs[b], sampling_ratio=0.05) for a, b in pairs]
+    batch = capi.RegistrationBatch(ctx, cfs, pairs)
+    ro, R = batch.row_offsets(), batch.num_residuals()
+    assert R == sum(c.num_residuals() for c in ref_cfs) > 30_000
+    for call in range(2):
+        tr = torch.full((R,), float("nan"), dtype=torch.float32, device="cuda:0")
+        tjo = torch.full((R, 4), float("nan"), dtype=torch.float32, device="cuda:0")
+        tje = torch.full((R, 4), float("nan"), dtype=torch.float32, device="cuda:0")
+        torch.cuda.synchronize()
+        assert np.all(batch.evaluate_points(poses, tr.data_ptr(), tjo.data_ptr(), tje.data_ptr()) == 0)
+        ctx.synchronize()
+        gr, gjo, gje = tr.cpu().numpy(), tjo.cpu().numpy(), tje.cpu().numpy()
+        for c, (a, b) in enumerate(pairs):
+            ok, r0, a0, b0 = ref_cfs[c].Evaluate(poses[a], poses[b])
+            sl = slice(int(ro[c]), int(ro[c + 1]))
+            assert ok and np.array_equal(gr[sl], r0.astype(np.float32)), (call, c)
+            assert np.array_equal(gjo[sl], a0.astype(np.float32)) and np.array_equal(gje[sl], b0.astype(np.float32)), (call, c)
+    batch.destroy()
+    for o in cfs + [cf_gpu] + gpus:
         o.destroy()
