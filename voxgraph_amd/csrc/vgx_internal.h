@@ -254,7 +254,8 @@ struct vgx_reg_batch_s {
   int32_t* d_node_pair = nullptr;
   int32_t* d_global_index = nullptr;
   // fused pass: coarser tiles, and node -> incident (constraint<<1 | side) CSR
-  std::vector<vgx::Tile> reduce_tiles;
+  std::vector<vgx::Tile> reduce_tiles;  // in launch order (XCD-aware, make_xcd_order)
+  int32_t reduce_tile_points = 0;       // residuals per fused tile (all but a constraint's last tile)
   vgx::Tile* d_reduce_tiles = nullptr;
   int32_t csr_nodes = 0;
   int32_t* d_node_first = nullptr;

@@ -457,19 +457,15 @@ constexpr int kReduceIters = 8;  // a reduce tile = kTilePoints * kReduceIters r
 constexpr bool kNonTemporalLoads = false;  // A/B: VGX_NT_LOADS=1
 constexpr bool kNonTemporalStores = true;  // measured 6.08 -> 5.40 ms (profiles/ab_nt.sh, VGX_NT_STORES=0/1)
 constexpr int kMaxReduceIters = 64;
-// 120 VGPRs -> 4 waves/SIMD.  Forcing 5 or 6 (launch_bounds) spills the 21 f64
-// accumulators: measured 7.8 / 13.0 ms per fused step against 2.45 ms.
-constexpr int kReduceWavesPerSimd = 4;
-// ~310 VALU instructions per point; VALU issue is about half of the kernel time, the rest is latency
-// that 4 waves/SIMD cannot hide (SQ counters, profiles/README.md "Fused kernel"):
-// fused multiply-adds for the 21 f64 accumulations took 2.23 -> 2.11 ms; a branch-free variant
-// (masked lanes carried through the FMAs) needed 144 VGPRs: 2.43 ms at 3 waves/SIMD, 2.94 ms spilling at 4.
-constexpr int kFusedVariantDefault = 622;  // lean kernel: 6 waves/SIMD (80 VGPRs), 2 points/thread, f32 accumulators
+// Fused-kernel variant: 100 * waves_per_simd + 10 * points_per_thread + (1 = f64, 2 = f32
+// accumulators); VGX_FUSED_KERNEL overrides it for A/B runs (profiles/ab_fused2.sh).  Measured on
+// config 3: 421 2.17 ms, 422 1.79, 522 1.80, 622 1.76, 612 2.07, 812 1.95 (the round-1 kernel --
+// reference operation order, f64 accumulators, 124 VGPRs -- 2.23 ms).
+constexpr int kFusedVariantDefault = 622;
 #ifndef VGX_BALLOT_SKIP
 #define VGX_BALLOT_SKIP 1
 #endif
 constexpr bool kBallotSkip = VGX_BALLOT_SKIP != 0;
-constexpr int kReducePointsPerThread = 2;  // measured: 3.72 / 3.29 / 3.41 ms per fused step at 4 / 2 / 1 (profiles/tune_fused.sh)
 
 // True when no point inside the sphere (centre in the reference frame) can have a
 // correspondence in grid g under pose pack P: the base block of p' is the block of p'
@@ -489,141 +485,8 @@ __device__ __forceinline__ bool chunk_outside(const GridDev& g, const PosePack& 
   return cx + r < lox || cx - r > hix || cy + r < loy || cy - r > hiy || cz + r < loz || cz - r > hiz;
 }
 
-template <int VPS, int PPT, bool NTL, int WAVES>
-__global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_kernel(
-    const ConstraintDev* __restrict__ cons, const PosePack* __restrict__ packs,
-    const Tile* __restrict__ tiles, int n_tiles, double* __restrict__ partials) {
-  static_assert(kBlockThreads * PPT == kChunkPoints, "one inner iteration == one culling chunk");
-  int t = swizzle_tile(blockIdx.x, n_tiles);
-  if (t >= n_tiles) return;
-  const Tile tile = tiles[t];
-  const ConstraintDev& C = cons[tile.constraint];
-  const PosePack P = packs[tile.constraint];
-  const GridDev g = C.grid;
-  // Chunks that cannot overlap the reading grid are skipped without touching their
-  // points (exact: such points only add w * no_correspondence_cost, which must be 0).
-  const float4* bounds = (C.no_corr_cost == 0.0 && C.chunk_bounds) ? C.chunk_bounds : nullptr;
-  const long long chunk0 = tile.start / kChunkPoints;  // tiles start on chunk boundaries
-  // one flag per chunk of this tile, decided up front by one thread each (a tile holds
-  // at most kMaxReduceIters * 2 chunks): the main loop then never waits on a bounds load
-  __shared__ unsigned char s_live[kMaxReduceIters * 2];
-  const int n_chunks = (tile.count + kChunkPoints - 1) / kChunkPoints;
-  if ((int)threadIdx.x < n_chunks)
-    s_live[threadIdx.x] = !(bounds && chunk_outside(g, P, bounds[chunk0 + threadIdx.x]));
-  __syncthreads();
-  double acc[21];
-#pragma unroll
-  for (int k = 0; k < 21; ++k) acc[k] = 0.0;
-
-  // The point stream is software-pipelined: iteration k+1's 20-byte points are requested
-  // before iteration k's dependent chain (block lookup -> brick gather -> arithmetic) runs,
-  // so the HBM stream stays in flight through all three latency phases.
-  f32x4 pt_next[PPT];
-  float w_next[PPT];
-  bool live_next = s_live[0] != 0;
-  if (live_next) {
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-      int local = j * kBlockThreads + (int)threadIdx.x;
-      int64_t i = tile.start + (local < tile.count ? local : 0);
-      pt_next[j] = load_stream<NTL>(as_global(reinterpret_cast<const f32x4*>(C.xyzd)) + i);
-      w_next[j] = load_stream<NTL>(as_global(C.weight) + i);
-    }
-  }
-  for (int base = 0, it = 0; base < tile.count; base += kChunkPoints, ++it) {
-    f32x4 pt[PPT];
-    float w[PPT];
-    const float* cell[PPT];
-    float Dx[PPT], Dy[PPT], Dz[PPT];
-    float d[PPT][8];
-    const bool live = live_next;
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-      pt[j] = pt_next[j];
-      w[j] = w_next[j];
-    }
-    live_next = false;
-    if (base + kChunkPoints < tile.count) {
-      live_next = s_live[it + 1] != 0;
-      if (live_next) {
-#pragma unroll
-        for (int j = 0; j < PPT; ++j) {
-          int local = base + kChunkPoints + j * kBlockThreads + (int)threadIdx.x;
-          int64_t i = tile.start + (local < tile.count ? local : 0);
-          pt_next[j] = load_stream<NTL>(as_global(reinterpret_cast<const f32x4*>(C.xyzd)) + i);
-          w_next[j] = load_stream<NTL>(as_global(C.weight) + i);
-        }
-      }
-    }
-    if (!live) continue;
-    Located loc[PPT];
-    bool have[PPT];
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-      loc[j] = locate_stage1<VPS>(g, P, pt[j].x, pt[j].y, pt[j].z);
-      Dx[j] = loc[j].Dx;
-      Dy[j] = loc[j].Dy;
-      Dz[j] = loc[j].Dz;
-      have[j] = false;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) d[j][k] = 0.0f;
-      cell[j] = nullptr;
-    }
-    if (g.bricks != nullptr) {
-      int slot[PPT];
-#pragma unroll
-      for (int j = 0; j < PPT; ++j) slot[j] = as_global(g.lut)[loc[j].lut_index];
-      constexpr int CELLS = (VPS + 1) * (VPS + 1) * (VPS + 1);
-#pragma unroll
-      for (int j = 0; j < PPT; ++j) {
-        have[j] = loc[j].inside && slot[j] >= 0;
-        cell[j] = g.bricks + (size_t)(have[j] ? slot[j] : 0) * CELLS + loc[j].cell_off;
-      }
-#pragma unroll
-      for (int j = 0; j < PPT; ++j) load_neighbours<VPS>(cell[j], d[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-      int local = base + j * kBlockThreads + (int)threadIdx.x;
-      if (local >= tile.count) continue;
-      PointEval e = eval_point(d[j], have[j], Dx[j], Dy[j], Dz[j], g.voxel_size_inv,
-                               P, pt[j].x, pt[j].y, pt[j].w, w[j], C.no_corr_cost, true);
-      if (e.ok) {
-        double u[6] = {(double)e.jo0, (double)e.jo1, (double)e.jo2, (double)e.jo3, (double)e.je3, e.r};
-        int k = 0;
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-          for (int b = a; b < 6; ++b, ++k) acc[k] = __builtin_fma(u[a], u[b], acc[k]);
-      } else {
-        acc[20] = __builtin_fma(e.r, e.r, acc[20]);  // w * no_correspondence_cost, zero Jacobian rows
-      }
-    }
-  }
-  // wave reduction (64 lanes), then across the 4 waves through LDS: a fixed
-  // tree, so results are bitwise reproducible
-#pragma unroll
-  for (int k = 0; k < 21; ++k) {
-    double v = acc[k];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    acc[k] = v;
-  }
-  __shared__ double lds[kBlockThreads / 64][kPartialSize];
-  int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (lane == 0) {
-#pragma unroll
-    for (int k = 0; k < 21; ++k) lds[wave][k] = acc[k];
-  }
-  __syncthreads();
-  if (threadIdx.x < 21) {
-    double v = ((lds[0][threadIdx.x] + lds[1][threadIdx.x]) + lds[2][threadIdx.x]) + lds[3][threadIdx.x];
-    partials[(size_t)t * kPartialSize + threadIdx.x] = v;
-  }
-}
-
 // ---------------------------------------------------------------------------
-// kernel 2b: fused normal equations, lean form (the default)
+// kernel 2: fused normal equations (lean form)
 // ---------------------------------------------------------------------------
 // The materialising kernel reproduces the reference's f32 operation order so that every output
 // value can be compared with the reference bit for bit.  The fused pass has no per-point output to
@@ -684,10 +547,14 @@ __device__ __forceinline__ void accumulate21(ACC acc[21], const float u[6]) {
     for (int b = a; b < 6; ++b, ++k) acc[k] = x[a] * x[b] + acc[k];
 }
 
+// Tiles are launched in an XCD-aware order (make_xcd_order); every tile still writes its partial
+// sums into the slot it has in its constraint's own contiguous range (tile_first[c] + k-th tile of
+// c), so the order in which a constraint's partials are summed never changes.
 template <int VPS, int PPT, typename ACC, int WAVES>
 __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_kernel(
     const ConstraintDev* __restrict__ cons, const PosePack* __restrict__ packs,
-    const Tile* __restrict__ tiles, int n_tiles, double* __restrict__ partials) {
+    const Tile* __restrict__ tiles, int n_tiles, const int32_t* __restrict__ tile_first, int tile_points,
+    double* __restrict__ partials) {
   constexpr int kIterPoints = kBlockThreads * PPT;
   static_assert(kChunkPoints % kIterPoints == 0, "an inner iteration never straddles a culling chunk");
   const int t = blockIdx.x;
@@ -824,7 +691,8 @@ __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_ker
   __syncthreads();
   if (threadIdx.x < 21) {
     double v = ((lds[0][threadIdx.x] + lds[1][threadIdx.x]) + lds[2][threadIdx.x]) + lds[3][threadIdx.x];
-    partials[(size_t)t * kPartialSize + threadIdx.x] = v;
+    const size_t slot = (size_t)tile_first[tile.constraint] + (size_t)(tile.start / tile_points);
+    partials[slot * kPartialSize + threadIdx.x] = v;
   }
 }
 
@@ -913,6 +781,86 @@ __global__ void reg_count_live_kernel(const ConstraintDev* __restrict__ cons, co
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off, 64);
   if ((threadIdx.x & 63) == 0 && mine) atomicAdd(live, mine);
+}
+
+// XCD-aware launch order of the fused pass's tiles.  Workgroup p of a launch runs on XCD p % 8
+// (the dispatcher deals workgroups round the 8 XCDs), and every XCD has its own 4 MB L2.  The
+// constraints that share a reference submap read the SAME point stream, chunk range by chunk range
+// (config 3: ~6 per submap; the shipped mirrored configuration: ~12), so their tiles of one chunk
+// range are placed on ONE XCD, next to each other in its dispatch sequence: they run at the same
+// time and all but the first find the points in that XCD's L2 instead of going to the fabric.
+// Groups (constraints with the same point array) are dealt to the 8 XCD streams longest first;
+// launch position 8 i + x takes the i-th tile of stream x.  VGX_FUSED_TILE_ORDER=0 keeps the plain
+// constraint-major order (A/B, profiles/ab_order.sh).  Only the launch order changes: every tile
+// writes its partial sums to its own slot, so results are bit for bit the same either way.
+static void make_xcd_order(const std::vector<ConstraintDev>& desc, const std::vector<int32_t>& tile_first,
+                           std::vector<Tile>& tiles) {
+  static const bool enabled = [] {
+    const char* e = getenv("VGX_FUSED_TILE_ORDER");
+    return e ? atoi(e) != 0 : true;
+  }();
+  const int n = (int)desc.size();
+  if (!enabled || n < 2 || tiles.size() < 16) return;
+  constexpr int kXcds = 8;
+  // groups of constraints reading the same points (sampling constraints read scattered points: alone)
+  std::vector<std::vector<int>> groups;
+  {
+    std::vector<std::pair<const void*, int>> key;  // (points, group)
+    for (int c = 0; c < n; ++c) {
+      int g = -1;
+      if (!desc[(size_t)c].sample_raw)
+        for (auto& k : key)
+          if (k.first == (const void*)desc[(size_t)c].xyzd) g = k.second;
+      if (g < 0) {
+        g = (int)groups.size();
+        groups.emplace_back();
+        if (!desc[(size_t)c].sample_raw) key.emplace_back((const void*)desc[(size_t)c].xyzd, g);
+      }
+      groups[(size_t)g].push_back(c);
+    }
+  }
+  // each group's tiles: chunk range major, constraint minor
+  std::vector<std::vector<Tile>> group_tiles(groups.size());
+  for (size_t g = 0; g < groups.size(); ++g) {
+    int most = 0;
+    for (int c : groups[g]) most = std::max(most, tile_first[(size_t)c + 1] - tile_first[(size_t)c]);
+    for (int r = 0; r < most; ++r)
+      for (int c : groups[g])
+        if (r < tile_first[(size_t)c + 1] - tile_first[(size_t)c])
+          group_tiles[g].push_back(tiles[(size_t)tile_first[(size_t)c] + (size_t)r]);
+  }
+  // longest group first onto the shortest stream
+  std::vector<size_t> order(groups.size());
+  for (size_t g = 0; g < order.size(); ++g) order[g] = g;
+  std::stable_sort(order.begin(), order.end(),
+                   [&](size_t a, size_t b) { return group_tiles[a].size() > group_tiles[b].size(); });
+  std::vector<std::vector<Tile>> stream(kXcds);
+  for (size_t g : order) {
+    int best = 0;
+    for (int x = 1; x < kXcds; ++x)
+      if (stream[(size_t)x].size() < stream[(size_t)best].size()) best = x;
+    stream[(size_t)best].insert(stream[(size_t)best].end(), group_tiles[g].begin(), group_tiles[g].end());
+  }
+  // interleave; a stream that has run dry lends its positions to the fullest one
+  std::vector<size_t> next(kXcds, 0);
+  std::vector<Tile> out;
+  out.reserve(tiles.size());
+  while (out.size() < tiles.size())
+    for (int x = 0; x < kXcds && out.size() < tiles.size(); ++x) {
+      int src = x;
+      if (next[(size_t)src] >= stream[(size_t)src].size()) {
+        size_t left = 0;
+        for (int y = 0; y < kXcds; ++y) {
+          const size_t l = stream[(size_t)y].size() - next[(size_t)y];
+          if (l > left) {
+            left = l;
+            src = y;
+          }
+        }
+      }
+      out.push_back(stream[(size_t)src][next[(size_t)src]++]);
+    }
+  tiles.swap(out);
 }
 
 // One workgroup per constraint: 12 groups of 21 lanes sum the constraint's tile
@@ -1494,6 +1442,8 @@ int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs, const int3
     max_node = std::max(max_node, std::max(node_pair[2 * c], node_pair[2 * c + 1]));
   }
   tile_first[(size_t)n] = (int32_t)ex->reduce_tiles.size();
+  ex->reduce_tile_points = kTilePoints * reduce_iters;
+  make_xcd_order(desc, tile_first, ex->reduce_tiles);
   // Sampling constraints: group by engine (order of first appearance).  One evaluation of the
   // batch is one Evaluate of every constraint in list order, so the constraints of an engine
   // consume consecutive ranges of its stream, 2 words per residual (RCF:113-122).
@@ -1691,22 +1641,17 @@ int vgx_reg_batch_evaluate_normal(vgx_reg_batch b, const double* poses, int32_t 
   if (b->n == 0) return VGX_OK;
   double* out = d_normal ? (double*)d_normal : b->d_normal;
   const int n_tiles = (int)ex->reduce_tiles.size();
-  apply_swizzle_env();
-  // Fused-kernel variant (A/B switch, profiles/ab_fused2.sh): 0 = round-1 kernel (reference
-  // operation order, f64 accumulators), otherwise the lean kernel, encoded as
-  // 100 * waves_per_simd + 10 * points_per_thread + (1 = f64 accumulators, 2 = f32 accumulators)
   static const int variant = [] {
-    const char* e = getenv("VGX_FUSED_KERNEL");
+    const char* e = getenv("VGX_FUSED_KERNEL");  // A/B switch (profiles/ab_fused2.sh)
     return e ? atoi(e) : kFusedVariantDefault;
   }();
-  if (n_tiles > 0 && variant == 0 && b->any_sampling)
-    return set_error(ctx, VGX_ERR_UNSUPPORTED, "VGX_FUSED_KERNEL=0 (the round-1 kernel) has no sampling mode");
-  if (n_tiles > 0 && variant != 0) {
+  if (n_tiles > 0) {
     dim3 grid(n_tiles), block(kBlockThreads);
     const int vps = b->regs[0]->reading->vps;
 #define VGX_LAUNCH_LEAN(VPS, PPT, ACC, W)                                                             \
   hipLaunchKernelGGL((reg_eval_reduce_lean_kernel<VPS, PPT, ACC, W>), grid, block, 0, ctx->stream,  \
-                     b->d_desc, b->d_pack, ex->d_reduce_tiles, n_tiles, b->d_partials)
+                     b->d_desc, b->d_pack, ex->d_reduce_tiles, n_tiles, b->d_tile_first,             \
+                     ex->reduce_tile_points, b->d_partials)
 #define VGX_LEAN_CASE(CODE, PPT, ACC, W)                                  \
   case CODE:                                                              \
     if (vps == 16) VGX_LAUNCH_LEAN(16, PPT, ACC, W);                      \
@@ -1719,29 +1664,11 @@ int vgx_reg_batch_evaluate_normal(vgx_reg_batch b, const double* poses, int32_t 
       VGX_LEAN_CASE(622, 2, float, 6);
       VGX_LEAN_CASE(612, 1, float, 6);
       VGX_LEAN_CASE(812, 1, float, 8);
-      VGX_LEAN_CASE(511, 1, double, 5);
       default:
         return set_error(ctx, VGX_ERR_INVALID, "VGX_FUSED_KERNEL: unknown variant");
     }
 #undef VGX_LEAN_CASE
 #undef VGX_LAUNCH_LEAN
-    VGX_HIP(ctx, hipGetLastError());
-  } else if (n_tiles > 0) {
-    dim3 grid(((n_tiles + 7) / 8) * 8), block(kBlockThreads);
-    static const bool ntl = [] {
-      const char* e = getenv("VGX_NT_LOADS");
-      return e ? atoi(e) != 0 : kNonTemporalLoads;
-    }();
-#define VGX_LAUNCH_REDUCE(VPS, NTL)                                                                 \
-  hipLaunchKernelGGL((reg_eval_reduce_kernel<VPS, kReducePointsPerThread, NTL, kReduceWavesPerSimd>), \
-                     grid, block, 0, ctx->stream, b->d_desc, b->d_pack, ex->d_reduce_tiles, n_tiles, \
-                     b->d_partials)
-    if (b->regs[0]->reading->vps == 16) {
-      if (ntl) VGX_LAUNCH_REDUCE(16, true); else VGX_LAUNCH_REDUCE(16, false);
-    } else {
-      if (ntl) VGX_LAUNCH_REDUCE(8, true); else VGX_LAUNCH_REDUCE(8, false);
-    }
-#undef VGX_LAUNCH_REDUCE
     VGX_HIP(ctx, hipGetLastError());
   }
   hipLaunchKernelGGL(reg_finalize_kernel, dim3(b->n), dim3(256), 0, ctx->stream, b->d_desc,
