@@ -254,7 +254,11 @@ struct vgx_reg_batch_s {
   int32_t* d_node_pair = nullptr;
   int32_t* d_global_index = nullptr;
   // fused pass: coarser tiles, and node -> incident (constraint<<1 | side) CSR
-  std::vector<vgx::Tile> reduce_tiles;  // in launch order (XCD-aware, make_xcd_order)
+  std::vector<vgx::Tile> reduce_tiles;  // constraint-major; the device copy is re-ordered for launch at
+                                        // the first evaluation (XCD-aware, make_xcd_order)
+  std::vector<vgx::ConstraintDev> host_desc;
+  std::vector<int32_t> host_tile_first;
+  bool launch_order_made = false;
   int32_t reduce_tile_points = 0;       // residuals per fused tile (all but a constraint's last tile)
   vgx::Tile* d_reduce_tiles = nullptr;
   int32_t csr_nodes = 0;

@@ -763,6 +763,30 @@ __global__ __launch_bounds__(256) void mt_generate_kernel(const StreamJobDev* __
   if (tid == 0) job.state[N] = idx;
 }
 
+// Points a fused tile will really load at these poses (its chunks that survive the bounding-sphere
+// test): the work estimate the XCD-aware launch order balances.  One wavefront per tile.
+__global__ __launch_bounds__(64) void reg_tile_live_kernel(const ConstraintDev* __restrict__ cons,
+                                                          const PosePack* __restrict__ packs,
+                                                          const Tile* __restrict__ tiles, int n_tiles,
+                                                          int32_t* __restrict__ live) {
+  const int t = blockIdx.x;
+  if (t >= n_tiles) return;
+  const Tile tile = tiles[t];
+  const ConstraintDev& C = cons[tile.constraint];
+  const PosePack P = packs[tile.constraint];
+  const bool cull = C.no_corr_cost == 0.0 && C.chunk_bounds && C.sample_raw == nullptr;
+  const long long chunk0 = tile.start / kChunkPoints;
+  const int n_chunks = (tile.count + kChunkPoints - 1) / kChunkPoints;
+  int mine = 0;
+  for (int k = threadIdx.x; k < n_chunks; k += 64) {
+    const int pts = (k + 1) * kChunkPoints <= tile.count ? kChunkPoints : tile.count - k * kChunkPoints;
+    if (!cull || !chunk_outside(C.grid, P, C.chunk_bounds[chunk0 + k])) mine += pts;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off, 64);
+  if (threadIdx.x == 0) live[t] = mine;
+}
+
 // Residuals the fused pass actually touches at these poses: the points of every chunk that
 // survives the bounding-sphere test (the rest cost no memory traffic at all).  One thread per chunk.
 __global__ void reg_count_live_kernel(const ConstraintDev* __restrict__ cons, const PosePack* __restrict__ packs,
@@ -789,12 +813,14 @@ __global__ void reg_count_live_kernel(const ConstraintDev* __restrict__ cons, co
 // (config 3: ~6 per submap; the shipped mirrored configuration: ~12), so their tiles of one chunk
 // range are placed on ONE XCD, next to each other in its dispatch sequence: they run at the same
 // time and all but the first find the points in that XCD's L2 instead of going to the fabric.
-// Groups (constraints with the same point array) are dealt to the 8 XCD streams longest first;
-// launch position 8 i + x takes the i-th tile of stream x.  VGX_FUSED_TILE_ORDER=0 keeps the plain
+// Groups (constraints with the same point array) are dealt to the 8 XCD streams heaviest first, by
+// the points their tiles really load under chunk culling at the poses of the first evaluation (the
+// pattern barely moves between solver iterations), so that the XCDs finish together; launch
+// position 8 i + x takes the i-th tile of stream x.  VGX_FUSED_TILE_ORDER=0 keeps the plain
 // constraint-major order (A/B, profiles/ab_order.sh).  Only the launch order changes: every tile
 // writes its partial sums to its own slot, so results are bit for bit the same either way.
 static void make_xcd_order(const std::vector<ConstraintDev>& desc, const std::vector<int32_t>& tile_first,
-                           std::vector<Tile>& tiles) {
+                           const std::vector<int32_t>& tile_work, std::vector<Tile>& tiles) {
   static const bool enabled = [] {
     const char* e = getenv("VGX_FUSED_TILE_ORDER");
     return e ? atoi(e) != 0 : true;
@@ -819,27 +845,33 @@ static void make_xcd_order(const std::vector<ConstraintDev>& desc, const std::ve
       groups[(size_t)g].push_back(c);
     }
   }
-  // each group's tiles: chunk range major, constraint minor
+  // each group's tiles: chunk range major, constraint minor; its work = the points its tiles will
+  // really load (chunk culling at the poses of the first evaluation) + a little per tile
   std::vector<std::vector<Tile>> group_tiles(groups.size());
+  std::vector<int64_t> group_work(groups.size(), 0);
   for (size_t g = 0; g < groups.size(); ++g) {
     int most = 0;
     for (int c : groups[g]) most = std::max(most, tile_first[(size_t)c + 1] - tile_first[(size_t)c]);
     for (int r = 0; r < most; ++r)
       for (int c : groups[g])
-        if (r < tile_first[(size_t)c + 1] - tile_first[(size_t)c])
-          group_tiles[g].push_back(tiles[(size_t)tile_first[(size_t)c] + (size_t)r]);
+        if (r < tile_first[(size_t)c + 1] - tile_first[(size_t)c]) {
+          const size_t t = (size_t)tile_first[(size_t)c] + (size_t)r;
+          group_tiles[g].push_back(tiles[t]);
+          group_work[g] += (int64_t)tile_work[t] + 256;
+        }
   }
-  // longest group first onto the shortest stream
+  // heaviest group first onto the least loaded stream: the XCDs finish together
   std::vector<size_t> order(groups.size());
   for (size_t g = 0; g < order.size(); ++g) order[g] = g;
-  std::stable_sort(order.begin(), order.end(),
-                   [&](size_t a, size_t b) { return group_tiles[a].size() > group_tiles[b].size(); });
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return group_work[a] > group_work[b]; });
   std::vector<std::vector<Tile>> stream(kXcds);
+  std::vector<int64_t> load(kXcds, 0);
   for (size_t g : order) {
     int best = 0;
     for (int x = 1; x < kXcds; ++x)
-      if (stream[(size_t)x].size() < stream[(size_t)best].size()) best = x;
+      if (load[(size_t)x] < load[(size_t)best]) best = x;
     stream[(size_t)best].insert(stream[(size_t)best].end(), group_tiles[g].begin(), group_tiles[g].end());
+    load[(size_t)best] += group_work[g];
   }
   // interleave; a stream that has run dry lends its positions to the fullest one
   std::vector<size_t> next(kXcds, 0);
@@ -1443,7 +1475,8 @@ int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs, const int3
   }
   tile_first[(size_t)n] = (int32_t)ex->reduce_tiles.size();
   ex->reduce_tile_points = kTilePoints * reduce_iters;
-  make_xcd_order(desc, tile_first, ex->reduce_tiles);
+  ex->host_desc = desc;            // (sample_raw is filled in below) for the launch order, made at the first evaluation
+  ex->host_tile_first = tile_first;
   // Sampling constraints: group by engine (order of first appearance).  One evaluation of the
   // batch is one Evaluate of every constraint in list order, so the constraints of an engine
   // consume consecutive ranges of its stream, 2 words per residual (RCF:113-122).
@@ -1492,6 +1525,7 @@ int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs, const int3
       }
     }
   }
+  ex->host_desc = desc;
   // CSR: node -> (constraint << 1 | side)
   ex->csr_nodes = max_node + 1;
   std::vector<int32_t> first((size_t)ex->csr_nodes + 1, 0), items(2 * (size_t)n);
@@ -1641,6 +1675,22 @@ int vgx_reg_batch_evaluate_normal(vgx_reg_batch b, const double* poses, int32_t 
   if (b->n == 0) return VGX_OK;
   double* out = d_normal ? (double*)d_normal : b->d_normal;
   const int n_tiles = (int)ex->reduce_tiles.size();
+  if (!ex->launch_order_made && n_tiles > 0) {
+    // one-time: per-tile live points at these poses -> XCD-aware launch order (results do not
+    // depend on the order: every tile writes its own slot)
+    DeviceScratch s_live;
+    VGX_HIP(ctx, s_live.alloc((size_t)n_tiles * sizeof(int32_t)));
+    hipLaunchKernelGGL(reg_tile_live_kernel, dim3(n_tiles), dim3(64), 0, ctx->stream, b->d_desc, b->d_pack,
+                       ex->d_reduce_tiles, n_tiles, s_live.as<int32_t>());
+    VGX_HIP(ctx, hipGetLastError());
+    std::vector<int32_t> work((size_t)n_tiles);
+    VGX_HIP(ctx, hipMemcpyAsync(work.data(), s_live.p, work.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<Tile> ordered = ex->reduce_tiles;
+    make_xcd_order(ex->host_desc, ex->host_tile_first, work, ordered);
+    VGX_HIP(ctx, hipMemcpy(ex->d_reduce_tiles, ordered.data(), ordered.size() * sizeof(Tile), hipMemcpyHostToDevice));
+    ex->launch_order_made = true;
+  }
   static const int variant = [] {
     const char* e = getenv("VGX_FUSED_KERNEL");  // A/B switch (profiles/ab_fused2.sh)
     return e ? atoi(e) : kFusedVariantDefault;
