@@ -14,6 +14,7 @@
 // decision agrees with the CPU restatement bit for bit.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -865,7 +866,7 @@ static void make_xcd_order(const std::vector<ConstraintDev>& desc, const std::ve
   // full-overlap workload (0.83 shareable) 4.03 -> 2.67 ms and 27.7 -> 11.9 GB of fabric reads; config 3
   // (constraints of a group overlap DIFFERENT parts of the reference, little to share) 1.66 -> 1.64 ms;
   // config 5 1.17 -> 1.42 ms: long runs of heavy and of culled tiles per XCD stall the in-order
-  // dispatcher.  So the grouped order is used only where there is something to share.
+  // dispatcher.  So the grouped order is used only where there is something to share and little is culled.
   {
     int64_t total = 0, shareable = 0;
     for (size_t g = 0; g < groups.size(); ++g) {
@@ -887,7 +888,15 @@ static void make_xcd_order(const std::vector<ConstraintDev>& desc, const std::ve
       const char* e = getenv("VGX_FUSED_SHARE_THRESHOLD");
       return e ? atof(e) : 0.3;
     }();
+    if (getenv("VGX_DEBUG_ORDER"))
+      fprintf(stderr, "[vgx] fused tile order: %zu tiles, %zu groups, shareable %.3f of %lld loaded points\n",
+              tiles.size(), groups.size(), total ? (double)shareable / (double)total : 0.0, (long long)total);
     if (total == 0 || (double)shareable < threshold * (double)total) return;
+    // ... and only when few tiles are culled: with long runs of culled (instant) and of heavy tiles in
+    // one XCD's sequence the in-order dispatcher stalls the other XCDs (config 5 above: 56 % culled)
+    int64_t all_points = 0;
+    for (const Tile& t : tiles) all_points += t.count;
+    if ((double)total < 0.75 * (double)all_points) return;
   }
   // heaviest group first onto the least loaded stream: the XCDs finish together
   std::vector<size_t> order(groups.size());
