@@ -756,21 +756,31 @@ def main():
         barrier()
         fdt = torch.tensor([time.perf_counter() - f0], dtype=torch.float64, device="cuda")
         # points the kernel actually loads: chunks whose bounding sphere cannot touch the reading
-        # grid are skipped without reading them (vgx_reg_batch_count_live)
-        live = torch.tensor([float(bt.count_live(ps))], dtype=torch.float64, device="cuda")
+        # grid are skipped without reading them (vgx_reg_batch_count_live); constraints that share a
+        # reference submap load the SAME points, which the launch order lets them share in one L2
+        lv, uq = bt.count_live(ps, unique=True)
+        live = torch.tensor([float(lv), float(uq)], dtype=torch.float64, device="cuda")
         if use_dist:
             dist.all_reduce(fdt, op=dist.ReduceOp.MAX)
             dist.all_reduce(live, op=dist.ReduceOp.SUM)
-        fdt, live = float(fdt.item()), float(live.item())
-        # per-branch algorithmic bytes: 52 B for a point that interpolates, 20 B for a loaded point
-        # that finds no reading block, 0 B for a culled one
-        alg_bytes = corr_total * BYTES_PER_EVAL_FUSED + max(live - corr_total, 0.0) * BYTES_NO_CORR_FUSED
+        fdt, live, unique_pts = float(fdt.item()), float(live[0].item()), float(live[1].item())
+        # algorithmic bytes: every DISTINCT loaded point once (20 B) + the 8 neighbours of every
+        # evaluation that interpolates (32 B); the per-evaluation pricing of SURVEY.md 8d (52 B / 20 B /
+        # 0 B), which re-counts a point for every constraint that reads it, is reported beside it
+        alg_bytes = unique_pts * BYTES_NO_CORR_FUSED + corr_total * (BYTES_PER_EVAL_FUSED - BYTES_NO_CORR_FUSED)
+        per_eval_bytes = corr_total * BYTES_PER_EVAL_FUSED + max(live - corr_total, 0.0) * BYTES_NO_CORR_FUSED
         out = {"value": evals_total * n_f / fdt / 1e6, "unit": "Mresiduals+Jacobians/s",
                "ms_per_step": fdt / n_f * 1e3, "stream_ms_per_step": f_kernel_ms,
                "kernels": "reg_eval_reduce_lean_kernel + reg_finalize_kernel + reg_assemble_kernel"
                           + (" + RCCL all-reduce" if use_dist else ""),
                "evaluations": evals_total, "with_correspondence": corr_total, "loaded_after_culling": live,
+               "distinct_points_loaded": unique_pts,
                "algorithmic_bytes_per_step": alg_bytes,
+               "per_evaluation_pricing_bytes_per_step": per_eval_bytes,
+               "per_evaluation_pricing_GBs": per_eval_bytes * n_f / fdt / 1e9,
+               "pricing": "algorithmic = 20 B x distinct loaded points + 32 B x interpolating evaluations; "
+                          "per_evaluation_pricing re-counts a point for every constraint that reads it (52 / 20 / 0 B) "
+                          "and can exceed the HBM peak where constraints share points through the L2",
                "algorithmic_GBs": alg_bytes * n_f / fdt / 1e9,
                "frac_of_hbm_peak": alg_bytes * n_f / fdt / 1e9 / HBM_PEAK_GBS,
                "value_with_correspondence": corr_total * n_f / fdt / 1e6,

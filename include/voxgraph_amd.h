@@ -260,9 +260,11 @@ VGX_API int vgx_reg_batch_evaluate_normal(vgx_reg_batch batch,
 /* Measurement aid for the fused pass: the number of residuals whose registration points the
  * fused kernel actually reads at these poses, i.e. the points of every 512-point chunk whose
  * bounding sphere can touch the reading submap's block box (chunks that cannot are skipped
- * without loading their points when no_correspondence_cost == 0).  Synchronous. */
+ * without loading their points when no_correspondence_cost == 0); and (nullable) the number of
+ * DISTINCT points behind them -- constraints that share a reference submap read the same points,
+ * which the fused pass's launch order lets them share through one XCD's L2.  Synchronous. */
 VGX_API int vgx_reg_batch_count_live(vgx_reg_batch batch, const double* poses, int32_t n_nodes,
-                                     int64_t* live_residuals);
+                                     int64_t* live_residuals, int64_t* unique_points);
 
 /* Scatter-adds this process's [n][45] blocks into the fused buffer every
  * process all-reduces once per solver evaluation, DEVICE f64:

@@ -47,6 +47,7 @@ def test_single_gpu_line_has_the_contract_fields(single):
     for f in (d["fused"], fo["fused"]):
         assert 0 < f["algorithmic_GBs"] <= d["roofline"]["peak"]
         assert f["with_correspondence"] <= f["loaded_after_culling"] <= f["evaluations"]
+        assert 0 < f["distinct_points_loaded"] <= f["loaded_after_culling"]
     assert d["config"]["passes_per_step"] == 10 and d["value_with_correspondence"] <= d["value"]
     # the shipped yaml's configuration (sampled, mirrored isosurface constraints) in one batched pass
     assert d["shipped_config"]["constraints"] == 2 * d["config"]["constraints"]

@@ -117,7 +117,7 @@ SIGNATURES = {
     "vgx_reg_batch_row_offsets": (C.c_int, [vp, i64p]),
     "vgx_reg_batch_evaluate_points": (C.c_int, [vp, f64p, C.c_int32, vp, vp, vp, i32p]),
     "vgx_reg_batch_evaluate_normal": (C.c_int, [vp, f64p, C.c_int32, vp, f64p, i32p]),
-    "vgx_reg_batch_count_live": (C.c_int, [vp, f64p, C.c_int32, i64p]),
+    "vgx_reg_batch_count_live": (C.c_int, [vp, f64p, C.c_int32, i64p, i64p]),
     "vgx_reg_batch_assemble": (C.c_int, [vp, vp, C.c_int32, vp, C.c_int32]),
     "vgx_reg_fused_size": (C.c_int64, [C.c_int32, C.c_int32]),
     "vgx_lpt_shards": (C.c_int, [C.c_int32, i64p, C.c_int32, i32p]),
@@ -473,13 +473,14 @@ class RegistrationBatch:
             _ptr(host, f64p), _ptr(status, i32p)))
         return status[:self.n], host
 
-    def count_live(self, poses):
-        """residuals whose points the fused pass reads at these poses (chunk culling applied)"""
+    def count_live(self, poses, unique=False):
+        """residuals whose points the fused pass reads at these poses (chunk culling applied);
+        with unique=True also the number of distinct points behind them"""
         poses = _f64(poses).reshape(-1, 4)
-        n = C.c_int64()
+        n, u = C.c_int64(), C.c_int64()
         self.ctx.check(self.ctx.lib.vgx_reg_batch_count_live(self.h, _ptr(poses, f64p), poses.shape[0],
-                                                             C.byref(n)))
-        return n.value
+                                                             C.byref(n), C.byref(u) if unique else None))
+        return (n.value, u.value) if unique else n.value
 
     def assemble(self, n_nodes, d_fused, d_normal=None, zero_first=True):
         self.ctx.check(self.ctx.lib.vgx_reg_batch_assemble(

@@ -472,7 +472,7 @@ constexpr bool kBallotSkip = VGX_BALLOT_SKIP != 0;
 // correspondence in grid g under pose pack P: the base block of p' is the block of p'
 // or its -1 neighbour, so p' must lie in [lut_min * bs, (lut_min + lut_dim + 1) * bs);
 // one voxel of slack covers the f32 rounding of the transformed centre.
-__device__ __forceinline__ bool chunk_outside(const GridDev& g, const PosePack& P, float4 sph) {
+__host__ __device__ __forceinline__ bool chunk_outside(const GridDev& g, const PosePack& P, float4 sph) {
   float uv0 = -(P.qz * sph.y), uv1 = P.qz * sph.x;
   uv0 += uv0;
   uv1 += uv1;
@@ -1770,11 +1770,13 @@ int vgx_reg_batch_evaluate_normal(vgx_reg_batch b, const double* poses, int32_t 
   return VGX_OK;
 }
 
-int vgx_reg_batch_count_live(vgx_reg_batch b, const double* poses, int32_t n_nodes, int64_t* live_residuals) {
+int vgx_reg_batch_count_live(vgx_reg_batch b, const double* poses, int32_t n_nodes, int64_t* live_residuals,
+                             int64_t* unique_points) {
   if (!b || !poses || !live_residuals) return VGX_ERR_INVALID;
   vgx_ctx ctx = b->ctx;
   std::lock_guard<std::mutex> lk(ctx->mu);
   *live_residuals = 0;
+  if (unique_points) *unique_points = 0;
   VGX_HIP(ctx, hipSetDevice(ctx->device));
   int rc = batch_upload_packs(b, poses, n_nodes, nullptr);
   if (rc != VGX_OK) return rc;
@@ -1789,6 +1791,45 @@ int vgx_reg_batch_count_live(vgx_reg_batch b, const double* poses, int32_t n_nod
   VGX_HIP(ctx, hipMemcpyAsync(&v, counter.p, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
   VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   *live_residuals = (int64_t)v;
+  if (!unique_points) return VGX_OK;
+  // Distinct registration points behind those residuals: constraints that share a reference submap
+  // load the same points, and a point counts once however many of them load it.  Host arithmetic
+  // (the same sphere test on downloaded chunk bounds): a measurement aid, not a hot path.
+  std::vector<std::pair<const float4*, std::vector<float4>>> bounds;  // per distinct point set
+  std::vector<std::pair<const float4*, std::vector<unsigned char>>> loaded;
+  int64_t unique = 0;
+  for (int c = 0; c < b->n; ++c) {
+    const ConstraintDev& C = b->host_desc[(size_t)c];
+    const int64_t n_chunks = (C.n + kChunkPoints - 1) / kChunkPoints;
+    if (C.sample_raw) {  // scattered draws: every draw is its own load
+      unique += C.n;
+      continue;
+    }
+    size_t k = 0;
+    while (k < bounds.size() && bounds[k].first != C.xyzd) ++k;
+    if (k == bounds.size()) {
+      bounds.emplace_back(C.xyzd, std::vector<float4>((size_t)n_chunks));
+      loaded.emplace_back(C.xyzd, std::vector<unsigned char>((size_t)n_chunks, 0));
+      if (n_chunks > 0 && C.chunk_bounds)
+        VGX_HIP(ctx, hipMemcpy(bounds[k].second.data(), C.chunk_bounds, (size_t)n_chunks * sizeof(float4), hipMemcpyDeviceToHost));
+    }
+    const bool cull = C.no_corr_cost == 0.0 && C.chunk_bounds;
+    PosePack P;
+    make_pose_pack(poses + 4 * (size_t)b->node_pair[2 * (size_t)c], poses + 4 * (size_t)b->node_pair[2 * (size_t)c + 1], &P);
+    for (int64_t q = 0; q < n_chunks; ++q)
+      if (!cull || !chunk_outside(C.grid, P, bounds[k].second[(size_t)q])) loaded[k].second[(size_t)q] = 1;
+  }
+  for (size_t k = 0; k < loaded.size(); ++k) {
+    // the point count of the set: n of any constraint that reads it (all-points constraints: n == set size)
+    int64_t n_pts = 0;
+    for (int c = 0; c < b->n; ++c)
+      if (b->host_desc[(size_t)c].xyzd == loaded[k].first && !b->host_desc[(size_t)c].sample_raw)
+        n_pts = std::max<int64_t>(n_pts, b->host_desc[(size_t)c].n);
+    const int64_t n_chunks = (int64_t)loaded[k].second.size();
+    for (int64_t q = 0; q < n_chunks; ++q)
+      if (loaded[k].second[(size_t)q]) unique += (q + 1) * kChunkPoints <= n_pts ? kChunkPoints : n_pts - q * kChunkPoints;
+  }
+  *unique_points = unique;
   return VGX_OK;
 }
 
