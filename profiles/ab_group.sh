@@ -2,7 +2,7 @@
 # A/B of the grouped fused kernel (VGX_FUSED_GROUPS=1: constraints sharing a reference submap fetch its points
 # once per chunk, reg_eval_reduce_group_kernel) against the lean kernel for everything (=0): fused ms per
 # solver evaluation on config 3 / full overlap / config 5, two rounds; then one PMC pass per setting.
-#   gpurun -- 'bash profiles/ab_order.sh'
+#   gpurun -- 'bash profiles/ab_group.sh'
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
@@ -16,19 +16,19 @@ print("fused config3 %.3f ms | full overlap %.3f ms | config5 evaluation %.3f ms
 for round in 1 2; do
   for v in 0 1; do
     printf "round %s VGX_FUSED_GROUPS=%s " $round $v
-    VGX_FUSED_GROUPS=$v timeout 300 python $REPO/bench.py $ARGS 2>$OUT/ab_order.err | python -c "$pick" || tail -3 $OUT/ab_order.err
+    VGX_FUSED_GROUPS=$v timeout 300 python $REPO/bench.py $ARGS 2>$OUT/ab_group.err | python -c "$pick" || tail -3 $OUT/ab_group.err
   done
 done
 cd /tmp
 for v in 0 1; do
   VGX_FUSED_GROUPS=$v timeout 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum \
-      --kernel-trace -f csv --kernel-include-regex "reg_eval_reduce" -d $OUT/prof_order$v -o rd -- \
+      --kernel-trace -f csv --kernel-include-regex "reg_eval_reduce" -d $OUT/prof_group$v -o rd -- \
       python $REPO/bench.py --steps 3 --inner 1 --warmup 1 --no-cpu-baseline --no-solve --no-tsdf --no-shipped --no-config5 --no-config2 \
-      > /dev/null 2> $OUT/prof_order$v.err
+      > /dev/null 2> $OUT/prof_group$v.err
   python - <<PY
 import csv, glob, collections
 d = collections.OrderedDict()
-for f in glob.glob("$OUT/prof_order$v/**/*counter_collection.csv", recursive=True):
+for f in glob.glob("$OUT/prof_group$v/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         e = d.setdefault((int(r["Grid_Size"]), int(r["Dispatch_Id"])), {})
         e[r["Counter_Name"]] = float(r["Counter_Value"])
