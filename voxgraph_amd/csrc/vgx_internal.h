@@ -258,7 +258,8 @@ struct vgx_reg_batch_s {
   std::vector<vgx::ConstraintDev> host_desc;
   int32_t reduce_tile_points = 0;       // residuals per lean tile (all but a constraint's last tile)
   int32_t n_partial_slots = 0;          // partial-sum slots of all constraints (lean and grouped tiles)
-  int32_t n_group_tiles = 0;            // grouped kernel: (group part, chunk range) work items
+  int32_t n_group_tiles = 0;            // grouped kernel: (group part, tile) work items
+  int32_t group_m = 2;                  // ... with up to this many constraints each
   void* d_group_tiles = nullptr;
   int32_t* d_group_members = nullptr;
   vgx::Tile* d_reduce_tiles = nullptr;

@@ -462,6 +462,7 @@ constexpr int kMaxReduceIters = 64;
 // accumulators); VGX_FUSED_KERNEL overrides it for A/B runs (profiles/ab_fused2.sh).  Measured on
 // config 3: 421 2.17 ms, 422 1.79, 522 1.80, 622 1.76, 612 2.07, 812 1.95 (the round-1 kernel --
 // reference operation order, f64 accumulators, 124 VGPRs -- 2.23 ms).
+constexpr int kGroupMembersDefault = 2;  // constraints per workgroup of the grouped kernel (VGX_FUSED_GROUP_M)
 constexpr int kFusedVariantDefault = 622;
 #ifndef VGX_BALLOT_SKIP
 #define VGX_BALLOT_SKIP 1
@@ -701,164 +702,171 @@ __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_ker
 // ---------------------------------------------------------------------------
 // In a pose graph a submap is the reference (first) submap of several constraints -- ~6 in config 3,
 // ~12 with the shipped mirrored constraints -- and all of them read the same registration points
-// (measured on config 3: 255 M points loaded, 82 M distinct).  Here one workgroup takes one chunk
-// range of a reference point set and up to kGroupWaves constraints of its group: the points of a
-// chunk are fetched from HBM ONCE, staged in LDS (double-buffered: chunk k+1 is in flight while
-// chunk k is evaluated), and wave w evaluates all of them against ITS constraint (its own pose pack,
-// reading grid and 21 accumulators).  A chunk nobody needs (culled for every member) is not loaded;
-// a wave whose constraint culls a chunk sits that chunk out.  Same arithmetic as the lean kernel
-// (exact cell location, lerp-form interpolation, f32 accumulators over <= 128 terms per lane, f64
-// wave reduction); every (constraint, chunk range) writes its own partial slot, so the result does
-// not depend on how constraints are grouped.
-constexpr int kGroupWaves = 4;
-constexpr int kGroupChunks = 16;                               // chunk ranges of 16 x 512 = 8192 points
-constexpr int kGroupTilePoints = kGroupChunks * kChunkPoints;
-#ifndef VGX_GROUP_WAVES_PER_SIMD
-#define VGX_GROUP_WAVES_PER_SIMD 4
-#endif
-constexpr int kGroupWavesPerSimd = VGX_GROUP_WAVES_PER_SIMD;  // 126 VGPRs; 5 or 6 waves/SIMD spill
-
+// (measured on config 3: 255 M points loaded by the lean kernel, 82 M of them distinct).  Here a
+// workgroup takes one tile of a reference point set and up to M constraints of its group: a thread
+// loads its two points of a chunk ONCE (same mapping and prefetch as the lean kernel) and evaluates
+// them against every member for which the chunk is live, each member with its own pose pack,
+// reading grid and 21 accumulators.  No LDS staging, no barrier in the loop, no idle wave: the price
+// is M accumulator sets in registers.  A chunk that is culled for every member is not loaded.
+// Thread <-> point mapping, arithmetic, tile size and per-tile reduction are the lean kernel's, and
+// every (constraint, tile) writes its own partial slot: results are BIT FOR BIT those of the lean
+// kernel, however the constraints are grouped.
 struct GroupTile {
   int32_t first_member;  // into the member list: constraint indices
-  int32_t n_members;     // 1 .. kGroupWaves
-  int32_t count;         // points in this range
+  int32_t n_members;     // 1 .. M
+  int32_t count;         // points in this tile
   int32_t pad;
-  int64_t start;         // first point of the range
+  int64_t start;         // first point of the tile
 };
 
-template <int VPS, int WAVES>
-__global__ __launch_bounds__(kGroupWaves * 64, WAVES) void reg_eval_reduce_group_kernel(
+template <int VPS, int M, int WAVES>
+__global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_group_kernel(
     const ConstraintDev* __restrict__ cons, const PosePack* __restrict__ packs,
     const GroupTile* __restrict__ gtiles, const int32_t* __restrict__ members,
-    const int32_t* __restrict__ tile_first, double* __restrict__ partials) {
-  constexpr int kThreads = kGroupWaves * 64;
-  constexpr int kLoadsPerThread = kChunkPoints / kThreads;    // 2
-  static_assert(kChunkPoints % kThreads == 0, "a chunk is staged by the whole workgroup");
+    const int32_t* __restrict__ tile_first, int tile_points, double* __restrict__ partials) {
+  constexpr int PPT = 2;
+  constexpr int kIterPoints = kBlockThreads * PPT;
+  static_assert(kIterPoints == kChunkPoints, "one iteration == one culling chunk");
   const GroupTile gt = gtiles[blockIdx.x];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const bool has = wave < gt.n_members;
-  const int c = members[gt.first_member + (has ? wave : 0)];
-  const ConstraintDev& C = cons[c];
-  const PosePack P = packs[c];
-  const GridDev g = C.grid;
-  const bool count_misses = C.no_corr_cost != 0.0;
-  const float nc = (float)C.no_corr_cost;
-  const bool grid_empty = g.bricks == nullptr;
-  const float4* bounds = (!count_misses && C.chunk_bounds) ? C.chunk_bounds : nullptr;
   const long long chunk0 = gt.start / kChunkPoints;
   const int n_chunks = (gt.count + kChunkPoints - 1) / kChunkPoints;
-
-  __shared__ unsigned char s_live[kGroupWaves][kGroupChunks];
-  __shared__ f32x4 s_pt[2][kChunkPoints];
-  __shared__ float s_w[2][kChunkPoints];
-  if (lane < n_chunks) s_live[wave][lane] = has && !(bounds && chunk_outside(g, P, bounds[chunk0 + lane]));
-  __syncthreads();
-  auto any_live = [&](int k) {
-    bool a = false;
-#pragma unroll
-    for (int w = 0; w < kGroupWaves; ++w) a |= s_live[w][k] != 0;
-    return a;
-  };
-  // the group's points (every member reads the same arrays)
-  const VGX_GLOBAL f32x4* xyzd = as_global(reinterpret_cast<const f32x4*>(C.xyzd));
-  const VGX_GLOBAL float* weight = as_global(C.weight);
-  f32x4 ld_pt[kLoadsPerThread];
-  float ld_w[kLoadsPerThread];
-  auto issue_loads = [&](int k) {
-#pragma unroll
-    for (int j = 0; j < kLoadsPerThread; ++j) {
-      const int local = k * kChunkPoints + j * kThreads + (int)threadIdx.x;
-      const int64_t i = gt.start + (local < gt.count ? local : 0);
-      ld_pt[j] = xyzd[i];
-      ld_w[j] = weight[i];
+  // bit m of s_live[k]: chunk k is live for member m
+  __shared__ unsigned char s_live[kMaxReduceIters * 2];
+  for (int k = threadIdx.x; k < n_chunks; k += kBlockThreads) {
+    unsigned char bits = 0;
+    for (int m = 0; m < gt.n_members; ++m) {
+      const ConstraintDev& Cm = cons[members[gt.first_member + m]];
+      const bool cull = Cm.no_corr_cost == 0.0 && Cm.chunk_bounds;
+      if (!cull || !chunk_outside(Cm.grid, packs[members[gt.first_member + m]], Cm.chunk_bounds[chunk0 + k]))
+        bits |= (unsigned char)(1u << m);
     }
-  };
-  float acc[21];
+    s_live[k] = bits;
+  }
+  __syncthreads();
+  const ConstraintDev& C0 = cons[members[gt.first_member]];  // the group's points
+  const VGX_GLOBAL f32x4* xyzd = as_global(reinterpret_cast<const f32x4*>(C0.xyzd));
+  const VGX_GLOBAL float* weight = as_global(C0.weight);
+  float acc[M][21];
 #pragma unroll
-  for (int q = 0; q < 21; ++q) acc[q] = 0.0f;
-  bool loaded = any_live(0);
-  if (loaded) issue_loads(0);
+  for (int m = 0; m < M; ++m)
+#pragma unroll
+    for (int q = 0; q < 21; ++q) acc[m][q] = 0.0f;
+
+  f32x4 pt_next[PPT];
+  float w_next[PPT];
+  unsigned live_next = s_live[0];
+  if (live_next) {
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      const int local = j * kBlockThreads + (int)threadIdx.x;
+      const int64_t i = gt.start + (local < gt.count ? local : 0);
+      pt_next[j] = xyzd[i];
+      w_next[j] = weight[i];
+    }
+  }
   for (int k = 0; k < n_chunks; ++k) {
-    const int buf = k & 1;
-    if (loaded) {
+    const int base = k * kChunkPoints;
+    f32x4 pt[PPT];
+    float w[PPT];
+    const unsigned live = live_next;
 #pragma unroll
-      for (int j = 0; j < kLoadsPerThread; ++j) {
-        s_pt[buf][j * kThreads + threadIdx.x] = ld_pt[j];
-        s_w[buf][j * kThreads + threadIdx.x] = ld_w[j];
+    for (int j = 0; j < PPT; ++j) {
+      pt[j] = pt_next[j];
+      w[j] = w_next[j];
+    }
+    live_next = 0;
+    if (k + 1 < n_chunks) {
+      live_next = s_live[k + 1];
+      if (live_next) {
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+          const int local = base + kChunkPoints + j * kBlockThreads + (int)threadIdx.x;
+          const int64_t i = gt.start + (local < gt.count ? local : 0);
+          pt_next[j] = xyzd[i];
+          w_next[j] = weight[i];
+        }
       }
     }
-    // one barrier per chunk: the buffer written above was last read two chunks ago, and every
-    // wave passed the previous barrier only after it had finished that read
-    __syncthreads();
-    const bool mine = s_live[wave][k] != 0;
-    loaded = k + 1 < n_chunks && any_live(k + 1);
-    if (loaded) issue_loads(k + 1);
-    if (!mine) continue;
-    const int base = k * kChunkPoints;
-#pragma unroll 1
-    for (int it = 0; it < kChunkPoints / 128; ++it) {
-      f32x4 pt[2];
-      float w[2];
-      Located loc[2];
-      bool have[2];
-      float d[2][8];
+    if (!live) continue;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int at = it * 128 + j * 64 + lane;
-        pt[j] = s_pt[buf][at];
-        w[j] = s_w[buf][at];
+    for (int m = 0; m < M; ++m) {
+      if (!(live & (1u << m))) continue;  // uniform: culled for this member (or no such member)
+      const int c = members[gt.first_member + m];
+      const ConstraintDev& C = cons[c];
+      const PosePack P = packs[c];
+      const GridDev g = C.grid;
+      const bool count_misses = C.no_corr_cost != 0.0;
+      const float nc = (float)C.no_corr_cost;
+      Located loc[PPT];
+      bool have[PPT];
+      float d[PPT][8];
+#pragma unroll
+      for (int j = 0; j < PPT; ++j) {
         loc[j] = locate_stage1<VPS>(g, P, pt[j].x, pt[j].y, pt[j].z);
         have[j] = false;
       }
-      if (!grid_empty) {
-        int slot[2];
+      if (g.bricks != nullptr) {
+        int slot[PPT];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) slot[j] = as_global(g.lut)[loc[j].lut_index];
+        for (int j = 0; j < PPT; ++j) slot[j] = as_global(g.lut)[loc[j].lut_index];
         constexpr int CELLS = (VPS + 1) * (VPS + 1) * (VPS + 1);
         bool any = false;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < PPT; ++j) {
           have[j] = loc[j].inside && slot[j] >= 0;
           any |= have[j];
         }
         if (kBallotSkip && !count_misses && __builtin_amdgcn_ballot_w64(any) == 0ull) continue;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < PPT; ++j) {
           const unsigned off = (unsigned)(have[j] ? slot[j] : 0) * (unsigned)CELLS + (unsigned)loc[j].cell_off;
           load_neighbours<VPS>(g.bricks + off, d[j]);
         }
       } else {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < PPT; ++j)
 #pragma unroll
           for (int q = 0; q < 8; ++q) d[j][q] = 0.0f;
       }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const bool in_range = base + it * 128 + j * 64 + lane < gt.count;
+      for (int j = 0; j < PPT; ++j) {
+        const bool in_range = base + j * kBlockThreads + (int)threadIdx.x < gt.count;
         float u[6];
         const bool ok = eval_point_lean(d[j], have[j], loc[j].Dx, loc[j].Dy, loc[j].Dz, g.voxel_size_inv, P,
                                         pt[j].x, pt[j].y, pt[j].w, w[j], u) && in_range;
 #pragma unroll
         for (int q = 0; q < 5; ++q) u[q] = ok ? u[q] : 0.0f;
         u[5] = ok ? u[5] : ((count_misses && in_range) ? w[j] * nc : 0.0f);
-        accumulate21<float>(acc, u);
+        accumulate21<float>(acc[m], u);
       }
     }
   }
-  if (!has) return;
-  // 64-lane fixed tree in f64, then lanes 0..20 write this (constraint, range)'s slot
-  double mine21 = 0.0;
+  // per member: the lean kernel's reduction (64-lane tree in f64, then the 4 waves through LDS)
+  __shared__ double lds[kBlockThreads / 64][kPartialSize];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
-  for (int q = 0; q < 21; ++q) {
-    double v = (double)acc[q];
+  for (int m = 0; m < M; ++m) {
+    if (m >= gt.n_members) break;
+    double accd[21];
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    if (lane == q) mine21 = v;
-  }
-  if (lane < 21) {
-    const size_t slot = (size_t)tile_first[c] + (size_t)(gt.start / kGroupTilePoints);
-    partials[slot * kPartialSize + lane] = mine21;
+    for (int q = 0; q < 21; ++q) {
+      double v = (double)acc[m][q];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+      accd[q] = v;
+    }
+    if (m > 0) __syncthreads();  // the previous member's sums have been read
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < 21; ++q) lds[wave][q] = accd[q];
+    }
+    __syncthreads();
+    if (threadIdx.x < 21) {
+      const double v = ((lds[0][threadIdx.x] + lds[1][threadIdx.x]) + lds[2][threadIdx.x]) + lds[3][threadIdx.x];
+      const int c = members[gt.first_member + m];
+      const size_t slot = (size_t)tile_first[c] + (size_t)(gt.start / tile_points);
+      partials[slot * kPartialSize + threadIdx.x] = v;
+    }
   }
 }
 
@@ -1554,11 +1562,17 @@ int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs, const int3
       if (groups[gi].size() >= 2)
         for (int c : groups[gi]) group_of[(size_t)c] = (int)gi;
   }
+  const int64_t group_tile_points = (int64_t)kTilePoints * reduce_iters;  // the lean kernel's tile size
+  static const int group_m = [] {
+    const char* e = getenv("VGX_FUSED_GROUP_M");
+    const int v = e ? atoi(e) : kGroupMembersDefault;
+    return v < 2 ? 2 : (v > 4 ? 4 : v);
+  }();
   int32_t slots = 0;
   for (int c = 0; c < n; ++c) {
     tile_first[(size_t)c] = slots;
     if (group_of[(size_t)c] >= 0) {
-      slots += (int32_t)((regs[c]->num_residuals + kGroupTilePoints - 1) / kGroupTilePoints);
+      slots += (int32_t)((regs[c]->num_residuals + group_tile_points - 1) / group_tile_points);
     } else {
       std::vector<Tile> rt = make_tiles(c, regs[c]->num_residuals, kTilePoints * reduce_iters);
       ex->reduce_tiles.insert(ex->reduce_tiles.end(), rt.begin(), rt.end());
@@ -1573,15 +1587,15 @@ int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs, const int3
   for (size_t gi = 0; gi < groups.size(); ++gi) {
     if (groups[gi].size() < 2) continue;
     const int64_t npts = regs[groups[gi][0]]->num_residuals;  // all-points constraints of one set: same n
-    for (size_t m0 = 0; m0 < groups[gi].size(); m0 += kGroupWaves) {
+    for (size_t m0 = 0; m0 < groups[gi].size(); m0 += (size_t)group_m) {
       const int32_t first = (int32_t)members.size();
-      const int32_t cnt = (int32_t)std::min<size_t>(kGroupWaves, groups[gi].size() - m0);
+      const int32_t cnt = (int32_t)std::min<size_t>((size_t)group_m, groups[gi].size() - m0);
       for (int32_t w = 0; w < cnt; ++w) members.push_back(groups[gi][m0 + (size_t)w]);
-      for (int64_t st = 0; st < npts; st += kGroupTilePoints) {
+      for (int64_t st = 0; st < npts; st += group_tile_points) {
         GroupTile gt;
         gt.first_member = first;
         gt.n_members = cnt;
-        gt.count = (int32_t)std::min<int64_t>(kGroupTilePoints, npts - st);
+        gt.count = (int32_t)std::min<int64_t>(group_tile_points, npts - st);
         gt.pad = 0;
         gt.start = st;
         gtiles.push_back(gt);
@@ -1589,6 +1603,7 @@ int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs, const int3
     }
   }
   ex->n_group_tiles = (int32_t)gtiles.size();
+  ex->group_m = group_m;
   ex->host_desc = desc;            // (sample_raw is filled in below) kept for vgx_reg_batch_count_live
   // Sampling constraints: group by engine (order of first appearance).  One evaluation of the
   // batch is one Evaluate of every constraint in list order, so the constraints of an engine
@@ -1797,13 +1812,19 @@ int vgx_reg_batch_evaluate_normal(vgx_reg_batch b, const double* poses, int32_t 
     return e ? atoi(e) : kFusedVariantDefault;
   }();
   if (ex->n_group_tiles > 0) {
-    dim3 grid((unsigned)ex->n_group_tiles), block(kGroupWaves * 64);
-    if (b->regs[0]->reading->vps == 16)
-      hipLaunchKernelGGL((reg_eval_reduce_group_kernel<16, kGroupWavesPerSimd>), grid, block, 0, ctx->stream, b->d_desc, b->d_pack,
-                         (const GroupTile*)ex->d_group_tiles, ex->d_group_members, b->d_tile_first, b->d_partials);
-    else
-      hipLaunchKernelGGL((reg_eval_reduce_group_kernel<8, kGroupWavesPerSimd>), grid, block, 0, ctx->stream, b->d_desc, b->d_pack,
-                         (const GroupTile*)ex->d_group_tiles, ex->d_group_members, b->d_tile_first, b->d_partials);
+    dim3 grid((unsigned)ex->n_group_tiles), block(kBlockThreads);
+    const int vps16 = b->regs[0]->reading->vps == 16;
+#define VGX_LAUNCH_GROUP(VPS, M, W)                                                                    \
+  hipLaunchKernelGGL((reg_eval_reduce_group_kernel<VPS, M, W>), grid, block, 0, ctx->stream, b->d_desc, \
+                     b->d_pack, (const GroupTile*)ex->d_group_tiles, ex->d_group_members, b->d_tile_first, \
+                     ex->reduce_tile_points, b->d_partials)
+    switch (ex->group_m) {
+      // waves/SIMD: what the M accumulator sets leave room for without spilling (128 / 168 VGPRs spill)
+      case 2: if (vps16) VGX_LAUNCH_GROUP(16, 2, 3); else VGX_LAUNCH_GROUP(8, 2, 3); break;
+      case 3: if (vps16) VGX_LAUNCH_GROUP(16, 3, 2); else VGX_LAUNCH_GROUP(8, 3, 2); break;
+      default: if (vps16) VGX_LAUNCH_GROUP(16, 4, 2); else VGX_LAUNCH_GROUP(8, 4, 2); break;
+    }
+#undef VGX_LAUNCH_GROUP
     VGX_HIP(ctx, hipGetLastError());
   }
   if (n_tiles > 0) {
