@@ -254,14 +254,12 @@ struct vgx_reg_batch_s {
   int32_t* d_node_pair = nullptr;
   int32_t* d_global_index = nullptr;
   // fused pass: coarser tiles, and node -> incident (constraint<<1 | side) CSR
-  std::vector<vgx::Tile> reduce_tiles;  // lean kernel: constraints that share their points with nobody
+  std::vector<vgx::Tile> reduce_tiles;  // constraint-major; the device copy is re-ordered for launch at
+                                        // the first evaluation (XCD-aware, make_xcd_order)
   std::vector<vgx::ConstraintDev> host_desc;
-  int32_t reduce_tile_points = 0;       // residuals per lean tile (all but a constraint's last tile)
-  int32_t n_partial_slots = 0;          // partial-sum slots of all constraints (lean and grouped tiles)
-  int32_t n_group_tiles = 0;            // grouped kernel: (group part, tile) work items
-  int32_t group_m = 2;                  // ... with up to this many constraints each
-  void* d_group_tiles = nullptr;
-  int32_t* d_group_members = nullptr;
+  std::vector<int32_t> host_tile_first;
+  bool launch_order_made = false;
+  int32_t reduce_tile_points = 0;       // residuals per fused tile (all but a constraint's last tile)
   vgx::Tile* d_reduce_tiles = nullptr;
   int32_t csr_nodes = 0;
   int32_t* d_node_first = nullptr;

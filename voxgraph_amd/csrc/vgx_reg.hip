@@ -462,7 +462,6 @@ constexpr int kMaxReduceIters = 64;
 // accumulators); VGX_FUSED_KERNEL overrides it for A/B runs (profiles/ab_fused2.sh).  Measured on
 // config 3: 421 2.17 ms, 422 1.79, 522 1.80, 622 1.76, 612 2.07, 812 1.95 (the round-1 kernel --
 // reference operation order, f64 accumulators, 124 VGPRs -- 2.23 ms).
-constexpr int kGroupMembersDefault = 2;  // constraints per workgroup of the grouped kernel (VGX_FUSED_GROUP_M)
 constexpr int kFusedVariantDefault = 622;
 #ifndef VGX_BALLOT_SKIP
 #define VGX_BALLOT_SKIP 1
@@ -549,8 +548,9 @@ __device__ __forceinline__ void accumulate21(ACC acc[21], const float u[6]) {
     for (int b = a; b < 6; ++b, ++k) acc[k] = x[a] * x[b] + acc[k];
 }
 
-// Every tile writes its partial sums into the slot it has in its constraint's own contiguous range
-// (tile_first[c] + k-th tile of c): the order in which a constraint's partials are summed is fixed.
+// Tiles are launched in an XCD-aware order (make_xcd_order); every tile still writes its partial
+// sums into the slot it has in its constraint's own contiguous range (tile_first[c] + k-th tile of
+// c), so the order in which a constraint's partials are summed never changes.
 template <int VPS, int PPT, typename ACC, int WAVES>
 __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_kernel(
     const ConstraintDev* __restrict__ cons, const PosePack* __restrict__ packs,
@@ -698,179 +698,6 @@ __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_ker
 }
 
 // ---------------------------------------------------------------------------
-// kernel 2g: fused normal equations of constraints that SHARE a reference submap
-// ---------------------------------------------------------------------------
-// In a pose graph a submap is the reference (first) submap of several constraints -- ~6 in config 3,
-// ~12 with the shipped mirrored constraints -- and all of them read the same registration points
-// (measured on config 3: 255 M points loaded by the lean kernel, 82 M of them distinct).  Here a
-// workgroup takes one tile of a reference point set and up to M constraints of its group: a thread
-// loads its two points of a chunk ONCE (same mapping and prefetch as the lean kernel) and evaluates
-// them against every member for which the chunk is live, each member with its own pose pack,
-// reading grid and 21 accumulators.  No LDS staging, no barrier in the loop, no idle wave: the price
-// is M accumulator sets in registers.  A chunk that is culled for every member is not loaded.
-// Thread <-> point mapping, arithmetic, tile size and per-tile reduction are the lean kernel's, and
-// every (constraint, tile) writes its own partial slot: results are BIT FOR BIT those of the lean
-// kernel, however the constraints are grouped.
-struct GroupTile {
-  int32_t first_member;  // into the member list: constraint indices
-  int32_t n_members;     // 1 .. M
-  int32_t count;         // points in this tile
-  int32_t pad;
-  int64_t start;         // first point of the tile
-};
-
-template <int VPS, int M, int WAVES>
-__global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_group_kernel(
-    const ConstraintDev* __restrict__ cons, const PosePack* __restrict__ packs,
-    const GroupTile* __restrict__ gtiles, const int32_t* __restrict__ members,
-    const int32_t* __restrict__ tile_first, int tile_points, double* __restrict__ partials) {
-  constexpr int PPT = 2;
-  constexpr int kIterPoints = kBlockThreads * PPT;
-  static_assert(kIterPoints == kChunkPoints, "one iteration == one culling chunk");
-  const GroupTile gt = gtiles[blockIdx.x];
-  const long long chunk0 = gt.start / kChunkPoints;
-  const int n_chunks = (gt.count + kChunkPoints - 1) / kChunkPoints;
-  // bit m of s_live[k]: chunk k is live for member m
-  __shared__ unsigned char s_live[kMaxReduceIters * 2];
-  for (int k = threadIdx.x; k < n_chunks; k += kBlockThreads) {
-    unsigned char bits = 0;
-    for (int m = 0; m < gt.n_members; ++m) {
-      const ConstraintDev& Cm = cons[members[gt.first_member + m]];
-      const bool cull = Cm.no_corr_cost == 0.0 && Cm.chunk_bounds;
-      if (!cull || !chunk_outside(Cm.grid, packs[members[gt.first_member + m]], Cm.chunk_bounds[chunk0 + k]))
-        bits |= (unsigned char)(1u << m);
-    }
-    s_live[k] = bits;
-  }
-  __syncthreads();
-  const ConstraintDev& C0 = cons[members[gt.first_member]];  // the group's points
-  const VGX_GLOBAL f32x4* xyzd = as_global(reinterpret_cast<const f32x4*>(C0.xyzd));
-  const VGX_GLOBAL float* weight = as_global(C0.weight);
-  float acc[M][21];
-#pragma unroll
-  for (int m = 0; m < M; ++m)
-#pragma unroll
-    for (int q = 0; q < 21; ++q) acc[m][q] = 0.0f;
-
-  f32x4 pt_next[PPT];
-  float w_next[PPT];
-  unsigned live_next = s_live[0];
-  if (live_next) {
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-      const int local = j * kBlockThreads + (int)threadIdx.x;
-      const int64_t i = gt.start + (local < gt.count ? local : 0);
-      pt_next[j] = xyzd[i];
-      w_next[j] = weight[i];
-    }
-  }
-  for (int k = 0; k < n_chunks; ++k) {
-    const int base = k * kChunkPoints;
-    f32x4 pt[PPT];
-    float w[PPT];
-    const unsigned live = live_next;
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-      pt[j] = pt_next[j];
-      w[j] = w_next[j];
-    }
-    live_next = 0;
-    if (k + 1 < n_chunks) {
-      live_next = s_live[k + 1];
-      if (live_next) {
-#pragma unroll
-        for (int j = 0; j < PPT; ++j) {
-          const int local = base + kChunkPoints + j * kBlockThreads + (int)threadIdx.x;
-          const int64_t i = gt.start + (local < gt.count ? local : 0);
-          pt_next[j] = xyzd[i];
-          w_next[j] = weight[i];
-        }
-      }
-    }
-    if (!live) continue;
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-      if (!(live & (1u << m))) continue;  // uniform: culled for this member (or no such member)
-      const int c = members[gt.first_member + m];
-      const ConstraintDev& C = cons[c];
-      const PosePack P = packs[c];
-      const GridDev g = C.grid;
-      const bool count_misses = C.no_corr_cost != 0.0;
-      const float nc = (float)C.no_corr_cost;
-      Located loc[PPT];
-      bool have[PPT];
-      float d[PPT][8];
-#pragma unroll
-      for (int j = 0; j < PPT; ++j) {
-        loc[j] = locate_stage1<VPS>(g, P, pt[j].x, pt[j].y, pt[j].z);
-        have[j] = false;
-      }
-      if (g.bricks != nullptr) {
-        int slot[PPT];
-#pragma unroll
-        for (int j = 0; j < PPT; ++j) slot[j] = as_global(g.lut)[loc[j].lut_index];
-        constexpr int CELLS = (VPS + 1) * (VPS + 1) * (VPS + 1);
-        bool any = false;
-#pragma unroll
-        for (int j = 0; j < PPT; ++j) {
-          have[j] = loc[j].inside && slot[j] >= 0;
-          any |= have[j];
-        }
-        if (kBallotSkip && !count_misses && __builtin_amdgcn_ballot_w64(any) == 0ull) continue;
-#pragma unroll
-        for (int j = 0; j < PPT; ++j) {
-          const unsigned off = (unsigned)(have[j] ? slot[j] : 0) * (unsigned)CELLS + (unsigned)loc[j].cell_off;
-          load_neighbours<VPS>(g.bricks + off, d[j]);
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < PPT; ++j)
-#pragma unroll
-          for (int q = 0; q < 8; ++q) d[j][q] = 0.0f;
-      }
-#pragma unroll
-      for (int j = 0; j < PPT; ++j) {
-        const bool in_range = base + j * kBlockThreads + (int)threadIdx.x < gt.count;
-        float u[6];
-        const bool ok = eval_point_lean(d[j], have[j], loc[j].Dx, loc[j].Dy, loc[j].Dz, g.voxel_size_inv, P,
-                                        pt[j].x, pt[j].y, pt[j].w, w[j], u) && in_range;
-#pragma unroll
-        for (int q = 0; q < 5; ++q) u[q] = ok ? u[q] : 0.0f;
-        u[5] = ok ? u[5] : ((count_misses && in_range) ? w[j] * nc : 0.0f);
-        accumulate21<float>(acc[m], u);
-      }
-    }
-  }
-  // per member: the lean kernel's reduction (64-lane tree in f64, then the 4 waves through LDS)
-  __shared__ double lds[kBlockThreads / 64][kPartialSize];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#pragma unroll
-  for (int m = 0; m < M; ++m) {
-    if (m >= gt.n_members) break;
-    double accd[21];
-#pragma unroll
-    for (int q = 0; q < 21; ++q) {
-      double v = (double)acc[m][q];
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-      accd[q] = v;
-    }
-    if (m > 0) __syncthreads();  // the previous member's sums have been read
-    if (lane == 0) {
-#pragma unroll
-      for (int q = 0; q < 21; ++q) lds[wave][q] = accd[q];
-    }
-    __syncthreads();
-    if (threadIdx.x < 21) {
-      const double v = ((lds[0][threadIdx.x] + lds[1][threadIdx.x]) + lds[2][threadIdx.x]) + lds[3][threadIdx.x];
-      const int c = members[gt.first_member + m];
-      const size_t slot = (size_t)tile_first[c] + (size_t)(gt.start / tile_points);
-      partials[slot * kPartialSize + threadIdx.x] = v;
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
 // std::mt19937 streams on the device (sampling mode of the batched passes)
 // ---------------------------------------------------------------------------
 // One workgroup per engine: the 624-word state sits in LDS, each "twist" (the only sequential
@@ -937,6 +764,30 @@ __global__ __launch_bounds__(256) void mt_generate_kernel(const StreamJobDev* __
   if (tid == 0) job.state[N] = idx;
 }
 
+// Points a fused tile will really load at these poses (its chunks that survive the bounding-sphere
+// test): the work estimate the XCD-aware launch order balances.  One wavefront per tile.
+__global__ __launch_bounds__(64) void reg_tile_live_kernel(const ConstraintDev* __restrict__ cons,
+                                                          const PosePack* __restrict__ packs,
+                                                          const Tile* __restrict__ tiles, int n_tiles,
+                                                          int32_t* __restrict__ live) {
+  const int t = blockIdx.x;
+  if (t >= n_tiles) return;
+  const Tile tile = tiles[t];
+  const ConstraintDev& C = cons[tile.constraint];
+  const PosePack P = packs[tile.constraint];
+  const bool cull = C.no_corr_cost == 0.0 && C.chunk_bounds && C.sample_raw == nullptr;
+  const long long chunk0 = tile.start / kChunkPoints;
+  const int n_chunks = (tile.count + kChunkPoints - 1) / kChunkPoints;
+  int mine = 0;
+  for (int k = threadIdx.x; k < n_chunks; k += 64) {
+    const int pts = (k + 1) * kChunkPoints <= tile.count ? kChunkPoints : tile.count - k * kChunkPoints;
+    if (!cull || !chunk_outside(C.grid, P, C.chunk_bounds[chunk0 + k])) mine += pts;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off, 64);
+  if (threadIdx.x == 0) live[t] = mine;
+}
+
 // Residuals the fused pass actually touches at these poses: the points of every chunk that
 // survives the bounding-sphere test (the rest cost no memory traffic at all).  One thread per chunk.
 __global__ void reg_count_live_kernel(const ConstraintDev* __restrict__ cons, const PosePack* __restrict__ packs,
@@ -955,6 +806,131 @@ __global__ void reg_count_live_kernel(const ConstraintDev* __restrict__ cons, co
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off, 64);
   if ((threadIdx.x & 63) == 0 && mine) atomicAdd(live, mine);
+}
+
+// XCD-aware launch order of the fused pass's tiles.  Workgroup p of a launch runs on XCD p % 8
+// (the dispatcher deals workgroups round the 8 XCDs), and every XCD has its own 4 MB L2.  The
+// constraints that share a reference submap read the SAME point stream, chunk range by chunk range
+// (config 3: ~6 per submap; the shipped mirrored configuration: ~12), so their tiles of one chunk
+// range are placed on ONE XCD, next to each other in its dispatch sequence: they run at the same
+// time and all but the first find the points in that XCD's L2 instead of going to the fabric.
+// Groups (constraints with the same point array) are dealt to the 8 XCD streams heaviest first, by
+// the points their tiles really load under chunk culling at the poses of the first evaluation (the
+// pattern barely moves between solver iterations), so that the XCDs finish together; launch
+// position 8 i + x takes the i-th tile of stream x.  VGX_FUSED_TILE_ORDER=0 keeps the plain
+// constraint-major order (A/B, profiles/ab_order.sh).  Only the launch order changes: every tile
+// writes its partial sums to its own slot, so results are bit for bit the same either way.
+static void make_xcd_order(const std::vector<ConstraintDev>& desc, const std::vector<int32_t>& tile_first,
+                           const std::vector<int32_t>& tile_work, std::vector<Tile>& tiles) {
+  static const bool enabled = [] {
+    const char* e = getenv("VGX_FUSED_TILE_ORDER");
+    return e ? atoi(e) != 0 : true;
+  }();
+  const int n = (int)desc.size();
+  if (!enabled || n < 2 || tiles.size() < 16) return;
+  constexpr int kXcds = 8;
+  // groups of constraints reading the same points (sampling constraints read scattered points: alone)
+  std::vector<std::vector<int>> groups;
+  {
+    std::vector<std::pair<const void*, int>> key;  // (points, group)
+    for (int c = 0; c < n; ++c) {
+      int g = -1;
+      if (!desc[(size_t)c].sample_raw)
+        for (auto& k : key)
+          if (k.first == (const void*)desc[(size_t)c].xyzd) g = k.second;
+      if (g < 0) {
+        g = (int)groups.size();
+        groups.emplace_back();
+        if (!desc[(size_t)c].sample_raw) key.emplace_back((const void*)desc[(size_t)c].xyzd, g);
+      }
+      groups[(size_t)g].push_back(c);
+    }
+  }
+  // each group's tiles: chunk range major, constraint minor; its work = the points its tiles will
+  // really load (chunk culling at the poses of the first evaluation) + a little per tile
+  std::vector<std::vector<Tile>> group_tiles(groups.size());
+  std::vector<int64_t> group_work(groups.size(), 0);
+  for (size_t g = 0; g < groups.size(); ++g) {
+    int most = 0;
+    for (int c : groups[g]) most = std::max(most, tile_first[(size_t)c + 1] - tile_first[(size_t)c]);
+    for (int r = 0; r < most; ++r)
+      for (int c : groups[g])
+        if (r < tile_first[(size_t)c + 1] - tile_first[(size_t)c]) {
+          const size_t t = (size_t)tile_first[(size_t)c] + (size_t)r;
+          group_tiles[g].push_back(tiles[t]);
+          group_work[g] += (int64_t)tile_work[t] + 256;
+        }
+  }
+  // How much of the point traffic is shareable at all: per (group, chunk range) everything beyond the
+  // heaviest constraint's points could come out of the L2.  Measured (profiles/ab_order.sh): the
+  // full-overlap workload (0.83 shareable) 4.03 -> 2.67 ms and 27.7 -> 11.9 GB of fabric reads; config 3
+  // (constraints of a group overlap DIFFERENT parts of the reference, little to share) 1.66 -> 1.64 ms;
+  // config 5 1.17 -> 1.42 ms: long runs of heavy and of culled tiles per XCD stall the in-order
+  // dispatcher.  So the grouped order is used only where there is something to share and little is culled.
+  {
+    int64_t total = 0, shareable = 0;
+    for (size_t g = 0; g < groups.size(); ++g) {
+      int most = 0;
+      for (int c : groups[g]) most = std::max(most, tile_first[(size_t)c + 1] - tile_first[(size_t)c]);
+      for (int r = 0; r < most; ++r) {
+        int64_t sum = 0, mx = 0;
+        for (int c : groups[g])
+          if (r < tile_first[(size_t)c + 1] - tile_first[(size_t)c]) {
+            const int64_t w = tile_work[(size_t)tile_first[(size_t)c] + (size_t)r];
+            sum += w;
+            mx = std::max(mx, w);
+          }
+        total += sum;
+        shareable += sum - mx;
+      }
+    }
+    static const double threshold = [] {
+      const char* e = getenv("VGX_FUSED_SHARE_THRESHOLD");
+      return e ? atof(e) : 0.3;
+    }();
+    if (getenv("VGX_DEBUG_ORDER"))
+      fprintf(stderr, "[vgx] fused tile order: %zu tiles, %zu groups, shareable %.3f of %lld loaded points\n",
+              tiles.size(), groups.size(), total ? (double)shareable / (double)total : 0.0, (long long)total);
+    if (total == 0 || (double)shareable < threshold * (double)total) return;
+    // ... and only when few tiles are culled: with long runs of culled (instant) and of heavy tiles in
+    // one XCD's sequence the in-order dispatcher stalls the other XCDs (config 5 above: 56 % culled)
+    int64_t all_points = 0;
+    for (const Tile& t : tiles) all_points += t.count;
+    if ((double)total < 0.75 * (double)all_points) return;
+  }
+  // heaviest group first onto the least loaded stream: the XCDs finish together
+  std::vector<size_t> order(groups.size());
+  for (size_t g = 0; g < order.size(); ++g) order[g] = g;
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return group_work[a] > group_work[b]; });
+  std::vector<std::vector<Tile>> stream(kXcds);
+  std::vector<int64_t> load(kXcds, 0);
+  for (size_t g : order) {
+    int best = 0;
+    for (int x = 1; x < kXcds; ++x)
+      if (load[(size_t)x] < load[(size_t)best]) best = x;
+    stream[(size_t)best].insert(stream[(size_t)best].end(), group_tiles[g].begin(), group_tiles[g].end());
+    load[(size_t)best] += group_work[g];
+  }
+  // interleave; a stream that has run dry lends its positions to the fullest one
+  std::vector<size_t> next(kXcds, 0);
+  std::vector<Tile> out;
+  out.reserve(tiles.size());
+  while (out.size() < tiles.size())
+    for (int x = 0; x < kXcds && out.size() < tiles.size(); ++x) {
+      int src = x;
+      if (next[(size_t)src] >= stream[(size_t)src].size()) {
+        size_t left = 0;
+        for (int y = 0; y < kXcds; ++y) {
+          const size_t l = stream[(size_t)y].size() - next[(size_t)y];
+          if (l > left) {
+            left = l;
+            src = y;
+          }
+        }
+      }
+      out.push_back(stream[(size_t)src][next[(size_t)src]++]);
+    }
+  tiles.swap(out);
 }
 
 // One workgroup per constraint: 12 groups of 21 lanes sum the constraint's tile
@@ -1530,81 +1506,15 @@ int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs, const int3
     b->row_offset[(size_t)c + 1] = b->row_offset[(size_t)c] + regs[c]->num_residuals;
     std::vector<Tile> t = make_tiles(c, regs[c]->num_residuals, kTilePoints);
     b->tiles.insert(b->tiles.end(), t.begin(), t.end());
+    tile_first[(size_t)c] = (int32_t)ex->reduce_tiles.size();
+    std::vector<Tile> rt = make_tiles(c, regs[c]->num_residuals, kTilePoints * reduce_iters);
+    ex->reduce_tiles.insert(ex->reduce_tiles.end(), rt.begin(), rt.end());
     max_node = std::max(max_node, std::max(node_pair[2 * c], node_pair[2 * c + 1]));
   }
-  // Fused pass: constraints that read the same registration points (all-points constraints with the
-  // same reference submap and point type) form a group and go through the grouped kernel, which
-  // fetches a chunk of points once for up to kGroupWaves of them; everything else (sampling
-  // constraints, constraints alone on their point set) goes through the lean kernel.  VGX_FUSED_GROUPS=0
-  // sends everything through the lean kernel (A/B, profiles/ab_group.sh).
-  static const bool use_groups = [] {
-    const char* e = getenv("VGX_FUSED_GROUPS");
-    return e ? atoi(e) != 0 : true;
-  }();
-  std::vector<int> group_of((size_t)n, -1);
-  std::vector<std::vector<int>> groups;
-  if (use_groups) {
-    std::vector<std::pair<const void*, int>> key;
-    for (int c = 0; c < n; ++c) {
-      if (regs[c]->sampling() || regs[c]->num_residuals == 0) continue;
-      const void* pts = (const void*)desc[(size_t)c].xyzd;
-      int gidx = -1;
-      for (auto& k : key)
-        if (k.first == pts) gidx = k.second;
-      if (gidx < 0) {
-        gidx = (int)groups.size();
-        groups.emplace_back();
-        key.emplace_back(pts, gidx);
-      }
-      groups[(size_t)gidx].push_back(c);
-    }
-    for (size_t gi = 0; gi < groups.size(); ++gi)
-      if (groups[gi].size() >= 2)
-        for (int c : groups[gi]) group_of[(size_t)c] = (int)gi;
-  }
-  const int64_t group_tile_points = (int64_t)kTilePoints * reduce_iters;  // the lean kernel's tile size
-  static const int group_m = [] {
-    const char* e = getenv("VGX_FUSED_GROUP_M");
-    const int v = e ? atoi(e) : kGroupMembersDefault;
-    return v < 2 ? 2 : (v > 4 ? 4 : v);
-  }();
-  int32_t slots = 0;
-  for (int c = 0; c < n; ++c) {
-    tile_first[(size_t)c] = slots;
-    if (group_of[(size_t)c] >= 0) {
-      slots += (int32_t)((regs[c]->num_residuals + group_tile_points - 1) / group_tile_points);
-    } else {
-      std::vector<Tile> rt = make_tiles(c, regs[c]->num_residuals, kTilePoints * reduce_iters);
-      ex->reduce_tiles.insert(ex->reduce_tiles.end(), rt.begin(), rt.end());
-      slots += (int32_t)rt.size();
-    }
-  }
-  tile_first[(size_t)n] = slots;
-  ex->n_partial_slots = slots;
+  tile_first[(size_t)n] = (int32_t)ex->reduce_tiles.size();
   ex->reduce_tile_points = kTilePoints * reduce_iters;
-  std::vector<GroupTile> gtiles;
-  std::vector<int32_t> members;
-  for (size_t gi = 0; gi < groups.size(); ++gi) {
-    if (groups[gi].size() < 2) continue;
-    const int64_t npts = regs[groups[gi][0]]->num_residuals;  // all-points constraints of one set: same n
-    for (size_t m0 = 0; m0 < groups[gi].size(); m0 += (size_t)group_m) {
-      const int32_t first = (int32_t)members.size();
-      const int32_t cnt = (int32_t)std::min<size_t>((size_t)group_m, groups[gi].size() - m0);
-      for (int32_t w = 0; w < cnt; ++w) members.push_back(groups[gi][m0 + (size_t)w]);
-      for (int64_t st = 0; st < npts; st += group_tile_points) {
-        GroupTile gt;
-        gt.first_member = first;
-        gt.n_members = cnt;
-        gt.count = (int32_t)std::min<int64_t>(group_tile_points, npts - st);
-        gt.pad = 0;
-        gt.start = st;
-        gtiles.push_back(gt);
-      }
-    }
-  }
-  ex->n_group_tiles = (int32_t)gtiles.size();
-  ex->group_m = group_m;
-  ex->host_desc = desc;            // (sample_raw is filled in below) kept for vgx_reg_batch_count_live
+  ex->host_desc = desc;            // (sample_raw is filled in below) for the launch order, made at the first evaluation
+  ex->host_tile_first = tile_first;
   // Sampling constraints: group by engine (order of first appearance).  One evaluation of the
   // batch is one Evaluate of every constraint in list order, so the constraints of an engine
   // consume consecutive ranges of its stream, 2 words per residual (RCF:113-122).
@@ -1675,8 +1585,6 @@ int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs, const int3
   int rc = up(desc.data(), desc.size() * sizeof(ConstraintDev), (void**)&b->d_desc);
   if (rc == VGX_OK) rc = up(b->tiles.data(), b->tiles.size() * sizeof(Tile), (void**)&b->d_tiles);
   if (rc == VGX_OK) rc = up(ex->reduce_tiles.data(), ex->reduce_tiles.size() * sizeof(Tile), (void**)&ex->d_reduce_tiles);
-  if (rc == VGX_OK) rc = up(gtiles.data(), gtiles.size() * sizeof(GroupTile), (void**)&ex->d_group_tiles);
-  if (rc == VGX_OK) rc = up(members.data(), members.size() * sizeof(int32_t), (void**)&ex->d_group_members);
   if (rc == VGX_OK) rc = up(tile_first.data(), tile_first.size() * sizeof(int32_t), (void**)&b->d_tile_first);
   if (rc == VGX_OK) rc = up(b->node_pair.data(), b->node_pair.size() * sizeof(int32_t), (void**)&b->d_node_pair);
   if (rc == VGX_OK) rc = up(b->global_index.data(), b->global_index.size() * sizeof(int32_t), (void**)&b->d_global_index);
@@ -1687,7 +1595,7 @@ int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs, const int3
         hipHostMalloc(&b->h_pack, 2 * (size_t)n * sizeof(PosePack)) != hipSuccess ||
         hipEventCreateWithFlags(&b->pack_copied[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&b->pack_copied[1], hipEventDisableTiming) != hipSuccess ||
-        hipMalloc(&b->d_partials, std::max<size_t>(1, (size_t)ex->n_partial_slots) * kPartialSize * sizeof(double)) != hipSuccess ||
+        hipMalloc(&b->d_partials, std::max<size_t>(1, ex->reduce_tiles.size()) * kPartialSize * sizeof(double)) != hipSuccess ||
         hipMalloc(&b->d_normal, (size_t)n * kNormalSize * sizeof(double)) != hipSuccess)
       rc = set_error(ctx, VGX_ERR_NOMEM, "vgx_reg_batch_create: device allocation failed");
   }
@@ -1708,8 +1616,6 @@ int vgx_reg_batch_destroy(vgx_reg_batch b) {
   if (b->d_node_first) (void)hipFree(b->d_node_first);
   if (b->d_node_items) (void)hipFree(b->d_node_items);
   if (b->d_reduce_tiles) (void)hipFree(b->d_reduce_tiles);
-  if (b->d_group_tiles) (void)hipFree(b->d_group_tiles);
-  if (b->d_group_members) (void)hipFree(b->d_group_members);
   if (b->d_desc) (void)hipFree(b->d_desc);
   if (b->d_pack) (void)hipFree(b->d_pack);
   if (b->h_pack) (void)hipHostFree(b->h_pack);
@@ -1807,26 +1713,26 @@ int vgx_reg_batch_evaluate_normal(vgx_reg_batch b, const double* poses, int32_t 
   if (b->n == 0) return VGX_OK;
   double* out = d_normal ? (double*)d_normal : b->d_normal;
   const int n_tiles = (int)ex->reduce_tiles.size();
+  if (!ex->launch_order_made && n_tiles > 0) {
+    // one-time: per-tile live points at these poses -> XCD-aware launch order (results do not
+    // depend on the order: every tile writes its own slot)
+    DeviceScratch s_live;
+    VGX_HIP(ctx, s_live.alloc((size_t)n_tiles * sizeof(int32_t)));
+    hipLaunchKernelGGL(reg_tile_live_kernel, dim3(n_tiles), dim3(64), 0, ctx->stream, b->d_desc, b->d_pack,
+                       ex->d_reduce_tiles, n_tiles, s_live.as<int32_t>());
+    VGX_HIP(ctx, hipGetLastError());
+    std::vector<int32_t> work((size_t)n_tiles);
+    VGX_HIP(ctx, hipMemcpyAsync(work.data(), s_live.p, work.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<Tile> ordered = ex->reduce_tiles;
+    make_xcd_order(ex->host_desc, ex->host_tile_first, work, ordered);
+    VGX_HIP(ctx, hipMemcpy(ex->d_reduce_tiles, ordered.data(), ordered.size() * sizeof(Tile), hipMemcpyHostToDevice));
+    ex->launch_order_made = true;
+  }
   static const int variant = [] {
     const char* e = getenv("VGX_FUSED_KERNEL");  // A/B switch (profiles/ab_fused2.sh)
     return e ? atoi(e) : kFusedVariantDefault;
   }();
-  if (ex->n_group_tiles > 0) {
-    dim3 grid((unsigned)ex->n_group_tiles), block(kBlockThreads);
-    const int vps16 = b->regs[0]->reading->vps == 16;
-#define VGX_LAUNCH_GROUP(VPS, M, W)                                                                    \
-  hipLaunchKernelGGL((reg_eval_reduce_group_kernel<VPS, M, W>), grid, block, 0, ctx->stream, b->d_desc, \
-                     b->d_pack, (const GroupTile*)ex->d_group_tiles, ex->d_group_members, b->d_tile_first, \
-                     ex->reduce_tile_points, b->d_partials)
-    switch (ex->group_m) {
-      // waves/SIMD: what the M accumulator sets leave room for without spilling (128 / 168 VGPRs spill)
-      case 2: if (vps16) VGX_LAUNCH_GROUP(16, 2, 3); else VGX_LAUNCH_GROUP(8, 2, 3); break;
-      case 3: if (vps16) VGX_LAUNCH_GROUP(16, 3, 2); else VGX_LAUNCH_GROUP(8, 3, 2); break;
-      default: if (vps16) VGX_LAUNCH_GROUP(16, 4, 2); else VGX_LAUNCH_GROUP(8, 4, 2); break;
-    }
-#undef VGX_LAUNCH_GROUP
-    VGX_HIP(ctx, hipGetLastError());
-  }
   if (n_tiles > 0) {
     dim3 grid(n_tiles), block(kBlockThreads);
     const int vps = b->regs[0]->reading->vps;
