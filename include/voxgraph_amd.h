@@ -365,6 +365,7 @@ typedef struct vgx_tsdf_config {
   float start_voxel_subsampling_factor; /* 2.0   */
   int32_t max_consecutive_ray_collisions; /* 2   */
   int32_t clear_checks_every_n_frames;  /* 1     */
+  int32_t enable_anti_grazing;          /* 0     (merged integrator only) */
 } vgx_tsdf_config;
 VGX_API void vgx_tsdf_config_default(vgx_tsdf_config* cfg);
 
@@ -416,6 +417,20 @@ VGX_API int vgx_tsdf_integrate(vgx_tsdf_integrator integrator, const float T_G_C
 VGX_API int vgx_tsdf_integrate_device(vgx_tsdf_integrator integrator, const float T_G_C[7],
                                       const void* d_points_C, const void* d_rgba, int64_t n,
                                       int32_t freespace_points, int64_t* n_updates);
+
+/* voxblox::MergedTsdfIntegrator::integratePointCloud (north_star names it; voxgraph itself
+ * constructs the Fast integrator, pointcloud_integrator.h:30) on the same integrator object -- config
+ * and layer; the approximate sets of the fast integrator are not involved: the valid points are
+ * grouped by the voxel their end point falls in (clearing rays separately), every group is merged
+ * into one weighted-mean point in the reference's visiting order and ONE ray is cast for it through
+ * all its voxels with the summed weight; with enable_anti_grazing a ray skips voxels that are the end
+ * voxel of another group.  Same argument conventions as vgx_tsdf_integrate[_device]. */
+VGX_API int vgx_tsdf_integrate_merged(vgx_tsdf_integrator integrator, const float T_G_C[7],
+                                      const float* points_C, const uint8_t* rgba, int64_t n,
+                                      int32_t freespace_points, int64_t* n_updates);
+VGX_API int vgx_tsdf_integrate_merged_device(vgx_tsdf_integrator integrator, const float T_G_C[7],
+                                             const void* d_points_C, const void* d_rgba, int64_t n,
+                                             int32_t freespace_points, int64_t* n_updates);
 
 /* finishSubmap() hand-off without a host round trip: turns the active layer's blocks
  * into a (not yet finished) submap holding the raw TSDF layer and its TSDF sampling

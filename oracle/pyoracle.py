@@ -253,7 +253,8 @@ class TsdfConfig(C.Structure):
                 ("sparsity_compensation_factor", C.c_float),
                 ("start_voxel_subsampling_factor", C.c_float),
                 ("max_consecutive_ray_collisions", C.c_int),
-                ("clear_checks_every_n_frames", C.c_int), ("integration_order_mixed", C.c_int)]
+                ("clear_checks_every_n_frames", C.c_int), ("integration_order_mixed", C.c_int),
+                ("enable_anti_grazing", C.c_int)]
 
 
 _tsdf_bound = False
@@ -276,6 +277,8 @@ def _tsdf_lib():
         L.orc_tsdf_integrator_set_layer.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_tsdf_integrate.argtypes = [C.c_void_p, c_f32p, c_f32p, c_u8p, C.c_int64, C.c_int]
         L.orc_tsdf_integrate.restype = C.c_int64
+        L.orc_tsdf_merged_integrate.argtypes = [C.c_void_p, c_f32p, c_f32p, c_u8p, C.c_int64, C.c_int]
+        L.orc_tsdf_merged_integrate.restype = C.c_int64
         _tsdf_bound = True
     return L
 
@@ -341,6 +344,14 @@ class FastTsdfIntegrator:
         col = None if colors is None else np.ascontiguousarray(colors, np.uint8).reshape(-1, 4)
         return _tsdf_lib().orc_tsdf_integrate(self.h, _p(T, c_f32p), _p(pts, c_f32p),
                                               _p(col, c_u8p), pts.shape[0], int(freespace_points))
+
+    def integratePointCloudMerged(self, T_G_C, points_C, colors=None, freespace_points=False):
+        """voxblox::MergedTsdfIntegrator::integratePointCloud on the same config / layer"""
+        T = _f32(T_G_C)
+        pts = _f32(points_C).reshape(-1, 3)
+        col = None if colors is None else np.ascontiguousarray(colors, np.uint8).reshape(-1, 4)
+        return _tsdf_lib().orc_tsdf_merged_integrate(self.h, _p(T, c_f32p), _p(pts, c_f32p),
+                                                     _p(col, c_u8p), pts.shape[0], int(freespace_points))
 
     def __del__(self):
         try:

@@ -28,6 +28,7 @@ void orc_tsdf_config_default(orc_tsdf_config* c) {
   c->max_consecutive_ray_collisions = 2;
   c->clear_checks_every_n_frames = 1;
   c->integration_order_mixed = 1;
+  c->enable_anti_grazing = 0;
 }
 
 /* ---- Layer<TsdfVoxel>: hash map BlockIndex -> block ---------------------- */
@@ -399,5 +400,192 @@ int64_t orc_tsdf_integrate(orc_tsdf_integrator* I, const float T_G_C[7], const f
       ++updates;
     }
   }
+  return updates;
+}
+
+/* ---- MergedTsdfIntegrator ---------------------------------------------------------------------- */
+typedef struct {
+  uint64_t key;  /* bit 63: clearing ray; bits 62..0: end voxel, 21 bits per axis biased by 2^20 */
+  int64_t rank;  /* position in the visiting order (MixedThreadSafeIndex) */
+  int64_t pi;    /* point index */
+} merged_entry;
+
+static int merged_cmp(const void* a, const void* b) {
+  const merged_entry* x = (const merged_entry*)a;
+  const merged_entry* y = (const merged_entry*)b;
+  if (x->key != y->key) return x->key < y->key ? -1 : 1;
+  return x->rank < y->rank ? -1 : (x->rank > y->rank ? 1 : 0);
+}
+
+static uint64_t pack_voxel_key(const int64_t v[3], int clearing) {
+  const uint64_t B = 1u << 20;
+  return ((uint64_t)clearing << 63) | (((uint64_t)(v[0] + (int64_t)B) & 0x1fffff) << 42) |
+         (((uint64_t)(v[1] + (int64_t)B) & 0x1fffff) << 21) | ((uint64_t)(v[2] + (int64_t)B) & 0x1fffff);
+}
+
+/* is `key` (a surface key) the end voxel of some surface group?  keys[0..n_surface) sorted */
+static int in_voxel_map(const merged_entry* e, int64_t n_surface, uint64_t key) {
+  int64_t lo = 0, hi = n_surface;
+  while (lo < hi) {
+    int64_t mid = (lo + hi) / 2;
+    if (e[mid].key < key) lo = mid + 1; else hi = mid;
+  }
+  return lo < n_surface && e[lo].key == key;
+}
+
+int64_t orc_tsdf_merged_integrate(orc_tsdf_integrator* I, const float T_G_C[7], const float* points_C,
+                                  const uint8_t* rgba, int64_t n, int freespace_points) {
+  const orc_tsdf_config* c = &I->cfg;
+  orc_tsdf_layer* L = I->layer;
+  const int vps = L->vps;
+  const float vsi = L->voxel_size_inv;
+  static const uint8_t zero_color[4] = {0, 0, 0, 0};
+  const float origin[3] = {T_G_C[4], T_G_C[5], T_G_C[6]};
+  merged_entry* e = (merged_entry*)malloc((size_t)(n > 0 ? n : 1) * sizeof(merged_entry));
+  int64_t m = 0, n_surface = 0, updates = 0;
+  /* bundleRays */
+  const int64_t step_size = 1024;
+  const int64_t number_of_groups = n / step_size;
+  for (int64_t seq = 0; seq < n; ++seq) {
+    int64_t pi = seq;
+    if (c->integration_order_mixed && seq < number_of_groups * step_size) {
+      int64_t group_num = seq % number_of_groups;
+      int64_t position_in_group = seq / number_of_groups;
+      pi = group_num * step_size + position_in_group;
+    }
+    const float* point_C = &points_C[3 * pi];
+    int is_clearing;
+    const float ray_distance = norm3(point_C);
+    if (ray_distance < c->min_ray_length_m) {
+      continue;
+    } else if (ray_distance > c->max_ray_length_m) {
+      if (c->allow_clear || freespace_points) is_clearing = 1; else continue;
+    } else {
+      is_clearing = freespace_points;
+    }
+    float point_G[3];
+    transform_point(T_G_C, point_C, point_G);
+    int64_t v[3];
+    for (int a = 0; a < 3; ++a) v[a] = (int64_t)floorf(point_G[a] * vsi + kCoordinateEpsilon);
+    e[m].key = pack_voxel_key(v, is_clearing);
+    e[m].rank = seq;
+    e[m].pi = pi;
+    ++m;
+    if (!is_clearing) ++n_surface;
+  }
+  qsort(e, (size_t)m, sizeof(merged_entry), merged_cmp);
+  /* integrateRays(clearing_ray = false), then (true): the sort put the surface groups first */
+  for (int64_t i0 = 0; i0 < m;) {
+    int64_t i1 = i0;
+    while (i1 < m && e[i1].key == e[i0].key) ++i1;
+    const int clearing_ray = (int)(e[i0].key >> 63);
+    /* integrateVoxel: merge */
+    float merged_point_C[3] = {0.0f, 0.0f, 0.0f}, merged_weight = 0.0f;
+    uint8_t merged_color[4] = {0, 0, 0, 0};
+    for (int64_t i = i0; i < i1; ++i) {
+      const float* point_C = &points_C[3 * e[i].pi];
+      const uint8_t* color = rgba ? &rgba[4 * e[i].pi] : zero_color;
+      float point_weight;
+      if (c->use_const_weight) {
+        point_weight = 1.0f;
+      } else {
+        float dist_z = fabsf(point_C[2]);
+        point_weight = dist_z > kEpsilon ? 1.0f / (dist_z * dist_z) : 0.0f;
+      }
+      if (point_weight < kEpsilon) continue;
+      const float total = merged_weight + point_weight;
+      for (int a = 0; a < 3; ++a)
+        merged_point_C[a] = (merged_point_C[a] * merged_weight + point_C[a] * point_weight) / total;
+      /* Color::blendTwoColors(merged_color, merged_weight, color, point_weight) */
+      {
+        const float fw = merged_weight / total, sw = point_weight / total;
+        for (int k = 0; k < 4; ++k)
+          merged_color[k] = (uint8_t)roundf((float)merged_color[k] * fw + (float)color[k] * sw);
+      }
+      merged_weight += point_weight;
+      if (clearing_ray) break; /* only take first point when clearing */
+    }
+    const uint64_t own_key = e[i0].key;
+    i0 = i1;
+    if (merged_weight == 0.0f) continue; /* every update would leave its voxel unchanged */
+    float point_G[3];
+    transform_point(T_G_C, merged_point_C, point_G);
+    /* RayCaster(origin, merged_point_G, clearing_ray, carving, max_ray, voxel_size_inv, trunc, false) */
+    float d[3] = {point_G[0] - origin[0], point_G[1] - origin[1], point_G[2] - origin[2]};
+    float len = norm3(d);
+    float unit_ray[3] = {d[0] / len, d[1] / len, d[2] / len};
+    float ray_start[3], ray_end[3];
+    const float trunc = c->default_truncation_distance;
+    if (clearing_ray) {
+      float ray_length = fminf(fmaxf(len - trunc, 0.0f), c->max_ray_length_m);
+      for (int a = 0; a < 3; ++a) {
+        ray_end[a] = origin[a] + unit_ray[a] * ray_length;
+        ray_start[a] = c->voxel_carving_enabled ? origin[a] : ray_end[a];
+      }
+    } else {
+      for (int a = 0; a < 3; ++a) {
+        ray_end[a] = point_G[a] + unit_ray[a] * trunc;
+        ray_start[a] = c->voxel_carving_enabled ? origin[a] : (point_G[a] - unit_ray[a] * trunc);
+      }
+    }
+    float start_scaled[3], end_scaled[3];
+    int bad = 0;
+    for (int a = 0; a < 3; ++a) {
+      start_scaled[a] = ray_end[a] * vsi;
+      end_scaled[a] = ray_start[a] * vsi;
+      if (isnan(start_scaled[a]) || isnan(end_scaled[a])) bad = 1;
+    }
+    if (bad) continue;
+    int64_t curr[3], ray_length_in_steps = 0;
+    int step_sign[3];
+    float t_to_next[3], t_step[3];
+    for (int a = 0; a < 3; ++a) {
+      curr[a] = (int64_t)floorf(start_scaled[a] + kCoordinateEpsilon);
+      int64_t end_index = (int64_t)floorf(end_scaled[a] + kCoordinateEpsilon);
+      int64_t diff = end_index - curr[a];
+      ray_length_in_steps += diff < 0 ? -diff : diff;
+      float ray_scaled = end_scaled[a] - start_scaled[a];
+      step_sign[a] = signum(ray_scaled);
+      float corrected_step = (float)(step_sign[a] > 0 ? step_sign[a] : 0);
+      float distance_to_boundary = corrected_step - (start_scaled[a] - (float)curr[a]);
+      if (ray_scaled == 0.0f) {
+        t_to_next[a] = INFINITY;
+        t_step[a] = INFINITY;
+      } else {
+        t_to_next[a] = distance_to_boundary / ray_scaled;
+        t_step[a] = (float)step_sign[a] / ray_scaled;
+      }
+    }
+    for (int64_t current_step = 0; current_step <= ray_length_in_steps; ++current_step) {
+      int64_t v[3] = {curr[0], curr[1], curr[2]};
+      int t_min_idx = 0;
+      if (t_to_next[1] < t_to_next[t_min_idx]) t_min_idx = 1;
+      if (t_to_next[2] < t_to_next[t_min_idx]) t_min_idx = 2;
+      curr[t_min_idx] += step_sign[t_min_idx];
+      t_to_next[t_min_idx] += t_step[t_min_idx];
+      if (c->enable_anti_grazing) {
+        /* skip voxels that are the end voxel of a (different) surface group */
+        const uint64_t k = pack_voxel_key(v, 0);
+        if ((clearing_ray || k != own_key) && in_voxel_map(e, n_surface, k)) continue;
+      }
+      int32_t b[3], lv[3];
+      for (int a = 0; a < 3; ++a) {
+        int64_t q = v[a] / vps, r = v[a] % vps;
+        if (r < 0) {
+          r += vps;
+          q -= 1;
+        }
+        b[a] = (int32_t)q;
+        lv[a] = (int32_t)r;
+      }
+      int slot = layer_get_or_allocate(L, b[0], b[1], b[2]);
+      size_t lin = (size_t)lv[0] + (size_t)vps * ((size_t)lv[1] + (size_t)vps * (size_t)lv[2]);
+      size_t at = (size_t)slot * L->nvox + lin;
+      update_voxel(I, origin, point_G, v, merged_color, merged_weight, &L->distance[at], &L->weight[at],
+                   &L->rgba[4 * at]);
+      ++updates;
+    }
+  }
+  free(e);
   return updates;
 }

@@ -40,6 +40,7 @@ typedef struct orc_tsdf_config {
   int max_consecutive_ray_collisions;     /* 2            */
   int clear_checks_every_n_frames;        /* 1            */
   int integration_order_mixed;            /* 1: "mixed" (default), 0: sequential */
+  int enable_anti_grazing;                /* 0 (MergedTsdfIntegrator only)        */
 } orc_tsdf_config;
 
 void orc_tsdf_config_default(orc_tsdf_config* cfg);
@@ -66,6 +67,18 @@ void orc_tsdf_integrator_set_layer(orc_tsdf_integrator* I, orc_tsdf_layer* layer
 int64_t orc_tsdf_integrate(orc_tsdf_integrator* I, const float T_G_C[7],
                            const float* points_C, const uint8_t* rgba, int64_t n,
                            int freespace_points);
+
+/* voxblox::MergedTsdfIntegrator::integratePointCloud [recalled, integrator/tsdf_integrator.cc]:
+ * bundleRays groups the valid points by the voxel their end point falls in (clearing rays in a map of
+ * their own), integrateVoxel merges a group into one weighted-mean point (running mean in visiting
+ * order, weight = sum of the point weights; a clearing group keeps only its first point), casts ONE
+ * ray for it through all its voxels (no early-out) and updates every voxel with the merged weight;
+ * with enable_anti_grazing a ray skips voxels that are the end voxel of another group.  All surface
+ * groups first, then all clearing groups.  Uses the same integrator object (config, layer); the
+ * approximate sets are not involved.  Returns the number of voxel updates. */
+int64_t orc_tsdf_merged_integrate(orc_tsdf_integrator* I, const float T_G_C[7],
+                                  const float* points_C, const uint8_t* rgba, int64_t n,
+                                  int freespace_points);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,135 @@
+"""voxblox::MergedTsdfIntegrator on the device (vgx_tsdf_integrate_merged) against its CPU restatement
+(oracle/tsdf_oracle.c orc_tsdf_merged_integrate; voxblox is not vendored: PARITY UNPINNED).
+
+Unlike the fast integrator, the merged one has no approximate sets and no early-out, so WHICH voxels
+are updated and with WHAT merged point and weight is deterministic; only the order in which different
+rays' updates land on a shared voxel differs between runs and implementations (a weighted running
+average: the same in exact arithmetic, last bits in f32).  So: voxel sets, update counts and integer
+weights exact; distances to f32 rounding; bit-exact where no voxel is shared."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as orc
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from voxgraph_amd import capi as m
+    m.load()
+    return m
+
+
+@pytest.fixture(scope="module")
+def ctx(capi):
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def _as_dict(bi, d, w, rgba, vps):
+    out = {}
+    lin = np.arange(vps ** 3)
+    for b in range(len(bi)):
+        base = bi[b].astype(np.int64) * vps
+        keys = np.stack([base[0] + lin % vps, base[1] + (lin // vps) % vps, base[2] + lin // (vps * vps)], 1)
+        sel = np.nonzero(w[b] > 0)[0]
+        for k, dd, ww, cc in zip(map(tuple, keys[sel]), d[b][sel], w[b][sel], rgba[b][sel]):
+            out[k] = (dd, ww, tuple(cc))
+    return out
+
+
+def _room_scan(n_az, n_el, seed):
+    rng = np.random.default_rng(seed)
+    az = np.linspace(-np.pi, np.pi, n_az, endpoint=False)
+    el = np.deg2rad(np.linspace(-20, 20, n_el))
+    A, E = np.meshgrid(az, el)
+    dirs = np.stack([np.cos(E) * np.cos(A), np.cos(E) * np.sin(A), np.sin(E)], -1).reshape(-1, 3)
+    lo, hi = np.array([-4.0, -3.0, -1.0]), np.array([4.0, 3.0, 2.0])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t = np.where(dirs > 0, hi / dirs, np.where(dirs < 0, lo / dirs, np.inf)).min(1)
+    pts = dirs * t[:, None]
+    pts[::37] *= 4.0                                    # some returns beyond max range: clearing rays
+    pts[5::41] *= 0.01                                  # some below min range: dropped
+    cols = rng.integers(0, 255, (len(pts), 4)).astype(np.uint8)
+    return pts.astype(F), cols
+
+
+@pytest.mark.parametrize("const_weight,anti_grazing", [(1, 0), (0, 0), (1, 1)])
+def test_merged_scans_against_the_oracle(capi, ctx, const_weight, anti_grazing):
+    vs, vps = 0.1, 16
+    kw = dict(default_truncation_distance=0.3, max_ray_length_m=6.0, use_const_weight=const_weight,
+              use_weight_dropoff=1, enable_anti_grazing=anti_grazing)
+    ol, gl = orc.TsdfLayer(vs, vps), capi.TsdfLayer(ctx, vs, vps)
+    oi, gi = orc.FastTsdfIntegrator(orc.tsdf_config(**kw), ol), capi.FastTsdfIntegrator(ctx, capi.tsdf_config(**kw), gl)
+    total = 0
+    for k in range(3):
+        pts, cols = _room_scan(360, 48, k)              # 17 280 points: ~4 points per end voxel
+        T = np.array([np.cos(0.1 * k), 0, 0, np.sin(0.1 * k), 0.3 * k, -0.2 * k, 0.05], F)
+        n_o = oi.integratePointCloudMerged(T, pts, cols)
+        n_g = gi.integratePointCloudMerged(T, pts, cols)
+        assert n_o == n_g > 20000, (k, n_o, n_g)      # same groups, same rays, same voxels
+        total += n_g
+    A = _as_dict(*ol.download(), vps)
+    B = _as_dict(*gl.download(), vps)
+    assert A.keys() == B.keys() and len(A) > 50000
+    assert gl.stats()[1] == 0
+    dw = max(abs(A[k][1] - B[k][1]) / max(A[k][1], 1e-9) for k in A)
+    dd = max(abs(A[k][0] - B[k][0]) for k in A)
+    # integer weights (const weight) add exactly in any order; 1/z^2 weights and distances to rounding
+    assert dw <= (0.0 if const_weight else 2e-6), dw
+    assert dd <= 2e-6, dd
+    exact = sum(A[k][0] == B[k][0] for k in A) / len(A)
+    assert exact > 0.9                                   # the bulk is bit-identical
+    for o in (gi, gl):
+        o.destroy()
+
+
+def test_merged_single_group_and_disjoint_rays_are_bit_exact(capi, ctx):
+    """no voxel shared between rays => nothing depends on update order: bit for bit, colours included"""
+    vs, vps = 0.2, 16
+    kw = dict(default_truncation_distance=0.6, max_ray_length_m=30.0, voxel_carving_enabled=0, use_const_weight=0)
+    ol, gl = orc.TsdfLayer(vs, vps), capi.TsdfLayer(ctx, vs, vps)
+    oi, gi = orc.FastTsdfIntegrator(orc.tsdf_config(**kw), ol), capi.FastTsdfIntegrator(ctx, capi.tsdf_config(**kw), gl)
+    rng = np.random.default_rng(2)
+    yy, zz = np.meshgrid(np.arange(-20, 20, 2.5), np.arange(-10, 10, 2.5))
+    base = np.stack([np.full(yy.size, 14.0), yy.ravel(), zz.ravel()], 1)
+    # five points per end voxel (jitter well inside the 0.2 m voxel), groups 2.5 m apart
+    pts = (base[:, None, :] + 0.05 + rng.uniform(0, 0.08, (len(base), 5, 3))).reshape(-1, 3).astype(F)
+    cols = rng.integers(0, 255, (len(pts), 4)).astype(np.uint8)
+    T = np.array([1, 0, 0, 0, 0.01, 0.02, 0.03], F)
+    assert oi.integratePointCloudMerged(T, pts, cols) == gi.integratePointCloudMerged(T, pts, cols) > 0
+    A = _as_dict(*ol.download(), vps)
+    B = _as_dict(*gl.download(), vps)
+    assert A.keys() == B.keys()
+    bad = [k for k in A if A[k] != B[k]]
+    assert not bad, (len(bad), bad[:3], A[bad[0]], B[bad[0]])
+    # merging really happened: weights are sums of five 1/z^2 terms, not single-point weights
+    assert max(v[1] for v in B.values()) > 4.0 / (14.2 ** 2)
+    for o in (gi, gl):
+        o.destroy()
+
+
+def test_merged_and_fast_agree_on_the_surface_they_reconstruct(capi, ctx):
+    """sanity across integrators: the zero crossing of both reconstructions is the same wall"""
+    import torch
+    vs, vps = 0.1, 16
+    kw = dict(default_truncation_distance=0.3, max_ray_length_m=6.0, use_const_weight=1)
+    pts, _ = _room_scan(720, 64, 9)
+    T = np.array([1, 0, 0, 0, 0.0, 0.0, 0.0], F)
+    dev = torch.from_numpy(pts).cuda()
+    torch.cuda.synchronize()
+    out = []
+    for merged in (False, True):
+        gl = capi.TsdfLayer(ctx, vs, vps)
+        gi = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(**kw), gl)
+        (gi.integrate_merged_device if merged else gi.integrate_device)(T, dev.data_ptr(), None, len(pts))
+        out.append(_as_dict(*gl.download(), vps))
+        for o in (gi, gl):
+            o.destroy()
+    common = [k for k in out[0].keys() & out[1].keys() if abs(out[0][k][0]) < 0.15]
+    assert len(common) > 5000
+    diff = np.array([abs(out[0][k][0] - out[1][k][0]) for k in common])
+    assert np.percentile(diff, 90) < 0.05

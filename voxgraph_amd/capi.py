@@ -69,7 +69,7 @@ class TsdfConfig(C.Structure):
                 ("sparsity_compensation_factor", C.c_float),
                 ("start_voxel_subsampling_factor", C.c_float),
                 ("max_consecutive_ray_collisions", C.c_int32),
-                ("clear_checks_every_n_frames", C.c_int32)]
+                ("clear_checks_every_n_frames", C.c_int32), ("enable_anti_grazing", C.c_int32)]
 
 
 # every symbol include/voxgraph_amd.h declares: name -> (restype, argtypes)
@@ -144,6 +144,8 @@ SIGNATURES = {
     "vgx_tsdf_integrator_set_layer": (C.c_int, [vp, vp]),
     "vgx_tsdf_integrate": (C.c_int, [vp, f32p, f32p, u8p, C.c_int64, C.c_int32, i64p]),
     "vgx_tsdf_integrate_device": (C.c_int, [vp, f32p, vp, vp, C.c_int64, C.c_int32, i64p]),
+    "vgx_tsdf_integrate_merged": (C.c_int, [vp, f32p, f32p, u8p, C.c_int64, C.c_int32, i64p]),
+    "vgx_tsdf_integrate_merged_device": (C.c_int, [vp, f32p, vp, vp, C.c_int64, C.c_int32, i64p]),
     "vgx_map_file_open": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(vp)]),
     "vgx_map_file_close": (C.c_int, [vp]),
     "vgx_map_file_last_error": (C.c_char_p, [vp]),
@@ -680,6 +682,25 @@ class FastTsdfIntegrator:
                                                        _ptr(col, u8p), pts.shape[0],
                                                        int(freespace_points), C.byref(n)))
         return n.value
+
+    def integratePointCloudMerged(self, T_G_C, points_C, colors=None, freespace_points=False):
+        """voxblox::MergedTsdfIntegrator::integratePointCloud (same config / layer)"""
+        T = _f32(T_G_C)
+        pts = _f32(points_C).reshape(-1, 3)
+        col = None if colors is None else np.ascontiguousarray(colors, np.uint8).reshape(-1, 4)
+        n = C.c_int64()
+        self.ctx.check(self.ctx.lib.vgx_tsdf_integrate_merged(self.h, _ptr(T, f32p), _ptr(pts, f32p),
+                                                              _ptr(col, u8p), pts.shape[0],
+                                                              int(freespace_points), C.byref(n)))
+        return n.value
+
+    def integrate_merged_device(self, T_G_C, d_points, d_rgba, n, freespace_points=False, count=False):
+        T = _f32(T_G_C)
+        out = C.c_int64()
+        self.ctx.check(self.ctx.lib.vgx_tsdf_integrate_merged_device(
+            self.h, _ptr(T, f32p), vp(d_points), vp(d_rgba) if d_rgba else None, n,
+            int(freespace_points), C.byref(out) if count else None))
+        return out.value
 
     def integrate_device(self, T_G_C, d_points, d_rgba, n, freespace_points=False, count=False):
         T = _f32(T_G_C)

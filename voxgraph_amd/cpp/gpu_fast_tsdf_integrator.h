@@ -91,6 +91,37 @@ class GpuFastTsdfIntegrator {
   vgx_tsdf_integrator integ_ = nullptr;
 };
 
+// voxblox::MergedTsdfIntegrator (the variant north_star also names; voxgraph constructs the Fast
+// one): same constructor, setLayer and integratePointCloud; points that end in the same voxel are
+// merged into one ray.  Config::enable_anti_grazing is voxblox's option of that name.
+class GpuMergedTsdfIntegrator {
+ public:
+  using Config = vgx_tsdf_config;
+  GpuMergedTsdfIntegrator(vgx_ctx ctx, const Config& config, GpuTsdfLayer* layer) : ctx_(ctx) {
+    if (vgx_tsdf_integrator_create(ctx, &config, layer ? layer->handle() : nullptr, &integ_) != VGX_OK)
+      throw std::runtime_error(std::string("vgx_tsdf_integrator_create: ") + vgx_last_error(ctx));
+  }
+  ~GpuMergedTsdfIntegrator() { vgx_tsdf_integrator_destroy(integ_); }
+  GpuMergedTsdfIntegrator(const GpuMergedTsdfIntegrator&) = delete;
+  GpuMergedTsdfIntegrator& operator=(const GpuMergedTsdfIntegrator&) = delete;
+
+  void setLayer(GpuTsdfLayer* layer) {
+    if (vgx_tsdf_integrator_set_layer(integ_, layer->handle()) != VGX_OK)
+      throw std::runtime_error("vgx_tsdf_integrator_set_layer failed");
+  }
+
+  void integratePointCloud(const float T_G_C[7], const float* points_C, const uint8_t* colors,
+                           int64_t n_points, bool freespace_points = false) {
+    if (vgx_tsdf_integrate_merged(integ_, T_G_C, points_C, colors, n_points, freespace_points ? 1 : 0,
+                                  nullptr) != VGX_OK)
+      throw std::runtime_error(std::string("vgx_tsdf_integrate_merged: ") + vgx_last_error(ctx_));
+  }
+
+ private:
+  vgx_ctx ctx_;
+  vgx_tsdf_integrator integ_ = nullptr;
+};
+
 }  // namespace voxgraph_amd
 
 #endif  // VOXGRAPH_AMD_CPP_GPU_FAST_TSDF_INTEGRATOR_H_

@@ -25,6 +25,8 @@
 #include <utility>
 #include <vector>
 
+#include <rocprim/rocprim.hpp>  // device radix sort (MergedTsdfIntegrator's bundleRays)
+
 #include "vgx_internal.h"
 
 #pragma clang fp contract(off)
@@ -437,6 +439,207 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(TsdfLayerDev L, Tsd
   }
 }
 
+// ---------------------------------------------------------------------------
+// voxblox::MergedTsdfIntegrator [recalled; restated in oracle/tsdf_oracle.c orc_tsdf_merged_integrate]
+// ---------------------------------------------------------------------------
+// bundleRays groups the valid points by the voxel their end point falls in, integrateVoxel merges a
+// group into one weighted-mean point and casts ONE ray for it.  On the device: every point gets the
+// key {clearing bit, end voxel} in the reference's visiting order (MixedThreadSafeIndex), a stable
+// radix sort brings the groups together with that order intact inside each group, one thread per
+// group merges its points sequentially (the running mean is order dependent in f32, so the order is
+// the reference's) and walks the ray, updating voxels with the same 64-bit CAS as the fast
+// integrator.  Surface groups first, clearing groups in a second launch (integrateRays twice).
+constexpr unsigned long long kMergedInvalid = ~0ull;
+constexpr long long kMergedBias = 1ll << 20;  // 21 bits per axis
+
+__device__ __forceinline__ unsigned long long merged_key(int x, int y, int z, bool clearing) {
+  return ((unsigned long long)clearing << 63) | (((unsigned long long)(x + kMergedBias) & 0x1fffffull) << 42) |
+         (((unsigned long long)(y + kMergedBias) & 0x1fffffull) << 21) | ((unsigned long long)(z + kMergedBias) & 0x1fffffull);
+}
+
+__global__ __launch_bounds__(256) void merged_bundle_kernel(vgx_tsdf_config c, float vsi, float qw, float qx, float qy,
+                                                           float qz, float tx, float ty, float tz,
+                                                           const float* __restrict__ points_C, long long n,
+                                                           int freespace_points, unsigned long long* __restrict__ keys,
+                                                           unsigned int* __restrict__ idx) {
+  const long long seq = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (seq >= n) return;
+  // MixedThreadSafeIndex: 1024-point groups visited round-robin, tail in order
+  const long long step_size = 1024, number_of_groups = n / step_size;
+  long long pi = seq;
+  if (seq < number_of_groups * step_size) pi = (seq % number_of_groups) * step_size + seq / number_of_groups;
+  const float px = points_C[3 * pi], py = points_C[3 * pi + 1], pz = points_C[3 * pi + 2];
+  bool valid = true, is_clearing = false;
+  const float ray_distance = norm3(px, py, pz);
+  if (ray_distance < c.min_ray_length_m) {
+    valid = false;
+  } else if (ray_distance > c.max_ray_length_m) {
+    if (c.allow_clear || freespace_points) is_clearing = true; else valid = false;
+  } else {
+    is_clearing = freespace_points != 0;
+  }
+  float uvx = qy * pz - qz * py, uvy = qz * px - qx * pz, uvz = qx * py - qy * px;
+  uvx += uvx; uvy += uvy; uvz += uvz;
+  const float ccx = qy * uvz - qz * uvy, ccy = qz * uvx - qx * uvz, ccz = qx * uvy - qy * uvx;
+  const float gx = (px + qw * uvx + ccx) + tx, gy = (py + qw * uvy + ccy) + ty, gz = (pz + qw * uvz + ccz) + tz;
+  const int vx = (int)floorf(gx * vsi + 1e-6f), vy = (int)floorf(gy * vsi + 1e-6f), vz = (int)floorf(gz * vsi + 1e-6f);
+  const bool in_range = vx > -kMergedBias && vx < kMergedBias && vy > -kMergedBias && vy < kMergedBias &&
+                        vz > -kMergedBias && vz < kMergedBias;
+  keys[seq] = (valid && in_range) ? merged_key(vx, vy, vz, is_clearing) : kMergedInvalid;
+  idx[seq] = (unsigned int)pi;
+}
+
+// counters[0] = number of groups, counters[1] = number of surface (non-clearing) entries
+__global__ __launch_bounds__(256) void merged_heads_kernel(const unsigned long long* __restrict__ keys, long long n,
+                                                          unsigned int* __restrict__ group_start,
+                                                          unsigned int* __restrict__ counters) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long k = keys[i];
+  if (k == kMergedInvalid) return;
+  if (!(k >> 63)) atomicMax(&counters[1], (unsigned int)(i + 1));
+  if (i == 0 || keys[i - 1] != k) group_start[atomicAdd(&counters[0], 1u)] = (unsigned int)i;
+}
+
+__global__ __launch_bounds__(256) void merged_integrate_kernel(TsdfLayerDev L, TsdfIntegratorDev I, float qw, float qx,
+                                                              float qy, float qz, float tx, float ty, float tz,
+                                                              const float* __restrict__ points_C,
+                                                              const uint32_t* __restrict__ rgba,
+                                                              const unsigned long long* __restrict__ keys,
+                                                              const unsigned int* __restrict__ idx, long long n,
+                                                              const unsigned int* __restrict__ group_start,
+                                                              const unsigned int* __restrict__ counters, int pass,
+                                                              int anti_grazing) {
+  const vgx_tsdf_config& c = I.cfg;
+  const unsigned int g = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long my_updates = 0, my_dropped = 0;
+  if (g < counters[0]) {
+    const long long i0 = group_start[g];
+    const unsigned long long key = keys[i0];
+    const bool clearing_ray = (key >> 63) != 0;
+    if ((int)clearing_ray == pass) {
+      // integrateVoxel: running weighted mean in visiting order
+      float mx = 0.0f, my = 0.0f, mz = 0.0f, mw = 0.0f;
+      uint32_t mcol = 0u;
+      for (long long i = i0; i < n && keys[i] == key; ++i) {
+        const long long pi = idx[i];
+        const float px = points_C[3 * pi], py = points_C[3 * pi + 1], pz = points_C[3 * pi + 2];
+        float pw = 1.0f;
+        if (!c.use_const_weight) {
+          const float dist_z = fabsf(pz);
+          pw = dist_z > 1e-6f ? 1.0f / (dist_z * dist_z) : 0.0f;
+        }
+        if (pw < 1e-6f) continue;  // kEpsilon
+        const float total = mw + pw;
+        mx = (mx * mw + px * pw) / total;
+        my = (my * mw + py * pw) / total;
+        mz = (mz * mw + pz * pw) / total;
+        mcol = blended_color(mcol, rgba ? rgba[pi] : 0u, mw, pw);
+        mw += pw;
+        if (clearing_ray) break;  // only the first point of a clearing group
+      }
+      if (mw != 0.0f) {
+        float uvx = qy * mz - qz * my, uvy = qz * mx - qx * mz, uvz = qx * my - qy * mx;
+        uvx += uvx; uvy += uvy; uvz += uvz;
+        const float ccx = qy * uvz - qz * uvy, ccy = qz * uvx - qx * uvz, ccz = qx * uvy - qy * uvx;
+        const float gx = (mx + qw * uvx + ccx) + tx, gy = (my + qw * uvy + ccy) + ty, gz = (mz + qw * uvz + ccz) + tz;
+        const float vsi = L.voxel_size_inv;
+        // RayCaster(origin, merged_point_G, clearing_ray, carving, max_ray, vsi, trunc, cast_from_origin = false)
+        const float dx = gx - tx, dy = gy - ty, dz = gz - tz;
+        const float len = norm3(dx, dy, dz);
+        const float ux = dx / len, uy = dy / len, uz = dz / len;
+        const float trunc = c.default_truncation_distance;
+        float sxx, syy, szz, exx, eyy, ezz;
+        if (clearing_ray) {
+          const float ray_length = fminf(fmaxf(len - trunc, 0.0f), c.max_ray_length_m);
+          exx = tx + ux * ray_length; eyy = ty + uy * ray_length; ezz = tz + uz * ray_length;
+          sxx = c.voxel_carving_enabled ? tx : exx;
+          syy = c.voxel_carving_enabled ? ty : eyy;
+          szz = c.voxel_carving_enabled ? tz : ezz;
+        } else {
+          exx = gx + ux * trunc; eyy = gy + uy * trunc; ezz = gz + uz * trunc;
+          sxx = c.voxel_carving_enabled ? tx : (gx - ux * trunc);
+          syy = c.voxel_carving_enabled ? ty : (gy - uy * trunc);
+          szz = c.voxel_carving_enabled ? tz : (gz - uz * trunc);
+        }
+        const float ss[3] = {exx * vsi, eyy * vsi, ezz * vsi};
+        const float es[3] = {sxx * vsi, syy * vsi, szz * vsi};
+        bool bad = false;
+        int curr[3], sign[3];
+        float t_next[3], t_step[3];
+        long long steps = 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          bad |= (ss[a] != ss[a]) | (es[a] != es[a]);
+          curr[a] = (int)floorf(ss[a] + 1e-6f);
+          const int end_index = (int)floorf(es[a] + 1e-6f);
+          const int diff = end_index - curr[a];
+          steps += diff < 0 ? -diff : diff;
+          const float ray_scaled = es[a] - ss[a];
+          sign[a] = signum(ray_scaled);
+          const float corrected = (float)(sign[a] > 0 ? sign[a] : 0);
+          const float dist_b = corrected - (ss[a] - (float)curr[a]);
+          if (ray_scaled == 0.0f) {
+            t_next[a] = INFINITY;
+            t_step[a] = INFINITY;
+          } else {
+            t_next[a] = dist_b / ray_scaled;
+            t_step[a] = (float)sign[a] / ray_scaled;
+          }
+        }
+        if (!bad) {
+          const int vps = L.vps, shift = L.vps_shift, mask = vps - 1;
+          const long long n_surface = counters[1];
+          int last_b[3] = {INT32_MIN, INT32_MIN, INT32_MIN}, last_slot = -1;
+          for (long long step = 0; step <= steps; ++step) {
+            const int vx = curr[0], vy = curr[1], vz = curr[2];
+            int m = 0;
+            if (t_next[1] < t_next[m]) m = 1;
+            if (t_next[2] < t_next[m]) m = 2;
+            curr[0] += m == 0 ? sign[0] : 0; curr[1] += m == 1 ? sign[1] : 0; curr[2] += m == 2 ? sign[2] : 0;
+            t_next[0] += m == 0 ? t_step[0] : 0.0f; t_next[1] += m == 1 ? t_step[1] : 0.0f;
+            t_next[2] += m == 2 ? t_step[2] : 0.0f;
+            if (anti_grazing) {
+              // skip voxels that are the end voxel of another surface group (voxel_map.find)
+              const unsigned long long k = merged_key(vx, vy, vz, false);
+              if (clearing_ray || k != key) {
+                long long lo = 0, hi = n_surface;
+                while (lo < hi) {
+                  const long long mid = (lo + hi) >> 1;
+                  if (keys[mid] < k) lo = mid + 1; else hi = mid;
+                }
+                if (lo < n_surface && keys[lo] == k) continue;
+              }
+            }
+            const int bx = vx >> shift, by = vy >> shift, bz = vz >> shift;
+            if (bx != last_b[0] || by != last_b[1] || bz != last_b[2]) {
+              last_slot = get_or_allocate_block(L, bx, by, bz);
+              last_b[0] = bx; last_b[1] = by; last_b[2] = bz;
+            }
+            if (last_slot < 0) {
+              ++my_dropped;
+              continue;
+            }
+            const size_t at = (size_t)last_slot * ((size_t)vps * vps * vps) +
+                              (size_t)((vx & mask) + vps * ((vy & mask) + vps * (vz & mask)));
+            update_voxel(L, c, at, tx, ty, tz, gx, gy, gz, vx, vy, vz, mcol, mw);
+            ++my_updates;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    my_updates += __shfl_xor(my_updates, off, 64);
+    my_dropped += __shfl_xor(my_dropped, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (my_updates) atomicAdd(I.n_updates, my_updates);
+    if (my_dropped) atomicAdd(L.dropped, my_dropped);
+  }
+}
+
 __global__ __launch_bounds__(256) void tsdf_unpack_kernel(const unsigned long long* __restrict__ voxels,
                                                          size_t n, float* __restrict__ distance,
                                                          float* __restrict__ weight) {
@@ -519,6 +722,15 @@ struct vgx_tsdf_integrator_s {
   uint32_t* d_rgba = nullptr;
   long long staging_cap = 0;
   std::mutex mu;  // one scan at a time per integrator: the staging buffers belong to the scan in flight
+  // MergedTsdfIntegrator scratch (grown on demand): sort keys / point indices (double-buffered),
+  // group starts, {groups, surface entries} counters, radix-sort workspace
+  unsigned long long* d_mkeys[2] = {nullptr, nullptr};
+  unsigned int* d_midx[2] = {nullptr, nullptr};
+  unsigned int* d_mstart = nullptr;
+  unsigned int* d_mcounters = nullptr;
+  void* d_msort = nullptr;
+  size_t msort_bytes = 0;
+  long long merged_cap = 0;
 };
 
 extern "C" {
@@ -538,6 +750,7 @@ void vgx_tsdf_config_default(vgx_tsdf_config* c) {
   c->start_voxel_subsampling_factor = 2.0f;
   c->max_consecutive_ray_collisions = 2;
   c->clear_checks_every_n_frames = 1;
+  c->enable_anti_grazing = 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -1003,7 +1216,8 @@ int vgx_tsdf_integrator_destroy(vgx_tsdf_integrator I) {
   if (!I) return VGX_ERR_INVALID;
   (void)hipSetDevice(I->ctx->device);
   (void)hipStreamSynchronize(I->ctx->stream);
-  void* ptrs[] = {I->dev.start_set, I->dev.observed_set, I->dev.n_updates, I->d_points, I->d_rgba};
+  void* ptrs[] = {I->dev.start_set, I->dev.observed_set, I->dev.n_updates, I->d_points, I->d_rgba,
+                  I->d_mkeys[0], I->d_mkeys[1], I->d_midx[0], I->d_midx[1], I->d_mstart, I->d_mcounters, I->d_msort};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete I;
@@ -1077,6 +1291,116 @@ static int integrate_locked(vgx_tsdf_integrator I, const float T[7], const void*
   return VGX_OK;
 }
 
+// MergedTsdfIntegrator::integratePointCloud with the scan already in device memory; the caller holds I->mu.
+static int merged_integrate_locked(vgx_tsdf_integrator I, const float T[7], const void* d_points, const void* d_rgba,
+                                   int64_t n, int32_t freespace, int64_t* n_updates) {
+  vgx_ctx ctx = I->ctx;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!I->layer) return set_error(ctx, VGX_ERR_INVALID, "vgx_tsdf_integrate_merged: no layer set");
+  if (n > (int64_t)1 << 31) return set_error(ctx, VGX_ERR_UNSUPPORTED, "vgx_tsdf_integrate_merged: more than 2^31 points");
+  VGX_HIP(ctx, hipSetDevice(ctx->device));
+  if (n_updates) VGX_HIP(ctx, hipMemsetAsync(I->dev.n_updates, 0, 8, ctx->stream));
+  if (n > 0) {
+    if (n > I->merged_cap) {
+      VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      void* old[] = {I->d_mkeys[0], I->d_mkeys[1], I->d_midx[0], I->d_midx[1], I->d_mstart, I->d_msort};
+      for (void* q : old)
+        if (q) (void)hipFree(q);
+      I->d_mkeys[0] = I->d_mkeys[1] = nullptr;
+      I->d_midx[0] = I->d_midx[1] = nullptr;
+      I->d_mstart = nullptr;
+      I->d_msort = nullptr;
+      I->merged_cap = 0;
+      for (int k = 0; k < 2; ++k) {
+        VGX_HIP(ctx, hipMalloc(&I->d_mkeys[k], (size_t)n * 8));
+        VGX_HIP(ctx, hipMalloc(&I->d_midx[k], (size_t)n * 4));
+      }
+      VGX_HIP(ctx, hipMalloc(&I->d_mstart, (size_t)n * 4));
+      if (!I->d_mcounters) VGX_HIP(ctx, hipMalloc(&I->d_mcounters, 8));
+      size_t bytes = 0;
+      VGX_HIP(ctx, rocprim::radix_sort_pairs(nullptr, bytes, I->d_mkeys[0], I->d_mkeys[1], I->d_midx[0], I->d_midx[1],
+                                             (size_t)n, 0, 64, ctx->stream));
+      VGX_HIP(ctx, hipMalloc(&I->d_msort, std::max<size_t>(bytes, 16)));
+      I->msort_bytes = bytes;
+      I->merged_cap = n;
+    }
+    const vgx_tsdf_config& c = I->dev.cfg;
+    const float origin[3] = {T[4], T[5], T[6]};
+    const float reach = c.max_ray_length_m + c.default_truncation_distance + 2.0f * I->layer->dev.voxel_size;
+    int rc = reserve_for_scan(I->layer, origin, reach);
+    if (rc != VGX_OK) return rc;
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    hipLaunchKernelGGL(merged_bundle_kernel, grid, block, 0, ctx->stream, c, I->layer->dev.voxel_size_inv, T[0], T[1],
+                       T[2], T[3], T[4], T[5], T[6], (const float*)d_points, (long long)n, (int)freespace,
+                       I->d_mkeys[0], I->d_midx[0]);
+    VGX_HIP(ctx, hipGetLastError());
+    size_t bytes = I->msort_bytes;
+    // stable: equal keys keep the visiting order they were written in
+    VGX_HIP(ctx, rocprim::radix_sort_pairs(I->d_msort, bytes, I->d_mkeys[0], I->d_mkeys[1], I->d_midx[0], I->d_midx[1],
+                                           (size_t)n, 0, 64, ctx->stream));
+    VGX_HIP(ctx, hipMemsetAsync(I->d_mcounters, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(merged_heads_kernel, grid, block, 0, ctx->stream, I->d_mkeys[1], (long long)n, I->d_mstart,
+                       I->d_mcounters);
+    VGX_HIP(ctx, hipGetLastError());
+    for (int pass = 0; pass < 2; ++pass) {  // integrateRays(clearing_ray = false), then (true)
+      hipLaunchKernelGGL(merged_integrate_kernel, grid, block, 0, ctx->stream, I->layer->dev, I->dev, T[0], T[1], T[2],
+                         T[3], T[4], T[5], T[6], (const float*)d_points, (const uint32_t*)d_rgba, I->d_mkeys[1],
+                         I->d_midx[1], (long long)n, I->d_mstart, I->d_mcounters, pass, (int)c.enable_anti_grazing);
+      VGX_HIP(ctx, hipGetLastError());
+    }
+    request_readback(I->layer);
+  }
+  if (n_updates) {
+    unsigned long long u = 0;
+    VGX_HIP(ctx, hipMemcpyAsync(&u, I->dev.n_updates, 8, hipMemcpyDeviceToHost, ctx->stream));
+    VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *n_updates = (int64_t)u;
+  }
+  return VGX_OK;
+}
+
+int vgx_tsdf_integrate_merged_device(vgx_tsdf_integrator I, const float T[7], const void* d_points,
+                                     const void* d_rgba, int64_t n, int32_t freespace, int64_t* n_updates) {
+  if (!I || !T || n < 0 || (n > 0 && !d_points)) return VGX_ERR_INVALID;
+  std::lock_guard<std::mutex> own(I->mu);
+  return merged_integrate_locked(I, T, d_points, d_rgba, n, freespace, n_updates);
+}
+
+static int stage_scan(vgx_tsdf_integrator I, const float* points, const uint8_t* rgba, int64_t n) {
+  vgx_ctx ctx = I->ctx;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  VGX_HIP(ctx, hipSetDevice(ctx->device));
+  if (n > I->staging_cap) {
+    VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (I->d_points) (void)hipFree(I->d_points);
+    if (I->d_rgba) (void)hipFree(I->d_rgba);
+    I->d_points = nullptr;
+    I->d_rgba = nullptr;
+    I->staging_cap = 0;
+    VGX_HIP(ctx, hipMalloc(&I->d_points, (size_t)n * 12));
+    VGX_HIP(ctx, hipMalloc(&I->d_rgba, (size_t)n * 4));
+    I->staging_cap = n;
+  }
+  if (n > 0) {
+    VGX_HIP(ctx, hipMemcpyAsync(I->d_points, points, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+    if (rgba)
+      VGX_HIP(ctx, hipMemcpyAsync(I->d_rgba, rgba, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  }
+  return VGX_OK;
+}
+
+int vgx_tsdf_integrate_merged(vgx_tsdf_integrator I, const float T[7], const float* points, const uint8_t* rgba,
+                              int64_t n, int32_t freespace, int64_t* n_updates) {
+  if (!I || !T || n < 0 || (n > 0 && !points)) return VGX_ERR_INVALID;
+  std::lock_guard<std::mutex> own(I->mu);
+  int rc = stage_scan(I, points, rgba, n);
+  if (rc != VGX_OK) return rc;
+  int64_t upd = 0;
+  rc = merged_integrate_locked(I, T, I->d_points, rgba ? I->d_rgba : nullptr, n, freespace, &upd);
+  if (n_updates) *n_updates = upd;
+  return rc;
+}
+
 int vgx_tsdf_integrate_device(vgx_tsdf_integrator I, const float T[7], const void* d_points,
                               const void* d_rgba, int64_t n, int32_t freespace, int64_t* n_updates) {
   if (!I || !T || n < 0 || (n > 0 && !d_points)) return VGX_ERR_INVALID;
@@ -1087,32 +1411,13 @@ int vgx_tsdf_integrate_device(vgx_tsdf_integrator I, const float T[7], const voi
 int vgx_tsdf_integrate(vgx_tsdf_integrator I, const float T[7], const float* points, const uint8_t* rgba,
                        int64_t n, int32_t freespace, int64_t* n_updates) {
   if (!I || !T || n < 0 || (n > 0 && !points)) return VGX_ERR_INVALID;
-  vgx_ctx ctx = I->ctx;
   // the staging buffers are this scan's from the upload to the launch: two threads calling the
   // same integrator are serialised here, not interleaved between the two steps
   std::lock_guard<std::mutex> own(I->mu);
-  {
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    VGX_HIP(ctx, hipSetDevice(ctx->device));
-    if (n > I->staging_cap) {
-      VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      if (I->d_points) (void)hipFree(I->d_points);
-      if (I->d_rgba) (void)hipFree(I->d_rgba);
-      I->d_points = nullptr;
-      I->d_rgba = nullptr;
-      I->staging_cap = 0;
-      VGX_HIP(ctx, hipMalloc(&I->d_points, (size_t)n * 12));
-      VGX_HIP(ctx, hipMalloc(&I->d_rgba, (size_t)n * 4));
-      I->staging_cap = n;
-    }
-    if (n > 0) {
-      VGX_HIP(ctx, hipMemcpyAsync(I->d_points, points, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
-      if (rgba)
-        VGX_HIP(ctx, hipMemcpyAsync(I->d_rgba, rgba, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-    }
-  }
+  int rc = stage_scan(I, points, rgba, n);
+  if (rc != VGX_OK) return rc;
   int64_t upd = 0;
-  int rc = integrate_locked(I, T, I->d_points, rgba ? I->d_rgba : nullptr, n, freespace, &upd);
+  rc = integrate_locked(I, T, I->d_points, rgba ? I->d_rgba : nullptr, n, freespace, &upd);
   if (n_updates) *n_updates = upd;
   return rc;
 }
