@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(TsdfLayerDev L, Tsd
 }
 
 // ---------------------------------------------------------------------------
-// voxblox::MergedTsdfIntegrator [recalled; restated in oracle/tsdf_oracle.c orc_tsdf_merged_integrate]
+// voxblox::MergedTsdfIntegrator [recalled, integrator/tsdf_integrator.cc]
 // ---------------------------------------------------------------------------
 // bundleRays groups the valid points by the voxel their end point falls in, integrateVoxel merges a
 // group into one weighted-mean point and casts ONE ray for it.  On the device: every point gets the
