@@ -41,7 +41,7 @@ def _as_dict(bi, d, w, rgba, vps):
     return out
 
 
-def _room_scan(n_az, n_el, seed):
+def _room_scan(n_az, n_el, seed, outliers=True):
     rng = np.random.default_rng(seed)
     az = np.linspace(-np.pi, np.pi, n_az, endpoint=False)
     el = np.deg2rad(np.linspace(-20, 20, n_el))
@@ -51,8 +51,9 @@ def _room_scan(n_az, n_el, seed):
     with np.errstate(divide="ignore", invalid="ignore"):
         t = np.where(dirs > 0, hi / dirs, np.where(dirs < 0, lo / dirs, np.inf)).min(1)
     pts = dirs * t[:, None]
-    pts[::37] *= 4.0                                    # some returns beyond max range: clearing rays
-    pts[5::41] *= 0.01                                  # some below min range: dropped
+    if outliers:
+        pts[::37] *= 4.0                                # some returns beyond max range: clearing rays
+        pts[5::41] *= 0.01                              # some below min range: dropped
     cols = rng.integers(0, 255, (len(pts), 4)).astype(np.uint8)
     return pts.astype(F), cols
 
@@ -78,8 +79,8 @@ def test_merged_scans_against_the_oracle(capi, ctx, const_weight, anti_grazing):
     assert gl.stats()[1] == 0
     dw = max(abs(A[k][1] - B[k][1]) / max(A[k][1], 1e-9) for k in A)
     dd = max(abs(A[k][0] - B[k][0]) for k in A)
-    # integer weights (const weight) add exactly in any order; 1/z^2 weights and distances to rounding
-    assert dw <= (0.0 if const_weight else 2e-6), dw
+    # weights (drop-off behind the surface makes them non-integer) and distances to f32 rounding
+    assert dw <= 2e-6, dw
     assert dd <= 2e-6, dd
     exact = sum(A[k][0] == B[k][0] for k in A) / len(A)
     assert exact > 0.9                                   # the bulk is bit-identical
@@ -117,8 +118,8 @@ def test_merged_and_fast_agree_on_the_surface_they_reconstruct(capi, ctx):
     import torch
     vs, vps = 0.1, 16
     kw = dict(default_truncation_distance=0.3, max_ray_length_m=6.0, use_const_weight=1)
-    pts, _ = _room_scan(720, 64, 9)
-    T = np.array([1, 0, 0, 0, 0.0, 0.0, 0.0], F)
+    pts, _ = _room_scan(720, 64, 9, outliers=False)     # (clearing rays through the walls are treated
+    T = np.array([1, 0, 0, 0, 0.0, 0.0, 0.0], F)         # differently by the two algorithms: left out)
     dev = torch.from_numpy(pts).cuda()
     torch.cuda.synchronize()
     out = []
