@@ -265,6 +265,19 @@ def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=2):
         first_updates = integ4.integrate_device(poses[0], dev[0].data_ptr(), None, n_pts, count=True)
         for o in (integ3, integ4, layer3, layer4, layer2b):
             o.destroy()
+        # voxblox's other integrator on the same scans: MergedTsdfIntegrator (one ray per end voxel)
+        layer6 = new_layer()
+        integ6 = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(**kw), layer6)
+        integ6.integrate_merged_device(poses[0], dev[0].data_ptr(), None, n_pts)
+        ctx.synchronize()
+        ctx.timer_start()
+        for k in range(1, scans):
+            integ6.integrate_merged_device(poses[k], dev[k].data_ptr(), None, n_pts)
+        merged_ms = ctx.timer_stop() / (scans - 1)
+        merged_updates = integ6.integrate_merged_device(poses[1], dev[1].data_ptr(), None, n_pts, count=True)
+        merged_dropped = layer6.stats()[1]
+        for o in (integ6, layer6):
+            o.destroy()
         # the drop-in call itself: host pointers (pageable), PCIe upload included, returns when done;
         # layer created the way voxblox creates one (no reservation at all)
         layer5 = capi.TsdfLayer(ctx, vs, 16)
@@ -307,6 +320,12 @@ def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=2):
                                            "layer_enlargements": host_growths,
                                            "note": "vgx_tsdf_integrate into an unreserved layer: pageable host "
                                                    "points, PCIe upload, enlargements and completion wait included"},
+                     "merged_integrator": {"ms_per_scan": merged_ms, "Mpoints_per_s": n_pts / merged_ms / 1e3,
+                                           "voxel_updates_per_scan": merged_updates, "dropped_updates": merged_dropped,
+                                           "Mvoxel_updates_per_s": merged_updates / merged_ms / 1e3,
+                                           "note": "vgx_tsdf_integrate_merged_device: key + stable radix sort + group "
+                                                   "heads + one full ray per end voxel (no early-out), surface then "
+                                                   "clearing groups"},
                      "first_scan": {"ms": first_ms, "voxel_updates": first_updates,
                                     "Mvoxel_updates_per_s": first_updates / first_ms / 1e3,
                                     "algorithmic_GBs": (16.0 * n_pts + 24.0 * first_updates) / first_ms / 1e6},
