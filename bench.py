@@ -356,6 +356,26 @@ def finish_bench(capi, ctx, args, true_poses):
     return out
 
 
+class GpuBackendLite:
+    """single batch: fused pass + assembly + copy of the fused buffer to the host (what
+    vgx_reg_multi_evaluate_fused returns), without the harness around it"""
+
+    def __init__(self, capi, ctx, batch, n_nodes, torch):
+        self.ctx, self.batch, self.n_nodes = ctx, batch, n_nodes
+        self.buf = torch.zeros(capi.fused_size(n_nodes, batch.n_global), dtype=torch.float64, device="cuda")
+        self.host = torch.zeros_like(self.buf, device="cpu").pin_memory()
+        torch.cuda.current_stream().synchronize()
+        self.torch = torch
+
+    def __call__(self):
+        self.batch.evaluate_normal(self._poses, to_host=False)
+        self.batch.assemble(self.n_nodes, self.buf.data_ptr(), zero_first=True)
+        self.ctx.synchronize()
+        self.host.copy_(self.buf, non_blocking=True)
+        self.torch.cuda.current_stream().synchronize()
+        return self.host.numpy()
+
+
 def config5_bench(capi, ctx, torch, dist, use_dist, rank, world, args):
     """BASELINE configs[4]: 1000 submaps @ 128^3 on a loop (serpentine) trajectory, odometry edges
     with accumulated drift, 20 injected loop-closure relative-pose edges
@@ -557,6 +577,7 @@ def main():
                     help="run the config-2 stand-in at full length (30 submaps x 100 scans, harness/pipeline.py) "
                          "instead of the bounded one (10 submaps x 30 scans) the default line carries")
     ap.add_argument("--no-config2", action="store_true")
+    ap.add_argument("--no-multi-ctx", action="store_true")
     ap.add_argument("--no-config5", action="store_true")
     ap.add_argument("--config", type=int, default=3, choices=[3, 5],
                     help="5: only BASELINE configs[4] (1000 submaps @ 128^3, loop closures, two-stage solve)")
@@ -865,6 +886,50 @@ def main():
         for o in [batch_s] + cfs_s:
             o.destroy()
 
+    # ---- the in-process multi-GPU component (vgx_reg_multi_*) with TWO CONTEXTS ON THIS ONE GPU: what
+    # its host threads, events and the fixed-order sum cost on top of the single-batch path.  (On a
+    # multi-GPU node each context sits on its own GPU; the driver's N > 1 runs use one process per GPU.)
+    multi_ctx = None
+    if world == 1 and not args.no_fused and not args.no_multi_ctx:
+        ctx_b = capi.Context(local_rank)
+        # second context: only the submaps its share of the constraints needs are uploaded
+        shard_of = capi.lpt_shards(weights, 2)
+        need = sorted({int(s_) for c in range(n_con) if shard_of[c] == 1 for s_ in pairs[c]})
+        sub_b = {}
+        for k in need:
+            sm = capi.Submap.synth_city(ctx_b, k, args.voxel_size, 16, args.block_min, args.block_dims,
+                                        args.truncation, args.esdf_max, 10.0, true_poses[k], args.seed)
+            sm.extract_voxel_points(1.0, 0.3, True)
+            sm.release_raw_layers()
+            sub_b[k] = sm
+        cfs_m = [capi.RegistrationCostFunction(ctx, submaps[a], submaps[b], cfg) if shard_of[c] == 0 else
+                 capi.RegistrationCostFunction(ctx_b, sub_b[int(a)], sub_b[int(b)], cfg)
+                 for c, (a, b) in enumerate(pairs)]
+        multi = capi.RegistrationMulti([ctx, ctx_b], cfs_m, pairs)
+        for _ in range(2):
+            fused_m, _ = multi.evaluate_fused(poses)
+        m0 = time.perf_counter()
+        for _ in range(args.steps):
+            fused_m, _ = multi.evaluate_fused(poses)
+        m_ms = (time.perf_counter() - m0) / args.steps * 1e3
+        single = GpuBackendLite(capi, ctx, batch, n_sub, torch)
+        single._poses = poses
+        for _ in range(2):
+            ref_buf = single()
+        s0_ = time.perf_counter()
+        for _ in range(args.steps):
+            ref_buf = single()
+        s_ms = (time.perf_counter() - s0_) / args.steps * 1e3
+        multi_ctx = {"contexts": 2, "devices": 1, "what": "vgx_reg_multi_evaluate_fused (LPT shard, one host thread per "
+                     "context, event-ordered fixed-order sum on context 0, result on the host) vs the single batch "
+                     "(evaluate + assemble + copy to the host), same GPU",
+                     "ms_per_evaluation": m_ms, "single_batch_ms_per_evaluation": s_ms,
+                     "max_rel_diff_vs_single_batch": float(np.abs(fused_m - ref_buf).max() / np.abs(ref_buf).max())}
+        multi.destroy()
+        for o in cfs_m + list(sub_b.values()):
+            o.destroy()
+        ctx_b.close()
+
     # ---- metric 2: full pose-graph solve (harness LM, stand-in for ceres::Solve) ---
     solve = None
     if not args.no_solve:
@@ -970,6 +1035,7 @@ def main():
                          "with_correspondence_frac": with_corr / max(R, 1)},
             "fused": fused,
             "shipped_config": shipped,
+            "multi_context": multi_ctx,
             "solve": solve,
             "setup_s": setup_s,
             "residual_checksum": checksum,
