@@ -187,3 +187,47 @@ def test_large_sparse_block_extent_and_table_limit(capi, ctx):
     with pytest.raises(capi.VgxError) as e:
         capi.Submap(ctx, 1, 0.1, 16, bi2, None, None, np.zeros((2, 4096), F), np.ones((2, 4096), np.uint8))
     assert e.value.code == capi.ERR_UNSUPPORTED
+
+
+def test_round2_entry_points_reject_bad_arguments(capi, ctx):
+    """status codes, never a crash: layer upload / reserve, merged integrator, multi-context batch"""
+    import ctypes as C
+    lib = ctx.lib
+    layer = capi.TsdfLayer(ctx, 0.1, 16)
+    # upload: NULL arrays with n > 0, negative n
+    assert lib.vgx_tsdf_layer_upload(layer.h, 3, None, None, None, None) == capi.ERR_INVALID
+    assert lib.vgx_tsdf_layer_upload(layer.h, -1, None, None, None, None) == capi.ERR_INVALID
+    assert lib.vgx_tsdf_layer_upload(None, 0, None, None, None, None) == capi.ERR_INVALID
+    # an empty upload is legal and leaves an empty layer
+    layer.upload(np.zeros((0, 3), np.int32), np.zeros((0, 4096), F), np.zeros((0, 4096), F))
+    assert layer.stats() == (0, 0)
+    # reserve: NULL origin, negative / NaN reach
+    assert lib.vgx_tsdf_layer_reserve(layer.h, None, C.c_float(1.0)) == capi.ERR_INVALID
+    o = np.zeros(3, F)
+    assert lib.vgx_tsdf_layer_reserve(layer.h, o.ctypes.data_as(capi.f32p), C.c_float(-1.0)) == capi.ERR_INVALID
+    assert lib.vgx_tsdf_layer_reserve(layer.h, o.ctypes.data_as(capi.f32p), C.c_float(float("nan"))) == capi.ERR_INVALID
+    layer.reserve(o, 3.0)
+    assert layer.growths() >= 1 and layer.stats() == (0, 0)
+    # merged integrator: NULL points with n > 0, negative n, empty scan
+    integ = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(), layer)
+    T = np.array([1, 0, 0, 0, 0, 0, 0], F)
+    assert lib.vgx_tsdf_integrate_merged(integ.h, T.ctypes.data_as(capi.f32p), None, None, 5, 0, None) == capi.ERR_INVALID
+    assert lib.vgx_tsdf_integrate_merged(integ.h, T.ctypes.data_as(capi.f32p), None, None, -1, 0, None) == capi.ERR_INVALID
+    assert integ.integratePointCloudMerged(T, np.zeros((0, 3), F)) == 0
+    # every point invalid (below the minimum ray length): nothing is integrated, nothing breaks
+    assert integ.integratePointCloudMerged(T, np.full((100, 3), 0.001, F)) == 0 and layer.stats() == (0, 0)
+    # multi-context batch: no contexts, too many, NULL context
+    h = capi.vp()
+    assert lib.vgx_reg_multi_create(0, None, 0, None, None, C.byref(h)) == capi.ERR_INVALID
+    arr = (capi.vp * 17)(*[ctx.h] * 17)
+    assert lib.vgx_reg_multi_create(17, arr, 0, None, None, C.byref(h)) == capi.ERR_INVALID
+    arr2 = (capi.vp * 2)(ctx.h, None)
+    assert lib.vgx_reg_multi_create(2, arr2, 0, None, None, C.byref(h)) == capi.ERR_INVALID
+    # an empty multi batch evaluates to an all-zero buffer
+    empty = capi.RegistrationMulti([ctx], [], np.zeros((0, 2), np.int32))
+    fused, _ = empty.evaluate_fused(np.zeros((2, 4)))
+    assert fused.shape == (capi.fused_size(2, 0),) and not fused.any()
+    empty.destroy()
+    assert capi.lpt_shards([], 3).shape == (0,)
+    for obj in (integ, layer):
+        obj.destroy()
