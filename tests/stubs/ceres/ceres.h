@@ -1,5 +1,6 @@
-// Minimal stand-in for <ceres/ceres.h> (Ceres is not installed in this image): just the
-// ceres::CostFunction surface the adapter in voxgraph_amd/cpp/ touches.  TEST ONLY.
+// Minimal stand-in for <ceres/ceres.h> (Ceres is not installed in this image): the
+// ceres::CostFunction / EvaluationCallback surface the adapters in voxgraph_amd/cpp/ touch, and a
+// small Problem / Solve with Ceres' calling conventions for end-to-end checks.  TEST ONLY.
 #ifndef TESTS_STUBS_CERES_CERES_H_
 #define TESTS_STUBS_CERES_CERES_H_
 #include <cmath>
@@ -56,5 +57,221 @@ class EvaluationCallback {
   virtual ~EvaluationCallback() {}
   virtual void PrepareForEvaluation(bool evaluate_jacobians, bool new_evaluation_point) = 0;
 };
+
+// ---- a small Problem / Solver with Ceres' calling conventions (TEST ONLY) ---------------------------
+// Enough of ceres::Problem and ceres::Solve to drive the GPU cost functions the way voxgraph does
+// (pose_graph.cpp:74-106): residual blocks over 4-parameter pose blocks, constant blocks
+// (SetParameterBlockConstant, pose_graph_interface.cpp:30-32), Solver::Options::evaluation_callback,
+// and a dense Levenberg-Marquardt loop with Ceres' acceptance / radius rules and default tolerances.
+// Jacobians of constant blocks are requested as nullptr, as Ceres does.
+class LossFunction;
+typedef int ResidualBlockId;
+
+class Problem {
+ public:
+  ~Problem() {
+    for (Block& b : blocks_) delete b.cost;  // TAKE_OWNERSHIP, Ceres' default
+  }
+  void AddParameterBlock(double* values, int size) { Index(values, size); }
+  void SetParameterBlockConstant(double* values) { constant_[Index(values, 4)] = true; }
+  ResidualBlockId AddResidualBlock(CostFunction* cost, LossFunction* /*loss*/, double* x0, double* x1) {
+    Block b;
+    b.cost = cost;
+    b.param[0] = Index(x0, cost->parameter_block_sizes()[0]);
+    b.param[1] = Index(x1, cost->parameter_block_sizes()[1]);
+    blocks_.push_back(b);
+    return static_cast<ResidualBlockId>(blocks_.size()) - 1;
+  }
+  int NumResidualBlocks() const { return static_cast<int>(blocks_.size()); }
+
+  // (stub: the solver below reads these directly)
+  struct Block {
+    CostFunction* cost;
+    int param[2];
+  };
+  int Index(double* values, int size) {
+    for (size_t k = 0; k < params_.size(); ++k)
+      if (params_[k] == values) return static_cast<int>(k);
+    params_.push_back(values);
+    sizes_.push_back(size);
+    constant_.push_back(false);
+    return static_cast<int>(params_.size()) - 1;
+  }
+  std::vector<Block> blocks_;
+  std::vector<double*> params_;
+  std::vector<int> sizes_;
+  std::vector<bool> constant_;
+};
+
+struct Solver {
+  struct Options {
+    int max_num_iterations = 50;
+    double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
+    double initial_trust_region_radius = 1e4;
+    int num_threads = 1;
+    EvaluationCallback* evaluation_callback = nullptr;
+  };
+  struct Summary {
+    int num_iterations = 0, num_evaluations = 0;
+    double initial_cost = 0, final_cost = 0;
+    const char* termination = "";
+  };
+};
+
+struct SolverImpl {
+  // cost = 0.5 sum r^2; g = J^T r; H = J^T J over the free parameters (dense)
+  static bool Evaluate(const Solver::Options& o, Problem* p, const std::vector<int>& offset, int nf, double* cost,
+                       std::vector<double>* g, std::vector<double>* H) {
+    if (o.evaluation_callback) o.evaluation_callback->PrepareForEvaluation(true, true);
+    *cost = 0;
+    g->assign(static_cast<size_t>(nf), 0.0);
+    H->assign(static_cast<size_t>(nf) * nf, 0.0);
+    for (Problem::Block& b : p->blocks_) {
+      const int nr = b.cost->num_residuals();
+      std::vector<double> r(static_cast<size_t>(nr)), J0(static_cast<size_t>(nr) * 4), J1(static_cast<size_t>(nr) * 4);
+      double* params[2] = {p->params_[static_cast<size_t>(b.param[0])], p->params_[static_cast<size_t>(b.param[1])]};
+      double* jac[2] = {p->constant_[static_cast<size_t>(b.param[0])] ? nullptr : J0.data(),
+                        p->constant_[static_cast<size_t>(b.param[1])] ? nullptr : J1.data()};
+      if (!b.cost->Evaluate(params, r.data(), jac)) return false;
+      for (int i = 0; i < nr; ++i) *cost += 0.5 * r[static_cast<size_t>(i)] * r[static_cast<size_t>(i)];
+      for (int s = 0; s < 2; ++s) {
+        if (!jac[s]) continue;
+        const int os = offset[static_cast<size_t>(b.param[s])];
+        for (int i = 0; i < nr; ++i)
+          for (int a = 0; a < 4; ++a) {
+            const double ja = jac[s][4 * i + a];
+            (*g)[static_cast<size_t>(os + a)] += ja * r[static_cast<size_t>(i)];
+            for (int t = 0; t < 2; ++t) {
+              if (!jac[t]) continue;
+              const int ot = offset[static_cast<size_t>(b.param[t])];
+              for (int c = 0; c < 4; ++c)
+                (*H)[static_cast<size_t>(os + a) * nf + static_cast<size_t>(ot + c)] += ja * jac[t][4 * i + c];
+            }
+          }
+      }
+    }
+    return true;
+  }
+  // solves (H + diag(d)) x = -g by Cholesky; false if not positive definite
+  static bool SolveDamped(const std::vector<double>& H, const std::vector<double>& d, const std::vector<double>& g, int n,
+                          std::vector<double>* x) {
+    std::vector<double> L(H);
+    for (int i = 0; i < n; ++i) L[static_cast<size_t>(i) * n + i] += d[static_cast<size_t>(i)];
+    for (int j = 0; j < n; ++j) {
+      double s = L[static_cast<size_t>(j) * n + j];
+      for (int k = 0; k < j; ++k) s -= L[static_cast<size_t>(j) * n + k] * L[static_cast<size_t>(j) * n + k];
+      if (!(s > 0)) return false;
+      L[static_cast<size_t>(j) * n + j] = std::sqrt(s);
+      for (int i = j + 1; i < n; ++i) {
+        double t = L[static_cast<size_t>(i) * n + j];
+        for (int k = 0; k < j; ++k) t -= L[static_cast<size_t>(i) * n + k] * L[static_cast<size_t>(j) * n + k];
+        L[static_cast<size_t>(i) * n + j] = t / L[static_cast<size_t>(j) * n + j];
+      }
+    }
+    x->assign(static_cast<size_t>(n), 0.0);
+    for (int i = 0; i < n; ++i) {
+      double t = -g[static_cast<size_t>(i)];
+      for (int k = 0; k < i; ++k) t -= L[static_cast<size_t>(i) * n + k] * (*x)[static_cast<size_t>(k)];
+      (*x)[static_cast<size_t>(i)] = t / L[static_cast<size_t>(i) * n + i];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+      double t = (*x)[static_cast<size_t>(i)];
+      for (int k = i + 1; k < n; ++k) t -= L[static_cast<size_t>(k) * n + i] * (*x)[static_cast<size_t>(k)];
+      (*x)[static_cast<size_t>(i)] = t / L[static_cast<size_t>(i) * n + i];
+    }
+    return true;
+  }
+};
+
+inline void Solve(const Solver::Options& o, Problem* p, Solver::Summary* summary) {
+  std::vector<int> offset(p->params_.size(), -1);
+  int nf = 0;
+  for (size_t k = 0; k < p->params_.size(); ++k)
+    if (!p->constant_[k]) {
+      offset[k] = nf;
+      nf += p->sizes_[k];
+    }
+  auto get = [&](std::vector<double>* x) {
+    x->assign(static_cast<size_t>(nf), 0.0);
+    for (size_t k = 0; k < p->params_.size(); ++k)
+      if (offset[k] >= 0)
+        for (int a = 0; a < p->sizes_[k]; ++a) (*x)[static_cast<size_t>(offset[k] + a)] = p->params_[k][a];
+  };
+  auto set = [&](const std::vector<double>& x) {
+    for (size_t k = 0; k < p->params_.size(); ++k)
+      if (offset[k] >= 0)
+        for (int a = 0; a < p->sizes_[k]; ++a) p->params_[k][a] = x[static_cast<size_t>(offset[k] + a)];
+  };
+  Solver::Summary& s = *summary;
+  s = Solver::Summary();
+  std::vector<double> x, g, H, ng, nH, step, d(static_cast<size_t>(nf));
+  get(&x);
+  double cost = 0;
+  s.termination = "FAILURE";
+  if (!SolverImpl::Evaluate(o, p, offset, nf, &cost, &g, &H)) return;
+  s.num_evaluations = 1;
+  s.initial_cost = s.final_cost = cost;
+  double radius = o.initial_trust_region_radius, decrease = 2.0;
+  s.termination = "NO_CONVERGENCE";
+  while (s.num_iterations < o.max_num_iterations) {
+    ++s.num_iterations;
+    double gmax = 0, xnorm = 0;
+    for (int i = 0; i < nf; ++i) {
+      gmax = std::fmax(gmax, std::fabs(g[static_cast<size_t>(i)]));
+      xnorm += x[static_cast<size_t>(i)] * x[static_cast<size_t>(i)];
+      d[static_cast<size_t>(i)] = std::fmin(std::fmax(H[static_cast<size_t>(i) * nf + i], 1e-6), 1e32) / radius;
+    }
+    if (gmax <= o.gradient_tolerance) {
+      s.termination = "CONVERGENCE (gradient)";
+      break;
+    }
+    if (!SolverImpl::SolveDamped(H, d, g, nf, &step)) {
+      radius /= decrease;
+      decrease *= 2;
+      continue;
+    }
+    double snorm = 0, model = 0;
+    for (int i = 0; i < nf; ++i) {
+      snorm += step[static_cast<size_t>(i)] * step[static_cast<size_t>(i)];
+      double hs = 0;
+      for (int j = 0; j < nf; ++j) hs += H[static_cast<size_t>(i) * nf + j] * step[static_cast<size_t>(j)];
+      model -= step[static_cast<size_t>(i)] * (g[static_cast<size_t>(i)] + 0.5 * hs);
+    }
+    if (std::sqrt(snorm) <= o.parameter_tolerance * (std::sqrt(xnorm) + o.parameter_tolerance)) {
+      s.termination = "CONVERGENCE (parameter)";
+      break;
+    }
+    std::vector<double> cand(x);
+    for (int i = 0; i < nf; ++i) cand[static_cast<size_t>(i)] += step[static_cast<size_t>(i)];
+    set(cand);
+    double ncost = 0;
+    if (!SolverImpl::Evaluate(o, p, offset, nf, &ncost, &ng, &nH)) {
+      set(x);
+      return;
+    }
+    ++s.num_evaluations;
+    const double rho = model > 0 ? (cost - ncost) / model : -1.0;
+    if (rho > 1e-3) {
+      const double rel = std::fabs(cost - ncost) / std::fmax(cost, 1e-300);
+      x = cand;
+      cost = ncost;
+      g = ng;
+      H = nH;
+      const double t = 2.0 * rho - 1.0;
+      radius = std::fmin(radius / std::fmax(1.0 / 3.0, 1.0 - t * t * t), 1e16);
+      decrease = 2.0;
+      if (rel <= o.function_tolerance) {
+        s.termination = "CONVERGENCE (function)";
+        break;
+      }
+    } else {
+      set(x);
+      radius /= decrease;
+      decrease *= 2.0;
+    }
+  }
+  set(x);
+  s.final_cost = cost;
+}
 }  // namespace ceres
 #endif
