@@ -20,8 +20,10 @@ constexpr int kBlockVoxelData = 7;      // repeated uint32
 // Block<TsdfVoxel>::serializeToIntegers: 3 words per voxel = distance bits, weight bits,
 // a | b << 8 | g << 16 | r << 24
 constexpr int kTsdfWordsPerVoxel = 3;
-// Block<EsdfVoxel>::serializeToIntegers: 2 words per voxel = distance bits,
-// observed | parent.x << 8 | parent.y << 16 | parent.z << 24 (int8 each)
+// Block<EsdfVoxel>::serializeToIntegers: 2 words per voxel = distance bits, then
+// parent.x << 24 | parent.y << 16 | parent.z << 8 | observed (int8 parent components; only the low
+// byte, `observed`, is read here; the writer emits zero parents -- REG never uses them and voxblox
+// recomputes them when it propagates)
 constexpr int kEsdfWordsPerVoxel = 2;
 // cblox SubmapCollectionProto
 constexpr int kCollectionVoxelSize = 1;      // double
