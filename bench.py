@@ -44,6 +44,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_EVAL = 88            # SURVEY.md 8d contract figure (materialising, f32 outputs)
 BYTES_NO_CORR = 56             # an evaluation that finds no reading block: 20 B in, 36 B out
+BYTES_OUT, BYTES_POINT, BYTES_NEIGHBOURS = 36, 20, 32   # the three parts of the 88 B
 BYTES_PER_EVAL_FUSED = 52      # fused form: 20 B point + 32 B neighbours, nothing written per point
 BYTES_NO_CORR_FUSED = 20       # a point the fused pass loads but that finds no reading block
 
@@ -557,6 +558,9 @@ def main():
                     help="full-overlap workload: perturbed duplicates per submap (config 3 has ~6 "
                          "constraints per reference submap)")
     ap.add_argument("--no-full-overlap", action="store_true")
+    ap.add_argument("--no-fo-plain", action="store_true",
+                    help="skip the plain-launch-order measurement of the full-overlap workload (PMC passes: "
+                         "one launch order per grid size)")
     ap.add_argument("--no-shipped", action="store_true",
                     help="skip the shipped-yaml evaluation (isosurface points, sampling_ratio 0.05, mirrored)")
     ap.add_argument("--grid", type=int, nargs=2, default=[20, 10], help="submap grid (200 submaps)")
@@ -742,34 +746,62 @@ def main():
         dist.all_reduce(wc_tot, op=dist.ReduceOp.SUM)
     with_corr_total = float(wc_tot.item())
 
+    # points the materialising kernel reads at these poses: tiles whose chunks all miss the reading
+    # submap's block box write zeros without reading (vgx_reg.hip reg_eval_points_body); where the
+    # launch order groups the constraints of a reference submap on one XCD they read its points once
+    def points_read(bt, ps):
+        lv, uq = bt.count_live(ps, unique=True)
+        grouped = bt.launch_order(points_pass=True)
+        return {"live": int(lv), "distinct": int(uq), "grouped": int(grouped),
+                "read": int(uq if grouped == 1 else lv)}
+    pr = points_read(batch, poses)
+
     # ---- full-overlap workload, timed the same way (HIP events on the kernel's stream) ----
     fo_out = None
     if fo:
-        def fo_pass():
-            fo["batch"].evaluate_points(fo["poses"], residuals.data_ptr(), jac_ref.data_ptr(),
-                                        jac_read.data_ptr())
-        n_fo = max(args.steps, 1)
-        for _ in range(2):
-            fo_pass()
-        torch.cuda.synchronize()
-        barrier()
-        ctx.timer_start()
-        f0 = time.perf_counter()
-        for _ in range(n_fo):
-            fo_pass()
-        fo_kernel_ms = ctx.timer_stop() / n_fo
-        torch.cuda.synchronize()
-        barrier()
-        fo_dt = time.perf_counter() - f0
+        def time_fo(bt):
+            def fo_pass():
+                bt.evaluate_points(fo["poses"], residuals.data_ptr(), jac_ref.data_ptr(), jac_read.data_ptr())
+            n_fo = max(args.steps, 1)
+            for _ in range(2):
+                fo_pass()
+            torch.cuda.synchronize()
+            barrier()
+            ctx.timer_start()
+            f0 = time.perf_counter()
+            for _ in range(n_fo):
+                fo_pass()
+            k_ms = ctx.timer_stop() / n_fo
+            torch.cuda.synchronize()
+            barrier()
+            return n_fo, time.perf_counter() - f0, k_ms
+        n_fo, fo_dt, fo_kernel_ms = time_fo(fo["batch"])
         fo_corr = int((jac_ref[:fo["R"]].abs().sum(dim=1) > 0).sum().item())
-        red = torch.tensor([fo_dt, fo_kernel_ms], dtype=torch.float64, device="cuda")
+        fo_pr = points_read(fo["batch"], fo["poses"])
+        # the same constraints in plain constraint-major launch order (nothing shared through the L2:
+        # the regime the 88 B-per-evaluation contract figure describes); the order is chosen at a
+        # batch's first evaluation, VGX_POINTS_TILE_ORDER is read then
+        fo_plain_ms = None
+        if not args.no_fo_plain:
+            prev = os.environ.get("VGX_POINTS_TILE_ORDER")
+            os.environ["VGX_POINTS_TILE_ORDER"] = "0"
+            plain = capi.RegistrationBatch(ctx, cfs_fo, pairs_fo[mine_fo], global_index=mine_fo, n_global=len(pairs_fo))
+            _, _, fo_plain_ms = time_fo(plain)
+            assert plain.launch_order(points_pass=True) == 0
+            plain.destroy()
+            if prev is None:
+                del os.environ["VGX_POINTS_TILE_ORDER"]
+            else:
+                os.environ["VGX_POINTS_TILE_ORDER"] = prev
+        red = torch.tensor([fo_dt, fo_kernel_ms, fo_plain_ms or 0.0], dtype=torch.float64, device="cuda")
         tot = torch.tensor([float(fo["R"]), float(fo_corr)], dtype=torch.float64, device="cuda")
         if use_dist:
             dist.all_reduce(red, op=dist.ReduceOp.MAX)
             dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         fo_out = {"dt": float(red[0].item()), "kernel_ms_max": float(red[1].item()), "kernel_ms": fo_kernel_ms,
+                  "plain_kernel_ms": fo_plain_ms, "plain_kernel_ms_max": float(red[2].item()) if fo_plain_ms else None,
                   "passes": n_fo, "R": fo["R"], "R_total": float(tot[0].item()), "with_corr": fo_corr,
-                  "with_corr_total": float(tot[1].item())}
+                  "with_corr_total": float(tot[1].item()), "points": fo_pr}
 
     # ---- fused pass + all-reduce (solver-iteration form), reported separately --
     def fused_bench(bt, ps, n_nodes, n_global, corr_total, evals_total, ref_cost):
@@ -981,12 +1013,15 @@ def main():
         value = total_evals * passes / dt / 1e6
         # roofline of the dominant kernel (reg_eval_points_kernel<16,float,4>) on rank 0
         bytes_contract = R * BYTES_PER_EVAL
-        bytes_conservative = with_corr * BYTES_PER_EVAL + (R - with_corr) * BYTES_NO_CORR
-        # `achieved` prices an evaluation that finds no reading block at 56 B (20 B
-        # point in, 36 B out: there are no neighbours to fetch) and one that
-        # interpolates at the contract's 88 B (DESIGN.md "Roofline accounting")
+        # `achieved` prices what this launch has to move (DESIGN.md "Roofline accounting"): 36 B written
+        # per evaluation, 20 B per registration point the kernel reads (none for the tiles whose chunks
+        # all miss the reading submap's block box; once per group of constraints where the launch order
+        # lets them share a reference submap's points in one L2, else once per constraint), and 32 B of
+        # neighbours per evaluation that interpolates.  Chunk-granular count: conservative, the kernel
+        # culls whole 1024-point tiles.
+        bytes_conservative = R * BYTES_OUT + pr["read"] * BYTES_POINT + with_corr * BYTES_NEIGHBOURS
         achieved = bytes_conservative / (kernel_ms * 1e-3) / 1e9
-        traffic = traffic_fo = None
+        traffic = traffic_fo = traffic_fo_plain = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             t = json.load(open(tpath))
@@ -996,6 +1031,9 @@ def main():
             tf = t.get("full_overlap") or {}
             if fo and tf.get("residuals_per_launch") == fo["R"] and t.get("n_gpus") == world:
                 traffic_fo = tf.get("hbm_bytes_per_launch")
+            tp = t.get("full_overlap_plain_order") or {}
+            if fo and tp.get("residuals_per_launch") == fo["R"] and t.get("n_gpus") == world:
+                traffic_fo_plain = tp.get("hbm_bytes_per_launch")
         out = {
             "metric": "Mresiduals+Jacobians/s per GPU; full pose-graph solve ms (200 submaps)",
             "value": value, "unit": "Mresiduals+Jacobians/s",
@@ -1025,11 +1063,15 @@ def main():
                          "kernel": "reg_eval_points_kernel<16,float,4>",
                          "kernel_ms": kernel_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
                          "bytes_per_unit": BYTES_PER_EVAL, "bytes_per_unit_without_correspondence": BYTES_NO_CORR,
+                         "bytes_per_unit_culled": BYTES_OUT,
                          "units_per_launch": int(R),
                          "bytes_per_launch": int(bytes_conservative),
-                         "pricing": "per branch: 88 B for an evaluation that interpolates, 56 B (20 in, 36 out) "
-                                    "for one that finds no reading block; see roofline_full_overlap for the "
-                                    "workload the 88 B contract figure describes",
+                         "points_read": pr,
+                         "pricing": "36 B out per evaluation + 20 B per registration point read (tiles whose "
+                                    "512-point chunks all miss the reading submap's block box are written as "
+                                    "zeros without reading their points) + 32 B of neighbours per evaluation "
+                                    "that interpolates; see roofline_full_overlap for the workload the 88 B "
+                                    "contract figure describes",
                          "all_88B_would_read_GBs": bytes_contract / (kernel_ms * 1e-3) / 1e9,
                          "traffic_GBs": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None,
                          "with_correspondence_frac": with_corr / max(R, 1)},
@@ -1042,19 +1084,37 @@ def main():
         }
         if fo_out:
             fk = fo_out["kernel_ms"] * 1e-3
-            fo_bytes_branch = fo_out["with_corr"] * BYTES_PER_EVAL + (fo_out["R"] - fo_out["with_corr"]) * BYTES_NO_CORR
+            fp = fo_out["points"]
+            fo_bytes = fo_out["R"] * BYTES_OUT + fp["read"] * BYTES_POINT + fo_out["with_corr"] * BYTES_NEIGHBOURS
+            plain = None
+            if fo_out.get("plain_kernel_ms"):
+                pk = fo_out["plain_kernel_ms"] * 1e-3
+                plain = {"what": "the same constraints launched in plain constraint-major order "
+                                 "(VGX_POINTS_TILE_ORDER=0): no two concurrent constraints share a submap, every "
+                                 "evaluation moves its own 88 B -- the regime SURVEY.md 8d's contract figure describes",
+                         "kernel_ms": fo_out["plain_kernel_ms"], "kernel_ms_max_over_ranks": fo_out["plain_kernel_ms_max"],
+                         "bytes_per_unit": BYTES_PER_EVAL,
+                         "achieved": fo_out["R"] * BYTES_PER_EVAL / pk / 1e9,
+                         "frac": fo_out["R"] * BYTES_PER_EVAL / pk / 1e9 / HBM_PEAK_GBS,
+                         "traffic": traffic_fo_plain,
+                         "traffic_GBs": (traffic_fo_plain / pk / 1e9) if traffic_fo_plain else None}
             out["roofline_full_overlap"] = {
                 "workload": f"the same {n_sub} submaps, each registered against {args.overlap_copies} duplicates of "
                             f"itself perturbed by N(0, {args.pose_sigma} m) / N(0, {args.yaw_sigma} rad) "
-                            f"({fo['n']} constraints, consecutive constraints share no submap)",
+                            f"({fo['n']} constraints)",
                 "bound": "hbm", "kernel": "reg_eval_points_kernel<16,float,4>",
                 "kernel_ms": fo_out["kernel_ms"], "kernel_ms_max_over_ranks": fo_out["kernel_ms_max"],
                 "units_per_launch": int(fo_out["R"]), "bytes_per_unit": BYTES_PER_EVAL,
-                # the contract figure, every evaluation priced at 88 B
-                "achieved": fo_out["R"] * BYTES_PER_EVAL / fk / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": fo_out["R"] * BYTES_PER_EVAL / fk / 1e9 / HBM_PEAK_GBS,
-                "achieved_per_branch": fo_bytes_branch / fk / 1e9,
-                "frac_per_branch": fo_bytes_branch / fk / 1e9 / HBM_PEAK_GBS,
+                "points_read": fp, "bytes_per_launch": int(fo_bytes),
+                "pricing": "as roofline: 36 B out per evaluation + 20 B per registration point READ (the launch "
+                           "order runs the constraints of a reference submap side by side on one XCD, its points "
+                           "are fetched once per group) + 32 B per interpolating evaluation",
+                "achieved": fo_bytes / fk / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": fo_bytes / fk / 1e9 / HBM_PEAK_GBS,
+                # the contract's per-evaluation pricing re-counts a point for every constraint that reads it
+                # and can exceed the HBM peak where the L2 serves the repeats; plain_order is where it applies
+                "per_evaluation_pricing_GBs": fo_out["R"] * BYTES_PER_EVAL / fk / 1e9,
+                "plain_order": plain,
                 "with_correspondence_frac": fo_out["with_corr"] / max(fo_out["R"], 1),
                 "traffic": traffic_fo,
                 "traffic_GBs": (traffic_fo / fk / 1e9) if traffic_fo else None,

@@ -266,6 +266,13 @@ VGX_API int vgx_reg_batch_evaluate_normal(vgx_reg_batch batch,
 VGX_API int vgx_reg_batch_count_live(vgx_reg_batch batch, const double* poses, int32_t n_nodes,
                                      int64_t* live_residuals, int64_t* unique_points);
 
+/* Measurement aid: which launch order the batch's tiles took at their first evaluation.  pass 0 =
+ * fused (evaluate_normal), 1 = materialising (evaluate_points).  *grouped = 1: constraints that share
+ * a reference submap run side by side on one XCD and read its points through that XCD's L2 once;
+ * 0: plain constraint-major order (nothing worth sharing, or too much culled); -1: that pass has not
+ * run yet.  Results never depend on the order. */
+VGX_API int vgx_reg_batch_launch_order(vgx_reg_batch batch, int32_t pass, int32_t* grouped);
+
 /* Scatter-adds this process's [n][45] blocks into the fused buffer every
  * process all-reduces once per solver evaluation, DEVICE f64:
  *   [0]                               sum of costs

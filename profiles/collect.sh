@@ -7,8 +7,10 @@
 #           WRITE_SIZE 2: MI355X_MICROARCH.md "rocprofv3 PMC slots"), never combined with
 #           hip/hsa/sys traces.  The command launches, in order: two calibration dispatches of
 #           reg_eval_points_kernel (poses 10 km apart: no evaluation finds a reading block, so each
-#           writes exactly 36 B per residual), config 3's launches, the full-overlap workload's, then
-#           the fused kernel on both workloads.
+#           writes exactly 36 B per residual and -- every tile being culled -- reads no points),
+#           config 3's launches, the full-overlap workload's (--no-fo-plain: in the shipped launch
+#           order only, so that a grid size names one workload), then the fused kernel on both.
+#   rd_plain / write_plain : the same with VGX_POINTS_TILE_ORDER=0 (plain constraint-major order)
 #   sq    : SQ wave-cycle breakdown of the REG kernels and the TSDF kernel
 # Outputs land in gpurun_out/prof_*; profiles/summarize.py turns them into profiles/rNN_*.json and
 # profiles/hbm_traffic.json.
@@ -17,21 +19,28 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_stats -o stats -- \
+timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_stats -o stats -- \
     python $REPO/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/prof_stats_bench.json 2> $OUT/prof_stats.err
-PMC_ARGS="--steps 3 --inner 1 --warmup 1 --no-cpu-baseline --no-solve --no-tsdf --no-shipped --no-config5 --no-config2 --calibrate"
+PMC_ARGS="--steps 3 --inner 1 --warmup 1 --no-cpu-baseline --no-solve --no-tsdf --no-shipped --no-config5 --no-config2 --no-fo-plain --calibrate"
 REGEX="reg_eval_points|reg_eval_reduce"
-rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum \
+timeout 240 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum \
     --kernel-trace -f csv --kernel-include-regex "$REGEX" \
     -d $OUT/prof_rd -o rd -- python $REPO/bench.py $PMC_ARGS \
     > $OUT/prof_rd_bench.json 2> $OUT/prof_rd.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv --kernel-include-regex "$REGEX" \
+timeout 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv --kernel-include-regex "$REGEX" \
     -d $OUT/prof_fetch -o fetch -- python $REPO/bench.py $PMC_ARGS \
     > $OUT/prof_fetch_bench.json 2> $OUT/prof_fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv --kernel-include-regex "$REGEX" \
+timeout 240 rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv --kernel-include-regex "$REGEX" \
     -d $OUT/prof_write -o write -- python $REPO/bench.py $PMC_ARGS \
     > $OUT/prof_write_bench.json 2> $OUT/prof_write.err
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES \
+# the full-overlap workload in plain constraint-major launch order (bench.py's plain_order object)
+for c in rd write; do
+  if [ $c = rd ]; then CNT="TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum"; else CNT="WRITE_SIZE"; fi
+  VGX_POINTS_TILE_ORDER=0 timeout 300 rocprofv3 --pmc $CNT --kernel-trace -f csv --kernel-include-regex "reg_eval_points" \
+      -d $OUT/prof_${c}_plain -o ${c}_plain -- python $REPO/bench.py $PMC_ARGS --no-fused \
+      > $OUT/prof_${c}_plain_bench.json 2> $OUT/prof_${c}_plain.err
+done
+timeout 240 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES \
     --kernel-trace -f csv --kernel-include-regex "reg_eval_points_kernel|reg_eval_reduce|tsdf_integrate" \
     -d $OUT/prof_sq -o sq -- python $REPO/bench.py --steps 2 --inner 1 --warmup 1 --no-cpu-baseline --no-solve --no-shipped --no-config5 --no-config2 \
     > /dev/null 2> $OUT/prof_sq.err

@@ -44,6 +44,13 @@ def test_single_gpu_line_has_the_contract_fields(single):
     fo = d["roofline_full_overlap"]
     assert fo["with_correspondence_frac"] > 0.9 and 0 < fo["frac"] <= 1.0
     assert fo["fused"]["cost_vs_materialised"] < 1e-6
+    # materialising pass: points read <= points live <= evaluations; the plain-order measurement of the
+    # full-overlap workload carries the 88 B-per-evaluation figure
+    for r, n in ((d["roofline"], d["roofline"]["units_per_launch"]), (fo, fo["units_per_launch"])):
+        pr = r["points_read"]
+        assert 0 < pr["read"] <= pr["live"] <= n and pr["distinct"] <= pr["live"] and pr["grouped"] in (0, 1)
+        assert 0 < r["frac"] <= 1.0 and r["bytes_per_launch"] <= 88 * n
+    assert fo["plain_order"]["kernel_ms"] > 0 and 0 < fo["plain_order"]["frac"] <= 1.0
     for f in (d["fused"], fo["fused"]):
         assert 0 < f["algorithmic_GBs"] <= d["roofline"]["peak"]
         assert f["with_correspondence"] <= f["loaded_after_culling"] <= f["evaluations"]

@@ -460,6 +460,24 @@ def test_fused_pass_with_partial_overlap_culling_and_nonzero_no_correspondence_c
         assert abs(normal[0, 0] - cost) <= 1e-6 * cost
         assert np.all(np.abs(normal[0, 1:9] - jtr) <= 1e-6 * np.abs(jtr).max())
         assert np.all(np.abs(normal[0, 9:] - jtj) <= 1e-6 * np.abs(jtj).max())
+        # the materialising pass culls whole 1024-point tiles the same way (rows of zeros written
+        # without reading the points): batched f32 launch and the f64 drop-in Evaluate, row for row
+        import torch
+        r = _torch_buf(n, torch.float32)
+        jo, je = _torch_buf(4 * n, torch.float32), _torch_buf(4 * n, torch.float32)
+        torch.cuda.synchronize()
+        assert np.all(batch.evaluate_points(poses, r.data_ptr(), jo.data_ptr(), je.data_ptr()) == 0)
+        ctx.synchronize()
+        assert batch.launch_order(points_pass=True) == 0 and batch.launch_order(points_pass=False) == 0
+        H.assert_parity(r.cpu().numpy(), r0, "culled tiles: residual")
+        H.assert_parity(jo.cpu().numpy().reshape(n, 4), jo0, "culled tiles: jac_ref")
+        dead_rows = ~np.any(jo0 != 0, axis=1)
+        if ncc == 0.0:
+            assert np.all(r.cpu().numpy()[dead_rows] == 0) and np.all(je.cpu().numpy().reshape(n, 4)[dead_rows] == 0)
+        okg, rg, jog, jeg = _gpu_eval(cf, poses[0], poses[1])
+        assert okg
+        H.assert_parity(rg, r0, "culled tiles, drop-in: residual")
+        H.assert_parity(jog, jo0, "culled tiles, drop-in: jac_ref")
         batch.destroy()
         cf.destroy()
     g_ref.destroy()

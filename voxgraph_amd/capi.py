@@ -118,6 +118,7 @@ SIGNATURES = {
     "vgx_reg_batch_evaluate_points": (C.c_int, [vp, f64p, C.c_int32, vp, vp, vp, i32p]),
     "vgx_reg_batch_evaluate_normal": (C.c_int, [vp, f64p, C.c_int32, vp, f64p, i32p]),
     "vgx_reg_batch_count_live": (C.c_int, [vp, f64p, C.c_int32, i64p, i64p]),
+    "vgx_reg_batch_launch_order": (C.c_int, [vp, C.c_int32, i32p]),
     "vgx_reg_batch_assemble": (C.c_int, [vp, vp, C.c_int32, vp, C.c_int32]),
     "vgx_reg_fused_size": (C.c_int64, [C.c_int32, C.c_int32]),
     "vgx_lpt_shards": (C.c_int, [C.c_int32, i64p, C.c_int32, i32p]),
@@ -483,6 +484,13 @@ class RegistrationBatch:
         self.ctx.check(self.ctx.lib.vgx_reg_batch_count_live(self.h, _ptr(poses, f64p), poses.shape[0],
                                                              C.byref(n), C.byref(u) if unique else None))
         return (n.value, u.value) if unique else n.value
+
+    def launch_order(self, points_pass):
+        """1: constraints sharing a reference submap run side by side on one XCD (points shared in its
+        L2); 0: constraint-major; -1: that pass has not run yet (vgx_reg_batch_launch_order)"""
+        g = C.c_int32()
+        self.ctx.check(self.ctx.lib.vgx_reg_batch_launch_order(self.h, int(bool(points_pass)), C.byref(g)))
+        return g.value
 
     def assemble(self, n_nodes, d_fused, d_normal=None, zero_first=True):
         self.ctx.check(self.ctx.lib.vgx_reg_batch_assemble(

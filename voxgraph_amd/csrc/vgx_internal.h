@@ -248,6 +248,7 @@ struct vgx_reg_batch_s {
   hipEvent_t pack_copied[2] = {nullptr, nullptr};  // H2D of staging half k finished
   int pack_turn = 0;
   vgx::Tile* d_tiles = nullptr;
+  unsigned char* d_tile_dead = nullptr;  // per materialising-pass tile, per launch: every chunk culled (rows are zeros)
   int32_t* d_tile_first = nullptr;    // [n+1] first tile of each constraint
   double* d_partials = nullptr;       // [n_tiles][kPartialSize]
   double* d_normal = nullptr;         // [n][45] (internal, when caller passes none)
@@ -259,6 +260,9 @@ struct vgx_reg_batch_s {
   std::vector<vgx::ConstraintDev> host_desc;
   std::vector<int32_t> host_tile_first;
   bool launch_order_made = false;
+  bool launch_order_grouped = false, points_order_grouped = false;  // what make_xcd_order decided
+  bool points_order_made = false;              // same, for the materialising pass's 1024-point tiles
+  std::vector<int32_t> host_points_tile_first;
   int32_t reduce_tile_points = 0;       // residuals per fused tile (all but a constraint's last tile)
   vgx::Tile* d_reduce_tiles = nullptr;
   int32_t csr_nodes = 0;

@@ -280,10 +280,29 @@ struct Out4<double> {
 // distant address ranges is worse for the memory system than one interleaved front.
 // Default: off (identity mapping); VGX_XCD_SWIZZLE=1 re-enables it for experiments.
 __constant__ int g_xcd_swizzle = 0;
+__constant__ int g_points_cull = 1;  // VGX_POINTS_CULL=0: the materialising pass reads every point (A/B)
 __device__ __forceinline__ int swizzle_tile(int b, int n_tiles) {
   if (!g_xcd_swizzle) return b;
   int chunk = (n_tiles + 7) >> 3;
   return (b & 7) * chunk + (b >> 3);
+}
+
+// True when no point inside the sphere (centre in the reference frame) can have a
+// correspondence in grid g under pose pack P: the base block of p' is the block of p'
+// or its -1 neighbour, so p' must lie in [lut_min * bs, (lut_min + lut_dim + 1) * bs);
+// one voxel of slack covers the f32 rounding of the transformed centre.
+__host__ __device__ __forceinline__ bool chunk_outside(const GridDev& g, const PosePack& P, float4 sph) {
+  float uv0 = -(P.qz * sph.y), uv1 = P.qz * sph.x;
+  uv0 += uv0;
+  uv1 += uv1;
+  float cx = (sph.x + P.qw * uv0 - P.qz * uv1) + P.tx;
+  float cy = (sph.y + P.qw * uv1 + P.qz * uv0) + P.ty;
+  float cz = sph.z + P.tz;
+  float r = sph.w + g.voxel_size;
+  float lox = (float)g.lut_min[0] * g.block_size, hix = (float)(g.lut_min[0] + g.lut_dim[0] + 1) * g.block_size;
+  float loy = (float)g.lut_min[1] * g.block_size, hiy = (float)(g.lut_min[1] + g.lut_dim[1] + 1) * g.block_size;
+  float loz = (float)g.lut_min[2] * g.block_size, hiz = (float)(g.lut_min[2] + g.lut_dim[2] + 1) * g.block_size;
+  return cx + r < lox || cx - r > hix || cy + r < loy || cy - r > hiy || cz + r < loz || cz - r > hiz;
 }
 
 // ---------------------------------------------------------------------------
@@ -346,13 +365,68 @@ __device__ __forceinline__ int32_t weighted_draw(const ConstraintDev& C, int64_t
   return C.inv_order ? as_global(C.inv_order)[first] : (int32_t)first;
 }
 
+// Chunk culling of the materialising pass (see reg_eval_points_body)
+__device__ __forceinline__ bool tile_cullable(const ConstraintDev& C) {
+  return C.no_corr_cost == 0.0 && C.sample_raw == nullptr && C.chunk_bounds != nullptr;
+}
+template <int PPT>
+__device__ __forceinline__ bool tile_outside(const ConstraintDev& C, const PosePack& P, const Tile& tile) {
+  const long long chunk0 = tile.start / kChunkPoints;  // tiles start on chunk boundaries
+  bool any_live = false;
+#pragma unroll
+  for (int q = 0; q < (kBlockThreads * PPT) / kChunkPoints; ++q)
+    if (q * kChunkPoints < tile.count) any_live |= !chunk_outside(C.grid, P, C.chunk_bounds[chunk0 + q]);
+  return !any_live;
+}
+// one thread per tile of the batched launch, in launch order
+template <int PPT>
+__global__ __launch_bounds__(256) void reg_points_tile_dead_kernel(const ConstraintDev* __restrict__ cons,
+                                                                  const PosePack* __restrict__ packs,
+                                                                  const Tile* __restrict__ tiles, int n_tiles,
+                                                                  unsigned char* __restrict__ dead) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_tiles) return;
+  const Tile tile = tiles[t];
+  const ConstraintDev& C = cons[tile.constraint];
+  dead[t] = g_points_cull && tile_cullable(C) && tile_outside<PPT>(C, packs[tile.constraint], tile);
+}
+
 template <int VPS, typename OUT, int PPT, bool NT, bool NTL>
 __device__ __forceinline__ void reg_eval_points_body(
-    const ConstraintDev& C, const PosePack& P, const Tile& tile, OUT* __restrict__ residuals,
+    const ConstraintDev& C, const PosePack& P, const Tile& tile, int dead_hint, OUT* __restrict__ residuals,
     typename Out4<OUT>::type* __restrict__ jac_ref, typename Out4<OUT>::type* __restrict__ jac_read) {
   const GridDev g = C.grid;
   const bool sampled = C.sample_raw != nullptr;
   const bool want_jac = (jac_ref != nullptr) | (jac_read != nullptr);
+  // Chunk culling, as in the fused pass: when the bounding spheres of the tile's 512-point chunks all
+  // map outside the reading submap's block box, none of its points finds a block (RCF:165-166), so
+  // with no_correspondence_cost == 0 its rows are zeros whatever the points are: they are written
+  // without reading the points at all (36 B per evaluation instead of 56).  Tiles start on chunk
+  // boundaries; the test is uniform over the workgroup.  A tile with one chunk in and one out takes
+  // the straight-line path below for both (its code stays free of per-chunk branches).
+  // The batched launch gets the verdict from reg_points_tile_dead_kernel (dead_hint 0 / 1, loaded
+  // together with the tile descriptor: the bounds test adds no dependent memory latency in front of
+  // the point loads -- in-kernel it cost 5-7 % on a workload with nothing to cull); the one-constraint
+  // drop-in launch decides here (dead_hint < 0).
+  {
+    bool any_live = dead_hint == 0;
+    if (dead_hint < 0) {
+      any_live = true;
+      if (g_points_cull && tile_cullable(C)) any_live = !tile_outside<PPT>(C, P, tile);
+    }
+    if (!any_live) {
+#pragma unroll
+      for (int j = 0; j < PPT; ++j) {
+        int local = j * kBlockThreads + (int)threadIdx.x;
+        if (local >= tile.count) continue;
+        int64_t row = C.row0 + tile.start + local;
+        store_out<NT>(&residuals[row], (OUT)0);  // r = w * 0, Jacobians zero (RCF:165-170)
+        if (jac_ref) store_out4<NT>(&jac_ref[row], Out4<OUT>::make(0.0, 0.0, 0.0, 0.0));
+        if (jac_read) store_out4<NT>(&jac_read[row], Out4<OUT>::make(0.0, 0.0, 0.0, 0.0));
+      }
+      return;
+    }
+  }
 
   f32x4 pt[PPT];
   float w[PPT];
@@ -424,12 +498,14 @@ __device__ __forceinline__ void reg_eval_points_body(
 template <int VPS, typename OUT, int PPT, bool NT, bool NTL>
 __global__ __launch_bounds__(kBlockThreads) void reg_eval_points_kernel(
     const ConstraintDev* __restrict__ cons, const PosePack* __restrict__ packs,
-    const Tile* __restrict__ tiles, int n_tiles, OUT* __restrict__ residuals,
-    typename Out4<OUT>::type* __restrict__ jac_ref, typename Out4<OUT>::type* __restrict__ jac_read) {
+    const Tile* __restrict__ tiles, const unsigned char* __restrict__ tile_dead, int n_tiles,
+    OUT* __restrict__ residuals, typename Out4<OUT>::type* __restrict__ jac_ref,
+    typename Out4<OUT>::type* __restrict__ jac_read) {
   int t = swizzle_tile(blockIdx.x, n_tiles);
   if (t >= n_tiles) return;
   const Tile tile = tiles[t];
-  reg_eval_points_body<VPS, OUT, PPT, NT, NTL>(cons[tile.constraint], packs[tile.constraint], tile,
+  const int dead = tile_dead[t];
+  reg_eval_points_body<VPS, OUT, PPT, NT, NTL>(cons[tile.constraint], packs[tile.constraint], tile, dead,
                                                residuals, jac_ref, jac_read);
 }
 
@@ -446,7 +522,7 @@ __global__ __launch_bounds__(kBlockThreads) void reg_eval_points_single_kernel(
   tile.start = (int64_t)t * (kBlockThreads * PPT);
   int64_t left = C.n - tile.start;
   tile.count = (int32_t)(left < kBlockThreads * PPT ? left : kBlockThreads * PPT);
-  reg_eval_points_body<VPS, OUT, PPT, NT, NTL>(C, P, tile, residuals, jac_ref, jac_read);
+  reg_eval_points_body<VPS, OUT, PPT, NT, NTL>(C, P, tile, /*dead_hint=*/-1, residuals, jac_ref, jac_read);
 }
 
 // ---------------------------------------------------------------------------
@@ -468,23 +544,6 @@ constexpr int kFusedVariantDefault = 622;
 #endif
 constexpr bool kBallotSkip = VGX_BALLOT_SKIP != 0;
 
-// True when no point inside the sphere (centre in the reference frame) can have a
-// correspondence in grid g under pose pack P: the base block of p' is the block of p'
-// or its -1 neighbour, so p' must lie in [lut_min * bs, (lut_min + lut_dim + 1) * bs);
-// one voxel of slack covers the f32 rounding of the transformed centre.
-__host__ __device__ __forceinline__ bool chunk_outside(const GridDev& g, const PosePack& P, float4 sph) {
-  float uv0 = -(P.qz * sph.y), uv1 = P.qz * sph.x;
-  uv0 += uv0;
-  uv1 += uv1;
-  float cx = (sph.x + P.qw * uv0 - P.qz * uv1) + P.tx;
-  float cy = (sph.y + P.qw * uv1 + P.qz * uv0) + P.ty;
-  float cz = sph.z + P.tz;
-  float r = sph.w + g.voxel_size;
-  float lox = (float)g.lut_min[0] * g.block_size, hix = (float)(g.lut_min[0] + g.lut_dim[0] + 1) * g.block_size;
-  float loy = (float)g.lut_min[1] * g.block_size, hiy = (float)(g.lut_min[1] + g.lut_dim[1] + 1) * g.block_size;
-  float loz = (float)g.lut_min[2] * g.block_size, hiz = (float)(g.lut_min[2] + g.lut_dim[2] + 1) * g.block_size;
-  return cx + r < lox || cx - r > hix || cy + r < loy || cy - r > hiy || cz + r < loz || cz - r > hiz;
-}
 
 // ---------------------------------------------------------------------------
 // kernel 2: fused normal equations (lean form)
@@ -820,14 +879,19 @@ __global__ void reg_count_live_kernel(const ConstraintDev* __restrict__ cons, co
 // position 8 i + x takes the i-th tile of stream x.  VGX_FUSED_TILE_ORDER=0 keeps the plain
 // constraint-major order (A/B, profiles/ab_order.sh).  Only the launch order changes: every tile
 // writes its partial sums to its own slot, so results are bit for bit the same either way.
-static void make_xcd_order(const std::vector<ConstraintDev>& desc, const std::vector<int32_t>& tile_first,
-                           const std::vector<int32_t>& tile_work, std::vector<Tile>& tiles) {
-  static const bool enabled = [] {
+static bool make_xcd_order(const std::vector<ConstraintDev>& desc, const std::vector<int32_t>& tile_first,
+                           const std::vector<int32_t>& tile_work, std::vector<Tile>& tiles, bool points_pass) {
+  static const bool enabled_fused = [] {
     const char* e = getenv("VGX_FUSED_TILE_ORDER");
     return e ? atoi(e) != 0 : true;
   }();
+  // read per batch (not once per process): bench.py measures one workload both ways in one process
+  const bool enabled_points = [] {
+    const char* e = getenv("VGX_POINTS_TILE_ORDER");
+    return e ? atoi(e) != 0 : true;
+  }();
   const int n = (int)desc.size();
-  if (!enabled || n < 2 || tiles.size() < 16) return;
+  if (!(points_pass ? enabled_points : enabled_fused) || n < 2 || tiles.size() < 16) return false;
   constexpr int kXcds = 8;
   // groups of constraints reading the same points (sampling constraints read scattered points: alone)
   std::vector<std::vector<int>> groups;
@@ -858,7 +922,9 @@ static void make_xcd_order(const std::vector<ConstraintDev>& desc, const std::ve
         if (r < tile_first[(size_t)c + 1] - tile_first[(size_t)c]) {
           const size_t t = (size_t)tile_first[(size_t)c] + (size_t)r;
           group_tiles[g].push_back(tiles[t]);
-          group_work[g] += (int64_t)tile_work[t] + 256;
+          // bytes-ish: the materialising pass writes every row (36 B) and reads + gathers only where live
+          group_work[g] += points_pass ? (int64_t)tiles[t].count * 36 + (int64_t)tile_work[t] * 52
+                                       : (int64_t)tile_work[t] + 256;
         }
   }
   // How much of the point traffic is shareable at all: per (group, chunk range) everything beyond the
@@ -889,14 +955,18 @@ static void make_xcd_order(const std::vector<ConstraintDev>& desc, const std::ve
       return e ? atof(e) : 0.3;
     }();
     if (getenv("VGX_DEBUG_ORDER"))
-      fprintf(stderr, "[vgx] fused tile order: %zu tiles, %zu groups, shareable %.3f of %lld loaded points\n",
-              tiles.size(), groups.size(), total ? (double)shareable / (double)total : 0.0, (long long)total);
-    if (total == 0 || (double)shareable < threshold * (double)total) return;
+      fprintf(stderr, "[vgx] %s tile order: %zu tiles, %zu groups, shareable %.3f of %lld loaded points\n",
+              points_pass ? "points" : "fused", tiles.size(), groups.size(), total ? (double)shareable / (double)total : 0.0, (long long)total);
+    if (total == 0 || (double)shareable < threshold * (double)total) return false;
     // ... and only when few tiles are culled: with long runs of culled (instant) and of heavy tiles in
     // one XCD's sequence the in-order dispatcher stalls the other XCDs (config 5 above: 56 % culled)
     int64_t all_points = 0;
     for (const Tile& t : tiles) all_points += t.count;
-    if ((double)total < 0.75 * (double)all_points) return;
+    static const double live_min = [] {
+      const char* e = getenv("VGX_ORDER_LIVE_MIN");
+      return e ? atof(e) : 0.75;
+    }();
+    if ((double)total < live_min * (double)all_points) return false;
   }
   // heaviest group first onto the least loaded stream: the XCDs finish together
   std::vector<size_t> order(groups.size());
@@ -931,6 +1001,7 @@ static void make_xcd_order(const std::vector<ConstraintDev>& desc, const std::ve
       out.push_back(stream[(size_t)src][next[(size_t)src]++]);
     }
   tiles.swap(out);
+  return true;
 }
 
 // One workgroup per constraint: 12 groups of 21 lanes sum the constraint's tile
@@ -1058,6 +1129,10 @@ static void apply_swizzle_env() {
       int v = atoi(e) != 0;
       (void)hipMemcpyToSymbol(HIP_SYMBOL(g_xcd_swizzle), &v, sizeof(int));
     }
+    if ((e = getenv("VGX_POINTS_CULL"))) {
+      int v = atoi(e) != 0;
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_points_cull), &v, sizeof(int));
+    }
     return true;
   }();
   (void)done;
@@ -1065,9 +1140,12 @@ static void apply_swizzle_env() {
 
 template <typename OUT>
 static void launch_points(vgx_ctx ctx, int vps, const ConstraintDev* d_desc, const PosePack* d_pack,
-                          const Tile* d_tiles, int n_tiles, void* res, void* jr, void* je) {
+                          const Tile* d_tiles, unsigned char* d_tile_dead, int n_tiles, void* res, void* jr,
+                          void* je) {
   if (n_tiles <= 0) return;
   apply_swizzle_env();
+  hipLaunchKernelGGL(reg_points_tile_dead_kernel<kPointsPerThread>, dim3((n_tiles + 255) / 256), dim3(256), 0,
+                     ctx->stream, d_desc, d_pack, d_tiles, n_tiles, d_tile_dead);
   dim3 grid(((n_tiles + 7) / 8) * 8), block(kBlockThreads);
   using O4 = typename Out4<OUT>::type;
   static const bool nt = [] {
@@ -1080,7 +1158,7 @@ static void launch_points(vgx_ctx ctx, int vps, const ConstraintDev* d_desc, con
   }();
 #define VGX_LAUNCH_POINTS(VPS, NT, NTL)                                                             \
   hipLaunchKernelGGL((reg_eval_points_kernel<VPS, OUT, kPointsPerThread, NT, NTL>), grid, block, 0, \
-                     ctx->stream, d_desc, d_pack, d_tiles, n_tiles, (OUT*)res, (O4*)jr, (O4*)je)
+                     ctx->stream, d_desc, d_pack, d_tiles, d_tile_dead, n_tiles, (OUT*)res, (O4*)jr, (O4*)je)
   if (vps == 16) {
     if (nt && ntl) VGX_LAUNCH_POINTS(16, true, true);
     else if (nt) VGX_LAUNCH_POINTS(16, true, false);
@@ -1492,7 +1570,7 @@ int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs, const int3
   for (int c = 0; c < n; ++c) b->global_index[(size_t)c] = global_index ? global_index[c] : c;
   b->row_offset.assign((size_t)n + 1, 0);
   std::vector<ConstraintDev> desc((size_t)n);
-  std::vector<int32_t> tile_first((size_t)n + 1, 0);
+  std::vector<int32_t> tile_first((size_t)n + 1, 0), points_tile_first((size_t)n + 1, 0);
   // Fused-pass tile size: each tile ends in a 21 x f64 wave + LDS reduction, so tiles
   // grow with the batch (8 Ki .. 64 Ki residuals) while keeping >= ~16 K tiles in flight.
   int64_t total_residuals = 0;
@@ -1505,6 +1583,7 @@ int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs, const int3
     desc[(size_t)c].row0 = b->row_offset[(size_t)c];
     b->row_offset[(size_t)c + 1] = b->row_offset[(size_t)c] + regs[c]->num_residuals;
     std::vector<Tile> t = make_tiles(c, regs[c]->num_residuals, kTilePoints);
+    points_tile_first[(size_t)c] = (int32_t)b->tiles.size();
     b->tiles.insert(b->tiles.end(), t.begin(), t.end());
     tile_first[(size_t)c] = (int32_t)ex->reduce_tiles.size();
     std::vector<Tile> rt = make_tiles(c, regs[c]->num_residuals, kTilePoints * reduce_iters);
@@ -1513,6 +1592,7 @@ int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs, const int3
   }
   tile_first[(size_t)n] = (int32_t)ex->reduce_tiles.size();
   ex->reduce_tile_points = kTilePoints * reduce_iters;
+  points_tile_first[(size_t)n] = (int32_t)b->tiles.size();
   ex->host_desc = desc;            // (sample_raw is filled in below) for the launch order, made at the first evaluation
   ex->host_tile_first = tile_first;
   // Sampling constraints: group by engine (order of first appearance).  One evaluation of the
@@ -1564,6 +1644,7 @@ int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs, const int3
     }
   }
   ex->host_desc = desc;
+  ex->host_points_tile_first = points_tile_first;
   // CSR: node -> (constraint << 1 | side)
   ex->csr_nodes = max_node + 1;
   std::vector<int32_t> first((size_t)ex->csr_nodes + 1, 0), items(2 * (size_t)n);
@@ -1584,6 +1665,7 @@ int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs, const int3
   };
   int rc = up(desc.data(), desc.size() * sizeof(ConstraintDev), (void**)&b->d_desc);
   if (rc == VGX_OK) rc = up(b->tiles.data(), b->tiles.size() * sizeof(Tile), (void**)&b->d_tiles);
+  if (rc == VGX_OK && !b->tiles.empty() && hipMalloc(&b->d_tile_dead, b->tiles.size()) != hipSuccess) rc = VGX_ERR_NOMEM;
   if (rc == VGX_OK) rc = up(ex->reduce_tiles.data(), ex->reduce_tiles.size() * sizeof(Tile), (void**)&ex->d_reduce_tiles);
   if (rc == VGX_OK) rc = up(tile_first.data(), tile_first.size() * sizeof(int32_t), (void**)&b->d_tile_first);
   if (rc == VGX_OK) rc = up(b->node_pair.data(), b->node_pair.size() * sizeof(int32_t), (void**)&b->d_node_pair);
@@ -1622,6 +1704,7 @@ int vgx_reg_batch_destroy(vgx_reg_batch b) {
   for (int k = 0; k < 2; ++k)
     if (b->pack_copied[k]) (void)hipEventDestroy(b->pack_copied[k]);
   if (b->d_tiles) (void)hipFree(b->d_tiles);
+  if (b->d_tile_dead) (void)hipFree(b->d_tile_dead);
   if (b->d_tile_first) (void)hipFree(b->d_tile_first);
   if (b->d_partials) (void)hipFree(b->d_partials);
   if (b->d_normal) (void)hipFree(b->d_normal);
@@ -1682,6 +1765,28 @@ static int batch_upload_packs(vgx_reg_batch b, const double* poses, int32_t n_no
   return VGX_OK;
 }
 
+// One-time per batch and pass: per-tile live points at the poses just uploaded -> XCD-aware launch
+// order (make_xcd_order decides whether it pays).  Results do not depend on the order: fused tiles
+// write their own partial-sum slots, materialising tiles their own rows.
+static int apply_launch_order(vgx_reg_batch b, const std::vector<Tile>& tiles, Tile* d_tiles,
+                              const std::vector<int32_t>& tile_first, bool points_pass) {
+  vgx_ctx ctx = b->ctx;
+  bool& grouped = points_pass ? b->points_order_grouped : b->launch_order_grouped;
+  const int n_tiles = (int)tiles.size();
+  DeviceScratch s_live;
+  VGX_HIP(ctx, s_live.alloc((size_t)n_tiles * sizeof(int32_t)));
+  hipLaunchKernelGGL(reg_tile_live_kernel, dim3(n_tiles), dim3(64), 0, ctx->stream, b->d_desc, b->d_pack,
+                     d_tiles, n_tiles, s_live.as<int32_t>());
+  VGX_HIP(ctx, hipGetLastError());
+  std::vector<int32_t> work((size_t)n_tiles);
+  VGX_HIP(ctx, hipMemcpyAsync(work.data(), s_live.p, work.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<Tile> ordered = tiles;
+  grouped = make_xcd_order(b->host_desc, tile_first, work, ordered, points_pass);
+  VGX_HIP(ctx, hipMemcpy(d_tiles, ordered.data(), ordered.size() * sizeof(Tile), hipMemcpyHostToDevice));
+  return VGX_OK;
+}
+
 int vgx_reg_batch_evaluate_points(vgx_reg_batch b, const double* poses, int32_t n_nodes,
                                   void* d_residuals, void* d_jac_ref, void* d_jac_read,
                                   int32_t* status) {
@@ -1694,7 +1799,12 @@ int vgx_reg_batch_evaluate_points(vgx_reg_batch b, const double* poses, int32_t 
   if (rc == VGX_OK) rc = batch_upload_packs(b, poses, n_nodes, status);
   if (rc != VGX_OK) return rc;
   if (b->n == 0) return VGX_OK;
-  launch_points<float>(ctx, b->regs[0]->reading->vps, b->d_desc, b->d_pack, b->d_tiles,
+  if (!b->points_order_made && !b->tiles.empty()) {
+    rc = apply_launch_order(b, b->tiles, b->d_tiles, b->host_points_tile_first, /*points_pass=*/true);
+    if (rc != VGX_OK) return rc;
+    b->points_order_made = true;
+  }
+  launch_points<float>(ctx, b->regs[0]->reading->vps, b->d_desc, b->d_pack, b->d_tiles, b->d_tile_dead,
                        (int)b->tiles.size(), d_residuals, d_jac_ref, d_jac_read);
   VGX_HIP(ctx, hipGetLastError());
   return VGX_OK;
@@ -1714,19 +1824,8 @@ int vgx_reg_batch_evaluate_normal(vgx_reg_batch b, const double* poses, int32_t 
   double* out = d_normal ? (double*)d_normal : b->d_normal;
   const int n_tiles = (int)ex->reduce_tiles.size();
   if (!ex->launch_order_made && n_tiles > 0) {
-    // one-time: per-tile live points at these poses -> XCD-aware launch order (results do not
-    // depend on the order: every tile writes its own slot)
-    DeviceScratch s_live;
-    VGX_HIP(ctx, s_live.alloc((size_t)n_tiles * sizeof(int32_t)));
-    hipLaunchKernelGGL(reg_tile_live_kernel, dim3(n_tiles), dim3(64), 0, ctx->stream, b->d_desc, b->d_pack,
-                       ex->d_reduce_tiles, n_tiles, s_live.as<int32_t>());
-    VGX_HIP(ctx, hipGetLastError());
-    std::vector<int32_t> work((size_t)n_tiles);
-    VGX_HIP(ctx, hipMemcpyAsync(work.data(), s_live.p, work.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    std::vector<Tile> ordered = ex->reduce_tiles;
-    make_xcd_order(ex->host_desc, ex->host_tile_first, work, ordered);
-    VGX_HIP(ctx, hipMemcpy(ex->d_reduce_tiles, ordered.data(), ordered.size() * sizeof(Tile), hipMemcpyHostToDevice));
+    rc = apply_launch_order(b, ex->reduce_tiles, ex->d_reduce_tiles, ex->host_tile_first, /*points_pass=*/false);
+    if (rc != VGX_OK) return rc;
     ex->launch_order_made = true;
   }
   static const int variant = [] {
@@ -1767,6 +1866,14 @@ int vgx_reg_batch_evaluate_normal(vgx_reg_batch b, const double* poses, int32_t 
                                 hipMemcpyDeviceToHost, ctx->stream));
     VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
+  return VGX_OK;
+}
+
+int vgx_reg_batch_launch_order(vgx_reg_batch b, int32_t pass, int32_t* grouped) {
+  if (!b || !grouped || (pass != 0 && pass != 1)) return VGX_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(b->ctx->mu);
+  const bool made = pass ? b->points_order_made : b->launch_order_made;
+  *grouped = !made ? -1 : (int32_t)(pass ? b->points_order_grouped : b->launch_order_grouped);
   return VGX_OK;
 }
 
