@@ -670,7 +670,18 @@ def main():
     setup_s = time.perf_counter() - t_setup
 
     cfg = capi.default_config(registration_point_type=capi.POINTS_VOXELS)
-    weights = [n_points[a] for a, _ in pairs]
+    weights = np.array([n_points[a] for a, _ in pairs], np.int64)
+    if world > 1:
+        # what a constraint costs is the bytes it moves at these poses, not its residual count: 36 B per
+        # row written + ~45 B per residual in a chunk that can touch the reading submap
+        # (vgx_reg_batch_count_live_each; profiles/shard_balance.py: slowest-shard balance at N = 8
+        # 0.980 -> 0.991).  Every rank computes the same weights from the same replicated inputs.
+        cfs_all = [capi.RegistrationCostFunction(ctx, submaps[a], submaps[b], cfg) for a, b in pairs]
+        probe = capi.RegistrationBatch(ctx, cfs_all, pairs)
+        weights = 36 * weights + 45 * probe.count_live_each(poses)
+        probe.destroy()
+        for cf in cfs_all:
+            cf.destroy()
     mine = lpt_shards(weights, world)[rank]
     cfs = [capi.RegistrationCostFunction(ctx, submaps[pairs[c][0]], submaps[pairs[c][1]], cfg)
            for c in mine]
@@ -1050,7 +1061,8 @@ def main():
                        "passes_per_step": args.inner,
                        "step": f"{args.inner} consecutive passes over all {n_con} constraints "
                                "(one batched launch per pass per rank)",
-                       "parallelism": f"pair-sharded x{world} (LPT), submaps replicated",
+                       "parallelism": f"pair-sharded x{world} (LPT" + (" on bytes moved at the initial poses" if world > 1 else "")
+                                      + "), submaps replicated",
                        "point_order": "extraction (block, then voxel linear index)",
                        "solve_stop_rule": "solve.ms: Ceres-default function_tolerance 1e-6 (NOT the reference's "
                                           "rule); solve.reference_stop_rule: parameter_tolerance 3e-3 "

@@ -266,6 +266,12 @@ VGX_API int vgx_reg_batch_evaluate_normal(vgx_reg_batch batch,
 VGX_API int vgx_reg_batch_count_live(vgx_reg_batch batch, const double* poses, int32_t n_nodes,
                                      int64_t* live_residuals, int64_t* unique_points);
 
+/* The same count per constraint (live_each[n], batch order): what a constraint costs at these poses is
+ * roughly 36 B x its residuals + 45 B x its live residuals, which is a better weight for
+ * vgx_lpt_shards than the residual count alone when much of the constraint list is culled. */
+VGX_API int vgx_reg_batch_count_live_each(vgx_reg_batch batch, const double* poses, int32_t n_nodes,
+                                          int64_t* live_each);
+
 /* Measurement aid: which launch order the batch's tiles took at their first evaluation.  pass 0 =
  * fused (evaluate_normal), 1 = materialising (evaluate_points).  *grouped = 1: constraints that share
  * a reference submap run side by side on one XCD and read its points through that XCD's L2 once;

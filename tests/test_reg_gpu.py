@@ -484,6 +484,19 @@ def test_fused_pass_with_partial_overlap_culling_and_nonzero_no_correspondence_c
     g_read.destroy()
 
 
+def test_live_counts_per_constraint_sum_to_the_batch_count(capi, ctx, small_graph):
+    G = small_graph
+    batch = capi.RegistrationBatch(ctx, G["cfs"], G["pairs"])
+    each = batch.count_live_each(G["poses"])
+    total, distinct = batch.count_live(G["poses"], unique=True)
+    assert each.sum() == total and 0 < distinct <= total
+    assert np.all(each <= [cf.num_residuals() for cf in G["cfs"]])
+    far = G["poses"].copy()
+    far[:, 0] += 1e3 * np.arange(len(far))
+    assert batch.count_live_each(far).sum() == 0 and batch.launch_order(points_pass=True) == -1
+    batch.destroy()
+
+
 def test_compressed_blocks_reproduce_the_normal_equations(capi, ctx, small_graph):
     """vgx_reg_compress_normal: 9 residuals per constraint with the same J^T J, J^T r, r^T r
     (what voxgraph_amd/cpp/gpu_registration_batch.h hands to Ceres)."""

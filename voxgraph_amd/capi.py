@@ -119,6 +119,7 @@ SIGNATURES = {
     "vgx_reg_batch_evaluate_normal": (C.c_int, [vp, f64p, C.c_int32, vp, f64p, i32p]),
     "vgx_reg_batch_count_live": (C.c_int, [vp, f64p, C.c_int32, i64p, i64p]),
     "vgx_reg_batch_launch_order": (C.c_int, [vp, C.c_int32, i32p]),
+    "vgx_reg_batch_count_live_each": (C.c_int, [vp, f64p, C.c_int32, i64p]),
     "vgx_reg_batch_assemble": (C.c_int, [vp, vp, C.c_int32, vp, C.c_int32]),
     "vgx_reg_fused_size": (C.c_int64, [C.c_int32, C.c_int32]),
     "vgx_lpt_shards": (C.c_int, [C.c_int32, i64p, C.c_int32, i32p]),
@@ -484,6 +485,14 @@ class RegistrationBatch:
         self.ctx.check(self.ctx.lib.vgx_reg_batch_count_live(self.h, _ptr(poses, f64p), poses.shape[0],
                                                              C.byref(n), C.byref(u) if unique else None))
         return (n.value, u.value) if unique else n.value
+
+    def count_live_each(self, poses):
+        """count_live per constraint (batch order)"""
+        poses = _f64(poses).reshape(-1, 4)
+        out = np.zeros(max(self.n, 1), np.int64)
+        self.ctx.check(self.ctx.lib.vgx_reg_batch_count_live_each(self.h, _ptr(poses, f64p), poses.shape[0],
+                                                                  out.ctypes.data_as(i64p)))
+        return out[:self.n]
 
     def launch_order(self, points_pass):
         """1: constraints sharing a reference submap run side by side on one XCD (points shared in its

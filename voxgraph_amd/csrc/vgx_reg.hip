@@ -850,7 +850,7 @@ __global__ __launch_bounds__(64) void reg_tile_live_kernel(const ConstraintDev* 
 // Residuals the fused pass actually touches at these poses: the points of every chunk that
 // survives the bounding-sphere test (the rest cost no memory traffic at all).  One thread per chunk.
 __global__ void reg_count_live_kernel(const ConstraintDev* __restrict__ cons, const PosePack* __restrict__ packs,
-                                      int n_cons, unsigned long long* __restrict__ live) {
+                                      int n_cons, unsigned long long* __restrict__ live /* [n_cons] */) {
   const int c = blockIdx.x;
   if (c >= n_cons) return;
   const ConstraintDev& C = cons[c];
@@ -864,7 +864,7 @@ __global__ void reg_count_live_kernel(const ConstraintDev* __restrict__ cons, co
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off, 64);
-  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(live, mine);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(live + c, mine);
 }
 
 // XCD-aware launch order of the fused pass's tiles.  Workgroup p of a launch runs on XCD p % 8
@@ -1877,6 +1877,35 @@ int vgx_reg_batch_launch_order(vgx_reg_batch b, int32_t pass, int32_t* grouped) 
   return VGX_OK;
 }
 
+// per constraint: residuals in chunks that survive the bounding-sphere test at the uploaded poses
+static int count_live_each(vgx_reg_batch b, std::vector<unsigned long long>& each) {
+  vgx_ctx ctx = b->ctx;
+  each.assign((size_t)b->n, 0);
+  DeviceScratch counter;
+  VGX_HIP(ctx, counter.alloc((size_t)b->n * sizeof(unsigned long long)));
+  VGX_HIP(ctx, hipMemsetAsync(counter.p, 0, (size_t)b->n * sizeof(unsigned long long), ctx->stream));
+  hipLaunchKernelGGL(reg_count_live_kernel, dim3(b->n), dim3(256), 0, ctx->stream, b->d_desc, b->d_pack, b->n,
+                     counter.as<unsigned long long>());
+  VGX_HIP(ctx, hipGetLastError());
+  VGX_HIP(ctx, hipMemcpyAsync(each.data(), counter.p, each.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+  VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VGX_OK;
+}
+
+int vgx_reg_batch_count_live_each(vgx_reg_batch b, const double* poses, int32_t n_nodes, int64_t* live_each) {
+  if (!b || !poses || (b->n > 0 && !live_each)) return VGX_ERR_INVALID;
+  vgx_ctx ctx = b->ctx;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  VGX_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = batch_upload_packs(b, poses, n_nodes, nullptr);
+  if (rc != VGX_OK || b->n == 0) return rc;
+  std::vector<unsigned long long> each;
+  rc = count_live_each(b, each);
+  if (rc != VGX_OK) return rc;
+  for (int c = 0; c < b->n; ++c) live_each[c] = (int64_t)each[(size_t)c];
+  return VGX_OK;
+}
+
 int vgx_reg_batch_count_live(vgx_reg_batch b, const double* poses, int32_t n_nodes, int64_t* live_residuals,
                              int64_t* unique_points) {
   if (!b || !poses || !live_residuals) return VGX_ERR_INVALID;
@@ -1888,15 +1917,11 @@ int vgx_reg_batch_count_live(vgx_reg_batch b, const double* poses, int32_t n_nod
   int rc = batch_upload_packs(b, poses, n_nodes, nullptr);
   if (rc != VGX_OK) return rc;
   if (b->n == 0) return VGX_OK;
-  DeviceScratch counter;
-  VGX_HIP(ctx, counter.alloc(sizeof(unsigned long long)));
-  VGX_HIP(ctx, hipMemsetAsync(counter.p, 0, sizeof(unsigned long long), ctx->stream));
-  hipLaunchKernelGGL(reg_count_live_kernel, dim3(b->n), dim3(256), 0, ctx->stream, b->d_desc, b->d_pack, b->n,
-                     counter.as<unsigned long long>());
-  VGX_HIP(ctx, hipGetLastError());
+  std::vector<unsigned long long> each;
+  rc = count_live_each(b, each);
+  if (rc != VGX_OK) return rc;
   unsigned long long v = 0;
-  VGX_HIP(ctx, hipMemcpyAsync(&v, counter.p, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
-  VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (unsigned long long e : each) v += e;
   *live_residuals = (int64_t)v;
   if (!unique_points) return VGX_OK;
   // Distinct registration points behind those residuals: constraints that share a reference submap
