@@ -57,7 +57,9 @@ struct alignas(16) ConstraintDev {
   // cumulative weights -> optional Morton permutation), bit for bit what the host code did
   const uint32_t* sample_raw;
   const double* cumulative;   // [n_points] WeightedSampler::cumulative_item_weights_
-  const int32_t* search_lut;  // [kSearchBuckets + 1] first index of every draw bucket, or null
+  const int32_t* search_lut;  // [search_buckets + 1] first index of every draw bucket, or null
+  int32_t search_buckets;     // K: a power of two
+  const int32_t* sample_idx;  // batch: this evaluation's draws, indexed by row (row0 + i); null: draw in place
   const int32_t* inv_order;   // uploaded index -> device index, or null
   int64_t n_points;
   const float4* chunk_bounds; // bounding spheres of consecutive kChunkPoints-point chunks
@@ -74,10 +76,12 @@ struct Tile {
   int64_t start;  // residual index within the constraint
 };
 
-// The weighted draw's std::upper_bound starts from a bucket table: with u = k / kSearchBuckets the
-// bound of u * total is precomputed, and upper_bound is monotone in its target, so the answer for
-// any u in bucket k lies in [lut[k], lut[k + 1]]: ~5 search steps instead of ~18, same result.
-constexpr int kSearchBuckets = 4096;
+// The weighted draw's std::upper_bound starts from a bucket table: with u = k / K the bound of
+// u * total is precomputed, and upper_bound is monotone in its target, so the answer for any u in
+// bucket k lies in [lut[k], lut[k + 1]].  K = the power of two >= n: the range holds about one
+// element and the search becomes table load + four parallel loads, same result.
+constexpr int kMinSearchBuckets = 4096;
+constexpr int kMaxSearchBuckets = 1 << 24;
 constexpr int kChunkPoints = 512;   // culling granule of the fused pass (= 256 threads x 2)
 constexpr int kNormalSize = 45;     // per-constraint fused output (doubles)
 constexpr int kPartialSize = 22;    // 21 unique products + reserved
@@ -171,7 +175,8 @@ struct PointSet {
   std::vector<int32_t> inv_order;        // uploaded index -> device index (for sampling)
   std::vector<double> cumulative_weight; // WeightedSampler::cumulative_item_weights_ (upload order)
   double* d_cumulative = nullptr;        // device copy, made when a sampling cost function is created
-  int32_t* d_search_lut = nullptr;       // bucket table of the draw (kSearchBuckets + 1 entries), same moment
+  int32_t search_buckets = 0;
+  int32_t* d_search_lut = nullptr;       // bucket table of the draw (search_buckets + 1 entries), same moment
   int32_t* d_inv_order = nullptr;        // device copy of inv_order (Morton-sorted sets only)
   // WeightedSampler's mutable engine (weighted_sampler.h:36-39): ONE default-seeded std::mt19937 per
   // point set, shared by every cost function that samples this set (vgx_reg_config.sampler_seed == 0)
@@ -248,6 +253,9 @@ struct vgx_reg_batch_s {
   hipEvent_t pack_copied[2] = {nullptr, nullptr};  // H2D of staging half k finished
   int pack_turn = 0;
   vgx::Tile* d_tiles = nullptr;
+  vgx::Tile* d_draw_tiles = nullptr;     // the sampling constraints' tiles in the draw kernel's launch order
+  int32_t n_draw_tiles = 0;
+  int32_t* d_drawn = nullptr;            // sampling: the point every row uses in this evaluation (reg_draw_kernel)
   unsigned char* d_tile_dead = nullptr;  // per materialising-pass tile, per launch: every chunk culled (rows are zeros)
   int32_t* d_tile_first = nullptr;    // [n+1] first tile of each constraint
   double* d_partials = nullptr;       // [n_tiles][kPartialSize]
