@@ -401,7 +401,8 @@ __device__ __forceinline__ int32_t weighted_draw(const ConstraintDev& C, int64_t
 // one point set run on one XCD with its tables in that L2: make_draw_order) hides the dependent loads
 // far better than the evaluation kernels' 80-100 VGPR waves did, and both passes read the 4-byte
 // result coalesced.  Shipped configuration (19.3 M draws): 2.49 ms fused kernel with the draw inside ->
-// 0.38 ms draw kernel + 0.97 ms fused kernel (2.90 -> 1.75 ms per solver evaluation).
+// 0.38 ms draw kernel + 0.97 ms fused kernel (2.90 -> 1.63 ms per solver evaluation with the faster
+// mt_generate_kernel).
 __global__ __launch_bounds__(256) void reg_draw_kernel(const ConstraintDev* __restrict__ cons,
                                                       const Tile* __restrict__ tiles, int n_tiles,
                                                       int32_t* __restrict__ drawn) {
@@ -849,51 +850,89 @@ __device__ __forceinline__ uint32_t mt_twist_word(uint32_t cur, uint32_t next, u
   return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
 }
 
-__global__ __launch_bounds__(256) void mt_generate_kernel(const StreamJobDev* __restrict__ jobs) {
-  constexpr int N = Mt19937::kN, M = 397;
+// One workgroup per engine.  The twist  mt[k] = mt[(k + 397) mod 624] ^ f(mt[k], mt[k + 1])  splits
+// into three ranges of 227 words in which word k of a later range needs the NEW word k - 227 of the
+// range before it: thread t owns words t, 227 + t and 454 + t, so that chain stays in its registers.
+// What it needs from other threads are OLD words only (k + 1 of each of its words, t + 397 for the
+// first): four independent LDS reads of the previous block, one round trip.  New words go to a second
+// LDS buffer (nobody's old value is overwritten), hence ONE barrier per twist -- it was three dependent
+// LDS phases and seven barriers in place: 363 -> 216 us for the shipped configuration's 200 engines x
+// 193 K outputs (a single-wave version without any s_barrier was slower, 709 us: too few lanes per phase).  Word 623 needs the new word 0: its owner recomputes that one itself.
+constexpr int kMtThreads = 256;
+// workgroup barrier that orders LDS accesses only (__syncthreads() also drains the global stores)
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= y >> 18;
+  return y;
+}
+
+__global__ __launch_bounds__(kMtThreads) void mt_generate_kernel(const StreamJobDev* __restrict__ jobs) {
+  constexpr int N = Mt19937::kN, M = 397, H = N - M;  // H = 227
+  constexpr int kLastOwner = N - 1 - 2 * H;            // thread 169 owns word 623 as its third
+  static_assert(kMtThreads >= H, "one thread per word of a range");
   const StreamJobDev job = jobs[blockIdx.x];
-  __shared__ uint32_t mt[N];
-  const int tid = threadIdx.x;
-  for (int k = tid; k < N; k += 256) mt[k] = job.state[k];
-  uint32_t idx = job.state[N];  // uniform
+  __shared__ uint32_t buf[2][N];
+  const int t = threadIdx.x;
+  for (int k = t; k < N; k += kMtThreads) buf[0][k] = job.state[k];
+  int idx = (int)job.state[N];  // uniform; N = block used up
+  int cur = 0;
   __syncthreads();
+  const bool owner = t < H;
+  const bool third = t <= kLastOwner;
+  uint32_t a = 0, b = 0, c = 0;  // this thread's words t, H + t, 2 H + t of the current block
+  if (owner) {
+    a = buf[0][t];
+    b = buf[0][H + t];
+    if (third) c = buf[0][2 * H + t];
+  }
   long long produced = 0;
   while (produced < job.count) {
-    if (idx >= (uint32_t)N) {
-      uint32_t nv = 0;
-      if (tid < N - M) nv = mt_twist_word(mt[tid], mt[tid + 1], mt[tid + M]);
-      __syncthreads();
-      if (tid < N - M) mt[tid] = nv;
-      __syncthreads();
-      if (tid < N - M) nv = mt_twist_word(mt[N - M + tid], mt[N - M + tid + 1], mt[tid]);
-      __syncthreads();
-      if (tid < N - M) mt[N - M + tid] = nv;
-      __syncthreads();
-      constexpr int C0 = 2 * (N - M);  // 454
-      if (tid < N - 1 - C0) nv = mt_twist_word(mt[C0 + tid], mt[C0 + tid + 1], mt[C0 + tid - (N - M)]);
-      __syncthreads();
-      if (tid < N - 1 - C0) mt[C0 + tid] = nv;
-      __syncthreads();
-      if (tid == 0) mt[N - 1] = mt_twist_word(mt[N - 1], mt[0], mt[M - 1]);
-      __syncthreads();
+    if (idx >= N) {
+      const uint32_t* o = buf[cur];
+      uint32_t* w = buf[cur ^ 1];
+      if (owner) {
+        const uint32_t a1 = o[t + 1], b1 = o[H + t + 1], far = o[t + M];
+        const uint32_t c1 = t < kLastOwner ? o[2 * H + t + 1] : 0u;
+        uint32_t o0 = 0, o1 = 0, oM = 0;
+        if (t == kLastOwner) {
+          o0 = o[0];
+          o1 = o[1];
+          oM = o[M];
+        }
+        a = mt_twist_word(a, a1, far);
+        b = mt_twist_word(b, b1, a);
+        if (t < kLastOwner) c = mt_twist_word(c, c1, b);
+        if (t == kLastOwner) c = mt_twist_word(c, mt_twist_word(o0, o1, oM), b);  // far = new word 396 = b
+        w[t] = a;
+        w[H + t] = b;
+        if (third) w[2 * H + t] = c;
+      }
+      lds_barrier();
+      cur ^= 1;
       idx = 0;
     }
     const long long left = job.count - produced;
     const int take = (int)(left < (long long)(N - idx) ? left : (long long)(N - idx));
-    for (int t = tid; t < take; t += 256) {
-      uint32_t y = mt[idx + t];
-      y ^= y >> 11;
-      y ^= (y << 7) & 0x9d2c5680u;
-      y ^= (y << 15) & 0xefc60000u;
-      y ^= y >> 18;
-      job.out[produced + t] = y;
+    if (owner) {
+      // positions [idx, idx + take) of the block go to out[produced ...]
+      const int pa = t - idx, pb = H + t - idx, pc = 2 * H + t - idx;
+      if (pa >= 0 && pa < take) job.out[produced + pa] = mt_temper(a);
+      if (pb >= 0 && pb < take) job.out[produced + pb] = mt_temper(b);
+      if (third && pc >= 0 && pc < take) job.out[produced + pc] = mt_temper(c);
     }
-    idx += (uint32_t)take;
+    idx += take;
     produced += take;
   }
   __syncthreads();
-  for (int k = tid; k < N; k += 256) job.state[k] = mt[k];
-  if (tid == 0) job.state[N] = idx;
+  for (int k = t; k < N; k += kMtThreads) job.state[k] = buf[cur][k];
+  if (t == 0) job.state[N] = (uint32_t)idx;
 }
 
 // Points a fused tile will really load at these poses (its chunks that survive the bounding-sphere
@@ -1862,7 +1901,7 @@ static int batch_begin(vgx_reg_batch b) {
     int rc = engine_to_device(ctx, *j.engine);
     if (rc != VGX_OK) return rc;
   }
-  hipLaunchKernelGGL(mt_generate_kernel, dim3((unsigned)b->stream_jobs.size()), dim3(256), 0, ctx->stream,
+  hipLaunchKernelGGL(mt_generate_kernel, dim3((unsigned)b->stream_jobs.size()), dim3(kMtThreads), 0, ctx->stream,
                      (const StreamJobDev*)b->d_stream_jobs);
   VGX_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(reg_draw_kernel, dim3((unsigned)b->n_draw_tiles), dim3(256), 0, ctx->stream,
