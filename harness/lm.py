@@ -256,12 +256,13 @@ def _spd_solve(A, b):
 
 def solve(problem, poses0, parameter_tolerance=3e-3, function_tolerance=1e-6,
           gradient_tolerance=1e-10, max_iterations=50, max_seconds=4.0,
-          initial_radius=1e4, verbose=False, blas_threads=4):
+          initial_radius=1e4, verbose=False, blas_threads=1):
     """Returns (poses, summary).  Ceres-style LM: (H + D^2/radius) step, gain-ratio
     acceptance, radius update radius / max(1/3, 1 - (2 rho - 1)^3).
-    The dense linear algebra runs on `blas_threads` threads (the reference gives Ceres
-    num_threads = 4, pose_graph.cpp:96; an 800x800 Cholesky on every core of a 256-core
-    host is an order of magnitude slower than on 4)."""
+    The banded Cholesky runs on `blas_threads` threads: one.  A band of ~60 over 800 columns has
+    nothing to parallelise, and OpenBLAS' fork-join costs more than the factorisation (measured on the
+    GPU box: 1.39 ms on all 256 cores, 1.03 ms on 4, the reference's Ceres num_threads
+    (pose_graph.cpp:96, which governs residual evaluation there, not the linear solver))."""
     global _THREADPOOLS
     if ThreadpoolController is None:
         return _solve(problem, poses0, parameter_tolerance, function_tolerance,
