@@ -65,6 +65,7 @@ struct alignas(16) ConstraintDev {
   const float4* chunk_bounds; // bounding spheres of consecutive kChunkPoints-point chunks
   int64_t n;                // num_residuals
   int64_t row0;             // first output row (stacked outputs)
+  int32_t tile_points;      // batch: residuals per fused-pass tile of this constraint (all but its last tile)
   double factor;            // N / sum(w)                              (.cpp:274)
   double no_corr_cost;      // config.no_correspondence_cost
 };
@@ -271,7 +272,6 @@ struct vgx_reg_batch_s {
   bool launch_order_grouped = false, points_order_grouped = false;  // what make_xcd_order decided
   bool points_order_made = false;              // same, for the materialising pass's 1024-point tiles
   std::vector<int32_t> host_points_tile_first;
-  int32_t reduce_tile_points = 0;       // residuals per fused tile (all but a constraint's last tile)
   vgx::Tile* d_reduce_tiles = nullptr;
   int32_t csr_nodes = 0;
   int32_t* d_node_first = nullptr;

@@ -604,7 +604,7 @@ __global__ __launch_bounds__(kBlockThreads) void reg_eval_points_single_kernel(
 // ---------------------------------------------------------------------------
 // u = (jo0, jo1, jo2, jo3, je3, r): [J r]^T [J r] (9x9) is a signed
 // re-arrangement of the 21 unique products of u because je0..2 == -jo0..2.
-constexpr int kReduceIters = 8;  // a reduce tile = kTilePoints * kReduceIters residuals
+constexpr int kReduceIters = 20;  // a fused-pass tile of a large constraint = kTilePoints * kReduceIters residuals
 constexpr bool kNonTemporalLoads = false;  // A/B: VGX_NT_LOADS=1
 constexpr bool kNonTemporalStores = true;  // measured 6.08 -> 5.40 ms (profiles/ab_nt.sh, VGX_NT_STORES=0/1)
 constexpr int kMaxReduceIters = 64;
@@ -687,7 +687,7 @@ __device__ __forceinline__ void accumulate21(ACC acc[21], const float u[6]) {
 template <int VPS, int PPT, typename ACC, int WAVES>
 __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_kernel(
     const ConstraintDev* __restrict__ cons, const PosePack* __restrict__ packs,
-    const Tile* __restrict__ tiles, int n_tiles, const int32_t* __restrict__ tile_first, int tile_points,
+    const Tile* __restrict__ tiles, int n_tiles, const int32_t* __restrict__ tile_first,
     double* __restrict__ partials) {
   constexpr int kIterPoints = kBlockThreads * PPT;
   static_assert(kChunkPoints % kIterPoints == 0, "an inner iteration never straddles a culling chunk");
@@ -825,7 +825,7 @@ __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_ker
   __syncthreads();
   if (threadIdx.x < 21) {
     double v = ((lds[0][threadIdx.x] + lds[1][threadIdx.x]) + lds[2][threadIdx.x]) + lds[3][threadIdx.x];
-    const size_t slot = (size_t)tile_first[tile.constraint] + (size_t)(tile.start / tile_points);
+    const size_t slot = (size_t)tile_first[tile.constraint] + (size_t)(tile.start / C.tile_points);
     partials[slot * kPartialSize + threadIdx.x] = v;
   }
 }
@@ -1727,12 +1727,23 @@ int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs, const int3
   b->row_offset.assign((size_t)n + 1, 0);
   std::vector<ConstraintDev> desc((size_t)n);
   std::vector<int32_t> tile_first((size_t)n + 1, 0), points_tile_first((size_t)n + 1, 0);
-  // Fused-pass tile size: each tile ends in a 21 x f64 wave + LDS reduction, so tiles
-  // grow with the batch (8 Ki .. 64 Ki residuals) while keeping >= ~16 K tiles in flight.
-  int64_t total_residuals = 0;
-  for (int c = 0; c < n; ++c) total_residuals += regs[c]->num_residuals;
-  const int reduce_iters =
-      (int)std::min<int64_t>(kMaxReduceIters, std::max<int64_t>(kReduceIters, total_residuals / ((int64_t)kTilePoints * 16384)));
+  // Fused-pass tile size: a function of the constraint alone, so that its partial sums -- f32 running
+  // products inside a tile -- and therefore its 45 numbers are bit for bit the same whichever batch or
+  // shard it is evaluated in.  20 Ki residuals for large constraints (each tile ends in a 21 x f64
+  // wave + LDS reduction; measured flat between 12 and 32 Ki), a fifth of the constraint for smaller
+  // ones so that the launch still has many tiles per CU (shipped configuration, 8 K draws per
+  // constraint: 1.60 -> 1.40 ms).  NOT a fixed number of tiles per constraint
+  // that is a multiple of 8: tile t runs on XCD t % 8 and chunk culling is spatially structured, so
+  // with 16 tiles per constraint the same XCDs got the live tiles of every constraint (config 3
+  // 1.58 -> 1.77 ms).
+  auto reduce_iters_of = [](int64_t n_residuals) {
+    static const int forced = [] {
+      const char* e = getenv("VGX_FUSED_TILE_ITERS");  // A/B switch
+      return e ? atoi(e) : 0;
+    }();
+    if (forced > 0) return std::min(forced, kMaxReduceIters);
+    return (int)std::min<int64_t>(kReduceIters, std::max<int64_t>(1, n_residuals / ((int64_t)kTilePoints * 5)));
+  };
   int max_node = -1;
   for (int c = 0; c < n; ++c) {
     desc[(size_t)c] = regs[c]->describe();
@@ -1742,12 +1753,12 @@ int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs, const int3
     points_tile_first[(size_t)c] = (int32_t)b->tiles.size();
     b->tiles.insert(b->tiles.end(), t.begin(), t.end());
     tile_first[(size_t)c] = (int32_t)ex->reduce_tiles.size();
-    std::vector<Tile> rt = make_tiles(c, regs[c]->num_residuals, kTilePoints * reduce_iters);
+    desc[(size_t)c].tile_points = kTilePoints * reduce_iters_of(regs[c]->num_residuals);
+    std::vector<Tile> rt = make_tiles(c, regs[c]->num_residuals, desc[(size_t)c].tile_points);
     ex->reduce_tiles.insert(ex->reduce_tiles.end(), rt.begin(), rt.end());
     max_node = std::max(max_node, std::max(node_pair[2 * c], node_pair[2 * c + 1]));
   }
   tile_first[(size_t)n] = (int32_t)ex->reduce_tiles.size();
-  ex->reduce_tile_points = kTilePoints * reduce_iters;
   points_tile_first[(size_t)n] = (int32_t)b->tiles.size();
   ex->host_desc = desc;            // (sample_raw is filled in below) for the launch order, made at the first evaluation
   ex->host_tile_first = tile_first;
@@ -2005,8 +2016,7 @@ int vgx_reg_batch_evaluate_normal(vgx_reg_batch b, const double* poses, int32_t 
     const int vps = b->regs[0]->reading->vps;
 #define VGX_LAUNCH_LEAN(VPS, PPT, ACC, W)                                                             \
   hipLaunchKernelGGL((reg_eval_reduce_lean_kernel<VPS, PPT, ACC, W>), grid, block, 0, ctx->stream,  \
-                     b->d_desc, b->d_pack, ex->d_reduce_tiles, n_tiles, b->d_tile_first,             \
-                     ex->reduce_tile_points, b->d_partials)
+                     b->d_desc, b->d_pack, ex->d_reduce_tiles, n_tiles, b->d_tile_first, b->d_partials)
 #define VGX_LEAN_CASE(CODE, PPT, ACC, W)                                  \
   case CODE:                                                              \
     if (vps == 16) VGX_LAUNCH_LEAN(16, PPT, ACC, W);                      \
