@@ -698,8 +698,9 @@ __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_ker
   const PosePack P = packs[tile.constraint];
   const GridDev g = C.grid;
   const bool count_misses = C.no_corr_cost != 0.0;
-  // sampling mode (RCF:113-122): residual i uses the point its weighted draw selects, with weight
-  // 1; draws are scattered over the whole set, so there is nothing to cull
+  // sampling mode (RCF:113-122): residual i uses the point its weighted draw selects (made by
+  // reg_draw_kernel before this launch: a batch always has sample_idx), with weight 1; draws are
+  // scattered over the whole set, so there is nothing to cull
   const bool sampled = C.sample_raw != nullptr;
   const float4* bounds = (!count_misses && !sampled && C.chunk_bounds) ? C.chunk_bounds : nullptr;
   const long long chunk0 = tile.start / kChunkPoints;  // tiles start on chunk boundaries
@@ -723,7 +724,7 @@ __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_ker
       int local = j * kBlockThreads + (int)threadIdx.x;
       int64_t i = tile.start + (local < tile.count ? local : 0);
       if (sampled) {
-        pt_next[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[sampled_index(C, i)];
+        pt_next[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[as_global(C.sample_idx)[C.row0 + i]];
         w_next[j] = 1.0f;  // RCF:121
       } else {
         pt_next[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[i];
@@ -749,7 +750,7 @@ __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_ker
           int local = base + kIterPoints + j * kBlockThreads + (int)threadIdx.x;
           int64_t i = tile.start + (local < tile.count ? local : 0);
           if (sampled) {
-            pt_next[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[sampled_index(C, i)];
+            pt_next[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[as_global(C.sample_idx)[C.row0 + i]];
             w_next[j] = 1.0f;
           } else {
             pt_next[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[i];
