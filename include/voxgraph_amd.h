@@ -226,7 +226,9 @@ VGX_API int vgx_reg_evaluate_device_f32(vgx_reg reg, const double ref_pose[4],
  * first submap) to node_pair[c][1] (reading, second submap).
  * global_index (nullable) gives each constraint's index in the whole graph
  * when the constraint list is sharded across processes; n_global is the
- * unsharded constraint count (== n when global_index == NULL). */
+ * unsharded constraint count (values below n are read as n when global_index == NULL; a
+ * shard that owns no constraint at all passes n = 0, global_index = NULL and the real n_global,
+ * so that its assembled buffer has -- and zeroes -- the full size). */
 VGX_API int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs,
                                  const int32_t* node_pair /* [n][2] */,
                                  const int32_t* global_index /* [n] or NULL */,

@@ -28,7 +28,43 @@ def _gfx950_present():
         return False
 
 
+# Execution order of the suite: `pytest -x` stops at the first failure, so the
+# deterministic bit-exact parity tests -- the evidence every row of SURVEY.md 8 rests on -- run
+# FIRST, the boundary / adapter / error-path tests next, and whatever is statistical or end-to-end
+# (racing TSDF scans compared in distribution, whole sessions, the bench line) LAST.  Files not
+# listed run in the middle, in their usual order; within a file the definition order is kept.
+_ORDER = [
+    # 1. REG hot path, bit-exact against the oracle / the reference's own source
+    "test_reg_gpu", "test_fullsize_gpu", "test_batch_sampling_gpu", "test_dropin_cpp_gpu",
+    # 2. TSDF: the order-independent (bit-exact) cases and the reproducible mode
+    "test_tsdf_deterministic_gpu", "test_tsdf_gpu", "test_tsdf_merged_gpu", "test_tsdf_dropin_gpu",
+    # 3. producers either side of the path, bit-exact
+    "test_overlap_gpu", "test_iso_gpu", "test_esdf_gpu", "test_mapfile_gpu",
+    # 4. boundary, adapters, sharding, error paths
+    "test_multi_gpu", "test_cpp_adapter", "test_errors_gpu", "test_solve_gpu",
+]
+_LAST = ["test_pipeline_gpu", "test_chain_compare_gpu", "test_bench_gpu"]
+# statistical tests inside otherwise deterministic files: moved behind every deterministic file
+_STATISTICAL = {
+    "test_full_scan_with_shipped_config_agrees_statistically",
+    "test_merged_and_fast_agree_on_the_surface_they_reconstruct",
+}
+
+
+def _rank(item):
+    stem = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+    name = item.name.split("[")[0]
+    if stem in _LAST:
+        return 3000 + _LAST.index(stem)
+    if name in _STATISTICAL:
+        return 2000
+    if stem in _ORDER:
+        return _ORDER.index(stem)
+    return 1000
+
+
 def pytest_collection_modifyitems(config, items):
+    items.sort(key=_rank)            # stable: definition order survives inside a rank
     # plain `pytest` on a host without an MI355X: skip the gpu-marked tests instead of erroring
     # (`-m gpu` on a GPU box and `-m "not gpu"` here are unaffected)
     markexpr = (config.getoption("markexpr", "") or "").strip()

@@ -106,13 +106,42 @@ def test_two_contexts_sum_to_the_unsharded_buffer(capi, world):
 def test_a_context_without_constraints_and_foreign_constraints(capi, world):
     ctxs, subs, poses = world["ctxs"], world["subs"], world["poses"]
     cfg = capi.default_config(registration_point_type=capi.POINTS_VOXELS)
+    import torch
+    # dirty the device memory an empty shard's buffer is likely to be carved from (the
+    # off-diagonal part of an empty shard's buffer used to be summed without ever being written):
+    # a multi whose context 1 DOES own constraints writes non-zero blocks there, then frees them
+    cfs1 = [capi.RegistrationCostFunction(ctxs[1], subs[1][a], subs[1][b], cfg) for a, b in PAIRS[:3]]
+    dirty = capi.RegistrationMulti(ctxs, cfs1, PAIRS[:3])
+    dirty.evaluate_fused(poses)
+    dirty.destroy()
     cfs = [capi.RegistrationCostFunction(ctxs[0], subs[0][a], subs[0][b], cfg) for a, b in PAIRS[:3]]
     multi = capi.RegistrationMulti(ctxs, cfs, PAIRS[:3])          # context 1 gets nothing
     fused, _ = multi.evaluate_fused(poses)
     single = capi.RegistrationBatch(ctxs[0], cfs, PAIRS[:3])
     status, normal = single.evaluate_normal(poses)
     assert abs(fused[0] - normal[:, 0].sum()) <= 1e-12 * fused[0]
+    # the WHOLE buffer, off-diagonal blocks included, equals the unsharded assembly
+    buf = torch.full((capi.fused_size(4, 3),), float("nan"), dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    single.assemble(4, buf.data_ptr(), zero_first=True)
+    ctxs[0].synchronize()
+    want = buf.cpu().numpy()
+    np.testing.assert_allclose(fused, want, rtol=1e-12, atol=1e-9 * np.abs(want).max())
+    # more contexts than constraints: one constraint, two contexts
+    one = capi.RegistrationMulti(ctxs, cfs[:1], PAIRS[:1])
+    f1, _ = one.evaluate_fused(poses)
+    s1 = capi.RegistrationBatch(ctxs[0], cfs[:1], PAIRS[:1])
+    buf1 = torch.full((capi.fused_size(4, 1),), float("nan"), dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    s1.evaluate_normal(poses)
+    s1.assemble(4, buf1.data_ptr(), zero_first=True)
+    ctxs[0].synchronize()
+    np.testing.assert_allclose(f1, buf1.cpu().numpy(), rtol=1e-12, atol=1e-9 * np.abs(want).max())
+    one.destroy()
+    s1.destroy()
     multi.destroy()
+    for o in cfs1:
+        o.destroy()
     single.destroy()
     third = capi.Context(0)
     with pytest.raises(capi.VgxError):

@@ -1696,7 +1696,9 @@ int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs, const int3
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (n < 0 || (n > 0 && (!regs || !node_pair)))
     return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_batch_create: bad n / NULL arrays");
-  if (!global_index) n_global = n;
+  // n_global is the caller's: a shard that owns none (or few) of the global list's constraints still
+  // assembles -- and zeroes -- the full-size buffer.  Only "no index, no size" means n_global = n.
+  if (!global_index && n_global < n) n_global = n;
   if (n_global < n) return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_batch_create: n_global < n");
   VGX_HIP(ctx, hipSetDevice(ctx->device));
   int vps = 0;
@@ -1901,13 +1903,19 @@ int vgx_reg_batch_row_offsets(vgx_reg_batch b, int64_t* row_offset) {
 
 // Start of one batched evaluation: the registration points every constraint was built on must still
 // be there, and in sampling mode this evaluation's engine outputs are generated on the device.
-static int batch_begin(vgx_reg_batch b) {
-  vgx_ctx ctx = b->ctx;
+static int batch_points_current(vgx_reg_batch b) {
   for (vgx_reg r : b->regs)
     if (!r->points_current())
-      return set_error(ctx, VGX_ERR_INVALID,
+      return set_error(b->ctx, VGX_ERR_INVALID,
                        "vgx_reg_batch: a reference submap's registration points were replaced after the "
                        "batch was created");
+  return VGX_OK;
+}
+
+static int batch_begin(vgx_reg_batch b) {
+  vgx_ctx ctx = b->ctx;
+  int rc0 = batch_points_current(b);
+  if (rc0 != VGX_OK) return rc0;
   if (!b->any_sampling) return VGX_OK;
   for (auto& j : b->stream_jobs) {
     int rc = engine_to_device(ctx, *j.engine);
@@ -2076,7 +2084,8 @@ int vgx_reg_batch_count_live_each(vgx_reg_batch b, const double* poses, int32_t 
   vgx_ctx ctx = b->ctx;
   std::lock_guard<std::mutex> lk(ctx->mu);
   VGX_HIP(ctx, hipSetDevice(ctx->device));
-  int rc = batch_upload_packs(b, poses, n_nodes, nullptr);
+  int rc = batch_points_current(b);  // the chunk bounds read below belong to the point sets (no RNG advance)
+  if (rc == VGX_OK) rc = batch_upload_packs(b, poses, n_nodes, nullptr);
   if (rc != VGX_OK || b->n == 0) return rc;
   std::vector<unsigned long long> each;
   rc = count_live_each(b, each);
@@ -2093,7 +2102,8 @@ int vgx_reg_batch_count_live(vgx_reg_batch b, const double* poses, int32_t n_nod
   *live_residuals = 0;
   if (unique_points) *unique_points = 0;
   VGX_HIP(ctx, hipSetDevice(ctx->device));
-  int rc = batch_upload_packs(b, poses, n_nodes, nullptr);
+  int rc = batch_points_current(b);
+  if (rc == VGX_OK) rc = batch_upload_packs(b, poses, n_nodes, nullptr);
   if (rc != VGX_OK) return rc;
   if (b->n == 0) return VGX_OK;
   std::vector<unsigned long long> each;
