@@ -381,6 +381,14 @@ typedef struct vgx_tsdf_config {
   int32_t max_consecutive_ray_collisions; /* 2   */
   int32_t clear_checks_every_n_frames;  /* 1     */
   int32_t enable_anti_grazing;          /* 0     (merged integrator only) */
+  /* 0: every ray is its own thread and rays race on the approximate sets and the voxels exactly as
+   * voxblox's worker threads do (a legal order, different from run to run on dense scans).
+   * 1: REPRODUCIBLE mode -- the scan is integrated as voxblox does with integrator_threads = 1 and
+   * integration_order_mode "mixed": the same rays are cast, stop at the same voxel and update
+   * every voxel in the same order, so the same scans give the same layer bit for bit, run after
+   * run (and the layer oracle/tsdf_oracle.c computes).  Slower (several sorts and a fixed-point
+   * iteration per scan instead of one kernel); meant for regression tests and reproducible maps. */
+  int32_t deterministic;                /* 0     */
 } vgx_tsdf_config;
 VGX_API void vgx_tsdf_config_default(vgx_tsdf_config* cfg);
 

@@ -1,0 +1,233 @@
+"""The reproducible integration mode (vgx_tsdf_config.deterministic).
+
+voxblox's Fast integrator with ONE thread and its fixed ("mixed") visiting order is deterministic --
+that is what oracle/tsdf_oracle.c restates, and what finishSubmap() consumes
+(voxgraph/src/frontend/submap_collection/voxgraph_submap.cpp:84-107).  In the reproducible mode the
+GPU integrates a scan exactly as that single thread does: the same rays are cast (start-voxel
+de-duplication through the approximate set, in visiting order), every ray stops at the same voxel
+(observed set, > max_consecutive_ray_collisions in a row), every voxel receives the same updates in
+the same order, and new blocks take their pool slots in the order a sequential run allocates them.
+
+So the comparison with the oracle is not statistical: block list (order included), distances,
+weights and colours are compared BIT FOR BIT on dense scans -- the racing mode can only do that where
+the algorithm is order independent (tests/test_tsdf_gpu.py)."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as orc
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from voxgraph_amd import capi
+    capi.load()
+    return capi
+
+
+@pytest.fixture(scope="module")
+def ctx(capi):
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def _lidar_scan(n_az, n_el, seed, room=((-5.0, -4.0, -1.0), (5.0, 4.0, 3.0)), origin=(0, 0, 0), el=0.35):
+    """rays from `origin` inside an analytic box room, sensor-frame points (sensor axes = room axes)"""
+    rng = np.random.default_rng(seed)
+    az = np.linspace(-np.pi, np.pi, n_az, endpoint=False) + rng.uniform(0, 1e-3)
+    e = np.linspace(-el, el, n_el)
+    A, E = np.meshgrid(az, e)
+    d = np.stack([np.cos(E) * np.cos(A), np.cos(E) * np.sin(A), np.sin(E)], -1).reshape(-1, 3)
+    lo, hi = np.array(room[0]) - origin, np.array(room[1]) - origin
+    with np.errstate(divide="ignore"):
+        t = np.where(d > 0, hi / d, lo / d)
+    r = t.min(1)
+    return (d * r[:, None]).astype(F)
+
+
+def _rgbd_scan(seed=0):
+    """640 x 480 pinhole depth image of a box room (BASELINE config 4 shape), sensor looks along +x"""
+    u, v = np.meshgrid((np.arange(640) - 319.5) / 525.0, (np.arange(480) - 239.5) / 525.0)
+    d = np.stack([np.ones_like(u), -u, -v], -1).reshape(-1, 3)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    lo, hi = np.array([-5.0, -4.0, -1.0]), np.array([4.0, 4.0, 3.0])
+    origin = np.array([-0.5 + 0.01 * seed, 0.3, 0.4])
+    with np.errstate(divide="ignore"):
+        t = np.where(d > 0, (hi - origin) / d, (lo - origin) / d).min(1)
+    return (d * t[:, None]).astype(F), origin.astype(F)
+
+
+def _assert_layers_identical(ol, gl, what=""):
+    obi, od, ow, oc = ol.download()
+    gbi, gd, gw, gc = gl.download()
+    assert len(obi) == len(gbi), (what, len(obi), len(gbi))
+    # same blocks, allocated in the same order (first update in visiting order)
+    assert np.array_equal(obi, gbi), (what, "block order", np.flatnonzero((obi != gbi).any(1))[:5])
+    for name, a, b in (("distance", od, gd), ("weight", ow, gw)):
+        same = a.view(np.uint32) == b.view(np.uint32)
+        assert same.all(), (what, name, int((~same).sum()), "of", same.size,
+                            a[~same][:4], b[~same][:4])
+    assert np.array_equal(oc, gc), (what, "colour", int((oc != gc).any(-1).sum()))
+    return len(obi), int((ow > 0).sum())
+
+
+def test_dense_lidar_scans_are_the_single_thread_result_bit_for_bit(capi, ctx):
+    """voxgraph_mapper.yaml:21-28 (0.2 m voxels, 16 m rays, truncation 0.6, constant weight, drop-off,
+    sparsity compensation 20), 64 x 1024 returns per scan, eight scans from a moving, turning sensor,
+    random colours: the layer after every scan is the oracle's, bit for bit."""
+    vs, vps = 0.2, 16
+    ocfg = orc.voxgraph_tsdf_config()
+    gcfg = capi.voxgraph_tsdf_config(deterministic=1)
+    ol, gl = orc.TsdfLayer(vs, vps), capi.TsdfLayer(ctx, vs, vps)
+    oi, gi = orc.FastTsdfIntegrator(ocfg, ol), capi.FastTsdfIntegrator(ctx, gcfg, gl)
+    rng = np.random.default_rng(7)
+    for k in range(8):
+        origin = np.array([0.35 * k - 1.0, -0.22 * k + 0.5, 0.03 * k], F)
+        pts = _lidar_scan(1024, 64, 10 + k, origin=origin.astype(np.float64))
+        yaw = 0.15 * k
+        q = np.array([np.cos(yaw / 2), 0, 0, np.sin(yaw / 2)], F)
+        # rotate the sensor: points given in the rotated sensor frame
+        c, s = np.cos(-yaw), np.sin(-yaw)
+        pts = np.stack([c * pts[:, 0] - s * pts[:, 1], s * pts[:, 0] + c * pts[:, 1], pts[:, 2]], 1).astype(F)
+        T = np.r_[q, origin].astype(F)
+        col = rng.integers(0, 256, (len(pts), 4)).astype(np.uint8)
+        a = oi.integratePointCloud(T, pts, col)
+        b = gi.integratePointCloud(T, pts, col)
+        assert a == b, (k, a, b)
+        nb, nobs = _assert_layers_identical(ol, gl, f"scan {k}")
+    assert gl.stats()[1] == 0
+    print("LiDAR: 8 scans, blocks", nb, "observed voxels", nobs, "updates in the last scan", a)
+    assert nobs > 30000
+    for o in (gi, gl):
+        o.destroy()
+
+
+def test_rgbd_fullsize_scans_bit_for_bit(capi, ctx):
+    """BASELINE config 4: 640 x 480 depth images at 0.05 m voxels, truncation 0.15 m, 5 m rays, 1/z^2
+    weights (voxblox's default), three consecutive frames from a slowly moving camera."""
+    vs, vps = 0.05, 16
+    kw = dict(default_truncation_distance=0.15, max_ray_length_m=5.0)
+    ocfg, gcfg = orc.tsdf_config(**kw), capi.tsdf_config(deterministic=1, **kw)
+    ol, gl = orc.TsdfLayer(vs, vps), capi.TsdfLayer(ctx, vs, vps)
+    oi, gi = orc.FastTsdfIntegrator(ocfg, ol), capi.FastTsdfIntegrator(ctx, gcfg, gl)
+    rng = np.random.default_rng(3)
+    for k in range(3):
+        pts, origin = _rgbd_scan(k)
+        assert len(pts) == 307200
+        T = np.r_[np.array([1, 0, 0, 0], F), origin].astype(F)
+        col = rng.integers(0, 256, (len(pts), 4)).astype(np.uint8)
+        a = oi.integratePointCloud(T, pts, col)
+        b = gi.integratePointCloud(T, pts, col)
+        assert a == b, (k, a, b)
+        nb, nobs = _assert_layers_identical(ol, gl, f"frame {k}")
+    print("RGB-D: 3 frames, blocks", nb, "observed voxels", nobs, "updates in the last frame", a)
+    assert a > 100000 and nobs > 200000
+    for o in (gi, gl):
+        o.destroy()
+
+
+def test_five_runs_give_the_same_layer(capi, ctx):
+    """Same scans, five runs, on a dense LiDAR and an RGB-D session: every download (block order,
+    distance, weight, colour) is byte-identical.  The racing mode, for contrast, differs between runs
+    on the same input (reported, not asserted: a race is allowed to come out the same)."""
+    import hashlib
+
+    def session(cfg, kind):
+        vs = 0.2 if kind == "lidar" else 0.05
+        gl = capi.TsdfLayer(ctx, vs, 16)
+        gi = capi.FastTsdfIntegrator(ctx, cfg, gl)
+        for k in range(3):
+            if kind == "lidar":
+                origin = np.array([0.4 * k, -0.2 * k, 0.0], F)
+                pts = _lidar_scan(1024, 64, 30 + k, origin=origin.astype(np.float64))
+            else:
+                pts, origin = _rgbd_scan(k)
+            gi.integratePointCloud(np.r_[np.array([1, 0, 0, 0], F), origin].astype(F), pts)
+        h = hashlib.sha256()
+        for a in gl.download():
+            h.update(np.ascontiguousarray(a).tobytes())
+        for o in (gi, gl):
+            o.destroy()
+        return h.hexdigest()
+
+    for kind, base in (("lidar", capi.voxgraph_tsdf_config),
+                       ("rgbd", lambda **kw: capi.tsdf_config(default_truncation_distance=0.15, **kw))):
+        det = {session(base(deterministic=1), kind) for _ in range(5)}
+        assert len(det) == 1, (kind, det)
+        racing = {session(base(), kind) for _ in range(3)}
+        print(kind, "reproducible mode: 5 runs, 1 digest; racing mode:", len(racing), "digest(s) in 3 runs")
+
+
+def test_randomised_configurations_multi_ray_scans(capi, ctx):
+    """eight random integrator configurations (vps 8/16, voxel 5-30 cm, carving on/off, constant or 1/z^2
+    weights, drop-off, sparsity compensation, low max_weight, max_consecutive_ray_collisions 0-3,
+    start-voxel subsampling 1/2/4, allow_clear on/off with returns beyond the maximum range, freespace
+    scans, points at the origin / too close / non-finite), four dense scans each."""
+    for seed in range(8):
+        rng = np.random.default_rng(900 + seed)
+        vps = 8 if seed % 2 else 16
+        vs = float(rng.choice([0.05, 0.1, 0.2, 0.3]))
+        kw = dict(default_truncation_distance=float(rng.uniform(2, 4) * vs),
+                  max_ray_length_m=float(rng.uniform(25, 45) * vs),
+                  min_ray_length_m=float(rng.uniform(0.5, 2) * vs),
+                  voxel_carving_enabled=int(rng.integers(0, 2)), use_const_weight=int(rng.integers(0, 2)),
+                  use_weight_dropoff=int(rng.integers(0, 2)),
+                  use_sparsity_compensation_factor=int(rng.integers(0, 2)),
+                  sparsity_compensation_factor=float(rng.uniform(1, 30)),
+                  allow_clear=int(rng.integers(0, 2)), max_weight=float(rng.choice([3.0, 50.0, 10000.0])),
+                  max_consecutive_ray_collisions=int(rng.integers(0, 4)),
+                  start_voxel_subsampling_factor=float(rng.choice([1.0, 2.0, 4.0])))
+        ocfg, gcfg = orc.tsdf_config(**kw), capi.tsdf_config(deterministic=1, **kw)
+        ol, gl = orc.TsdfLayer(vs, vps), capi.TsdfLayer(ctx, vs, vps)
+        oi, gi = orc.FastTsdfIntegrator(ocfg, ol), capi.FastTsdfIntegrator(ctx, gcfg, gl)
+        room = ((-30 * vs, -24 * vs, -6 * vs), (32 * vs, 50 * vs, 14 * vs))   # partly beyond max range
+        for k in range(4):
+            origin = (rng.uniform(-3, 3, 3) * vs).astype(F)
+            pts = _lidar_scan(300, 20, seed * 10 + k, room=room, origin=origin.astype(np.float64), el=0.5)
+            pts = pts[rng.permutation(len(pts))]                       # not a multiple of 1024: tail in order
+            pts[:5] = 0.0                                              # at the sensor: shorter than min_ray
+            pts[5:8] *= F(0.3 * kw["min_ray_length_m"]) / np.linalg.norm(pts[5:8], axis=1, keepdims=True).astype(F)
+            pts[8] = [np.nan, 1.0, 1.0]
+            pts[9] = [np.inf, 0.0, 0.0]
+            ang = rng.uniform(-3, 3)
+            ax = rng.normal(0, 1, 3); ax /= np.linalg.norm(ax)
+            T = np.r_[np.cos(ang / 2), np.sin(ang / 2) * ax, origin].astype(F)
+            col = rng.integers(0, 256, (len(pts), 4)).astype(np.uint8)
+            free = bool(k == 3)
+            a = oi.integratePointCloud(T, pts, col, free)
+            b = gi.integratePointCloud(T, pts, col, free)
+            assert a == b, (seed, k, a, b, kw)
+            _assert_layers_identical(ol, gl, f"seed {seed} scan {k} {kw}")
+        assert gl.stats()[1] == 0
+        for o in (gi, gl):
+            o.destroy()
+
+
+def test_layer_grows_under_the_reproducible_mode(capi, ctx):
+    """80 single-ray scans while the sensor walks 40 m: the block table is re-boxed and the pool
+    enlarged under the reproducible mode as under the racing one, nothing is dropped, and -- single
+    rays being order independent -- BOTH modes equal the oracle bit for bit, block order included."""
+    vs, vps = 0.2, 16
+    kw = dict(default_truncation_distance=0.6, max_ray_length_m=10.0, use_const_weight=1)
+    ol = orc.TsdfLayer(vs, vps)
+    oi = orc.FastTsdfIntegrator(orc.tsdf_config(**kw), ol)
+    gl, gl2 = capi.TsdfLayer(ctx, vs, vps), capi.TsdfLayer(ctx, vs, vps)
+    g_det = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(deterministic=1, **kw), gl)
+    g_race = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(**kw), gl2)
+    rng = np.random.default_rng(11)
+    for k in range(80):
+        origin = np.array([0.5 * k, 0.1 * k, 0.0], F)
+        dirv = rng.normal(0, 1, 3); dirv /= np.linalg.norm(dirv)
+        p = (dirv * rng.uniform(0.5, 14.0)).astype(F)[None]
+        T = np.r_[np.array([1, 0, 0, 0], F), origin].astype(F)
+        col = rng.integers(0, 256, (1, 4)).astype(np.uint8)
+        a = oi.integratePointCloud(T, p, col)
+        assert a == g_det.integratePointCloud(T, p, col) == g_race.integratePointCloud(T, p, col)
+    _assert_layers_identical(ol, gl, "reproducible mode, 40 m walk")
+    assert gl.growths() > 0 and gl.stats()[1] == 0
+    _assert_layers_identical(ol, gl2, "racing mode, single rays")
+    for o in (g_det, g_race, gl, gl2):
+        o.destroy()

@@ -69,7 +69,8 @@ class TsdfConfig(C.Structure):
                 ("sparsity_compensation_factor", C.c_float),
                 ("start_voxel_subsampling_factor", C.c_float),
                 ("max_consecutive_ray_collisions", C.c_int32),
-                ("clear_checks_every_n_frames", C.c_int32), ("enable_anti_grazing", C.c_int32)]
+                ("clear_checks_every_n_frames", C.c_int32), ("enable_anti_grazing", C.c_int32),
+                ("deterministic", C.c_int32)]
 
 
 # every symbol include/voxgraph_amd.h declares: name -> (restype, argtypes)

@@ -27,88 +27,13 @@
 
 #include <rocprim/rocprim.hpp>  // device radix sort (MergedTsdfIntegrator's bundleRays)
 
-#include "vgx_internal.h"
+#include "vgx_tsdf_internal.h"
 
 #pragma clang fp contract(off)
 
 namespace vgx {
 
-struct TsdfLayerDev {
-  unsigned long long* voxels;  // [max_blocks][vps^3] {distance (lo), weight (hi)}
-  uint32_t* rgba;              // [max_blocks][vps^3]
-  int32_t* lut;                // dense [dim.z][dim.y][dim.x]: slot, -1 free, -2 being allocated, -3 pool exhausted
-  int32_t* block_index;        // [max_blocks][3]
-  int32_t* n_blocks;           // allocation counter
-  unsigned long long* dropped; // updates lost to box / pool limits
-  int32_t lut_min[3], lut_dim[3];
-  int32_t max_blocks, vps, vps_shift;
-  float voxel_size, voxel_size_inv;
-};
 
-struct TsdfIntegratorDev {
-  vgx_tsdf_config cfg;
-  unsigned long long* start_set;     // [2^20]
-  unsigned long long* observed_set;  // [2^20]
-  unsigned long long start_offset, observed_offset;
-  unsigned long long* n_updates;
-};
-
-constexpr unsigned kSetBits = 20;
-constexpr unsigned kSetMask = (1u << kSetBits) - 1u;
-constexpr unsigned long long kFullResetThreshold = 10000ull;
-
-// ApproxHashSet::replaceHash with LongIndexHash [recalled]: true if the slot did
-// not already hold this (hash + offset)
-__device__ __forceinline__ bool approx_replace(unsigned long long* set, unsigned long long offset,
-                                               int x, int y, int z) {
-  unsigned int h = (unsigned int)x + (unsigned int)y * 17191u + (unsigned int)z * 295530481u;
-  unsigned long long v = (unsigned long long)h + offset;
-  unsigned long long old = atomicExch(&set[v & kSetMask], v);
-  return old != v;
-}
-
-__device__ __forceinline__ float norm3(float x, float y, float z) {
-  return sqrtf(x * x + y * y + z * z);
-}
-
-__device__ __forceinline__ int signum(float x) { return (x > 0.0f) - (x < 0.0f); }
-
-// Layer::allocateBlockPtrByIndex without locks: returns the pool slot of block
-// (bx,by,bz) or -1 when it lies outside the box / the pool is exhausted.
-__device__ __forceinline__ int get_or_allocate_block(const TsdfLayerDev& L, int bx, int by, int bz) {
-  int rx = bx - L.lut_min[0], ry = by - L.lut_min[1], rz = bz - L.lut_min[2];
-  if ((unsigned)rx >= (unsigned)L.lut_dim[0] || (unsigned)ry >= (unsigned)L.lut_dim[1] ||
-      (unsigned)rz >= (unsigned)L.lut_dim[2])
-    return -1;
-  int32_t* entry = &L.lut[rx + L.lut_dim[0] * (ry + L.lut_dim[1] * rz)];
-  int slot = __hip_atomic_load(entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // every lane stays in this loop; the lane that wins the CAS finishes the
-  // allocation inside the same iteration, so nobody waits on a masked-off lane
-  while (slot == -1 || slot == -2) {
-    if (slot == -1 && atomicCAS(entry, -1, -2) == -1) {
-      int s = atomicAdd(L.n_blocks, 1);
-      if (s >= L.max_blocks) {
-        atomicSub(L.n_blocks, 1);
-        s = -3;
-      } else {
-        L.block_index[3 * s + 0] = bx;
-        L.block_index[3 * s + 1] = by;
-        L.block_index[3 * s + 2] = bz;
-        __threadfence();
-      }
-      __hip_atomic_store(entry, s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      slot = s;
-    } else {
-      __builtin_amdgcn_s_sleep(1);
-      slot = __hip_atomic_load(entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  return slot >= 0 ? slot : -1;
-}
-
-__device__ __forceinline__ unsigned long long pack_voxel(float d, float w) {
-  return (unsigned long long)__float_as_uint(d) | ((unsigned long long)__float_as_uint(w) << 32);
-}
 
 // updateTsdfVoxel + computeDistance + Color::blendTwoColors [recalled]
 __device__ __forceinline__ void update_voxel(const TsdfLayerDev& L, const vgx_tsdf_config& c,
@@ -231,17 +156,6 @@ __device__ __forceinline__ unsigned long long blended_voxel(const vgx_tsdf_confi
   return pack_voxel(nd, nw);
 }
 
-__device__ __forceinline__ uint32_t blended_color(uint32_t oc, uint32_t color, float old_w, float w) {
-  float total = old_w + w;
-  float fw = old_w / total, sw = w / total;
-  uint32_t nc = 0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    float a = (float)((oc >> (8 * k)) & 0xffu), b = (float)((color >> (8 * k)) & 0xffu);
-    nc |= ((uint32_t)(uint8_t)roundf(a * fw + b * sw)) << (8 * k);
-  }
-  return nc;
-}
 
 // One pipeline beat: issues every stage's memory operation, then consumes the results and
 // shifts.  `s1` enters with an address only; leaves through s2 and s3.
@@ -689,49 +603,6 @@ __global__ __launch_bounds__(256) void tsdf_pack_kernel(const float* __restrict_
 
 using namespace vgx;
 
-struct TsdfStats {  // one device allocation: TsdfLayerDev::n_blocks / ::dropped point into it
-  int32_t n_blocks;
-  int32_t pad;
-  unsigned long long dropped;
-};
-
-struct vgx_tsdf_layer_s {
-  vgx_ctx ctx = nullptr;
-  TsdfLayerDev dev{};
-  size_t lut_cells = 0;
-  TsdfStats* d_stats = nullptr;
-  // What the host knows about the device's allocation counter without waiting for it: the value
-  // as of scan `known_seq` (read back asynchronously after scans) plus an upper bound on what the
-  // scans launched since may have allocated.  known + pending is never below the true count.
-  TsdfStats* h_stats = nullptr;  // pinned
-  hipEvent_t readback_done = nullptr;
-  bool readback_inflight = false;
-  uint64_t scan_seq = 0, inflight_seq = 0, known_seq = 0;
-  int64_t known_blocks = 0;
-  std::vector<std::pair<uint64_t, int64_t>> recent;  // (scan, bound) of scans after known_seq
-  unsigned long long dropped_seen = 0;
-  int64_t growths = 0;  // re-boxings + pool enlargements so far
-};
-
-struct vgx_tsdf_integrator_s {
-  vgx_ctx ctx = nullptr;
-  vgx_tsdf_layer layer = nullptr;
-  TsdfIntegratorDev dev{};
-  long long reset_counter = 0;
-  float* d_points = nullptr;  // staging for host-pointer scans
-  uint32_t* d_rgba = nullptr;
-  long long staging_cap = 0;
-  std::mutex mu;  // one scan at a time per integrator: the staging buffers belong to the scan in flight
-  // MergedTsdfIntegrator scratch (grown on demand): sort keys / point indices (double-buffered),
-  // group starts, {groups, surface entries} counters, radix-sort workspace
-  unsigned long long* d_mkeys[2] = {nullptr, nullptr};
-  unsigned int* d_midx[2] = {nullptr, nullptr};
-  unsigned int* d_mstart = nullptr;
-  unsigned int* d_mcounters = nullptr;
-  void* d_msort = nullptr;
-  size_t msort_bytes = 0;
-  long long merged_cap = 0;
-};
 
 extern "C" {
 
@@ -751,6 +622,7 @@ void vgx_tsdf_config_default(vgx_tsdf_config* c) {
   c->max_consecutive_ray_collisions = 2;
   c->clear_checks_every_n_frames = 1;
   c->enable_anti_grazing = 0;
+  c->deterministic = 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -960,6 +832,16 @@ void request_readback(vgx_tsdf_layer L) {
 }
 
 }  // namespace
+
+}  // extern "C"
+
+namespace vgx {
+int tsdf_reserve_for_scan(vgx_tsdf_layer L, const float origin[3], float reach) { return reserve_for_scan(L, origin, reach); }
+int64_t tsdf_last_scan_bound(vgx_tsdf_layer L) { return L->recent.empty() ? 0 : L->recent.back().second; }
+void tsdf_request_readback(vgx_tsdf_layer L) { request_readback(L); }
+}  // namespace vgx
+
+extern "C" {
 
 int vgx_tsdf_layer_create(vgx_ctx ctx, float voxel_size, int32_t vps, const int32_t lut_min[3],
                           const int32_t lut_dim[3], int32_t max_blocks, vgx_tsdf_layer* out) {
@@ -1220,6 +1102,7 @@ int vgx_tsdf_integrator_destroy(vgx_tsdf_integrator I) {
                   I->d_mkeys[0], I->d_mkeys[1], I->d_midx[0], I->d_midx[1], I->d_mstart, I->d_mcounters, I->d_msort};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  if (I->det) det_scratch_free(I->det);
   delete I;
   return VGX_OK;
 }
@@ -1266,6 +1149,12 @@ static int integrate_locked(vgx_tsdf_integrator I, const float T[7], const void*
     const float reach = c.max_ray_length_m + c.default_truncation_distance + 2.0f * I->layer->dev.voxel_size;
     int rc = reserve_for_scan(I->layer, origin, reach);
     if (rc != VGX_OK) return rc;
+    if (c.deterministic) {
+      // reproducible mode: the single-thread visiting order of the reference, resolved in parallel
+      rc = det_integrate(I, T, d_points, d_rgba, n, freespace, n_updates);
+      if (rc == VGX_OK) request_readback(I->layer);
+      return rc;
+    }
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
     static const bool pipelined = [] {
       const char* e = getenv("VGX_TSDF_PIPELINED");  // A/B switch (profiles/ab_tsdf.sh)

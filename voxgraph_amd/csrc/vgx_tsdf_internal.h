@@ -1,0 +1,253 @@
+// Shared pieces of the TSDF path (vgx_tsdf.hip: the racing integrators and the layer;
+// vgx_tsdf_det.hip: the reproducible integration mode).  gfx950 only.
+#ifndef VGX_TSDF_INTERNAL_H_
+#define VGX_TSDF_INTERNAL_H_
+
+#include <cmath>
+#include <utility>
+#include <vector>
+
+#include "vgx_internal.h"
+
+namespace vgx {
+
+struct TsdfLayerDev {
+  unsigned long long* voxels;  // [max_blocks][vps^3] {distance (lo), weight (hi)}
+  uint32_t* rgba;              // [max_blocks][vps^3]
+  int32_t* lut;                // dense [dim.z][dim.y][dim.x]: slot, -1 free, -2 being allocated, -3 pool exhausted
+  int32_t* block_index;        // [max_blocks][3]
+  int32_t* n_blocks;           // allocation counter
+  unsigned long long* dropped; // updates lost to box / pool limits
+  int32_t lut_min[3], lut_dim[3];
+  int32_t max_blocks, vps, vps_shift;
+  float voxel_size, voxel_size_inv;
+};
+
+struct TsdfIntegratorDev {
+  vgx_tsdf_config cfg;
+  unsigned long long* start_set;     // [2^20]
+  unsigned long long* observed_set;  // [2^20]
+  unsigned long long start_offset, observed_offset;
+  unsigned long long* n_updates;
+};
+
+constexpr unsigned kSetBits = 20;
+constexpr unsigned kSetMask = (1u << kSetBits) - 1u;
+constexpr unsigned long long kFullResetThreshold = 10000ull;
+
+// ApproxHashSet::replaceHash with LongIndexHash [recalled]: true if the slot did
+// not already hold this (hash + offset)
+__device__ __forceinline__ bool approx_replace(unsigned long long* set, unsigned long long offset,
+                                               int x, int y, int z) {
+  unsigned int h = (unsigned int)x + (unsigned int)y * 17191u + (unsigned int)z * 295530481u;
+  unsigned long long v = (unsigned long long)h + offset;
+  unsigned long long old = atomicExch(&set[v & kSetMask], v);
+  return old != v;
+}
+
+__device__ __forceinline__ float norm3(float x, float y, float z) {
+  return sqrtf(x * x + y * y + z * z);
+}
+
+__device__ __forceinline__ int signum(float x) { return (x > 0.0f) - (x < 0.0f); }
+
+// Layer::allocateBlockPtrByIndex without locks: returns the pool slot of block
+// (bx,by,bz) or -1 when it lies outside the box / the pool is exhausted.
+__device__ __forceinline__ int get_or_allocate_block(const TsdfLayerDev& L, int bx, int by, int bz) {
+  int rx = bx - L.lut_min[0], ry = by - L.lut_min[1], rz = bz - L.lut_min[2];
+  if ((unsigned)rx >= (unsigned)L.lut_dim[0] || (unsigned)ry >= (unsigned)L.lut_dim[1] ||
+      (unsigned)rz >= (unsigned)L.lut_dim[2])
+    return -1;
+  int32_t* entry = &L.lut[rx + L.lut_dim[0] * (ry + L.lut_dim[1] * rz)];
+  int slot = __hip_atomic_load(entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // every lane stays in this loop; the lane that wins the CAS finishes the
+  // allocation inside the same iteration, so nobody waits on a masked-off lane
+  while (slot == -1 || slot == -2) {
+    if (slot == -1 && atomicCAS(entry, -1, -2) == -1) {
+      int s = atomicAdd(L.n_blocks, 1);
+      if (s >= L.max_blocks) {
+        atomicSub(L.n_blocks, 1);
+        s = -3;
+      } else {
+        L.block_index[3 * s + 0] = bx;
+        L.block_index[3 * s + 1] = by;
+        L.block_index[3 * s + 2] = bz;
+        __threadfence();
+      }
+      __hip_atomic_store(entry, s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      slot = s;
+    } else {
+      __builtin_amdgcn_s_sleep(1);
+      slot = __hip_atomic_load(entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  return slot >= 0 ? slot : -1;
+}
+
+__device__ __forceinline__ unsigned long long pack_voxel(float d, float w) {
+  return (unsigned long long)__float_as_uint(d) | ((unsigned long long)__float_as_uint(w) << 32);
+}
+
+// Color::blendTwoColors [recalled]
+__device__ __forceinline__ uint32_t blended_color(uint32_t oc, uint32_t color, float old_w, float w) {
+  float total = old_w + w;
+  float fw = old_w / total, sw = w / total;
+  uint32_t nc = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float a = (float)((oc >> (8 * k)) & 0xffu), b = (float)((color >> (8 * k)) & 0xffu);
+    nc |= ((uint32_t)(uint8_t)roundf(a * fw + b * sw)) << (8 * k);
+  }
+  return nc;
+}
+
+// RayCaster [recalled, voxblox integrator_utils.h] set up from sensor origin t and end point g (both
+// layer frame): ray_start / ray_end as the constructor computes them, then setupRayCaster on the
+// scaled ends -- from the far end towards the origin (cast_from_origin = false, the fast
+// integrator) or from the origin outwards (true, the merged and simple integrators).
+struct RayDda {
+  int curr[3], sign[3];
+  float t_next[3], t_step[3];
+  long long steps;
+  bool bad;
+};
+
+__device__ __forceinline__ RayDda ray_setup(const vgx_tsdf_config& c, float vsi, float tx, float ty, float tz,
+                                            float gx, float gy, float gz, bool is_clearing,
+                                            bool cast_from_origin) {
+  const float dx = gx - tx, dy = gy - ty, dz = gz - tz;
+  const float len = norm3(dx, dy, dz);
+  const float ux = dx / len, uy = dy / len, uz = dz / len;
+  const float trunc = c.default_truncation_distance;
+  float sxx, syy, szz, exx, eyy, ezz;  // ray_start, ray_end
+  if (is_clearing) {
+    const float ray_length = fminf(fmaxf(len - trunc, 0.0f), c.max_ray_length_m);
+    exx = tx + ux * ray_length; eyy = ty + uy * ray_length; ezz = tz + uz * ray_length;
+    sxx = c.voxel_carving_enabled ? tx : exx;
+    syy = c.voxel_carving_enabled ? ty : eyy;
+    szz = c.voxel_carving_enabled ? tz : ezz;
+  } else {
+    exx = gx + ux * trunc; eyy = gy + uy * trunc; ezz = gz + uz * trunc;
+    sxx = c.voxel_carving_enabled ? tx : (gx - ux * trunc);
+    syy = c.voxel_carving_enabled ? ty : (gy - uy * trunc);
+    szz = c.voxel_carving_enabled ? tz : (gz - uz * trunc);
+  }
+  const float a_[3] = {sxx * vsi, syy * vsi, szz * vsi};  // start_scaled
+  const float b_[3] = {exx * vsi, eyy * vsi, ezz * vsi};  // end_scaled
+  RayDda r;
+  r.bad = false;
+  r.steps = 0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float ss = cast_from_origin ? a_[a] : b_[a];
+    const float es = cast_from_origin ? b_[a] : a_[a];
+    r.bad |= (ss != ss) | (es != es);
+    r.curr[a] = (int)floorf(ss + 1e-6f);
+    const int end_index = (int)floorf(es + 1e-6f);
+    const int diff = end_index - r.curr[a];
+    r.steps += diff < 0 ? -diff : diff;
+    const float ray_scaled = es - ss;
+    r.sign[a] = signum(ray_scaled);
+    const float corrected = (float)(r.sign[a] > 0 ? r.sign[a] : 0);
+    const float dist_b = corrected - (ss - (float)r.curr[a]);
+    if (ray_scaled == 0.0f) {
+      r.t_next[a] = INFINITY;
+      r.t_step[a] = INFINITY;
+    } else {
+      r.t_next[a] = dist_b / ray_scaled;
+      r.t_step[a] = (float)r.sign[a] / ray_scaled;
+    }
+  }
+  return r;
+}
+
+// RayCaster::nextRayIndex: advance along the axis with the smallest t (minCoeff: first minimum)
+__device__ __forceinline__ void dda_advance(RayDda& r) {
+  int m = 0;
+  if (r.t_next[1] < r.t_next[m]) m = 1;
+  if (r.t_next[2] < r.t_next[m]) m = 2;
+  r.curr[0] += m == 0 ? r.sign[0] : 0; r.curr[1] += m == 1 ? r.sign[1] : 0; r.curr[2] += m == 2 ? r.sign[2] : 0;
+  r.t_next[0] += m == 0 ? r.t_step[0] : 0.0f; r.t_next[1] += m == 1 ? r.t_step[1] : 0.0f;
+  r.t_next[2] += m == 2 ? r.t_step[2] : 0.0f;
+}
+
+// MixedThreadSafeIndex [recalled]: 1024-point groups visited round-robin, the tail in order
+__device__ __forceinline__ long long mixed_order_point(long long seq, long long n) {
+  const long long step_size = 1024, number_of_groups = n / step_size;
+  if (seq < number_of_groups * step_size) return (seq % number_of_groups) * step_size + seq / number_of_groups;
+  return seq;
+}
+
+// kindr::minimal transform of a sensor-frame point: Eigen _transformVector + translation
+__device__ __forceinline__ void transform_point(float qw, float qx, float qy, float qz, float tx, float ty, float tz,
+                                                float px, float py, float pz, float& gx, float& gy, float& gz) {
+  float uvx = qy * pz - qz * py, uvy = qz * px - qx * pz, uvz = qx * py - qy * px;
+  uvx += uvx; uvy += uvy; uvz += uvz;
+  const float ccx = qy * uvz - qz * uvy, ccy = qz * uvx - qx * uvz, ccz = qx * uvy - qy * uvx;
+  gx = (px + qw * uvx + ccx) + tx;
+  gy = (py + qw * uvy + ccy) + ty;
+  gz = (pz + qw * uvz + ccz) + tz;
+}
+
+struct DetScratch;  // vgx_tsdf_det.hip
+void det_scratch_free(DetScratch* s);
+
+}  // namespace vgx
+
+struct TsdfStats {  // one device allocation: TsdfLayerDev::n_blocks / ::dropped point into it
+  int32_t n_blocks;
+  int32_t pad;
+  unsigned long long dropped;
+};
+
+struct vgx_tsdf_layer_s {
+  vgx_ctx ctx = nullptr;
+  vgx::TsdfLayerDev dev{};
+  size_t lut_cells = 0;
+  TsdfStats* d_stats = nullptr;
+  // What the host knows about the device's allocation counter without waiting for it: the value
+  // as of scan `known_seq` (read back asynchronously after scans) plus an upper bound on what the
+  // scans launched since may have allocated.  known + pending is never below the true count.
+  TsdfStats* h_stats = nullptr;  // pinned
+  hipEvent_t readback_done = nullptr;
+  bool readback_inflight = false;
+  uint64_t scan_seq = 0, inflight_seq = 0, known_seq = 0;
+  int64_t known_blocks = 0;
+  std::vector<std::pair<uint64_t, int64_t>> recent;  // (scan, bound) of scans after known_seq
+  unsigned long long dropped_seen = 0;
+  int64_t growths = 0;  // re-boxings + pool enlargements so far
+};
+
+struct vgx_tsdf_integrator_s {
+  vgx_ctx ctx = nullptr;
+  vgx_tsdf_layer layer = nullptr;
+  vgx::TsdfIntegratorDev dev{};
+  long long reset_counter = 0;
+  float* d_points = nullptr;  // staging for host-pointer scans
+  uint32_t* d_rgba = nullptr;
+  long long staging_cap = 0;
+  std::mutex mu;  // one scan at a time per integrator: the staging buffers belong to the scan in flight
+  // MergedTsdfIntegrator scratch (grown on demand): sort keys / point indices (double-buffered),
+  // group starts, {groups, surface entries} counters, radix-sort workspace
+  unsigned long long* d_mkeys[2] = {nullptr, nullptr};
+  unsigned int* d_midx[2] = {nullptr, nullptr};
+  unsigned int* d_mstart = nullptr;
+  unsigned int* d_mcounters = nullptr;
+  void* d_msort = nullptr;
+  size_t msort_bytes = 0;
+  long long merged_cap = 0;
+  vgx::DetScratch* det = nullptr;  // reproducible mode's buffers (vgx_tsdf_det.hip), grown on demand
+};
+
+namespace vgx {
+// vgx_tsdf.hip: room for a scan (block table box + pool), counters read-back, ApproxHashSet reset
+int tsdf_reserve_for_scan(vgx_tsdf_layer L, const float origin[3], float reach);
+int64_t tsdf_last_scan_bound(vgx_tsdf_layer L);
+void tsdf_request_readback(vgx_tsdf_layer L);
+// vgx_tsdf_det.hip: one scan in the reproducible mode (vgx_tsdf_config.deterministic); the caller
+// holds the integrator's and the context's locks, the approximate sets have been reset for the scan
+int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points, const void* d_rgba, int64_t n,
+                  int32_t freespace, int64_t* n_updates);
+}  // namespace vgx
+
+#endif  // VGX_TSDF_INTERNAL_H_
