@@ -40,7 +40,10 @@ def _compose(pose, delta):
 
 def run(capi, ctx, torch, n_submaps=6, scans_per_submap=30, n_az=512, n_el=32, voxel_size=0.2,
         full_session_submaps=30, seed=1, drift_sigma=(0.12, 0.008), use_esdf_distance=True,
-        isosurface_points=True):
+        isosurface_points=True, deterministic_tsdf=True):
+    """deterministic_tsdf: the GPU chain integrates in the reproducible mode (vgx_tsdf_config.deterministic),
+    i.e. in the oracle's own single-thread order -- its TSDF layers are then the oracle's bit for bit and
+    whatever separates the two chains comes from the later stages alone."""
     from oracle import pyoracle as orc
     rng = np.random.default_rng(seed)
     vps = 16
@@ -48,7 +51,7 @@ def run(capi, ctx, torch, n_submaps=6, scans_per_submap=30, n_az=512, n_el=32, v
     poses_all = session_sensor_poses(full_session_submaps, scans_per_submap)
     sensor_poses = poses_all[:n_submaps * scans_per_submap]
     el_span = np.deg2rad(33.2)
-    gcfg, ocfg = capi.voxgraph_tsdf_config(), orc.voxgraph_tsdf_config()
+    gcfg, ocfg = capi.voxgraph_tsdf_config(deterministic=int(bool(deterministic_tsdf))), orc.voxgraph_tsdf_config()
     pts = torch.empty((n_az * n_el, 3), dtype=torch.float32, device="cuda")
     g_sub, true_poses = [], []
     o_layers, o_points, o_tsdf = [], [], []
@@ -105,7 +108,9 @@ def run(capi, ctx, torch, n_submaps=6, scans_per_submap=30, n_az=512, n_el=32, v
         dd = np.abs(gtd[ia][both] - td[ib][both])
         tsdf_cmp.append(dict(blocks_gpu=int(len(gbi)), blocks_oracle=int(len(bi)), blocks_common=len(common),
                              observed_both=int(both.sum()), p50=float(np.percentile(dd, 50)),
-                             p99=float(np.percentile(dd, 99))))
+                             p99=float(np.percentile(dd, 99)), max=float(dd.max()),
+                             bit_identical=bool(np.array_equal(gbi, bi) and np.array_equal(gtd.view(np.uint32), td.view(np.uint32))
+                                                and np.array_equal(gtw.view(np.uint32), tw.view(np.uint32)))))
         for o in (ginteg, glayer):
             o.destroy()
     true_poses = np.array(true_poses)
@@ -134,12 +139,22 @@ def run(capi, ctx, torch, n_submaps=6, scans_per_submap=30, n_az=512, n_el=32, v
     def rmse(p):
         return float(np.sqrt(((p[:, :2] - true_poses[:, :2]) ** 2).sum(1).mean()))
     out = {"submaps": n_submaps, "scans_per_submap": scans_per_submap, "points_per_scan": n_az * n_el,
+           "tsdf_mode": "reproducible" if deterministic_tsdf else "racing",
            "mode": ("kIsosurfacePoints mirrored, " if isosurface_points else "kVoxels, ") +
                    ("ESDF distance" if use_esdf_distance else "TSDF distance"),
            "constraints": len(pairs), "xy_rmse_m_odometry_only": rmse(drifted),
            "esdf_gpu_vs_oracle_same_tsdf": esdf_cmp, "tsdf_gpu_vs_oracle": tsdf_cmp,
            "points_per_submap_gpu": [int(s.num_points(ptype)) for s in g_sub],
            "points_per_submap_oracle": [int(len(p[2])) for p in o_points]}
+    same_points = []
+    for m, sm in enumerate(g_sub):
+        gx, gd_, gw_ = sm.download_points(ptype)
+        ox, od_, ow_ = o_points[m]
+        ox, od_, ow_ = (np.ascontiguousarray(a, np.float32) for a in (ox, od_, ow_))
+        same_points.append(bool(gx.shape == ox.shape and np.array_equal(gx.view(np.uint32), ox.view(np.uint32))
+                                and np.array_equal(gd_.view(np.uint32), od_.view(np.uint32))
+                                and np.array_equal(gw_.view(np.uint32), ow_.view(np.uint32))))
+    out["registration_points_bit_identical"] = same_points
     ends = {}
     for start_name, start in (("from_truth", true_poses), ("from_drift", drifted)):
         for chain, backend in (("gpu", gpu_backend), ("oracle", orc_backend)):

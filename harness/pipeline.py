@@ -79,9 +79,11 @@ def session_sensor_poses(n_submaps, scans_per_submap, step_m=None):
 
 def run(capi, ctx, torch, n_submaps=30, scans_per_submap=20, n_az=1024, n_el=64, voxel_size=0.2,
         step_m=None, seed=1, drift_sigma=(0.12, 0.008), solve_kw=None, verbose=False,
-        use_esdf_distance=False, isosurface_points=True):
+        use_esdf_distance=False, isosurface_points=True, deterministic_tsdf=False):
     rng = np.random.default_rng(seed)
-    cfg = capi.voxgraph_tsdf_config()                         # voxgraph_mapper.yaml:21-28
+    # voxgraph_mapper.yaml:21-28; deterministic_tsdf: the reproducible integration mode (same session,
+    # same map, bit for bit, on every run -- what the tests use; the benchmark times the racing kernel)
+    cfg = capi.voxgraph_tsdf_config(deterministic=int(bool(deterministic_tsdf)))
     el_span = np.deg2rad(33.2)                                # OS1-64
     sensor_poses = session_sensor_poses(n_submaps, scans_per_submap, step_m)
     n_scans_total = len(sensor_poses)

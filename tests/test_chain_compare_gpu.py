@@ -3,12 +3,17 @@ GPU chain and through an oracle-only chain (harness/chain_compare.py) in the ref
 mode -- mirrored isosurface constraints against the reading submap's ESDF
 (registration_cost_function.h:35, pose_graph.cpp:62-71) -- sharing only the scans and the solver.
 
-Measured (profiles/r02_chain_compare_{6,30}submaps.json): the two chains end within a few cm of each
-other and drift from the ground truth ALIKE (30-submap lap, from truth: GPU 0.11 m / oracle 0.13 m;
-from drift 0.29 / 0.28 m), so the residual registration error of that synthetic session is a
-property of the data, not of the kernels.  The one deterministic producer, the ESDF, agrees with
-voxblox's queue (restated) to 1e-7 at the 99th percentile and 1-2 mm at worst (the queue's own
-min_diff_m = 1 mm slack), never above it."""
+The GPU chain integrates in the REPRODUCIBLE mode (vgx_tsdf_config.deterministic): the single-thread
+visiting order of the reference, which is the order the oracle restates.  The chain is then pinned
+stage by stage: TSDF layers bit-identical (block order included), isosurface registration points
+bit-identical, ESDF equal to voxblox's queue (restated) up to the queue's own min_diff_m slack, and
+the two solves end within 1 mm / 0.01 deg of each other (measured: 5-30 um, < 6e-6 rad,
+profiles/r03_chain_compare.json) -- north_star's pose tolerance, end to end from raw scans.
+
+The racing mode (every ray its own thread, as voxblox's worker threads race) is a different legal
+order on every run: on this weakly constrained street its end state moves by centimetres from run to
+run (r03: GPU 0.03-0.10 m RMSE against the reproducible 0.050 / 0.039 m).  It is reported by
+test_racing_mode_spread_is_reported, with bounds wide enough that a race cannot fail the suite."""
 import numpy as np
 import pytest
 
@@ -41,19 +46,41 @@ def test_esdf_fields_agree_on_the_oracles_tsdf(result):
 def test_both_chains_end_in_the_same_place(result):
     summary = {k: v for k, v in result.items() if k.startswith("from_") or k.startswith("xy_")}
     print(summary)
+    assert result["tsdf_mode"] == "reproducible"
     assert result["constraints"] >= 10
+    # every producer up to the registration points is pinned bit for bit ...
+    assert all(t["bit_identical"] for t in result["tsdf_gpu_vs_oracle"]), result["tsdf_gpu_vs_oracle"]
+    assert all(result["registration_points_bit_identical"]), result["registration_points_bit_identical"]
+    # ... so the two solves see the same points against ESDFs that differ by the queue's 1 mm slack in a
+    # few voxels: north_star's end-pose tolerance, 1 mm / 0.01 deg, holds end to end
     for start in ("from_truth", "from_drift"):
-        g, o = result[f"{start}_gpu"]["xy_rmse_m"], result[f"{start}_oracle"]["xy_rmse_m"]
-        # The street of this cut constrains the along-street direction weakly, and the GPU's TSDF
-        # differs from the oracle's by a legal reordering of racing updates (p99 of |d distance|
-        # 7-8 cm) and from run to run: the end states land a few cm apart (measured 0.2-4 cm; on
-        # the 30-submap lap the two RMSEs agree to 3-18 %, profiles/r02_chain_compare_30submaps.json)
-        assert abs(g - o) <= 0.10, (start, g, o, summary)    # racing mode: r2 driver box saw 0.057
         d = result[f"{start}_end_pose_difference"]
-        assert d["xy_max_m"] < 0.20 and d["yaw_max_rad"] < 0.01, (start, d, summary)
+        assert d["xy_max_m"] < 1e-3 and d["yaw_max_rad"] < np.deg2rad(0.01), (start, d, summary)
+        g, o = result[f"{start}_gpu"]["xy_rmse_m"], result[f"{start}_oracle"]["xy_rmse_m"]
+        assert abs(g - o) < 1e-3, (start, g, o)
     # both improve on the odometry from the drifted start, and neither wanders off from the truth
     assert result["from_drift_gpu"]["xy_rmse_m"] < 0.6 * result["xy_rmse_m_odometry_only"], summary
-    assert result["from_truth_gpu"]["xy_rmse_m"] < 0.16 and result["from_truth_oracle"]["xy_rmse_m"] < 0.12, summary
+    assert result["from_truth_gpu"]["xy_rmse_m"] < 0.12 and result["from_truth_oracle"]["xy_rmse_m"] < 0.12, summary
+
+
+def test_racing_mode_spread_is_reported():
+    """two runs of the same chain with the racing TSDF kernel: statistics only (what a race may
+    legally produce), no comparison that a particular interleaving could fail"""
+    import torch
+    from voxgraph_amd import capi
+    from harness import chain_compare
+    ctx = capi.Context(0)
+    runs = [chain_compare.run(capi, ctx, torch, n_submaps=6, scans_per_submap=30, use_esdf_distance=True,
+                              isosurface_points=True, deterministic_tsdf=False) for _ in range(2)]
+    ctx.close()
+    for r in runs:
+        print({k: round(v["xy_rmse_m"], 4) for k, v in r.items() if k.startswith("from_") and "xy_rmse_m" in v},
+              "TSDF p99 |d| vs oracle:", [round(t["p99"], 3) for t in r["tsdf_gpu_vs_oracle"]])
+        for t in r["tsdf_gpu_vs_oracle"]:
+            assert t["blocks_gpu"] == t["blocks_oracle"] == t["blocks_common"]    # same blocks whatever the order
+            assert t["p50"] < 0.01                                                # the bulk is (nearly) identical
+        for start in ("from_truth", "from_drift"):
+            assert r[f"{start}_gpu"]["xy_rmse_m"] < 0.5                           # sanity only
 
 
 def test_reference_source_agrees_with_the_oracle_chain(result):
@@ -63,7 +90,7 @@ def test_reference_source_agrees_with_the_oracle_chain(result):
     assert chk["equal"], chk
 
 
-def test_tsdf_producers_allocate_the_same_blocks(result):
+def test_tsdf_layers_are_the_oracles_bit_for_bit(result):
     for t in result["tsdf_gpu_vs_oracle"]:
         assert t["blocks_gpu"] == t["blocks_oracle"] == t["blocks_common"]
-        assert t["p50"] <= 1e-6 and t["p99"] < 0.15      # race order only: the bulk is identical
+        assert t["bit_identical"] and t["max"] == 0.0, t
