@@ -47,6 +47,7 @@ BYTES_NO_CORR = 56             # an evaluation that finds no reading block: 20 B
 BYTES_OUT, BYTES_POINT, BYTES_NEIGHBOURS = 36, 20, 32   # the three parts of the 88 B
 BYTES_PER_EVAL_FUSED = 52      # fused form: 20 B point + 32 B neighbours, nothing written per point
 BYTES_NO_CORR_FUSED = 20       # a point the fused pass loads but that finds no reading block
+PROFILE_TRAFFIC = {}           # profiles/hbm_traffic.json: PMC bytes per launch of the workloads below
 
 
 def build_graph(args):
@@ -128,7 +129,7 @@ def cpu_baseline(capi, ctx, args, true_poses, poses, pairs, seconds):
            "kind": "port",
            "sample": f"constraint 0 of the same graph ({n} residuals, one 256^3 pair) evaluated "
                      f"{done // n} times, one evaluation per task on {cores} threads, {dt:.1f} s; "
-                     "oracle/reg_oracle.c (gcc -O2)"}
+                     "oracle/reg_oracle.c (" + orc.build_flags() + ")"}
     # The reference's OWN RegistrationCostFunction::Evaluate (oracle/_ref: its source compiled
     # against stand-in headers, hashed-block voxblox layer included), when the prebuilt library
     # travelled here: same constraint, same poses, its results checked against the port's.
@@ -279,6 +280,21 @@ def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=2):
         merged_dropped = layer6.stats()[1]
         for o in (integ6, layer6):
             o.destroy()
+        # the REPRODUCIBLE mode (vgx_tsdf_config.deterministic) on the same scans: wall clock per scan (the
+        # mode synchronises with the host several times per scan), its voxel updates, and -- the TSDF
+        # path's same-run parity evidence -- its layer after the CPU sample's scans against the oracle's
+        layer7 = new_layer()
+        integ7 = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(deterministic=1, **kw), layer7)
+        integ7.integrate_device(poses[0], dev[0].data_ptr(), None, n_pts)
+        ctx.synchronize()
+        d0 = time.perf_counter()
+        for k in range(1, scans):
+            integ7.integrate_device(poses[k], dev[k].data_ptr(), None, n_pts)
+        ctx.synchronize()
+        det_ms = (time.perf_counter() - d0) * 1e3 / (scans - 1)
+        det_updates = integ7.integrate_device(poses[1], dev[1].data_ptr(), None, n_pts, count=True)
+        for o in (integ7, layer7):
+            o.destroy()
         # the drop-in call itself: host pointers (pageable), PCIe upload included, returns when done;
         # layer created the way voxblox creates one (no reservation at all)
         layer5 = capi.TsdfLayer(ctx, vs, 16)
@@ -299,6 +315,47 @@ def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=2):
         for k in range(1, 1 + cpu_scans):
             cu += oi.integratePointCloud(poses[k], clouds[k])
         cdt = time.perf_counter() - t0
+        # same scans through the reproducible mode: bit for bit the oracle's layer?
+        layer8 = capi.TsdfLayer(ctx, vs, 16)
+        integ8 = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(deterministic=1, **kw), layer8)
+        gu = 0
+        for k in range(0, 1 + cpu_scans):
+            u_ = integ8.integrate_device(poses[k], dev[k].data_ptr(), None, n_pts, count=True)
+            gu += u_ if k >= 1 else 0
+        obi, od, ow, oc = ol.download()
+        gbi, gd, gw, gc = layer8.download()
+        det_parity = {"scans": 1 + cpu_scans, "voxel_updates_equal": bool(gu == cu),
+                      "blocks": int(len(obi)), "voxels_compared": int(od.size),
+                      "bit_identical": bool(np.array_equal(obi, gbi) and np.array_equal(od.view(np.uint32), gd.view(np.uint32))
+                                            and np.array_equal(ow.view(np.uint32), gw.view(np.uint32)) and np.array_equal(oc, gc)),
+                      "checker": "oracle/tsdf_oracle.c (single thread, mixed order) [recalled: parity unpinned]"}
+        for o in (integ8, layer8):
+            o.destroy()
+        # the same port on all host cores: the path does not shard (one active submap), so this is
+        # REPLICAS -- one integrator + layer per thread, every thread the same scans
+        from concurrent.futures import ThreadPoolExecutor
+        cores = os.cpu_count() or 1
+        reps = []
+        for _ in range(cores):
+            l_ = orc.TsdfLayer(vs, 16)
+            i_ = orc.FastTsdfIntegrator(orc.tsdf_config(**kw), l_)
+            reps.append((l_, i_))
+
+        def replica(j):
+            i_ = reps[j][1]
+            i_.integratePointCloud(poses[0], clouds[0])
+            t_ = time.perf_counter()
+            for k in range(1, 1 + cpu_scans):
+                i_.integratePointCloud(poses[k], clouds[k])
+            return time.perf_counter() - t_
+        t0r = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            rt = list(ex.map(replica, range(cores)))
+        cpu_all = {"Mpoints_per_s": n_pts * cpu_scans * cores / max(rt) / 1e6, "cores": cores, "kind": "port",
+                   "replicas": cores, "wall_s": time.perf_counter() - t0r,
+                   "sample": f"{cores} replicas (one integrator + layer per thread) x {cpu_scans} scans; the "
+                             "restatement is serial within a scan"}
+        del reps
         timed = scans - 1
         alg_bytes_scan = 16.0 * n_pts + 24.0 * updates / timed
         out[name] = {"points_per_scan": n_pts, "scans_timed": timed, "ms_per_scan": ms / timed,
@@ -322,17 +379,33 @@ def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=2):
                                            "note": "vgx_tsdf_integrate into an unreserved layer: pageable host "
                                                    "points, PCIe upload, enlargements and completion wait included"},
                      "merged_integrator": {"ms_per_scan": merged_ms, "Mpoints_per_s": n_pts / merged_ms / 1e3,
+                                           "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                                                        "bytes_per_launch": 16.0 * n_pts + 24.0 * merged_updates,
+                                                        "achieved": (16.0 * n_pts + 24.0 * merged_updates) / merged_ms / 1e6,
+                                                        "frac": (16.0 * n_pts + 24.0 * merged_updates) / merged_ms / 1e6 / HBM_PEAK_GBS,
+                                                        "time": "back-to-back scans, all kernels of a scan (keys, sort, "
+                                                                "heads, rays)"},
                                            "voxel_updates_per_scan": merged_updates, "dropped_updates": merged_dropped,
                                            "Mvoxel_updates_per_s": merged_updates / merged_ms / 1e3,
                                            "note": "vgx_tsdf_integrate_merged_device: key + stable radix sort + group "
                                                    "heads + one full ray per end voxel (no early-out), surface then "
                                                    "clearing groups"},
+                     "reproducible_mode": {"ms_per_scan": det_ms, "Mpoints_per_s": n_pts / det_ms / 1e3,
+                                           "voxel_updates_per_scan": det_updates,
+                                           "over_racing_kernel": det_ms / (ms / timed),
+                                           "parity_vs_oracle": det_parity,
+                                           "note": "vgx_tsdf_config.deterministic = 1: the single-thread visiting "
+                                                   "order resolved in parallel (sort by approximate-set slot, "
+                                                   "fixed-point sweeps, ordered per-voxel updates); wall clock incl. "
+                                                   "its host synchronisations"},
                      "first_scan": {"ms": first_ms, "voxel_updates": first_updates,
                                     "Mvoxel_updates_per_s": first_updates / first_ms / 1e3,
                                     "algorithmic_GBs": (16.0 * n_pts + 24.0 * first_updates) / first_ms / 1e6},
                      "cpu_baseline": {"Mpoints_per_s": n_pts * cpu_scans / cdt / 1e6,
                                       "Mvoxel_updates_per_s": cu / cdt / 1e6, "cores": 1,
-                                      "kind": "port", "sample": f"{cpu_scans} scans, oracle/tsdf_oracle.c"}}
+                                      "kind": "port", "sample": f"{cpu_scans} scans, oracle/tsdf_oracle.c ("
+                                                                + orc.build_flags() + ")",
+                                      "all_cores": cpu_all}}
         for o in (integ, layer, layer2):
             o.destroy()
     return out
@@ -524,6 +597,8 @@ def config5_bench(capi, ctx, torch, dist, use_dist, rank, world, args):
            "submaps": n, "registration_constraints": int(len(pairs)), "loop_closures": n_lc,
            "residuals_per_evaluation": float(rs.item()),
            "solve_ms": float(sdt.item()) * 1e3,
+           "solve_gpu_evaluation_ms": sum(s_["backend_seconds"] for s_ in summaries) * 1e3,
+           "solve_host_linear_algebra_ms": sum(s_["host_linear_algebra_seconds"] for s_ in summaries) * 1e3,
            "stage1_without_registration": {k: summaries[0][k] for k in ("iterations", "evaluations", "termination")},
            "stage2_all_constraints": {k: summaries[1][k] for k in ("iterations", "evaluations", "termination",
                                                                   "initial_cost", "final_cost")},
@@ -542,6 +617,22 @@ def config5_bench(capi, ctx, torch, dist, use_dist, rank, world, args):
                           f"{capi.fused_size(n, len(pairs)) * 8} B per evaluation",
            "setup_s": setup_s,
            "solver": "harness/lm.py (LM, banded Cholesky on the host; Ceres absent)"}
+    if rank == 0 and not args.no_parity:
+        from harness import parity_gate
+        t_par = time.perf_counter()
+
+        def layers_of(k):
+            sm = capi.Submap.synth_city(ctx, k, vs, 16, bmin, dims, args.truncation, args.esdf_max, 10.0, true[k], args.seed)
+            td, tw, ed, eo = sm.download_layers(16)
+            bi = sm.block_index()
+            sm.destroy()
+            return bi, td, tw, ed, eo
+        live_each = batch.count_live_each(poses0)
+        chosen = parity_gate.choose(np.diff(batch.row_offsets()), live_each, n_total=8, n_partial=3, n_dead=1)
+        e = parity_gate.check(capi, ctx, torch, "config 5 (the timed batch at the initial poses)", layers_of, submaps,
+                              batch, pairs[mine], poses0, chosen, None, vs)
+        e["seconds"] = time.perf_counter() - t_par
+        out["parity"] = e
     for o in [batch] + cfs + submaps:
         o.destroy()
     return out
@@ -552,8 +643,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--inner", type=int, default=10,
-                    help="passes over all constraints per step (a converged solve takes 9)")
+    ap.add_argument("--inner", type=int, default=25,
+                    help="passes over all constraints per step (the driver's 20 steps then time > 2 s)")
+    ap.add_argument("--no-parity", action="store_true",
+                    help="skip the same-run parity gate (harness/parity_gate.py: a sample of the timed launches' "
+                         "constraints against the reference source / the oracle)")
     ap.add_argument("--overlap-copies", type=int, default=6,
                     help="full-overlap workload: perturbed duplicates per submap (config 3 has ~6 "
                          "constraints per reference submap)")
@@ -634,6 +728,9 @@ def main():
         if use_dist:
             dist.barrier()
 
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import pyoracle
+        pyoracle.use_native_build()      # the CPU port as BASELINE.md times it: -O3 -march=native, built on this host
     ctx = capi.Context(local_rank)
     # one explicit (non-null) stream shared by the HIP library, torch ops and RCCL,
     # so kernel -> all-reduce ordering is by stream order, not by host syncs
@@ -654,6 +751,9 @@ def main():
 
     true_poses, poses, pairs = build_graph(args)
     n_sub, n_con = len(true_poses), len(pairs)
+    global PROFILE_TRAFFIC
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    PROFILE_TRAFFIC = json.load(open(tpath)) if os.path.exists(tpath) else {}
 
     # ---- resident inputs: every rank holds every finished submap -------------
     t_setup = time.perf_counter()
@@ -757,6 +857,27 @@ def main():
         dist.all_reduce(wc_tot, op=dist.ReduceOp.SUM)
     with_corr_total = float(wc_tot.item())
 
+    # ---- parity gate, config 3: rows of the LAST TIMED PASS (still in the output buffers) ----
+    parity_entries = []
+
+    def layers_of_config3(k):
+        sm = capi.Submap.synth_city(ctx, k, args.voxel_size, 16, args.block_min, args.block_dims,
+                                    args.truncation, args.esdf_max, 10.0, true_poses[k], args.seed)
+        td, tw, ed, eo = sm.download_layers(16)
+        bi = sm.block_index()
+        sm.destroy()
+        return bi, td, tw, ed, eo
+    if rank == 0 and not args.no_parity:
+        from harness import parity_gate
+        t_par = time.perf_counter()
+        live_each = batch.count_live_each(poses)
+        chosen = parity_gate.choose(np.diff(batch.row_offsets()), live_each, n_total=8, n_partial=3, n_dead=1)
+        e = parity_gate.check(capi, ctx, torch, "config 3 (rows of the last timed pass)", layers_of_config3, submaps, batch,
+                              pairs[mine], poses, chosen, (residuals, jac_ref, jac_read), args.voxel_size)
+        e["partly_culled_constraints"] = int(sum(1 for c in chosen if 0 < live_each[c] < 0.9 * np.diff(batch.row_offsets())[c]))
+        e["seconds"] = time.perf_counter() - t_par
+        parity_entries.append(e)
+
     # points the materialising kernel reads at these poses: tiles whose chunks all miss the reading
     # submap's block box write zeros without reading (vgx_reg.hip reg_eval_points_body); where the
     # launch order groups the constraints of a reference submap on one XCD they read its points once
@@ -814,9 +935,23 @@ def main():
                   "passes": n_fo, "R": fo["R"], "R_total": float(tot[0].item()), "with_corr": fo_corr,
                   "with_corr_total": float(tot[1].item()), "points": fo_pr}
 
+    if fo and rank == 0 and not args.no_parity:
+        t_par = time.perf_counter()
+        fo["batch"].evaluate_points(fo["poses"], residuals.data_ptr(), jac_ref.data_ptr(), jac_read.data_ptr())
+        torch.cuda.synchronize()
+        n_fo_local = len(mine_fo)
+        chosen = [int(c) for c in np.unique(np.linspace(0, n_fo_local - 1, 4).round().astype(int))]
+        e = parity_gate.check(capi, ctx, torch, "full overlap (one more launch of the timed batch)", layers_of_config3,
+                              submaps, fo["batch"], pairs_fo[mine_fo], fo["poses"], chosen,
+                              (residuals, jac_ref, jac_read), args.voxel_size, submap_of_node=lambda nd: nd % n_sub)
+        e["seconds"] = time.perf_counter() - t_par
+        parity_entries.append(e)
+
     # ---- fused pass + all-reduce (solver-iteration form), reported separately --
-    def fused_bench(bt, ps, n_nodes, n_global, corr_total, evals_total, ref_cost):
+    def fused_bench(bt, ps, n_nodes, n_global, corr_total, evals_total, ref_cost, traffic_key):
         size = capi.fused_size(n_nodes, n_global)
+        tr = (PROFILE_TRAFFIC.get("fused") or {}).get(traffic_key) or {}
+        tr_bytes = tr.get("hbm_bytes_per_launch") if (tr.get("evaluations") == evals_total and world == 1) else None
         buf = torch.zeros(size, dtype=torch.float64, device="cuda")
 
         def fused_step():
@@ -865,7 +1000,12 @@ def main():
                           "per_evaluation_pricing re-counts a point for every constraint that reads it (52 / 20 / 0 B) "
                           "and can exceed the HBM peak where constraints share points through the L2",
                "algorithmic_GBs": alg_bytes * n_f / fdt / 1e9,
-               "frac_of_hbm_peak": alg_bytes * n_f / fdt / 1e9 / HBM_PEAK_GBS,
+               # NOT an HBM fraction: algorithmic bytes include neighbour bytes the L2 / MALL serve
+               "algorithmic_over_hbm_peak": alg_bytes * n_f / fdt / 1e9 / HBM_PEAK_GBS,
+               # counter bytes (profiles/hbm_traffic.json, a separate rocprofv3 --pmc run of this workload)
+               # / this run's time / 8 TB/s: the HBM fraction proper
+               "traffic_from_profiles": tr_bytes,
+               "hbm_frac": (tr_bytes / (f_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr_bytes else None,
                "value_with_correspondence": corr_total * n_f / fdt / 1e6,
                "allreduce_bytes": int(size * 8) if use_dist else 0,
                "cost": float(buf[0].item()), "cost_vs_materialised": None}
@@ -876,11 +1016,11 @@ def main():
     fused = None
     fused_fo = None
     if not args.no_fused:
-        fused = fused_bench(batch, poses, n_sub, n_con, with_corr_total, total_evals, checksum)
+        fused = fused_bench(batch, poses, n_sub, n_con, with_corr_total, total_evals, checksum, "config3")
         if fo:
             fo_cost = float(residuals[:fo["R"]].double().pow(2).sum().item()) if world == 1 else None
             fused_fo = fused_bench(fo["batch"], fo["poses"], len(fo["poses"]), fo["n"],
-                                   fo_out["with_corr_total"], fo_out["R_total"], fo_cost)
+                                   fo_out["with_corr_total"], fo_out["R_total"], fo_cost, "full_overlap")
 
     # ---- the reference's SHIPPED configuration (voxgraph_mapper.yaml:34-35): explicit_to_implicit =
     # isosurface points, sampling_ratio 0.05, both directions of every pair (pose_graph.cpp:62-71),
@@ -907,9 +1047,11 @@ def main():
         torch.cuda.synchronize()
         barrier()
         n_s = max(args.steps, 1)
+        ctx.timer_start()
         s0 = time.perf_counter()
         for _ in range(n_s):
             shipped_step()
+        shipped_stream_ms = ctx.timer_stop() / n_s
         torch.cuda.synchronize()
         barrier()
         sdt = torch.tensor([time.perf_counter() - s0], dtype=torch.float64, device="cuda")
@@ -922,10 +1064,19 @@ def main():
                    "constraints": 2 * n_con, "residuals_per_evaluation": float(rs.item()),
                    "isosurface_points_per_submap": float(np.mean(n_iso)),
                    "ms_per_evaluation": float(sdt.item()) / n_s * 1e3,
+                   "stream_ms_per_evaluation": shipped_stream_ms,
                    "Mresiduals_per_s": float(rs.item()) * n_s / float(sdt.item()) / 1e6,
                    "cost": float(buf_s[0].item()),
                    "what": "one solver evaluation: device mt19937 streams + fused normal equations of every "
                            "constraint + assembly" + (" + RCCL all-reduce" if use_dist else "")}
+        tr = (PROFILE_TRAFFIC.get("fused") or {}).get("shipped") or {}
+        tr_bytes = tr.get("hbm_bytes_per_launch") if (tr.get("evaluations") == shipped["residuals_per_evaluation"]
+                                                     and world == 1) else None
+        shipped["traffic_from_profiles"] = tr_bytes
+        shipped["fused_kernel_ms_from_profiles"] = tr.get("avg_ms_rocprof") if tr_bytes else None
+        shipped["hbm_frac"] = (tr_bytes / (tr["avg_ms_rocprof"] * 1e-3) / 1e9 / HBM_PEAK_GBS) \
+            if (tr_bytes and tr.get("avg_ms_rocprof")) else None
+        shipped["hbm_frac_note"] = "fused kernel alone: counter bytes / its rocprofv3 average duration / 8 TB/s (profiles/)"
         for o in [batch_s] + cfs_s:
             o.destroy()
 
@@ -1005,6 +1156,8 @@ def main():
             if use_dist:
                 dist.all_reduce(sdt, op=dist.ReduceOp.MAX)
             return {"ms": float(sdt.item()) * 1e3, "iterations": summ["iterations"],
+                    "gpu_evaluation_ms": summ["backend_seconds"] * 1e3,
+                    "host_linear_algebra_ms": summ["host_linear_algebra_seconds"] * 1e3,
                     "evaluations": summ["evaluations"], "termination": summ["termination"],
                     "initial_cost": summ["initial_cost"], "final_cost": summ["final_cost"],
                     "position_rmse_m_before": rmse(poses), "position_rmse_m_after": rmse(x)}
@@ -1017,6 +1170,9 @@ def main():
         solve["reference_stop_rule"] = timed_solve(parameter_tolerance=3e-3)
         solve["reference_stop_rule"]["stop_rule"] = "parameter_tolerance 3e-3 relative to |x| (pose_graph.cpp:93)"
         solve["solver"] = "harness/lm.py (LM, banded Cholesky on the host; Ceres absent)"
+        solve["split"] = ("gpu_evaluation_ms = time inside the registration backend (fused pass, assembly, copy of "
+                          "the fused buffer, all-reduce): the product; host_linear_algebra_ms = the harness' own "
+                          "assembly + banded Cholesky, which Ceres does in the real system")
 
     out = None
     if rank == 0:
@@ -1033,9 +1189,8 @@ def main():
         bytes_conservative = R * BYTES_OUT + pr["read"] * BYTES_POINT + with_corr * BYTES_NEIGHBOURS
         achieved = bytes_conservative / (kernel_ms * 1e-3) / 1e9
         traffic = traffic_fo = traffic_fo_plain = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            t = json.load(open(tpath))
+        if PROFILE_TRAFFIC:
+            t = PROFILE_TRAFFIC
             # same workload (per-launch residual count) as the PMC passes were taken on
             if t.get("residuals_per_launch") == R and t.get("n_gpus") == world:
                 traffic = t.get("hbm_bytes_per_launch")
@@ -1072,6 +1227,18 @@ def main():
             "ms_per_pass": dt / passes * 1e3,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         # `traffic` is REPLAYED from profiles/hbm_traffic.json (rocprofv3 --pmc passes of this
+                         # same workload, collected by profiles/collect.sh), not measured in this run
+                         "traffic_from_profiles": traffic,
+                         "traffic_source": PROFILE_TRAFFIC.get("source") if traffic else None,
+                         "hbm_frac": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "hbm_frac_note": "counter bytes / this run's kernel time / 8 TB/s",
+                         # SURVEY.md 8(d)'s literal pricing, 88 B x every evaluation: NOT an HBM fraction here
+                         # (exceeds 1): most evaluations of this workload find no reading block (20 B + 36 B) and
+                         # culled tiles are written without being read (36 B) -- `frac` prices those as such;
+                         # roofline_full_overlap.plain_order is the workload the 88 B figure describes
+                         "contract_88B_frac": bytes_contract / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "contract_88B_frac_note": "not an HBM fraction: prices bytes this launch does not move",
                          "kernel": "reg_eval_points_kernel<16,float,4>",
                          "kernel_ms": kernel_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
                          "bytes_per_unit": BYTES_PER_EVAL, "bytes_per_unit_without_correspondence": BYTES_NO_CORR,
@@ -1108,7 +1275,8 @@ def main():
                          "bytes_per_unit": BYTES_PER_EVAL,
                          "achieved": fo_out["R"] * BYTES_PER_EVAL / pk / 1e9,
                          "frac": fo_out["R"] * BYTES_PER_EVAL / pk / 1e9 / HBM_PEAK_GBS,
-                         "traffic": traffic_fo_plain,
+                         "traffic": traffic_fo_plain, "traffic_from_profiles": traffic_fo_plain,
+                         "hbm_frac": (traffic_fo_plain / pk / 1e9 / HBM_PEAK_GBS) if traffic_fo_plain else None,
                          "traffic_GBs": (traffic_fo_plain / pk / 1e9) if traffic_fo_plain else None}
             out["roofline_full_overlap"] = {
                 "workload": f"the same {n_sub} submaps, each registered against {args.overlap_copies} duplicates of "
@@ -1123,6 +1291,10 @@ def main():
                            "are fetched once per group) + 32 B per interpolating evaluation",
                 "achieved": fo_bytes / fk / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": fo_bytes / fk / 1e9 / HBM_PEAK_GBS,
+                "frac_note": "algorithmic bytes / time / 8 TB/s; part of the neighbour bytes is served by the L2: "
+                             "hbm_frac is the HBM fraction proper",
+                "traffic_from_profiles": traffic_fo,
+                "hbm_frac": (traffic_fo / fk / 1e9 / HBM_PEAK_GBS) if traffic_fo else None,
                 # the contract's per-evaluation pricing re-counts a point for every constraint that reads it
                 # and can exceed the HBM peak where the L2 serves the repeats; plain_order is where it applies
                 "per_evaluation_pricing_GBs": fo_out["R"] * BYTES_PER_EVAL / fk / 1e9,
@@ -1165,6 +1337,8 @@ def main():
         c5 = config5_bench(capi, ctx, torch, dist, use_dist, rank, world, args)
         if rank == 0:
             out["config5"] = c5
+            if c5.get("parity"):
+                parity_entries.append(c5["parity"])
     if rank == 0 and world == 1 and not args.no_config2:
         from harness import pipeline
         # 30 submaps, 10 Hz, 10 s per submap = 100 scans per submap; the
@@ -1175,6 +1349,9 @@ def main():
         out["pipeline_config2"]["cut"] = "full: 30 submaps x 100 scans" if full else \
             "bounded: 10 submaps x 30 scans of the 30 x 100 session (python bench.py --pipeline runs all of it)"
     if rank == 0:
+        if not args.no_parity:
+            from harness import parity_gate
+            out["parity"] = parity_gate.merge(parity_entries)
         print(json.dumps(out))
     if use_dist:
         dist.barrier()

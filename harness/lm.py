@@ -103,6 +103,7 @@ class Problem:
             free[4 * k:4 * k + 4] = False
         self.free = np.where(free)[0]
         self.evaluations = 0
+        self.backend_seconds = 0.0      # time inside backend(poses): the product's part of a solve
         n = n_nodes
         pa = np.array([p[0] for p in self.pairs], np.int64).reshape(-1)
         pb = np.array([p[1] for p in self.pairs], np.int64).reshape(-1)
@@ -178,7 +179,9 @@ class Problem:
         """-> (0.5 sum r^2, g_f [nf], (ab [u+1, nf] upper banded J^T J, coo values))"""
         if not hasattr(self, "_nf"):
             self._prepare_reduced(poses)
+        tb = time.perf_counter()
         buf = np.asarray(self.backend(poses))
+        self.backend_seconds += time.perf_counter() - tb
         self.evaluations += 1
         n, m = self.n, len(self.pairs)
         cost = float(buf[0])
@@ -249,7 +252,9 @@ class Problem:
 
     def evaluate(self, poses):
         """0.5 * sum r^2, gradient J^T r, Gauss-Newton Hessian J^T J (registration + edges)."""
+        tb = time.perf_counter()
         buf = np.asarray(self.backend(poses))
+        self.backend_seconds += time.perf_counter() - tb
         self.evaluations += 1
         n = self.n
         cost = float(buf[0])
@@ -350,7 +355,12 @@ def _solve(problem, poses0, parameter_tolerance, function_tolerance, gradient_to
             break
     return x, {"iterations": it, "evaluations": problem.evaluations, "termination": reason,
                "final_cost": cost, "initial_cost": history[0],
-               "seconds": time.perf_counter() - t0}
+               "seconds": time.perf_counter() - t0,
+               # instrumentation only: what the registration backend took -- kernels,
+               # copy of the fused buffer, all-reduce -- and what this harness' own assembly + banded
+               # Cholesky took (Ceres does that part in the real system)
+               "backend_seconds": problem.backend_seconds,
+               "host_linear_algebra_seconds": time.perf_counter() - t0 - problem.backend_seconds}
 
 
 def zero_registration_backend(n_nodes, n_constraints):

@@ -13,8 +13,37 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
 
 
+_NATIVE = False
+
+
+def use_native_build():
+    """bench.py's cpu_baseline: BASELINE.md promises the CPU port built `-O3 -march=native`.  Such a
+    library only runs on the host it was built on, so it is (re)built HERE, now, into
+    _build/liboracle_native.so (oracle/Makefile `native`: same sources, same -ffp-contract=off
+    -fno-fast-math, so the same IEEE results) and loaded instead of the portable -O2 build the tests
+    use.  Must be called before the first use of the library; returns False (and keeps the portable
+    build) if the compile fails."""
+    global _LIB_PATH, _NATIVE
+    if _lib is not None:
+        return _NATIVE
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "native"])
+        path = os.path.join(_HERE, "_build", "liboracle_native.so")
+        C.CDLL(path)
+        _LIB_PATH, _NATIVE = path, True
+    except Exception:
+        _NATIVE = False
+    return _NATIVE
+
+
+def build_flags():
+    return "gcc -O3 -march=native, built on this host" if _NATIVE else "gcc -O2, portable build"
+
+
 def build(force=False):
     """Compile the oracle with gcc (oracle/Makefile)."""
+    if _NATIVE:
+        return _LIB_PATH
     if force or not os.path.exists(_LIB_PATH) or _stale():
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _LIB_PATH

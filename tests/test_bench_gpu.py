@@ -55,7 +55,17 @@ def test_single_gpu_line_has_the_contract_fields(single):
         assert 0 < f["algorithmic_GBs"] <= d["roofline"]["peak"]
         assert f["with_correspondence"] <= f["loaded_after_culling"] <= f["evaluations"]
         assert 0 < f["distinct_points_loaded"] <= f["loaded_after_culling"]
-    assert d["config"]["passes_per_step"] == 10 and d["value_with_correspondence"] <= d["value"]
+    assert d["config"]["passes_per_step"] == 25 and d["value_with_correspondence"] <= d["value"]
+    # same-run parity gate: a sample of the timed launches' constraints against the reference source
+    # (exact) and the fused blocks against the oracle (1e-6)
+    par = d["parity"]
+    assert par["checked"] > 0 and par["exact"] and par["max_rel"] == 0.0 and par["fused_blocks_within_1e-6"], par
+    assert len(par["per_workload"]) == 3
+    # every "*frac*" is an HBM fraction <= 1 or says what else it is
+    assert d["roofline"]["contract_88B_frac"] > 0 and "not an HBM fraction" in d["roofline"]["contract_88B_frac_note"]
+    assert "algorithmic_over_hbm_peak" in d["fused"] and "frac_of_hbm_peak" not in d["fused"]
+    assert d["solve"]["gpu_evaluation_ms"] > 0 and d["solve"]["host_linear_algebra_ms"] > 0
+    assert d["solve"]["gpu_evaluation_ms"] + d["solve"]["host_linear_algebra_ms"] <= 1.05 * d["solve"]["ms"]
     # the shipped yaml's configuration (sampled, mirrored isosurface constraints) in one batched pass
     assert d["shipped_config"]["constraints"] == 2 * d["config"]["constraints"]
     assert d["shipped_config"]["ms_per_evaluation"] > 0 and d["shipped_config"]["cost"] > 0
