@@ -387,9 +387,10 @@ def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=2):
                                                                 "heads, rays)"},
                                            "voxel_updates_per_scan": merged_updates, "dropped_updates": merged_dropped,
                                            "Mvoxel_updates_per_s": merged_updates / merged_ms / 1e3,
-                                           "note": "vgx_tsdf_integrate_merged_device: key + stable radix sort + group "
-                                                   "heads + one full ray per end voxel (no early-out), surface then "
-                                                   "clearing groups"},
+                                           "note": "vgx_tsdf_integrate_merged_device: key + stable radix sort + group heads + "
+                                                   "cooperative merge, then every ray written out, sorted by voxel and applied "
+                                                   "voxel by voxel in group order (no early-out: the voxels next to the sensor "
+                                                   "take one update per group, a sequential f32 chain)"},
                      "reproducible_mode": {"ms_per_scan": det_ms, "Mpoints_per_s": n_pts / det_ms / 1e3,
                                            "voxel_updates_per_scan": det_updates,
                                            "over_racing_kernel": det_ms / (ms / timed),

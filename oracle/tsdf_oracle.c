@@ -510,7 +510,7 @@ int64_t orc_tsdf_merged_integrate(orc_tsdf_integrator* I, const float T_G_C[7], 
     if (merged_weight == 0.0f) continue; /* every update would leave its voxel unchanged */
     float point_G[3];
     transform_point(T_G_C, merged_point_C, point_G);
-    /* RayCaster(origin, merged_point_G, clearing_ray, carving, max_ray, voxel_size_inv, trunc, false) */
+    /* RayCaster(origin, merged_point_G, clearing_ray, carving, max_ray, voxel_size_inv, trunc) */
     float d[3] = {point_G[0] - origin[0], point_G[1] - origin[1], point_G[2] - origin[2]};
     float len = norm3(d);
     float unit_ray[3] = {d[0] / len, d[1] / len, d[2] / len};
@@ -530,9 +530,12 @@ int64_t orc_tsdf_merged_integrate(orc_tsdf_integrator* I, const float T_G_C[7], 
     }
     float start_scaled[3], end_scaled[3];
     int bad = 0;
+    /* cast_from_origin == true (the RayCaster default, which MergedTsdfIntegrator::integrateVoxel
+     * leaves alone; only the fast integrator passes false): setupRayCaster(start_scaled, end_scaled),
+     * the walk runs from the sensor outwards */
     for (int a = 0; a < 3; ++a) {
-      start_scaled[a] = ray_end[a] * vsi;
-      end_scaled[a] = ray_start[a] * vsi;
+      start_scaled[a] = ray_start[a] * vsi;
+      end_scaled[a] = ray_end[a] * vsi;
       if (isnan(start_scaled[a]) || isnan(end_scaled[a])) bad = 1;
     }
     if (bad) continue;

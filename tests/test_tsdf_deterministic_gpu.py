@@ -231,3 +231,61 @@ def test_layer_grows_under_the_reproducible_mode(capi, ctx):
     _assert_layers_identical(ol, gl2, "racing mode, single rays")
     for o in (g_det, g_race, gl, gl2):
         o.destroy()
+
+
+@pytest.mark.parametrize("const_weight,anti_grazing", [(1, 0), (0, 0), (1, 1)])
+def test_merged_integrator_reproducible_mode_bit_for_bit(capi, ctx, const_weight, anti_grazing):
+    """voxblox::MergedTsdfIntegrator in the reproducible mode: groups in key order, every voxel takes its
+    updates in group order (surface groups, then clearing groups) -- the single thread's order, which is
+    the order oracle/tsdf_oracle.c walks.  Dense scans with clearing returns, colours, drop-off, with and
+    without anti-grazing: block order, distances, weights and colours equal the oracle's exactly (the
+    racing mode reaches 60-97 % identical distances on these scans, tests/test_tsdf_merged_gpu.py)."""
+    vs, vps = 0.1, 16
+    kw = dict(default_truncation_distance=0.3, max_ray_length_m=6.0, use_const_weight=const_weight,
+              use_weight_dropoff=1, enable_anti_grazing=anti_grazing)
+    ol, gl = orc.TsdfLayer(vs, vps), capi.TsdfLayer(ctx, vs, vps)
+    oi = orc.FastTsdfIntegrator(orc.tsdf_config(**kw), ol)
+    gi = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(deterministic=1, **kw), gl)
+    rng = np.random.default_rng(21)
+    for k in range(3):
+        pts = _lidar_scan(360, 48, 40 + k, room=((-4.0, -3.0, -1.0), (4.0, 3.0, 2.0)),
+                          origin=np.array([0.3 * k, -0.2 * k, 0.05]))
+        pts[::37] *= 4.0                                # returns beyond the maximum range: clearing rays
+        pts[5::41] *= 0.01                              # below the minimum range: dropped
+        cols = rng.integers(0, 255, (len(pts), 4)).astype(np.uint8)
+        T = np.array([np.cos(0.1 * k), 0, 0, np.sin(0.1 * k), 0.3 * k, -0.2 * k, 0.05], F)
+        n_o = oi.integratePointCloudMerged(T, pts, cols)
+        n_g = gi.integratePointCloudMerged(T, pts, cols)
+        assert n_o == n_g > 20000, (k, n_o, n_g)
+        nb, nobs = _assert_layers_identical(ol, gl, f"merged scan {k}")
+    assert gl.stats()[1] == 0 and nobs > 50000
+    for o in (gi, gl):
+        o.destroy()
+
+
+def test_merged_integrator_reproducible_mode_fullsize(capi, ctx):
+    """the two BASELINE sensor shapes through the merged integrator, reproducible mode: one 64 x 1024 LiDAR
+    sweep with the shipped yaml and one 640 x 480 depth image at 0.05 m, each on top of a previous scan"""
+    for kind in ("lidar", "rgbd"):
+        if kind == "lidar":
+            vs, ocfg, gcfg = 0.2, orc.voxgraph_tsdf_config(), capi.voxgraph_tsdf_config(deterministic=1)
+        else:
+            vs = 0.05
+            kw = dict(default_truncation_distance=0.15, max_ray_length_m=5.0)
+            ocfg, gcfg = orc.tsdf_config(**kw), capi.tsdf_config(deterministic=1, **kw)
+        ol, gl = orc.TsdfLayer(vs, 16), capi.TsdfLayer(ctx, vs, 16)
+        oi, gi = orc.FastTsdfIntegrator(ocfg, ol), capi.FastTsdfIntegrator(ctx, gcfg, gl)
+        for k in range(2):
+            if kind == "lidar":
+                origin = np.array([0.4 * k, -0.2 * k, 0.0], F)
+                pts = _lidar_scan(1024, 64, 60 + k, origin=origin.astype(np.float64))
+            else:
+                pts, origin = _rgbd_scan(k)
+            T = np.r_[np.array([1, 0, 0, 0], F), origin].astype(F)
+            a = oi.integratePointCloudMerged(T, pts)
+            b = gi.integratePointCloudMerged(T, pts)
+            assert a == b > 0, (kind, k, a, b)
+            nb, nobs = _assert_layers_identical(ol, gl, f"merged {kind} scan {k}")
+        print("merged", kind, "updates per scan", a, "blocks", nb, "observed voxels", nobs)
+        for o in (gi, gl):
+            o.destroy()

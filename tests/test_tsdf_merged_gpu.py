@@ -1,11 +1,14 @@
 """voxblox::MergedTsdfIntegrator on the device (vgx_tsdf_integrate_merged) against its CPU restatement
 (oracle/tsdf_oracle.c orc_tsdf_merged_integrate; voxblox is not vendored: PARITY UNPINNED).
 
-Unlike the fast integrator, the merged one has no approximate sets and no early-out, so WHICH voxels
-are updated and with WHAT merged point and weight is deterministic; only the order in which different
-rays' updates land on a shared voxel differs between runs and implementations (a weighted running
-average: the same in exact arithmetic, last bits in f32).  So: voxel sets, update counts and integer
-weights exact; distances to f32 rounding; bit-exact where no voxel is shared."""
+The merged integrator has no approximate sets and no early-out, so WHICH voxels are updated and with
+WHAT merged point and weight is deterministic; what could differ is the order in which different rays'
+updates land on a shared voxel (a running average clamped after every update).  The device applies
+every voxel's updates in group order -- surface groups in key order, then clearing groups: the order
+the oracle's single thread walks -- in BOTH modes (round 3: thousands of rays contending for one
+compare-and-swap on the voxels next to the sensor cost 30 ms per RGB-D scan), so distances, weights and
+colours equal the oracle's bit for bit; vgx_tsdf_config.deterministic additionally fixes the order
+blocks are allocated in (tests/test_tsdf_deterministic_gpu.py compares the block lists too)."""
 import numpy as np
 import pytest
 
@@ -77,17 +80,10 @@ def test_merged_scans_against_the_oracle(capi, ctx, const_weight, anti_grazing):
     B = _as_dict(*gl.download(), vps)
     assert A.keys() == B.keys() and len(A) > 50000
     assert gl.stats()[1] == 0
-    dw = max(abs(A[k][1] - B[k][1]) / max(A[k][1], 1e-9) for k in A)
-    dd = np.array([abs(A[k][0] - B[k][0]) for k in A])
-    exact = float((dd == 0).mean())
-    print(f"merged GPU vs oracle: {len(A)} voxels, weights rel {dw:.1e}, distance exact {exact:.3f}, "
-          f"p99 {np.percentile(dd, 99):.2e}, max {dd.max():.3f}")
-    # weights add up the same in any order (to f32 rounding: the drop-off makes them non-integer)
-    assert dw <= 2e-6, dw
-    # distances: a voxel several rays update is a running average CLAMPED to +-truncation after every
-    # update, so its value depends on the order the rays arrive in (voxblox's own threads race the same
-    # way): identical wherever one ray or same-sign updates meet, a few cm apart in the mixed voxels
-    assert exact > 0.6 and np.percentile(dd, 90) < 1e-5 and dd.max() < kw["default_truncation_distance"]
+    bad = [k for k in A if A[k] != B[k]]
+    print(f"merged GPU vs oracle: {len(A)} voxels, {len(bad)} differ")
+    # every voxel: distance, weight and colour bit for bit (updates applied in the oracle's order)
+    assert not bad, (len(bad), bad[:3], [A[k] for k in bad[:3]], [B[k] for k in bad[:3]])
     for o in (gi, gl):
         o.destroy()
 

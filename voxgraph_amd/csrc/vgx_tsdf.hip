@@ -397,160 +397,123 @@ __global__ __launch_bounds__(256) void merged_bundle_kernel(vgx_tsdf_config c, f
   const float ccx = qy * uvz - qz * uvy, ccy = qz * uvx - qx * uvz, ccz = qx * uvy - qy * uvx;
   const float gx = (px + qw * uvx + ccx) + tx, gy = (py + qw * uvy + ccy) + ty, gz = (pz + qw * uvz + ccz) + tz;
   const int vx = (int)floorf(gx * vsi + 1e-6f), vy = (int)floorf(gy * vsi + 1e-6f), vz = (int)floorf(gz * vsi + 1e-6f);
-  const bool in_range = vx > -kMergedBias && vx < kMergedBias && vy > -kMergedBias && vy < kMergedBias &&
-                        vz > -kMergedBias && vz < kMergedBias;
+  // (strictly inside: the all-ones key is the invalid marker)
+  const bool in_range = vx > -kMergedBias && vx < kMergedBias - 1 && vy > -kMergedBias && vy < kMergedBias - 1 &&
+                        vz > -kMergedBias && vz < kMergedBias - 1;
   keys[seq] = (valid && in_range) ? merged_key(vx, vy, vz, is_clearing) : kMergedInvalid;
   idx[seq] = (unsigned int)pi;
 }
 
-// counters[0] = number of groups, counters[1] = number of surface (non-clearing) entries
+// After the sort: group heads.  The heads are ranked by a prefix sum (group g = the g-th distinct key, so
+// groups are numbered in key order: surface groups first, then clearing groups -- the order the
+// reference's single thread walks its two voxel maps in, oracle/tsdf_oracle.c), and
+//   counters[0] = number of groups            counters[1] = number of surface (non-clearing) entries
+//   counters[2] = number of surface groups    counters[3] = number of valid entries
+struct MergedHeadOp {
+  const unsigned long long* keys;
+  __host__ __device__ unsigned int operator()(unsigned int i) const {
+    const unsigned long long k = keys[i];
+    return (k != kMergedInvalid && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
+  }
+};
+
 __global__ __launch_bounds__(256) void merged_heads_kernel(const unsigned long long* __restrict__ keys, long long n,
+                                                          const unsigned int* __restrict__ rank,
                                                           unsigned int* __restrict__ group_start,
                                                           unsigned int* __restrict__ counters) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const unsigned long long k = keys[i];
-  if (k == kMergedInvalid) return;
-  if (!(k >> 63)) atomicMax(&counters[1], (unsigned int)(i + 1));
-  if (i == 0 || keys[i - 1] != k) group_start[atomicAdd(&counters[0], 1u)] = (unsigned int)i;
+  const bool valid = k != kMergedInvalid;
+  const bool head = valid && (i == 0 || keys[i - 1] != k);
+  if (head) group_start[rank[i]] = (unsigned int)i;
+  const bool next_valid = i + 1 < n && keys[i + 1] != kMergedInvalid;
+  if (valid && !next_valid) {  // the last valid entry
+    counters[0] = rank[i] + (head ? 1u : 0u);
+    counters[3] = (unsigned int)(i + 1);
+  }
+  if (valid && !(k >> 63)) {
+    const bool next_surface = next_valid && !(keys[i + 1] >> 63);
+    if (!next_surface) {  // the last surface entry
+      counters[1] = (unsigned int)(i + 1);
+      counters[2] = rank[i] + (head ? 1u : 0u);
+    }
+  }
 }
 
-__global__ __launch_bounds__(256) void merged_integrate_kernel(TsdfLayerDev L, TsdfIntegratorDev I, float qw, float qx,
-                                                              float qy, float qz, float tx, float ty, float tz,
-                                                              const float* __restrict__ points_C,
-                                                              const uint32_t* __restrict__ rgba,
-                                                              const unsigned long long* __restrict__ keys,
-                                                              const unsigned int* __restrict__ idx, long long n,
-                                                              const unsigned int* __restrict__ group_start,
-                                                              const unsigned int* __restrict__ counters, int pass,
-                                                              int anti_grazing) {
-  const vgx_tsdf_config& c = I.cfg;
-  const unsigned int g = blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned long long my_updates = 0, my_dropped = 0;
-  if (g < counters[0]) {
-    const long long i0 = group_start[g];
-    const unsigned long long key = keys[i0];
-    const bool clearing_ray = (key >> 63) != 0;
-    if ((int)clearing_ray == pass) {
-      // integrateVoxel: running weighted mean in visiting order
-      float mx = 0.0f, my = 0.0f, mz = 0.0f, mw = 0.0f;
-      uint32_t mcol = 0u;
-      for (long long i = i0; i < n && keys[i] == key; ++i) {
-        const long long pi = idx[i];
-        const float px = points_C[3 * pi], py = points_C[3 * pi + 1], pz = points_C[3 * pi + 2];
-        float pw = 1.0f;
-        if (!c.use_const_weight) {
+enum { kGroupValid = 1u, kGroupClearing = 2u };
+
+// integrateVoxel's merge: L lanes per group load L of its points at a time; the running weighted mean
+// is order dependent in f32, so the chain itself runs in the reference's visiting order (the stable
+// sort kept it inside a group), fed by lane broadcasts.  Also the group's complete ray length.
+template <int L>
+__global__ __launch_bounds__(256) void merged_merge_kernel(vgx_tsdf_config c, float vsi, float qw, float qx, float qy,
+                                                          float qz, float tx, float ty, float tz,
+                                                          const float* __restrict__ points_C,
+                                                          const uint32_t* __restrict__ rgba,
+                                                          const unsigned long long* __restrict__ keys,
+                                                          const unsigned int* __restrict__ idx,
+                                                          const unsigned int* __restrict__ group_start,
+                                                          const unsigned int* __restrict__ counters,
+                                                          float4* __restrict__ g_pg, uint32_t* __restrict__ g_color,
+                                                          uint32_t* __restrict__ g_flags,
+                                                          uint32_t* __restrict__ g_count) {
+  const int lane = threadIdx.x & (L - 1);
+  const unsigned int n_sub = gridDim.x * (blockDim.x / L);
+  const unsigned int G = counters[0], n_valid = counters[3];
+  for (unsigned int g = blockIdx.x * (blockDim.x / L) + threadIdx.x / L; g < G; g += n_sub) {
+    const unsigned int i0 = group_start[g], i1 = g + 1 < G ? group_start[g + 1] : n_valid;
+    const bool clearing_ray = (keys[i0] >> 63) != 0;
+    float mx = 0.0f, my = 0.0f, mz = 0.0f, mw = 0.0f;
+    uint32_t mcol = 0u;
+    bool done = false;
+    for (unsigned int b = i0; b < i1 && !done; b += L) {
+      float px = 0.0f, py = 0.0f, pz = 0.0f, pw = 0.0f;
+      uint32_t pc = 0u;
+      if (b + lane < i1) {
+        const unsigned int pi = idx[b + lane];
+        px = points_C[3 * (size_t)pi]; py = points_C[3 * (size_t)pi + 1]; pz = points_C[3 * (size_t)pi + 2];
+        pc = rgba ? rgba[pi] : 0u;
+        pw = 1.0f;
+        if (!c.use_const_weight) {  // getVoxelWeight
           const float dist_z = fabsf(pz);
           pw = dist_z > 1e-6f ? 1.0f / (dist_z * dist_z) : 0.0f;
         }
-        if (pw < 1e-6f) continue;  // kEpsilon
-        const float total = mw + pw;
-        mx = (mx * mw + px * pw) / total;
-        my = (my * mw + py * pw) / total;
-        mz = (mz * mw + pz * pw) / total;
-        mcol = blended_color(mcol, rgba ? rgba[pi] : 0u, mw, pw);
-        mw += pw;
-        if (clearing_ray) break;  // only the first point of a clearing group
       }
-      if (mw != 0.0f) {
-        float uvx = qy * mz - qz * my, uvy = qz * mx - qx * mz, uvz = qx * my - qy * mx;
-        uvx += uvx; uvy += uvy; uvz += uvz;
-        const float ccx = qy * uvz - qz * uvy, ccy = qz * uvx - qx * uvz, ccz = qx * uvy - qy * uvx;
-        const float gx = (mx + qw * uvx + ccx) + tx, gy = (my + qw * uvy + ccy) + ty, gz = (mz + qw * uvz + ccz) + tz;
-        const float vsi = L.voxel_size_inv;
-        // RayCaster(origin, merged_point_G, clearing_ray, carving, max_ray, vsi, trunc, cast_from_origin = false)
-        const float dx = gx - tx, dy = gy - ty, dz = gz - tz;
-        const float len = norm3(dx, dy, dz);
-        const float ux = dx / len, uy = dy / len, uz = dz / len;
-        const float trunc = c.default_truncation_distance;
-        float sxx, syy, szz, exx, eyy, ezz;
-        if (clearing_ray) {
-          const float ray_length = fminf(fmaxf(len - trunc, 0.0f), c.max_ray_length_m);
-          exx = tx + ux * ray_length; eyy = ty + uy * ray_length; ezz = tz + uz * ray_length;
-          sxx = c.voxel_carving_enabled ? tx : exx;
-          syy = c.voxel_carving_enabled ? ty : eyy;
-          szz = c.voxel_carving_enabled ? tz : ezz;
-        } else {
-          exx = gx + ux * trunc; eyy = gy + uy * trunc; ezz = gz + uz * trunc;
-          sxx = c.voxel_carving_enabled ? tx : (gx - ux * trunc);
-          syy = c.voxel_carving_enabled ? ty : (gy - uy * trunc);
-          szz = c.voxel_carving_enabled ? tz : (gz - uz * trunc);
-        }
-        const float ss[3] = {exx * vsi, eyy * vsi, ezz * vsi};
-        const float es[3] = {sxx * vsi, syy * vsi, szz * vsi};
-        bool bad = false;
-        int curr[3], sign[3];
-        float t_next[3], t_step[3];
-        long long steps = 0;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          bad |= (ss[a] != ss[a]) | (es[a] != es[a]);
-          curr[a] = (int)floorf(ss[a] + 1e-6f);
-          const int end_index = (int)floorf(es[a] + 1e-6f);
-          const int diff = end_index - curr[a];
-          steps += diff < 0 ? -diff : diff;
-          const float ray_scaled = es[a] - ss[a];
-          sign[a] = signum(ray_scaled);
-          const float corrected = (float)(sign[a] > 0 ? sign[a] : 0);
-          const float dist_b = corrected - (ss[a] - (float)curr[a]);
-          if (ray_scaled == 0.0f) {
-            t_next[a] = INFINITY;
-            t_step[a] = INFINITY;
-          } else {
-            t_next[a] = dist_b / ray_scaled;
-            t_step[a] = (float)sign[a] / ray_scaled;
-          }
-        }
-        if (!bad) {
-          const int vps = L.vps, shift = L.vps_shift, mask = vps - 1;
-          const long long n_surface = counters[1];
-          int last_b[3] = {INT32_MIN, INT32_MIN, INT32_MIN}, last_slot = -1;
-          for (long long step = 0; step <= steps; ++step) {
-            const int vx = curr[0], vy = curr[1], vz = curr[2];
-            int m = 0;
-            if (t_next[1] < t_next[m]) m = 1;
-            if (t_next[2] < t_next[m]) m = 2;
-            curr[0] += m == 0 ? sign[0] : 0; curr[1] += m == 1 ? sign[1] : 0; curr[2] += m == 2 ? sign[2] : 0;
-            t_next[0] += m == 0 ? t_step[0] : 0.0f; t_next[1] += m == 1 ? t_step[1] : 0.0f;
-            t_next[2] += m == 2 ? t_step[2] : 0.0f;
-            if (anti_grazing) {
-              // skip voxels that are the end voxel of another surface group (voxel_map.find)
-              const unsigned long long k = merged_key(vx, vy, vz, false);
-              if (clearing_ray || k != key) {
-                long long lo = 0, hi = n_surface;
-                while (lo < hi) {
-                  const long long mid = (lo + hi) >> 1;
-                  if (keys[mid] < k) lo = mid + 1; else hi = mid;
-                }
-                if (lo < n_surface && keys[lo] == k) continue;
-              }
-            }
-            const int bx = vx >> shift, by = vy >> shift, bz = vz >> shift;
-            if (bx != last_b[0] || by != last_b[1] || bz != last_b[2]) {
-              last_slot = get_or_allocate_block(L, bx, by, bz);
-              last_b[0] = bx; last_b[1] = by; last_b[2] = bz;
-            }
-            if (last_slot < 0) {
-              ++my_dropped;
-              continue;
-            }
-            const size_t at = (size_t)last_slot * ((size_t)vps * vps * vps) +
-                              (size_t)((vx & mask) + vps * ((vy & mask) + vps * (vz & mask)));
-            update_voxel(L, c, at, tx, ty, tz, gx, gy, gz, vx, vy, vz, mcol, mw);
-            ++my_updates;
-          }
+      const int m = (int)min((unsigned int)L, i1 - b);
+      for (int j = 0; j < m; ++j) {
+        const float x = __shfl(px, j, L), y = __shfl(py, j, L), z = __shfl(pz, j, L), w = __shfl(pw, j, L);
+        const uint32_t col = (uint32_t)__shfl((int)pc, j, L);
+        if (w < 1e-6f) continue;  // kEpsilon
+        const float total = mw + w;
+        mx = (mx * mw + x * w) / total;
+        my = (my * mw + y * w) / total;
+        mz = (mz * mw + z * w) / total;
+        mcol = blended_color(mcol, col, mw, w);
+        mw += w;
+        if (clearing_ray) {  // only the first point of a clearing group
+          done = true;
+          break;
         }
       }
     }
-  }
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    my_updates += __shfl_xor(my_updates, off, 64);
-    my_dropped += __shfl_xor(my_dropped, off, 64);
-  }
-  if ((threadIdx.x & 63) == 0) {
-    if (my_updates) atomicAdd(I.n_updates, my_updates);
-    if (my_dropped) atomicAdd(L.dropped, my_dropped);
+    if (lane == 0) {
+      uint32_t flags = clearing_ray ? kGroupClearing : 0u, count = 0u;
+      float gx = 0.0f, gy = 0.0f, gz = 0.0f;
+      if (mw != 0.0f) {  // else every update would leave its voxel unchanged
+        transform_point(qw, qx, qy, qz, tx, ty, tz, mx, my, mz, gx, gy, gz);
+        // RayCaster(origin, merged_point_G, clearing_ray, carving, max_ray, vsi, trunc): cast_from_origin = true
+        const RayDda r = ray_setup(c, vsi, tx, ty, tz, gx, gy, gz, clearing_ray, true);
+        if (!r.bad && r.steps + 1 < (1ll << 24)) {
+          flags |= kGroupValid;
+          count = (uint32_t)(r.steps + 1);
+        }
+      }
+      g_pg[g] = make_float4(gx, gy, gz, mw);
+      g_color[g] = mcol;
+      g_flags[g] = flags;
+      g_count[g] = count;
+    }
   }
 }
 
@@ -1099,7 +1062,8 @@ int vgx_tsdf_integrator_destroy(vgx_tsdf_integrator I) {
   (void)hipSetDevice(I->ctx->device);
   (void)hipStreamSynchronize(I->ctx->stream);
   void* ptrs[] = {I->dev.start_set, I->dev.observed_set, I->dev.n_updates, I->d_points, I->d_rgba,
-                  I->d_mkeys[0], I->d_mkeys[1], I->d_midx[0], I->d_midx[1], I->d_mstart, I->d_mcounters, I->d_msort};
+                  I->d_mkeys[0], I->d_mkeys[1], I->d_midx[0], I->d_midx[1], I->d_mstart, I->d_mcounters, I->d_msort,
+                  I->d_mrank, I->d_gpg, I->d_gcolor, I->d_gflags, I->d_gcount};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (I->det) det_scratch_free(I->det);
@@ -1190,14 +1154,18 @@ static int merged_integrate_locked(vgx_tsdf_integrator I, const float T[7], cons
   VGX_HIP(ctx, hipSetDevice(ctx->device));
   if (n_updates) VGX_HIP(ctx, hipMemsetAsync(I->dev.n_updates, 0, 8, ctx->stream));
   if (n > 0) {
+    const unsigned long long* keys_sorted = nullptr;
+    const unsigned int* idx_sorted = nullptr;
     if (n > I->merged_cap) {
       VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      void* old[] = {I->d_mkeys[0], I->d_mkeys[1], I->d_midx[0], I->d_midx[1], I->d_mstart, I->d_msort};
+      void* old[] = {I->d_mkeys[0], I->d_mkeys[1], I->d_midx[0], I->d_midx[1], I->d_mstart, I->d_msort,
+                     I->d_mrank, I->d_gpg, I->d_gcolor, I->d_gflags, I->d_gcount};
       for (void* q : old)
         if (q) (void)hipFree(q);
       I->d_mkeys[0] = I->d_mkeys[1] = nullptr;
       I->d_midx[0] = I->d_midx[1] = nullptr;
-      I->d_mstart = nullptr;
+      I->d_mstart = I->d_mrank = I->d_gcolor = I->d_gflags = I->d_gcount = nullptr;
+      I->d_gpg = nullptr;
       I->d_msort = nullptr;
       I->merged_cap = 0;
       for (int k = 0; k < 2; ++k) {
@@ -1205,10 +1173,20 @@ static int merged_integrate_locked(vgx_tsdf_integrator I, const float T[7], cons
         VGX_HIP(ctx, hipMalloc(&I->d_midx[k], (size_t)n * 4));
       }
       VGX_HIP(ctx, hipMalloc(&I->d_mstart, (size_t)n * 4));
-      if (!I->d_mcounters) VGX_HIP(ctx, hipMalloc(&I->d_mcounters, 8));
-      size_t bytes = 0;
+      VGX_HIP(ctx, hipMalloc(&I->d_mrank, (size_t)n * 4));
+      VGX_HIP(ctx, hipMalloc(&I->d_gpg, (size_t)n * 16));
+      VGX_HIP(ctx, hipMalloc(&I->d_gcolor, (size_t)n * 4));
+      VGX_HIP(ctx, hipMalloc(&I->d_gflags, (size_t)n * 4));
+      VGX_HIP(ctx, hipMalloc(&I->d_gcount, ((size_t)n + 1) * 4));
+      if (!I->d_mcounters) VGX_HIP(ctx, hipMalloc(&I->d_mcounters, 16));
+      size_t bytes = 0, b2 = 0;
       VGX_HIP(ctx, rocprim::radix_sort_pairs(nullptr, bytes, I->d_mkeys[0], I->d_mkeys[1], I->d_midx[0], I->d_midx[1],
                                              (size_t)n, 0, 64, ctx->stream));
+      VGX_HIP(ctx, rocprim::exclusive_scan(nullptr, b2,
+                                           rocprim::make_transform_iterator(rocprim::make_counting_iterator<unsigned int>(0u),
+                                                                            MergedHeadOp{I->d_mkeys[1]}),
+                                           I->d_mrank, 0u, (size_t)n, rocprim::plus<unsigned int>(), ctx->stream));
+      bytes = std::max(bytes, b2);
       VGX_HIP(ctx, hipMalloc(&I->d_msort, std::max<size_t>(bytes, 16)));
       I->msort_bytes = bytes;
       I->merged_cap = n;
@@ -1227,16 +1205,35 @@ static int merged_integrate_locked(vgx_tsdf_integrator I, const float T[7], cons
     // stable: equal keys keep the visiting order they were written in
     VGX_HIP(ctx, rocprim::radix_sort_pairs(I->d_msort, bytes, I->d_mkeys[0], I->d_mkeys[1], I->d_midx[0], I->d_midx[1],
                                            (size_t)n, 0, 64, ctx->stream));
-    VGX_HIP(ctx, hipMemsetAsync(I->d_mcounters, 0, 8, ctx->stream));
-    hipLaunchKernelGGL(merged_heads_kernel, grid, block, 0, ctx->stream, I->d_mkeys[1], (long long)n, I->d_mstart,
+    keys_sorted = I->d_mkeys[1];
+    idx_sorted = I->d_midx[1];
+    VGX_HIP(ctx, hipMemsetAsync(I->d_mcounters, 0, 16, ctx->stream));
+    bytes = I->msort_bytes;
+    VGX_HIP(ctx, rocprim::exclusive_scan(I->d_msort, bytes,
+                                         rocprim::make_transform_iterator(rocprim::make_counting_iterator<unsigned int>(0u),
+                                                                          MergedHeadOp{keys_sorted}),
+                                         I->d_mrank, 0u, (size_t)n, rocprim::plus<unsigned int>(), ctx->stream));
+    hipLaunchKernelGGL(merged_heads_kernel, grid, block, 0, ctx->stream, keys_sorted, (long long)n, I->d_mrank, I->d_mstart,
                        I->d_mcounters);
     VGX_HIP(ctx, hipGetLastError());
-    for (int pass = 0; pass < 2; ++pass) {  // integrateRays(clearing_ray = false), then (true)
-      hipLaunchKernelGGL(merged_integrate_kernel, grid, block, 0, ctx->stream, I->layer->dev, I->dev, T[0], T[1], T[2],
-                         T[3], T[4], T[5], T[6], (const float*)d_points, (const uint32_t*)d_rgba, I->d_mkeys[1],
-                         I->d_midx[1], (long long)n, I->d_mstart, I->d_mcounters, pass, (int)c.enable_anti_grazing);
-      VGX_HIP(ctx, hipGetLastError());
-    }
+    VGX_HIP(ctx, hipMemsetAsync(I->d_gcount, 0, ((size_t)n + 1) * 4, ctx->stream));  // groups that do not exist: no voxels
+    // one L-lane sub-group per group, grid-stride (the number of groups stays on the device)
+    constexpr int kLanes = 16;
+    const unsigned work_groups = (unsigned)std::min<long long>(((long long)n * kLanes + 255) / 256, (long long)ctx->cu_count * 16);
+    hipLaunchKernelGGL(merged_merge_kernel<kLanes>, dim3(work_groups), block, 0, ctx->stream, c, I->layer->dev.voxel_size_inv,
+                       T[0], T[1], T[2], T[3], T[4], T[5], T[6], (const float*)d_points, (const uint32_t*)d_rgba, keys_sorted,
+                       idx_sorted, I->d_mstart, I->d_mcounters, I->d_gpg, I->d_gcolor, I->d_gflags, I->d_gcount);
+    VGX_HIP(ctx, hipGetLastError());
+    // integrateRays.  Every ray crosses the sensor's own neighbourhood, so those voxels take one update
+    // per group: thousands of rays contending for one compare-and-swap (measured: 30 ms per RGB-D
+    // scan, most of it retries).  Instead the rays are written out, sorted by voxel and every voxel
+    // applies its updates in group order -- surface groups in key order, then clearing groups: the
+    // single thread's order (vgx_tsdf_det.hip).  The voxel VALUES are therefore the same on every run in
+    // either mode; vgx_tsdf_config.deterministic additionally fixes the order blocks are allocated in.
+    rc = det_merged_commit(I, T, (long long)n, I->d_gpg, I->d_gcolor, I->d_gflags, I->d_gcount, keys_sorted, I->d_mstart,
+                           I->d_mcounters, n_updates);
+    if (rc == VGX_OK) request_readback(I->layer);
+    return rc;
     request_readback(I->layer);
   }
   if (n_updates) {

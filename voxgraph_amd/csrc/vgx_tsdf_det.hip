@@ -61,14 +61,14 @@ struct DetScratch {
   Buf acc_vox, acc_key, acc_ray, s_key, s_idx, s_r, s_k, s_h, last, seen, c_idx, c_key;
   Buf tmp;  // rocprim temporary storage
   // block allocation
-  Buf first_touch, new_cells, new_cells_sorted, new_keys, new_keys_sorted;
+  Buf first_touch, new_cells, new_cells_sorted, new_keys, new_keys_sorted, long_runs, t_at, t_sdf, t_w, t_color;
   bool first_touch_dirty = false;  // a scan failed between marking and assigning: refill
   // device counters {changed, n_new, error, pad, total accesses, total updates (u64 each)} + pinned mirror
   unsigned long long* d_ctr = nullptr;
   unsigned long long* h_ctr = nullptr;
 };
 
-enum { kCtrChanged = 0, kCtrNew = 1, kCtrError = 2, kCtrDropped = 3, kCtrCount = 8 };
+enum { kCtrChanged = 0, kCtrNew = 1, kCtrError = 2, kCtrDropped = 3, kCtrLong = 4, kCtrCount = 8 };
 enum { kRayValid = 1u, kRayClearing = 2u, kRayCast = 4u };
 constexpr uint32_t kInvalidStartKey = 1u << kSetBits;
 constexpr long long kVoxBias = 1ll << 20;  // 21 bits per axis
@@ -78,7 +78,8 @@ void det_scratch_free(DetScratch* s) {
   Buf* all[] = {&s->ray_pg, &s->ray_color, &s->ray_flags, &s->start_val, &s->start_key, &s->start_key_sorted,
                 &s->start_seq_sorted, &s->count, &s->off, &s->T, &s->broke, &s->acc_vox, &s->acc_key, &s->acc_ray,
                 &s->s_key, &s->s_idx, &s->s_r, &s->s_k, &s->s_h, &s->last, &s->seen, &s->c_idx, &s->c_key, &s->tmp,
-                &s->first_touch, &s->new_cells, &s->new_cells_sorted, &s->new_keys, &s->new_keys_sorted};
+                &s->first_touch, &s->new_cells, &s->new_cells_sorted, &s->new_keys, &s->new_keys_sorted, &s->long_runs,
+                &s->t_at, &s->t_sdf, &s->t_w, &s->t_color};
   for (Buf* b : all)
     if (b->p) (void)hipFree(b->p);
   if (s->d_ctr) (void)hipFree(s->d_ctr);
@@ -247,14 +248,18 @@ struct HappenedOp {  // position + 1 of an access whose exchange happens, else 0
   const int32_t* T;
   __host__ __device__ uint32_t operator()(uint32_t p) const { return (int32_t)s_k[p] <= T[s_r[p]] ? p + 1u : 0u; }
 };
-struct UpdateOp {  // 1 for an access that updates its voxel (happened and did not stop the ray)
+struct UpdateOp {  // 1 for an access that updates its voxel
   const uint32_t* s_r;
   const uint32_t* s_k;
   const int32_t* T;
   const uint8_t* broke;
+  const uint32_t* s_idx;   // with `flags` (merged integrator): the decision was taken when the ray was written out
+  const uint8_t* flags;
   uint32_t N;
   __host__ __device__ uint32_t operator()(uint32_t p) const {
     if (p >= N) return 0u;
+    if (flags) return flags[s_idx[p]] ? 1u : 0u;
+    // fast integrator: the exchange happened and did not stop the ray
     const uint32_t r = s_r[p];
     const int32_t k = (int32_t)s_k[p], t = T[r];
     return (k < t || (k == t && !broke[r])) ? 1u : 0u;
@@ -322,6 +327,7 @@ __global__ __launch_bounds__(256) void det_finish_kernel(size_t N, const uint32_
     c_idx[q] = s_idx[p];
     c_key[q] = key;
   }
+  if (!observed_set) return;  // merged integrator: no approximate sets
   if (p == N - 1 || s_key[p + 1] != key) {  // the slot keeps what the last exchange of its run wrote
     const uint32_t li = happened((uint32_t)p) ? (uint32_t)p + 1u : last[p];
     if (li > 0 && s_key[li - 1] == key) observed_set[key] = (unsigned long long)s_h[li - 1] + observed_offset;
@@ -385,38 +391,115 @@ __global__ void det_assign_kernel(TsdfLayerDev L, uint32_t n_new, int32_t base, 
   if (i == 0) *L.n_blocks = (int32_t)min((long long)base + n_new, (long long)L.max_blocks);
 }
 
-// ---- 3c. updateTsdfVoxel, one thread per slot run, updates in visiting order ----------------------
-__global__ __launch_bounds__(256) void det_apply_kernel(TsdfLayerDev L, vgx_tsdf_config c, float tx, float ty, float tz,
+// ---- 3c. updateTsdfVoxel in a fixed order -----------------------------------------------------------
+// computeDistance + updateTsdfVoxel's weight [recalled]; the same operations as update_voxel (vgx_tsdf.hip)
+struct UpdateTerm {
+  float sdf, w;
+};
+__device__ __forceinline__ UpdateTerm update_term(const vgx_tsdf_config& c, float vs, float tx, float ty, float tz,
+                                                  const float4& g, int vx, int vy, int vz) {
+  const float trunc = c.default_truncation_distance;
+  const float cx = ((float)vx + 0.5f) * vs, cy = ((float)vy + 0.5f) * vs, cz = ((float)vz + 0.5f) * vs;
+  const float vvx = cx - tx, vvy = cy - ty, vvz = cz - tz;
+  const float vpx = g.x - tx, vpy = g.y - ty, vpz = g.z - tz;
+  const float dist_G = norm3(vpx, vpy, vpz);
+  const float dot = (vvx * vpx + vvy * vpy) + vvz * vpz;
+  const float dist_G_V = dot / dist_G;
+  UpdateTerm u;
+  u.sdf = dist_G - dist_G_V;
+  u.w = g.w;
+  if (c.use_weight_dropoff && u.sdf < -vs) {
+    u.w = g.w * (trunc + u.sdf) / (trunc - vs);
+    u.w = fmaxf(u.w, 0.0f);
+  }
+  if (c.use_sparsity_compensation_factor && fabsf(u.sdf) < trunc) u.w *= c.sparsity_compensation_factor;
+  return u;
+}
+
+// the running average itself (the voxel mutex's critical section)
+__device__ __forceinline__ void apply_term(const vgx_tsdf_config& c, float sdf, float uw, uint32_t color, float& d, float& w,
+                                           uint32_t& col, bool& dirty) {
+  const float trunc = c.default_truncation_distance;
+  const float new_weight = w + uw;
+  if (new_weight < 1e-6f) return;  // kFloatEpsilon
+  const float new_sdf = (sdf * uw + d * w) / new_weight;
+  if (fabsf(sdf) < trunc) col = blended_color(col, color, w, uw);
+  d = (new_sdf > 0.0f) ? fminf(trunc, new_sdf) : fmaxf(-trunc, new_sdf);
+  w = fminf(c.max_weight, new_weight);
+  dirty = true;
+}
+
+template <bool ALLOCATE>
+__device__ __forceinline__ int block_slot(const TsdfLayerDev& L, int bx, int by, int bz) {
+  if (ALLOCATE) return get_or_allocate_block(L, bx, by, bz);
+  const long long cell = lut_cell(L, bx, by, bz);
+  return cell >= 0 ? L.lut[cell] : -1;
+}
+
+constexpr int kShortRun = 32;
+
+// What an update contributes, evaluated for all M updates in parallel (sorted order): the voxel it
+// goes to, its sdf, its weight, its colour.  Only the running average itself is order dependent.
+// ALLOCATE: blocks are taken from the pool on demand (merged integrator outside the reproducible mode:
+// the values are order-exact all the same, only the pool order is arrival order); otherwise they have
+// been allocated, in order, beforehand.
+template <bool ALLOCATE>
+__global__ __launch_bounds__(256) void det_terms_kernel(TsdfLayerDev L, vgx_tsdf_config c, float tx, float ty, float tz,
                                                        size_t M, const uint32_t* __restrict__ c_idx,
-                                                       const uint32_t* __restrict__ c_key,
                                                        const unsigned long long* __restrict__ acc_vox,
                                                        const uint32_t* __restrict__ acc_ray,
                                                        const float4* __restrict__ ray_pg,
                                                        const uint32_t* __restrict__ ray_color,
+                                                       long long* __restrict__ t_at, float* __restrict__ t_sdf,
+                                                       float* __restrict__ t_w, uint32_t* __restrict__ t_color) {
+  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= M) return;
+  const uint32_t idx = c_idx[q];
+  int vx, vy, vz;
+  unpack_vox(acc_vox[idx], vx, vy, vz);
+  const int vps = L.vps, shift = L.vps_shift, mask = vps - 1;
+  const int slot = block_slot<ALLOCATE>(L, vx >> shift, vy >> shift, vz >> shift);
+  const uint32_t r = acc_ray[idx];
+  const UpdateTerm u = update_term(c, L.voxel_size, tx, ty, tz, ray_pg[r], vx, vy, vz);
+  t_at[q] = slot < 0 ? -1ll
+                     : (long long)((size_t)slot * ((size_t)vps * vps * vps) +
+                                   (size_t)((vx & mask) + vps * ((vy & mask) + vps * (vz & mask))));
+  t_sdf[q] = u.sdf;
+  t_w[q] = u.w;
+  t_color[q] = ray_color[r];
+}
+
+// One thread per slot run: all updates of a voxel are contiguous and in order.  Runs longer than
+// kShortRun (voxels every ray crosses: the sensor's own neighbourhood under the merged integrator) are
+// left to det_apply_long_kernel.
+__global__ __launch_bounds__(256) void det_apply_kernel(TsdfLayerDev L, vgx_tsdf_config c, size_t M,
+                                                       const uint32_t* __restrict__ c_key,
+                                                       const long long* __restrict__ t_at,
+                                                       const float* __restrict__ t_sdf, const float* __restrict__ t_w,
+                                                       const uint32_t* __restrict__ t_color,
+                                                       uint32_t* __restrict__ long_runs,
                                                        unsigned long long* __restrict__ ctr) {
   const size_t q0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q0 >= M) return;
   const uint32_t key = c_key[q0];
   if (q0 > 0 && c_key[q0 - 1] == key) return;  // not the head of its run
-  const float vs = L.voxel_size, trunc = c.default_truncation_distance;
-  const int vps = L.vps, shift = L.vps_shift, mask = vps - 1;
-  const size_t vpb = (size_t)vps * vps * vps;
-  size_t at_cached = ~(size_t)0;
+  size_t q1 = q0 + 1;
+  while (q1 < M && q1 - q0 <= (size_t)kShortRun && c_key[q1] == key) ++q1;
+  if (q1 - q0 > (size_t)kShortRun) {
+    long_runs[atomicAdd(&ctr[kCtrLong], 1ull)] = (uint32_t)q0;
+    return;
+  }
+  long long at_cached = -1;
   float d = 0.0f, w = 0.0f;
   uint32_t col = 0u;
   bool dirty = false;
   unsigned long long dropped = 0;
-  for (size_t q = q0; q < M && c_key[q] == key; ++q) {
-    const uint32_t idx = c_idx[q];
-    int vx, vy, vz;
-    unpack_vox(acc_vox[idx], vx, vy, vz);
-    const long long cell = lut_cell(L, vx >> shift, vy >> shift, vz >> shift);
-    const int slot = cell >= 0 ? L.lut[cell] : -1;
-    if (slot < 0) {
+  for (size_t q = q0; q < q1; ++q) {
+    const long long at = t_at[q];
+    if (at < 0) {
       ++dropped;
       continue;
     }
-    const size_t at = (size_t)slot * vpb + (size_t)((vx & mask) + vps * ((vy & mask) + vps * (vz & mask)));
     if (at != at_cached) {  // another voxel that shares the slot: write the current one back
       if (dirty) {
         L.voxels[at_cached] = pack_voxel(d, w);
@@ -429,29 +512,7 @@ __global__ __launch_bounds__(256) void det_apply_kernel(TsdfLayerDev L, vgx_tsdf
       at_cached = at;
       dirty = false;
     }
-    const uint32_t r = acc_ray[idx];
-    const float4 g = ray_pg[r];
-    // computeDistance + updateTsdfVoxel [recalled]; same operations as update_voxel (vgx_tsdf.hip)
-    const float cx = ((float)vx + 0.5f) * vs, cy = ((float)vy + 0.5f) * vs, cz = ((float)vz + 0.5f) * vs;
-    const float vvx = cx - tx, vvy = cy - ty, vvz = cz - tz;
-    const float vpx = g.x - tx, vpy = g.y - ty, vpz = g.z - tz;
-    const float dist_G = norm3(vpx, vpy, vpz);
-    const float dot = (vvx * vpx + vvy * vpy) + vvz * vpz;
-    const float dist_G_V = dot / dist_G;
-    const float sdf = dist_G - dist_G_V;
-    float updated_weight = g.w;
-    if (c.use_weight_dropoff && sdf < -vs) {
-      updated_weight = g.w * (trunc + sdf) / (trunc - vs);
-      updated_weight = fmaxf(updated_weight, 0.0f);
-    }
-    if (c.use_sparsity_compensation_factor && fabsf(sdf) < trunc) updated_weight *= c.sparsity_compensation_factor;
-    const float new_weight = w + updated_weight;
-    if (new_weight < 1e-6f) continue;  // kFloatEpsilon
-    const float new_sdf = (sdf * updated_weight + d * w) / new_weight;
-    if (fabsf(sdf) < trunc) col = blended_color(col, ray_color[r], w, updated_weight);
-    d = (new_sdf > 0.0f) ? fminf(trunc, new_sdf) : fmaxf(-trunc, new_sdf);
-    w = fminf(c.max_weight, new_weight);
-    dirty = true;
+    apply_term(c, t_sdf[q], t_w[q], t_color[q], d, w, col, dirty);
   }
   if (dirty) {
     L.voxels[at_cached] = pack_voxel(d, w);
@@ -463,9 +524,199 @@ __global__ __launch_bounds__(256) void det_apply_kernel(TsdfLayerDev L, vgx_tsdf
   }
 }
 
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// Long runs: one wavefront per run streams the run's terms 64 at a time (the next 64 are in flight
+// while the current ones are applied) and runs the clamped running average -- a handful of dependent
+// f32 operations per update -- over lane broadcasts.
+// Updates that cannot move a voxel that already sits at +truncation only add their weight: with
+// d = t, sdf >= 2 t and w >= 1e-5 W,  fl((sdf w + t W) / (W + w)) >= t [1 + w / (W + w)] (1 - 4 eps) >= t,
+// so the clamp returns t exactly (eps = 2^-24; w / (W + w) >= 1e-5 >> 4 eps).  Where that holds for a
+// whole batch of 64 (the sensor's own neighbourhood: free space, seen by every ray) the batch is a
+// chain of 64 additions, and nothing at all once the weight has reached max_weight.
+__global__ __launch_bounds__(64) void det_apply_long_kernel(TsdfLayerDev L, vgx_tsdf_config c, size_t M,
+                                                           const uint32_t* __restrict__ c_key,
+                                                           const long long* __restrict__ t_at,
+                                                           const float* __restrict__ t_sdf,
+                                                           const float* __restrict__ t_w,
+                                                           const uint32_t* __restrict__ t_color,
+                                                           const uint32_t* __restrict__ long_runs,
+                                                           unsigned long long* __restrict__ ctr) {
+  const int lane = threadIdx.x;
+  const unsigned long long n_long = ctr[kCtrLong];
+  const float trunc = c.default_truncation_distance;
+  unsigned long long dropped = 0;
+  for (unsigned long long j = blockIdx.x; j < n_long; j += gridDim.x) {
+    const size_t q0 = long_runs[j];
+    const uint32_t key = c_key[q0];
+    long long at_cached = -1;
+    float d = 0.0f, w = 0.0f;
+    uint32_t col = 0u;
+    bool dirty = false;
+    // batch in flight
+    size_t qn = q0 + lane;
+    bool n_valid = qn < M && c_key[qn] == key;
+    long long n_at = n_valid ? t_at[qn] : -1;
+    float n_sdf = n_valid ? t_sdf[qn] : 0.0f, n_uw = n_valid ? t_w[qn] : 0.0f;
+    uint32_t n_color = n_valid ? t_color[qn] : 0u;
+    for (size_t b = q0;; b += 64) {
+      const bool valid = n_valid;
+      const long long at = n_at;
+      const float sdf = n_sdf, uw = n_uw;
+      const uint32_t color = n_color;
+      const unsigned long long vmask = __ballot(valid);
+      const int cnt = __popcll(vmask);  // the valid lanes are a prefix: the run is contiguous
+      if (cnt == 64) {                  // fetch the next batch while this one is applied
+        qn = b + 64 + lane;
+        n_valid = qn < M && c_key[qn] == key;
+        n_at = n_valid ? t_at[qn] : -1;
+        n_sdf = n_valid ? t_sdf[qn] : 0.0f;
+        n_uw = n_valid ? t_w[qn] : 0.0f;
+        n_color = n_valid ? t_color[qn] : 0u;
+      }
+      if (cnt == 0) break;
+      const long long at0 = ((long long)__builtin_amdgcn_readfirstlane((int)(at >> 32)) << 32) |
+                            (unsigned int)__builtin_amdgcn_readfirstlane((int)(at & 0xffffffffll));
+      const bool one_voxel = at0 >= 0 && __ballot(valid && at != at0) == 0ull;
+      bool done = false;
+      if (one_voxel) {
+        if (at0 != at_cached) {
+          if (dirty && lane == 0) {
+            L.voxels[at_cached] = pack_voxel(d, w);
+            L.rgba[at_cached] = col;
+          }
+          const unsigned long long v = L.voxels[at0];
+          d = __uint_as_float((unsigned)(v & 0xffffffffull));
+          w = __uint_as_float((unsigned)(v >> 32));
+          col = L.rgba[at0];
+          at_cached = at0;
+          dirty = false;
+        }
+        const bool all_far = __ballot(valid && !(sdf >= 2.0f * trunc)) == 0ull;
+        if (all_far && d == trunc) {
+          const float min_uw = wave_min(valid ? uw : INFINITY);
+          const float bound = fminf(fmaxf(w, c.max_weight), (w + wave_sum(valid ? uw : 0.0f)) * 1.01f);
+          if (min_uw * 1.0e5f >= bound && w + min_uw >= 1e-6f) {  // every step of the batch only adds its weight
+            if (w != c.max_weight) {
+              for (int k = 0; k < cnt; ++k)
+                w = fminf(c.max_weight, w + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(uw), k)));
+              dirty = true;
+            }
+            done = true;  // (at max_weight already: min(max_weight, max_weight + uw) = max_weight, nothing moves)
+          }
+        }
+      }
+      if (!done) {
+        for (int k = 0; k < cnt; ++k) {
+          const long long at_k = ((long long)__builtin_amdgcn_readlane((int)(at >> 32), k) << 32) |
+                                 (unsigned int)__builtin_amdgcn_readlane((int)(at & 0xffffffffll), k);
+          if (at_k < 0) {
+            ++dropped;
+            continue;
+          }
+          if (at_k != at_cached) {
+            if (dirty && lane == 0) {
+              L.voxels[at_cached] = pack_voxel(d, w);
+              L.rgba[at_cached] = col;
+            }
+            const unsigned long long v = L.voxels[at_k];
+            d = __uint_as_float((unsigned)(v & 0xffffffffull));
+            w = __uint_as_float((unsigned)(v >> 32));
+            col = L.rgba[at_k];
+            at_cached = at_k;
+            dirty = false;
+          }
+          const float sdf_k = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sdf), k));
+          const float uw_k = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(uw), k));
+          if (d == trunc && sdf_k >= 2.0f * trunc && uw_k * 1.0e5f >= w && w + uw_k >= 1e-6f) {
+            w = fminf(c.max_weight, w + uw_k);  // the average stays at +truncation: weight only
+            dirty = true;
+          } else {
+            const uint32_t color_k = (uint32_t)__builtin_amdgcn_readlane((int)color, k);
+            apply_term(c, sdf_k, uw_k, color_k, d, w, col, dirty);
+          }
+        }
+      }
+      if (cnt < 64) break;
+    }
+    if (dirty && lane == 0) {
+      L.voxels[at_cached] = pack_voxel(d, w);
+      L.rgba[at_cached] = col;
+    }
+  }
+  if (dropped && lane == 0) {
+    atomicAdd(L.dropped, dropped);
+    atomicAdd(&ctr[kCtrDropped], dropped);
+  }
+}
+
 __global__ void det_fill_u64_kernel(unsigned long long* p, size_t n, unsigned long long v) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
+}
+
+// ---- merged integrator: every group's ray written out (cast from the origin outwards) ---------------
+constexpr unsigned long long kMergedKeyBias = 1ull << 20;
+__device__ __forceinline__ unsigned long long merged_voxel_key(int x, int y, int z) {
+  return (((unsigned long long)(x + (long long)kMergedKeyBias) & 0x1fffffull) << 42) |
+         (((unsigned long long)(y + (long long)kMergedKeyBias) & 0x1fffffull) << 21) |
+         ((unsigned long long)(z + (long long)kMergedKeyBias) & 0x1fffffull);
+}
+
+__global__ __launch_bounds__(256) void det_merged_walk_kernel(vgx_tsdf_config c, float vsi, float tx, float ty, float tz,
+                                                             uint32_t G, const float4* __restrict__ g_pg,
+                                                             const uint32_t* __restrict__ g_flags,
+                                                             const uint32_t* __restrict__ g_count,
+                                                             const uint32_t* __restrict__ off,
+                                                             const unsigned long long* __restrict__ keys,
+                                                             const unsigned int* __restrict__ group_start,
+                                                             const unsigned int* __restrict__ counters, int anti_grazing,
+                                                             unsigned long long* __restrict__ acc_vox,
+                                                             uint32_t* __restrict__ acc_key, uint32_t* __restrict__ acc_ray,
+                                                             uint8_t* __restrict__ upd,
+                                                             unsigned long long* __restrict__ ctr) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G || g >= counters[0]) return;
+  const uint32_t cnt = g_count[g];
+  if (cnt == 0) return;
+  const long long n_surface = counters[1];
+  const bool clearing_ray = (g_flags[g] & 2u) != 0;
+  const float4 pg = g_pg[g];
+  const unsigned long long own_key = keys[group_start[g]] & ~(1ull << 63);
+  RayDda r = ray_setup(c, vsi, tx, ty, tz, pg.x, pg.y, pg.z, clearing_ray, true);
+  const size_t base = off[g];
+  bool out_of_range = false;
+  for (uint32_t k = 0; k < cnt; ++k) {
+    const int vx = r.curr[0], vy = r.curr[1], vz = r.curr[2];
+    dda_advance(r);
+    out_of_range |= vx <= -kVoxBias || vx >= kVoxBias || vy <= -kVoxBias || vy >= kVoxBias || vz <= -kVoxBias || vz >= kVoxBias;
+    uint8_t u = 1;
+    if (anti_grazing) {  // skip voxels that are the end voxel of another surface group (voxel_map.find)
+      const unsigned long long key = merged_voxel_key(vx, vy, vz);
+      if (clearing_ray || key != own_key) {
+        long long lo = 0, hi = n_surface;
+        while (lo < hi) {
+          const long long mid = (lo + hi) >> 1;
+          if (keys[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        if (lo < n_surface && keys[lo] == key) u = 0;
+      }
+    }
+    acc_vox[base + k] = pack_vox(vx, vy, vz);
+    acc_key[base + k] = index_hash(vx, vy, vz) & kSetMask;
+    acc_ray[base + k] = g;
+    upd[base + k] = u;
+  }
+  if (out_of_range) ctr[kCtrError] = 2ull;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -500,6 +751,133 @@ int read_counters(vgx_ctx ctx, DetScratch* S) {
 
 }  // namespace
 
+static int ensure_scratch(vgx_tsdf_integrator I) {
+  vgx_ctx ctx = I->ctx;
+  if (I->det) return VGX_OK;
+  I->det = new (std::nothrow) DetScratch();
+  if (!I->det) return set_error(ctx, VGX_ERR_NOMEM, "TSDF reproducible mode: out of host memory");
+  if (hipMalloc(&I->det->d_ctr, kCtrCount * 8) != hipSuccess ||
+      hipHostMalloc((void**)&I->det->h_ctr, kCtrCount * 8, hipHostMallocDefault) != hipSuccess)
+    return set_error(ctx, VGX_ERR_NOMEM, "TSDF reproducible mode: counter allocation failed");
+  return VGX_OK;
+}
+
+// ---- 3. the updates that happen, in sorted order -> compaction, new blocks, ordered application ----
+// (shared by both integrators: `update` says which of the N sorted accesses update their voxel; rays are
+// indexed by acc_ray, their point / weight / colour live in ray_pg / ray_color)
+static int det_commit(vgx_tsdf_integrator I, DetScratch* S, const float T[7], size_t N, const HappenedOp& happened,
+                      const UpdateOp* update, bool update_set, bool ordered_blocks, const float4* ray_pg,
+                      const uint32_t* ray_color, int64_t* n_updates) {
+  vgx_ctx ctx = I->ctx;
+  vgx_tsdf_layer layer = I->layer;
+  const vgx_tsdf_config& c = I->dev.cfg;
+  hipStream_t st = ctx->stream;
+  auto pos = rocprim::make_counting_iterator<uint32_t>(0u);
+  size_t M = N;
+  const uint32_t* c_idx = S->s_idx.as<uint32_t>();  // without a filter every sorted access is an update
+  const uint32_t* c_key = S->s_key.as<uint32_t>();
+  if (update) {
+    {
+      size_t b2 = 0;
+      VGX_HIP(ctx, rocprim::exclusive_scan(nullptr, b2, rocprim::make_transform_iterator(pos, *update), S->last.as<uint32_t>(),
+                                           0u, N + 1, rocprim::plus<uint32_t>(), st));
+      DET_TRY(grow(ctx, S->tmp, b2));
+    }
+    // `last` is consumed by the finish kernel (set state) and cannot hold the compaction offsets too
+    uint32_t* cpos = S->acc_key.as<uint32_t>();  // free since the sort: the compaction offsets live there
+    {
+      size_t bytes = S->tmp.bytes;
+      VGX_HIP(ctx, rocprim::exclusive_scan(S->tmp.p, bytes, rocprim::make_transform_iterator(pos, *update), cpos, 0u, N + 1,
+                                           rocprim::plus<uint32_t>(), st));
+    }
+    hipLaunchKernelGGL(det_finish_kernel, dim3(blocks_for(N)), dim3(256), 0, st, N, S->s_key.as<uint32_t>(),
+                       S->s_idx.as<uint32_t>(), S->s_h.as<uint32_t>(), S->last.as<uint32_t>(), happened, *update, cpos,
+                       S->c_idx.as<uint32_t>(), S->c_key.as<uint32_t>(), update_set ? I->dev.observed_set : nullptr,
+                       I->dev.observed_offset);
+    VGX_HIP(ctx, hipGetLastError());
+    uint32_t M32 = 0;
+    VGX_HIP(ctx, hipMemcpyAsync(&M32, cpos + N, 4, hipMemcpyDeviceToHost, st));
+    VGX_HIP(ctx, hipStreamSynchronize(st));
+    M = M32;
+    c_idx = S->c_idx.as<uint32_t>();
+    c_key = S->c_key.as<uint32_t>();
+  }
+  if (M == 0) return VGX_OK;
+  TsdfLayerDev& L = layer->dev;
+  if (ordered_blocks) {
+    // new blocks take their pool slots in the order of their first update (the table may have been
+    // re-boxed since the last scan)
+    if (S->first_touch.bytes < layer->lut_cells * 8 || S->first_touch_dirty) {  // else: all ~0 since the last scan
+      DET_TRY(grow(ctx, S->first_touch, layer->lut_cells * 8));
+      S->first_touch_dirty = false;
+      const size_t cells = S->first_touch.bytes / 8;
+      hipLaunchKernelGGL(det_fill_u64_kernel, dim3(blocks_for(cells)), dim3(256), 0, st, S->first_touch.as<unsigned long long>(),
+                         cells, ~0ull);
+      VGX_HIP(ctx, hipGetLastError());
+    }
+    const size_t new_cap = (size_t)std::max<int64_t>(tsdf_last_scan_bound(layer), 1);
+    DET_TRY(grow(ctx, S->new_cells, new_cap * 4));
+    DET_TRY(grow(ctx, S->new_cells_sorted, new_cap * 4));
+    DET_TRY(grow(ctx, S->new_keys, new_cap * 8));
+    DET_TRY(grow(ctx, S->new_keys_sorted, new_cap * 8));
+    hipLaunchKernelGGL(det_blocks_kernel, dim3(blocks_for(M)), dim3(256), 0, st, L, M, c_idx,
+                       S->acc_vox.as<unsigned long long>(), S->acc_ray.as<uint32_t>(), S->off.as<uint32_t>(),
+                       S->first_touch.as<unsigned long long>(), S->new_cells.as<int32_t>(), (uint32_t)new_cap, S->d_ctr);
+    VGX_HIP(ctx, hipGetLastError());
+    int32_t n_blocks_now = 0;
+    VGX_HIP(ctx, hipMemcpyAsync(&n_blocks_now, L.n_blocks, 4, hipMemcpyDeviceToHost, st));
+    DET_TRY(read_counters(ctx, S));
+    const size_t n_new = (size_t)S->h_ctr[kCtrNew];
+    if (n_new > new_cap) {
+      S->first_touch_dirty = true;
+      return set_error(ctx, VGX_ERR_HIP, "TSDF reproducible mode: more new blocks than the scan's reach allows (internal error)");
+    }
+    if (n_new > 0) {
+      hipLaunchKernelGGL(det_new_keys_kernel, dim3(blocks_for(n_new)), dim3(256), 0, st, (uint32_t)n_new,
+                         S->new_cells.as<int32_t>(), S->first_touch.as<unsigned long long>(),
+                         S->new_keys.as<unsigned long long>());
+      VGX_HIP(ctx, hipGetLastError());
+      size_t bytes = 0;
+      VGX_HIP(ctx, rocprim::radix_sort_pairs(nullptr, bytes, S->new_keys.as<unsigned long long>(),
+                                             S->new_keys_sorted.as<unsigned long long>(), S->new_cells.as<int32_t>(),
+                                             S->new_cells_sorted.as<int32_t>(), n_new, 0, 64, st));
+      DET_TRY(grow(ctx, S->tmp, bytes));
+      bytes = S->tmp.bytes;
+      VGX_HIP(ctx, rocprim::radix_sort_pairs(S->tmp.p, bytes, S->new_keys.as<unsigned long long>(),
+                                             S->new_keys_sorted.as<unsigned long long>(), S->new_cells.as<int32_t>(),
+                                             S->new_cells_sorted.as<int32_t>(), n_new, 0, 64, st));
+      hipLaunchKernelGGL(det_assign_kernel, dim3(blocks_for(n_new)), dim3(256), 0, st, L, (uint32_t)n_new, n_blocks_now,
+                         S->new_cells_sorted.as<int32_t>(), S->first_touch.as<unsigned long long>());
+      VGX_HIP(ctx, hipGetLastError());
+    }
+  }
+  DET_TRY(grow(ctx, S->long_runs, (M / kShortRun + 2) * 4));
+  DET_TRY(grow(ctx, S->t_at, M * 8));
+  DET_TRY(grow(ctx, S->t_sdf, M * 4));
+  DET_TRY(grow(ctx, S->t_w, M * 4));
+  DET_TRY(grow(ctx, S->t_color, M * 4));
+  if (ordered_blocks)
+    hipLaunchKernelGGL(det_terms_kernel<false>, dim3(blocks_for(M)), dim3(256), 0, st, L, c, T[4], T[5], T[6], M, c_idx,
+                       S->acc_vox.as<unsigned long long>(), S->acc_ray.as<uint32_t>(), ray_pg, ray_color,
+                       S->t_at.as<long long>(), S->t_sdf.as<float>(), S->t_w.as<float>(), S->t_color.as<uint32_t>());
+  else
+    hipLaunchKernelGGL(det_terms_kernel<true>, dim3(blocks_for(M)), dim3(256), 0, st, L, c, T[4], T[5], T[6], M, c_idx,
+                       S->acc_vox.as<unsigned long long>(), S->acc_ray.as<uint32_t>(), ray_pg, ray_color,
+                       S->t_at.as<long long>(), S->t_sdf.as<float>(), S->t_w.as<float>(), S->t_color.as<uint32_t>());
+  VGX_HIP(ctx, hipGetLastError());
+  hipLaunchKernelGGL(det_apply_kernel, dim3(blocks_for(M)), dim3(256), 0, st, L, c, M, c_key, S->t_at.as<long long>(),
+                     S->t_sdf.as<float>(), S->t_w.as<float>(), S->t_color.as<uint32_t>(), S->long_runs.as<uint32_t>(), S->d_ctr);
+  const unsigned long_grid = (unsigned)std::min<size_t>((size_t)ctx->cu_count * 8, M / kShortRun + 1);
+  hipLaunchKernelGGL(det_apply_long_kernel, dim3(long_grid), dim3(64), 0, st, L, c, M, c_key, S->t_at.as<long long>(),
+                     S->t_sdf.as<float>(), S->t_w.as<float>(), S->t_color.as<uint32_t>(), S->long_runs.as<uint32_t>(), S->d_ctr);
+  VGX_HIP(ctx, hipGetLastError());
+  if (n_updates) {
+    DET_TRY(read_counters(ctx, S));
+    *n_updates = (int64_t)M - (int64_t)S->h_ctr[kCtrDropped];
+  }
+  return VGX_OK;
+}
+
 int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points, const void* d_rgba, int64_t n,
                   int32_t freespace, int64_t* n_updates) {
   vgx_ctx ctx = I->ctx;
@@ -508,13 +886,7 @@ int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points,
   hipStream_t st = ctx->stream;
   if (n_updates) *n_updates = 0;
   if (n >= (1ll << 31)) return set_error(ctx, VGX_ERR_UNSUPPORTED, "TSDF reproducible mode: more than 2^31 points in a scan");
-  if (!I->det) {
-    I->det = new (std::nothrow) DetScratch();
-    if (!I->det) return set_error(ctx, VGX_ERR_NOMEM, "TSDF reproducible mode: out of host memory");
-    if (hipMalloc(&I->det->d_ctr, kCtrCount * 8) != hipSuccess ||
-        hipHostMalloc((void**)&I->det->h_ctr, kCtrCount * 8, hipHostMallocDefault) != hipSuccess)
-      return set_error(ctx, VGX_ERR_NOMEM, "TSDF reproducible mode: counter allocation failed");
-  }
+  DET_TRY(ensure_scratch(I));
   DetScratch* S = I->det;
   const float vsi = layer->dev.voxel_size_inv;
   const size_t np = (size_t)n;
@@ -621,7 +993,8 @@ int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points,
   VGX_HIP(ctx, hipGetLastError());
   // ---- sweeps to the fixed point ----
   const HappenedOp happened{S->s_r.as<uint32_t>(), S->s_k.as<uint32_t>(), S->T.as<int32_t>()};
-  const UpdateOp update{S->s_r.as<uint32_t>(), S->s_k.as<uint32_t>(), S->T.as<int32_t>(), S->broke.as<uint8_t>(), (uint32_t)N};
+  const UpdateOp update{S->s_r.as<uint32_t>(), S->s_k.as<uint32_t>(), S->T.as<int32_t>(), S->broke.as<uint8_t>(),
+                        nullptr, nullptr, (uint32_t)N};
   auto pos = rocprim::make_counting_iterator<uint32_t>(0u);
   size_t scan_bytes = 0;
   VGX_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, rocprim::make_transform_iterator(pos, happened),
@@ -656,76 +1029,75 @@ int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points,
   }
   if (S->h_ctr[kCtrError])
     return set_error(ctx, VGX_ERR_UNSUPPORTED, "TSDF reproducible mode: a voxel index beyond +-2^20 voxels of the layer origin");
-  // ---- 3. updates ----
-  // `last` is consumed by the finish kernel (set state) and cannot hold the compaction offsets too
-  uint32_t* cpos = S->acc_key.as<uint32_t>();  // free since the sort: the compaction offsets live there
+  return det_commit(I, S, T, N, happened, &update, true, true, S->ray_pg.as<float4>(), S->ray_color.as<uint32_t>(), n_updates);
+}
+
+int det_merged_commit(vgx_tsdf_integrator I, const float T[7], long long n, const float4* g_pg, const uint32_t* g_color,
+                      const uint32_t* g_flags, uint32_t* g_count, const unsigned long long* keys_sorted,
+                      const unsigned int* group_start, const unsigned int* counters, int64_t* n_updates) {
+  vgx_ctx ctx = I->ctx;
+  const vgx_tsdf_config& c = I->dev.cfg;
+  hipStream_t st = ctx->stream;
+  if (n_updates) *n_updates = 0;
+  DET_TRY(ensure_scratch(I));
+  DetScratch* S = I->det;
+  // g_count is zero beyond the last group (the caller cleared it): the scan runs over n + 1 entries and
+  // the number of groups never has to come to the host
+  const size_t G = (size_t)n;
+  VGX_HIP(ctx, hipMemsetAsync(S->d_ctr, 0, kCtrCount * 8, st));
+  DET_TRY(grow(ctx, S->off, (G + 1) * 4));
   {
-    size_t bytes = S->tmp.bytes;
-    VGX_HIP(ctx, rocprim::exclusive_scan(S->tmp.p, bytes, rocprim::make_transform_iterator(pos, update), cpos, 0u, N + 1,
-                                         rocprim::plus<uint32_t>(), st));
-  }
-  hipLaunchKernelGGL(det_finish_kernel, dim3(blocks_for(N)), dim3(256), 0, st, N, S->s_key.as<uint32_t>(),
-                     S->s_idx.as<uint32_t>(), S->s_h.as<uint32_t>(), S->last.as<uint32_t>(), happened, update, cpos,
-                     S->c_idx.as<uint32_t>(), S->c_key.as<uint32_t>(), I->dev.observed_set, I->dev.observed_offset);
-  VGX_HIP(ctx, hipGetLastError());
-  uint32_t M32 = 0;
-  VGX_HIP(ctx, hipMemcpyAsync(&M32, cpos + N, 4, hipMemcpyDeviceToHost, st));
-  VGX_HIP(ctx, hipStreamSynchronize(st));
-  const size_t M = M32;
-  if (M == 0) return VGX_OK;
-  // blocks: the table may have been re-boxed since the last scan
-  TsdfLayerDev& L = layer->dev;
-  if (S->first_touch.bytes < layer->lut_cells * 8 || S->first_touch_dirty) {  // else: all ~0 since the last scan
-    DET_TRY(grow(ctx, S->first_touch, layer->lut_cells * 8));
-    S->first_touch_dirty = false;
-    const size_t cells = S->first_touch.bytes / 8;
-    hipLaunchKernelGGL(det_fill_u64_kernel, dim3(blocks_for(cells)), dim3(256), 0, st, S->first_touch.as<unsigned long long>(),
-                       cells, ~0ull);
-    VGX_HIP(ctx, hipGetLastError());
-  }
-  const size_t new_cap = (size_t)std::max<int64_t>(tsdf_last_scan_bound(layer), 1);
-  DET_TRY(grow(ctx, S->new_cells, new_cap * 4));
-  DET_TRY(grow(ctx, S->new_cells_sorted, new_cap * 4));
-  DET_TRY(grow(ctx, S->new_keys, new_cap * 8));
-  DET_TRY(grow(ctx, S->new_keys_sorted, new_cap * 8));
-  hipLaunchKernelGGL(det_blocks_kernel, dim3(blocks_for(M)), dim3(256), 0, st, L, M, S->c_idx.as<uint32_t>(),
-                     S->acc_vox.as<unsigned long long>(), S->acc_ray.as<uint32_t>(), S->off.as<uint32_t>(),
-                     S->first_touch.as<unsigned long long>(), S->new_cells.as<int32_t>(), (uint32_t)new_cap, S->d_ctr);
-  VGX_HIP(ctx, hipGetLastError());
-  int32_t n_blocks_now = 0;
-  VGX_HIP(ctx, hipMemcpyAsync(&n_blocks_now, L.n_blocks, 4, hipMemcpyDeviceToHost, st));
-  DET_TRY(read_counters(ctx, S));
-  const size_t n_new = (size_t)S->h_ctr[kCtrNew];
-  if (n_new > new_cap) S->first_touch_dirty = true;
-  if (n_new > new_cap)
-    return set_error(ctx, VGX_ERR_HIP, "TSDF reproducible mode: more new blocks than the scan's reach allows (internal error)");
-  if (n_new > 0) {
-    hipLaunchKernelGGL(det_new_keys_kernel, dim3(blocks_for(n_new)), dim3(256), 0, st, (uint32_t)n_new,
-                       S->new_cells.as<int32_t>(), S->first_touch.as<unsigned long long>(),
-                       S->new_keys.as<unsigned long long>());
-    VGX_HIP(ctx, hipGetLastError());
     size_t bytes = 0;
-    VGX_HIP(ctx, rocprim::radix_sort_pairs(nullptr, bytes, S->new_keys.as<unsigned long long>(),
-                                           S->new_keys_sorted.as<unsigned long long>(), S->new_cells.as<int32_t>(),
-                                           S->new_cells_sorted.as<int32_t>(), n_new, 0, 64, st));
+    VGX_HIP(ctx, rocprim::exclusive_scan(nullptr, bytes, g_count, S->off.as<uint32_t>(), 0u, G + 1, rocprim::plus<uint32_t>(), st));
     DET_TRY(grow(ctx, S->tmp, bytes));
     bytes = S->tmp.bytes;
-    VGX_HIP(ctx, rocprim::radix_sort_pairs(S->tmp.p, bytes, S->new_keys.as<unsigned long long>(),
-                                           S->new_keys_sorted.as<unsigned long long>(), S->new_cells.as<int32_t>(),
-                                           S->new_cells_sorted.as<int32_t>(), n_new, 0, 64, st));
-    hipLaunchKernelGGL(det_assign_kernel, dim3(blocks_for(n_new)), dim3(256), 0, st, L, (uint32_t)n_new, n_blocks_now,
-                       S->new_cells_sorted.as<int32_t>(), S->first_touch.as<unsigned long long>());
-    VGX_HIP(ctx, hipGetLastError());
+    VGX_HIP(ctx, rocprim::exclusive_scan(S->tmp.p, bytes, g_count, S->off.as<uint32_t>(), 0u, G + 1, rocprim::plus<uint32_t>(), st));
   }
-  hipLaunchKernelGGL(det_apply_kernel, dim3(blocks_for(M)), dim3(256), 0, st, L, c, T[4], T[5], T[6], M,
-                     S->c_idx.as<uint32_t>(), S->c_key.as<uint32_t>(), S->acc_vox.as<unsigned long long>(),
-                     S->acc_ray.as<uint32_t>(), S->ray_pg.as<float4>(), S->ray_color.as<uint32_t>(), S->d_ctr);
+  uint32_t total = 0;
+  VGX_HIP(ctx, hipMemcpyAsync(&total, S->off.as<uint32_t>() + G, 4, hipMemcpyDeviceToHost, st));
+  VGX_HIP(ctx, hipStreamSynchronize(st));
+  {
+    const double max_steps = 3.0 * ((double)c.max_ray_length_m + 2.0 * c.default_truncation_distance) * I->layer->dev.voxel_size_inv + 8.0;
+    if ((double)G * max_steps >= 4.0e9)
+      return set_error(ctx, VGX_ERR_UNSUPPORTED, "TSDF merged integrator: more than 2^32 voxel steps in a scan");
+  }
+  const size_t N = total;
+  if (N == 0) return VGX_OK;
+  DET_TRY(grow(ctx, S->acc_vox, N * 8));
+  DET_TRY(grow(ctx, S->acc_key, (N + 1) * 4));
+  DET_TRY(grow(ctx, S->acc_ray, N * 4));
+  DET_TRY(grow(ctx, S->s_key, N * 4));
+  DET_TRY(grow(ctx, S->s_idx, N * 4));
+  DET_TRY(grow(ctx, S->s_h, N * 4));
+  DET_TRY(grow(ctx, S->last, (N + 1) * 4));
+  DET_TRY(grow(ctx, S->seen, N));
+  DET_TRY(grow(ctx, S->c_idx, N * 4));
+  DET_TRY(grow(ctx, S->c_key, N * 4));
+  hipLaunchKernelGGL(det_merged_walk_kernel, dim3(blocks_for(G)), dim3(256), 0, st, c, I->layer->dev.voxel_size_inv, T[4], T[5],
+                     T[6], (uint32_t)G, g_pg, g_flags, g_count, S->off.as<uint32_t>(), keys_sorted, group_start, counters,
+                     (int)c.enable_anti_grazing, S->acc_vox.as<unsigned long long>(),
+                     S->acc_key.as<uint32_t>(), S->acc_ray.as<uint32_t>(), S->seen.as<uint8_t>(), S->d_ctr);
   VGX_HIP(ctx, hipGetLastError());
-  if (n_updates) {
-    DET_TRY(read_counters(ctx, S));
-    *n_updates = (int64_t)M - (int64_t)S->h_ctr[kCtrDropped];
+  {
+    size_t bytes = 0;
+    auto iota = rocprim::make_counting_iterator<uint32_t>(0u);
+    VGX_HIP(ctx, rocprim::radix_sort_pairs(nullptr, bytes, S->acc_key.as<uint32_t>(), S->s_key.as<uint32_t>(), iota,
+                                           S->s_idx.as<uint32_t>(), N, 0, kSetBits, st));
+    DET_TRY(grow(ctx, S->tmp, bytes));
+    bytes = S->tmp.bytes;
+    // stable: a voxel's updates stay in (group, step) order
+    VGX_HIP(ctx, rocprim::radix_sort_pairs(S->tmp.p, bytes, S->acc_key.as<uint32_t>(), S->s_key.as<uint32_t>(), iota,
+                                           S->s_idx.as<uint32_t>(), N, 0, kSetBits, st));
   }
-  return VGX_OK;
+  DET_TRY(read_counters(ctx, S));
+  if (S->h_ctr[kCtrError])
+    return set_error(ctx, VGX_ERR_UNSUPPORTED, "TSDF reproducible mode: a voxel index beyond +-2^20 voxels of the layer origin");
+  const HappenedOp happened{nullptr, nullptr, nullptr};  // unused: no approximate sets
+  // only anti-grazing removes updates; blocks in order of first update only in the reproducible mode
+  // (otherwise on demand: the VALUES are order-exact either way, only the pool order is arrival order)
+  const UpdateOp update{nullptr, nullptr, nullptr, nullptr, S->s_idx.as<uint32_t>(), S->seen.as<uint8_t>(), (uint32_t)N};
+  return det_commit(I, S, T, N, happened, c.enable_anti_grazing ? &update : nullptr, false, c.deterministic != 0, g_pg,
+                    g_color, n_updates);
 }
 
 }  // namespace vgx

@@ -232,7 +232,12 @@ struct vgx_tsdf_integrator_s {
   unsigned long long* d_mkeys[2] = {nullptr, nullptr};
   unsigned int* d_midx[2] = {nullptr, nullptr};
   unsigned int* d_mstart = nullptr;
-  unsigned int* d_mcounters = nullptr;
+  unsigned int* d_mrank = nullptr;     // rank of every sorted entry's group
+  unsigned int* d_mcounters = nullptr; // {groups, surface entries, surface groups, valid entries}
+  float4* d_gpg = nullptr;             // per group: merged point (layer frame) + merged weight
+  uint32_t* d_gcolor = nullptr;
+  uint32_t* d_gflags = nullptr;
+  uint32_t* d_gcount = nullptr;        // voxels on the group's ray
   void* d_msort = nullptr;
   size_t msort_bytes = 0;
   long long merged_cap = 0;
@@ -248,6 +253,11 @@ void tsdf_request_readback(vgx_tsdf_layer L);
 // holds the integrator's and the context's locks, the approximate sets have been reset for the scan
 int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points, const void* d_rgba, int64_t n,
                   int32_t freespace, int64_t* n_updates);
+// the merged integrator's rays (merged point / colour / flags / ray length per group, groups in key order)
+// applied voxel by voxel in group order
+int det_merged_commit(vgx_tsdf_integrator I, const float T[7], long long n, const float4* g_pg, const uint32_t* g_color,
+                      const uint32_t* g_flags, uint32_t* g_count, const unsigned long long* keys_sorted,
+                      const unsigned int* group_start, const unsigned int* counters, int64_t* n_updates);
 }  // namespace vgx
 
 #endif  // VGX_TSDF_INTERNAL_H_
