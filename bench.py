@@ -639,6 +639,61 @@ def config5_bench(capi, ctx, torch, dist, use_dist, rank, world, args):
     return out
 
 
+def multi_context_bench(capi, ctx0, torch, args, devices, submaps0, true_poses, pairs, weights, poses, cfg, single_batch,
+                        n_sub, n_con):
+    """vgx_reg_multi_evaluate_fused over len(devices) contexts (context 0 = ctx0, whose submaps are
+    resident already; every other context gets the submaps its LPT share of the constraints needs)."""
+    n_ctx = len(devices)
+    t_setup = time.perf_counter()
+    ctxs = [ctx0] + [capi.Context(d) for d in devices[1:]]
+    shard_of = capi.lpt_shards(weights, n_ctx)
+    subs = [dict(enumerate(submaps0))] + [dict() for _ in range(n_ctx - 1)]
+    for k_ctx in range(1, n_ctx):
+        need = sorted({int(s_) for c in range(n_con) if shard_of[c] == k_ctx for s_ in pairs[c]})
+        for k in need:
+            sm = capi.Submap.synth_city(ctxs[k_ctx], k, args.voxel_size, 16, args.block_min, args.block_dims,
+                                        args.truncation, args.esdf_max, 10.0, true_poses[k], args.seed)
+            sm.extract_voxel_points(1.0, 0.3, True)
+            sm.release_raw_layers()
+            subs[k_ctx][k] = sm
+    cfs_m = [capi.RegistrationCostFunction(ctxs[shard_of[c]], subs[shard_of[c]][int(a)], subs[shard_of[c]][int(b)], cfg)
+             for c, (a, b) in enumerate(pairs)]
+    multi = capi.RegistrationMulti(ctxs, cfs_m, pairs)
+    setup_s = time.perf_counter() - t_setup
+    for _ in range(2):
+        fused_m, _ = multi.evaluate_fused(poses)
+    m0 = time.perf_counter()
+    for _ in range(args.steps):
+        fused_m, _ = multi.evaluate_fused(poses)
+    m_ms = (time.perf_counter() - m0) / args.steps * 1e3
+    out = {"contexts": n_ctx, "devices": len(set(devices)), "device_ids": devices,
+           "what": "vgx_reg_multi_evaluate_fused (LPT shard by bytes moved, one host thread per context, event-ordered "
+                   "fixed-order sum on context 0 over peer mappings, result on the host)",
+           "ms_per_evaluation": m_ms,
+           "Mresiduals_per_s": float(sum(cf.num_residuals() for cf in cfs_m)) / m_ms / 1e3,
+           "constraints_per_context": [int((shard_of == k).sum()) for k in range(n_ctx)],
+           "cost": float(fused_m[0]), "setup_s": setup_s}
+    if single_batch is not None:
+        single = GpuBackendLite(capi, ctx0, single_batch, n_sub, torch)
+        single._poses = poses
+        for _ in range(2):
+            ref_buf = single()
+        s0_ = time.perf_counter()
+        for _ in range(args.steps):
+            ref_buf = single()
+        out["single_batch_ms_per_evaluation"] = (time.perf_counter() - s0_) / args.steps * 1e3
+        out["single_batch_what"] = "the single batch (evaluate + assemble + copy to the host) on context 0 alone"
+        out["max_rel_diff_vs_single_batch"] = float(np.abs(fused_m - ref_buf).max() / np.abs(ref_buf).max())
+    multi.destroy()
+    for o in cfs_m:
+        o.destroy()
+    for k_ctx in range(1, n_ctx):
+        for sm in subs[k_ctx].values():
+            sm.destroy()
+        ctxs[k_ctx].close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -677,6 +732,10 @@ def main():
                          "instead of the bounded one (10 submaps x 30 scans) the default line carries")
     ap.add_argument("--no-config2", action="store_true")
     ap.add_argument("--no-multi-ctx", action="store_true")
+    ap.add_argument("--inprocess", action="store_true",
+                    help="ONE process drives --gpus N devices through vgx_reg_multi_* (the product's in-process "
+                         "multi-GPU component); launch WITHOUT torch.distributed.run.  The headline loop then "
+                         "runs on device 0 alone and `multi_context` carries the N-GPU evaluation")
     ap.add_argument("--no-config5", action="store_true")
     ap.add_argument("--config", type=int, default=3, choices=[3, 5],
                     help="5: only BASELINE configs[4] (1000 submaps @ 128^3, loop closures, two-stage solve)")
@@ -704,8 +763,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if world != args.gpus and not (args.inprocess and world == 1):
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                         "(or pass --inprocess for the one-process multi-GPU component)")
     # VGX_BENCH_DRYRUN=gloo: every rank on cuda:0 with the gloo backend, to walk the N>1
     # code path on a one-GPU box (profiles/README.md); never used for reported numbers
     dryrun = os.environ.get("VGX_BENCH_DRYRUN", "")
@@ -772,7 +832,7 @@ def main():
 
     cfg = capi.default_config(registration_point_type=capi.POINTS_VOXELS)
     weights = np.array([n_points[a] for a, _ in pairs], np.int64)
-    if world > 1:
+    if world > 1 or not args.no_multi_ctx:
         # what a constraint costs is the bytes it moves at these poses, not its residual count: 36 B per
         # row written + ~45 B per residual in a chunk that can touch the reading submap
         # (vgx_reg_batch_count_live_each; profiles/shard_balance.py: slowest-shard balance at N = 8
@@ -783,6 +843,7 @@ def main():
         probe.destroy()
         for cf in cfs_all:
             cf.destroy()
+    weights_bytes = weights
     mine = lpt_shards(weights, world)[rank]
     cfs = [capi.RegistrationCostFunction(ctx, submaps[pairs[c][0]], submaps[pairs[c][1]], cfg)
            for c in mine]
@@ -1081,49 +1142,26 @@ def main():
         for o in [batch_s] + cfs_s:
             o.destroy()
 
-    # ---- the in-process multi-GPU component (vgx_reg_multi_*) with TWO CONTEXTS ON THIS ONE GPU: what
-    # its host threads, events and the fixed-order sum cost on top of the single-batch path.  (On a
-    # multi-GPU node each context sits on its own GPU; the driver's N > 1 runs use one process per GPU.)
+    # ---- the in-process multi-GPU component (vgx_reg_multi_*: one process, one vgx_ctx + host thread per
+    # GPU, fixed-order sum over xGMI peer mappings) -- the PRODUCT's multi-GPU path (voxgraph is one process).
+    #   N = 1 (default)          : two contexts on this one GPU: what the threads, events and the sum cost
+    #   --inprocess --gpus N     : one process, contexts on devices 0..N-1
+    #   N > 1 under torchrun     : after the per-rank measurements every rank waits at a barrier while
+    #                              rank 0 drives all N GPUs through the component, so the driver's
+    #                              scaling runs time it beside the one-process-per-GPU RCCL route
     multi_ctx = None
-    if world == 1 and not args.no_fused and not args.no_multi_ctx:
-        ctx_b = capi.Context(local_rank)
-        # second context: only the submaps its share of the constraints needs are uploaded
-        shard_of = capi.lpt_shards(weights, 2)
-        need = sorted({int(s_) for c in range(n_con) if shard_of[c] == 1 for s_ in pairs[c]})
-        sub_b = {}
-        for k in need:
-            sm = capi.Submap.synth_city(ctx_b, k, args.voxel_size, 16, args.block_min, args.block_dims,
-                                        args.truncation, args.esdf_max, 10.0, true_poses[k], args.seed)
-            sm.extract_voxel_points(1.0, 0.3, True)
-            sm.release_raw_layers()
-            sub_b[k] = sm
-        cfs_m = [capi.RegistrationCostFunction(ctx, submaps[a], submaps[b], cfg) if shard_of[c] == 0 else
-                 capi.RegistrationCostFunction(ctx_b, sub_b[int(a)], sub_b[int(b)], cfg)
-                 for c, (a, b) in enumerate(pairs)]
-        multi = capi.RegistrationMulti([ctx, ctx_b], cfs_m, pairs)
-        for _ in range(2):
-            fused_m, _ = multi.evaluate_fused(poses)
-        m0 = time.perf_counter()
-        for _ in range(args.steps):
-            fused_m, _ = multi.evaluate_fused(poses)
-        m_ms = (time.perf_counter() - m0) / args.steps * 1e3
-        single = GpuBackendLite(capi, ctx, batch, n_sub, torch)
-        single._poses = poses
-        for _ in range(2):
-            ref_buf = single()
-        s0_ = time.perf_counter()
-        for _ in range(args.steps):
-            ref_buf = single()
-        s_ms = (time.perf_counter() - s0_) / args.steps * 1e3
-        multi_ctx = {"contexts": 2, "devices": 1, "what": "vgx_reg_multi_evaluate_fused (LPT shard, one host thread per "
-                     "context, event-ordered fixed-order sum on context 0, result on the host) vs the single batch "
-                     "(evaluate + assemble + copy to the host), same GPU",
-                     "ms_per_evaluation": m_ms, "single_batch_ms_per_evaluation": s_ms,
-                     "max_rel_diff_vs_single_batch": float(np.abs(fused_m - ref_buf).max() / np.abs(ref_buf).max())}
-        multi.destroy()
-        for o in cfs_m + list(sub_b.values()):
-            o.destroy()
-        ctx_b.close()
+    if not args.no_fused and not args.no_multi_ctx:
+        barrier()
+        if rank == 0:
+            if world > 1:
+                devices = [0] * world if dryrun else list(range(world))
+            elif args.inprocess:
+                devices = [0] * args.gpus if dryrun else list(range(args.gpus))
+            else:
+                devices = [local_rank, local_rank]
+            multi_ctx = multi_context_bench(capi, ctx, torch, args, devices, submaps, true_poses, pairs, weights_bytes,
+                                            poses, cfg, batch if world == 1 else None, n_sub, n_con)
+        barrier()
 
     # ---- metric 2: full pose-graph solve (harness LM, stand-in for ceres::Solve) ---
     solve = None
@@ -1205,6 +1243,7 @@ def main():
             "metric": "Mresiduals+Jacobians/s per GPU; full pose-graph solve ms (200 submaps)",
             "value": value, "unit": "Mresiduals+Jacobians/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "inprocess_gpus": args.gpus if args.inprocess else None,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" if not dryrun else f"synthetic (DRY RUN: all ranks on one GPU, {dryrun})",

@@ -97,7 +97,28 @@ def test_two_rank_path_dry_run_on_one_gpu(single):
     assert abs(d["solve"]["final_cost"] - single["solve"]["final_cost"]) <= 1e-9 * single["solve"]["final_cost"]
     assert abs(d["solve"]["position_rmse_m_after"] - single["solve"]["position_rmse_m_after"]) < 1e-7
     assert abs(d["fused"]["cost"] - single["fused"]["cost"]) <= 1e-9 * single["fused"]["cost"]
+    # the driver's N > 1 runs also drive the in-process multi-GPU component (rank 0, all N devices; here both
+    # contexts on the one GPU): same fused buffer as the all-reduced one
+    mc = d["multi_context"]
+    assert mc["contexts"] == 2 and mc["ms_per_evaluation"] > 0
+    assert abs(mc["cost"] - d["fused"]["cost"]) <= 1e-9 * d["fused"]["cost"]
     # config 5 sharded over two ranks is the single-rank solve
     for k in ("stage1_without_registration", "stage2_all_constraints"):
         assert d["config5"][k]["iterations"] == single["config5"][k]["iterations"], k
     assert abs(d["config5"]["position_rmse_m_aligned_after"] - single["config5"]["position_rmse_m_aligned_after"]) < 1e-7
+
+
+def test_inprocess_flag_dry_run_on_one_gpu(single):
+    """`bench.py --gpus 2 --inprocess`: ONE process, two contexts (here both on the one GPU), the headline loop
+    on context 0 and vgx_reg_multi_evaluate_fused over both in `multi_context` -- same line, same keys"""
+    env = dict(os.environ, VGX_BENCH_DRYRUN="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--inprocess", "--no-cpu-baseline",
+                        "--no-config5", "--no-config2", "--no-solve", "--no-shipped"] + SMALL,
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 1 and d["inprocess_gpus"] == 2
+    mc = d["multi_context"]
+    assert mc["contexts"] == 2 and mc["device_ids"] == [0, 0] and sum(mc["constraints_per_context"]) == d["config"]["constraints"]
+    assert mc["max_rel_diff_vs_single_batch"] < 1e-9
+    assert abs(mc["cost"] - single["fused"]["cost"]) <= 1e-9 * single["fused"]["cost"]

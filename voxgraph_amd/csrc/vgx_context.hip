@@ -40,8 +40,7 @@ __global__ __launch_bounds__(256) void brickify_kernel(
     int3 lut_min, int3 lut_dim, const float* __restrict__ distance,
     const float* __restrict__ weight, const uint8_t* __restrict__ observed,
     float* __restrict__ bricks) {
-  constexpr int B = VPS + 1;
-  constexpr int CELLS = B * B * B;
+  constexpr int CELLS = BrickLayout<VPS>::cells;
   constexpr int VOX = VPS * VPS * VPS;
   const int b = blockIdx.x;
   const int bx = block_index[3 * b + 0] - lut_min.x;
@@ -49,9 +48,11 @@ __global__ __launch_bounds__(256) void brickify_kernel(
   const int bz = block_index[3 * b + 2] - lut_min.z;
   float* out = bricks + (size_t)b * CELLS;
   for (int cell = threadIdx.x; cell < CELLS; cell += blockDim.x) {
-    int cx = cell % B;
-    int cy = (cell / B) % B;
-    int cz = cell / (B * B);
+    int cx, cy, cz;
+    if (!BrickLayout<VPS>::decode(cell, cx, cy, cz)) {
+      out[cell] = 0.0f;  // padding, never read
+      continue;
+    }
     int ox = cx == VPS, oy = cy == VPS, oz = cz == VPS;
     int sx = bx + ox, sy = by + oy, sz = bz + oz;
     int slot = b;
@@ -76,8 +77,8 @@ int launch_brickify(vgx_submap sm, int which) {
   const float* dist = which == 0 ? sm->d_tsdf_distance : sm->d_esdf_distance;
   const float* w = which == 0 ? sm->d_tsdf_weight : nullptr;
   const uint8_t* obs = which == 0 ? nullptr : sm->d_esdf_observed;
-  const int B = sm->vps + 1;
-  size_t bytes = (size_t)sm->n_blocks * B * B * B * sizeof(float);
+  const size_t cells = sm->vps == 16 ? BrickLayout<16>::cells : BrickLayout<8>::cells;
+  size_t bytes = (size_t)sm->n_blocks * cells * sizeof(float);
   VGX_HIP(ctx, hipMalloc(&sm->grid[which].d_bricks, bytes));
   int3 mn = make_int3(sm->lut_min[0], sm->lut_min[1], sm->lut_min[2]);
   int3 dm = make_int3(sm->lut_dim[0], sm->lut_dim[1], sm->lut_dim[2]);

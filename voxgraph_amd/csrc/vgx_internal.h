@@ -25,8 +25,53 @@ namespace vgx {
 // blocks for index == vps, so the 8 trilinear neighbours of any base voxel of
 // block b live in ONE brick.  Invalid voxels (unobserved / zero weight /
 // missing neighbour block) are stored as NaN: validity travels with the value.
+// Brick layouts (compile-time choice, VGX_BRICK_LAYOUT; profiles/ab_layout.sh builds and times them):
+//   0  apron brick: (vps+1)^3 floats, x fastest.  A neighbourhood is four 8-byte x-pairs in four rows
+//      (y, z), (y, z+1), (y+1, z), (y+1, z+1): 68 B, 1156 B apart -> four cache lines.  1.2 x memory.
+//   1  quad brick: for every x in [0, vps], y, z in [0, vps) the float4 {d(x,y,z), d(x,y+1,z), d(x,y,z+1),
+//      d(x,y+1,z+1)}, x fastest.  A neighbourhood is two consecutive float4: 32 contiguous bytes.
+//      4.25 x memory.
+//   2  4^3 sub-tiles with their own aprons (5^3 floats, padded to 128): the four x-pairs of a
+//      neighbourhood lie within 128 B.  2 x memory.
+#ifndef VGX_BRICK_LAYOUT
+#define VGX_BRICK_LAYOUT 0
+#endif
+template <int VPS>
+struct BrickLayout {
+  static constexpr int B = VPS + 1;
+#if VGX_BRICK_LAYOUT == 0
+  static constexpr int cells = B * B * B;
+  __host__ __device__ static int anchor(int vx, int vy, int vz) { return vx + B * (vy + B * vz); }
+  // brick float index -> apron cell (cx, cy, cz in [0, VPS]); false: padding
+  __host__ __device__ static bool decode(int i, int& cx, int& cy, int& cz) {
+    cx = i % B; cy = (i / B) % B; cz = i / (B * B);
+    return true;
+  }
+#elif VGX_BRICK_LAYOUT == 1
+  static constexpr int cells = B * VPS * VPS * 4;
+  __host__ __device__ static int anchor(int vx, int vy, int vz) { return 4 * (vx + B * (vy + VPS * vz)); }
+  __host__ __device__ static bool decode(int i, int& cx, int& cy, int& cz) {
+    const int comp = i & 3, e = i >> 2;
+    cx = e % B; cy = (e / B) % VPS + (comp & 1); cz = e / (B * VPS) + (comp >> 1);
+    return true;
+  }
+#else
+  static constexpr int S = VPS / 4;
+  static constexpr int cells = S * S * S * 128;
+  __host__ __device__ static int anchor(int vx, int vy, int vz) {
+    return 128 * ((vx >> 2) + S * ((vy >> 2) + S * (vz >> 2))) + (vx & 3) + 5 * ((vy & 3) + 5 * (vz & 3));
+  }
+  __host__ __device__ static bool decode(int i, int& cx, int& cy, int& cz) {
+    const int s = i >> 7, k = i & 127;
+    if (k >= 125) return false;
+    cx = 4 * (s % S) + k % 5; cy = 4 * ((s / S) % S) + (k / 5) % 5; cz = 4 * (s / (S * S)) + k / 25;
+    return true;
+  }
+#endif
+};
+
 struct GridDev {
-  const float* bricks;   // [n_blocks][(vps+1)^3]
+  const float* bricks;   // [n_blocks][BrickLayout<vps>::cells]
   const int32_t* lut;    // dense block lookup [dim.z][dim.y][dim.x] -> brick or -1
   int32_t lut_min[3];
   int32_t lut_dim[3];

@@ -150,17 +150,29 @@ struct PointEval {
 
 template <int VPS>
 __device__ __forceinline__ void load_neighbours(const float* cell, float d[8]) {
-  constexpr int B = VPS + 1;
-  // neighbour k sits at base + (k>>2 & 1, k>>1 & 1, k & 1); x is the
-  // contiguous axis, so (k, k+4) is one 8-byte load
+  // neighbour k sits at base + (k>>2 & 1, k>>1 & 1, k & 1)
+#if VGX_BRICK_LAYOUT == 1
+  // quad brick: {(y,z), (y+1,z), (y,z+1), (y+1,z+1)} of x, then of x + 1
+  const f32x4 q0 = *(const VGX_GLOBAL f32x4*)(cell);
+  const f32x4 q1 = *(const VGX_GLOBAL f32x4*)(cell + 4);
+  d[0] = q0.x; d[2] = q0.y; d[1] = q0.z; d[3] = q0.w;
+  d[4] = q1.x; d[6] = q1.y; d[5] = q1.z; d[7] = q1.w;
+#else
+#if VGX_BRICK_LAYOUT == 0
+  constexpr int SY = VPS + 1, SZ = (VPS + 1) * (VPS + 1);
+#else
+  constexpr int SY = 5, SZ = 25;
+#endif
+  // x is the contiguous axis, so (k, k+4) is one 8-byte load
   f32x2 p0 = *(const VGX_GLOBAL f32x2u*)(cell);
-  f32x2 p1 = *(const VGX_GLOBAL f32x2u*)(cell + B * B);
-  f32x2 p2 = *(const VGX_GLOBAL f32x2u*)(cell + B);
-  f32x2 p3 = *(const VGX_GLOBAL f32x2u*)(cell + B + B * B);
+  f32x2 p1 = *(const VGX_GLOBAL f32x2u*)(cell + SZ);
+  f32x2 p2 = *(const VGX_GLOBAL f32x2u*)(cell + SY);
+  f32x2 p3 = *(const VGX_GLOBAL f32x2u*)(cell + SY + SZ);
   d[0] = p0.x; d[4] = p0.y;
   d[1] = p1.x; d[5] = p1.y;
   d[2] = p2.x; d[6] = p2.y;
   d[3] = p3.x; d[7] = p3.y;
+#endif
 }
 
 // Branch-free two-stage point location + load_neighbours used by the kernels: all
@@ -200,8 +212,7 @@ __device__ __forceinline__ Located locate_stage1(const GridDev& g, const PosePac
   int cx = min(max(bx, 0), g.lut_dim[0] - 1), cy = min(max(by, 0), g.lut_dim[1] - 1),
       cz = min(max(bz, 0), g.lut_dim[2] - 1);
   L.lut_index = cx + g.lut_dim[0] * (cy + g.lut_dim[1] * cz);
-  constexpr int B = VPS + 1;
-  L.cell_off = vx + B * (vy + B * vz);
+  L.cell_off = BrickLayout<VPS>::anchor(vx, vy, vz);
   return L;
 }
 
@@ -541,7 +552,7 @@ __device__ __forceinline__ void reg_eval_points_body(
     int slot[PPT];
 #pragma unroll
     for (int j = 0; j < PPT; ++j) slot[j] = as_global(g.lut)[loc[j].lut_index];
-    constexpr int CELLS = (VPS + 1) * (VPS + 1) * (VPS + 1);
+    constexpr int CELLS = BrickLayout<VPS>::cells;
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
       have[j] = loc[j].inside && slot[j] >= 0;
@@ -772,7 +783,7 @@ __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_ker
       int slot[PPT];
 #pragma unroll
       for (int j = 0; j < PPT; ++j) slot[j] = as_global(g.lut)[loc[j].lut_index];
-      constexpr int CELLS = (VPS + 1) * (VPS + 1) * (VPS + 1);
+      constexpr int CELLS = BrickLayout<VPS>::cells;
       bool any = false;
 #pragma unroll
       for (int j = 0; j < PPT; ++j) {
@@ -784,7 +795,7 @@ __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_ker
       if (kBallotSkip && !count_misses && __builtin_amdgcn_ballot_w64(any) == 0ull) continue;
 #pragma unroll
       for (int j = 0; j < PPT; ++j) {
-        // 32-bit offsets: a grid holds < 2^31 floats (4096 bricks of 17^3 = 20 M)
+        // 32-bit offsets: a grid holds < 2^31 floats (4096 quad bricks of 17 408 floats = 71 M)
         const unsigned off = (unsigned)(have[j] ? slot[j] : 0) * (unsigned)CELLS + (unsigned)loc[j].cell_off;
         load_neighbours<VPS>(g.bricks + off, d[j]);
       }
