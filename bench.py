@@ -673,6 +673,23 @@ def multi_context_bench(capi, ctx0, torch, args, devices, submaps0, true_poses, 
            "Mresiduals_per_s": float(sum(cf.num_residuals() for cf in cfs_m)) / m_ms / 1e3,
            "constraints_per_context": [int((shard_of == k).sum()) for k in range(n_ctx)],
            "cost": float(fused_m[0]), "setup_s": setup_s}
+    if len(set(devices)) == n_ctx and n_ctx > 1:
+        # SURVEY.md 8(e) "compare": the same evaluation with ONE ncclAllReduce of the fused buffer instead of
+        # the fixed-order sum over peer mappings
+        try:
+            multi.set_reduction(True)
+            for _ in range(2):
+                fused_r, _ = multi.evaluate_fused(poses)
+            r0 = time.perf_counter()
+            for _ in range(args.steps):
+                fused_r, _ = multi.evaluate_fused(poses)
+            out["rccl_allreduce"] = {"ms_per_evaluation": (time.perf_counter() - r0) / args.steps * 1e3,
+                                     "max_rel_diff_vs_peer_sum": float(np.abs(fused_r - fused_m).max() / np.abs(fused_m).max()),
+                                     "what": "vgx_reg_multi_set_reduction(VGX_REDUCE_RCCL): ncclAllReduce(sum, f64) in place "
+                                             "on every context's stream, one communicator per context"}
+            multi.set_reduction(False)
+        except Exception as e:                                   # never sink the line on the optional variant
+            out["rccl_allreduce"] = {"error": repr(e)}
     if single_batch is not None:
         single = GpuBackendLite(capi, ctx0, single_batch, n_sub, torch)
         single._poses = poses

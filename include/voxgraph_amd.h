@@ -320,6 +320,14 @@ VGX_API int vgx_reg_multi_create(int32_t n_ctx, const vgx_ctx* ctxs, int32_t n, 
                                  const int32_t* node_pair /* [n][2] */, vgx_reg_multi* out);
 VGX_API int vgx_reg_multi_destroy(vgx_reg_multi multi);
 VGX_API int32_t vgx_reg_multi_num_shards(vgx_reg_multi multi);
+/* How the contexts' fused buffers meet (default VGX_REDUCE_PEER_SUM: context 0 sums them in context
+ * order through peer mappings -- bitwise reproducible).  VGX_REDUCE_RCCL: ONE ncclAllReduce(sum, f64)
+ * of the buffer per solver evaluation over xGMI (BASELINE north_star; librccl.so is opened at run time,
+ * one communicator per context from ncclCommInitAll, so every context needs its own device);
+ * VGX_ERR_UNSUPPORTED if RCCL cannot be opened or two contexts share a device. */
+#define VGX_REDUCE_PEER_SUM 0
+#define VGX_REDUCE_RCCL 1
+VGX_API int vgx_reg_multi_set_reduction(vgx_reg_multi multi, int32_t reduction);
 VGX_API int vgx_reg_multi_shard_of(vgx_reg_multi multi, int32_t* shard_of /* [n] */);
 /* One solver evaluation: every context runs vgx_reg_batch_evaluate_normal + vgx_reg_batch_assemble on
  * its share concurrently (own thread, own stream); context 0 then sums the per-context buffers in

@@ -149,3 +149,32 @@ def test_a_context_without_constraints_and_foreign_constraints(capi, world):
     third.close()
     for o in cfs:
         o.destroy()
+
+
+def test_rccl_reduction_variant(capi, world):
+    """vgx_reg_multi_set_reduction(VGX_REDUCE_RCCL): one ncclAllReduce of the fused buffer per evaluation
+    instead of the fixed-order peer sum (BASELINE north_star names an RCCL all-reduce of the stacked
+    J^T r).  RCCL wants one device per rank, so on a one-GPU box the variant can only run with ONE
+    context (communicator of size 1: the whole call sequence -- dlopen, ncclCommInitAll, grouped
+    ncclAllReduce on the context's stream, copy back -- with a trivial reduction); two contexts on one
+    device must be refused, not hang."""
+    ctxs, subs, poses = world["ctxs"], world["subs"], world["poses"]
+    cfg = capi.default_config(registration_point_type=capi.POINTS_VOXELS)
+    cfs = [capi.RegistrationCostFunction(ctxs[0], subs[0][a], subs[0][b], cfg) for a, b in PAIRS]
+    one = capi.RegistrationMulti(ctxs[:1], cfs, PAIRS)
+    want, _ = one.evaluate_fused(poses)
+    one.set_reduction(True)
+    for _ in range(2):
+        got, status = one.evaluate_fused(poses)
+        assert np.all(status == 0) and np.array_equal(got, want)
+    one.set_reduction(False)
+    assert np.array_equal(one.evaluate_fused(poses)[0], want)
+    one.destroy()
+    cfs1 = [capi.RegistrationCostFunction(ctxs[1], subs[1][a], subs[1][b], cfg) for a, b in PAIRS[:2]]
+    two = capi.RegistrationMulti(ctxs, cfs[:3] + cfs1, PAIRS[:3] + PAIRS[:2])
+    with pytest.raises(capi.VgxError):
+        two.set_reduction(True)                          # both contexts sit on device 0
+    two.evaluate_fused(poses)                            # still usable with the default reduction
+    two.destroy()
+    for o in cfs + cfs1:
+        o.destroy()

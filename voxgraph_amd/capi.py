@@ -127,6 +127,7 @@ SIGNATURES = {
     "vgx_reg_multi_create": (C.c_int, [C.c_int32, C.POINTER(vp), C.c_int32, C.POINTER(vp), i32p, C.POINTER(vp)]),
     "vgx_reg_multi_destroy": (C.c_int, [vp]),
     "vgx_reg_multi_num_shards": (C.c_int32, [vp]),
+    "vgx_reg_multi_set_reduction": (C.c_int, [vp, C.c_int32]),
     "vgx_reg_multi_shard_of": (C.c_int, [vp, i32p]),
     "vgx_reg_multi_evaluate_fused": (C.c_int, [vp, f64p, C.c_int32, f64p, i32p]),
     "vgx_reg_multi_evaluate_normal": (C.c_int, [vp, f64p, C.c_int32, f64p, i32p]),
@@ -548,6 +549,10 @@ class RegistrationMulti:
         self.ctxs[0].check(self.ctxs[0].lib.vgx_reg_multi_evaluate_fused(
             self.h, _ptr(poses, f64p), poses.shape[0], _ptr(out, f64p), _ptr(status, i32p)))
         return out, status[:self.n]
+
+    def set_reduction(self, rccl):
+        """False: fixed-order sum over peer mappings (default); True: one ncclAllReduce per evaluation"""
+        self.ctxs[0].check(self.ctxs[0].lib.vgx_reg_multi_set_reduction(self.h, 1 if rccl else 0))
 
     def evaluate_normal(self, poses):
         poses = _f64(poses).reshape(-1, 4)

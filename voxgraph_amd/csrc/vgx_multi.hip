@@ -13,12 +13,16 @@
 // all-reduce whose ring order depends on the communicator.  The same sharding with one process
 // per GPU and an RCCL all-reduce (what bench.py's torchrun launch does) uses the same entry
 // points underneath (vgx_lpt_shards, vgx_reg_batch_*).
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <condition_variable>
 #include <cstring>
 #include <memory>
 #include <numeric>
 #include <thread>
+
+#include <rccl/rccl.h>  // types and prototypes only: the library is opened at run time (RcclApi)
 
 #include "vgx_internal.h"
 
@@ -38,6 +42,41 @@ __global__ void multi_sum_kernel(SumArgs a, long long n, double* __restrict__ ou
   double v = a.src[0][i];
   for (int k = 1; k < a.n_src; ++k) v += a.src[k][i];
   out[i] = v;
+}
+
+// RCCL, opened on demand (VGX_REDUCE_RCCL): the alternative reduction SURVEY.md 8(e) asks to compare --
+// ONE ncclAllReduce(sum, f64) of the fused buffer per solver evaluation over xGMI, every context
+// contributing its own assembled buffer in place.  No link-time dependency: librccl.so.1 is whatever
+// copy the process already has (PyTorch's, when the bench drives this) or the ROCm one.
+struct RcclApi {
+  void* handle = nullptr;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  bool ok() const { return handle && CommInitAll && CommDestroy && AllReduce && GroupStart && GroupEnd && GetErrorString; }
+};
+
+static RcclApi& rccl_api() {
+  static RcclApi api = [] {
+    RcclApi a;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      a.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (a.handle) break;
+    }
+    if (a.handle) {
+      a.CommInitAll = (decltype(a.CommInitAll))dlsym(a.handle, "ncclCommInitAll");
+      a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.handle, "ncclCommDestroy");
+      a.AllReduce = (decltype(a.AllReduce))dlsym(a.handle, "ncclAllReduce");
+      a.GroupStart = (decltype(a.GroupStart))dlsym(a.handle, "ncclGroupStart");
+      a.GroupEnd = (decltype(a.GroupEnd))dlsym(a.handle, "ncclGroupEnd");
+      a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.handle, "ncclGetErrorString");
+    }
+    return a;
+  }();
+  return api;
 }
 
 }  // namespace vgx
@@ -74,6 +113,9 @@ struct vgx_reg_multi_s {
   double* h_sum = nullptr;         // pinned
   int64_t sum_cap = 0;
   std::mutex call_mu;              // one evaluation at a time
+  // VGX_REDUCE_RCCL: one communicator per shard (ncclCommInitAll over the shards' devices)
+  int reduction = VGX_REDUCE_PEER_SUM;
+  std::vector<ncclComm_t> comms;
 };
 
 static void run_shard(vgx_reg_multi_s* m, vgx_reg_multi_s::Shard& s) {
@@ -157,6 +199,8 @@ int vgx_reg_multi_destroy(vgx_reg_multi m) {
   m->go.notify_all();
   for (auto& s : m->shards)
     if (s->th.joinable()) s->th.join();
+  for (ncclComm_t c : m->comms)
+    if (c) (void)rccl_api().CommDestroy(c);
   for (auto& s : m->shards) {
     (void)hipSetDevice(s->ctx->device);
     if (s->batch) vgx_reg_batch_destroy(s->batch);
@@ -244,6 +288,31 @@ int vgx_reg_multi_create(int32_t n_ctx, const vgx_ctx* ctxs, int32_t n, const vg
 
 int32_t vgx_reg_multi_num_shards(vgx_reg_multi m) { return m ? (int32_t)m->shards.size() : -1; }
 
+int vgx_reg_multi_set_reduction(vgx_reg_multi m, int32_t reduction) {
+  if (!m || (reduction != VGX_REDUCE_PEER_SUM && reduction != VGX_REDUCE_RCCL)) return VGX_ERR_INVALID;
+  std::lock_guard<std::mutex> call(m->call_mu);
+  vgx_ctx ctx0 = m->shards[0]->ctx;
+  if (reduction == VGX_REDUCE_RCCL && m->comms.empty()) {
+    RcclApi& api = rccl_api();
+    if (!api.ok()) return set_error(ctx0, VGX_ERR_UNSUPPORTED, "vgx_reg_multi_set_reduction: librccl.so could not be opened");
+    std::vector<int> devs;
+    for (auto& s : m->shards) devs.push_back(s->ctx->device);
+    for (size_t a = 0; a < devs.size(); ++a)
+      for (size_t b = a + 1; b < devs.size(); ++b)
+        if (devs[a] == devs[b])
+          return set_error(ctx0, VGX_ERR_UNSUPPORTED,
+                           "vgx_reg_multi_set_reduction: RCCL needs one device per context (two contexts share a device)");
+    m->comms.assign(devs.size(), nullptr);
+    ncclResult_t r = api.CommInitAll(m->comms.data(), (int)devs.size(), devs.data());
+    if (r != ncclSuccess) {
+      m->comms.clear();
+      return set_error(ctx0, VGX_ERR_HIP, std::string("ncclCommInitAll: ") + api.GetErrorString(r));
+    }
+  }
+  m->reduction = reduction;
+  return VGX_OK;
+}
+
 int vgx_reg_multi_shard_of(vgx_reg_multi m, int32_t* shard_of) {
   if (!m || !shard_of) return VGX_ERR_INVALID;
   std::copy(m->shard_of.begin(), m->shard_of.end(), shard_of);
@@ -286,18 +355,36 @@ int vgx_reg_multi_evaluate_fused(vgx_reg_multi m, const double* poses, int32_t n
       if (s->rc != VGX_OK) return set_error(ctx0, s->rc, std::string("vgx_reg_multi: shard failed: ") + vgx_last_error(s->ctx));
     return rc;
   }
-  // one reduction per solver evaluation, on shard 0's stream, in shard order
-  VGX_HIP(ctx0, hipSetDevice(ctx0->device));
-  SumArgs a{};
-  a.n_src = (int)m->shards.size();
-  for (int k = 0; k < a.n_src; ++k) {
-    a.src[k] = m->shards[(size_t)k]->d_fused;
-    if (k > 0) VGX_HIP(ctx0, hipStreamWaitEvent(ctx0->stream, m->shards[(size_t)k]->done, 0));
+  const double* d_result = m->d_sum;
+  if (m->reduction == VGX_REDUCE_RCCL) {
+    // one all-reduce per solver evaluation: every context's buffer in place, each on its own stream
+    // (behind that context's evaluation and assembly); context 0's copy goes to the host
+    RcclApi& api = rccl_api();
+    ncclResult_t r = api.GroupStart();
+    for (size_t k = 0; k < m->shards.size() && r == ncclSuccess; ++k) {
+      vgx_reg_multi_s::Shard& s = *m->shards[k];
+      if (hipSetDevice(s.ctx->device) != hipSuccess) return set_error(ctx0, VGX_ERR_HIP, "hipSetDevice");
+      r = api.AllReduce(s.d_fused, s.d_fused, (size_t)size, ncclDouble, ncclSum, m->comms[k], s.ctx->stream);
+    }
+    ncclResult_t r2 = api.GroupEnd();
+    if (r == ncclSuccess) r = r2;
+    if (r != ncclSuccess) return set_error(ctx0, VGX_ERR_HIP, std::string("ncclAllReduce: ") + api.GetErrorString(r));
+    VGX_HIP(ctx0, hipSetDevice(ctx0->device));
+    d_result = m->shards[0]->d_fused;
+  } else {
+    // one reduction per solver evaluation, on shard 0's stream, in shard order
+    VGX_HIP(ctx0, hipSetDevice(ctx0->device));
+    SumArgs a{};
+    a.n_src = (int)m->shards.size();
+    for (int k = 0; k < a.n_src; ++k) {
+      a.src[k] = m->shards[(size_t)k]->d_fused;
+      if (k > 0) VGX_HIP(ctx0, hipStreamWaitEvent(ctx0->stream, m->shards[(size_t)k]->done, 0));
+    }
+    hipLaunchKernelGGL(multi_sum_kernel, dim3((unsigned)((size + 255) / 256)), dim3(256), 0, ctx0->stream, a,
+                       (long long)size, m->d_sum);
+    VGX_HIP(ctx0, hipGetLastError());
   }
-  hipLaunchKernelGGL(multi_sum_kernel, dim3((unsigned)((size + 255) / 256)), dim3(256), 0, ctx0->stream, a,
-                     (long long)size, m->d_sum);
-  VGX_HIP(ctx0, hipGetLastError());
-  VGX_HIP(ctx0, hipMemcpyAsync(m->h_sum, m->d_sum, (size_t)size * sizeof(double), hipMemcpyDeviceToHost, ctx0->stream));
+  VGX_HIP(ctx0, hipMemcpyAsync(m->h_sum, d_result, (size_t)size * sizeof(double), hipMemcpyDeviceToHost, ctx0->stream));
   VGX_HIP(ctx0, hipStreamSynchronize(ctx0->stream));
   std::memcpy(fused_host, m->h_sum, (size_t)size * sizeof(double));
   if (status)
