@@ -420,6 +420,10 @@ VGX_API int vgx_tsdf_layer_stats(vgx_tsdf_layer layer, int32_t* n_blocks,
  * reach_m metres (max_ray_length + truncation), so that the first scans there do not pay for the
  * enlargement.  Scans reserve for themselves anyway. */
 VGX_API int vgx_tsdf_layer_reserve(vgx_tsdf_layer layer, const float origin[3], float reach_m);
+/* Acknowledges dropped updates (the GPU ran out of memory during an earlier scan: integrate calls keep
+ * failing with VGX_ERR_NOMEM until then) and resets the counter, after the caller has made room or
+ * decided to live with the hole.  Waits for the scans in flight. */
+VGX_API int vgx_tsdf_layer_clear_dropped(vgx_tsdf_layer layer);
 /* how often the layer has enlarged its block table or pool so far (diagnostics) */
 VGX_API int64_t vgx_tsdf_layer_growths(vgx_tsdf_layer layer);
 /* block_index[n][3], distance / weight [n][vps^3], rgba [n][vps^3][4]; any may be NULL */

@@ -114,6 +114,10 @@ def test_tsdf_initial_box_and_pool_are_only_a_reservation(capi, ctx):
     n2 = integ2.integratePointCloud(T, np.array([[3.0, 0, 0]], F))
     blocks2, dropped2 = layer2.stats()
     assert blocks2 == 3 and n2 == 34 and dropped2 == 0 and layer2.growths() >= 1
+    # acknowledging dropped updates (none here) is harmless and leaves the layer usable
+    layer2.clear_dropped()
+    assert layer2.stats() == (3, 0)
+    assert integ2.integratePointCloud(T, np.array([[0.0, 2.5, 0]], F)) > 0 and layer2.stats()[1] == 0
     with pytest.raises(capi.VgxError):
         capi.TsdfLayer(ctx, 0.1, 16, (0, 0, 0), (0, 1, 1), 8)
     with pytest.raises(capi.VgxError):

@@ -140,6 +140,7 @@ SIGNATURES = {
     "vgx_tsdf_layer_destroy": (C.c_int, [vp]),
     "vgx_tsdf_layer_stats": (C.c_int, [vp, i32p, i64p]),
     "vgx_tsdf_layer_reserve": (C.c_int, [vp, f32p, C.c_float]),
+    "vgx_tsdf_layer_clear_dropped": (C.c_int, [vp]),
     "vgx_tsdf_layer_growths": (C.c_int64, [vp]),
     "vgx_tsdf_layer_download": (C.c_int, [vp, i32p, f32p, f32p, u8p]),
     "vgx_tsdf_layer_upload": (C.c_int, [vp, C.c_int32, i32p, f32p, f32p, u8p]),
@@ -648,6 +649,9 @@ class TsdfLayer:
 
     def growths(self):
         return int(self.ctx.lib.vgx_tsdf_layer_growths(self.h))
+
+    def clear_dropped(self):
+        self.ctx.check(self.ctx.lib.vgx_tsdf_layer_clear_dropped(self.h))
 
     def reserve(self, origin, reach_m):
         o = _f32(origin)

@@ -713,20 +713,30 @@ int reserve_for_scan(vgx_tsdf_layer L, const float origin[3], float reach) {
     hi[a] = (int32_t)std::floor((origin[a] + reach) * bs_inv) + 1;
   }
   // upper bound on the blocks this scan can allocate: the blocks that come within `reach` of the
-  // origin (about half of the bounding cube; a few thousand cells to test)
-  int64_t bound = 0;
-  for (int32_t z = lo[2]; z <= hi[2]; ++z)
-    for (int32_t y = lo[1]; y <= hi[1]; ++y)
-      for (int32_t x = lo[0]; x <= hi[0]; ++x) {
-        const int32_t b[3] = {x, y, z};
-        float d2 = 0.0f;
-        for (int a = 0; a < 3; ++a) {
-          const float mn = (float)b[a] * bs, mx = mn + bs;
-          const float g = origin[a] < mn ? mn - origin[a] : (origin[a] > mx ? origin[a] - mx : 0.0f);
-          d2 += g * g;
+  // origin, WHEREVER in its block the origin sits (a block whose box comes within reach of some point of
+  // the unit block around the origin: box-to-box distance).  A function of `reach` alone, so it is
+  // computed once per reach and block size, not per scan (the per-scan triple loop grew as
+  // (reach / block size)^3).
+  if (L->bound_reach != reach) {
+    const int32_t r = (int32_t)std::ceil(reach * bs_inv) + 1;
+    int64_t count = 0;
+    const float lim = (reach + bs * 0.01f) * (reach + bs * 0.01f);
+    for (int32_t z = -r; z <= r; ++z)
+      for (int32_t y = -r; y <= r; ++y)
+        for (int32_t x = -r; x <= r; ++x) {
+          const int32_t b[3] = {x, y, z};
+          float d2 = 0.0f;
+          for (int a = 0; a < 3; ++a) {
+            // gap between block b[a] and the origin's own block (index 0) along this axis
+            const float g = b[a] > 0 ? (float)(b[a] - 1) * bs : (b[a] < 0 ? (float)(-b[a] - 1) * bs : 0.0f);
+            d2 += g * g;
+          }
+          if (d2 <= lim) ++count;
         }
-        if (d2 <= (reach + bs * 0.01f) * (reach + bs * 0.01f)) ++bound;
-      }
+    L->bound_reach = reach;
+    L->bound_blocks = count;
+  }
+  const int64_t bound = L->bound_blocks;
   // 1. the box
   bool inside = L->lut_cells > 0;
   for (int a = 0; a < 3 && inside; ++a) inside = lo[a] >= d.lut_min[a] && hi[a] < d.lut_min[a] + d.lut_dim[a];
@@ -876,6 +886,19 @@ int vgx_tsdf_layer_stats(vgx_tsdf_layer L, int32_t* n_blocks, int64_t* dropped) 
 }
 
 int64_t vgx_tsdf_layer_growths(vgx_tsdf_layer L) { return L ? L->growths : -1; }
+
+int vgx_tsdf_layer_clear_dropped(vgx_tsdf_layer L) {
+  if (!L) return VGX_ERR_INVALID;
+  vgx_ctx ctx = L->ctx;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  VGX_HIP(ctx, hipSetDevice(ctx->device));
+  VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  VGX_HIP(ctx, hipMemsetAsync(L->dev.dropped, 0, 8, ctx->stream));
+  VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  L->dropped_seen = 0;
+  L->readback_inflight = false;  // a read-back in flight may still carry the old count
+  return VGX_OK;
+}
 
 int vgx_tsdf_layer_reserve(vgx_tsdf_layer L, const float origin[3], float reach_m) {
   if (!L || !origin || !(reach_m >= 0)) return VGX_ERR_INVALID;

@@ -216,6 +216,8 @@ struct vgx_tsdf_layer_s {
   std::vector<std::pair<uint64_t, int64_t>> recent;  // (scan, bound) of scans after known_seq
   unsigned long long dropped_seen = 0;
   int64_t growths = 0;  // re-boxings + pool enlargements so far
+  float bound_reach = -1.0f;  // blocks a scan of this reach can touch (computed once per reach)
+  int64_t bound_blocks = 0;
 };
 
 struct vgx_tsdf_integrator_s {
