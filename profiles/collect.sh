@@ -21,7 +21,7 @@ export TMPDIR=/tmp
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_stats -o stats -- \
     python $REPO/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/prof_stats_bench.json 2> $OUT/prof_stats.err
-PMC_ARGS="--steps 3 --inner 1 --warmup 1 --no-cpu-baseline --no-solve --no-tsdf --no-shipped --no-config5 --no-config2 --no-fo-plain --calibrate"
+PMC_ARGS="--steps 3 --inner 1 --warmup 1 --no-cpu-baseline --no-solve --no-tsdf --no-config5 --no-config2 --no-fo-plain --no-multi-ctx --no-parity --calibrate"
 REGEX="reg_eval_points|reg_eval_reduce"
 timeout 240 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum \
     --kernel-trace -f csv --kernel-include-regex "$REGEX" \
@@ -37,14 +37,14 @@ timeout 240 rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv --kernel-include-re
 for c in rd write; do
   if [ $c = rd ]; then CNT="TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum"; else CNT="WRITE_SIZE"; fi
   VGX_POINTS_TILE_ORDER=0 timeout 300 rocprofv3 --pmc $CNT --kernel-trace -f csv --kernel-include-regex "reg_eval_points" \
-      -d $OUT/prof_${c}_plain -o ${c}_plain -- python $REPO/bench.py $PMC_ARGS --no-fused \
+      -d $OUT/prof_${c}_plain -o ${c}_plain -- python $REPO/bench.py $PMC_ARGS --no-fused --no-shipped \
       > $OUT/prof_${c}_plain_bench.json 2> $OUT/prof_${c}_plain.err
 done
 timeout 240 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES \
-    --kernel-trace -f csv --kernel-include-regex "reg_eval_points_kernel|reg_eval_reduce|tsdf_integrate" \
-    -d $OUT/prof_sq -o sq -- python $REPO/bench.py --steps 2 --inner 1 --warmup 1 --no-cpu-baseline --no-solve --no-shipped --no-config5 --no-config2 \
+    --kernel-trace -f csv --kernel-include-regex "reg_eval_points_kernel|reg_eval_reduce|tsdf_integrate|det_apply|det_seen" \
+    -d $OUT/prof_sq -o sq -- python $REPO/bench.py --steps 2 --inner 1 --warmup 1 --no-cpu-baseline --no-solve --no-shipped --no-config5 --no-config2 --no-multi-ctx --no-parity \
     > /dev/null 2> $OUT/prof_sq.err
 # un-profiled full line (what the driver will see), N = 1
 python $REPO/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_full.json 2> $OUT/bench_full.err
 cd $REPO
-python profiles/summarize.py --round ${ROUND:-02} || true
+python profiles/summarize.py --round ${ROUND:-03} || true

@@ -76,7 +76,7 @@ def by_grid(trace, kernel):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--round", default="02")
+    ap.add_argument("--round", default="03")
     a = ap.parse_args()
     tag = f"r{int(a.round):02d}"
     N_CAL = 2                                            # bench.py --calibrate: two far-pose launches
@@ -84,7 +84,7 @@ def main():
     stats = rows("prof_stats/**/*kernel_stats.csv")
     trace = rows("prof_stats/**/*kernel_trace.csv")
     bench = bench_line("prof_stats_bench.json")
-    summ = {"command": "rocprofv3 --kernel-trace --stats -f csv -- python bench.py --gpus 1 --steps 20 --warmup 5",
+    summ = {"command": "rocprofv3 --kernel-trace --stats -f csv -- python bench.py --gpus 1 --steps 20 --warmup 5 (25 passes per step)",
             "kernels": [{k: v for k, v in x.items()} for x in stats[:14]],
             "bench_line": bench, "per_workload": {}}
     pw = summ["per_workload"]
@@ -110,7 +110,10 @@ def main():
             durs = durs[:half]
         pw["full_overlap_points"] = entry(durs, fo_b["kernel_ms"], grid=pts[1][0])
     red = by_grid(trace, FUSED)
-    names = ["config3_fused", "full_overlap_fused", "shipped_config_fused", "config5_fused"]
+    # grids in order of first appearance in bench.py: config 3, full overlap, shipped (sampled), the two
+    # shards of the in-process multi-context section, config 5
+    names = ["config3_fused", "full_overlap_fused", "shipped_config_fused", "multi_context_shard0_fused",
+             "multi_context_shard1_fused", "config5_fused"]
     for (grid, durs), nm in zip(red, names):
         pw[nm] = entry(durs, grid=grid)
     if bench and "config3_fused" in pw:
@@ -214,9 +217,22 @@ def main():
     fused = {}
     if frd and fwr and pmc_bench:
         g0 = frd[0]["grid"]
+        grids = []
+        for c in frd:
+            if c["grid"] not in grids:
+                grids.append(c["grid"])
+        g1 = grids[1] if len(grids) > 1 else None
+        g2 = grids[2] if len(grids) > 2 else None
+        sh = pmc_bench.get("shipped_config")
+        sh_fb = None
+        if sh:      # the shipped (sampled) configuration: priced per residual, 52 B each (scattered draws)
+            sh_fb = {"algorithmic_bytes_per_step": 52.0 * sh["residuals_per_evaluation"],
+                     "evaluations": sh["residuals_per_evaluation"], "with_correspondence": None,
+                     "loaded_after_culling": sh["residuals_per_evaluation"]}
         for name, sel, fb in (("config3", lambda c: c["grid"] == g0, pmc_bench.get("fused")),
-                              ("full_overlap", lambda c: c["grid"] != g0,
-                               (pmc_bench.get("roofline_full_overlap") or {}).get("fused"))):
+                              ("full_overlap", lambda c: g1 is not None and c["grid"] == g1,
+                               (pmc_bench.get("roofline_full_overlap") or {}).get("fused")),
+                              ("shipped", lambda c: g2 is not None and c["grid"] == g2, sh_fb)):
             r_ = [c for c in frd if sel(c)]
             w_ = [c for c in fwr if sel(c)]
             if not r_ or not w_ or not fb:
@@ -229,7 +245,7 @@ def main():
                  "loaded_after_culling": fb["loaded_after_culling"]}
             e["hbm_bytes_per_launch"] = e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]
             e["traffic_over_algorithmic"] = e["hbm_bytes_per_launch"] / e["algorithmic_bytes_per_step"]
-            key = name + "_fused"
+            key = {"shipped": "shipped_config_fused"}.get(name, name + "_fused")
             if key in pw:
                 e["avg_ms_rocprof"] = pw[key]["avg_ms_rocprof"]
                 e["hbm_GBs_at_rocprof_avg"] = e["hbm_bytes_per_launch"] / (e["avg_ms_rocprof"] * 1e-3) / 1e9
@@ -237,11 +253,20 @@ def main():
                 e["frac_of_hbm_time"] = e["hbm_time_ms_at_8TBs"] / e["avg_ms_rocprof"]
             fused[name] = e
         json.dump(fused, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_fused.json"), "w"), indent=1)
+        # what bench.py replays as fused.*.traffic_from_profiles / hbm_frac
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            t = json.load(open(tpath))
+            t["fused"] = {k: {"evaluations": v["evaluations"], "hbm_bytes_per_launch": v["hbm_bytes_per_launch"],
+                              "avg_ms_rocprof": v.get("avg_ms_rocprof"), "source": f"profiles/{tag}_pmc_fused.json"}
+                          for k, v in fused.items()}
+            json.dump(t, open(tpath, "w"), indent=1)
     # ---- SQ wave-cycle breakdown ---------------------------------------------------------------------
     d = collections.OrderedDict()
     for r in rows("prof_sq/**/*counter_collection.csv"):
         kn = r["Kernel_Name"]
-        k = "fused" if "reduce" in kn else ("tsdf_integrate" if "tsdf" in kn else "materialising")
+        k = ("fused" if "reduce" in kn else "tsdf_integrate" if "tsdf_integrate" in kn else
+             "tsdf_reproducible_" + ("apply" if "det_apply" in kn else "seen") if "det_" in kn else "materialising")
         d.setdefault((k, int(r["Grid_Size"])), collections.defaultdict(list))[r["Counter_Name"]].append(float(r["Counter_Value"]))
     sq = {}
     for (k, grid), c in d.items():
