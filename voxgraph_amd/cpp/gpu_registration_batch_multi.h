@@ -56,6 +56,14 @@ class GpuRegistrationBatchMulti : public GpuRegistrationBlocks {
     FinalizeBlocks();
   }
 
+  // How EvaluateFused's per-GPU buffers meet: VGX_REDUCE_PEER_SUM (default: GPU 0 sums them in GPU order
+  // over xGMI peer mappings, bitwise reproducible) or VGX_REDUCE_RCCL (one ncclAllReduce per evaluation).
+  // Call after Finalize().
+  void SetReduction(int32_t reduction) {
+    if (vgx_reg_multi_set_reduction(multi_, reduction) != VGX_OK)
+      throw std::runtime_error(std::string("vgx_reg_multi_set_reduction: ") + vgx_last_error(gpus_[0]));
+  }
+
   // The assembled normal equations of every registration constraint at `poses` ([n_nodes][4], node
   // numbering = order in which pose blocks were first passed to AddConstraint):
   // [cost | J^T r (4 n) | diagonal blocks (16 n) | off-diagonal blocks (16 m)], summed over the GPUs.
