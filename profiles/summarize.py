@@ -267,12 +267,14 @@ def main():
         kn = r["Kernel_Name"]
         k = ("fused" if "reduce" in kn else "tsdf_integrate" if "tsdf_integrate" in kn else
              "tsdf_reproducible_" + ("apply" if "det_apply" in kn else "seen") if "det_" in kn else "materialising")
-        d.setdefault((k, int(r["Grid_Size"])), collections.defaultdict(list))[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        # the reproducible TSDF mode's grids change from scan to scan: one entry per kernel
+        grid = 0 if k.startswith("tsdf_reproducible") else int(r["Grid_Size"])
+        d.setdefault((k, grid), collections.defaultdict(list))[r["Counter_Name"]].append(float(r["Counter_Value"]))
     sq = {}
     for (k, grid), c in d.items():
         m = {n: sum(v) / len(v) for n, v in c.items()}
         wc = m.get("SQ_WAVE_CYCLES", 0) or 1
-        sq[f"{k}@grid{grid}"] = {"dispatches": len(next(iter(c.values()))), **m,
+        sq[f"{k}@grid{grid}" if grid else k] = {"dispatches": len(next(iter(c.values()))), **m,
                                  "frac_wait_any": m.get("SQ_WAIT_ANY", 0) / wc,
                                  "frac_wait_inst_any": m.get("SQ_WAIT_INST_ANY", 0) / wc,
                                  "frac_active_inst_any": m.get("SQ_ACTIVE_INST_ANY", 0) / wc,
