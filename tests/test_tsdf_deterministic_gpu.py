@@ -289,3 +289,34 @@ def test_merged_integrator_reproducible_mode_fullsize(capi, ctx):
         print("merged", kind, "updates per scan", a, "blocks", nb, "observed voxels", nobs)
         for o in (gi, gl):
             o.destroy()
+
+
+def test_small_scans_and_sets_that_are_not_reset_every_frame(capi, ctx):
+    """clear_checks_every_n_frames = 3: the approximate sets keep their contents (and their offset) over
+    three scans, so what a ray finds in a slot may have been written by an EARLIER scan -- the
+    reproducible mode reads the sets' state where its own scan has no predecessor in a slot and leaves them
+    as the single thread would.  Scans of 0, 1, 2, 5, 1023, 1024, 1025 and 3000 points (the mixed
+    visiting order groups points by 1024) while the sensor moves: bit for bit after every scan."""
+    vs, vps = 0.1, 16
+    kw = dict(default_truncation_distance=0.3, max_ray_length_m=8.0, use_const_weight=1,
+              clear_checks_every_n_frames=3, max_consecutive_ray_collisions=1)
+    ol, gl = orc.TsdfLayer(vs, vps), capi.TsdfLayer(ctx, vs, vps)
+    oi = orc.FastTsdfIntegrator(orc.tsdf_config(**kw), ol)
+    gi = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(deterministic=1, **kw), gl)
+    rng = np.random.default_rng(5)
+    full = _lidar_scan(300, 10, 77, room=((-3.0, -2.5, -1.0), (3.5, 2.0, 1.5)), el=0.4)
+    for k, n in enumerate([0, 1, 2, 5, 1023, 1024, 1025, 3000, 3000, 3000, 1, 3000]):
+        origin = np.array([0.02 * k, -0.015 * k, 0.01 * k], F)
+        pts = full[rng.permutation(len(full))[:n]] - origin
+        T = np.r_[np.array([1, 0, 0, 0], F), origin].astype(F)
+        col = rng.integers(0, 256, (n, 4)).astype(np.uint8)
+        a = oi.integratePointCloud(T, pts.reshape(-1, 3), col if n else None)
+        b = gi.integratePointCloud(T, pts.reshape(-1, 3), col if n else None)
+        assert a == b, (k, n, a, b)
+        if ol.num_blocks():
+            _assert_layers_identical(ol, gl, f"scan {k} of {n} points")
+        else:
+            assert gl.stats()[0] == 0
+    assert gl.stats()[1] == 0 and ol.num_blocks() > 20
+    for o in (gi, gl):
+        o.destroy()
