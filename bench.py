@@ -1176,8 +1176,11 @@ def main():
                 devices = [0] * args.gpus if dryrun else list(range(args.gpus))
             else:
                 devices = [local_rank, local_rank]
-            multi_ctx = multi_context_bench(capi, ctx, torch, args, devices, submaps, true_poses, pairs, weights_bytes,
-                                            poses, cfg, batch if world == 1 else None, n_sub, n_con)
+            try:
+                multi_ctx = multi_context_bench(capi, ctx, torch, args, devices, submaps, true_poses, pairs, weights_bytes,
+                                                poses, cfg, batch if world == 1 else None, n_sub, n_con)
+            except Exception as e:       # an optional section must never cost the line (peer access, memory, ...)
+                multi_ctx = {"error": repr(e), "device_ids": devices}
         barrier()
 
     # ---- metric 2: full pose-graph solve (harness LM, stand-in for ceres::Solve) ---
