@@ -749,6 +749,8 @@ def main():
                          "instead of the bounded one (10 submaps x 30 scans) the default line carries")
     ap.add_argument("--no-config2", action="store_true")
     ap.add_argument("--no-multi-ctx", action="store_true")
+    ap.add_argument("--no-quad", action="store_true",
+                    help="skip the shipped configuration's second measurement on quad bricks")
     ap.add_argument("--inprocess", action="store_true",
                     help="ONE process drives --gpus N devices through vgx_reg_multi_* (the product's in-process "
                          "multi-GPU component); launch WITHOUT torch.distributed.run.  The headline loop then "
@@ -1111,43 +1113,50 @@ def main():
         shard = lpt_shards([n_iso[a] + n_iso[b] for a, b in pairs], world)[rank]
         pairs_s = [(int(a), int(b)) for c in shard for a, b in (pairs[c], pairs[c][::-1])]
         gidx_s = [2 * c + k for c in shard for k in (0, 1)]
-        cfs_s = [capi.RegistrationCostFunction(ctx, submaps[a], submaps[b], cfg_s) for a, b in pairs_s]
-        batch_s = capi.RegistrationBatch(ctx, cfs_s, pairs_s, global_index=gidx_s, n_global=2 * n_con)
         buf_s = torch.zeros(capi.fused_size(n_sub, 2 * n_con), dtype=torch.float64, device="cuda")
 
-        def shipped_step():
-            batch_s.evaluate_normal(poses, to_host=False)
-            batch_s.assemble(n_sub, buf_s.data_ptr(), zero_first=True)
-            if use_dist:
-                dist.all_reduce(buf_s)
+        def shipped_eval(ctx_s, submaps_s):
+            cfs_s = [capi.RegistrationCostFunction(ctx_s, submaps_s[a], submaps_s[b], cfg_s) for a, b in pairs_s]
+            batch_s = capi.RegistrationBatch(ctx_s, cfs_s, pairs_s, global_index=gidx_s, n_global=2 * n_con)
 
-        for _ in range(2):
-            shipped_step()
-        torch.cuda.synchronize()
-        barrier()
-        n_s = max(args.steps, 1)
-        ctx.timer_start()
-        s0 = time.perf_counter()
-        for _ in range(n_s):
-            shipped_step()
-        shipped_stream_ms = ctx.timer_stop() / n_s
-        torch.cuda.synchronize()
-        barrier()
-        sdt = torch.tensor([time.perf_counter() - s0], dtype=torch.float64, device="cuda")
-        rs = torch.tensor([float(batch_s.num_residuals())], dtype=torch.float64, device="cuda")
-        if use_dist:
-            dist.all_reduce(sdt, op=dist.ReduceOp.MAX)
-            dist.all_reduce(rs, op=dist.ReduceOp.SUM)
+            def shipped_step():
+                batch_s.evaluate_normal(poses, to_host=False)
+                batch_s.assemble(n_sub, buf_s.data_ptr(), zero_first=True)
+                if use_dist:
+                    dist.all_reduce(buf_s)
+
+            for _ in range(2):
+                shipped_step()
+            torch.cuda.synchronize()
+            barrier()
+            n_s = max(args.steps, 1)
+            ctx_s.timer_start()
+            s0 = time.perf_counter()
+            for _ in range(n_s):
+                shipped_step()
+            stream_ms = ctx_s.timer_stop() / n_s
+            torch.cuda.synchronize()
+            barrier()
+            sdt = torch.tensor([time.perf_counter() - s0], dtype=torch.float64, device="cuda")
+            rs = torch.tensor([float(batch_s.num_residuals())], dtype=torch.float64, device="cuda")
+            if use_dist:
+                dist.all_reduce(sdt, op=dist.ReduceOp.MAX)
+                dist.all_reduce(rs, op=dist.ReduceOp.SUM)
+            e = {"residuals_per_evaluation": float(rs.item()),
+                 "ms_per_evaluation": float(sdt.item()) / n_s * 1e3,
+                 "stream_ms_per_evaluation": stream_ms,
+                 "Mresiduals_per_s": float(rs.item()) * n_s / float(sdt.item()) / 1e6,
+                 "cost": float(buf_s[0].item())}
+            for o in [batch_s] + cfs_s:
+                o.destroy()
+            return e
         shipped = {"config": "registration_method explicit_to_implicit (isosurface points), sampling_ratio 0.05, "
                              "mirrored constraints, ESDF distance (voxgraph_mapper.yaml:34-35, pose_graph.cpp:62-71)",
-                   "constraints": 2 * n_con, "residuals_per_evaluation": float(rs.item()),
-                   "isosurface_points_per_submap": float(np.mean(n_iso)),
-                   "ms_per_evaluation": float(sdt.item()) / n_s * 1e3,
-                   "stream_ms_per_evaluation": shipped_stream_ms,
-                   "Mresiduals_per_s": float(rs.item()) * n_s / float(sdt.item()) / 1e6,
-                   "cost": float(buf_s[0].item()),
+                   "constraints": 2 * n_con, "isosurface_points_per_submap": float(np.mean(n_iso)),
+                   "brick_layout": "apron (the headline's submaps)",
                    "what": "one solver evaluation: device mt19937 streams + fused normal equations of every "
                            "constraint + assembly" + (" + RCCL all-reduce" if use_dist else "")}
+        shipped.update(shipped_eval(ctx, submaps))
         tr = (PROFILE_TRAFFIC.get("fused") or {}).get("shipped") or {}
         tr_bytes = tr.get("hbm_bytes_per_launch") if (tr.get("evaluations") == shipped["residuals_per_evaluation"]
                                                      and world == 1) else None
@@ -1156,8 +1165,27 @@ def main():
         shipped["hbm_frac"] = (tr_bytes / (tr["avg_ms_rocprof"] * 1e-3) / 1e9 / HBM_PEAK_GBS) \
             if (tr_bytes and tr.get("avg_ms_rocprof")) else None
         shipped["hbm_frac_note"] = "fused kernel alone: counter bytes / its rocprofv3 average duration / 8 TB/s (profiles/)"
-        for o in [batch_s] + cfs_s:
-            o.destroy()
+        if not args.no_quad:
+            # what a sampling session would configure: vgx_ctx_set_brick_layout(VGX_BRICKS_QUAD) -- the same
+            # submaps with a 2x2x2 neighbourhood in 32 contiguous bytes (scattered evaluations are bound by the
+            # 64-byte lines they touch); same draws, same results
+            ctx_q = capi.Context(local_rank)
+            ctx_q.set_stream(stream.cuda_stream)
+            ctx_q.set_brick_layout(capi.BRICKS_QUAD)
+            subs_q = []
+            for k in range(n_sub):
+                sm = capi.Submap.synth_city(ctx_q, k, args.voxel_size, 16, args.block_min, args.block_dims,
+                                            args.truncation, args.esdf_max, 10.0, true_poses[k], args.seed)
+                sm.extract_isosurface_points(1.0)
+                sm.release_raw_layers()
+                subs_q.append(sm)
+            q = shipped_eval(ctx_q, subs_q)
+            q["brick_layout"] = "quad (vgx_ctx_set_brick_layout(VGX_BRICKS_QUAD): 4.25 x the grid memory)"
+            q["cost_equals_apron"] = bool(q["cost"] == shipped["cost"])
+            shipped["quad_bricks"] = q
+            for sm in subs_q:
+                sm.destroy()
+            ctx_q.close()
 
     # ---- the in-process multi-GPU component (vgx_reg_multi_*: one process, one vgx_ctx + host thread per
     # GPU, fixed-order sum over xGMI peer mappings) -- the PRODUCT's multi-GPU path (voxgraph is one process).

@@ -58,6 +58,17 @@ VGX_API const char* vgx_last_error(vgx_ctx ctx);
  * caller's PyTorch stream).  NULL restores the context's own stream. */
 VGX_API int vgx_ctx_set_stream(vgx_ctx ctx, void* hip_stream);
 VGX_API void* vgx_ctx_get_stream(vgx_ctx ctx);
+/* How the sampling grids of the submaps created on this context FROM NOW ON are laid out in HBM (set it
+ * once, before the first submap; a batch refuses to mix layouts).  Results never depend on it.
+ *   VGX_BRICKS_APRON (default)  17^3 floats per block; fewest bytes: fastest where every registration
+ *                               point is evaluated (sampling_ratio -1).
+ *   VGX_BRICKS_QUAD             a 2x2x2 neighbourhood is 32 contiguous bytes (4.25 x the memory):
+ *                               fastest where evaluations are scattered -- the reference's shipped
+ *                               sampling_ratio 0.05 (voxgraph_mapper.yaml:34): -14 % per solver evaluation,
+ *                               at +18-25 % on the all-points passes. */
+#define VGX_BRICKS_APRON 0
+#define VGX_BRICKS_QUAD 1
+VGX_API int vgx_ctx_set_brick_layout(vgx_ctx ctx, int32_t layout);
 VGX_API int vgx_ctx_synchronize(vgx_ctx ctx);
 /* hipEvent-based timer on the context's stream (used by bench.py so that
  * the kernel time is measured on the stream the kernels run on). */

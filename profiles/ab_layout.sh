@@ -1,6 +1,8 @@
 #!/bin/bash
-# A/B of the brick layouts (VGX_BRICK_LAYOUT, vgx_internal.h): apron (default build), quad
-# (make SUFFIX=_quad EXTRA=-DVGX_BRICK_LAYOUT=1), sub-tiles (make SUFFIX=_sub EXTRA=-DVGX_BRICK_LAYOUT=2).
+# A/B of the brick layouts (vgx_internal.h) as the DEFAULT of every context: apron (default build), quad
+# (make SUFFIX=_quad EXTRA=-DVGX_BRICK_LAYOUT_DEFAULT=1), sub-tiles (make SUFFIX=_sub EXTRA=-DVGX_BRICK_LAYOUT_DEFAULT=2).
+# (At run time a context picks apron or quad with vgx_ctx_set_brick_layout; bench.py's
+# shipped_config.quad_bricks measures that.)
 #   gpurun -- 'bash profiles/ab_layout.sh'
 # Per library: the REG parity tests, then fused / materialising ms on config 3 and full overlap and the
 # shipped (sampled) configuration's ms per evaluation.  Two rounds (box drift).

@@ -35,7 +35,7 @@ def _gfx950_present():
 # listed run in the middle, in their usual order; within a file the definition order is kept.
 _ORDER = [
     # 1. REG hot path, bit-exact against the oracle / the reference's own source
-    "test_reg_gpu", "test_fullsize_gpu", "test_batch_sampling_gpu", "test_dropin_cpp_gpu",
+    "test_reg_gpu", "test_fullsize_gpu", "test_batch_sampling_gpu", "test_dropin_cpp_gpu", "test_brick_layout_gpu",
     # 2. TSDF: the order-independent (bit-exact) cases and the reproducible mode
     "test_tsdf_deterministic_gpu", "test_tsdf_gpu", "test_tsdf_merged_gpu", "test_tsdf_dropin_gpu",
     # 3. producers either side of the path, bit-exact

@@ -1,0 +1,129 @@
+"""vgx_ctx_set_brick_layout: the sampling grids of a context's submaps as apron bricks (default) or quad
+bricks (a 2x2x2 neighbourhood in 32 contiguous bytes, for sampling sessions).  The layout is a memory
+arrangement only: every REG kernel must return bit for bit the same results on both, and those are the
+oracle's / the reference source's (registration_cost_function.cpp:113-291)."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as orc
+from oracle import synth
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from voxgraph_amd import capi
+    return capi
+
+
+def _world(capi, layout, asymmetric=True):
+    ctx = capi.Context(0)
+    ctx.set_brick_layout(layout)
+    ref, read = synth.config1_pair(asymmetric=asymmetric)
+    subs = [H.gpu_submap(capi, ctx, sm, k) for k, sm in enumerate((ref, read))]
+    for g in subs:
+        g.extract_voxel_points(1.0, 0.3, True)
+    return ctx, (ref, read), subs
+
+
+def test_every_kernel_gives_the_same_bits_on_both_layouts(capi):
+    import torch
+    poses = np.array([[0.02, -0.01, 0.03, 0.01], [0.31, -0.2, 0.08, 0.12]])
+    out = {}
+    for layout in (capi.BRICKS_APRON, capi.BRICKS_QUAD):
+        ctx, (ref, read), subs = _world(capi, layout)
+        res = {}
+        for use_esdf in (1, 0):
+            cfg = capi.default_config(registration_point_type=capi.POINTS_VOXELS, use_esdf_distance=use_esdf,
+                                      no_correspondence_cost=0.25)
+            cf = capi.RegistrationCostFunction(ctx, subs[0], subs[1], cfg)
+            n = cf.num_residuals()
+            r, jo, je = np.zeros(n), np.zeros((n, 4)), np.zeros((n, 4))
+            assert cf.Evaluate([poses[0], poses[1]], r, [jo, je])            # drop-in f64 kernel
+            res[("evaluate", use_esdf)] = (r.copy(), jo.copy(), je.copy())
+            cf.destroy()
+        # batched: materialising f32 pass + fused pass, all points and sampled
+        for ratio in (-1.0, 0.3):
+            cfg = capi.default_config(registration_point_type=capi.POINTS_VOXELS, sampling_ratio=ratio)
+            cfs = [capi.RegistrationCostFunction(ctx, subs[a], subs[b], cfg) for a, b in ((0, 1), (1, 0), (0, 0))]
+            batch = capi.RegistrationBatch(ctx, cfs, [(0, 1), (1, 0), (0, 0)])
+            R = batch.num_residuals()
+            tr = torch.full((R,), float("nan"), dtype=torch.float32, device="cuda:0")
+            tjo = torch.full((R, 4), float("nan"), dtype=torch.float32, device="cuda:0")
+            tje = torch.full((R, 4), float("nan"), dtype=torch.float32, device="cuda:0")
+            torch.cuda.synchronize()
+            assert np.all(batch.evaluate_points(poses, tr.data_ptr(), tjo.data_ptr(), tje.data_ptr()) == 0)
+            ctx.synchronize()
+            status, normal = batch.evaluate_normal(poses)
+            res[("batch", ratio)] = (tr.cpu().numpy(), tjo.cpu().numpy(), tje.cpu().numpy(), normal.copy())
+            batch.destroy()
+            for cf in cfs:
+                cf.destroy()
+        out[layout] = res
+        if layout == capi.BRICKS_APRON:
+            # ... and they are the oracle's (all points, ESDF distance, no_correspondence_cost 0.25)
+            layer = H.oracle_layer(read)
+            xyz, dist, w = H.oracle_points(ref)
+            ok, r0, jo0, je0 = orc.reg_evaluate(layer, xyz, dist, w, poses[0], poses[1], no_correspondence_cost=0.25)
+            r, jo, je = res[("evaluate", 1)]
+            assert ok and np.array_equal(r, r0) and np.array_equal(jo, jo0) and np.array_equal(je, je0)
+            assert int((np.abs(jo0).sum(1) > 0).sum()) > 1000
+        for g in subs:
+            g.destroy()
+        ctx.close()
+    a, q = out[capi.BRICKS_APRON], out[capi.BRICKS_QUAD]
+    for key in a:
+        for x, y in zip(a[key], q[key]):
+            assert np.array_equal(x, y, equal_nan=True), key
+
+
+def test_vps8_grids_on_both_layouts(capi):
+    sdf = synth.sphere_ground_sdf((1.6, 1.6, 1.2), 1.0, 0.35)
+    sm = synth.make_submap(sdf, 0.1, 8, (0, 0, 0), (4, 4, 3), trunc=0.3, esdf_max=1.0, drop_empty_blocks=True)
+    poses = np.array([[0.0, 0.0, 0.0, 0.0], [0.13, -0.07, 0.04, 0.05]])
+    got = []
+    for layout in (capi.BRICKS_APRON, capi.BRICKS_QUAD):
+        ctx = capi.Context(0)
+        ctx.set_brick_layout(layout)
+        g = H.gpu_submap(capi, ctx, sm, 0)
+        n = g.extract_voxel_points(1.0, 0.3, True)
+        cf = capi.RegistrationCostFunction(ctx, g, g, capi.default_config(registration_point_type=capi.POINTS_VOXELS))
+        r, jo, je = np.zeros(n), np.zeros((n, 4)), np.zeros((n, 4))
+        assert cf.Evaluate([poses[0], poses[1]], r, [jo, je])
+        batch = capi.RegistrationBatch(ctx, [cf], [(0, 1)])
+        _, normal = batch.evaluate_normal(poses)
+        got.append((r, jo, je, normal.copy()))
+        for o in (batch, cf, g):
+            o.destroy()
+        ctx.close()
+    layer = H.oracle_layer(sm)
+    xyz, dist, w = H.oracle_points(sm)
+    ok, r0, jo0, je0 = orc.reg_evaluate(layer, xyz, dist, w, poses[0], poses[1])
+    assert ok and np.array_equal(got[0][0], r0) and np.array_equal(got[0][1], jo0) and np.array_equal(got[0][2], je0)
+    for x, y in zip(got[0], got[1]):
+        assert np.array_equal(x, y)
+
+
+def test_a_batch_refuses_submaps_of_different_layouts(capi):
+    ctx = capi.Context(0)
+    ref, read = synth.config1_pair()
+    g0 = H.gpu_submap(capi, ctx, ref, 0)
+    ctx.set_brick_layout(capi.BRICKS_QUAD)
+    g1 = H.gpu_submap(capi, ctx, read, 1)
+    for g in (g0, g1):
+        g.extract_voxel_points(1.0, 0.3, True)
+    cfg = capi.default_config(registration_point_type=capi.POINTS_VOXELS)
+    cfs = [capi.RegistrationCostFunction(ctx, g0, g1, cfg), capi.RegistrationCostFunction(ctx, g1, g0, cfg)]
+    with pytest.raises(capi.VgxError):
+        capi.RegistrationBatch(ctx, cfs, [(0, 1), (1, 0)])
+    # one by one they work: a drop-in Evaluate reads its own reading submap's layout
+    n = cfs[0].num_residuals()
+    r = np.zeros(n)
+    assert cfs[0].Evaluate([np.zeros(4), np.array([0.1, 0, 0, 0.02])], r, None) and np.abs(r).sum() > 0
+    with pytest.raises(capi.VgxError):
+        ctx.set_brick_layout(7)
+    for o in cfs + [g0, g1]:
+        o.destroy()
+    ctx.close()

@@ -17,6 +17,7 @@ OK = 0
 EVALUATE_FALSE = 1
 ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_UNSUPPORTED, ERR_NO_DEVICE = -1, -2, -3, -4, -5
 
+BRICKS_APRON, BRICKS_QUAD = 0, 1
 POINTS_ISOSURFACE = 0
 POINTS_VOXELS = 1
 POINTS_KEEP_ORDER = 0
@@ -81,6 +82,7 @@ SIGNATURES = {
     "vgx_ctx_set_stream": (C.c_int, [vp, vp]),
     "vgx_ctx_get_stream": (vp, [vp]),
     "vgx_ctx_synchronize": (C.c_int, [vp]),
+    "vgx_ctx_set_brick_layout": (C.c_int, [vp, C.c_int32]),
     "vgx_ctx_timer_start": (C.c_int, [vp]),
     "vgx_ctx_timer_stop": (C.c_int, [vp, f32p]),
     "vgx_submap_create": (C.c_int, [vp, C.c_int32, C.c_float, C.c_int32, C.c_int32, i32p, f32p,
@@ -241,6 +243,10 @@ class Context:
 
     def synchronize(self):
         self.check(self.lib.vgx_ctx_synchronize(self.h))
+
+    def set_brick_layout(self, layout):
+        """BRICKS_APRON (default) or BRICKS_QUAD, for the submaps created from now on"""
+        self.check(self.lib.vgx_ctx_set_brick_layout(self.h, int(layout)))
 
     def timer_start(self):
         self.check(self.lib.vgx_ctx_timer_start(self.h))

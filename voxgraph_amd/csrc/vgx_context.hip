@@ -34,13 +34,13 @@ int set_error(vgx_ctx ctx, int code, const std::string& msg) {
 // ---------------------------------------------------------------------------
 // One workgroup per block.  mode 0: valid iff weight > 0 (Interpolator<TsdfVoxel>
 // ::isVoxelValid), mode 1: valid iff observed (Interpolator<EsdfVoxel>) [recalled].
-template <int VPS>
+template <int VPS, int LAYOUT>
 __global__ __launch_bounds__(256) void brickify_kernel(
     const int32_t* __restrict__ block_index, const int32_t* __restrict__ lut,
     int3 lut_min, int3 lut_dim, const float* __restrict__ distance,
     const float* __restrict__ weight, const uint8_t* __restrict__ observed,
     float* __restrict__ bricks) {
-  constexpr int CELLS = BrickLayout<VPS>::cells;
+  constexpr int CELLS = BrickLayout<VPS, LAYOUT>::cells;
   constexpr int VOX = VPS * VPS * VPS;
   const int b = blockIdx.x;
   const int bx = block_index[3 * b + 0] - lut_min.x;
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void brickify_kernel(
   float* out = bricks + (size_t)b * CELLS;
   for (int cell = threadIdx.x; cell < CELLS; cell += blockDim.x) {
     int cx, cy, cz;
-    if (!BrickLayout<VPS>::decode(cell, cx, cy, cz)) {
+    if (!BrickLayout<VPS, LAYOUT>::decode(cell, cx, cy, cz)) {
       out[cell] = 0.0f;  // padding, never read
       continue;
     }
@@ -77,20 +77,22 @@ int launch_brickify(vgx_submap sm, int which) {
   const float* dist = which == 0 ? sm->d_tsdf_distance : sm->d_esdf_distance;
   const float* w = which == 0 ? sm->d_tsdf_weight : nullptr;
   const uint8_t* obs = which == 0 ? nullptr : sm->d_esdf_observed;
-  const size_t cells = sm->vps == 16 ? BrickLayout<16>::cells : BrickLayout<8>::cells;
+  const int layout = ctx->brick_layout;
+  const size_t cells = brick_cells(sm->vps, layout);
   size_t bytes = (size_t)sm->n_blocks * cells * sizeof(float);
   VGX_HIP(ctx, hipMalloc(&sm->grid[which].d_bricks, bytes));
+  sm->grid[which].layout = layout;
   int3 mn = make_int3(sm->lut_min[0], sm->lut_min[1], sm->lut_min[2]);
   int3 dm = make_int3(sm->lut_dim[0], sm->lut_dim[1], sm->lut_dim[2]);
+#define VGX_BRICKIFY(VPS, LAYOUT)                                                                       \
+  hipLaunchKernelGGL((brickify_kernel<VPS, LAYOUT>), dim3(sm->n_blocks), dim3(256), 0, ctx->stream,    \
+                     sm->d_block_index, sm->d_lut, mn, dm, dist, w, obs, sm->grid[which].d_bricks)
   if (sm->vps == 16) {
-    hipLaunchKernelGGL(brickify_kernel<16>, dim3(sm->n_blocks), dim3(256), 0, ctx->stream,
-                       sm->d_block_index, sm->d_lut, mn, dm, dist, w, obs,
-                       sm->grid[which].d_bricks);
+    if (layout == 0) VGX_BRICKIFY(16, 0); else if (layout == 1) VGX_BRICKIFY(16, 1); else VGX_BRICKIFY(16, 2);
   } else {
-    hipLaunchKernelGGL(brickify_kernel<8>, dim3(sm->n_blocks), dim3(256), 0, ctx->stream,
-                       sm->d_block_index, sm->d_lut, mn, dm, dist, w, obs,
-                       sm->grid[which].d_bricks);
+    if (layout == 0) VGX_BRICKIFY(8, 0); else if (layout == 1) VGX_BRICKIFY(8, 1); else VGX_BRICKIFY(8, 2);
   }
+#undef VGX_BRICKIFY
   VGX_HIP(ctx, hipGetLastError());
   sm->grid[which].present = true;
   return VGX_OK;
@@ -238,6 +240,7 @@ using namespace vgx;
 vgx::GridDev vgx_submap_s::grid_dev(int which) const {
   GridDev g;
   g.bricks = grid[which].d_bricks;
+  g.layout = grid[which].layout;
   g.lut = d_lut;
   for (int a = 0; a < 3; ++a) {
     g.lut_min[a] = lut_min[a];
@@ -335,6 +338,15 @@ int vgx_ctx_set_stream(vgx_ctx ctx, void* hip_stream) {
 }
 
 void* vgx_ctx_get_stream(vgx_ctx ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int vgx_ctx_set_brick_layout(vgx_ctx ctx, int32_t layout) {
+  if (!ctx) return VGX_ERR_INVALID;
+  if (layout != VGX_BRICKS_APRON && layout != VGX_BRICKS_QUAD)
+    return set_error(ctx, VGX_ERR_INVALID, "vgx_ctx_set_brick_layout: unknown layout");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  ctx->brick_layout = layout;
+  return VGX_OK;
+}
 
 int vgx_ctx_synchronize(vgx_ctx ctx) {
   if (!ctx) return VGX_ERR_INVALID;

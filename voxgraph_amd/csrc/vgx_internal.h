@@ -25,57 +25,61 @@ namespace vgx {
 // blocks for index == vps, so the 8 trilinear neighbours of any base voxel of
 // block b live in ONE brick.  Invalid voxels (unobserved / zero weight /
 // missing neighbour block) are stored as NaN: validity travels with the value.
-// Brick layouts (compile-time choice, VGX_BRICK_LAYOUT; profiles/ab_layout.sh builds and times them):
-//   0  apron brick: (vps+1)^3 floats, x fastest.  A neighbourhood is four 8-byte x-pairs in four rows
-//      (y, z), (y, z+1), (y+1, z), (y+1, z+1): 68 B, 1156 B apart -> four cache lines.  1.2 x memory.
+// Brick layouts.  A context chooses one for the submaps it will hold (vgx_ctx_set_brick_layout):
+//   0  apron brick (default): (vps+1)^3 floats, x fastest.  A neighbourhood is four 8-byte x-pairs in four
+//      rows (y, z), (y, z+1), (y+1, z), (y+1, z+1): 68 B, 1156 B apart -> four cache lines.  1.2 x memory.
+//      Fastest for the all-points passes (HBM / VALU bound: fewest bytes).
 //   1  quad brick: for every x in [0, vps], y, z in [0, vps) the float4 {d(x,y,z), d(x,y+1,z), d(x,y,z+1),
-//      d(x,y+1,z+1)}, x fastest.  A neighbourhood is two consecutive float4: 32 contiguous bytes.
-//      4.25 x memory.
+//      d(x,y+1,z+1)}, x fastest.  A neighbourhood is two consecutive float4: 32 contiguous bytes, one or
+//      two cache lines.  4.25 x memory.  Fastest where evaluations are scattered (sampling mode: every
+//      touched line is an HBM fetch): -14 % per evaluation of the shipped configuration, +18-25 % on the
+//      all-points passes (profiles/ab_layout.sh).
 //   2  4^3 sub-tiles with their own aprons (5^3 floats, padded to 128): the four x-pairs of a
-//      neighbourhood lie within 128 B.  2 x memory.
-#ifndef VGX_BRICK_LAYOUT
-#define VGX_BRICK_LAYOUT 0
+//      neighbourhood lie within 128 B.  2 x memory.  Measured in between; kept as an experiment
+//      (compile-time default only: -DVGX_BRICK_LAYOUT_DEFAULT=2).
+#ifndef VGX_BRICK_LAYOUT_DEFAULT
+#define VGX_BRICK_LAYOUT_DEFAULT 0
 #endif
-template <int VPS>
+template <int VPS, int LAYOUT>
 struct BrickLayout {
   static constexpr int B = VPS + 1;
-#if VGX_BRICK_LAYOUT == 0
-  static constexpr int cells = B * B * B;
-  __host__ __device__ static int anchor(int vx, int vy, int vz) { return vx + B * (vy + B * vz); }
-  // brick float index -> apron cell (cx, cy, cz in [0, VPS]); false: padding
-  __host__ __device__ static bool decode(int i, int& cx, int& cy, int& cz) {
-    cx = i % B; cy = (i / B) % B; cz = i / (B * B);
-    return true;
-  }
-#elif VGX_BRICK_LAYOUT == 1
-  static constexpr int cells = B * VPS * VPS * 4;
-  __host__ __device__ static int anchor(int vx, int vy, int vz) { return 4 * (vx + B * (vy + VPS * vz)); }
-  __host__ __device__ static bool decode(int i, int& cx, int& cy, int& cz) {
-    const int comp = i & 3, e = i >> 2;
-    cx = e % B; cy = (e / B) % VPS + (comp & 1); cz = e / (B * VPS) + (comp >> 1);
-    return true;
-  }
-#else
   static constexpr int S = VPS / 4;
-  static constexpr int cells = S * S * S * 128;
+  static constexpr int cells = LAYOUT == 0 ? B * B * B : (LAYOUT == 1 ? B * VPS * VPS * 4 : S * S * S * 128);
+  // float offset of a base voxel's neighbourhood anchor inside its brick
   __host__ __device__ static int anchor(int vx, int vy, int vz) {
+    if (LAYOUT == 0) return vx + B * (vy + B * vz);
+    if (LAYOUT == 1) return 4 * (vx + B * (vy + VPS * vz));
     return 128 * ((vx >> 2) + S * ((vy >> 2) + S * (vz >> 2))) + (vx & 3) + 5 * ((vy & 3) + 5 * (vz & 3));
   }
+  // brick float index -> apron cell (cx, cy, cz in [0, VPS]); false: padding
   __host__ __device__ static bool decode(int i, int& cx, int& cy, int& cz) {
+    if (LAYOUT == 0) {
+      cx = i % B; cy = (i / B) % B; cz = i / (B * B);
+      return true;
+    }
+    if (LAYOUT == 1) {
+      const int comp = i & 3, e = i >> 2;
+      cx = e % B; cy = (e / B) % VPS + (comp & 1); cz = e / (B * VPS) + (comp >> 1);
+      return true;
+    }
     const int s = i >> 7, k = i & 127;
     if (k >= 125) return false;
     cx = 4 * (s % S) + k % 5; cy = 4 * ((s / S) % S) + (k / 5) % 5; cz = 4 * (s / (S * S)) + k / 25;
     return true;
   }
-#endif
 };
+inline size_t brick_cells(int vps, int layout) {
+  if (vps == 16) return layout == 0 ? BrickLayout<16, 0>::cells : (layout == 1 ? BrickLayout<16, 1>::cells : BrickLayout<16, 2>::cells);
+  return layout == 0 ? BrickLayout<8, 0>::cells : (layout == 1 ? BrickLayout<8, 1>::cells : BrickLayout<8, 2>::cells);
+}
 
 struct GridDev {
-  const float* bricks;   // [n_blocks][BrickLayout<vps>::cells]
+  const float* bricks;   // [n_blocks][BrickLayout<vps, layout>::cells]
   const int32_t* lut;    // dense block lookup [dim.z][dim.y][dim.x] -> brick or -1
   int32_t lut_min[3];
   int32_t lut_dim[3];
   float voxel_size, voxel_size_inv, block_size, block_size_inv;
+  int32_t layout;        // brick layout of `bricks` (0 apron, 1 quad, 2 sub-tiles)
 };
 
 // Per-evaluation pose data of one constraint, computed on the host in the
@@ -144,6 +148,7 @@ struct Context {
   std::mutex err_mu;       // guards last_error only (set_error is called with and without `mu`)
   std::string last_error;
   int cu_count = 256;
+  int brick_layout = VGX_BRICK_LAYOUT_DEFAULT;  // of the submaps created from now on (vgx_ctx_set_brick_layout)
   // Evaluation slots of the drop-in Evaluate path.  A call takes a free slot for its duration
   // (stream, ordering event, device staging for the f64 outputs, pinned + device staging for the
   // sampler's engine outputs -- all grown on demand and reused), so constructing a cost function
@@ -232,6 +237,7 @@ struct PointSet {
 struct Grid {
   float* d_bricks = nullptr;
   bool present = false;
+  int layout = 0;  // the context's brick layout when this grid was built
 };
 
 }  // namespace vgx
@@ -288,6 +294,7 @@ struct vgx_reg_batch_s {
   vgx_ctx ctx = nullptr;
   int32_t n = 0;
   int32_t n_global = 0;
+  int layout = 0;                     // brick layout of every reading grid in the batch
   std::vector<vgx_reg> regs;
   std::vector<int32_t> node_pair;     // [n][2]
   std::vector<int32_t> global_index;  // [n]

@@ -148,31 +148,27 @@ struct PointEval {
   float je3;           // d r / d reading yaw; je0..2 == -jo0..2 (RCF:223-227)
 };
 
-template <int VPS>
+template <int VPS, int LAYOUT>
 __device__ __forceinline__ void load_neighbours(const float* cell, float d[8]) {
   // neighbour k sits at base + (k>>2 & 1, k>>1 & 1, k & 1)
-#if VGX_BRICK_LAYOUT == 1
-  // quad brick: {(y,z), (y+1,z), (y,z+1), (y+1,z+1)} of x, then of x + 1
-  const f32x4 q0 = *(const VGX_GLOBAL f32x4*)(cell);
-  const f32x4 q1 = *(const VGX_GLOBAL f32x4*)(cell + 4);
-  d[0] = q0.x; d[2] = q0.y; d[1] = q0.z; d[3] = q0.w;
-  d[4] = q1.x; d[6] = q1.y; d[5] = q1.z; d[7] = q1.w;
-#else
-#if VGX_BRICK_LAYOUT == 0
-  constexpr int SY = VPS + 1, SZ = (VPS + 1) * (VPS + 1);
-#else
-  constexpr int SY = 5, SZ = 25;
-#endif
-  // x is the contiguous axis, so (k, k+4) is one 8-byte load
-  f32x2 p0 = *(const VGX_GLOBAL f32x2u*)(cell);
-  f32x2 p1 = *(const VGX_GLOBAL f32x2u*)(cell + SZ);
-  f32x2 p2 = *(const VGX_GLOBAL f32x2u*)(cell + SY);
-  f32x2 p3 = *(const VGX_GLOBAL f32x2u*)(cell + SY + SZ);
-  d[0] = p0.x; d[4] = p0.y;
-  d[1] = p1.x; d[5] = p1.y;
-  d[2] = p2.x; d[6] = p2.y;
-  d[3] = p3.x; d[7] = p3.y;
-#endif
+  if (LAYOUT == 1) {
+    // quad brick: {(y,z), (y+1,z), (y,z+1), (y+1,z+1)} of x, then of x + 1
+    const f32x4 q0 = *(const VGX_GLOBAL f32x4*)(cell);
+    const f32x4 q1 = *(const VGX_GLOBAL f32x4*)(cell + 4);
+    d[0] = q0.x; d[2] = q0.y; d[1] = q0.z; d[3] = q0.w;
+    d[4] = q1.x; d[6] = q1.y; d[5] = q1.z; d[7] = q1.w;
+  } else {
+    constexpr int SY = LAYOUT == 0 ? VPS + 1 : 5, SZ = LAYOUT == 0 ? (VPS + 1) * (VPS + 1) : 25;
+    // x is the contiguous axis, so (k, k+4) is one 8-byte load
+    f32x2 p0 = *(const VGX_GLOBAL f32x2u*)(cell);
+    f32x2 p1 = *(const VGX_GLOBAL f32x2u*)(cell + SZ);
+    f32x2 p2 = *(const VGX_GLOBAL f32x2u*)(cell + SY);
+    f32x2 p3 = *(const VGX_GLOBAL f32x2u*)(cell + SY + SZ);
+    d[0] = p0.x; d[4] = p0.y;
+    d[1] = p1.x; d[5] = p1.y;
+    d[2] = p2.x; d[6] = p2.y;
+    d[3] = p3.x; d[7] = p3.y;
+  }
 }
 
 // Branch-free two-stage point location + load_neighbours used by the kernels: all
@@ -187,7 +183,7 @@ struct Located {
   float Dx, Dy, Dz;
 };
 
-template <int VPS>
+template <int VPS, int LAYOUT>
 __device__ __forceinline__ Located locate_stage1(const GridDev& g, const PosePack& P, float x, float y,
                                                  float z) {
   float uv0 = -(P.qz * y);
@@ -212,7 +208,7 @@ __device__ __forceinline__ Located locate_stage1(const GridDev& g, const PosePac
   int cx = min(max(bx, 0), g.lut_dim[0] - 1), cy = min(max(by, 0), g.lut_dim[1] - 1),
       cz = min(max(bz, 0), g.lut_dim[2] - 1);
   L.lut_index = cx + g.lut_dim[0] * (cy + g.lut_dim[1] * cz);
-  L.cell_off = BrickLayout<VPS>::anchor(vx, vy, vz);
+  L.cell_off = BrickLayout<VPS, LAYOUT>::anchor(vx, vy, vz);
   return L;
 }
 
@@ -476,7 +472,7 @@ __global__ __launch_bounds__(256) void reg_points_tile_dead_kernel(const Constra
   dead[t] = g_points_cull && tile_cullable(C) && tile_outside<PPT>(C, packs[tile.constraint], tile);
 }
 
-template <int VPS, typename OUT, int PPT, bool NT, bool NTL>
+template <int VPS, int LAYOUT, typename OUT, int PPT, bool NT, bool NTL>
 __device__ __forceinline__ void reg_eval_points_body(
     const ConstraintDev& C, const PosePack& P, const Tile& tile, int dead_hint, OUT* __restrict__ residuals,
     typename Out4<OUT>::type* __restrict__ jac_ref, typename Out4<OUT>::type* __restrict__ jac_read) {
@@ -538,7 +534,7 @@ __device__ __forceinline__ void reg_eval_points_body(
   const bool grid_empty = g.bricks == nullptr;  // reading submap without blocks
 #pragma unroll
   for (int j = 0; j < PPT; ++j) {
-    loc[j] = locate_stage1<VPS>(g, P, pt[j].x, pt[j].y, pt[j].z);
+    loc[j] = locate_stage1<VPS, LAYOUT>(g, P, pt[j].x, pt[j].y, pt[j].z);
     Dx[j] = loc[j].Dx;
     Dy[j] = loc[j].Dy;
     Dz[j] = loc[j].Dz;
@@ -552,14 +548,14 @@ __device__ __forceinline__ void reg_eval_points_body(
     int slot[PPT];
 #pragma unroll
     for (int j = 0; j < PPT; ++j) slot[j] = as_global(g.lut)[loc[j].lut_index];
-    constexpr int CELLS = BrickLayout<VPS>::cells;
+    constexpr int CELLS = BrickLayout<VPS, LAYOUT>::cells;
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
       have[j] = loc[j].inside && slot[j] >= 0;
       cell[j] = g.bricks + (size_t)(have[j] ? slot[j] : 0) * CELLS + loc[j].cell_off;
     }
 #pragma unroll
-    for (int j = 0; j < PPT; ++j) load_neighbours<VPS>(cell[j], d[j]);
+    for (int j = 0; j < PPT; ++j) load_neighbours<VPS, LAYOUT>(cell[j], d[j]);
   }
 #pragma unroll
   for (int j = 0; j < PPT; ++j) {
@@ -580,7 +576,7 @@ __device__ __forceinline__ void reg_eval_points_body(
 }
 
 // batched form: descriptors, pose packs and tiles live in device memory
-template <int VPS, typename OUT, int PPT, bool NT, bool NTL>
+template <int VPS, int LAYOUT, typename OUT, int PPT, bool NT, bool NTL>
 __global__ __launch_bounds__(kBlockThreads) void reg_eval_points_kernel(
     const ConstraintDev* __restrict__ cons, const PosePack* __restrict__ packs,
     const Tile* __restrict__ tiles, const unsigned char* __restrict__ tile_dead, int n_tiles,
@@ -590,13 +586,13 @@ __global__ __launch_bounds__(kBlockThreads) void reg_eval_points_kernel(
   if (t >= n_tiles) return;
   const Tile tile = tiles[t];
   const int dead = tile_dead[t];
-  reg_eval_points_body<VPS, OUT, PPT, NT, NTL>(cons[tile.constraint], packs[tile.constraint], tile, dead,
-                                               residuals, jac_ref, jac_read);
+  reg_eval_points_body<VPS, LAYOUT, OUT, PPT, NT, NTL>(cons[tile.constraint], packs[tile.constraint], tile, dead,
+                                                       residuals, jac_ref, jac_read);
 }
 
 // drop-in form (one constraint per Evaluate): descriptor and pose pack travel as kernel
 // arguments and tiles are implicit, so an Evaluate needs no host->device copy at all
-template <int VPS, typename OUT, int PPT, bool NT, bool NTL>
+template <int VPS, int LAYOUT, typename OUT, int PPT, bool NT, bool NTL>
 __global__ __launch_bounds__(kBlockThreads) void reg_eval_points_single_kernel(
     ConstraintDev C, PosePack P, int n_tiles, OUT* __restrict__ residuals,
     typename Out4<OUT>::type* __restrict__ jac_ref, typename Out4<OUT>::type* __restrict__ jac_read) {
@@ -607,7 +603,7 @@ __global__ __launch_bounds__(kBlockThreads) void reg_eval_points_single_kernel(
   tile.start = (int64_t)t * (kBlockThreads * PPT);
   int64_t left = C.n - tile.start;
   tile.count = (int32_t)(left < kBlockThreads * PPT ? left : kBlockThreads * PPT);
-  reg_eval_points_body<VPS, OUT, PPT, NT, NTL>(C, P, tile, /*dead_hint=*/-1, residuals, jac_ref, jac_read);
+  reg_eval_points_body<VPS, LAYOUT, OUT, PPT, NT, NTL>(C, P, tile, /*dead_hint=*/-1, residuals, jac_ref, jac_read);
 }
 
 // ---------------------------------------------------------------------------
@@ -695,7 +691,7 @@ __device__ __forceinline__ void accumulate21(ACC acc[21], const float u[6]) {
 // Tiles are launched in an XCD-aware order (make_xcd_order); every tile still writes its partial
 // sums into the slot it has in its constraint's own contiguous range (tile_first[c] + k-th tile of
 // c), so the order in which a constraint's partials are summed never changes.
-template <int VPS, int PPT, typename ACC, int WAVES>
+template <int VPS, int LAYOUT, int PPT, typename ACC, int WAVES>
 __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_kernel(
     const ConstraintDev* __restrict__ cons, const PosePack* __restrict__ packs,
     const Tile* __restrict__ tiles, int n_tiles, const int32_t* __restrict__ tile_first,
@@ -776,14 +772,14 @@ __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_ker
     float d[PPT][8];
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
-      loc[j] = locate_stage1<VPS>(g, P, pt[j].x, pt[j].y, pt[j].z);
+      loc[j] = locate_stage1<VPS, LAYOUT>(g, P, pt[j].x, pt[j].y, pt[j].z);
       have[j] = false;
     }
     if (!grid_empty) {
       int slot[PPT];
 #pragma unroll
       for (int j = 0; j < PPT; ++j) slot[j] = as_global(g.lut)[loc[j].lut_index];
-      constexpr int CELLS = BrickLayout<VPS>::cells;
+      constexpr int CELLS = BrickLayout<VPS, LAYOUT>::cells;
       bool any = false;
 #pragma unroll
       for (int j = 0; j < PPT; ++j) {
@@ -797,7 +793,7 @@ __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_ker
       for (int j = 0; j < PPT; ++j) {
         // 32-bit offsets: a grid holds < 2^31 floats (4096 quad bricks of 17 408 floats = 71 M)
         const unsigned off = (unsigned)(have[j] ? slot[j] : 0) * (unsigned)CELLS + (unsigned)loc[j].cell_off;
-        load_neighbours<VPS>(g.bricks + off, d[j]);
+        load_neighbours<VPS, LAYOUT>(g.bricks + off, d[j]);
       }
     } else {
 #pragma unroll
@@ -1300,7 +1296,7 @@ static void apply_swizzle_env() {
 }
 
 template <typename OUT>
-static void launch_points(vgx_ctx ctx, int vps, const ConstraintDev* d_desc, const PosePack* d_pack,
+static void launch_points(vgx_ctx ctx, int vps, int layout, const ConstraintDev* d_desc, const PosePack* d_pack,
                           const Tile* d_tiles, unsigned char* d_tile_dead, int n_tiles, void* res, void* jr,
                           void* je) {
   if (n_tiles <= 0) return;
@@ -1317,17 +1313,25 @@ static void launch_points(vgx_ctx ctx, int vps, const ConstraintDev* d_desc, con
     const char* e = getenv("VGX_NT_LOADS");
     return e ? atoi(e) != 0 : kNonTemporalLoads;
   }();
-#define VGX_LAUNCH_POINTS(VPS, NT, NTL)                                                             \
-  hipLaunchKernelGGL((reg_eval_points_kernel<VPS, OUT, kPointsPerThread, NT, NTL>), grid, block, 0, \
+#define VGX_LAUNCH_POINTS(VPS, LAYOUT, NT, NTL)                                                             \
+  hipLaunchKernelGGL((reg_eval_points_kernel<VPS, LAYOUT, OUT, kPointsPerThread, NT, NTL>), grid, block, 0, \
                      ctx->stream, d_desc, d_pack, d_tiles, d_tile_dead, n_tiles, (OUT*)res, (O4*)jr, (O4*)je)
-  if (vps == 16) {
-    if (nt && ntl) VGX_LAUNCH_POINTS(16, true, true);
-    else if (nt) VGX_LAUNCH_POINTS(16, true, false);
-    else if (ntl) VGX_LAUNCH_POINTS(16, false, true);
-    else VGX_LAUNCH_POINTS(16, false, false);
+  if (layout == 0) {  // apron bricks: the A/B switches of the non-temporal hints live here
+    if (vps == 16) {
+      if (nt && ntl) VGX_LAUNCH_POINTS(16, 0, true, true);
+      else if (nt) VGX_LAUNCH_POINTS(16, 0, true, false);
+      else if (ntl) VGX_LAUNCH_POINTS(16, 0, false, true);
+      else VGX_LAUNCH_POINTS(16, 0, false, false);
+    } else {
+      if (nt) VGX_LAUNCH_POINTS(8, 0, true, kNonTemporalLoads);
+      else VGX_LAUNCH_POINTS(8, 0, false, kNonTemporalLoads);
+    }
+  } else if (layout == 1) {
+    if (vps == 16) VGX_LAUNCH_POINTS(16, 1, kNonTemporalStores, kNonTemporalLoads);
+    else VGX_LAUNCH_POINTS(8, 1, kNonTemporalStores, kNonTemporalLoads);
   } else {
-    if (nt) VGX_LAUNCH_POINTS(8, true, kNonTemporalLoads);
-    else VGX_LAUNCH_POINTS(8, false, kNonTemporalLoads);
+    if (vps == 16) VGX_LAUNCH_POINTS(16, 2, kNonTemporalStores, kNonTemporalLoads);
+    else VGX_LAUNCH_POINTS(8, 2, kNonTemporalStores, kNonTemporalLoads);
   }
 #undef VGX_LAUNCH_POINTS
 }
@@ -1344,13 +1348,22 @@ static void launch_points_single(hipStream_t stream, int vps, const ConstraintDe
     const char* e = getenv("VGX_NT_STORES");
     return e ? atoi(e) != 0 : kNonTemporalStores;
   }();
-#define VGX_LAUNCH_SINGLE(VPS, NT)                                                                  \
-  hipLaunchKernelGGL((reg_eval_points_single_kernel<VPS, OUT, kPointsPerThread, NT, kNonTemporalLoads>), \
+#define VGX_LAUNCH_SINGLE(VPS, LAYOUT, NT)                                                                  \
+  hipLaunchKernelGGL((reg_eval_points_single_kernel<VPS, LAYOUT, OUT, kPointsPerThread, NT, kNonTemporalLoads>), \
                      grid, block, 0, stream, desc, pack, n_tiles, (OUT*)res, (O4*)jr, (O4*)je)
-  if (vps == 16 && nt) VGX_LAUNCH_SINGLE(16, true);
-  else if (vps == 16) VGX_LAUNCH_SINGLE(16, false);
-  else if (nt) VGX_LAUNCH_SINGLE(8, true);
-  else VGX_LAUNCH_SINGLE(8, false);
+  const int layout = desc.grid.layout;
+  if (layout == 0) {
+    if (vps == 16 && nt) VGX_LAUNCH_SINGLE(16, 0, true);
+    else if (vps == 16) VGX_LAUNCH_SINGLE(16, 0, false);
+    else if (nt) VGX_LAUNCH_SINGLE(8, 0, true);
+    else VGX_LAUNCH_SINGLE(8, 0, false);
+  } else if (layout == 1) {
+    if (vps == 16) VGX_LAUNCH_SINGLE(16, 1, kNonTemporalStores);
+    else VGX_LAUNCH_SINGLE(8, 1, kNonTemporalStores);
+  } else {
+    if (vps == 16) VGX_LAUNCH_SINGLE(16, 2, kNonTemporalStores);
+    else VGX_LAUNCH_SINGLE(8, 2, kNonTemporalStores);
+  }
 #undef VGX_LAUNCH_SINGLE
 }
 
@@ -1712,7 +1725,7 @@ int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs, const int3
   if (!global_index && n_global < n) n_global = n;
   if (n_global < n) return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_batch_create: n_global < n");
   VGX_HIP(ctx, hipSetDevice(ctx->device));
-  int vps = 0;
+  int vps = 0, layout = 0;
   for (int c = 0; c < n; ++c) {
     if (!regs[c] || regs[c]->ctx != ctx)
       return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_batch_create: NULL or foreign constraint");
@@ -1727,6 +1740,12 @@ int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs, const int3
     if (vps == 0) vps = regs[c]->reading->vps;
     if (regs[c]->reading->vps != vps)
       return set_error(ctx, VGX_ERR_UNSUPPORTED, "vgx_reg_batch_create: mixed voxels_per_side");
+    const int lay = regs[c]->reading->grid[regs[c]->cfg.use_esdf_distance ? 1 : 0].layout;
+    if (c == 0) layout = lay;
+    if (lay != layout)
+      return set_error(ctx, VGX_ERR_UNSUPPORTED,
+                       "vgx_reg_batch_create: submaps with different brick layouts (vgx_ctx_set_brick_layout was "
+                       "changed between their creation)");
   }
   vgx_reg_batch b = new (std::nothrow) vgx_reg_batch_s();
   if (!b) return set_error(ctx, VGX_ERR_NOMEM, "vgx_reg_batch_create: out of host memory");
@@ -1734,6 +1753,7 @@ int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs, const int3
   b->ctx = ctx;
   b->n = n;
   b->n_global = n_global;
+  b->layout = layout;
   b->regs.assign(regs, regs + n);
   b->node_pair.assign(node_pair, node_pair + 2 * (size_t)n);
   b->global_index.resize((size_t)n);
@@ -2003,7 +2023,7 @@ int vgx_reg_batch_evaluate_points(vgx_reg_batch b, const double* poses, int32_t 
     if (rc != VGX_OK) return rc;
     b->points_order_made = true;
   }
-  launch_points<float>(ctx, b->regs[0]->reading->vps, b->d_desc, b->d_pack, b->d_tiles, b->d_tile_dead,
+  launch_points<float>(ctx, b->regs[0]->reading->vps, b->layout, b->d_desc, b->d_pack, b->d_tiles, b->d_tile_dead,
                        (int)b->tiles.size(), d_residuals, d_jac_ref, d_jac_read);
   VGX_HIP(ctx, hipGetLastError());
   return VGX_OK;
@@ -2034,14 +2054,21 @@ int vgx_reg_batch_evaluate_normal(vgx_reg_batch b, const double* poses, int32_t 
   if (n_tiles > 0) {
     dim3 grid(n_tiles), block(kBlockThreads);
     const int vps = b->regs[0]->reading->vps;
-#define VGX_LAUNCH_LEAN(VPS, PPT, ACC, W)                                                             \
-  hipLaunchKernelGGL((reg_eval_reduce_lean_kernel<VPS, PPT, ACC, W>), grid, block, 0, ctx->stream,  \
+#define VGX_LAUNCH_LEAN(VPS, LAYOUT, PPT, ACC, W)                                                             \
+  hipLaunchKernelGGL((reg_eval_reduce_lean_kernel<VPS, LAYOUT, PPT, ACC, W>), grid, block, 0, ctx->stream,  \
                      b->d_desc, b->d_pack, ex->d_reduce_tiles, n_tiles, b->d_tile_first, b->d_partials)
 #define VGX_LEAN_CASE(CODE, PPT, ACC, W)                                  \
   case CODE:                                                              \
-    if (vps == 16) VGX_LAUNCH_LEAN(16, PPT, ACC, W);                      \
-    else VGX_LAUNCH_LEAN(8, PPT, ACC, W);                                 \
+    if (vps == 16) VGX_LAUNCH_LEAN(16, 0, PPT, ACC, W);                   \
+    else VGX_LAUNCH_LEAN(8, 0, PPT, ACC, W);                              \
     break
+    if (b->layout == 1) {  // quad bricks: the shipped variant only
+      if (vps == 16) VGX_LAUNCH_LEAN(16, 1, 2, float, 6);
+      else VGX_LAUNCH_LEAN(8, 1, 2, float, 6);
+    } else if (b->layout == 2) {
+      if (vps == 16) VGX_LAUNCH_LEAN(16, 2, 2, float, 6);
+      else VGX_LAUNCH_LEAN(8, 2, 2, float, 6);
+    } else
     switch (variant) {
       VGX_LEAN_CASE(421, 2, double, 4);
       VGX_LEAN_CASE(422, 2, float, 4);
