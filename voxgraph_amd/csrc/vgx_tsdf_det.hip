@@ -31,6 +31,8 @@
 // HBM traffic is a few sorts and scans over the speculative accesses (~60 B each); the mode trades
 // 10-50 x the racing kernel's time for a layer that is the same bit for bit on every run.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -61,7 +63,7 @@ struct DetScratch {
   Buf acc_vox, acc_key, acc_ray, s_key, s_idx, s_r, s_k, s_h, last, seen, c_idx, c_key;
   Buf tmp;  // rocprim temporary storage
   // block allocation
-  Buf first_touch, new_cells, new_cells_sorted, new_keys, new_keys_sorted, long_runs, t_at, t_sdf, t_w, t_color;
+  Buf first_touch, new_cells, new_cells_sorted, new_keys, new_keys_sorted, long_runs, t_at, t_sdf, t_w, t_color, t_far;
   bool first_touch_dirty = false;  // a scan failed between marking and assigning: refill
   // device counters {changed, n_new, error, pad, total accesses, total updates (u64 each)} + pinned mirror
   unsigned long long* d_ctr = nullptr;
@@ -79,7 +81,7 @@ void det_scratch_free(DetScratch* s) {
                 &s->start_seq_sorted, &s->count, &s->off, &s->T, &s->broke, &s->acc_vox, &s->acc_key, &s->acc_ray,
                 &s->s_key, &s->s_idx, &s->s_r, &s->s_k, &s->s_h, &s->last, &s->seen, &s->c_idx, &s->c_key, &s->tmp,
                 &s->first_touch, &s->new_cells, &s->new_cells_sorted, &s->new_keys, &s->new_keys_sorted, &s->long_runs,
-                &s->t_at, &s->t_sdf, &s->t_w, &s->t_color};
+                &s->t_at, &s->t_sdf, &s->t_w, &s->t_color, &s->t_far};
   for (Buf* b : all)
     if (b->p) (void)hipFree(b->p);
   if (s->d_ctr) (void)hipFree(s->d_ctr);
@@ -451,7 +453,8 @@ __global__ __launch_bounds__(256) void det_terms_kernel(TsdfLayerDev L, vgx_tsdf
                                                        const float4* __restrict__ ray_pg,
                                                        const uint32_t* __restrict__ ray_color,
                                                        long long* __restrict__ t_at, float* __restrict__ t_sdf,
-                                                       float* __restrict__ t_w, uint32_t* __restrict__ t_color) {
+                                                       float* __restrict__ t_w, uint32_t* __restrict__ t_color,
+                                                       uint8_t* __restrict__ t_far) {
   const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= M) return;
   const uint32_t idx = c_idx[q];
@@ -467,6 +470,8 @@ __global__ __launch_bounds__(256) void det_terms_kernel(TsdfLayerDev L, vgx_tsdf
   t_sdf[q] = u.sdf;
   t_w[q] = u.w;
   t_color[q] = ray_color[r];
+  // "cannot move a voxel that sits at +truncation and weighs at most max_weight" (det_apply_long_kernel)
+  t_far[q] = (u.sdf >= 2.0f * c.default_truncation_distance && u.w * 1.0e5f >= c.max_weight && u.w >= 1e-6f) ? 1 : 0;
 }
 
 // One thread per slot run: all updates of a voxel are contiguous and in order.  Runs longer than
@@ -524,33 +529,26 @@ __global__ __launch_bounds__(256) void det_apply_kernel(TsdfLayerDev L, vgx_tsdf
   }
 }
 
-__device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
-  return v;
-}
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-
 // Long runs: one wavefront per run streams the run's terms 64 at a time (the next 64 are in flight
 // while the current ones are applied) and runs the clamped running average -- a handful of dependent
 // f32 operations per update -- over lane broadcasts.
 // Updates that cannot move a voxel that already sits at +truncation only add their weight: with
 // d = t, sdf >= 2 t and w >= 1e-5 W,  fl((sdf w + t W) / (W + w)) >= t [1 + w / (W + w)] (1 - 4 eps) >= t,
-// so the clamp returns t exactly (eps = 2^-24; w / (W + w) >= 1e-5 >> 4 eps).  Where that holds for a
-// whole batch of 64 (the sensor's own neighbourhood: free space, seen by every ray) the batch is a
-// chain of 64 additions, and nothing at all once the weight has reached max_weight.
+// so the clamp returns t exactly (eps = 2^-24; w / (W + w) >= 1e-5 >> 4 eps).  det_terms_kernel marks
+// the updates for which that holds whatever the voxel weighs (sdf >= 2 t, 1e5 w >= max_weight >= W);
+// where a whole sub-batch of 64 is marked (the sensor's own neighbourhood: free space, seen by every
+// ray) one ballot turns it into a chain of 64 additions, and into nothing at all once the weight has
+// reached max_weight.
 __global__ __launch_bounds__(64) void det_apply_long_kernel(TsdfLayerDev L, vgx_tsdf_config c, size_t M,
                                                            const uint32_t* __restrict__ c_key,
                                                            const long long* __restrict__ t_at,
                                                            const float* __restrict__ t_sdf,
                                                            const float* __restrict__ t_w,
                                                            const uint32_t* __restrict__ t_color,
+                                                           const uint8_t* __restrict__ t_far,
                                                            const uint32_t* __restrict__ long_runs,
                                                            unsigned long long* __restrict__ ctr) {
+  constexpr int E = 8;  // sub-batches of 64 in flight: the chain of a batch is short, the loads are not
   const int lane = threadIdx.x;
   const unsigned long long n_long = ctr[kCtrLong];
   const float trunc = c.default_truncation_distance;
@@ -562,50 +560,78 @@ __global__ __launch_bounds__(64) void det_apply_long_kernel(TsdfLayerDev L, vgx_
     float d = 0.0f, w = 0.0f;
     uint32_t col = 0u;
     bool dirty = false;
-    // batch in flight
-    size_t qn = q0 + lane;
-    bool n_valid = qn < M && c_key[qn] == key;
-    long long n_at = n_valid ? t_at[qn] : -1;
-    float n_sdf = n_valid ? t_sdf[qn] : 0.0f, n_uw = n_valid ? t_w[qn] : 0.0f;
-    uint32_t n_color = n_valid ? t_color[qn] : 0u;
-    for (size_t b = q0;; b += 64) {
-      const bool valid = n_valid;
-      const long long at = n_at;
-      const float sdf = n_sdf, uw = n_uw;
-      const uint32_t color = n_color;
-      const unsigned long long vmask = __ballot(valid);
-      const int cnt = __popcll(vmask);  // the valid lanes are a prefix: the run is contiguous
-      if (cnt == 64) {                  // fetch the next batch while this one is applied
-        qn = b + 64 + lane;
-        n_valid = qn < M && c_key[qn] == key;
-        n_at = n_valid ? t_at[qn] : -1;
-        n_sdf = n_valid ? t_sdf[qn] : 0.0f;
-        n_uw = n_valid ? t_w[qn] : 0.0f;
-        n_color = n_valid ? t_color[qn] : 0u;
+    bool n_valid[E], n_far[E];
+    long long n_at[E];
+    float n_sdf[E], n_uw[E];
+    uint32_t n_color[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      // (all loads unconditional on a clamped index: none waits for the key comparison)
+      const size_t qn = q0 + (size_t)e * 64 + lane, qc = qn < M ? qn : M - 1;
+      const uint32_t k_ = c_key[qc];
+      n_at[e] = t_at[qc];
+      n_sdf[e] = t_sdf[qc];
+      n_uw[e] = t_w[qc];
+      n_color[e] = t_color[qc];
+      n_far[e] = t_far[qc] != 0;
+      n_valid[e] = qn < M && k_ == key;
+    }
+    bool run_ended = false;
+    for (size_t b = q0; !run_ended; b += (size_t)E * 64) {
+      bool valid_[E], far_[E];
+      long long at_[E];
+      float sdf_[E], uw_[E];
+      uint32_t color_[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        valid_[e] = n_valid[e]; at_[e] = n_at[e]; sdf_[e] = n_sdf[e]; uw_[e] = n_uw[e]; color_[e] = n_color[e];
+        far_[e] = n_far[e];
       }
-      if (cnt == 0) break;
-      const long long at0 = ((long long)__builtin_amdgcn_readfirstlane((int)(at >> 32)) << 32) |
-                            (unsigned int)__builtin_amdgcn_readfirstlane((int)(at & 0xffffffffll));
-      const bool one_voxel = at0 >= 0 && __ballot(valid && at != at0) == 0ull;
-      bool done = false;
-      if (one_voxel) {
-        if (at0 != at_cached) {
-          if (dirty && lane == 0) {
-            L.voxels[at_cached] = pack_voxel(d, w);
-            L.rgba[at_cached] = col;
-          }
-          const unsigned long long v = L.voxels[at0];
-          d = __uint_as_float((unsigned)(v & 0xffffffffull));
-          w = __uint_as_float((unsigned)(v >> 32));
-          col = L.rgba[at0];
-          at_cached = at0;
-          dirty = false;
+      // the valid lanes are a prefix of the E * 64 (the run is contiguous): a full last sub-batch means the
+      // run may go on -- fetch the next E sub-batches while these are applied
+      if (__popcll(__ballot(valid_[E - 1])) == 64) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const size_t qn = b + (size_t)(E + e) * 64 + lane, qc = qn < M ? qn : M - 1;
+          const uint32_t k_ = c_key[qc];
+          n_at[e] = t_at[qc];
+          n_sdf[e] = t_sdf[qc];
+          n_uw[e] = t_w[qc];
+          n_color[e] = t_color[qc];
+          n_far[e] = t_far[qc] != 0;
+          n_valid[e] = qn < M && k_ == key;
         }
-        const bool all_far = __ballot(valid && !(sdf >= 2.0f * trunc)) == 0ull;
-        if (all_far && d == trunc) {
-          const float min_uw = wave_min(valid ? uw : INFINITY);
-          const float bound = fminf(fmaxf(w, c.max_weight), (w + wave_sum(valid ? uw : 0.0f)) * 1.01f);
-          if (min_uw * 1.0e5f >= bound && w + min_uw >= 1e-6f) {  // every step of the batch only adds its weight
+      } else {
+        run_ended = true;
+      }
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const bool valid = valid_[e];
+        const long long at = valid ? at_[e] : -1;
+        const float sdf = sdf_[e], uw = uw_[e];
+        const uint32_t color = color_[e];
+        const int cnt = __popcll(__ballot(valid));
+        if (cnt == 0) break;
+        const long long at0 = ((long long)__builtin_amdgcn_readfirstlane((int)(at >> 32)) << 32) |
+                              (unsigned int)__builtin_amdgcn_readfirstlane((int)(at & 0xffffffffll));
+        const bool one_voxel = at0 >= 0 && __ballot(valid && at != at0) == 0ull;
+        bool done = false;
+        if (one_voxel) {
+          if (at0 != at_cached) {
+            if (dirty && lane == 0) {
+              L.voxels[at_cached] = pack_voxel(d, w);
+              L.rgba[at_cached] = col;
+            }
+            const unsigned long long v = L.voxels[at0];
+            d = __uint_as_float((unsigned)(v & 0xffffffffull));
+            w = __uint_as_float((unsigned)(v >> 32));
+            col = L.rgba[at0];
+            at_cached = at0;
+            dirty = false;
+          }
+          // every update of the sub-batch is "far" (sdf >= 2 t, 1e5 w >= max_weight >= W) and the voxel sits at
+          // +t with W <= max_weight: every step only adds its weight (see above) -- one ballot decides
+          if (d == trunc && w <= c.max_weight && __ballot(valid && !far_[e]) == 0ull) {  // (far_ of invalid lanes: ignored)
             if (w != c.max_weight) {
               for (int k = 0; k < cnt; ++k)
                 w = fminf(c.max_weight, w + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(uw), k)));
@@ -614,39 +640,38 @@ __global__ __launch_bounds__(64) void det_apply_long_kernel(TsdfLayerDev L, vgx_
             done = true;  // (at max_weight already: min(max_weight, max_weight + uw) = max_weight, nothing moves)
           }
         }
-      }
-      if (!done) {
-        for (int k = 0; k < cnt; ++k) {
-          const long long at_k = ((long long)__builtin_amdgcn_readlane((int)(at >> 32), k) << 32) |
-                                 (unsigned int)__builtin_amdgcn_readlane((int)(at & 0xffffffffll), k);
-          if (at_k < 0) {
-            ++dropped;
-            continue;
-          }
-          if (at_k != at_cached) {
-            if (dirty && lane == 0) {
-              L.voxels[at_cached] = pack_voxel(d, w);
-              L.rgba[at_cached] = col;
+        if (!done) {
+          for (int k = 0; k < cnt; ++k) {
+            const long long at_k = ((long long)__builtin_amdgcn_readlane((int)(at >> 32), k) << 32) |
+                                   (unsigned int)__builtin_amdgcn_readlane((int)(at & 0xffffffffll), k);
+            if (at_k < 0) {
+              ++dropped;
+              continue;
             }
-            const unsigned long long v = L.voxels[at_k];
-            d = __uint_as_float((unsigned)(v & 0xffffffffull));
-            w = __uint_as_float((unsigned)(v >> 32));
-            col = L.rgba[at_k];
-            at_cached = at_k;
-            dirty = false;
-          }
-          const float sdf_k = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sdf), k));
-          const float uw_k = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(uw), k));
-          if (d == trunc && sdf_k >= 2.0f * trunc && uw_k * 1.0e5f >= w && w + uw_k >= 1e-6f) {
-            w = fminf(c.max_weight, w + uw_k);  // the average stays at +truncation: weight only
-            dirty = true;
-          } else {
-            const uint32_t color_k = (uint32_t)__builtin_amdgcn_readlane((int)color, k);
-            apply_term(c, sdf_k, uw_k, color_k, d, w, col, dirty);
+            if (at_k != at_cached) {
+              if (dirty && lane == 0) {
+                L.voxels[at_cached] = pack_voxel(d, w);
+                L.rgba[at_cached] = col;
+              }
+              const unsigned long long v = L.voxels[at_k];
+              d = __uint_as_float((unsigned)(v & 0xffffffffull));
+              w = __uint_as_float((unsigned)(v >> 32));
+              col = L.rgba[at_k];
+              at_cached = at_k;
+              dirty = false;
+            }
+            const float sdf_k = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sdf), k));
+            const float uw_k = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(uw), k));
+            if (d == trunc && sdf_k >= 2.0f * trunc && uw_k * 1.0e5f >= w && w + uw_k >= 1e-6f) {
+              w = fminf(c.max_weight, w + uw_k);  // the average stays at +truncation: weight only
+              dirty = true;
+            } else {
+              const uint32_t color_k = (uint32_t)__builtin_amdgcn_readlane((int)color, k);
+              apply_term(c, sdf_k, uw_k, color_k, d, w, col, dirty);
+            }
           }
         }
       }
-      if (cnt < 64) break;
     }
     if (dirty && lane == 0) {
       L.voxels[at_cached] = pack_voxel(d, w);
@@ -856,21 +881,31 @@ static int det_commit(vgx_tsdf_integrator I, DetScratch* S, const float T[7], si
   DET_TRY(grow(ctx, S->t_sdf, M * 4));
   DET_TRY(grow(ctx, S->t_w, M * 4));
   DET_TRY(grow(ctx, S->t_color, M * 4));
+  DET_TRY(grow(ctx, S->t_far, M));
   if (ordered_blocks)
     hipLaunchKernelGGL(det_terms_kernel<false>, dim3(blocks_for(M)), dim3(256), 0, st, L, c, T[4], T[5], T[6], M, c_idx,
                        S->acc_vox.as<unsigned long long>(), S->acc_ray.as<uint32_t>(), ray_pg, ray_color,
-                       S->t_at.as<long long>(), S->t_sdf.as<float>(), S->t_w.as<float>(), S->t_color.as<uint32_t>());
+                       S->t_at.as<long long>(), S->t_sdf.as<float>(), S->t_w.as<float>(), S->t_color.as<uint32_t>(),
+                       S->t_far.as<uint8_t>());
   else
     hipLaunchKernelGGL(det_terms_kernel<true>, dim3(blocks_for(M)), dim3(256), 0, st, L, c, T[4], T[5], T[6], M, c_idx,
                        S->acc_vox.as<unsigned long long>(), S->acc_ray.as<uint32_t>(), ray_pg, ray_color,
-                       S->t_at.as<long long>(), S->t_sdf.as<float>(), S->t_w.as<float>(), S->t_color.as<uint32_t>());
+                       S->t_at.as<long long>(), S->t_sdf.as<float>(), S->t_w.as<float>(), S->t_color.as<uint32_t>(),
+                       S->t_far.as<uint8_t>());
   VGX_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(det_apply_kernel, dim3(blocks_for(M)), dim3(256), 0, st, L, c, M, c_key, S->t_at.as<long long>(),
                      S->t_sdf.as<float>(), S->t_w.as<float>(), S->t_color.as<uint32_t>(), S->long_runs.as<uint32_t>(), S->d_ctr);
-  const unsigned long_grid = (unsigned)std::min<size_t>((size_t)ctx->cu_count * 8, M / kShortRun + 1);
+  const unsigned long_grid = (unsigned)std::min<size_t>((size_t)ctx->cu_count * 32, M / kShortRun + 1);
   hipLaunchKernelGGL(det_apply_long_kernel, dim3(long_grid), dim3(64), 0, st, L, c, M, c_key, S->t_at.as<long long>(),
-                     S->t_sdf.as<float>(), S->t_w.as<float>(), S->t_color.as<uint32_t>(), S->long_runs.as<uint32_t>(), S->d_ctr);
+                     S->t_sdf.as<float>(), S->t_w.as<float>(), S->t_color.as<uint32_t>(), S->t_far.as<uint8_t>(),
+                     S->long_runs.as<uint32_t>(), S->d_ctr);
   VGX_HIP(ctx, hipGetLastError());
+  static const bool debug = getenv("VGX_DET_DEBUG") != nullptr;  // experiment aid: sizes of the ordered application
+  if (debug) {
+    DET_TRY(read_counters(ctx, S));
+    fprintf(stderr, "[vgx det] updates %zu, long runs %llu (of more than %d), accesses sorted %zu\n", M,
+            (unsigned long long)S->h_ctr[kCtrLong], kShortRun, N);
+  }
   if (n_updates) {
     DET_TRY(read_counters(ctx, S));
     *n_updates = (int64_t)M - (int64_t)S->h_ctr[kCtrDropped];
