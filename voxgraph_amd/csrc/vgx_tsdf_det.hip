@@ -58,7 +58,8 @@ struct Buf {
 
 struct DetScratch {
   // per point, indexed by position in the visiting order
-  Buf ray_pg, ray_color, ray_flags, start_val, start_key, start_key_sorted, start_seq_sorted, count, off, T, broke;
+  Buf ray_pg, ray_color, ray_flags, start_val, start_key, start_key_sorted, start_seq_sorted, count, off, T, broke,
+      full_count, ext;
   // per speculative access
   Buf acc_vox, acc_key, acc_ray, s_key, s_idx, s_r, s_k, s_h, last, seen, c_idx, c_key;
   Buf tmp;  // rocprim temporary storage
@@ -70,7 +71,7 @@ struct DetScratch {
   unsigned long long* h_ctr = nullptr;
 };
 
-enum { kCtrChanged = 0, kCtrNew = 1, kCtrError = 2, kCtrDropped = 3, kCtrLong = 4, kCtrCount = 8 };
+enum { kCtrChanged = 0, kCtrNew = 1, kCtrError = 2, kCtrDropped = 3, kCtrLong = 4, kCtrOverflow = 5, kCtrCount = 8 };
 enum { kRayValid = 1u, kRayClearing = 2u, kRayCast = 4u };
 constexpr uint32_t kInvalidStartKey = 1u << kSetBits;
 constexpr long long kVoxBias = 1ll << 20;  // 21 bits per axis
@@ -78,7 +79,7 @@ constexpr long long kVoxBias = 1ll << 20;  // 21 bits per axis
 void det_scratch_free(DetScratch* s) {
   if (!s) return;
   Buf* all[] = {&s->ray_pg, &s->ray_color, &s->ray_flags, &s->start_val, &s->start_key, &s->start_key_sorted,
-                &s->start_seq_sorted, &s->count, &s->off, &s->T, &s->broke, &s->acc_vox, &s->acc_key, &s->acc_ray,
+                &s->start_seq_sorted, &s->count, &s->off, &s->T, &s->broke, &s->full_count, &s->ext, &s->acc_vox, &s->acc_key, &s->acc_ray,
                 &s->s_key, &s->s_idx, &s->s_r, &s->s_k, &s->s_h, &s->last, &s->seen, &s->c_idx, &s->c_key, &s->tmp,
                 &s->first_touch, &s->new_cells, &s->new_cells_sorted, &s->new_keys, &s->new_keys_sorted, &s->long_runs,
                 &s->t_at, &s->t_sdf, &s->t_w, &s->t_color, &s->t_far};
@@ -174,24 +175,48 @@ __global__ __launch_bounds__(256) void det_start_kernel(long long n, const uint3
   }
 }
 
-// ---- 2a. length of every cast ray's complete walk ------------------------------------------------
+// ---- 2a. how far every cast ray is written out --------------------------------------------------------
+// Speculating every ray's COMPLETE walk writes out 10-30 x what happens: all but a few "pioneer" rays of
+// a scan stop within a handful of voxels (their neighbours have just been there).  So a ray is written
+// out `cap` steps deep at first; rays that reach the end of what was written without having stopped
+// (ext[] set by det_extend_kernel) get their complete walk in the next attempt, the others keep theirs.
+// The fixed point of an attempt in which no ray is cut short is the fixed point of the complete system
+// (same accesses happen, same decisions; it is unique), so the result does not depend on `cap`.
+constexpr uint32_t kSpeculationCap = 32;
+
 __global__ __launch_bounds__(256) void det_count_kernel(vgx_tsdf_config c, float vsi, float tx, float ty, float tz,
                                                        long long n, const float4* __restrict__ ray_pg,
                                                        const uint32_t* __restrict__ ray_flags,
-                                                       uint32_t* __restrict__ count,
+                                                       const uint8_t* __restrict__ ext, uint32_t* __restrict__ count,
+                                                       uint32_t* __restrict__ full_count,
                                                        unsigned long long* __restrict__ ctr) {
   const long long seq = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (seq > n) return;
-  uint32_t cnt = 0;
+  uint32_t full = 0;
   if (seq < n && (ray_flags[seq] & kRayCast)) {
     const float4 g = ray_pg[seq];
     const RayDda r = ray_setup(c, vsi, tx, ty, tz, g.x, g.y, g.z, (ray_flags[seq] & kRayClearing) != 0, false);
     if (!r.bad) {
       if (r.steps + 1 >= (1ll << 24)) ctr[kCtrError] = 1ull;  // step index is packed into 24 bits below
-      else cnt = (uint32_t)(r.steps + 1);
+      else full = (uint32_t)(r.steps + 1);
     }
   }
-  count[seq] = cnt;  // count[n] = 0: the scan's last output is the total
+  const bool complete = seq < n && ext[seq] != 0;
+  count[seq] = complete ? full : min(full, kSpeculationCap);  // count[n] = 0: the scan's last output is the total
+  if (seq < n) full_count[seq] = full;
+}
+
+// after the sweeps of an attempt: rays that did not stop within what was written out of them
+__global__ __launch_bounds__(256) void det_extend_kernel(long long n, const uint32_t* __restrict__ count,
+                                                        const uint32_t* __restrict__ full_count,
+                                                        const uint8_t* __restrict__ broke, uint8_t* __restrict__ ext,
+                                                        unsigned long long* __restrict__ ctr) {
+  const long long seq = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (seq >= n) return;
+  if (count[seq] < full_count[seq] && !broke[seq]) {
+    ext[seq] = 1;
+    ctr[kCtrOverflow] = 1ull;
+  }
 }
 
 // ---- 2b. the complete walks, written out ---------------------------------------------------------
@@ -960,107 +985,137 @@ int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points,
                        S->start_val.as<unsigned long long>(), I->dev.start_set, S->ray_flags.as<uint32_t>(), pass);
     VGX_HIP(ctx, hipGetLastError());
   }
-  // ---- 2. complete walks ----
-  hipLaunchKernelGGL(det_count_kernel, dim3(blocks_for(np + 1)), dim3(256), 0, st, c, vsi, T[4], T[5], T[6], (long long)n,
-                     S->ray_pg.as<float4>(), S->ray_flags.as<uint32_t>(), S->count.as<uint32_t>(), S->d_ctr);
-  VGX_HIP(ctx, hipGetLastError());
-  {
-    // 64-bit accumulation so that an overflowing total is seen, not wrapped
-    size_t bytes = 0;
-    VGX_HIP(ctx, rocprim::exclusive_scan(nullptr, bytes, S->count.as<uint32_t>(), S->off.as<uint32_t>(), 0u, np + 1,
-                                         rocprim::plus<uint32_t>(), st));
-    DET_TRY(grow(ctx, S->tmp, bytes));
-    bytes = S->tmp.bytes;
-    VGX_HIP(ctx, rocprim::exclusive_scan(S->tmp.p, bytes, S->count.as<uint32_t>(), S->off.as<uint32_t>(), 0u, np + 1,
-                                         rocprim::plus<uint32_t>(), st));
-  }
-  uint32_t total = 0;
-  VGX_HIP(ctx, hipMemcpyAsync(&total, S->off.as<uint32_t>() + np, 4, hipMemcpyDeviceToHost, st));
-  DET_TRY(read_counters(ctx, S));
-  if (S->h_ctr[kCtrError])
-    return set_error(ctx, VGX_ERR_UNSUPPORTED, "TSDF reproducible mode: a ray longer than 2^24 voxel steps");
-  // the 32-bit total wraps silently: bound it by what a ray can be
-  {
-    const double max_steps = 3.0 * ((double)c.max_ray_length_m + 2.0 * c.default_truncation_distance) * vsi + 8.0;
-    if ((double)n * max_steps >= 4.0e9) {
-      // exact check only when the cheap bound does not settle it
-      std::vector<uint32_t> cnt(np);
-      VGX_HIP(ctx, hipMemcpy(cnt.data(), S->count.p, np * 4, hipMemcpyDeviceToHost));
-      unsigned long long sum = 0;
-      for (uint32_t v : cnt) sum += v;
-      if (sum >= (1ull << 32) - 2)
-        return set_error(ctx, VGX_ERR_UNSUPPORTED, "TSDF reproducible mode: more than 2^32 voxel steps in a scan");
+  // ---- 2. walks written out (bounded speculation: see det_count_kernel), sorted, swept to the fixed point ----
+  DET_TRY(grow(ctx, S->full_count, np * 4));
+  DET_TRY(grow(ctx, S->ext, np + 1));
+  // The first count is of the COMPLETE walks.  Small scans (a LiDAR sweep at 0.2 m: < 1 M steps) are swept as
+  // they are -- an attempt costs a dozen launches and two read-backs, more than the steps saved; large ones
+  // (a depth image at 0.05 m: 18 M steps) are cut to `kSpeculationCap` steps per ray and extended on demand.
+  // With the early-out switched off every ray runs its full length anyway.
+  VGX_HIP(ctx, hipMemsetAsync(S->ext.p, 1, np + 1, st));
+  bool may_cap = c.max_consecutive_ray_collisions < (1 << 20);
+  constexpr uint32_t kCapThreshold = 4u << 20;
+  size_t N = 0;
+  HappenedOp happened{nullptr, nullptr, nullptr};
+  UpdateOp update{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
+  for (int attempt = 0;; ++attempt) {
+    if (attempt > 64) return set_error(ctx, VGX_ERR_HIP, "TSDF reproducible mode: speculation did not settle (internal error)");
+    hipLaunchKernelGGL(det_count_kernel, dim3(blocks_for(np + 1)), dim3(256), 0, st, c, vsi, T[4], T[5], T[6], (long long)n,
+                       S->ray_pg.as<float4>(), S->ray_flags.as<uint32_t>(), S->ext.as<uint8_t>(), S->count.as<uint32_t>(),
+                       S->full_count.as<uint32_t>(), S->d_ctr);
+    VGX_HIP(ctx, hipGetLastError());
+    {
+      // 64-bit accumulation so that an overflowing total is seen, not wrapped
+      size_t bytes = 0;
+      VGX_HIP(ctx, rocprim::exclusive_scan(nullptr, bytes, S->count.as<uint32_t>(), S->off.as<uint32_t>(), 0u, np + 1,
+                                           rocprim::plus<uint32_t>(), st));
+      DET_TRY(grow(ctx, S->tmp, bytes));
+      bytes = S->tmp.bytes;
+      VGX_HIP(ctx, rocprim::exclusive_scan(S->tmp.p, bytes, S->count.as<uint32_t>(), S->off.as<uint32_t>(), 0u, np + 1,
+                                           rocprim::plus<uint32_t>(), st));
     }
-  }
-  const size_t N = total;
-  if (N == 0) return VGX_OK;  // nothing was cast (the start set has been updated)
-  DET_TRY(grow(ctx, S->acc_vox, N * 8));
-  DET_TRY(grow(ctx, S->acc_key, (N + 1) * 4));  // + 1: reused for the compaction offsets
-  DET_TRY(grow(ctx, S->acc_ray, N * 4));
-  DET_TRY(grow(ctx, S->s_key, N * 4));
-  DET_TRY(grow(ctx, S->s_idx, N * 4));
-  DET_TRY(grow(ctx, S->s_r, N * 4));
-  DET_TRY(grow(ctx, S->s_k, N * 4));
-  DET_TRY(grow(ctx, S->s_h, N * 4));
-  DET_TRY(grow(ctx, S->last, (N + 1) * 4));
-  DET_TRY(grow(ctx, S->seen, N));
-  DET_TRY(grow(ctx, S->c_idx, N * 4));
-  DET_TRY(grow(ctx, S->c_key, N * 4));
-  hipLaunchKernelGGL(det_walk_kernel, dim3(blocks_for(np)), dim3(256), 0, st, c, vsi, T[4], T[5], T[6], (long long)n,
-                     S->ray_pg.as<float4>(), S->ray_flags.as<uint32_t>(), S->count.as<uint32_t>(), S->off.as<uint32_t>(),
-                     I->dev.observed_offset, S->acc_vox.as<unsigned long long>(), S->acc_key.as<uint32_t>(),
-                     S->acc_ray.as<uint32_t>(), S->T.as<int32_t>(), S->broke.as<uint8_t>(), S->d_ctr);
-  VGX_HIP(ctx, hipGetLastError());
-  {
-    size_t bytes = 0;
-    auto iota = rocprim::make_counting_iterator<uint32_t>(0u);
-    VGX_HIP(ctx, rocprim::radix_sort_pairs(nullptr, bytes, S->acc_key.as<uint32_t>(), S->s_key.as<uint32_t>(), iota,
-                                           S->s_idx.as<uint32_t>(), N, 0, kSetBits, st));
-    DET_TRY(grow(ctx, S->tmp, bytes));
-    bytes = S->tmp.bytes;
-    // stable: inside a slot the accesses stay in (ray, step) = visiting order
-    VGX_HIP(ctx, rocprim::radix_sort_pairs(S->tmp.p, bytes, S->acc_key.as<uint32_t>(), S->s_key.as<uint32_t>(), iota,
-                                           S->s_idx.as<uint32_t>(), N, 0, kSetBits, st));
-  }
-  hipLaunchKernelGGL(det_gather_kernel, dim3(blocks_for(N)), dim3(256), 0, st, N, S->s_idx.as<uint32_t>(),
-                     S->acc_vox.as<unsigned long long>(), S->acc_ray.as<uint32_t>(), S->off.as<uint32_t>(),
-                     S->s_r.as<uint32_t>(), S->s_k.as<uint32_t>(), S->s_h.as<uint32_t>());
-  VGX_HIP(ctx, hipGetLastError());
-  // ---- sweeps to the fixed point ----
-  const HappenedOp happened{S->s_r.as<uint32_t>(), S->s_k.as<uint32_t>(), S->T.as<int32_t>()};
-  const UpdateOp update{S->s_r.as<uint32_t>(), S->s_k.as<uint32_t>(), S->T.as<int32_t>(), S->broke.as<uint8_t>(),
-                        nullptr, nullptr, (uint32_t)N};
-  auto pos = rocprim::make_counting_iterator<uint32_t>(0u);
-  size_t scan_bytes = 0;
-  VGX_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, rocprim::make_transform_iterator(pos, happened),
-                                       S->last.as<uint32_t>(), 0u, N, rocprim::maximum<uint32_t>(), st));
-  {
-    size_t b2 = 0;
-    VGX_HIP(ctx, rocprim::exclusive_scan(nullptr, b2, rocprim::make_transform_iterator(pos, update), S->last.as<uint32_t>(),
-                                         0u, N + 1, rocprim::plus<uint32_t>(), st));
-    scan_bytes = std::max(scan_bytes, b2);
-  }
-  DET_TRY(grow(ctx, S->tmp, scan_bytes));
-  {
-    // a sweep that changes no stopping step is the fixed point; n + 1 sweeps always suffice
-    for (long long sweep = 0;; ++sweep) {
-      if (sweep > n + 1) return set_error(ctx, VGX_ERR_HIP, "TSDF reproducible mode: the sweeps did not settle (internal error)");
-      VGX_HIP(ctx, hipMemsetAsync(S->d_ctr + kCtrChanged, 0, 8, st));
-      size_t bytes = S->tmp.bytes;
-      VGX_HIP(ctx, rocprim::exclusive_scan(S->tmp.p, bytes, rocprim::make_transform_iterator(pos, happened),
-                                           S->last.as<uint32_t>(), 0u, N, rocprim::maximum<uint32_t>(), st));
-      hipLaunchKernelGGL(det_seen_kernel, dim3(blocks_for(N)), dim3(256), 0, st, N, S->s_key.as<uint32_t>(),
-                         S->s_idx.as<uint32_t>(), S->s_h.as<uint32_t>(), S->last.as<uint32_t>(), I->dev.observed_set,
-                         I->dev.observed_offset, S->seen.as<uint8_t>());
-      VGX_HIP(ctx, hipGetLastError());
-      hipLaunchKernelGGL(det_ray_kernel, dim3(blocks_for(np)), dim3(256), 0, st, (long long)n,
-                         (int)c.max_consecutive_ray_collisions, S->count.as<uint32_t>(), S->off.as<uint32_t>(),
-                         S->seen.as<uint8_t>(), S->T.as<int32_t>(), S->broke.as<uint8_t>(), S->d_ctr);
-      VGX_HIP(ctx, hipGetLastError());
-      DET_TRY(read_counters(ctx, S));
-      if (S->h_ctr[kCtrError]) break;
-      if (!S->h_ctr[kCtrChanged]) break;
+    uint32_t total = 0;
+    VGX_HIP(ctx, hipMemcpyAsync(&total, S->off.as<uint32_t>() + np, 4, hipMemcpyDeviceToHost, st));
+    DET_TRY(read_counters(ctx, S));
+    if (S->h_ctr[kCtrError])
+      return set_error(ctx, VGX_ERR_UNSUPPORTED, "TSDF reproducible mode: a ray longer than 2^24 voxel steps");
+    // the 32-bit total wraps silently: bound it by what a ray can be
+    {
+      const double max_steps = 3.0 * ((double)c.max_ray_length_m + 2.0 * c.default_truncation_distance) * vsi + 8.0;
+      if ((double)n * max_steps >= 4.0e9) {
+        // exact check only when the cheap bound does not settle it
+        std::vector<uint32_t> cnt(np);
+        VGX_HIP(ctx, hipMemcpy(cnt.data(), S->count.p, np * 4, hipMemcpyDeviceToHost));
+        unsigned long long sum = 0;
+        for (uint32_t v : cnt) sum += v;
+        if (sum >= (1ull << 32) - 2)
+          return set_error(ctx, VGX_ERR_UNSUPPORTED, "TSDF reproducible mode: more than 2^32 voxel steps in a scan");
+      }
     }
+    N = total;
+    if (N == 0) return VGX_OK;  // nothing was cast (the start set has been updated)
+    if (may_cap) {
+      may_cap = false;
+      if (total > kCapThreshold) {  // count again, this time cut to the cap
+        VGX_HIP(ctx, hipMemsetAsync(S->ext.p, 0, np + 1, st));
+        continue;
+      }
+    }
+    DET_TRY(grow(ctx, S->acc_vox, N * 8));
+    DET_TRY(grow(ctx, S->acc_key, (N + 1) * 4));  // + 1: reused for the compaction offsets
+    DET_TRY(grow(ctx, S->acc_ray, N * 4));
+    DET_TRY(grow(ctx, S->s_key, N * 4));
+    DET_TRY(grow(ctx, S->s_idx, N * 4));
+    DET_TRY(grow(ctx, S->s_r, N * 4));
+    DET_TRY(grow(ctx, S->s_k, N * 4));
+    DET_TRY(grow(ctx, S->s_h, N * 4));
+    DET_TRY(grow(ctx, S->last, (N + 1) * 4));
+    DET_TRY(grow(ctx, S->seen, N));
+    DET_TRY(grow(ctx, S->c_idx, N * 4));
+    DET_TRY(grow(ctx, S->c_key, N * 4));
+    hipLaunchKernelGGL(det_walk_kernel, dim3(blocks_for(np)), dim3(256), 0, st, c, vsi, T[4], T[5], T[6], (long long)n,
+                       S->ray_pg.as<float4>(), S->ray_flags.as<uint32_t>(), S->count.as<uint32_t>(), S->off.as<uint32_t>(),
+                       I->dev.observed_offset, S->acc_vox.as<unsigned long long>(), S->acc_key.as<uint32_t>(),
+                       S->acc_ray.as<uint32_t>(), S->T.as<int32_t>(), S->broke.as<uint8_t>(), S->d_ctr);
+    VGX_HIP(ctx, hipGetLastError());
+    {
+      size_t bytes = 0;
+      auto iota = rocprim::make_counting_iterator<uint32_t>(0u);
+      VGX_HIP(ctx, rocprim::radix_sort_pairs(nullptr, bytes, S->acc_key.as<uint32_t>(), S->s_key.as<uint32_t>(), iota,
+                                             S->s_idx.as<uint32_t>(), N, 0, kSetBits, st));
+      DET_TRY(grow(ctx, S->tmp, bytes));
+      bytes = S->tmp.bytes;
+      // stable: inside a slot the accesses stay in (ray, step) = visiting order
+      VGX_HIP(ctx, rocprim::radix_sort_pairs(S->tmp.p, bytes, S->acc_key.as<uint32_t>(), S->s_key.as<uint32_t>(), iota,
+                                             S->s_idx.as<uint32_t>(), N, 0, kSetBits, st));
+    }
+    hipLaunchKernelGGL(det_gather_kernel, dim3(blocks_for(N)), dim3(256), 0, st, N, S->s_idx.as<uint32_t>(),
+                       S->acc_vox.as<unsigned long long>(), S->acc_ray.as<uint32_t>(), S->off.as<uint32_t>(),
+                       S->s_r.as<uint32_t>(), S->s_k.as<uint32_t>(), S->s_h.as<uint32_t>());
+    VGX_HIP(ctx, hipGetLastError());
+    // ---- sweeps to the fixed point ----
+    happened = HappenedOp{S->s_r.as<uint32_t>(), S->s_k.as<uint32_t>(), S->T.as<int32_t>()};
+    update = UpdateOp{S->s_r.as<uint32_t>(), S->s_k.as<uint32_t>(), S->T.as<int32_t>(), S->broke.as<uint8_t>(),
+                      nullptr, nullptr, (uint32_t)N};
+    auto pos = rocprim::make_counting_iterator<uint32_t>(0u);
+    size_t scan_bytes = 0;
+    VGX_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, rocprim::make_transform_iterator(pos, happened),
+                                         S->last.as<uint32_t>(), 0u, N, rocprim::maximum<uint32_t>(), st));
+    {
+      size_t b2 = 0;
+      VGX_HIP(ctx, rocprim::exclusive_scan(nullptr, b2, rocprim::make_transform_iterator(pos, update), S->last.as<uint32_t>(),
+                                           0u, N + 1, rocprim::plus<uint32_t>(), st));
+      scan_bytes = std::max(scan_bytes, b2);
+    }
+    DET_TRY(grow(ctx, S->tmp, scan_bytes));
+    {
+      // a sweep that changes no stopping step is the fixed point; n + 1 sweeps always suffice
+      for (long long sweep = 0;; ++sweep) {
+        if (sweep > n + 1) return set_error(ctx, VGX_ERR_HIP, "TSDF reproducible mode: the sweeps did not settle (internal error)");
+        VGX_HIP(ctx, hipMemsetAsync(S->d_ctr + kCtrChanged, 0, 8, st));
+        size_t bytes = S->tmp.bytes;
+        VGX_HIP(ctx, rocprim::exclusive_scan(S->tmp.p, bytes, rocprim::make_transform_iterator(pos, happened),
+                                             S->last.as<uint32_t>(), 0u, N, rocprim::maximum<uint32_t>(), st));
+        hipLaunchKernelGGL(det_seen_kernel, dim3(blocks_for(N)), dim3(256), 0, st, N, S->s_key.as<uint32_t>(),
+                           S->s_idx.as<uint32_t>(), S->s_h.as<uint32_t>(), S->last.as<uint32_t>(), I->dev.observed_set,
+                           I->dev.observed_offset, S->seen.as<uint8_t>());
+        VGX_HIP(ctx, hipGetLastError());
+        hipLaunchKernelGGL(det_ray_kernel, dim3(blocks_for(np)), dim3(256), 0, st, (long long)n,
+                           (int)c.max_consecutive_ray_collisions, S->count.as<uint32_t>(), S->off.as<uint32_t>(),
+                           S->seen.as<uint8_t>(), S->T.as<int32_t>(), S->broke.as<uint8_t>(), S->d_ctr);
+        VGX_HIP(ctx, hipGetLastError());
+        DET_TRY(read_counters(ctx, S));
+        if (S->h_ctr[kCtrError]) break;
+        if (!S->h_ctr[kCtrChanged]) break;
+      }
+    }
+    if (S->h_ctr[kCtrError]) break;
+    VGX_HIP(ctx, hipMemsetAsync(S->d_ctr + kCtrOverflow, 0, 8, st));
+    hipLaunchKernelGGL(det_extend_kernel, dim3(blocks_for(np)), dim3(256), 0, st, (long long)n, S->count.as<uint32_t>(),
+                       S->full_count.as<uint32_t>(), S->broke.as<uint8_t>(), S->ext.as<uint8_t>(), S->d_ctr);
+    VGX_HIP(ctx, hipGetLastError());
+    DET_TRY(read_counters(ctx, S));
+    if (!S->h_ctr[kCtrOverflow]) break;  // no ray was cut short: this is the sequential execution
   }
   if (S->h_ctr[kCtrError])
     return set_error(ctx, VGX_ERR_UNSUPPORTED, "TSDF reproducible mode: a voxel index beyond +-2^20 voxels of the layer origin");
