@@ -1209,6 +1209,10 @@ def main():
                                                 poses, cfg, batch if world == 1 else None, n_sub, n_con)
             except Exception as e:       # an optional section must never cost the line (peer access, memory, ...)
                 multi_ctx = {"error": repr(e), "device_ids": devices}
+            finally:
+                # the library selects each context's device for its calls; PyTorch must find the rank's own
+                # device current again (its allocator and the RCCL communicator live there)
+                torch.cuda.set_device(local_rank)
         barrier()
 
     # ---- metric 2: full pose-graph solve (harness LM, stand-in for ceres::Solve) ---
