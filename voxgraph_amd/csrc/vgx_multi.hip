@@ -79,6 +79,18 @@ static RcclApi& rccl_api() {
   return api;
 }
 
+// The multi-context entry points select one device after another; the caller (voxgraph's own thread, or
+// PyTorch in the bench) finds its current device unchanged afterwards.
+struct DeviceGuard {
+  int dev = -1;
+  DeviceGuard() {
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+  }
+  ~DeviceGuard() {
+    if (dev >= 0) (void)hipSetDevice(dev);
+  }
+};
+
 }  // namespace vgx
 
 using namespace vgx;
@@ -192,6 +204,7 @@ int vgx_lpt_shards(int32_t n, const int64_t* weight, int32_t n_shards, int32_t* 
 
 int vgx_reg_multi_destroy(vgx_reg_multi m) {
   if (!m) return VGX_ERR_INVALID;
+  DeviceGuard guard;
   {
     std::lock_guard<std::mutex> lk(m->mu);
     m->quit = true;
@@ -222,6 +235,7 @@ int vgx_reg_multi_create(int32_t n_ctx, const vgx_ctx* ctxs, int32_t n, const vg
   if (n_ctx <= 0 || n_ctx > kMaxShards || !ctxs || n < 0 || (n > 0 && (!regs || !node_pair))) return VGX_ERR_INVALID;
   for (int k = 0; k < n_ctx; ++k)
     if (!ctxs[k]) return VGX_ERR_INVALID;
+  DeviceGuard guard;
   vgx_ctx ctx0 = ctxs[0];
   vgx_reg_multi m = new (std::nothrow) vgx_reg_multi_s();
   if (!m) return set_error(ctx0, VGX_ERR_NOMEM, "vgx_reg_multi_create: out of host memory");
@@ -290,6 +304,7 @@ int32_t vgx_reg_multi_num_shards(vgx_reg_multi m) { return m ? (int32_t)m->shard
 
 int vgx_reg_multi_set_reduction(vgx_reg_multi m, int32_t reduction) {
   if (!m || (reduction != VGX_REDUCE_PEER_SUM && reduction != VGX_REDUCE_RCCL)) return VGX_ERR_INVALID;
+  DeviceGuard guard;
   std::lock_guard<std::mutex> call(m->call_mu);
   vgx_ctx ctx0 = m->shards[0]->ctx;
   if (reduction == VGX_REDUCE_RCCL && m->comms.empty()) {
@@ -322,6 +337,7 @@ int vgx_reg_multi_shard_of(vgx_reg_multi m, int32_t* shard_of) {
 int vgx_reg_multi_evaluate_fused(vgx_reg_multi m, const double* poses, int32_t n_nodes, double* fused_host,
                                  int32_t* status) {
   if (!m || !poses || !fused_host || n_nodes <= 0) return VGX_ERR_INVALID;
+  DeviceGuard guard;
   std::lock_guard<std::mutex> call(m->call_mu);
   vgx_ctx ctx0 = m->shards[0]->ctx;
   const int64_t size = vgx_reg_fused_size(n_nodes, m->n);
