@@ -203,3 +203,27 @@ def test_solve_survives_single_thread_blas_environment():
     env = dict(os.environ, OMP_NUM_THREADS="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "SOLVED" in r.stdout, (r.returncode, r.stderr[-2000:])
+
+
+def test_parity_gate_picks_culled_and_live_constraints():
+    """bench.py's same-run parity gate samples deterministically: a fully culled constraint when there is
+    one, partly culled ones spread over the culled fraction, the rest the heaviest live ones"""
+    from harness import parity_gate
+    n_rows = np.array([1000, 2000, 3000, 4000, 5000, 6000, 7000, 8000, 9000, 10000])
+    live = np.array([0, 2000, 300, 4000, 2500, 6000, 0, 7900, 4500, 10000])
+    got = parity_gate.choose(n_rows, live, n_total=6, n_partial=3, n_dead=1)
+    assert len(got) == len(set(got)) == 6
+    assert got[0] == 0                                            # the first fully culled one
+    partial = [c for c in got if 0 < live[c] < 0.9 * n_rows[c]]
+    assert len(partial) >= 3 and 2 in partial and 4 in partial     # least and most live of the partly culled
+    full = [c for c in got if live[c] >= 0.9 * n_rows[c]]
+    assert full and full[0] == 9                                   # heaviest fully live first
+    assert parity_gate.choose(n_rows, live, 6, 3, 1) == got        # deterministic
+    # fewer constraints than asked for: all of them, once
+    assert sorted(parity_gate.choose(n_rows[:3], live[:3], 8, 3, 1)) == [0, 1, 2]
+    m = parity_gate.merge([dict(values_checked=10, constraints_checked=2, max_rel=0.0, exact=True, fused_blocks_max_rel=1e-7,
+                                **{"fused_blocks_within_1e-6": True}, checker="x", rule="y"),
+                           dict(values_checked=5, constraints_checked=1, max_rel=1e-3, exact=False, fused_blocks_max_rel=2e-6,
+                                **{"fused_blocks_within_1e-6": False}, checker="x", rule="y"), None])
+    assert m["checked"] == 15 and not m["exact"] and m["max_rel"] == 1e-3 and not m["fused_blocks_within_1e-6"]
+    assert parity_gate.merge([None]) is None
