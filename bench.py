@@ -1181,6 +1181,10 @@ def main():
                 subs_q.append(sm)
             q = shipped_eval(ctx_q, subs_q)
             q["brick_layout"] = "quad (vgx_ctx_set_brick_layout(VGX_BRICKS_QUAD): 4.25 x the grid memory)"
+            trq = (PROFILE_TRAFFIC.get("fused") or {}).get("shipped_quad") or {}
+            okq = trq.get("evaluations") == q["residuals_per_evaluation"] and world == 1 and trq.get("avg_ms_rocprof")
+            q["traffic_from_profiles"] = trq.get("hbm_bytes_per_launch") if okq else None
+            q["hbm_frac"] = (trq["hbm_bytes_per_launch"] / (trq["avg_ms_rocprof"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if okq else None
             q["cost_equals_apron"] = bool(q["cost"] == shipped["cost"])
             shipped["quad_bricks"] = q
             for sm in subs_q:
