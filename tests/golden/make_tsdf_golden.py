@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Golden digests of the TSDF oracle (oracle/tsdf_oracle.c, single thread, mixed order) on seeded scans:
+    python tests/golden/make_tsdf_golden.py        -> tests/golden/tsdf_oracle_digests.json
+The oracle restates voxblox from recall (parity unpinned: voxblox is not vendored in /root/reference), so
+these digests pin the RESTATEMENT, not voxblox: tests/test_oracle_tsdf.py checks that the oracle still
+produces them (a silent change of the restatement would move every GPU comparison with it), and
+tests/test_tsdf_deterministic_gpu.py that the device's reproducible mode produces the same bytes."""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+F = np.float32
+
+
+def scan(n_az, n_el, seed, origin):
+    rng = np.random.default_rng(seed)
+    az = np.linspace(-np.pi, np.pi, n_az, endpoint=False) + rng.uniform(0, 1e-3)
+    el = np.linspace(-0.35, 0.35, n_el)
+    A, E = np.meshgrid(az, el)
+    d = np.stack([np.cos(E) * np.cos(A), np.cos(E) * np.sin(A), np.sin(E)], -1).reshape(-1, 3)
+    lo, hi = np.array([-5.0, -4.0, -1.0]) - origin, np.array([5.0, 4.0, 3.0]) - origin
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t = np.where(d > 0, hi / d, np.where(d < 0, lo / d, np.inf)).min(1)
+    pts = (d * t[:, None]).astype(F)
+    pts[::53] *= F(3.0)                      # beyond the maximum range: clearing rays
+    pts[7::61] *= F(0.005)                   # below the minimum range: dropped
+    col = rng.integers(0, 256, (len(pts), 4)).astype(np.uint8)
+    return pts, col
+
+
+def sessions():
+    """(name, config kwargs, merged?, [(T, points, colours)])"""
+    out = []
+    for name, kw, merged in (("fast_voxgraph_yaml", dict(default_truncation_distance=0.6, max_ray_length_m=8.0, use_const_weight=1,
+                                                          use_weight_dropoff=1, use_sparsity_compensation_factor=1,
+                                                          sparsity_compensation_factor=20.0), False),
+                             ("fast_voxblox_defaults", dict(default_truncation_distance=0.4, max_ray_length_m=6.0), False),
+                             ("merged_anti_grazing", dict(default_truncation_distance=0.6, max_ray_length_m=8.0,
+                                                          enable_anti_grazing=1), True)):
+        scans = []
+        for k in range(3):
+            origin = np.array([0.3 * k - 0.2, -0.25 * k, 0.05 * k])
+            pts, col = scan(512, 24, 100 + k, origin)
+            yaw = 0.2 * k
+            c, s_ = np.cos(-yaw), np.sin(-yaw)
+            pts = np.stack([c * pts[:, 0] - s_ * pts[:, 1], s_ * pts[:, 0] + c * pts[:, 1], pts[:, 2]], 1).astype(F)
+            T = np.r_[np.cos(yaw / 2), 0, 0, np.sin(yaw / 2), origin].astype(F)
+            scans.append((T, pts, col))
+        out.append((name, kw, merged, scans))
+    return out
+
+
+def digest(layer_download):
+    h = hashlib.sha256()
+    for a in layer_download:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def run(make_layer, make_integrator, kw, merged, scans):
+    layer = make_layer(0.2, 16)
+    integ = make_integrator(kw, layer)
+    updates = []
+    for T, pts, col in scans:
+        updates.append(int((integ.integratePointCloudMerged if merged else integ.integratePointCloud)(T, pts, col)))
+    return {"updates": updates, "blocks": int(len(layer.download()[0])), "sha256": digest(layer.download())}
+
+
+def main():
+    from oracle import pyoracle as orc
+    out = {}
+    for name, kw, merged, scans in sessions():
+        out[name] = run(lambda vs, vps: orc.TsdfLayer(vs, vps), lambda kw_, l: orc.FastTsdfIntegrator(orc.tsdf_config(**kw_), l),
+                        kw, merged, scans)
+        print(name, out[name])
+    json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tsdf_oracle_digests.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -152,3 +152,19 @@ def test_wall_scan_reconstructs_plane_distance():
     assert len(band) > 300
     err = [abs(v[0] - (3.02 - (k[0] + 0.5) * vs)) for k, v in band]
     assert np.percentile(err, 95) < 0.015
+
+
+def test_oracle_reproduces_its_committed_digests(golden_dir):
+    """tests/golden/tsdf_oracle_digests.json (made by tests/golden/make_tsdf_golden.py): three seeded
+    sessions -- fast integrator with the shipped yaml, fast integrator with voxblox's defaults (1/z^2
+    weights), merged integrator with anti-grazing -- with clearing and too-short returns and colours.  A
+    change of the restatement moves these digests (the merged integrator's ray direction did, in round 3)
+    and must be made on purpose."""
+    import json
+    import os
+    from tests.golden import make_tsdf_golden as G
+    want = json.load(open(os.path.join(golden_dir, "tsdf_oracle_digests.json")))
+    for name, kw, merged, scans in G.sessions():
+        got = G.run(lambda vs, vps: orc.TsdfLayer(vs, vps), lambda kw_, l: orc.FastTsdfIntegrator(orc.tsdf_config(**kw_), l),
+                    kw, merged, scans)
+        assert got == want[name], (name, got, want[name])

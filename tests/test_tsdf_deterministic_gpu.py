@@ -320,3 +320,27 @@ def test_small_scans_and_sets_that_are_not_reset_every_frame(capi, ctx):
     assert gl.stats()[1] == 0 and ol.num_blocks() > 20
     for o in (gi, gl):
         o.destroy()
+
+
+def test_reproducible_mode_matches_the_committed_oracle_digests(capi, ctx, golden_dir):
+    """the same three sessions as tests/test_oracle_tsdf.py's golden test, on the device in the
+    reproducible mode: update counts, block count and the SHA-256 of the downloaded layer (block list,
+    distances, weights, colours) equal the committed digests of the oracle"""
+    import json
+    import os
+    from tests.golden import make_tsdf_golden as G
+    want = json.load(open(os.path.join(golden_dir, "tsdf_oracle_digests.json")))
+    for name, kw, merged, scans in G.sessions():
+        made = []
+
+        def make_layer(vs, vps):
+            made.append(capi.TsdfLayer(ctx, vs, vps))
+            return made[-1]
+
+        def make_integ(kw_, layer):
+            made.append(capi.FastTsdfIntegrator(ctx, capi.tsdf_config(deterministic=1, **kw_), layer))
+            return made[-1]
+        got = G.run(make_layer, make_integ, kw, merged, scans)
+        assert got == want[name], (name, got, want[name])
+        for o in reversed(made):
+            o.destroy()
