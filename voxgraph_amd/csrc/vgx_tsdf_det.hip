@@ -722,6 +722,9 @@ __device__ __forceinline__ unsigned long long merged_voxel_key(int x, int y, int
          ((unsigned long long)(z + (long long)kMergedKeyBias) & 0x1fffffull);
 }
 
+// 16 lanes per group: the DDA is a sequential f32 recurrence, so all 16 run it in lock step (the same
+// arithmetic as the single-thread walk, hence the same voxels) and lane l keeps step base + l: the records
+// of 16 consecutive steps are written side by side instead of one thread striding through its ray.
 __global__ __launch_bounds__(256) void det_merged_walk_kernel(vgx_tsdf_config c, float vsi, float tx, float ty, float tz,
                                                              uint32_t G, const float4* __restrict__ g_pg,
                                                              const uint32_t* __restrict__ g_flags,
@@ -734,37 +737,49 @@ __global__ __launch_bounds__(256) void det_merged_walk_kernel(vgx_tsdf_config c,
                                                              uint32_t* __restrict__ acc_key, uint32_t* __restrict__ acc_ray,
                                                              uint8_t* __restrict__ upd,
                                                              unsigned long long* __restrict__ ctr) {
-  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= G || g >= counters[0]) return;
-  const uint32_t cnt = g_count[g];
-  if (cnt == 0) return;
+  constexpr int LANES = 16;
+  const int lane = threadIdx.x & (LANES - 1);
+  const uint32_t n_groups = min(G, counters[0]);
   const long long n_surface = counters[1];
-  const bool clearing_ray = (g_flags[g] & 2u) != 0;
-  const float4 pg = g_pg[g];
-  const unsigned long long own_key = keys[group_start[g]] & ~(1ull << 63);
-  RayDda r = ray_setup(c, vsi, tx, ty, tz, pg.x, pg.y, pg.z, clearing_ray, true);
-  const size_t base = off[g];
+  const uint32_t n_sub = gridDim.x * (blockDim.x / LANES);
   bool out_of_range = false;
-  for (uint32_t k = 0; k < cnt; ++k) {
-    const int vx = r.curr[0], vy = r.curr[1], vz = r.curr[2];
-    dda_advance(r);
-    out_of_range |= vx <= -kVoxBias || vx >= kVoxBias || vy <= -kVoxBias || vy >= kVoxBias || vz <= -kVoxBias || vz >= kVoxBias;
-    uint8_t u = 1;
-    if (anti_grazing) {  // skip voxels that are the end voxel of another surface group (voxel_map.find)
-      const unsigned long long key = merged_voxel_key(vx, vy, vz);
-      if (clearing_ray || key != own_key) {
-        long long lo = 0, hi = n_surface;
-        while (lo < hi) {
-          const long long mid = (lo + hi) >> 1;
-          if (keys[mid] < key) lo = mid + 1; else hi = mid;
+  for (uint32_t g = blockIdx.x * (blockDim.x / LANES) + threadIdx.x / LANES; g < n_groups; g += n_sub) {
+    const uint32_t cnt = g_count[g];
+    if (cnt == 0) continue;
+    const bool clearing_ray = (g_flags[g] & 2u) != 0;
+    const float4 pg = g_pg[g];
+    const unsigned long long own_key = keys[group_start[g]] & ~(1ull << 63);
+    RayDda r = ray_setup(c, vsi, tx, ty, tz, pg.x, pg.y, pg.z, clearing_ray, true);
+    const size_t base = off[g];
+    for (uint32_t k0 = 0; k0 < cnt; k0 += LANES) {
+      int vx = 0, vy = 0, vz = 0;
+#pragma unroll
+      for (int i = 0; i < LANES; ++i) {
+        if (i == lane) {
+          vx = r.curr[0]; vy = r.curr[1]; vz = r.curr[2];
         }
-        if (lo < n_surface && keys[lo] == key) u = 0;
+        dda_advance(r);
       }
+      const uint32_t k = k0 + lane;
+      if (k >= cnt) continue;
+      out_of_range |= vx <= -kVoxBias || vx >= kVoxBias || vy <= -kVoxBias || vy >= kVoxBias || vz <= -kVoxBias || vz >= kVoxBias;
+      uint8_t u = 1;
+      if (anti_grazing) {  // skip voxels that are the end voxel of another surface group (voxel_map.find)
+        const unsigned long long key = merged_voxel_key(vx, vy, vz);
+        if (clearing_ray || key != own_key) {
+          long long lo = 0, hi = n_surface;
+          while (lo < hi) {
+            const long long mid = (lo + hi) >> 1;
+            if (keys[mid] < key) lo = mid + 1; else hi = mid;
+          }
+          if (lo < n_surface && keys[lo] == key) u = 0;
+        }
+      }
+      acc_vox[base + k] = pack_vox(vx, vy, vz);
+      acc_key[base + k] = index_hash(vx, vy, vz) & kSetMask;
+      acc_ray[base + k] = g;
+      upd[base + k] = u;
     }
-    acc_vox[base + k] = pack_vox(vx, vy, vz);
-    acc_key[base + k] = index_hash(vx, vy, vz) & kSetMask;
-    acc_ray[base + k] = g;
-    upd[base + k] = u;
   }
   if (out_of_range) ctr[kCtrError] = 2ull;
 }
@@ -1163,7 +1178,8 @@ int det_merged_commit(vgx_tsdf_integrator I, const float T[7], long long n, cons
   DET_TRY(grow(ctx, S->seen, N));
   DET_TRY(grow(ctx, S->c_idx, N * 4));
   DET_TRY(grow(ctx, S->c_key, N * 4));
-  hipLaunchKernelGGL(det_merged_walk_kernel, dim3(blocks_for(G)), dim3(256), 0, st, c, I->layer->dev.voxel_size_inv, T[4], T[5],
+  const unsigned walk_grid = (unsigned)std::min<size_t>((G * 16 + 255) / 256, (size_t)ctx->cu_count * 16);
+  hipLaunchKernelGGL(det_merged_walk_kernel, dim3(walk_grid), dim3(256), 0, st, c, I->layer->dev.voxel_size_inv, T[4], T[5],
                      T[6], (uint32_t)G, g_pg, g_flags, g_count, S->off.as<uint32_t>(), keys_sorted, group_start, counters,
                      (int)c.enable_anti_grazing, S->acc_vox.as<unsigned long long>(),
                      S->acc_key.as<uint32_t>(), S->acc_ray.as<uint32_t>(), S->seen.as<uint8_t>(), S->d_ctr);
