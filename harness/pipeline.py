@@ -34,7 +34,10 @@ through an oracle-only chain (tsdf_oracle -> esdf_oracle -> iso_oracle -> reg_or
 drift alike in every mode (batch solve of the whole 30-submap lap, 512 x 32 rays, 30 scans per
 submap: mirrored isosurface + ESDF from truth GPU 0.11 m / oracle 0.13 m, from drift 0.29 / 0.28 m;
 + TSDF 0.19 / 0.16 and 0.59 / 0.60; kVoxels + ESDF 0.35 / 0.30 and 0.67 / 0.73;
-profiles/r02_chain_compare_30submaps.json, tests/test_chain_compare_gpu.py).
+profiles/r02_chain_compare_30submaps.json).  Round 3 refined that: with the TSDF integrated in the
+reproducible mode (deterministic_tsdf=True) the GPU chain's end state equals the oracle chain's to
+5-30 um (tests/test_chain_compare_gpu.py); the racing TSDF mode adds a run-to-run spread of a few cm of
+its own on this weakly constrained street (profiles/r03_chain_compare.json).
 
 Measurement / test infrastructure (uses harness.lm, torch for device buffers)."""
 import time
