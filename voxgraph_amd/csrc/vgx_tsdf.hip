@@ -375,9 +375,17 @@ __global__ __launch_bounds__(256) void merged_bundle_kernel(vgx_tsdf_config c, f
                                                            float qz, float tx, float ty, float tz,
                                                            const float* __restrict__ points_C, long long n,
                                                            int freespace_points, unsigned long long* __restrict__ keys,
-                                                           unsigned int* __restrict__ idx) {
+                                                           unsigned int* __restrict__ idx,
+                                                           unsigned int* __restrict__ counters,
+                                                           uint32_t* __restrict__ g_count) {
   const long long seq = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (seq >= n) return;
+  // (this scan's group counters and per-group ray lengths start from zero: two memsets saved)
+  g_count[seq] = 0u;
+  if (seq == 0) {
+    g_count[n] = 0u;
+    counters[0] = counters[1] = counters[2] = counters[3] = 0u;
+  }
   // MixedThreadSafeIndex: 1024-point groups visited round-robin, tail in order
   const long long step_size = 1024, number_of_groups = n / step_size;
   long long pi = seq;
@@ -1222,7 +1230,7 @@ static int merged_integrate_locked(vgx_tsdf_integrator I, const float T[7], cons
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
     hipLaunchKernelGGL(merged_bundle_kernel, grid, block, 0, ctx->stream, c, I->layer->dev.voxel_size_inv, T[0], T[1],
                        T[2], T[3], T[4], T[5], T[6], (const float*)d_points, (long long)n, (int)freespace,
-                       I->d_mkeys[0], I->d_midx[0]);
+                       I->d_mkeys[0], I->d_midx[0], I->d_mcounters, I->d_gcount);
     VGX_HIP(ctx, hipGetLastError());
     size_t bytes = I->msort_bytes;
     // stable: equal keys keep the visiting order they were written in
@@ -1230,7 +1238,6 @@ static int merged_integrate_locked(vgx_tsdf_integrator I, const float T[7], cons
                                            (size_t)n, 0, 64, ctx->stream));
     keys_sorted = I->d_mkeys[1];
     idx_sorted = I->d_midx[1];
-    VGX_HIP(ctx, hipMemsetAsync(I->d_mcounters, 0, 16, ctx->stream));
     bytes = I->msort_bytes;
     VGX_HIP(ctx, rocprim::exclusive_scan(I->d_msort, bytes,
                                          rocprim::make_transform_iterator(rocprim::make_counting_iterator<unsigned int>(0u),
@@ -1239,7 +1246,6 @@ static int merged_integrate_locked(vgx_tsdf_integrator I, const float T[7], cons
     hipLaunchKernelGGL(merged_heads_kernel, grid, block, 0, ctx->stream, keys_sorted, (long long)n, I->d_mrank, I->d_mstart,
                        I->d_mcounters);
     VGX_HIP(ctx, hipGetLastError());
-    VGX_HIP(ctx, hipMemsetAsync(I->d_gcount, 0, ((size_t)n + 1) * 4, ctx->stream));  // groups that do not exist: no voxels
     // one L-lane sub-group per group, grid-stride (the number of groups stays on the device)
     constexpr int kLanes = 16;
     const unsigned work_groups = (unsigned)std::min<long long>(((long long)n * kLanes + 255) / 256, (long long)ctx->cu_count * 16);
