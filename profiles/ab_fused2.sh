@@ -8,7 +8,7 @@
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
-ARGS="--steps 5 --warmup 1 --inner 2 --no-cpu-baseline --no-solve --no-tsdf --no-shipped"
+ARGS="--steps 5 --warmup 1 --inner 2 --no-cpu-baseline --no-solve --no-tsdf --no-shipped --no-config5 --no-config2 --no-multi-ctx --no-parity"
 pick='import json,sys
 d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith("{")][-1])
 f,fo=d["fused"],d["roofline_full_overlap"]
