@@ -15,7 +15,7 @@ f,fo=d["fused"],d["roofline_full_overlap"]
 print("fused %.3f ms (stream %.3f, rel.err %.1e) | fused full-overlap %.3f ms (rel.err %.1e) | points %.3f ms | points full-overlap %.3f ms" % (
  f["ms_per_step"],f["stream_ms_per_step"],f["cost_vs_materialised"],fo["fused"]["ms_per_step"],fo["fused"]["cost_vs_materialised"],
  d["roofline"]["kernel_ms"],fo["kernel_ms"]))'
-for round in 1 2; do
+for round in ${ROUNDS:-1 2}; do
   for lib in libvoxgraph_amd.so libvoxgraph_amd_slp.so; do
     [ -f $REPO/voxgraph_amd/lib/$lib ] || continue
     for v in ${VARIANTS:-0 421 422 522 622 612 812}; do
