@@ -1,6 +1,7 @@
 #!/bin/bash
 # L1 / texture-address path counters of the fused kernel (config 3 and full-overlap grids), one small
-# --pmc pass per group, never combined with API traces:  gpurun -- 'bash profiles/pmc_gather.sh'
+# --pmc pass per group, never combined with API traces (TA_TA_BUSY_sum / TA_FLAT_READ_WAVEFRONTS_sum /
+# TA_ADDR_STALLED_* abort rocprofv3 on this image: left out):  gpurun -- 'bash profiles/pmc_gather.sh'
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
@@ -16,8 +17,6 @@ while read -r group; do
       || echo "group $i ($group) failed: $(tail -2 $OUT/prof_ta_$i.err | tr '\n' ' ')"
 done <<'GROUPS'
 GRBM_GUI_ACTIVE TA_BUSY_avr TA_BUSY_max
-TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TA_TOTAL_WAVEFRONTS_sum
-TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_ADDR_STALLED_BY_TD_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum
 TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum
 TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_PENDING_STALL_CYCLES_sum
 TCP_TA_TCP_STATE_READ_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TD_TCP_STALL_CYCLES_sum

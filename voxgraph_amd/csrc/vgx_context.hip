@@ -100,88 +100,52 @@ int launch_brickify(vgx_submap sm, int which) {
 
 // Bounding sphere of every kChunkPoints consecutive registration points (one
 // wavefront per chunk).  The fused REG pass tests a chunk's sphere against the reading
-// grid's box before it requests the chunk's points at all.  Also two axis-aligned boxes per
-// chunk: a chunk of voxel points (block after block, vgx_extract.hip) is cut where the block
-// changes first, so that each part -- a few z-slices of one block -- has a tight box; the
-// windowed fused kernel stages the reading grid under each box in LDS.
+// grid's box before it requests the chunk's points at all.
 __global__ __launch_bounds__(64) void chunk_bounds_kernel(const float4* __restrict__ xyzd, long long n,
-                                                         float block_size_inv,
                                                          float4* __restrict__ bounds,
-                                                         float4* __restrict__ boxes,
                                                          float* __restrict__ chunk_minmax) {
   const long long first = (long long)blockIdx.x * kChunkPoints;
-  const float4 p_first = xyzd[first];
-  const int fbx = (int)floorf(p_first.x * block_size_inv), fby = (int)floorf(p_first.y * block_size_inv),
-            fbz = (int)floorf(p_first.z * block_size_inv);
-  int split = kChunkPoints;
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
   for (long long i = first + threadIdx.x; i < first + kChunkPoints && i < n; i += 64) {
     float4 p = xyzd[i];
-    const bool other = (int)floorf(p.x * block_size_inv) != fbx || (int)floorf(p.y * block_size_inv) != fby ||
-                       (int)floorf(p.z * block_size_inv) != fbz;
-    if (other) split = min(split, (int)(i - first));
+    mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
+    mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
+    mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
   }
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) split = min(split, __shfl_xor(split, off, 64));
-  float mn[2][3] = {{INFINITY, INFINITY, INFINITY}, {INFINITY, INFINITY, INFINITY}};
-  float mx[2][3] = {{-INFINITY, -INFINITY, -INFINITY}, {-INFINITY, -INFINITY, -INFINITY}};
-  for (long long i = first + threadIdx.x; i < first + kChunkPoints && i < n; i += 64) {
-    float4 p = xyzd[i];
-    const int part = (int)(i - first) >= split;
-    mn[part][0] = fminf(mn[part][0], p.x); mx[part][0] = fmaxf(mx[part][0], p.x);
-    mn[part][1] = fminf(mn[part][1], p.y); mx[part][1] = fmaxf(mx[part][1], p.y);
-    mn[part][2] = fminf(mn[part][2], p.z); mx[part][2] = fmaxf(mx[part][2], p.z);
-  }
+  for (int a = 0; a < 3; ++a)
 #pragma unroll
-  for (int part = 0; part < 2; ++part)
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) {
-        mn[part][a] = fminf(mn[part][a], __shfl_xor(mn[part][a], off, 64));
-        mx[part][a] = fmaxf(mx[part][a], __shfl_xor(mx[part][a], off, 64));
-      }
-  if (threadIdx.x == 0) {
-    boxes[4 * blockIdx.x + 0] = make_float4(mn[0][0], mn[0][1], mn[0][2], __int_as_float(split));
-    boxes[4 * blockIdx.x + 1] = make_float4(mx[0][0], mx[0][1], mx[0][2], 0.0f);
-    boxes[4 * blockIdx.x + 2] = make_float4(mn[1][0], mn[1][1], mn[1][2], 0.0f);
-    boxes[4 * blockIdx.x + 3] = make_float4(mx[1][0], mx[1][1], mx[1][2], 0.0f);
-    float lo[3], hi[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      lo[a] = fminf(mn[0][a], mn[1][a]);
-      hi[a] = fmaxf(mx[0][a], mx[1][a]);
+    for (int off = 32; off >= 1; off >>= 1) {
+      mn[a] = fminf(mn[a], __shfl_xor(mn[a], off, 64));
+      mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off, 64));
     }
-    float hx = 0.5f * (hi[0] - lo[0]), hy = 0.5f * (hi[1] - lo[1]), hz = 0.5f * (hi[2] - lo[2]);
+  if (threadIdx.x == 0) {
+    float hx = 0.5f * (mx[0] - mn[0]), hy = 0.5f * (mx[1] - mn[1]), hz = 0.5f * (mx[2] - mn[2]);
     // radius rounded up generously: the test it feeds is conservative anyway
     float r = sqrtf(hx * hx + hy * hy + hz * hz) * 1.0001f + 1e-4f;
-    bounds[blockIdx.x] = make_float4(0.5f * (hi[0] + lo[0]), 0.5f * (hi[1] + lo[1]),
-                                     0.5f * (hi[2] + lo[2]), r);
+    bounds[blockIdx.x] = make_float4(0.5f * (mx[0] + mn[0]), 0.5f * (mx[1] + mn[1]),
+                                     0.5f * (mx[2] + mn[2]), r);
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      chunk_minmax[6 * blockIdx.x + a] = lo[a];
-      chunk_minmax[6 * blockIdx.x + 3 + a] = hi[a];
+      chunk_minmax[6 * blockIdx.x + a] = mn[a];
+      chunk_minmax[6 * blockIdx.x + 3 + a] = mx[a];
     }
   }
 }
 
-int build_chunk_bounds(vgx_ctx ctx, PointSet& ps, float block_size_inv) {
+int build_chunk_bounds(vgx_ctx ctx, PointSet& ps) {
   if (ps.d_chunk_bounds) {
     (void)hipFree(ps.d_chunk_bounds);
     ps.d_chunk_bounds = nullptr;
   }
-  if (ps.d_chunk_boxes) {
-    (void)hipFree(ps.d_chunk_boxes);
-    ps.d_chunk_boxes = nullptr;
-  }
   if (ps.n <= 0) return VGX_OK;
   const long long chunks = (ps.n + kChunkPoints - 1) / kChunkPoints;
   VGX_HIP(ctx, hipMalloc(&ps.d_chunk_bounds, (size_t)chunks * sizeof(float4)));
-  VGX_HIP(ctx, hipMalloc(&ps.d_chunk_boxes, (size_t)chunks * 4 * sizeof(float4)));
   DeviceScratch s_minmax;
   VGX_HIP(ctx, s_minmax.alloc((size_t)chunks * 6 * sizeof(float)));
   float* d_minmax = s_minmax.as<float>();
   hipLaunchKernelGGL(chunk_bounds_kernel, dim3((unsigned)chunks), dim3(64), 0, ctx->stream, ps.d_xyzd,
-                     (long long)ps.n, block_size_inv, ps.d_chunk_bounds, ps.d_chunk_boxes, d_minmax);
+                     (long long)ps.n, ps.d_chunk_bounds, d_minmax);
   // exact AABB of the point positions (feeds getSubmapFrameSurfaceObb for kVoxels points)
   std::vector<float> mm((size_t)chunks * 6);
   hipError_t e = hipGetLastError();
@@ -243,7 +207,6 @@ void reset_point_set(PointSet& ps) {
   if (ps.d_xyzd) (void)hipFree(ps.d_xyzd);
   if (ps.d_weight) (void)hipFree(ps.d_weight);
   if (ps.d_chunk_bounds) (void)hipFree(ps.d_chunk_bounds);
-  if (ps.d_chunk_boxes) (void)hipFree(ps.d_chunk_boxes);
   if (ps.d_cumulative) (void)hipFree(ps.d_cumulative);
   if (ps.d_search_lut) (void)hipFree(ps.d_search_lut);
   if (ps.d_inv_order) (void)hipFree(ps.d_inv_order);
@@ -604,7 +567,7 @@ int vgx_submap_set_points(vgx_submap sm, int32_t point_type, int64_t n, const fl
     VGX_HIP(ctx, hipMemcpy(ps.d_xyzd, h_xyzd.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice));
     VGX_HIP(ctx, hipMemcpy(ps.d_weight, h_w.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
   }
-  const int rc = build_chunk_bounds(ctx, ps, sm->block_size_inv);
+  const int rc = build_chunk_bounds(ctx, ps);
   ps.present = rc == VGX_OK;  // only a completely built set is offered to cost functions
   return rc;
 }

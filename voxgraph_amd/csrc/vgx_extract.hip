@@ -188,7 +188,7 @@ extern "C" int vgx_submap_extract_voxel_points(vgx_submap sm, double min_voxel_w
       if (e != hipSuccess) rc = set_error(ctx, VGX_ERR_HIP, std::string("extract: ") + hipGetErrorString(e));
     }
   }
-  if (rc == VGX_OK) rc = build_chunk_bounds(ctx, ps, sm->block_size_inv);
+  if (rc == VGX_OK) rc = build_chunk_bounds(ctx, ps);
   if (rc == VGX_OK && n_points_out) *n_points_out = ps.n;
   // the set is offered to cost functions only once every allocation and kernel has succeeded
   if (rc == VGX_OK) ps.present = true; else reset_point_set(ps);

@@ -112,7 +112,6 @@ struct alignas(16) ConstraintDev {
   const int32_t* inv_order;   // uploaded index -> device index, or null
   int64_t n_points;
   const float4* chunk_bounds; // bounding spheres of consecutive kChunkPoints-point chunks
-  const float4* chunk_boxes;  // 4 per chunk: {lo0, split}, hi0, lo1, hi1 (chunk_bounds_kernel), or null
   int64_t n;                // num_residuals
   int64_t row0;             // first output row (stacked outputs)
   int32_t tile_points;      // batch: residuals per fused-pass tile of this constraint (all but its last tile)
@@ -220,9 +219,6 @@ struct PointSet {
   float4* d_xyzd = nullptr;
   float* d_weight = nullptr;
   float4* d_chunk_bounds = nullptr;  // per kChunkPoints points: bounding sphere {cx,cy,cz,r}
-  // per chunk two axis-aligned boxes (submap frame): of its points before the first change of block
-  // and of the rest -- what the windowed fused kernel stages of the reading grid (vgx_reg.hip)
-  float4* d_chunk_boxes = nullptr;
   float aabb_min[3] = {0, 0, 0}, aabb_max[3] = {0, 0, 0};  // of the point positions (n > 0)
   double sum_weight = 0;
   bool present = false;
@@ -380,7 +376,7 @@ void set_global_error(const std::string& msg);
 // kernels' launch wrappers implemented in the .hip files
 int launch_brickify(vgx_submap sm, int which);
 int build_block_lut(vgx_submap sm);
-int build_chunk_bounds(vgx_ctx ctx, PointSet& ps, float block_size_inv = 0.0f);
+int build_chunk_bounds(vgx_ctx ctx, PointSet& ps);
 // frees a point set's device arrays and leaves it empty (present = false) with a new version
 void reset_point_set(PointSet& ps);
 // sampler engines: make the host / the device copy the current one (ctx->mu held)

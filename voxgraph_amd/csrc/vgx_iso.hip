@@ -432,7 +432,7 @@ extern "C" int vgx_submap_extract_isosurface_points(vgx_submap sm, double min_vo
   if (d_counts) (void)hipFree(d_counts);
   if (d_offsets) (void)hipFree(d_offsets);
   if (d_has) (void)hipFree(d_has);
-  if (rc == VGX_OK) rc = build_chunk_bounds(ctx, ps, sm->block_size_inv);
+  if (rc == VGX_OK) rc = build_chunk_bounds(ctx, ps);
   if (rc == VGX_OK && !sm->isosurface_blocks.empty()) {
     std::vector<int32_t> ib(3 * sm->isosurface_blocks.size());
     for (size_t k = 0; k < sm->isosurface_blocks.size(); ++k)

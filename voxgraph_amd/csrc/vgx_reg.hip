@@ -181,7 +181,6 @@ struct Located {
   int cell_off;    // offset of the base voxel inside a brick
   bool inside;     // base block index within the table's box
   float Dx, Dy, Dz;
-  int gx, gy, gz;  // base voxel, global index (block * VPS + voxel): the windowed kernel's address
 };
 
 template <int VPS, int LAYOUT>
@@ -201,9 +200,6 @@ __device__ __forceinline__ Located locate_stage1(const GridDev& g, const PosePac
   locate_axis<VPS>(px, g, bx, vx, L.Dx);
   locate_axis<VPS>(py, g, by, vy, L.Dy);
   locate_axis<VPS>(pz, g, bz, vz, L.Dz);
-  L.gx = bx * VPS + vx;
-  L.gy = by * VPS + vy;
-  L.gz = bz * VPS + vz;
   bx -= g.lut_min[0];
   by -= g.lut_min[1];
   bz -= g.lut_min[2];
@@ -842,304 +838,6 @@ __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_ker
   }
 }
 
-
-// ---------------------------------------------------------------------------
-// kernel 2, windowed form: the reading grid under a chunk staged in LDS
-// ---------------------------------------------------------------------------
-// Where every point interpolates (loop closures with full overlap) the lean kernel above is bound
-// by the L1: TCP_TOTAL_CACHE_ACCESSES = 2.05 lines per evaluation, 0.87 per cycle and CU, TA busy
-// 77-90 % (profiles/r03_pmc_gather.txt) -- 64 lanes gathering 8 bytes each touch ~25 lines per
-// instruction, four instructions per point.  A chunk of 512 consecutive voxel points is a few
-// z-slices of ONE block of the reference submap (vgx_extract.hip), so under a yaw-only transform it
-// lands in a box of the reading grid about 23 x 23 x 3 voxels large: this kernel loads that box
-// row by row (8 lanes x 16 bytes per row, x origin aligned to 4 voxels so that a 16-byte piece never
-// leaves a brick row) into LDS once per chunk -- ~4 cells per point instead of 8, ~2.5 lines per
-// 128-byte row instead of one per lane -- and the eight neighbours of every point come from LDS.
-// A chunk that straddles two blocks carries two boxes (chunk_bounds_kernel).  Lanes whose base
-// voxel is not in a staged window (a box too large for the LDS budget, the clamped lanes of a
-// constraint's last chunk, float rounding at a window face) gather from global memory exactly as
-// the lean kernel does, so the two kernels produce the same bits: same values, same order.
-constexpr int kWindowCap = 4608;  // floats of LDS per workgroup for the staged windows (18 KB)
-
-typedef f32x4 f32x4u __attribute__((aligned(4)));  // 16-byte load, 4-byte aligned
-
-struct Window {
-  int x0, y0, z0;      // global voxel index of cell (0, 0, 0); x0 is a multiple of 4
-  int nx, ny, nz;      // cells; nx a multiple of 4, <= 32; 0 cells: not staged
-  int off;             // first float in the LDS array
-  int rows;            // ny * nz
-  unsigned magic;      // (r * magic) >> 20 == r / ny for r < 16384
-};
-
-// the window covering the base voxel and its +1 neighbours of every point of the box {lo, hi}
-// (reference submap frame) under pose pack P
-__device__ __forceinline__ Window make_window(const GridDev& g, const PosePack& P, float4 lo, float4 hi,
-                                              int off, int budget) {
-  Window w;
-  w.x0 = w.y0 = w.z0 = 0;
-  w.nx = w.ny = w.nz = 0;
-  w.off = off;
-  w.rows = 0;
-  w.magic = 0;
-  if (!(lo.x <= hi.x)) return w;  // empty part
-  const float cs = 1.0f - 2.0f * P.qz * P.qz, sn = 2.0f * P.qw * P.qz;
-  const float cx = 0.5f * (lo.x + hi.x), cy = 0.5f * (lo.y + hi.y), cz = 0.5f * (lo.z + hi.z);
-  const float hx = 0.5f * (hi.x - lo.x), hy = 0.5f * (hi.y - lo.y), hz = 0.5f * (hi.z - lo.z);
-  const float px = (cx * cs - cy * sn) + P.tx, py = (cx * sn + cy * cs) + P.ty, pz = cz + P.tz;
-  const float ex = fabsf(cs) * hx + fabsf(sn) * hy, ey = fabsf(sn) * hx + fabsf(cs) * hy, ez = hz;
-  // slack in voxels: the box is transformed in another association than the points are
-  const float eps = 2e-3f + 1e-5f * (fabsf(px) + fabsf(py) + fabsf(pz)) * g.voxel_size_inv;
-  const float fx0 = floorf((px - ex) * g.voxel_size_inv - 0.5f - eps), fx1 = floorf((px + ex) * g.voxel_size_inv - 0.5f + eps);
-  const float fy0 = floorf((py - ey) * g.voxel_size_inv - 0.5f - eps), fy1 = floorf((py + ey) * g.voxel_size_inv - 0.5f + eps);
-  const float fz0 = floorf((pz - ez) * g.voxel_size_inv - 0.5f - eps), fz1 = floorf((pz + ez) * g.voxel_size_inv - 0.5f + eps);
-  // anything absurd (a pose kilometres away, NaN) stays unstaged
-  if (!(fabsf(fx0) < 1e8f && fabsf(fy0) < 1e8f && fabsf(fz0) < 1e8f)) return w;
-  if (!(fx1 - fx0 < 64.0f && fy1 - fy0 < 256.0f && fz1 - fz0 < 256.0f)) return w;
-  const int x0 = (int)fx0 & ~3;
-  const int nx = (((int)fx1 + 1 - x0 + 1) + 3) & ~3;
-  const int ny = (int)fy1 + 1 - (int)fy0 + 1, nz = (int)fz1 + 1 - (int)fz0 + 1;
-  if (nx > 32 || nx * ny * nz > budget) return w;
-  w.x0 = x0; w.y0 = (int)fy0; w.z0 = (int)fz0;
-  w.nx = nx; w.ny = ny; w.nz = nz;
-  w.rows = ny * nz;
-  w.magic = (1u << 20) / (unsigned)ny + 1u;
-  return w;
-}
-
-// One 16-byte piece of a window row: where it comes from (block table entry, float offset inside the
-// brick) and where it goes.  Addresses are clamped so that both loads can be issued unconditionally,
-// all table loads of a thread's pieces first, then all brick loads (two memory round trips per chunk).
-struct WindowPiece {
-  int lut_index;   // clamped
-  unsigned cell;   // float offset inside the brick
-  int dst;         // float offset in the LDS array, -1: nothing to do
-  bool inside;
-};
-
-template <int VPS>
-__device__ __forceinline__ WindowPiece window_piece(const GridDev& g, const Window& w0, const Window& w1, int r,
-                                                    int rows_total, int q) {
-  constexpr int B = VPS + 1;
-  constexpr int SH = VPS == 16 ? 4 : 3;
-  const bool second = r >= w0.rows;
-  const Window& w = second ? w1 : w0;
-  const int rr = second ? r - w0.rows : r;
-  const int iz = (int)(((unsigned)rr * w.magic) >> 20);
-  const int iy = rr - iz * w.ny;
-  const int gx = w.x0 + 4 * q, gy = w.y0 + iy, gz = w.z0 + iz;
-  const int bx = (gx >> SH) - g.lut_min[0], by = (gy >> SH) - g.lut_min[1], bz = (gz >> SH) - g.lut_min[2];
-  WindowPiece p;
-  p.inside = (unsigned)bx < (unsigned)g.lut_dim[0] && (unsigned)by < (unsigned)g.lut_dim[1] &&
-             (unsigned)bz < (unsigned)g.lut_dim[2];
-  const int cx = min(max(bx, 0), g.lut_dim[0] - 1), cy = min(max(by, 0), g.lut_dim[1] - 1),
-            cz = min(max(bz, 0), g.lut_dim[2] - 1);
-  p.lut_index = cx + g.lut_dim[0] * (cy + g.lut_dim[1] * cz);
-  p.cell = (unsigned)((gx & (VPS - 1)) + B * ((gy & (VPS - 1)) + B * (gz & (VPS - 1))));
-  p.dst = (r < rows_total && 4 * q < w.nx) ? w.off + rr * w.nx + 4 * q : -1;
-  return p;
-}
-
-template <int VPS, typename ACC, int WAVES>
-__global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_window_kernel(
-    const ConstraintDev* __restrict__ cons, const PosePack* __restrict__ packs,
-    const Tile* __restrict__ tiles, int n_tiles, const int32_t* __restrict__ tile_first,
-    double* __restrict__ partials) {
-  constexpr int PPT = 2, LAYOUT = 0;
-  constexpr int kIterPoints = kBlockThreads * PPT;
-  static_assert(kChunkPoints == kIterPoints, "one inner iteration == one chunk == one pair of windows");
-  const int t = blockIdx.x;
-  if (t >= n_tiles) return;
-  const Tile tile = tiles[t];
-  const ConstraintDev& C = cons[tile.constraint];
-  const PosePack P = packs[tile.constraint];
-  const GridDev g = C.grid;
-  const bool count_misses = C.no_corr_cost != 0.0;
-  const bool sampled = C.sample_raw != nullptr;
-  const float4* bounds = (!count_misses && !sampled && C.chunk_bounds) ? C.chunk_bounds : nullptr;
-  const bool grid_empty = g.bricks == nullptr;
-  // sampled residuals are scattered over the whole set: nothing to stage
-  const float4* boxes = (!sampled && !grid_empty) ? C.chunk_boxes : nullptr;
-  const long long chunk0 = tile.start / kChunkPoints;  // tiles start on chunk boundaries
-  __shared__ unsigned char s_live[kMaxReduceIters * 2];
-  __shared__ __attribute__((aligned(16))) float s_win[kWindowCap];
-  const int n_chunks = (tile.count + kChunkPoints - 1) / kChunkPoints;
-  if ((int)threadIdx.x < n_chunks)
-    s_live[threadIdx.x] = !(bounds && chunk_outside(g, P, bounds[chunk0 + threadIdx.x]));
-  __syncthreads();
-  ACC acc[21];
-#pragma unroll
-  for (int k = 0; k < 21; ++k) acc[k] = (ACC)0;
-  const float nc = (float)C.no_corr_cost;
-
-  f32x4 pt_next[PPT];
-  float w_next[PPT];
-  bool live_next = s_live[0] != 0;
-  if (live_next) {
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-      int local = j * kBlockThreads + (int)threadIdx.x;
-      int64_t i = tile.start + (local < tile.count ? local : 0);
-      if (sampled) {
-        pt_next[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[as_global(C.sample_idx)[C.row0 + i]];
-        w_next[j] = 1.0f;  // RCF:121
-      } else {
-        pt_next[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[i];
-        w_next[j] = as_global(C.weight)[i];
-      }
-    }
-  }
-  bool staged_before = false;
-  for (int base = 0; base < tile.count; base += kIterPoints) {
-    f32x4 pt[PPT];
-    float w[PPT];
-    const bool live = live_next;
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-      pt[j] = pt_next[j];
-      w[j] = w_next[j];
-    }
-    live_next = false;
-    if (base + kIterPoints < tile.count) {
-      live_next = s_live[(base + kIterPoints) / kChunkPoints] != 0;
-      if (live_next) {
-#pragma unroll
-        for (int j = 0; j < PPT; ++j) {
-          int local = base + kIterPoints + j * kBlockThreads + (int)threadIdx.x;
-          int64_t i = tile.start + (local < tile.count ? local : 0);
-          if (sampled) {
-            pt_next[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[as_global(C.sample_idx)[C.row0 + i]];
-            w_next[j] = 1.0f;
-          } else {
-            pt_next[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[i];
-            w_next[j] = as_global(C.weight)[i];
-          }
-        }
-      }
-    }
-    if (!live) continue;  // the whole workgroup: s_live is per chunk
-    // --- stage the reading grid under this chunk's two boxes ------------------------------------
-    Window win[2];
-    int split = kChunkPoints;
-    win[0] = win[1] = Window{0, 0, 0, 0, 0, 0, 0, 0, 0u};
-    if (boxes) {
-      const float4* bx = boxes + 4 * (chunk0 + base / kChunkPoints);
-      const float4 lo0 = bx[0], hi0 = bx[1], lo1 = bx[2], hi1 = bx[3];
-      split = __float_as_int(lo0.w);
-      win[0] = make_window(g, P, lo0, hi0, 0, kWindowCap);
-      const int used = win[0].nx * win[0].rows;
-      win[1] = make_window(g, P, lo1, hi1, used, kWindowCap - used);
-    }
-    const int rows_total = win[0].rows + win[1].rows;
-    if (rows_total > 0) {  // uniform
-      if (staged_before) __syncthreads();  // the previous chunk's readers are done with s_win
-      const int q = (int)threadIdx.x & 7;
-      constexpr int kRowsPerPass = kBlockThreads / 8, U = 4;
-      constexpr int CELLS = BrickLayout<VPS, LAYOUT>::cells;
-      for (int r0 = (int)threadIdx.x >> 3; r0 < rows_total; r0 += kRowsPerPass * U) {
-        WindowPiece pc[U];
-        int slot[U];
-        f32x4 v[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) pc[u] = window_piece<VPS>(g, win[0], win[1], r0 + u * kRowsPerPass, rows_total, q);
-#pragma unroll
-        for (int u = 0; u < U; ++u) slot[u] = as_global(g.lut)[pc[u].lut_index];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const bool hv = pc[u].inside && slot[u] >= 0;
-          slot[u] = hv ? slot[u] : -1;
-          v[u] = *(const VGX_GLOBAL f32x4u*)(g.bricks + ((unsigned)(hv ? slot[u] : 0) * (unsigned)CELLS + pc[u].cell));
-        }
-        const float nan = __builtin_nanf("");
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          if (slot[u] < 0) v[u] = f32x4{nan, nan, nan, nan};
-          if (pc[u].dst >= 0) *reinterpret_cast<f32x4*>(s_win + pc[u].dst) = v[u];
-        }
-      }
-      __syncthreads();
-      staged_before = true;
-    }
-    // --- evaluate -------------------------------------------------------------------------------
-    Located loc[PPT];
-    bool have[PPT], from_global[PPT];
-    float d[PPT][8];
-    bool any_global = false;
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-      loc[j] = locate_stage1<VPS, LAYOUT>(g, P, pt[j].x, pt[j].y, pt[j].z);
-      const int in_chunk = j * kBlockThreads + (int)threadIdx.x;
-      const Window& W = in_chunk >= split ? win[1] : win[0];
-      const int lx = loc[j].gx - W.x0, ly = loc[j].gy - W.y0, lz = loc[j].gz - W.z0;
-      const bool in_win = (unsigned)lx < (unsigned)(W.nx - 1) && (unsigned)ly < (unsigned)(W.ny - 1) &&
-                          (unsigned)lz < (unsigned)(W.nz - 1);
-      const bool staged = W.rows > 0 && in_win;  // (an unstaged part has nx == 0: in_win alone would admit it)
-      have[j] = staged;
-      from_global[j] = !staged && !grid_empty && (base + in_chunk < tile.count);
-      any_global |= from_global[j];
-      // clamped, always-valid LDS address
-      const int at = staged ? W.off + (lz * W.ny + ly) * W.nx + lx : 0;
-      const int sy = staged ? W.nx : 0, sz = staged ? W.ny * W.nx : 0;
-      const float* cell = s_win + at;
-      d[j][0] = cell[0];       d[j][4] = cell[1];
-      d[j][1] = cell[sz];      d[j][5] = cell[sz + 1];
-      d[j][2] = cell[sy];      d[j][6] = cell[sy + 1];
-      d[j][3] = cell[sy + sz]; d[j][7] = cell[sy + sz + 1];
-    }
-    if (__builtin_amdgcn_ballot_w64(any_global) != 0ull) {
-      // the lean kernel's path for the lanes no window serves
-      int slot[PPT];
-#pragma unroll
-      for (int j = 0; j < PPT; ++j) slot[j] = as_global(g.lut)[loc[j].lut_index];
-      constexpr int CELLS = BrickLayout<VPS, LAYOUT>::cells;
-#pragma unroll
-      for (int j = 0; j < PPT; ++j) {
-        const bool hv = loc[j].inside && slot[j] >= 0;
-        const unsigned off = (unsigned)(hv ? slot[j] : 0) * (unsigned)CELLS + (unsigned)loc[j].cell_off;
-        float dg[8];
-        load_neighbours<VPS, LAYOUT>(g.bricks + off, dg);
-        if (from_global[j]) {
-          have[j] = hv;
-#pragma unroll
-          for (int k = 0; k < 8; ++k) d[j][k] = dg[k];
-        }
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-      const int local = base + j * kBlockThreads + (int)threadIdx.x;
-      float u[6];
-      const bool in_range = local < tile.count;
-      const bool ok = eval_point_lean(d[j], have[j], loc[j].Dx, loc[j].Dy, loc[j].Dz, g.voxel_size_inv, P,
-                                      pt[j].x, pt[j].y, pt[j].w, w[j], u) && in_range;
-#pragma unroll
-      for (int k = 0; k < 5; ++k) u[k] = ok ? u[k] : 0.0f;
-      // RCF:165-166: w * no_correspondence_cost with zero Jacobian rows
-      u[5] = ok ? u[5] : ((count_misses && in_range) ? w[j] * nc : 0.0f);
-      accumulate21<ACC>(acc, u);
-    }
-  }
-  double accd[21];
-#pragma unroll
-  for (int k = 0; k < 21; ++k) {
-    double v = (double)acc[k];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    accd[k] = v;
-  }
-  __shared__ double lds[kBlockThreads / 64][kPartialSize];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (lane == 0) {
-#pragma unroll
-    for (int k = 0; k < 21; ++k) lds[wave][k] = accd[k];
-  }
-  __syncthreads();
-  if (threadIdx.x < 21) {
-    double v = ((lds[0][threadIdx.x] + lds[1][threadIdx.x]) + lds[2][threadIdx.x]) + lds[3][threadIdx.x];
-    const size_t slot = (size_t)tile_first[tile.constraint] + (size_t)(tile.start / C.tile_points);
-    partials[slot * kPartialSize + threadIdx.x] = v;
-  }
-}
-
 // ---------------------------------------------------------------------------
 // std::mt19937 streams on the device (sampling mode of the batched passes)
 // ---------------------------------------------------------------------------
@@ -1692,7 +1390,6 @@ vgx::ConstraintDev vgx_reg_s::describe() const {
     c.n_points = ps.n;
   }
   c.chunk_bounds = ps.d_chunk_bounds;
-  c.chunk_boxes = ps.d_chunk_boxes;
   c.n = num_residuals;
   c.row0 = 0;
   // RCF:274: num_residuals / summed_reference_weight; sampled points weigh 1
@@ -2350,10 +2047,10 @@ int vgx_reg_batch_evaluate_normal(vgx_reg_batch b, const double* poses, int32_t 
     if (rc != VGX_OK) return rc;
     ex->launch_order_made = true;
   }
-  // A/B switch (profiles/ab_fused2.sh, tests/test_fused_window_gpu.py): read per call, so that one
-  // process can compare the variants bit for bit
-  const char* variant_env = getenv("VGX_FUSED_KERNEL");
-  const int variant = variant_env ? atoi(variant_env) : kFusedVariantDefault;
+  static const int variant = [] {
+    const char* e = getenv("VGX_FUSED_KERNEL");  // A/B switch (profiles/ab_fused2.sh)
+    return e ? atoi(e) : kFusedVariantDefault;
+  }();
   if (n_tiles > 0) {
     dim3 grid(n_tiles), block(kBlockThreads);
     const int vps = b->regs[0]->reading->vps;
@@ -2379,19 +2076,6 @@ int vgx_reg_batch_evaluate_normal(vgx_reg_batch b, const double* poses, int32_t 
       VGX_LEAN_CASE(622, 2, float, 6);
       VGX_LEAN_CASE(612, 1, float, 6);
       VGX_LEAN_CASE(812, 1, float, 8);
-#define VGX_WINDOW_CASE(CODE, ACC, W)                                                                          \
-  case CODE:                                                                                                   \
-    if (vps == 16)                                                                                             \
-      hipLaunchKernelGGL((reg_eval_reduce_window_kernel<16, ACC, W>), grid, block, 0, ctx->stream, b->d_desc, \
-                         b->d_pack, ex->d_reduce_tiles, n_tiles, b->d_tile_first, b->d_partials);             \
-    else                                                                                                       \
-      hipLaunchKernelGGL((reg_eval_reduce_window_kernel<8, ACC, W>), grid, block, 0, ctx->stream, b->d_desc,  \
-                         b->d_pack, ex->d_reduce_tiles, n_tiles, b->d_tile_first, b->d_partials);             \
-    break
-      VGX_WINDOW_CASE(722, float, 4);
-      VGX_WINDOW_CASE(752, float, 5);
-      VGX_WINDOW_CASE(762, float, 6);
-#undef VGX_WINDOW_CASE
       default:
         return set_error(ctx, VGX_ERR_INVALID, "VGX_FUSED_KERNEL: unknown variant");
     }
