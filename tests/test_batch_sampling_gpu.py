@@ -130,6 +130,66 @@ def test_batched_sampling_follows_the_shared_sampler_streams(capi, ctx, graph, m
         o.destroy()
 
 
+def test_two_batches_and_drop_in_calls_share_the_engines(capi, ctx, graph):
+    """Two batches on the same point-set engines, evaluated alternately, with drop-in Evaluates in between
+    and one batch destroyed on the way: every evaluation sees the engines' streams exactly as successive
+    Evaluate calls in the same order would (RCF:113-122, weighted_sampler.h:36-39) -- the engine state
+    travels between the host and the device as often as the callers alternate."""
+    gs, cfs = _gpu_graph(capi, ctx, graph)
+    sel_a, sel_b = [0, 1, 2, 3, 4], [2, 0, 4]                     # B: a subset, another order
+    cfs_b = [capi.RegistrationCostFunction(ctx, gs[PAIRS[c][0]], gs[PAIRS[c][1]],
+                                           capi.default_config(registration_point_type=capi.POINTS_VOXELS,
+                                                               sampling_ratio=RATIO)) for c in sel_b]
+    batch_a = capi.RegistrationBatch(ctx, cfs, PAIRS)
+    batch_b = capi.RegistrationBatch(ctx, cfs_b, [PAIRS[c] for c in sel_b])
+    layers = [H.oracle_layer(sm) for sm in graph["sms"]]
+    engines = {a: orc.Mt19937(5489) for a in {p[0] for p in PAIRS}}
+    cums = {a: sequential_cumsum(graph["pts"][a][2]) for a in engines}
+    poses = graph["poses"]
+
+    def oracle_rows(c):
+        a, b = PAIRS[c]
+        xyz, dist, w = graph["pts"][a]
+        n = int(F(RATIO) * F(len(w)))
+        idx = np.array([engines[a].weighted_draw(cums[a]) for _ in range(n)], np.int64)
+        ok, r0, jo0, je0 = orc.reg_evaluate(layers[b], xyz, dist, w, poses[a], poses[b], sample_idx=idx)
+        assert ok
+        return r0, jo0, je0
+
+    def check_batch(batch, sel, what):
+        ro = batch.row_offsets()
+        r, jo, je = _eval_points(batch, poses, ctx)
+        for k, c in enumerate(sel):
+            r0, jo0, je0 = oracle_rows(c)
+            s = slice(ro[k], ro[k + 1])
+            assert np.array_equal(r[s], r0.astype(F)), (what, c)
+            assert np.array_equal(jo[s], jo0.astype(F)) and np.array_equal(je[s], je0.astype(F)), (what, c)
+
+    def check_dropin(c, what):
+        n = cfs[c].num_residuals()
+        r1, j1, j2 = np.zeros(n), np.zeros((n, 4)), np.zeros((n, 4))
+        a, b = PAIRS[c]
+        assert cfs[c].Evaluate([poses[a], poses[b]], r1, [j1, j2])
+        r0, jo0, je0 = oracle_rows(c)
+        assert np.array_equal(r1, r0) and np.array_equal(j1, jo0) and np.array_equal(j2, je0), what
+
+    check_batch(batch_a, sel_a, "A1")
+    check_batch(batch_a, sel_a, "A2")
+    check_batch(batch_b, sel_b, "B1")
+    check_batch(batch_a, sel_a, "A3")
+    check_dropin(3, "drop-in after A3")
+    check_batch(batch_b, sel_b, "B2")
+    check_batch(batch_b, sel_b, "B3")
+    check_dropin(1, "drop-in after B3")
+    check_dropin(2, "second drop-in in a row (engine already on the host)")
+    batch_b.destroy()
+    check_batch(batch_a, sel_a, "A4")
+    check_batch(batch_a, sel_a, "A5")
+    batch_a.destroy()
+    for o in cfs + cfs_b + gs:
+        o.destroy()
+
+
 @pytest.mark.skipif(not ref_reg.available(), reason="oracle/_ref/libref_reg.so not built (needs /root/reference)")
 def test_batched_sampling_equals_the_reference_source_called_in_the_same_order(capi, ctx, graph):
     """The same five sampling constraints through the reference's OWN RegistrationCostFunction
