@@ -31,6 +31,7 @@
 // HBM traffic is a few sorts and scans over the speculative accesses (~60 B each); the mode trades
 // 10-50 x the racing kernel's time for a layer that is the same bit for bit on every run.
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1104,9 +1105,15 @@ int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points,
     }
     DET_TRY(grow(ctx, S->tmp, scan_bytes));
     {
-      // a sweep that changes no stopping step is the fixed point; n + 1 sweeps always suffice
+      // a sweep that changes no stopping step is the fixed point (and so is every sweep after it); n + 1
+      // sweeps always suffice.  On small scans the flag comes to the host only every fourth sweep: a look
+      // costs a stream round trip, more than a sweep over < 1 M accesses does, and up to three sweeps past
+      // the fixed point change nothing (measured: LiDAR 0.55 -> 0.51 ms per scan; on a depth image's 4 M
+      // accesses the wasted sweeps cost more than the looks, 1.49 -> 1.62 ms, so there every sweep is looked at).
+      const int kSweepsPerLook = N <= (1u << 20) ? 4 : 1;
       for (long long sweep = 0;; ++sweep) {
-        if (sweep > n + 1) return set_error(ctx, VGX_ERR_HIP, "TSDF reproducible mode: the sweeps did not settle (internal error)");
+        if (sweep > n + 1 + kSweepsPerLook)
+          return set_error(ctx, VGX_ERR_HIP, "TSDF reproducible mode: the sweeps did not settle (internal error)");
         VGX_HIP(ctx, hipMemsetAsync(S->d_ctr + kCtrChanged, 0, 8, st));
         size_t bytes = S->tmp.bytes;
         VGX_HIP(ctx, rocprim::exclusive_scan(S->tmp.p, bytes, rocprim::make_transform_iterator(pos, happened),
@@ -1119,7 +1126,8 @@ int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points,
                            (int)c.max_consecutive_ray_collisions, S->count.as<uint32_t>(), S->off.as<uint32_t>(),
                            S->seen.as<uint8_t>(), S->T.as<int32_t>(), S->broke.as<uint8_t>(), S->d_ctr);
         VGX_HIP(ctx, hipGetLastError());
-        DET_TRY(read_counters(ctx, S));
+        if ((sweep + 1) % kSweepsPerLook != 0) continue;
+        DET_TRY(read_counters(ctx, S));  // kCtrChanged: of the last sweep
         if (S->h_ctr[kCtrError]) break;
         if (!S->h_ctr[kCtrChanged]) break;
       }
@@ -1195,9 +1203,18 @@ int det_merged_commit(vgx_tsdf_integrator I, const float T[7], long long n, cons
     VGX_HIP(ctx, rocprim::radix_sort_pairs(S->tmp.p, bytes, S->acc_key.as<uint32_t>(), S->s_key.as<uint32_t>(), iota,
                                            S->s_idx.as<uint32_t>(), N, 0, kSetBits, st));
   }
-  DET_TRY(read_counters(ctx, S));
-  if (S->h_ctr[kCtrError])
-    return set_error(ctx, VGX_ERR_UNSUPPORTED, "TSDF reproducible mode: a voxel index beyond +-2^20 voxels of the layer origin");
+  {
+    // Every voxel a ray visits lies between the sensor and its (clipped) end point plus the truncation
+    // band: when that box is inside +-2^20 voxels the walk kernel's range flag cannot be set and does not
+    // have to be waited for (one stream round trip per scan).
+    const double reach = (double)c.max_ray_length_m + 2.0 * (double)c.default_truncation_distance + 2.0 * I->layer->dev.voxel_size;
+    const double far = std::max(std::max(std::fabs((double)T[4]), std::fabs((double)T[5])), std::fabs((double)T[6])) + reach;
+    if (!(far * (double)I->layer->dev.voxel_size_inv + 4.0 < (double)kVoxBias)) {
+      DET_TRY(read_counters(ctx, S));
+      if (S->h_ctr[kCtrError])
+        return set_error(ctx, VGX_ERR_UNSUPPORTED, "TSDF merged integrator: a voxel index beyond +-2^20 voxels of the layer origin");
+    }
+  }
   const HappenedOp happened{nullptr, nullptr, nullptr};  // unused: no approximate sets
   // only anti-grazing removes updates; blocks in order of first update only in the reproducible mode
   // (otherwise on demand: the VALUES are order-exact either way, only the pool order is arrival order)
