@@ -890,14 +890,15 @@ static int det_commit(vgx_tsdf_integrator I, DetScratch* S, const float T[7], si
                        S->acc_vox.as<unsigned long long>(), S->acc_ray.as<uint32_t>(), S->off.as<uint32_t>(),
                        S->first_touch.as<unsigned long long>(), S->new_cells.as<int32_t>(), (uint32_t)new_cap, S->d_ctr);
     VGX_HIP(ctx, hipGetLastError());
+    // from here until det_assign_kernel has put the marked cells back to ~0, a failure leaves marks behind:
+    // the next scan refills the table
+    S->first_touch_dirty = true;
     int32_t n_blocks_now = 0;
     VGX_HIP(ctx, hipMemcpyAsync(&n_blocks_now, L.n_blocks, 4, hipMemcpyDeviceToHost, st));
     DET_TRY(read_counters(ctx, S));
     const size_t n_new = (size_t)S->h_ctr[kCtrNew];
-    if (n_new > new_cap) {
-      S->first_touch_dirty = true;
+    if (n_new > new_cap)
       return set_error(ctx, VGX_ERR_HIP, "TSDF reproducible mode: more new blocks than the scan's reach allows (internal error)");
-    }
     if (n_new > 0) {
       hipLaunchKernelGGL(det_new_keys_kernel, dim3(blocks_for(n_new)), dim3(256), 0, st, (uint32_t)n_new,
                          S->new_cells.as<int32_t>(), S->first_touch.as<unsigned long long>(),
@@ -916,6 +917,7 @@ static int det_commit(vgx_tsdf_integrator I, DetScratch* S, const float T[7], si
                          S->new_cells_sorted.as<int32_t>(), S->first_touch.as<unsigned long long>());
       VGX_HIP(ctx, hipGetLastError());
     }
+    S->first_touch_dirty = false;  // (n_new == 0: nothing was marked)
   }
   DET_TRY(grow(ctx, S->long_runs, (M / kShortRun + 2) * 4));
   DET_TRY(grow(ctx, S->t_at, M * 8));
