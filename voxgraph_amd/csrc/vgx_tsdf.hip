@@ -1263,9 +1263,8 @@ static int merged_integrate_locked(vgx_tsdf_integrator I, const float T[7], cons
                            I->d_mcounters, n_updates);
     if (rc == VGX_OK) request_readback(I->layer);
     return rc;
-    request_readback(I->layer);
   }
-  if (n_updates) {
+  if (n_updates) {  // an empty scan
     unsigned long long u = 0;
     VGX_HIP(ctx, hipMemcpyAsync(&u, I->dev.n_updates, 8, hipMemcpyDeviceToHost, ctx->stream));
     VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
