@@ -4,7 +4,9 @@ voxels per side, spheres + ground, blocks dropped at random), random poses (tiny
 aligned, yaw near +-pi), ESDF / TSDF grids, no-correspondence cost on / off, voxel and isosurface points:
   * drop-in vgx_reg_evaluate (f64): every residual and Jacobian entry EQUAL to the oracle's;
   * batched materialising pass (f32): EQUAL to the f32 rounding of the oracle's f64 values;
-  * batched fused pass: 45 sums within 1e-6 of the sums of the oracle's rows.
+  * batched fused pass: 45 sums within 1e-6 of the sums of the oracle's rows;
+  * the producers on the same submaps: extracted voxel points and isosurface vertices (random weights,
+    min weight 1 / 6) EQUAL to the oracle's, order included.
     gpurun -- 'SEEDS=200 python profiles/fuzz_reg.py'"""
 import os
 import sys
@@ -47,6 +49,26 @@ def main():
         kind = capi.POINTS_VOXELS
         n0 = gs[0].extract_voxel_points(1.0, float(rng.choice([0.3, 3 * vs])), bool(use_esdf))
         n1 = gs[1].extract_voxel_points(1.0, 0.3, bool(use_esdf))
+        try:                                                                    # the two producers, bit for bit
+            for k, (g, sm) in enumerate(zip(gs, sms)):
+                md = 0.3 if k else None
+                gx, gd, gw = g.download_points(capi.POINTS_VOXELS) if (n0 if k == 0 else n1) > 0 else (np.zeros((0, 3), F),) * 3
+                if k == 1 and len(gw):
+                    ox, od, ow = H.oracle_points(sm, use_esdf=bool(use_esdf), min_w=1.0, max_d=0.3)
+                    assert np.array_equal(gx, ox) and np.array_equal(gd, od) and np.array_equal(gw, ow), "extracted voxel points"
+                rw = np.where(sm.tsdf_weight > 0, rng.uniform(0.5, 12.0, sm.tsdf_weight.shape), 0).astype(F)
+                g2 = capi.Submap(ctx, 7, sm.voxel_size, sm.vps, sm.block_index, sm.tsdf_distance, rw, sm.esdf_distance, sm.esdf_observed)
+                min_w = float(rng.choice([1.0, 6.0]))
+                ni = g2.extract_isosurface_points(min_w)
+                ix, idist, iw = orc.isosurface_points(sm.voxel_size, sm.vps, sm.block_index, sm.tsdf_distance, rw, min_w)
+                assert ni == len(iw), ("isosurface count", ni, len(iw))
+                if ni:
+                    jx, jd, jw = g2.download_points(capi.POINTS_ISOSURFACE)
+                    assert np.array_equal(jx, ix) and np.array_equal(jd, idist) and np.array_equal(jw, iw), "isosurface points"
+                g2.destroy()
+        except AssertionError as e:
+            print("MISMATCH producers", dict(seed=seed, vps=vps, vs=vs, dims=dims), str(e)[:300])
+            return 1
         if n0 == 0:
             for g in gs:
                 g.destroy()
