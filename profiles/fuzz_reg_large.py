@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""One-off differential fuzzing of the BATCHED REG passes at sizes where tiles, culling chunks, dead tiles and
+the XCD-aware launch order all matter: city-scene submaps of 128^3 voxels (512 blocks, ~10^5 points), four
+submaps, every ordered pair a constraint, random poses from "on top of each other" to "apart"; EVERY
+materialised f32 row compared with the f32 rounding of oracle/reg_oracle.c's f64 row, the fused sums within
+2e-6 of the sums of the oracle's rows (worst case reported).  This fuzzer is what made the fused kernel take
+the interpolated value in the reference's association (vgx_reg.hip, interpolated_value): with its own
+association the cost of a constraint whose few hundred correspondences all sit on one plane was off by 4.4e-5.
+    gpurun -- 'SEEDS=12 python profiles/fuzz_reg_large.py'"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+F = np.float32
+
+
+def main():
+    import torch
+    from oracle import pyoracle as orc
+    from voxgraph_amd import capi
+    capi.load()
+    ctx = capi.Context(0)
+    n_seeds, first = int(os.environ.get("SEEDS", "8")), int(os.environ.get("FIRST", "0"))
+    vs, vps = 0.2, 16
+    bmin, bdim = (-4, -4, -2), (8, 8, 8)
+    rows = cons = dead = 0
+    worst = [0.0, 0.0, 0.0]
+    for seed in range(first, first + n_seeds):
+        rng = np.random.default_rng(seed)
+        n_sub = 4
+        true = np.c_[rng.uniform(-14, 14, (n_sub, 2)), rng.uniform(-0.5, 0.5, n_sub), rng.uniform(-0.4, 0.4, n_sub)]
+        subs, layers, pts = [], [], []
+        use_esdf = 1   # (the device scene generator builds the ESDF sampling grid only)
+        for k in range(n_sub):
+            sm = capi.Submap.synth_city(ctx, k, vs, vps, bmin, bdim, 0.6, 2.0, 10.0, true[k], seed % 5)
+            n = sm.extract_voxel_points(1.0, 0.3, bool(use_esdf))
+            td, tw, ed, eo = sm.download_layers(vps)
+            layers.append(orc.Layer(vs, vps, sm.block_index(), ed, eo) if use_esdf else
+                          orc.Layer(vs, vps, sm.block_index(), td, (tw > 0).astype(np.uint8)))
+            pts.append(sm.download_points(capi.POINTS_VOXELS) if n else None)
+            subs.append(sm)
+        pairs = [(a, b) for a in range(n_sub) for b in range(n_sub) if a != b and pts[a] is not None]
+        nc = float(rng.choice([0.0, 0.0, 0.25]))
+        cfg = capi.default_config(registration_point_type=capi.POINTS_VOXELS, use_esdf_distance=use_esdf, no_correspondence_cost=nc)
+        cfs = [capi.RegistrationCostFunction(ctx, subs[a], subs[b], cfg) for a, b in pairs]
+        batch = capi.RegistrationBatch(ctx, cfs, pairs)
+        ro = batch.row_offsets()
+        R = batch.num_residuals()
+        for trial in range(2):
+            poses = true + rng.normal(0, 1, (n_sub, 4)) * [0.3, 0.3, 0.05, 0.05]
+            tr = torch.full((R,), float("nan"), dtype=torch.float32, device="cuda:0")
+            tjo = torch.full((R, 4), float("nan"), dtype=torch.float32, device="cuda:0")
+            tje = torch.full((R, 4), float("nan"), dtype=torch.float32, device="cuda:0")
+            torch.cuda.synchronize()
+            st = batch.evaluate_points(poses, tr.data_ptr(), tjo.data_ptr(), tje.data_ptr())
+            ctx.synchronize()
+            _, normal = batch.evaluate_normal(poses)
+            r, jo, je = tr.cpu().numpy(), tjo.cpu().numpy(), tje.cpu().numpy()
+            for c, (a, b) in enumerate(pairs):
+                xyz, dist, w = pts[a]
+                ok, r0, jo0, je0 = orc.reg_evaluate(layers[b], xyz, dist, w, poses[a], poses[b], no_correspondence_cost=nc)
+                s = slice(ro[c], ro[c + 1])
+                good = ok and np.array_equal(r[s], r0.astype(F)) and np.array_equal(jo[s], jo0.astype(F)) and np.array_equal(je[s], je0.astype(F))
+                if good:
+                    J = np.concatenate([jo0, je0], axis=1)
+                    want = np.r_[float(r0 @ r0), J.T @ r0, (J.T @ J)[np.triu_indices(8)]]
+                    for part, (lo, hi) in enumerate(((0, 1), (1, 9), (9, 45))):
+                        scale = np.abs(want[lo:hi]).max()
+                        if scale > 0:
+                            err = float(np.abs(normal[c][lo:hi] - want[lo:hi]).max() / scale)
+                            worst[part] = max(worst[part], err)
+                            good = good and err <= 2e-6
+                        else:
+                            good = good and np.abs(normal[c][lo:hi]).max() == 0
+                if not good:
+                    print("MISMATCH seed", seed, "trial", trial, "constraint", (a, b), "esdf", use_esdf, "nc", nc, "ok", ok, "status", st[c])
+                    for name, g_, w_ in (("r", r[s], r0.astype(F)), ("jo", jo[s], jo0.astype(F)), ("je", je[s], je0.astype(F))):
+                        bad = np.flatnonzero((g_ != w_).reshape(len(w_), -1).any(1))
+                        print(" ", name, "rows differing:", len(bad), "of", len(w_), "first", bad[:5],
+                              "gpu", g_[bad[:2]].tolist(), "oracle", w_[bad[:2]].tolist())
+                    J = np.concatenate([jo0, je0], axis=1)
+                    want = np.r_[float(r0 @ r0), J.T @ r0, (J.T @ J)[np.triu_indices(8)]]
+                    print("  fused rel err per part:", [float(np.abs(normal[c][lo:hi] - want[lo:hi]).max() / max(np.abs(want[lo:hi]).max(), 1e-300))
+                                                       for lo, hi in ((0, 1), (1, 9), (9, 45))], "with correspondence:", int((np.abs(jo0).sum(1) > 0).sum()))
+                    return 1
+                rows += len(r0)
+                cons += 1
+                dead += int(np.abs(jo0).sum() == 0)
+        for o in [batch] + cfs + subs:
+            o.destroy()
+    print("no mismatch:", cons, "constraints,", rows, "rows compared exactly,", dead, "constraints without any correspondence;",
+          "fused sums' worst relative error (cost, J^T r, J^T J): %.2e %.2e %.2e" % tuple(worst))
+    ctx.close()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

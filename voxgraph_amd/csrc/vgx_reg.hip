@@ -212,6 +212,26 @@ __device__ __forceinline__ Located locate_stage1(const GridDev& g, const PosePac
   return L;
 }
 
+// The interpolated distance in the reference's own association: c = interp_table_ * distances^T
+// (registration_cost_function.h:73-81), q_vector (Interpolator::getQVector), their product (RCF:158-159);
+// no contraction (this file compiles with fp contract off).  Shared by the exact kernel and the fused
+// kernel: the residual d_ref - value amplifies a one-ulp difference in the value by |value / residual|,
+// so the fused kernel must not have its own association here (see eval_point_lean).
+__device__ __forceinline__ float interpolated_value(const float d[8], float Dx, float Dy, float Dz, float& c0,
+                                                    float& c1, float& c2, float& c3, float& c4, float& c5,
+                                                    float& c6, float& c7) {
+  c0 = d[0];
+  c1 = -d[0] + d[4];
+  c2 = -d[0] + d[2];
+  c3 = -d[0] + d[1];
+  c4 = ((d[0] - d[2]) - d[4]) + d[6];
+  c5 = ((d[0] - d[1]) - d[2]) + d[3];
+  c6 = ((d[0] - d[1]) - d[4]) + d[5];
+  c7 = (((((( -d[0] + d[1]) + d[2]) - d[3]) + d[4]) - d[5]) - d[6]) + d[7];
+  const float q4 = Dx * Dy, q5 = Dy * Dz, q6 = Dz * Dx, q7 = Dx * Dy * Dz;
+  return ((((((c0 + Dx * c1) + Dy * c2) + Dz * c3) + q4 * c4) + q5 * c5) + q6 * c6) + q7 * c7;
+}
+
 __device__ __forceinline__ PointEval eval_point(const float d[8], bool have, float Dx, float Dy,
                                                 float Dz, float inv_f, const PosePack& P, float xi,
                                                 float yi, float d_ref, float w,
@@ -227,17 +247,8 @@ __device__ __forceinline__ PointEval eval_point(const float d[8], bool have, flo
     return e;
   }
   // c = interp_table_ * distances^T (registration_cost_function.h:73-81)
-  float c0 = d[0];
-  float c1 = -d[0] + d[4];
-  float c2 = -d[0] + d[2];
-  float c3 = -d[0] + d[1];
-  float c4 = ((d[0] - d[2]) - d[4]) + d[6];
-  float c5 = ((d[0] - d[1]) - d[2]) + d[3];
-  float c6 = ((d[0] - d[1]) - d[4]) + d[5];
-  float c7 = (((((( -d[0] + d[1]) + d[2]) - d[3]) + d[4]) - d[5]) - d[6]) + d[7];
-  // q_vector (Interpolator::getQVector) and RCF:158-159
-  float q4 = Dx * Dy, q5 = Dy * Dz, q6 = Dz * Dx, q7 = Dx * Dy * Dz;
-  float dot = ((((((c0 + Dx * c1) + Dy * c2) + Dz * c3) + q4 * c4) + q5 * c5) + q6 * c6) + q7 * c7;
+  float c0, c1, c2, c3, c4, c5, c6, c7;
+  const float dot = interpolated_value(d, Dx, Dy, Dz, c0, c1, c2, c3, c4, c5, c6, c7);
   e.r = ((double)d_ref - (double)dot) * (double)w;  // RCF:161-163
   if (!want_jac) return e;
   // RCF:183-202: doubles rounded into a float matrix
@@ -642,14 +653,20 @@ constexpr bool kBallotSkip = VGX_BALLOT_SKIP != 0;
 //   * validity from the interpolated value itself: every neighbour enters it, so it is NaN exactly
 //     when a neighbour is the NaN sentinel,
 //   * -w/voxel_size folded into one scale, (dxs - dyc) and (dxc + dys) precomputed per constraint.
-// Each of these differs from the reference's rounding by a few f32 ulp per point (relative 1e-7),
-// unbiased, so the sums agree to ~1e-9; what would NOT average out -- a point assigned to the
-// neighbouring cell -- cannot happen because locate_stage1 is shared with the exact kernel.
+// Each of these differs from the reference's rounding by a few f32 ulp per point, with ONE exception that
+// is kept in the reference's association: the interpolated value itself (interpolated_value, +32 VALU per
+// point).  The residual d_ref - value amplifies a one-ulp difference in the value by |value / residual|,
+// and where thousands of points share one local configuration (an axis-aligned plane: the same offsets and
+// neighbours for every point) that difference has the same sign for all of them: with the value from the
+// nested lerps the cost of such a constraint was off by up to 4.4e-5, J^T r by 2.2e-5
+// (profiles/fuzz_reg_large.py, 1 440 constraints of 128^3 submaps; rows exact throughout).  Gradients have
+// no such cancellation (they are differences of neighbours in both associations).  What must not happen in
+// either kernel -- a point assigned to the neighbouring cell -- cannot, because locate_stage1 is shared.
 // ACC = float keeps the 21 running products in f32 per thread across a tile (<= 2 * kMaxReduceIters
 // terms), widened to f64 for the wave / workgroup / constraint reduction: half the accumulator
 // registers and no f64 FMA in the loop.  Fixed order throughout => bitwise reproducible.
 __device__ __forceinline__ bool eval_point_lean(const float d[8], bool have, float Dx, float Dy, float Dz,
-                                                float inv_f, const PosePack& P, float xi, float yi,
+                                                float value, float inv_f, const PosePack& P, float xi, float yi,
                                                 float d_ref, float w, float u[6]) {
 #pragma clang fp contract(fast)
   // neighbour k = 4 x + 2 y + z
@@ -659,7 +676,7 @@ __device__ __forceinline__ bool eval_point_lean(const float d[8], bool have, flo
   const float u0 = Dy * b0 + v0, u1 = Dy * b1 + v1;
   const float ax0 = Dy * (a2 - a0) + a0, ax1 = Dy * (a3 - a1) + a1;
   const float gz = u1 - u0;
-  const float val = Dz * gz + u0;
+  const float val = value;  // the reference's association (interpolated_value), computed by the caller
   const float gx = Dz * (ax1 - ax0) + ax0;
   const float gy = Dz * (b1 - b0) + b0;
   const float s = -w * inv_f;
@@ -807,7 +824,10 @@ __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_ker
       // branch-free: lanes without a correspondence carry zeros (or the miss cost) through the FMAs
       float u[6];
       const bool in_range = local < tile.count;
-      const bool ok = eval_point_lean(d[j], have[j], loc[j].Dx, loc[j].Dy, loc[j].Dz, g.voxel_size_inv, P,
+      float c_[8];
+      const float value = interpolated_value(d[j], loc[j].Dx, loc[j].Dy, loc[j].Dz, c_[0], c_[1], c_[2], c_[3], c_[4],
+                                             c_[5], c_[6], c_[7]);
+      const bool ok = eval_point_lean(d[j], have[j], loc[j].Dx, loc[j].Dy, loc[j].Dz, value, g.voxel_size_inv, P,
                                       pt[j].x, pt[j].y, pt[j].w, w[j], u) && in_range;
 #pragma unroll
       for (int k = 0; k < 5; ++k) u[k] = ok ? u[k] : 0.0f;
