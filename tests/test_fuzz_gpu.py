@@ -42,3 +42,13 @@ def test_overlap_random_clusters_equal_the_oracle():
 
 def test_sampling_random_setups_follow_the_oracles_streams():
     assert _run("fuzz_sampling", 30, 300) == 0
+
+
+def test_reg_at_128_cubed_every_row_equal_and_fused_sums_close():
+    """four 128^3 city submaps, twelve constraints, two pose sets per seed: every materialised row exact, fused
+    sums within 2e-6 (this is the fuzzer that made the fused kernel share the reference's interpolated value)"""
+    assert _run("fuzz_reg_large", 3, 300) == 0
+
+
+def test_sampling_at_128_cubed_follows_the_oracles_streams():
+    assert _run("fuzz_sampling_large", 3, 300) == 0
