@@ -33,13 +33,29 @@ def main():
         n_sub = 4
         true = np.c_[rng.uniform(-14, 14, (n_sub, 2)), rng.uniform(-0.5, 0.5, n_sub), rng.uniform(-0.4, 0.4, n_sub)]
         subs, layers, pts = [], [], []
-        use_esdf = 1   # (the device scene generator builds the ESDF sampling grid only)
+        # every third seed: submaps built on the host (oracle/synth.py) and uploaded -- TSDF sampling grids,
+        # 8 voxels per side, blocks without observed voxels dropped, noise; otherwise the device generator
+        # (ESDF grid only)
+        host_built = seed % 3 == 2
+        use_esdf = int(rng.integers(0, 2)) if host_built else 1
+        if host_built:
+            from oracle import synth
+            from tests import helpers as H
+            vps_s = int(rng.choice([8, 16]))
+            dims_s = tuple(int(128 // vps_s) for _ in range(3))
+            bmin_s = tuple(int(-d // 2) for d in dims_s)
         for k in range(n_sub):
-            sm = capi.Submap.synth_city(ctx, k, vs, vps, bmin, bdim, 0.6, 2.0, 10.0, true[k], seed % 5)
-            n = sm.extract_voxel_points(1.0, 0.3, bool(use_esdf))
-            td, tw, ed, eo = sm.download_layers(vps)
-            layers.append(orc.Layer(vs, vps, sm.block_index(), ed, eo) if use_esdf else
-                          orc.Layer(vs, vps, sm.block_index(), td, (tw > 0).astype(np.uint8)))
+            if host_built:
+                hs = synth.make_submap(synth.city_sdf(seed % 5), vs, vps_s, bmin_s, dims_s, 0.6, pose=true[k], esdf_max=2.0,
+                                       drop_empty_blocks=True, noise=float(rng.choice([0.0, 0.01])), seed=seed + k)
+                sm = H.gpu_submap(capi, ctx, hs, k)
+                n = sm.extract_voxel_points(1.0, 0.3, bool(use_esdf))
+                layers.append(H.oracle_layer(hs, use_esdf=bool(use_esdf)))
+            else:
+                sm = capi.Submap.synth_city(ctx, k, vs, vps, bmin, bdim, 0.6, 2.0, 10.0, true[k], seed % 5)
+                n = sm.extract_voxel_points(1.0, 0.3, True)
+                td, tw, ed, eo = sm.download_layers(vps)
+                layers.append(orc.Layer(vs, vps, sm.block_index(), ed, eo))
             pts.append(sm.download_points(capi.POINTS_VOXELS) if n else None)
             subs.append(sm)
         pairs = [(a, b) for a in range(n_sub) for b in range(n_sub) if a != b and pts[a] is not None]

@@ -19,6 +19,7 @@ def main():
     from tests.test_tsdf_deterministic_gpu import _lidar_scan, _assert_layers_identical
     capi.load()
     ctx = capi.Context(0)
+    big = int(os.environ.get("BIG", "0"))      # BIG=1: eight larger scans per session, the sensor moving 2-3 m a scan
     n_seeds = int(os.environ.get("SEEDS", "40"))
     first = int(os.environ.get("FIRST", "1000"))
     tally = {"fast": 0, "merged": 0, "merged racing": 0}
@@ -44,9 +45,12 @@ def main():
             gi = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(deterministic=det, **kw), gl)
             room = ((-30 * vs, -24 * vs, -6 * vs), (32 * vs, 50 * vs, 14 * vs))
             srng = np.random.default_rng(seed * 7 + 1)
-            for k in range(3):
+            for k in range(8 if big else 3):
                 origin = (srng.uniform(-3, 3, 3) * vs).astype(F)
-                pts = _lidar_scan(int(srng.integers(40, 400)), int(srng.integers(4, 30)), seed * 10 + k, room=room,
+                if big:
+                    origin = (origin + np.array([10.0 * k, -6.0 * k, 0.5 * k]) * vs).astype(F)   # the layer grows, the table is re-boxed
+                pts = _lidar_scan(int(srng.integers(400, 1100)) if big else int(srng.integers(40, 400)),
+                                  int(srng.integers(16, 40)) if big else int(srng.integers(4, 30)), seed * 10 + k, room=room,
                                   origin=origin.astype(np.float64), el=0.5)
                 pts = pts[srng.permutation(len(pts))]
                 pts[:3] = 0.0
@@ -55,7 +59,7 @@ def main():
                 ax = srng.normal(0, 1, 3); ax /= np.linalg.norm(ax)
                 T = np.r_[np.cos(ang / 2), np.sin(ang / 2) * ax, origin].astype(F)
                 col = srng.integers(0, 256, (len(pts), 4)).astype(np.uint8)
-                free = bool(k == 2 and seed % 3 == 0)
+                free = bool(k % 3 == 2 and seed % 3 == 0)
                 try:
                     if kind == "fast":
                         a = oi.integratePointCloud(T, pts, col, free)
@@ -81,7 +85,7 @@ def main():
             tally[kind] += 1
             for o in (gi, gl):
                 o.destroy()
-    print("no mismatch:", tally, "configurations x 3 scans each")
+    print("no mismatch:", tally, "configurations x", 8 if big else 3, "scans each")
     ctx.close()
     return 0
 
