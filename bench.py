@@ -41,12 +41,13 @@ sys.path.insert(0, ROOT)
 # "hipIpcGetMemHandle: invalid argument" (already exported on the GPU boxes; kept for safety)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-BYTES_PER_EVAL = 88            # SURVEY.md 8d contract figure (materialising, f32 outputs)
-BYTES_NO_CORR = 56             # an evaluation that finds no reading block: 20 B in, 36 B out
-BYTES_OUT, BYTES_POINT, BYTES_NEIGHBOURS = 36, 20, 32   # the three parts of the 88 B
-BYTES_PER_EVAL_FUSED = 52      # fused form: 20 B point + 32 B neighbours, nothing written per point
-BYTES_NO_CORR_FUSED = 20       # a point the fused pass loads but that finds no reading block
+from harness.bench_common import (HBM_PEAK_GBS, BYTES_PER_EVAL, BYTES_NO_CORR, BYTES_OUT, BYTES_POINT,  # noqa: E402
+                                   BYTES_NEIGHBOURS, BYTES_PER_EVAL_FUSED, BYTES_NO_CORR_FUSED, lpt_shards)
+from harness.bench_cpu import cpu_baseline  # noqa: E402
+from harness.bench_tsdf import tsdf_bench, finish_bench  # noqa: E402
+from harness.bench_config5 import config5_bench  # noqa: E402
+from harness.bench_multi import multi_context_bench  # noqa: E402
+
 PROFILE_TRAFFIC = {}           # profiles/hbm_traffic.json: PMC bytes per launch of the workloads below
 
 
@@ -79,646 +80,24 @@ def build_graph(args):
     return true_poses, poses, np.array(pairs, np.int32)
 
 
-def lpt_shards(weights, n):
-    """Greedy longest-processing-time partition of constraints onto n ranks: the library's own
-    placement (vgx_lpt_shards), the one the in-process multi-GPU component uses."""
-    from voxgraph_amd import capi
-    shard_of = capi.lpt_shards(weights, n)
-    return [[int(c) for c in np.nonzero(shard_of == r)[0]] for r in range(n)]
 
-
-def cpu_baseline(capi, ctx, args, true_poses, poses, pairs, seconds):
-    """The CPU oracle ("port") timed on this host on ONE constraint of the same
-    workload, replicated over all host cores (one constraint per task, the
-    reference's parallelism axis, pose_graph.cpp:96)."""
-    from concurrent.futures import ThreadPoolExecutor
-    from oracle import pyoracle as orc
-    a, b = int(pairs[0][0]), int(pairs[0][1])
-    subs = {}
-    for k in (a, b):
-        sm = capi.Submap.synth_city(ctx, k, args.voxel_size, 16, args.block_min, args.block_dims,
-                                    args.truncation, args.esdf_max, 10.0, true_poses[k], args.seed)
-        td, tw, ed, eo = sm.download_layers(16)
-        subs[k] = (sm.block_index(), td, tw, ed, eo)
-        sm.destroy()
-    bi, td, tw, ed, eo = subs[a]
-    xyz, dist, w = orc.find_relevant_voxels(args.voxel_size, 16, bi, td, tw, ed)
-    bi, td, tw, ed, eo = subs[b]
-    layer = orc.Layer(args.voxel_size, 16, bi, ed, eo)
-    cores = os.cpu_count() or 1
-    n = len(w)
-
-    def task(_):
-        ok, r, jo, je = orc.reg_evaluate(layer, xyz, dist, w, poses[a], poses[b])
-        return n
-
-    task(0)                                   # page everything in
-    done, t0 = 0, time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:
-        while time.perf_counter() - t0 < seconds:
-            done += sum(ex.map(task, range(cores)))
-    dt = time.perf_counter() - t0
-    # the reference's own setting: Ceres num_threads = 4 (pose_graph.cpp:96)
-    done4, t4 = 0, time.perf_counter()
-    with ThreadPoolExecutor(4) as ex:
-        while time.perf_counter() - t4 < max(2.0, seconds / 4):
-            done4 += sum(ex.map(task, range(4)))
-    dt4 = time.perf_counter() - t4
-    out = {"value": done / dt / 1e6, "unit": "Mresiduals+Jacobians/s", "cores": cores,
-           "value_4_threads": done4 / dt4 / 1e6,
-           "kind": "port",
-           "sample": f"constraint 0 of the same graph ({n} residuals, one 256^3 pair) evaluated "
-                     f"{done // n} times, one evaluation per task on {cores} threads, {dt:.1f} s; "
-                     "oracle/reg_oracle.c (" + orc.build_flags() + ")"}
-    # The reference's OWN RegistrationCostFunction::Evaluate (oracle/_ref: its source compiled
-    # against stand-in headers, hashed-block voxblox layer included), when the prebuilt library
-    # travelled here: same constraint, same poses, its results checked against the port's.
+def emit(full, detail_path, full_line=False):
+    """Everything measured -> `detail_path` (and stderr); ONE compact line -> stdout (harness/bench_line.py:
+    contract keys first, numbers only, below bench_line.LINE_LIMIT bytes so that the driver can parse it)."""
+    from harness import bench_line
+    text = json.dumps(full, indent=1)
+    where = None
     try:
-        from oracle import ref_reg
-        if ref_reg.available():
-            subs_ref = {}
-            for k in (a, b):
-                bi, td, tw, ed, eo = subs[k]
-                subs_ref[k] = ref_reg.Submap(k, true_poses[k], args.voxel_size, 16, bi, td, tw, ed, eo)
-            # the reference walks its hash map in its own block order: same point SET, so compare sorted
-            cf0 = ref_reg.RegistrationCostFunction(subs_ref[a], subs_ref[b])
-            ok_r, r_ref, _, _ = cf0.Evaluate(poses[a], poses[b])
-            ok_p, r_port, _, _ = orc.reg_evaluate(layer, xyz, dist, w, poses[a], poses[b])
-            same = bool(ok_r and ok_p and np.array_equal(np.sort(r_ref), np.sort(r_port)))
-            n_thr = min(cores, 64)
-            cfs = [ref_reg.RegistrationCostFunction(subs_ref[a], subs_ref[b]) for _ in range(n_thr)]
-
-            def ref_task(i):
-                cfs[i].Evaluate(poses[a], poses[b])
-                return cfs[i].num_residuals()
-
-            def timed(threads, budget):
-                cnt, t = 0, time.perf_counter()
-                with ThreadPoolExecutor(threads) as ex:
-                    while time.perf_counter() - t < budget:
-                        cnt += sum(ex.map(ref_task, range(threads)))
-                return cnt / (time.perf_counter() - t) / 1e6
-            out["reference_source"] = {
-                "kind": "reference", "unit": "Mresiduals+Jacobians/s",
-                "value": timed(n_thr, max(2.0, seconds / 3)), "cores": n_thr,
-                "value_4_threads": timed(4, max(2.0, seconds / 6)),
-                "residuals_equal_to_port": same,
-                "sample": "the same constraint through /root/reference's registration_cost_function.cpp, "
-                          "compiled (g++ -O2) against oracle/ref_shims (hashed 16^3 blocks of 12/20-byte "
-                          "voxels behind shared_ptr, minimal Eigen); one cost function per thread"}
-    except Exception as e:                                    # the checker must never sink the bench
-        out["reference_source"] = {"error": repr(e)}
-    return out
-
-
-def _room_points(dirs, origin):
-    """first hit of unit rays from `origin` with the inside of a 10 x 8 x 4 m room"""
-    lo, hi = np.array([-5.0, -4.0, -1.0]) - origin, np.array([5.0, 4.0, 3.0]) - origin
-    with np.errstate(divide="ignore", invalid="ignore"):
-        t = np.where(dirs > 0, hi / dirs, np.where(dirs < 0, lo / dirs, np.inf))
-    return (dirs * t.min(1)[:, None]).astype(np.float32)
-
-
-def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=2):
-    """Second hot path (TSDF): whole scans resident in HBM, one integratePointCloud per
-    scan into the active layer, HIP-event timed.  Two sensor shapes from BASELINE.json:
-    RGB-D 640x480 @ 0.05 m voxels (config 4) and OS1-64-shaped LiDAR 64x1024 @ 0.20 m with
-    the shipped yaml (config 2's integrator settings)."""
-    from oracle import pyoracle as orc
-    out = {}
-    u, v = np.meshgrid((np.arange(640) - 319.5) / 525.0, (np.arange(480) - 239.5) / 525.0)
-    d_rgbd = np.stack([np.ones_like(u), -u, -v], -1).reshape(-1, 3)
-    d_rgbd /= np.linalg.norm(d_rgbd, axis=1, keepdims=True)
-    az = np.linspace(-np.pi, np.pi, 1024, endpoint=False)
-    el = np.deg2rad(np.linspace(-16.6, 16.6, 64))
-    A, E = np.meshgrid(az, el)
-    d_lidar = np.stack([np.cos(E) * np.cos(A), np.cos(E) * np.sin(A), np.sin(E)], -1).reshape(-1, 3)
-    cases = {
-        "rgbd_640x480_0.05m": (d_rgbd, 0.05, dict(default_truncation_distance=0.15, max_ray_length_m=5.0),
-                               (-8, -6, -2), (16, 12, 7)),
-        "lidar_64x1024_0.20m_voxgraph_yaml": (d_lidar, 0.20, dict(
-            default_truncation_distance=0.60, max_ray_length_m=16.0, use_const_weight=1,
-            use_weight_dropoff=1, use_sparsity_compensation_factor=1,
-            sparsity_compensation_factor=20.0), (-3, -3, -2), (6, 6, 4)),
-    }
-    for name, (dirs, vs, kw, bmin, bdim) in cases.items():
-        poses, clouds = [], []
-        for k in range(scans):
-            origin = np.array([-2.0 + 0.15 * k, 0.5 - 0.05 * k, 0.3 + 0.01 * k])
-            yaw = 0.05 * k
-            c, s_ = np.cos(yaw), np.sin(yaw)
-            R = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1.0]])
-            pts_w = _room_points(dirs @ R.T, origin)            # hits, relative to the sensor, world axes
-            pts_c = (pts_w @ R).astype(np.float32)              # sensor frame
-            poses.append(np.array([np.cos(yaw / 2), 0, 0, np.sin(yaw / 2), *origin], np.float32))
-            clouds.append(pts_c)
-        n_pts = clouds[0].shape[0]
-        reach = kw["max_ray_length_m"] + kw["default_truncation_distance"] + 2 * vs
-
-        def new_layer():
-            # unbounded layer; room for the whole sweep is reserved up front so that no timed
-            # scan pays for an enlargement (scans would reserve for themselves otherwise)
-            lay = capi.TsdfLayer(ctx, vs, 16)
-            for k in (0, scans - 1):
-                lay.reserve(poses[k][4:7], reach)
-            return lay
-
-        layer = new_layer()
-        integ = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(**kw), layer)
-        dev = [torch.from_numpy(c_).cuda() for c_ in clouds]
-        torch.cuda.synchronize()
-        integ.integrate_device(poses[0], dev[0].data_ptr(), None, n_pts)        # warm-up scan
-        ctx.synchronize()
-        g0 = layer.growths()
-        updates = 0
-        ctx.timer_start()
-        for k in range(1, scans):
-            integ.integrate_device(poses[k], dev[k].data_ptr(), None, n_pts)
-        ms = ctx.timer_stop()
-        grew = layer.growths() - g0
-        # second pass: voxel updates per scan (the count needs a sync per scan) and, with the stream
-        # drained around every launch, the duration of each scan's kernel by itself (HIP events)
-        layer2 = new_layer()
-        integ.setLayer(layer2)
-        kernel_ms = 0.0
-        for k in range(scans):
-            ctx.synchronize()
-            ctx.timer_start()
-            integ.integrate_device(poses[k], dev[k].data_ptr(), None, n_pts)
-            t_k = ctx.timer_stop()
-            kernel_ms += t_k if k >= 1 else 0.0
-        kernel_ms /= (scans - 1)
-        layer2b = new_layer()
-        integ.setLayer(layer2b)
-        for k in range(scans):
-            u_ = integ.integrate_device(poses[k], dev[k].data_ptr(), None, n_pts, count=True)
-            updates += u_ if k >= 1 else 0
-        n_blocks, dropped = layer.stats()
-        # heaviest case: the first scan into an empty layer with a fresh integrator (no
-        # previously observed voxels: every ray runs to its early-out or to the sensor)
-        layer3 = new_layer()
-        integ3 = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(**kw), layer3)
-        ctx.synchronize()
-        ctx.timer_start()
-        integ3.integrate_device(poses[0], dev[0].data_ptr(), None, n_pts)
-        first_ms = ctx.timer_stop()
-        layer4 = new_layer()
-        integ4 = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(**kw), layer4)
-        first_updates = integ4.integrate_device(poses[0], dev[0].data_ptr(), None, n_pts, count=True)
-        for o in (integ3, integ4, layer3, layer4, layer2b):
-            o.destroy()
-        # voxblox's other integrator on the same scans: MergedTsdfIntegrator (one ray per end voxel)
-        layer6 = new_layer()
-        integ6 = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(**kw), layer6)
-        integ6.integrate_merged_device(poses[0], dev[0].data_ptr(), None, n_pts)
-        ctx.synchronize()
-        ctx.timer_start()
-        for k in range(1, scans):
-            integ6.integrate_merged_device(poses[k], dev[k].data_ptr(), None, n_pts)
-        merged_ms = ctx.timer_stop() / (scans - 1)
-        merged_updates = integ6.integrate_merged_device(poses[1], dev[1].data_ptr(), None, n_pts, count=True)
-        merged_dropped = layer6.stats()[1]
-        for o in (integ6, layer6):
-            o.destroy()
-        # the REPRODUCIBLE mode (vgx_tsdf_config.deterministic) on the same scans: wall clock per scan (the
-        # mode synchronises with the host several times per scan), its voxel updates, and -- the TSDF
-        # path's same-run parity evidence -- its layer after the CPU sample's scans against the oracle's
-        layer7 = new_layer()
-        integ7 = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(deterministic=1, **kw), layer7)
-        integ7.integrate_device(poses[0], dev[0].data_ptr(), None, n_pts)
-        ctx.synchronize()
-        d0 = time.perf_counter()
-        for k in range(1, scans):
-            integ7.integrate_device(poses[k], dev[k].data_ptr(), None, n_pts)
-        ctx.synchronize()
-        det_ms = (time.perf_counter() - d0) * 1e3 / (scans - 1)
-        det_updates = integ7.integrate_device(poses[1], dev[1].data_ptr(), None, n_pts, count=True)
-        for o in (integ7, layer7):
-            o.destroy()
-        # the drop-in call itself: host pointers (pageable), PCIe upload included, returns when done;
-        # layer created the way voxblox creates one (no reservation at all)
-        layer5 = capi.TsdfLayer(ctx, vs, 16)
-        integ5 = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(**kw), layer5)
-        integ5.integratePointCloud(poses[0], clouds[0])
-        h0 = time.perf_counter()
-        for k in range(1, scans):
-            integ5.integratePointCloud(poses[k], clouds[k])
-        host_ms = (time.perf_counter() - h0) * 1e3 / (scans - 1)
-        host_growths = layer5.growths()
-        for o in (integ5, layer5):
-            o.destroy()
-        # CPU oracle on a bounded sample (single thread: the restatement is serial)
-        ol = orc.TsdfLayer(vs, 16)
-        oi = orc.FastTsdfIntegrator(orc.tsdf_config(**kw), ol)
-        oi.integratePointCloud(poses[0], clouds[0])
-        t0, cu = time.perf_counter(), 0
-        for k in range(1, 1 + cpu_scans):
-            cu += oi.integratePointCloud(poses[k], clouds[k])
-        cdt = time.perf_counter() - t0
-        # same scans through the reproducible mode: bit for bit the oracle's layer?
-        layer8 = capi.TsdfLayer(ctx, vs, 16)
-        integ8 = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(deterministic=1, **kw), layer8)
-        gu = 0
-        for k in range(0, 1 + cpu_scans):
-            u_ = integ8.integrate_device(poses[k], dev[k].data_ptr(), None, n_pts, count=True)
-            gu += u_ if k >= 1 else 0
-        obi, od, ow, oc = ol.download()
-        gbi, gd, gw, gc = layer8.download()
-        det_parity = {"scans": 1 + cpu_scans, "voxel_updates_equal": bool(gu == cu),
-                      "blocks": int(len(obi)), "voxels_compared": int(od.size),
-                      "bit_identical": bool(np.array_equal(obi, gbi) and np.array_equal(od.view(np.uint32), gd.view(np.uint32))
-                                            and np.array_equal(ow.view(np.uint32), gw.view(np.uint32)) and np.array_equal(oc, gc)),
-                      "checker": "oracle/tsdf_oracle.c (single thread, mixed order) [recalled: parity unpinned]"}
-        for o in (integ8, layer8):
-            o.destroy()
-        # the same port on all host cores: the path does not shard (one active submap), so this is
-        # REPLICAS -- one integrator + layer per thread, every thread the same scans
-        from concurrent.futures import ThreadPoolExecutor
-        cores = os.cpu_count() or 1
-        reps = []
-        for _ in range(cores):
-            l_ = orc.TsdfLayer(vs, 16)
-            i_ = orc.FastTsdfIntegrator(orc.tsdf_config(**kw), l_)
-            reps.append((l_, i_))
-
-        def replica(j):
-            i_ = reps[j][1]
-            i_.integratePointCloud(poses[0], clouds[0])
-            t_ = time.perf_counter()
-            for k in range(1, 1 + cpu_scans):
-                i_.integratePointCloud(poses[k], clouds[k])
-            return time.perf_counter() - t_
-        t0r = time.perf_counter()
-        with ThreadPoolExecutor(cores) as ex:
-            rt = list(ex.map(replica, range(cores)))
-        cpu_all = {"Mpoints_per_s": n_pts * cpu_scans * cores / max(rt) / 1e6, "cores": cores, "kind": "port",
-                   "replicas": cores, "wall_s": time.perf_counter() - t0r,
-                   "sample": f"{cores} replicas (one integrator + layer per thread) x {cpu_scans} scans; the "
-                             "restatement is serial within a scan"}
-        del reps
-        timed = scans - 1
-        alg_bytes_scan = 16.0 * n_pts + 24.0 * updates / timed
-        out[name] = {"points_per_scan": n_pts, "scans_timed": timed, "ms_per_scan": ms / timed,
-                     "Mpoints_per_s": n_pts * timed / ms / 1e3,
-                     "Mvoxel_updates_per_s": updates / ms / 1e3,
-                     "voxel_updates_per_scan": updates / timed, "blocks": n_blocks,
-                     "dropped_updates": dropped, "layer_enlargements_in_timed_region": grew,
-                     "algorithmic_GBs": alg_bytes_scan * timed / ms / 1e6,
-                     # the TSDF kernel is latency bound (one dependent L2 round trip per DDA step of
-                     # the longest ray), nowhere near the HBM roofline: reported for completeness
-                     "roofline": {"bound": "hbm", "kernel": "tsdf_integrate_kernel<true>",
-                                  "kernel_ms": kernel_ms,
-                                  "kernel_ms_how": "HIP events around each scan's launch, stream drained before",
-                                  "bytes_per_launch": alg_bytes_scan,
-                                  "achieved": alg_bytes_scan / kernel_ms / 1e6, "peak": HBM_PEAK_GBS,
-                                  "unit": "GB/s", "frac": alg_bytes_scan / kernel_ms / 1e6 / HBM_PEAK_GBS,
-                                  "back_to_back_ms_per_scan": ms / timed,
-                                  "back_to_back_over_kernel": (ms / timed) / kernel_ms},
-                     "host_pointer_call": {"ms_per_scan": host_ms, "Mpoints_per_s": n_pts / host_ms / 1e3,
-                                           "layer_enlargements": host_growths,
-                                           "note": "vgx_tsdf_integrate into an unreserved layer: pageable host "
-                                                   "points, PCIe upload, enlargements and completion wait included"},
-                     "merged_integrator": {"ms_per_scan": merged_ms, "Mpoints_per_s": n_pts / merged_ms / 1e3,
-                                           "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
-                                                        "bytes_per_launch": 16.0 * n_pts + 24.0 * merged_updates,
-                                                        "achieved": (16.0 * n_pts + 24.0 * merged_updates) / merged_ms / 1e6,
-                                                        "frac": (16.0 * n_pts + 24.0 * merged_updates) / merged_ms / 1e6 / HBM_PEAK_GBS,
-                                                        "time": "back-to-back scans, all kernels of a scan (keys, sort, "
-                                                                "heads, rays)"},
-                                           "voxel_updates_per_scan": merged_updates, "dropped_updates": merged_dropped,
-                                           "Mvoxel_updates_per_s": merged_updates / merged_ms / 1e3,
-                                           "note": "vgx_tsdf_integrate_merged_device: key + stable radix sort + group heads + "
-                                                   "cooperative merge, then every ray written out, sorted by voxel and applied "
-                                                   "voxel by voxel in group order (no early-out: the voxels next to the sensor "
-                                                   "take one update per group, a sequential f32 chain)"},
-                     "reproducible_mode": {"ms_per_scan": det_ms, "Mpoints_per_s": n_pts / det_ms / 1e3,
-                                           "voxel_updates_per_scan": det_updates,
-                                           "over_racing_kernel": det_ms / (ms / timed),
-                                           "parity_vs_oracle": det_parity,
-                                           "note": "vgx_tsdf_config.deterministic = 1: the single-thread visiting "
-                                                   "order resolved in parallel (sort by approximate-set slot, "
-                                                   "fixed-point sweeps, ordered per-voxel updates); wall clock incl. "
-                                                   "its host synchronisations"},
-                     "first_scan": {"ms": first_ms, "voxel_updates": first_updates,
-                                    "Mvoxel_updates_per_s": first_updates / first_ms / 1e3,
-                                    "algorithmic_GBs": (16.0 * n_pts + 24.0 * first_updates) / first_ms / 1e6},
-                     "cpu_baseline": {"Mpoints_per_s": n_pts * cpu_scans / cdt / 1e6,
-                                      "Mvoxel_updates_per_s": cu / cdt / 1e6, "cores": 1,
-                                      "kind": "port", "sample": f"{cpu_scans} scans, oracle/tsdf_oracle.c ("
-                                                                + orc.build_flags() + ")",
-                                      "all_cores": cpu_all}}
-        for o in (integ, layer, layer2):
-            o.destroy()
-    return out
-
-
-def finish_bench(capi, ctx, args, true_poses):
-    """finishSubmap() on the device for one 256^3 submap of the bench scene (HIP-event
-    timed): ESDF from TSDF, kVoxels and kIsosurfacePoints extraction."""
-    sm = capi.Submap.synth_city(ctx, 0, args.voxel_size, 16, args.block_min, args.block_dims,
-                                args.truncation, args.esdf_max, 10.0, true_poses[0], args.seed)
-    out = {}
-    for name, fn in (("generate_esdf_ms", lambda: sm.generate_esdf()),
-                     ("extract_voxel_points_ms", lambda: sm.extract_voxel_points(1.0, 0.3, True)),
-                     ("extract_isosurface_points_ms", lambda: sm.extract_isosurface_points(1.0))):
-        fn()
-        ctx.synchronize()
-        ctx.timer_start()
-        r = fn()
-        out[name] = ctx.timer_stop()
-        out[name.replace("_ms", "_result")] = int(r)
-    sm.destroy()
-    return out
-
-
-class GpuBackendLite:
-    """single batch: fused pass + assembly + copy of the fused buffer to the host (what
-    vgx_reg_multi_evaluate_fused returns), without the harness around it"""
-
-    def __init__(self, capi, ctx, batch, n_nodes, torch):
-        self.ctx, self.batch, self.n_nodes = ctx, batch, n_nodes
-        self.buf = torch.zeros(capi.fused_size(n_nodes, batch.n_global), dtype=torch.float64, device="cuda")
-        self.host = torch.zeros_like(self.buf, device="cpu").pin_memory()
-        torch.cuda.current_stream().synchronize()
-        self.torch = torch
-
-    def __call__(self):
-        self.batch.evaluate_normal(self._poses, to_host=False)
-        self.batch.assemble(self.n_nodes, self.buf.data_ptr(), zero_first=True)
-        self.ctx.synchronize()
-        self.host.copy_(self.buf, non_blocking=True)
-        self.torch.cuda.current_stream().synchronize()
-        return self.host.numpy()
-
-
-def config5_bench(capi, ctx, torch, dist, use_dist, rank, world, args):
-    """BASELINE configs[4]: 1000 submaps @ 128^3 on a loop (serpentine) trajectory, odometry edges
-    with accumulated drift, 20 injected loop-closure relative-pose edges
-    (PoseGraphInterface::addLoopClosureMeasurement, pose_graph_interface.cpp:68-92) and the
-    reference's two-stage optimisation (PoseGraphInterface::optimize, :177-198: loop closures are
-    new, so first optimise WITHOUT the registration constraints, then with all of them).
-    Constraints pair-sharded over the ranks; one all-reduce per solver evaluation."""
-    from harness import lm
-    from harness.backends import GpuBackend
-    n_lanes, per_lane = args.config5_grid
-    n = n_lanes * per_lane
-    rng = np.random.default_rng(4)                                 # SURVEY.md 8d: seed 4
-    vs, dims, bmin = 0.2, (8, 8, 8), (-4, -4, -2)                   # 128^3 voxels, 25.6 m cubes
-    dx, dy = 12.8, 19.2                                             # 50 % overlap along a lane, 25 % across
-
-    def idx(lane, q):                                               # path index of x-position q in a lane
-        return lane * per_lane + (q if lane % 2 == 0 else per_lane - 1 - q)
-    true = np.zeros((n, 4))
-    for lane in range(n_lanes):
-        for q in range(per_lane):
-            true[idx(lane, q)] = [q * dx, lane * dy, 0.0, rng.uniform(-0.1, 0.1)]
-    pairs = [(i, i + 1) for i in range(n - 1)]
-    for lane in range(n_lanes - 1):
-        for q in range(per_lane):
-            for dq in (-1, 0, 1):
-                if 0 <= q + dq < per_lane:
-                    a, b = idx(lane, q), idx(lane + 1, q + dq)
-                    if abs(a - b) > 1:
-                        pairs.append((min(a, b), max(a, b)))
-    pairs = np.array(sorted(set(pairs)), np.int32)
-
-    def between(pa, pb):
-        c, s_ = np.cos(pa[3]), np.sin(pa[3])
-        d = pb[:3] - pa[:3]
-        return np.array([c * d[0] + s_ * d[1], -s_ * d[0] + c * d[1], d[2], lm.normalize_angle(pb[3] - pa[3])])
-
-    def compose(pose, delta):
-        c, s_ = np.cos(pose[3]), np.sin(pose[3])
-        return np.array([pose[0] + c * delta[0] - s_ * delta[1], pose[1] + s_ * delta[0] + c * delta[1],
-                         pose[2] + delta[2], lm.normalize_angle(pose[3] + delta[3])])
-    # odometry: good in z and yaw (the yaml's information 2500), drifting in x, y.  The per-step noise
-    # is sized so that neighbours across lanes (40-80 steps apart along the path) start within the
-    # registration basin (a few voxels), as they do when voxgraph optimises after every new submap
-    sig = np.array([0.01, 0.01, 0.001, 5e-5])
-    info_odo = [1.0, 1.0, 2500.0, 2500.0]                            # voxgraph_mapper.yaml:41-47
-    info_lc = [100.0, 100.0, 2500.0, 2500.0]                         # not in the yaml (template is zero): 0.1 m
-    poses0 = true[:1].copy()
-    edges = []
-    for k in range(n - 1):
-        delta = between(true[k], true[k + 1]) + rng.normal(0, sig)
-        edges.append(lm.RelativePoseEdge(k, k + 1, delta[:3], delta[3], info_odo))
-        poses0 = np.vstack([poses0, compose(poses0[k], delta)])
-    n_lc = 20
-    for j in range(n_lc):
-        lane = 1 + (j * (n_lanes - 1)) // n_lc
-        q = (7 * j + 3) % per_lane
-        a, b = idx(lane - 1, q), idx(lane, q)
-        # a loop closure's yaw error acts over the whole lane behind it (1 mrad over 500 m = 0.5 m), so
-        # a usable one is accurate to a fraction of that
-        delta = between(true[a], true[b]) + rng.normal(0, [0.03, 0.03, 0.005, 1e-4])
-        edges.append(lm.RelativePoseEdge(a, b, delta[:3], delta[3], info_lc))
-
-    t0 = time.perf_counter()
-    submaps, n_points = [], []
-    for k in range(n):
-        sm = capi.Submap.synth_city(ctx, k, vs, 16, bmin, dims, args.truncation, args.esdf_max, 10.0,
-                                    true[k], args.seed)
-        n_points.append(sm.extract_voxel_points(1.0, 0.3, True))
-        sm.release_raw_layers()
-        submaps.append(sm)
-    ctx.synchronize()
-    setup_s = time.perf_counter() - t0
-    cfg = capi.default_config(registration_point_type=capi.POINTS_VOXELS)
-    mine = lpt_shards([n_points[a] for a, _ in pairs], world)[rank]
-    cfs = [capi.RegistrationCostFunction(ctx, submaps[pairs[c][0]], submaps[pairs[c][1]], cfg) for c in mine]
-    batch = capi.RegistrationBatch(ctx, cfs, pairs[mine], global_index=mine, n_global=len(pairs))
-    backend = GpuBackend(capi, ctx, batch, n, dist if use_dist else None)
-
-    def barrier():
-        if use_dist:
-            dist.barrier()
-
-    def rmse(p):
-        return float(np.sqrt(((p[:, :3] - true[:, :3]) ** 2).sum(1).mean()))
-
-    def rmse_aligned(p):
-        """absolute trajectory error after the best rigid alignment (yaw + translation) of the whole
-        estimate onto the truth: what is left once the gauge -- which submap 0 alone holds, through the
-        few constraints it takes part in -- is taken out"""
-        a, b = p[:, :2] - p[:, :2].mean(0), true[:, :2] - true[:, :2].mean(0)
-        H = a.T @ b
-        th = np.arctan2(H[0, 1] - H[1, 0], H[0, 0] + H[1, 1])
-        R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
-        dxy = a @ R.T - b
-        dz = (p[:, 2] - p[:, 2].mean()) - (true[:, 2] - true[:, 2].mean())
-        return float(np.sqrt((dxy ** 2).sum(1).mean() + (dz ** 2).mean()))
-    kw = dict(parameter_tolerance=1e-10, max_seconds=1e9)            # Ceres-default function_tolerance decides
-    if os.environ.get("VGX_C5_DEBUG"):
-        def parts(p):
-            reg = float(backend(p)[0]) * 0.5
-            tot = lm.Problem(backend, n, pairs, edges).evaluate_reduced(p)[0]
-            return {"registration": reg, "edges": tot - reg, "rmse": rmse(p)}
-        print("C5 at truth", parts(true), file=sys.stderr)
-        print("C5 at odometry", parts(poses0), file=sys.stderr)
-        xt, st = lm.solve(lm.Problem(backend, n, pairs, edges), true, **kw)
-        print("C5 from truth ->", parts(xt), st["iterations"], st["termination"], file=sys.stderr)
-        xo, so = lm.solve(lm.Problem(backend, n, pairs, edges), poses0, **kw)
-        print("C5 from odometry (no stage 1) ->", parts(xo), so["iterations"], so["termination"], file=sys.stderr)
-        err = np.linalg.norm((xo - true)[:, :2], axis=1)
-        print("C5 error by lane", [round(float(err[l * per_lane:(l + 1) * per_lane].mean()), 3) for l in range(n_lanes)], file=sys.stderr)
-        print("C5 aligned rmse: odometry", rmse_aligned(poses0), "from odometry ->", rmse_aligned(xo), file=sys.stderr)
-        reg_only = lm.Problem(backend, n, pairs, [])
-        xr, sr = lm.solve(reg_only, poses0, **kw)
-        print("C5 registration only from odometry ->", rmse(xr), sr["iterations"], sr["termination"], file=sys.stderr)
-        import contextlib
-        with contextlib.redirect_stdout(sys.stderr):                 # the two-stage solve, step by step
-            lm.optimize_two_stage(backend, n, pairs, edges, poses0, True, verbose=True, **kw)
-    lm.optimize_two_stage(backend, n, pairs, edges, poses0, True, **kw)      # untimed warm-up
-    torch.cuda.synchronize()
-    barrier()
-    s0 = time.perf_counter()
-    x, summaries = lm.optimize_two_stage(backend, n, pairs, edges, poses0, True, **kw)
-    torch.cuda.synchronize()
-    barrier()
-    sdt = torch.tensor([time.perf_counter() - s0], dtype=torch.float64, device="cuda")
-    # stage 1 alone, for the intermediate error
-    x1, _ = lm.solve(lm.Problem(lm.zero_registration_backend(n, len(pairs)), n, pairs, edges), poses0, **kw)
-    # one fused evaluation of every registration constraint at the initial guess, timed by itself
-    for _ in range(2):
-        backend(poses0)
-    torch.cuda.synchronize()
-    barrier()
-    e0 = time.perf_counter()
-    for _ in range(10):
-        backend(poses0)
-    torch.cuda.synchronize()
-    barrier()
-    edt = torch.tensor([(time.perf_counter() - e0) / 10], dtype=torch.float64, device="cuda")
-    rs = torch.tensor([float(batch.num_residuals())], dtype=torch.float64, device="cuda")
-    if use_dist:
-        dist.all_reduce(sdt, op=dist.ReduceOp.MAX)
-        dist.all_reduce(edt, op=dist.ReduceOp.MAX)
-        dist.all_reduce(rs, op=dist.ReduceOp.SUM)
-    out = {"workload": f"configs[4]: {n} submaps @ 128^3 (0.2 m) on a serpentine loop trajectory "
-                       f"({n_lanes} lanes x {per_lane}), {len(pairs)} registration constraints (kVoxels, all points), "
-                       f"{n - 1} odometry edges with accumulated drift, {n_lc} injected loop-closure edges; "
-                       "two-stage optimisation (pose_graph_interface.cpp:177-198)",
-           "submaps": n, "registration_constraints": int(len(pairs)), "loop_closures": n_lc,
-           "residuals_per_evaluation": float(rs.item()),
-           "solve_ms": float(sdt.item()) * 1e3,
-           "solve_gpu_evaluation_ms": sum(s_["backend_seconds"] for s_ in summaries) * 1e3,
-           "solve_host_linear_algebra_ms": sum(s_["host_linear_algebra_seconds"] for s_ in summaries) * 1e3,
-           "stage1_without_registration": {k: summaries[0][k] for k in ("iterations", "evaluations", "termination")},
-           "stage2_all_constraints": {k: summaries[1][k] for k in ("iterations", "evaluations", "termination",
-                                                                  "initial_cost", "final_cost")},
-           # Past the first few iterations stage 2 walks at random among the kinks of the trilinear field
-           # (steps of 1e-5 m, gain ratios between -50 and +100: VGX_C5_DEBUG=1 prints them), so WHEN
-           # function_tolerance or the iteration cap ends it depends on the last bits of the sums: the
-           # iteration count, and with it solve_ms, is not a property of the kernels.  These two are:
-           "stage2_ms_per_iteration": summaries[1]["seconds"] * 1e3 / max(summaries[1]["iterations"], 1),
-           "stage2_iterations_to_within_1e-3_of_final_cost": next(
-               (int(it_) for it_, c_ in summaries[1]["cost_history"] if c_ <= summaries[1]["final_cost"] * (1 + 1e-3)), None),
-           "registration_evaluation_ms": float(edt.item()) * 1e3,
-           "position_rmse_m_odometry": rmse(poses0), "position_rmse_m_after_stage1": rmse(x1),
-           "position_rmse_m_after": rmse(x),
-           "position_rmse_m_aligned_odometry": rmse_aligned(poses0),
-           "position_rmse_m_aligned_after_stage1": rmse_aligned(x1),
-           "position_rmse_m_aligned_after": rmse_aligned(x),
-           "rmse_note": "position_rmse_m_*: in the frame of the fixed first submap (the reference's gauge, "
-                        "pose_graph_interface.cpp:30-32); *_aligned_*: after the best rigid alignment of the "
-                        "whole estimate onto the truth (the registration cost is invariant to that transform "
-                        "except through submap 0's own few constraints)",
-           "stop_rule": "function_tolerance 1e-6 (Ceres default) in both stages, parameter_tolerance off",
-           "parallelism": f"pair-sharded x{world} (LPT), submaps replicated, one all-reduce of "
-                          f"{capi.fused_size(n, len(pairs)) * 8} B per evaluation",
-           "setup_s": setup_s,
-           "solver": "harness/lm.py (LM, banded Cholesky on the host; Ceres absent)"}
-    if rank == 0 and not args.no_parity:
-        from harness import parity_gate
-        t_par = time.perf_counter()
-
-        def layers_of(k):
-            sm = capi.Submap.synth_city(ctx, k, vs, 16, bmin, dims, args.truncation, args.esdf_max, 10.0, true[k], args.seed)
-            td, tw, ed, eo = sm.download_layers(16)
-            bi = sm.block_index()
-            sm.destroy()
-            return bi, td, tw, ed, eo
-        live_each = batch.count_live_each(poses0)
-        chosen = parity_gate.choose(np.diff(batch.row_offsets()), live_each, n_total=8, n_partial=3, n_dead=1)
-        e = parity_gate.check(capi, ctx, torch, "config 5 (the timed batch at the initial poses)", layers_of, submaps,
-                              batch, pairs[mine], poses0, chosen, None, vs)
-        e["seconds"] = time.perf_counter() - t_par
-        out["parity"] = e
-    for o in [batch] + cfs + submaps:
-        o.destroy()
-    return out
-
-
-def multi_context_bench(capi, ctx0, torch, args, devices, submaps0, true_poses, pairs, weights, poses, cfg, single_batch,
-                        n_sub, n_con):
-    """vgx_reg_multi_evaluate_fused over len(devices) contexts (context 0 = ctx0, whose submaps are
-    resident already; every other context gets the submaps its LPT share of the constraints needs)."""
-    n_ctx = len(devices)
-    t_setup = time.perf_counter()
-    ctxs = [ctx0] + [capi.Context(d) for d in devices[1:]]
-    shard_of = capi.lpt_shards(weights, n_ctx)
-    subs = [dict(enumerate(submaps0))] + [dict() for _ in range(n_ctx - 1)]
-    for k_ctx in range(1, n_ctx):
-        need = sorted({int(s_) for c in range(n_con) if shard_of[c] == k_ctx for s_ in pairs[c]})
-        for k in need:
-            sm = capi.Submap.synth_city(ctxs[k_ctx], k, args.voxel_size, 16, args.block_min, args.block_dims,
-                                        args.truncation, args.esdf_max, 10.0, true_poses[k], args.seed)
-            sm.extract_voxel_points(1.0, 0.3, True)
-            sm.release_raw_layers()
-            subs[k_ctx][k] = sm
-    cfs_m = [capi.RegistrationCostFunction(ctxs[shard_of[c]], subs[shard_of[c]][int(a)], subs[shard_of[c]][int(b)], cfg)
-             for c, (a, b) in enumerate(pairs)]
-    multi = capi.RegistrationMulti(ctxs, cfs_m, pairs)
-    setup_s = time.perf_counter() - t_setup
-    for _ in range(2):
-        fused_m, _ = multi.evaluate_fused(poses)
-    m0 = time.perf_counter()
-    for _ in range(args.steps):
-        fused_m, _ = multi.evaluate_fused(poses)
-    m_ms = (time.perf_counter() - m0) / args.steps * 1e3
-    out = {"contexts": n_ctx, "devices": len(set(devices)), "device_ids": devices,
-           "what": "vgx_reg_multi_evaluate_fused (LPT shard by bytes moved, one host thread per context, event-ordered "
-                   "fixed-order sum on context 0 over peer mappings, result on the host)",
-           "ms_per_evaluation": m_ms,
-           "Mresiduals_per_s": float(sum(cf.num_residuals() for cf in cfs_m)) / m_ms / 1e3,
-           "constraints_per_context": [int((shard_of == k).sum()) for k in range(n_ctx)],
-           "cost": float(fused_m[0]), "setup_s": setup_s}
-    if len(set(devices)) == n_ctx and n_ctx > 1:
-        # SURVEY.md 8(e) "compare": the same evaluation with ONE ncclAllReduce of the fused buffer instead of
-        # the fixed-order sum over peer mappings
-        try:
-            multi.set_reduction(True)
-            for _ in range(2):
-                fused_r, _ = multi.evaluate_fused(poses)
-            r0 = time.perf_counter()
-            for _ in range(args.steps):
-                fused_r, _ = multi.evaluate_fused(poses)
-            out["rccl_allreduce"] = {"ms_per_evaluation": (time.perf_counter() - r0) / args.steps * 1e3,
-                                     "max_rel_diff_vs_peer_sum": float(np.abs(fused_r - fused_m).max() / np.abs(fused_m).max()),
-                                     "what": "vgx_reg_multi_set_reduction(VGX_REDUCE_RCCL): ncclAllReduce(sum, f64) in place "
-                                             "on every context's stream, one communicator per context"}
-            multi.set_reduction(False)
-        except Exception as e:                                   # never sink the line on the optional variant
-            out["rccl_allreduce"] = {"error": repr(e)}
-    if single_batch is not None:
-        single = GpuBackendLite(capi, ctx0, single_batch, n_sub, torch)
-        single._poses = poses
-        for _ in range(2):
-            ref_buf = single()
-        s0_ = time.perf_counter()
-        for _ in range(args.steps):
-            ref_buf = single()
-        out["single_batch_ms_per_evaluation"] = (time.perf_counter() - s0_) / args.steps * 1e3
-        out["single_batch_what"] = "the single batch (evaluate + assemble + copy to the host) on context 0 alone"
-        out["max_rel_diff_vs_single_batch"] = float(np.abs(fused_m - ref_buf).max() / np.abs(ref_buf).max())
-    multi.destroy()
-    for o in cfs_m:
-        o.destroy()
-    for k_ctx in range(1, n_ctx):
-        for sm in subs[k_ctx].values():
-            sm.destroy()
-        ctxs[k_ctx].close()
-    return out
+        with open(detail_path, "w") as f:
+            f.write(text + "\n")
+        where = os.path.relpath(detail_path, ROOT) if os.path.abspath(detail_path).startswith(ROOT) else detail_path
+    except OSError as e:                          # a read-only checkout must not cost the line
+        print(f"bench.py: could not write {detail_path}: {e}", file=sys.stderr)
+    print(text, file=sys.stderr)
+    sys.stderr.flush()
+    _, line = bench_line.compact(full, where)
+    print(json.dumps(full) if full_line else line)
+    sys.stdout.flush()
 
 
 def main():
@@ -769,6 +148,12 @@ def main():
     ap.add_argument("--config", type=int, default=3, choices=[3, 5],
                     help="5: only BASELINE configs[4] (1000 submaps @ 128^3, loop closures, two-stage solve)")
     ap.add_argument("--config5-grid", type=int, nargs=2, default=[25, 40], help="lanes x submaps per lane")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"),
+                    help="where the FULL result object goes (every block with its notes); the stdout line is the "
+                         "compact summary of harness/bench_line.py")
+    ap.add_argument("--full-line", action="store_true",
+                    help="print the FULL object on stdout instead of the compact line (profiles/ab_*.sh pick nested "
+                         "keys from it); never what the driver runs")
     ap.add_argument("--calibrate", action="store_true",
                     help="PMC calibration: first launch evaluates poses 10 km apart, so every "
                          "evaluation reads exactly 20 B and writes exactly 36 B (profiles/README.md)")
@@ -831,9 +216,13 @@ def main():
     if args.config == 5:
         c5 = config5_bench(capi, ctx, torch, dist, use_dist, rank, world, args)
         if rank == 0:
-            print(json.dumps({"metric": "full pose-graph solve ms (1000 submaps, two-stage)", "value": c5["solve_ms"],
-                              "unit": "ms", "n_gpus": world, "higher_is_better": False, "scaling": "strong",
-                              "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": c5}))
+            emit({"metric": "full pose-graph solve ms (1000 submaps, two-stage)", "value": c5["solve_ms"],
+                  "unit": "ms", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": c5["solve_ms"],
+                  "higher_is_better": False, "scaling": "strong",
+                  "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                  "config": {"workload": c5["workload"], "submaps": c5["submaps"],
+                             "constraints": c5["registration_constraints"], "parallelism": c5["parallelism"]},
+                  "config5": c5, "parity": c5.get("parity")}, args.detail, args.full_line)
         if use_dist:
             dist.barrier()
             dist.destroy_process_group()
@@ -1458,7 +847,8 @@ def main():
         if not args.no_parity:
             from harness import parity_gate
             out["parity"] = parity_gate.merge(parity_entries)
-        print(json.dumps(out))
+        out["rccl_ranks"] = world if (use_dist and not dryrun) else 0
+        emit(out, args.detail, args.full_line)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

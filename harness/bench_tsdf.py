@@ -1,0 +1,306 @@
+"""bench.py's TSDF block (metric 3) and the finishSubmap() timings."""
+import os
+import sys
+import time
+
+import numpy as np
+
+from harness.bench_common import HBM_PEAK_GBS, lpt_shards  # noqa: F401
+
+def _room_points(dirs, origin):
+    """first hit of unit rays from `origin` with the inside of a 10 x 8 x 4 m room"""
+    lo, hi = np.array([-5.0, -4.0, -1.0]) - origin, np.array([5.0, 4.0, 3.0]) - origin
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t = np.where(dirs > 0, hi / dirs, np.where(dirs < 0, lo / dirs, np.inf))
+    return (dirs * t.min(1)[:, None]).astype(np.float32)
+
+
+def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=8):
+    """Second hot path (TSDF): whole scans resident in HBM, one integratePointCloud per
+    scan into the active layer, HIP-event timed.  Two sensor shapes from BASELINE.json:
+    RGB-D 640x480 @ 0.05 m voxels (config 4) and OS1-64-shaped LiDAR 64x1024 @ 0.20 m with
+    the shipped yaml (config 2's integrator settings)."""
+    from oracle import pyoracle as orc
+    out = {}
+    u, v = np.meshgrid((np.arange(640) - 319.5) / 525.0, (np.arange(480) - 239.5) / 525.0)
+    d_rgbd = np.stack([np.ones_like(u), -u, -v], -1).reshape(-1, 3)
+    d_rgbd /= np.linalg.norm(d_rgbd, axis=1, keepdims=True)
+    az = np.linspace(-np.pi, np.pi, 1024, endpoint=False)
+    el = np.deg2rad(np.linspace(-16.6, 16.6, 64))
+    A, E = np.meshgrid(az, el)
+    d_lidar = np.stack([np.cos(E) * np.cos(A), np.cos(E) * np.sin(A), np.sin(E)], -1).reshape(-1, 3)
+    cases = {
+        "rgbd_640x480_0.05m": (d_rgbd, 0.05, dict(default_truncation_distance=0.15, max_ray_length_m=5.0),
+                               (-8, -6, -2), (16, 12, 7)),
+        "lidar_64x1024_0.20m_voxgraph_yaml": (d_lidar, 0.20, dict(
+            default_truncation_distance=0.60, max_ray_length_m=16.0, use_const_weight=1,
+            use_weight_dropoff=1, use_sparsity_compensation_factor=1,
+            sparsity_compensation_factor=20.0), (-3, -3, -2), (6, 6, 4)),
+    }
+    for name, (dirs, vs, kw, bmin, bdim) in cases.items():
+        poses, clouds = [], []
+        for k in range(scans):
+            origin = np.array([-2.0 + 0.15 * k, 0.5 - 0.05 * k, 0.3 + 0.01 * k])
+            yaw = 0.05 * k
+            c, s_ = np.cos(yaw), np.sin(yaw)
+            R = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1.0]])
+            pts_w = _room_points(dirs @ R.T, origin)            # hits, relative to the sensor, world axes
+            pts_c = (pts_w @ R).astype(np.float32)              # sensor frame
+            poses.append(np.array([np.cos(yaw / 2), 0, 0, np.sin(yaw / 2), *origin], np.float32))
+            clouds.append(pts_c)
+        n_pts = clouds[0].shape[0]
+        reach = kw["max_ray_length_m"] + kw["default_truncation_distance"] + 2 * vs
+
+        def new_layer():
+            # unbounded layer; room for the whole sweep is reserved up front so that no timed
+            # scan pays for an enlargement (scans would reserve for themselves otherwise)
+            lay = capi.TsdfLayer(ctx, vs, 16)
+            for k in (0, scans - 1):
+                lay.reserve(poses[k][4:7], reach)
+            return lay
+
+        layer = new_layer()
+        integ = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(**kw), layer)
+        dev = [torch.from_numpy(c_).cuda() for c_ in clouds]
+        torch.cuda.synchronize()
+        integ.integrate_device(poses[0], dev[0].data_ptr(), None, n_pts)        # warm-up scan
+        ctx.synchronize()
+        g0 = layer.growths()
+        updates = 0
+        ctx.timer_start()
+        for k in range(1, scans):
+            integ.integrate_device(poses[k], dev[k].data_ptr(), None, n_pts)
+        ms = ctx.timer_stop()
+        grew = layer.growths() - g0
+        # second pass: voxel updates per scan (the count needs a sync per scan) and, with the stream
+        # drained around every launch, the duration of each scan's kernel by itself (HIP events)
+        layer2 = new_layer()
+        integ.setLayer(layer2)
+        kernel_ms = 0.0
+        for k in range(scans):
+            ctx.synchronize()
+            ctx.timer_start()
+            integ.integrate_device(poses[k], dev[k].data_ptr(), None, n_pts)
+            t_k = ctx.timer_stop()
+            kernel_ms += t_k if k >= 1 else 0.0
+        kernel_ms /= (scans - 1)
+        layer2b = new_layer()
+        integ.setLayer(layer2b)
+        walks = []
+        for k in range(scans):
+            u_ = integ.integrate_device(poses[k], dev[k].data_ptr(), None, n_pts, count=True)
+            updates += u_ if k >= 1 else 0
+            if k >= 1:
+                walks.append(integ.longest_walk())     # dependent exchanges on this scan's longest ray
+        n_blocks, dropped = layer.stats()
+        # the operation a ray waits for once per voxel step, by itself: a chain of dependent device-scope
+        # exchanges on an 8 MiB table (an approximate hash set), one wavefront alone and as many wavefronts
+        # as this scan launches side by side
+        rt_unloaded_ns = capi.atomic_roundtrip_ns(ctx, 8 << 20, 1, 2000)
+        rt_loaded_ns = capi.atomic_roundtrip_ns(ctx, 8 << 20, max(n_pts // 64, 1), 200)
+        # heaviest case: the first scan into an empty layer with a fresh integrator (no
+        # previously observed voxels: every ray runs to its early-out or to the sensor)
+        layer3 = new_layer()
+        integ3 = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(**kw), layer3)
+        ctx.synchronize()
+        ctx.timer_start()
+        integ3.integrate_device(poses[0], dev[0].data_ptr(), None, n_pts)
+        first_ms = ctx.timer_stop()
+        layer4 = new_layer()
+        integ4 = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(**kw), layer4)
+        first_updates = integ4.integrate_device(poses[0], dev[0].data_ptr(), None, n_pts, count=True)
+        for o in (integ3, integ4, layer3, layer4, layer2b):
+            o.destroy()
+        # voxblox's other integrator on the same scans: MergedTsdfIntegrator (one ray per end voxel)
+        layer6 = new_layer()
+        integ6 = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(**kw), layer6)
+        integ6.integrate_merged_device(poses[0], dev[0].data_ptr(), None, n_pts)
+        ctx.synchronize()
+        ctx.timer_start()
+        for k in range(1, scans):
+            integ6.integrate_merged_device(poses[k], dev[k].data_ptr(), None, n_pts)
+        merged_ms = ctx.timer_stop() / (scans - 1)
+        merged_updates = integ6.integrate_merged_device(poses[1], dev[1].data_ptr(), None, n_pts, count=True)
+        merged_dropped = layer6.stats()[1]
+        for o in (integ6, layer6):
+            o.destroy()
+        # the REPRODUCIBLE mode (vgx_tsdf_config.deterministic) on the same scans: wall clock per scan (the
+        # mode synchronises with the host several times per scan), its voxel updates, and -- the TSDF
+        # path's same-run parity evidence -- its layer after the CPU sample's scans against the oracle's
+        layer7 = new_layer()
+        integ7 = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(deterministic=1, **kw), layer7)
+        integ7.integrate_device(poses[0], dev[0].data_ptr(), None, n_pts)
+        ctx.synchronize()
+        d0 = time.perf_counter()
+        for k in range(1, scans):
+            integ7.integrate_device(poses[k], dev[k].data_ptr(), None, n_pts)
+        ctx.synchronize()
+        det_ms = (time.perf_counter() - d0) * 1e3 / (scans - 1)
+        det_updates = integ7.integrate_device(poses[1], dev[1].data_ptr(), None, n_pts, count=True)
+        for o in (integ7, layer7):
+            o.destroy()
+        # the drop-in call itself: host pointers (pageable), PCIe upload included, returns when done;
+        # layer created the way voxblox creates one (no reservation at all)
+        layer5 = capi.TsdfLayer(ctx, vs, 16)
+        integ5 = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(**kw), layer5)
+        integ5.integratePointCloud(poses[0], clouds[0])
+        h0 = time.perf_counter()
+        for k in range(1, scans):
+            integ5.integratePointCloud(poses[k], clouds[k])
+        host_ms = (time.perf_counter() - h0) * 1e3 / (scans - 1)
+        host_growths = layer5.growths()
+        for o in (integ5, layer5):
+            o.destroy()
+        # CPU oracle on a bounded sample (single thread: the restatement is serial)
+        ol = orc.TsdfLayer(vs, 16)
+        oi = orc.FastTsdfIntegrator(orc.tsdf_config(**kw), ol)
+        oi.integratePointCloud(poses[0], clouds[0])
+        t0, cu = time.perf_counter(), 0
+        for k in range(1, 1 + cpu_scans):
+            cu += oi.integratePointCloud(poses[k], clouds[k])
+        cdt = time.perf_counter() - t0
+        # same scans through the reproducible mode: bit for bit the oracle's layer?
+        layer8 = capi.TsdfLayer(ctx, vs, 16)
+        integ8 = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(deterministic=1, **kw), layer8)
+        gu = 0
+        for k in range(0, 1 + cpu_scans):
+            u_ = integ8.integrate_device(poses[k], dev[k].data_ptr(), None, n_pts, count=True)
+            gu += u_ if k >= 1 else 0
+        obi, od, ow, oc = ol.download()
+        gbi, gd, gw, gc = layer8.download()
+        det_parity = {"scans": 1 + cpu_scans, "voxel_updates_equal": bool(gu == cu),
+                      "blocks": int(len(obi)), "voxels_compared": int(od.size),
+                      "bit_identical": bool(np.array_equal(obi, gbi) and np.array_equal(od.view(np.uint32), gd.view(np.uint32))
+                                            and np.array_equal(ow.view(np.uint32), gw.view(np.uint32)) and np.array_equal(oc, gc)),
+                      "checker": "oracle/tsdf_oracle.c (single thread, mixed order) [recalled: parity unpinned]"}
+        for o in (integ8, layer8):
+            o.destroy()
+        # the same port on all host cores: the path does not shard (one active submap), so this is
+        # REPLICAS -- one integrator + layer per thread, every thread the same scans.  All replicas start
+        # behind a barrier and run their whole sequence inside ONE foreign call (oracle/tsdf_oracle.c
+        # orc_tsdf_integrate_sequence: no interpreter lock between scans); rate = total points / wall clock
+        # from the barrier's release to the LAST replica's finish.
+        import threading
+        cores = os.cpu_count() or 1
+        one_scan_s = cdt / cpu_scans
+        seq_scans = min(scans - 1, 8)
+        repeats = max(int(np.ceil(50 / seq_scans)), int(np.ceil(0.4 / max(one_scan_s * seq_scans, 1e-6))))
+        seq_poses = np.stack(poses[1:1 + seq_scans]).astype(np.float32)
+        seq_clouds = np.stack(clouds[1:1 + seq_scans]).astype(np.float32)
+        reps = []
+        for _ in range(cores):
+            l_ = orc.TsdfLayer(vs, 16)
+            i_ = orc.FastTsdfIntegrator(orc.tsdf_config(**kw), l_)
+            i_.integratePointCloud(poses[0], clouds[0])          # untimed: the layer exists, pages are touched
+            reps.append((l_, i_))
+        gate = threading.Barrier(cores)
+        t_begin, t_end = [0.0] * cores, [0.0] * cores
+
+        def replica(j):
+            gate.wait()
+            t_begin[j] = time.perf_counter()
+            reps[j][1].integrate_sequence(seq_poses, seq_clouds, repeats)
+            t_end[j] = time.perf_counter()
+        threads = [threading.Thread(target=replica, args=(j,)) for j in range(cores)]
+        for t_ in threads:
+            t_.start()
+        for t_ in threads:
+            t_.join()
+        wall = max(t_end) - min(t_begin)
+        one_core = n_pts * cpu_scans / cdt / 1e6
+        all_rate = n_pts * seq_scans * repeats * cores / wall / 1e6
+        cpu_all = {"Mpoints_per_s": all_rate, "cores": cores, "kind": "port", "replicas": cores, "wall_s": wall,
+                   "scans_per_replica": seq_scans * repeats,
+                   "slowest_replica_s": max(e_ - b_ for b_, e_ in zip(t_begin, t_end)),
+                   "fastest_replica_s": min(e_ - b_ for b_, e_ in zip(t_begin, t_end)),
+                   "per_core_over_one_core": all_rate / cores / one_core,
+                   "at_most_cores_x_one_core": bool(all_rate <= 1.05 * cores * one_core),
+                   "sample": f"{cores} replicas (one integrator + layer per thread) x {seq_scans * repeats} scans "
+                             f"({repeats} passes over {seq_scans}), started behind a barrier; total points / wall "
+                             "clock to the last finish; the restatement is serial within a scan"}
+        del reps
+        timed = scans - 1
+        alg_bytes_scan = 16.0 * n_pts + 24.0 * updates / timed
+        out[name] = {"points_per_scan": n_pts, "scans_timed": timed, "ms_per_scan": ms / timed,
+                     "Mpoints_per_s": n_pts * timed / ms / 1e3,
+                     "Mvoxel_updates_per_s": updates / ms / 1e3,
+                     "voxel_updates_per_scan": updates / timed, "blocks": n_blocks,
+                     "dropped_updates": dropped, "layer_enlargements_in_timed_region": grew,
+                     "algorithmic_GBs": alg_bytes_scan * timed / ms / 1e6,
+                     # The racing kernel is LATENCY bound: a ray knows whether to take step k + 1 only when the
+                     # exchange of step k has come back, so a scan cannot finish before its longest ray's
+                     # chain of dependent exchanges has (DESIGN.md 3 "TSDF latency model").  bound = longest
+                     # walk (counted by the kernel) x the measured round trip of one such exchange on an idle
+                     # GPU; `frac` = that lower bound / the kernel's measured time.  The HBM figures
+                     # (SURVEY 8d's 16 B / point + 24 B / update) stay beside it: a scan is 1-8 MB, a
+                     # microsecond of HBM time, which is why hbm_frac reads 0.005.
+                     "roofline": {"bound": "latency", "kernel": "tsdf_integrate_kernel<true>",
+                                  "kernel_ms": kernel_ms,
+                                  "kernel_ms_how": "HIP events around each scan's launch, stream drained before",
+                                  "longest_walk_steps": float(np.mean(walks)), "longest_walk_steps_max": int(max(walks)),
+                                  "roundtrip_ns_unloaded": rt_unloaded_ns, "roundtrip_ns_loaded": rt_loaded_ns,
+                                  "achieved": kernel_ms, "peak": float(np.mean(walks)) * rt_unloaded_ns * 1e-6, "unit": "ms",
+                                  "frac": float(np.mean(walks)) * rt_unloaded_ns * 1e-6 / kernel_ms,
+                                  "frac_at_loaded_roundtrip": float(np.mean(walks)) * rt_loaded_ns * 1e-6 / kernel_ms,
+                                  "traffic": None,
+                                  "bytes_per_launch": alg_bytes_scan,
+                                  "hbm_achieved_GBs": alg_bytes_scan / kernel_ms / 1e6, "hbm_peak_GBs": HBM_PEAK_GBS,
+                                  "hbm_frac": alg_bytes_scan / kernel_ms / 1e6 / HBM_PEAK_GBS,
+                                  "back_to_back_ms_per_scan": ms / timed,
+                                  "back_to_back_over_kernel": (ms / timed) / kernel_ms},
+                     "host_pointer_call": {"ms_per_scan": host_ms, "Mpoints_per_s": n_pts / host_ms / 1e3,
+                                           "layer_enlargements": host_growths,
+                                           "note": "vgx_tsdf_integrate into an unreserved layer: pageable host "
+                                                   "points, PCIe upload, enlargements and completion wait included"},
+                     "merged_integrator": {"ms_per_scan": merged_ms, "Mpoints_per_s": n_pts / merged_ms / 1e3,
+                                           "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                                                        "bytes_per_launch": 16.0 * n_pts + 24.0 * merged_updates,
+                                                        "achieved": (16.0 * n_pts + 24.0 * merged_updates) / merged_ms / 1e6,
+                                                        "frac": (16.0 * n_pts + 24.0 * merged_updates) / merged_ms / 1e6 / HBM_PEAK_GBS,
+                                                        "time": "back-to-back scans, all kernels of a scan (keys, sort, "
+                                                                "heads, rays)"},
+                                           "voxel_updates_per_scan": merged_updates, "dropped_updates": merged_dropped,
+                                           "Mvoxel_updates_per_s": merged_updates / merged_ms / 1e3,
+                                           "note": "vgx_tsdf_integrate_merged_device: key + stable radix sort + group heads + "
+                                                   "cooperative merge, then every ray written out, sorted by voxel and applied "
+                                                   "voxel by voxel in group order (no early-out: the voxels next to the sensor "
+                                                   "take one update per group, a sequential f32 chain)"},
+                     "reproducible_mode": {"ms_per_scan": det_ms, "Mpoints_per_s": n_pts / det_ms / 1e3,
+                                           "voxel_updates_per_scan": det_updates,
+                                           "over_racing_kernel": det_ms / (ms / timed),
+                                           "parity_vs_oracle": det_parity,
+                                           "note": "vgx_tsdf_config.deterministic = 1: the single-thread visiting "
+                                                   "order resolved in parallel (sort by approximate-set slot, "
+                                                   "fixed-point sweeps, ordered per-voxel updates); wall clock incl. "
+                                                   "its host synchronisations"},
+                     "first_scan": {"ms": first_ms, "voxel_updates": first_updates,
+                                    "Mvoxel_updates_per_s": first_updates / first_ms / 1e3,
+                                    "algorithmic_GBs": (16.0 * n_pts + 24.0 * first_updates) / first_ms / 1e6},
+                     "cpu_baseline": {"Mpoints_per_s": n_pts * cpu_scans / cdt / 1e6,
+                                      "Mvoxel_updates_per_s": cu / cdt / 1e6, "cores": 1,
+                                      "kind": "port", "sample": f"{cpu_scans} scans, oracle/tsdf_oracle.c ("
+                                                                + orc.build_flags() + ")",
+                                      "all_cores": cpu_all}}
+        for o in (integ, layer, layer2):
+            o.destroy()
+    return out
+
+
+def finish_bench(capi, ctx, args, true_poses):
+    """finishSubmap() on the device for one 256^3 submap of the bench scene (HIP-event
+    timed): ESDF from TSDF, kVoxels and kIsosurfacePoints extraction."""
+    sm = capi.Submap.synth_city(ctx, 0, args.voxel_size, 16, args.block_min, args.block_dims,
+                                args.truncation, args.esdf_max, 10.0, true_poses[0], args.seed)
+    out = {}
+    for name, fn in (("generate_esdf_ms", lambda: sm.generate_esdf()),
+                     ("extract_voxel_points_ms", lambda: sm.extract_voxel_points(1.0, 0.3, True)),
+                     ("extract_isosurface_points_ms", lambda: sm.extract_isosurface_points(1.0))):
+        fn()
+        ctx.synchronize()
+        ctx.timer_start()
+        r = fn()
+        out[name] = ctx.timer_stop()
+        out[name.replace("_ms", "_result")] = int(r)
+    sm.destroy()
+    return out
+

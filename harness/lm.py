@@ -311,6 +311,7 @@ def _solve(problem, poses0, parameter_tolerance, function_tolerance, gradient_to
     it, reason = 0, "max_iterations"
     history = [cost]
     accepted_at = [0]          # instrumentation only: the iteration every entry of `history` was accepted at
+    accepted_s = [time.perf_counter() - t0]   # ... and the time since the solve began (instrumentation only)
     while it < max_iterations:
         it += 1
         if np.abs(gf).max() <= gradient_tolerance:
@@ -344,6 +345,7 @@ def _solve(problem, poses0, parameter_tolerance, function_tolerance, gradient_to
             x, cost, gf, band, V = cand, new_cost, new_gf, new_band, new_V
             history.append(cost)
             accepted_at.append(it)
+            accepted_s.append(time.perf_counter() - t0)
             radius = min(radius / max(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3), 1e16)
             decrease = 2.0
             if rel <= function_tolerance:
@@ -358,6 +360,7 @@ def _solve(problem, poses0, parameter_tolerance, function_tolerance, gradient_to
     return x, {"iterations": it, "evaluations": problem.evaluations, "termination": reason,
                "final_cost": cost, "initial_cost": history[0],
                "cost_history": list(zip(accepted_at, history)),
+               "seconds_history": accepted_s,
                "seconds": time.perf_counter() - t0,
                # instrumentation only: what the registration backend took -- kernels,
                # copy of the fused buffer, all-reduce -- and what this harness' own assembly + banded

@@ -37,6 +37,16 @@ VGX_API int vgx_synth_city_scan(vgx_ctx ctx, const double sensor_pose[4], int32_
                                 int32_t n_el, float el_span, float max_range, uint32_t seed,
                                 void* d_points_C);
 
+/* Latency model of the racing TSDF kernel (bench.py `tsdf.*.roofline`): ns per step of a chain of
+ * DEPENDENT device-scope 64-bit exchanges on pseudo-random words of a table of table_bytes (a power of two; an
+ * approximate hash set is 8 MiB), `waves` wavefronts of 64 such chains running side by side (1 = unloaded). */
+VGX_API int vgx_bench_atomic_roundtrip(vgx_ctx ctx, int64_t table_bytes, int32_t waves, int32_t chain,
+                                       float* ns_per_step);
+
+/* The longest chain of dependent approximate-set exchanges any ray of the last COUNTED racing scan walked
+ * (vgx_tsdf_integrate[_device] with n_updates != NULL resets the statistic before the scan). */
+VGX_API int vgx_tsdf_integrator_longest_walk(vgx_tsdf_integrator integrator, int64_t* steps);
+
 #ifdef __cplusplus
 }
 #endif

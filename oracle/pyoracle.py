@@ -308,6 +308,8 @@ def _tsdf_lib():
         L.orc_tsdf_integrate.restype = C.c_int64
         L.orc_tsdf_merged_integrate.argtypes = [C.c_void_p, c_f32p, c_f32p, c_u8p, C.c_int64, C.c_int]
         L.orc_tsdf_merged_integrate.restype = C.c_int64
+        L.orc_tsdf_integrate_sequence.argtypes = [C.c_void_p, C.c_int, c_f32p, c_f32p, C.c_int64, C.c_int]
+        L.orc_tsdf_integrate_sequence.restype = C.c_int64
         _tsdf_bound = True
     return L
 
@@ -373,6 +375,14 @@ class FastTsdfIntegrator:
         col = None if colors is None else np.ascontiguousarray(colors, np.uint8).reshape(-1, 4)
         return _tsdf_lib().orc_tsdf_integrate(self.h, _p(T, c_f32p), _p(pts, c_f32p),
                                               _p(col, c_u8p), pts.shape[0], int(freespace_points))
+
+    def integrate_sequence(self, poses, clouds, repeats=1):
+        """`repeats` passes over the scans (poses [k][7], clouds [k][n][3]) inside ONE foreign call (no
+        interpreter between scans: bench.py's all-cores timing); returns the number of voxel updates"""
+        P = _f32(poses).reshape(-1, 7)
+        pts = _f32(clouds).reshape(P.shape[0], -1, 3)
+        return _tsdf_lib().orc_tsdf_integrate_sequence(self.h, P.shape[0], _p(P, c_f32p), _p(pts, c_f32p),
+                                                       pts.shape[1], int(repeats))
 
     def integratePointCloudMerged(self, T_G_C, points_C, colors=None, freespace_points=False):
         """voxblox::MergedTsdfIntegrator::integratePointCloud on the same config / layer"""

@@ -403,6 +403,15 @@ int64_t orc_tsdf_integrate(orc_tsdf_integrator* I, const float T_G_C[7], const f
   return updates;
 }
 
+int64_t orc_tsdf_integrate_sequence(orc_tsdf_integrator* I, int n_scans, const float* poses,
+                                    const float* points_C, int64_t n, int repeats) {
+  int64_t updates = 0;
+  for (int r = 0; r < repeats; ++r)
+    for (int k = 0; k < n_scans; ++k)
+      updates += orc_tsdf_integrate(I, &poses[7 * k], &points_C[(size_t)3 * n * k], NULL, n, 0);
+  return updates;
+}
+
 /* ---- MergedTsdfIntegrator ---------------------------------------------------------------------- */
 typedef struct {
   uint64_t key;  /* bit 63: clearing ray; bits 62..0: end voxel, 21 bits per axis biased by 2^20 */

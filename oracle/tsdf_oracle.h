@@ -68,6 +68,12 @@ int64_t orc_tsdf_integrate(orc_tsdf_integrator* I, const float T_G_C[7],
                            const float* points_C, const uint8_t* rgba, int64_t n,
                            int freespace_points);
 
+/* bench.py's cpu_baseline leg: `repeats` passes over `n_scans` scans (poses [n_scans][7], clouds of n points
+ * each, concatenated) in one call, so that a timing loop over many host threads never goes back to the
+ * interpreter between scans.  Returns the total number of voxel updates. */
+int64_t orc_tsdf_integrate_sequence(orc_tsdf_integrator* I, int n_scans, const float* poses,
+                                    const float* points_C, int64_t n, int repeats);
+
 /* voxblox::MergedTsdfIntegrator::integratePointCloud [recalled, integrator/tsdf_integrator.cc]:
  * bundleRays groups the valid points by the voxel their end point falls in (clearing rays in a map of
  * their own), integrateVoxel merges a group into one weighted-mean point (running mean in visiting

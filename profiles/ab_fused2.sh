@@ -20,7 +20,7 @@ for round in ${ROUNDS:-1 2}; do
     [ -f $REPO/voxgraph_amd/lib/$lib ] || continue
     for v in ${VARIANTS:-0 421 422 522 622 612 812}; do
       printf "round %s %-26s VGX_FUSED_KERNEL=%-4s " $round $lib $v
-      VGX_LIB=$REPO/voxgraph_amd/lib/$lib VGX_FUSED_KERNEL=$v python $REPO/bench.py $ARGS 2>$OUT/ab_fused2.err | python -c "$pick" || tail -3 $OUT/ab_fused2.err
+      VGX_LIB=$REPO/voxgraph_amd/lib/$lib VGX_FUSED_KERNEL=$v python $REPO/bench.py --full-line $ARGS 2>$OUT/ab_fused2.err | python -c "$pick" || tail -3 $OUT/ab_fused2.err
     done
   done
 done

@@ -25,6 +25,6 @@ for round in 1 2; do
   for lib in ${LIBS:-libvoxgraph_amd.so libvoxgraph_amd_quad.so libvoxgraph_amd_sub.so}; do
     [ -f $REPO/voxgraph_amd/lib/$lib ] || continue
     printf "round %s %-26s " $round $lib
-    VGX_LIB=$REPO/voxgraph_amd/lib/$lib python $REPO/bench.py $ARGS 2>$OUT/ab_layout.err | python -c "$pick" || tail -3 $OUT/ab_layout.err
+    VGX_LIB=$REPO/voxgraph_amd/lib/$lib python $REPO/bench.py --full-line $ARGS 2>$OUT/ab_layout.err | python -c "$pick" || tail -3 $OUT/ab_layout.err
   done
 done

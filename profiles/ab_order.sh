@@ -16,7 +16,7 @@ print("fused config3 %.3f ms | full overlap %.3f ms | config5 evaluation %.3f ms
 for round in 1 2; do
   for v in 0 1; do
     printf "round %s VGX_FUSED_TILE_ORDER=%s " $round $v
-    VGX_FUSED_TILE_ORDER=$v timeout 300 python $REPO/bench.py $ARGS 2>$OUT/ab_order.err | python -c "$pick" || tail -3 $OUT/ab_order.err
+    VGX_FUSED_TILE_ORDER=$v timeout 300 python $REPO/bench.py --full-line $ARGS 2>$OUT/ab_order.err | python -c "$pick" || tail -3 $OUT/ab_order.err
   done
 done
 cd /tmp

@@ -16,7 +16,7 @@ print("points kernel config3 %.3f ms/pass (%.1f G evals/s) | full overlap %.3f m
 for round in 1 2; do
   for v in 0 1; do for k in 0 1; do
     printf "round %s VGX_POINTS_TILE_ORDER=%s VGX_POINTS_CULL=%s " $round $v $k
-    VGX_POINTS_CULL=$k VGX_POINTS_TILE_ORDER=$v timeout 300 python $REPO/bench.py $ARGS 2>$OUT/ab_porder.err | python -c "$pick" || tail -3 $OUT/ab_porder.err
+    VGX_POINTS_CULL=$k VGX_POINTS_TILE_ORDER=$v timeout 300 python $REPO/bench.py --full-line $ARGS 2>$OUT/ab_porder.err | python -c "$pick" || tail -3 $OUT/ab_porder.err
   done; done
 done
 cd /tmp

@@ -51,6 +51,11 @@ def read_bytes(c):
 
 
 def bench_line(name):
+    """the FULL result object of a bench.py run: its --detail file (round 4 on: stdout carries only the compact
+    summary line), else the stdout line of the earlier rounds"""
+    pd = os.path.join(ROOT, "gpurun_out", name.replace("_bench.json", "_detail.json"))
+    if name.endswith("_bench.json") and os.path.exists(pd):
+        return json.load(open(pd))
     p = os.path.join(ROOT, "gpurun_out", name)
     if os.path.exists(p):
         for line in open(p):
@@ -76,7 +81,7 @@ def by_grid(trace, kernel):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--round", default="03")
+    ap.add_argument("--round", default="04")
     a = ap.parse_args()
     tag = f"r{int(a.round):02d}"
     N_CAL = 2                                            # bench.py --calibrate: two far-pose launches

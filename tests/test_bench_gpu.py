@@ -16,18 +16,63 @@ SMALL = ["--grid", "4", "3", "--block-dims", "4", "4", "4", "--block-min", "-2",
 pytestmark = pytest.mark.gpu
 
 
-def _line(out):
-    lines = [l for l in out.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out[-2000:]
-    return json.loads(lines[0])
+LINE_LIMIT = 10_000      # the driver failed to parse a 22.4 KB line; r02's 14.7 KB parsed
+
+
+def _run(cmd, tmp, env=None, timeout=900):
+    """runs bench.py; returns (full result object from --detail, the stdout line parsed, the raw line).
+    stdout must be EXACTLY one line: the compact JSON summary (everything else goes to stderr / the file)."""
+    detail = os.path.join(tmp, "detail.json")
+    r = subprocess.run(cmd + ["--detail", detail], capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]
+    assert len(lines[0]) < LINE_LIMIT, len(lines[0])
+    line = json.loads(lines[0])
+    full = json.load(open(detail))
+    # the line is a cut of the full object: same headline, same contract keys first
+    assert list(line)[:12] == ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                               "scaling", "vs_baseline", "dtype", "data"]
+    assert abs(line["value"] - full["value"]) <= 1e-5 * full["value"]
+    return full, line, lines[0]
 
 
 @pytest.fixture(scope="module")
-def single():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--cpu-seconds", "1"] + SMALL,
-                       capture_output=True, text=True, timeout=600, cwd=ROOT)
-    assert r.returncode == 0, r.stderr[-2000:]
-    return _line(r.stdout)
+def single_run(tmp_path_factory):
+    return _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--cpu-seconds", "1"] + SMALL,
+                str(tmp_path_factory.mktemp("bench1")), timeout=600)
+
+
+@pytest.fixture(scope="module")
+def single(single_run):
+    return single_run[0]
+
+
+def test_stdout_line_is_small_and_carries_the_contract(single_run):
+    """what the driver parses: ONE line, < 10 KB, headline keys first, roofline / cpu_baseline / parity inside"""
+    full, line, raw = single_run
+    assert len(raw) < LINE_LIMIT
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1 and line["dtype"] == "f32"
+    assert "workload" in line["config"] and "model" not in line["config"]
+    rf = line["roofline"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic", "hbm_frac")) <= set(rf)
+    assert rf["bound"] == "hbm" and 0 < rf["frac"] <= 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
+    cb = line["cpu_baseline"]
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(cb) and cb["value"] > 0 and cb["kind"] == "port"
+    assert line["parity"]["exact"] is True and line["parity"]["checked"] > 0
+    # numbers only below the contract keys: no prose blocks (notes live in the detail file)
+    def strings(o, path=""):
+        if isinstance(o, dict):
+            for k, v in o.items():
+                yield from strings(v, path + "/" + k)
+        elif isinstance(o, str):
+            yield path, o
+    long_strings = [(p_, v) for p_, v in strings(line) if len(v) > 180]
+    assert not long_strings, long_strings
+    assert line["detail"] and "tsdf" not in line            # SMALL runs --no-tsdf
 
 
 def test_single_gpu_line_has_the_contract_fields(single):
@@ -60,6 +105,7 @@ def test_single_gpu_line_has_the_contract_fields(single):
     # (exact) and the fused blocks against the oracle (1e-6)
     par = d["parity"]
     assert par["checked"] > 0 and par["exact"] and par["max_rel"] == 0.0 and par["fused_blocks_within_1e-6"], par
+    assert c5_headline(d["config5"])
     assert len(par["per_workload"]) == 3
     # every "*frac*" is an HBM fraction <= 1 or says what else it is
     assert d["roofline"]["contract_88B_frac"] > 0 and "not an HBM fraction" in d["roofline"]["contract_88B_frac_note"]
@@ -83,13 +129,17 @@ def test_single_gpu_line_has_the_contract_fields(single):
     assert c2["submaps"] == 10 and c2["dropped_updates"] == 0 and c2["solves"] == 9
 
 
-def test_two_rank_path_dry_run_on_one_gpu(single):
+def c5_headline(c5):
+    """config 5's headline is the time to within 1e-3 of the final cost, never above solve_ms"""
+    return 0 < c5["solve_ms_to_within_1e-3_of_final_cost"] <= c5["solve_ms"] * 1.001
+
+
+def test_two_rank_path_dry_run_on_one_gpu(single, tmp_path):
     env = dict(os.environ, VGX_BENCH_DRYRUN="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
-    assert r.returncode == 0, r.stderr[-3000:]
-    d = _line(r.stdout)
+    d, line, _ = _run(cmd, str(tmp_path), env=env)
+    assert line["n_gpus"] == 2 and line["cpu_baseline"] is None and line["rccl_ranks"] == 0     # dry run: gloo
     assert d["n_gpus"] == 2 and "DRY RUN" in d["data"] and d["cpu_baseline"] is None
     assert d["fused"]["allreduce_bytes"] > 0
     # the sharded solve is the single-rank solve: same evaluations, same answer
@@ -110,17 +160,39 @@ def test_two_rank_path_dry_run_on_one_gpu(single):
     assert abs(d["config5"]["position_rmse_m_aligned_after"] - single["config5"]["position_rmse_m_aligned_after"]) < 1e-7
 
 
-def test_inprocess_flag_dry_run_on_one_gpu(single):
+def test_inprocess_flag_dry_run_on_one_gpu(single, tmp_path):
     """`bench.py --gpus 2 --inprocess`: ONE process, two contexts (here both on the one GPU), the headline loop
     on context 0 and vgx_reg_multi_evaluate_fused over both in `multi_context` -- same line, same keys"""
     env = dict(os.environ, VGX_BENCH_DRYRUN="gloo")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--inprocess", "--no-cpu-baseline",
-                        "--no-config5", "--no-config2", "--no-solve", "--no-shipped"] + SMALL,
-                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
-    assert r.returncode == 0, r.stderr[-2000:]
-    d = _line(r.stdout)
+    d, line, _ = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--inprocess", "--no-cpu-baseline",
+                       "--no-config5", "--no-config2", "--no-solve", "--no-shipped"] + SMALL, str(tmp_path), env=env, timeout=600)
     assert d["n_gpus"] == 1 and d["inprocess_gpus"] == 2
     mc = d["multi_context"]
     assert mc["contexts"] == 2 and mc["device_ids"] == [0, 0] and sum(mc["constraints_per_context"]) == d["config"]["constraints"]
     assert mc["max_rel_diff_vs_single_batch"] < 1e-9
     assert abs(mc["cost"] - single["fused"]["cost"]) <= 1e-9 * single["fused"]["cost"]
+
+
+def test_tsdf_block_has_a_latency_roofline_and_a_sane_all_cores_row():
+    """(a) the all-cores CPU row is total points / wall clock behind a barrier and can never
+    exceed cores x the one-core rate; (b) the racing kernel's roofline is the latency model (longest chain of
+    dependent exchanges x measured round trip), with the HBM figure beside it"""
+    import torch
+    from harness.bench_tsdf import tsdf_bench
+    from voxgraph_amd import capi
+    ctx = capi.Context(0)
+    try:
+        out = tsdf_bench(capi, ctx, torch, scans=5, cpu_scans=2)
+    finally:
+        ctx.close()
+    assert set(out) == {"rgbd_640x480_0.05m", "lidar_64x1024_0.20m_voxgraph_yaml"}
+    for name, t in out.items():
+        rf = t["roofline"]
+        assert rf["bound"] == "latency" and rf["unit"] == "ms" and rf["longest_walk_steps"] >= 1, (name, rf)
+        assert 20.0 < rf["roundtrip_ns_unloaded"] < 20000.0, rf
+        assert abs(rf["frac"] - rf["peak"] / rf["achieved"]) < 1e-9 and 0 < rf["frac"] <= 1.0, rf   # a LOWER bound on time
+        assert 0 < rf["hbm_frac"] < 1.0
+        ac = t["cpu_baseline"]["all_cores"]
+        assert ac["at_most_cores_x_one_core"], ac
+        assert ac["scans_per_replica"] >= 50 and ac["wall_s"] >= ac["slowest_replica_s"] > 0
+        assert t["reproducible_mode"]["parity_vs_oracle"]["bit_identical"]

@@ -107,6 +107,8 @@ SIGNATURES = {
                                         C.POINTER(vp)]),
     "vgx_synth_city_scan": (C.c_int, [vp, f64p, C.c_int32, C.c_int32, C.c_float, C.c_float,
                                       C.c_uint32, vp]),
+    "vgx_bench_atomic_roundtrip": (C.c_int, [vp, C.c_int64, C.c_int32, C.c_int32, f32p]),
+    "vgx_tsdf_integrator_longest_walk": (C.c_int, [vp, i64p]),
     "vgx_reg_config_default": (None, [C.POINTER(RegConfig)]),
     "vgx_reg_create": (C.c_int, [vp, vp, vp, C.POINTER(RegConfig), C.POINTER(vp)]),
     "vgx_reg_destroy": (C.c_int, [vp]),
@@ -575,6 +577,13 @@ class RegistrationMulti:
             self.h = None
 
 
+def atomic_roundtrip_ns(ctx, table_bytes=8 << 20, waves=1, chain=2000):
+    """bench tooling (vgx_bench_atomic_roundtrip): ns per step of a chain of dependent device-scope exchanges"""
+    out = C.c_float()
+    ctx.check(ctx.lib.vgx_bench_atomic_roundtrip(ctx.h, table_bytes, waves, chain, C.byref(out)))
+    return out.value
+
+
 def synth_city_scan(ctx, sensor_pose, n_az, n_el, el_span, max_range, seed, d_points):
     """Benchmark tooling: sphere-traced LiDAR scan of the analytic city (sensor frame)."""
     ctx.check(ctx.lib.vgx_synth_city_scan(ctx.h, _ptr(_f64(sensor_pose), f64p), n_az, n_el,
@@ -741,6 +750,12 @@ class FastTsdfIntegrator:
         self.ctx.check(self.ctx.lib.vgx_tsdf_integrate_device(
             self.h, _ptr(T, f32p), vp(d_points), vp(d_rgba) if d_rgba else None, n,
             int(freespace_points), C.byref(out) if count else None))
+        return out.value
+
+    def longest_walk(self):
+        """bench tooling: longest chain of dependent approximate-set exchanges of the last counted racing scan"""
+        out = C.c_int64()
+        self.ctx.check(self.ctx.lib.vgx_tsdf_integrator_longest_walk(self.h, C.byref(out)))
         return out.value
 
     def destroy(self):

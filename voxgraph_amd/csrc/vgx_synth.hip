@@ -110,9 +110,59 @@ __global__ __launch_bounds__(256) void synth_city_scan_kernel(float sx, float sy
   out[3 * i + 2] = dz * hit;
 }
 
+// vgx_bench_atomic_roundtrip: every lane runs `chain` DEPENDENT device-scope exchanges on pseudo-random words of
+// a table the size of an approximate hash set -- the memory operation a ray of tsdf_integrate_kernel
+// issues once per voxel step and has to wait for before it knows whether to go on.
+__global__ __launch_bounds__(256) void atomic_chain_kernel(unsigned long long* __restrict__ table, unsigned mask,
+                                                          int chain, unsigned long long* __restrict__ sink) {
+  unsigned idx = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u + 12345u;
+  unsigned long long acc = 0;
+  for (int k = 0; k < chain; ++k) {
+    const unsigned long long old = atomicExch(&table[idx & mask], (unsigned long long)idx + 1ull);
+    acc += old;
+    idx = (idx * 1664525u + 1013904223u) ^ (unsigned)(old & 1ull);  // the next address needs this result
+  }
+  if (acc == 0x123456789abcdefull) *sink = acc;  // keeps the chain alive
+}
+
 }  // namespace vgx
 
 using namespace vgx;
+
+extern "C" int vgx_bench_atomic_roundtrip(vgx_ctx ctx, int64_t table_bytes, int32_t waves, int32_t chain,
+                                          float* ns_per_step) {
+  if (!ctx || !ns_per_step || table_bytes < 8 || (table_bytes & (table_bytes - 1)) || waves <= 0 || chain <= 0)
+    return VGX_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  VGX_HIP(ctx, hipSetDevice(ctx->device));
+  unsigned long long* table = nullptr;
+  VGX_HIP(ctx, hipMalloc(&table, (size_t)table_bytes + 8));
+  hipEvent_t e[3];
+  for (auto& ev : e) (void)hipEventCreate(&ev);
+  int rc = VGX_OK;
+  const unsigned mask = (unsigned)(table_bytes / 8 - 1);
+  const dim3 grid((unsigned)((waves * 64 + 255) / 256)), block(waves * 64 < 256 ? waves * 64 : 256);
+  unsigned long long* sink = table + table_bytes / 8;
+  float ms1 = 0.0f, ms2 = 0.0f;
+  if (hipMemsetAsync(table, 0, (size_t)table_bytes + 8, ctx->stream) != hipSuccess) rc = VGX_ERR_HIP;
+  if (rc == VGX_OK) {
+    hipLaunchKernelGGL(atomic_chain_kernel, grid, block, 0, ctx->stream, table, mask, chain, sink);  // warm
+    (void)hipEventRecord(e[0], ctx->stream);
+    hipLaunchKernelGGL(atomic_chain_kernel, grid, block, 0, ctx->stream, table, mask, chain, sink);
+    (void)hipEventRecord(e[1], ctx->stream);
+    hipLaunchKernelGGL(atomic_chain_kernel, grid, block, 0, ctx->stream, table, mask, 3 * chain, sink);
+    (void)hipEventRecord(e[2], ctx->stream);
+    if (hipEventSynchronize(e[2]) != hipSuccess || hipEventElapsedTime(&ms1, e[0], e[1]) != hipSuccess ||
+        hipEventElapsedTime(&ms2, e[1], e[2]) != hipSuccess)
+      rc = VGX_ERR_HIP;
+  }
+  for (auto& ev : e) (void)hipEventDestroy(ev);
+  (void)hipFree(table);
+  if (rc != VGX_OK) return set_error(ctx, rc, "vgx_bench_atomic_roundtrip: HIP failure");
+  // two launches of `chain` and 3 x `chain` steps: the difference cancels the launch itself
+  *ns_per_step = (ms2 - ms1) * 1e6f / (2.0f * (float)chain);
+  return VGX_OK;
+}
 
 extern "C" int vgx_synth_city_scan(vgx_ctx ctx, const double pose[4], int32_t n_az, int32_t n_el,
                                    float el_span, float max_range, uint32_t seed, void* d_points) {

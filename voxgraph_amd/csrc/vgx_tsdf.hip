@@ -28,6 +28,7 @@
 #include <rocprim/rocprim.hpp>  // device radix sort (MergedTsdfIntegrator's bundleRays)
 
 #include "vgx_tsdf_internal.h"
+#include "voxgraph_amd_bench.h"  // vgx_tsdf_integrator_longest_walk
 
 #pragma clang fp contract(off)
 
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(TsdfLayerDev L, Tsd
                                                             long long n, int freespace_points) {
   const vgx_tsdf_config& c = I.cfg;
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned long long my_updates = 0, my_dropped = 0;
+  unsigned long long my_updates = 0, my_dropped = 0, my_walk = 0;
   if (i < n) {
     float px = points_C[3 * i], py = points_C[3 * i + 1], pz = points_C[3 * i + 2];
     uint32_t color = rgba ? rgba[i] : 0u;
@@ -312,6 +313,7 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(TsdfLayerDev L, Tsd
             unsigned int h = (unsigned int)vx + (unsigned int)vy * 17191u + (unsigned int)vz * 295530481u;
             unsigned long long v = (unsigned long long)h + I.observed_offset;
             unsigned long long seen = atomicExch(&I.observed_set[v & kSetMask], v);
+            ++my_walk;  // dependent exchanges on this ray: the scan's critical path is the longest such chain
             if (PIPELINED) pipeline_beat(L, c, color, s1, s2, s3);
             if (seen == v) ++collisions; else collisions = 0;
             if (collisions > c.max_consecutive_ray_collisions) break;
@@ -346,10 +348,13 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(TsdfLayerDev L, Tsd
   for (int off = 32; off >= 1; off >>= 1) {
     my_updates += __shfl_xor(my_updates, off, 64);
     my_dropped += __shfl_xor(my_dropped, off, 64);
+    const unsigned long long other = __shfl_xor(my_walk, off, 64);
+    my_walk = other > my_walk ? other : my_walk;
   }
   if ((threadIdx.x & 63) == 0) {
     if (my_updates) atomicAdd(I.n_updates, my_updates);
     if (my_dropped) atomicAdd(L.dropped, my_dropped);
+    if (my_walk) atomicMax(I.n_updates + 1, my_walk);  // vgx_tsdf_integrator_longest_walk (bench header)
   }
 }
 
@@ -1071,12 +1076,12 @@ int vgx_tsdf_integrator_create(vgx_ctx ctx, const vgx_tsdf_config* cfg, vgx_tsdf
   const size_t set_bytes = ((size_t)1 << kSetBits) * 8;
   bool ok = hipMalloc(&I->dev.start_set, set_bytes) == hipSuccess &&
             hipMalloc(&I->dev.observed_set, set_bytes) == hipSuccess &&
-            hipMalloc(&I->dev.n_updates, 8) == hipSuccess;
+            hipMalloc(&I->dev.n_updates, 16) == hipSuccess;
   const unsigned long long poison = ~0ull;
   if (ok)
     ok = hipMemset(I->dev.start_set, 0, set_bytes) == hipSuccess &&
          hipMemset(I->dev.observed_set, 0, set_bytes) == hipSuccess &&
-         hipMemset(I->dev.n_updates, 0, 8) == hipSuccess &&
+         hipMemset(I->dev.n_updates, 0, 16) == hipSuccess &&
          // the zero hash would look present in every zeroed slot (ApproxHashSet ctor)
          hipMemcpy(I->dev.start_set, &poison, 8, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(I->dev.observed_set, &poison, 8, hipMemcpyHostToDevice) == hipSuccess;
@@ -1134,7 +1139,7 @@ static int integrate_locked(vgx_tsdf_integrator I, const float T[7], const void*
     if (rc == VGX_OK) rc = reset_set(ctx, I->dev.observed_set, &I->dev.observed_offset);
     if (rc != VGX_OK) return rc;
   }
-  if (n_updates) VGX_HIP(ctx, hipMemsetAsync(I->dev.n_updates, 0, 8, ctx->stream));
+  if (n_updates) VGX_HIP(ctx, hipMemsetAsync(I->dev.n_updates, 0, 16, ctx->stream));
   if (n > 0) {
     // Every voxel a ray of this scan can touch lies within max_ray_length + truncation of the
     // sensor origin (a longer return is a clearing ray cut at max_ray_length, RayCaster [recalled]);
@@ -1320,6 +1325,21 @@ int vgx_tsdf_integrate_device(vgx_tsdf_integrator I, const float T[7], const voi
   if (!I || !T || n < 0 || (n > 0 && !d_points)) return VGX_ERR_INVALID;
   std::lock_guard<std::mutex> own(I->mu);
   return integrate_locked(I, T, d_points, d_rgba, n, freespace, n_updates);
+}
+
+// bench header: the longest chain of dependent approximate-set exchanges any ray of the last COUNTED racing
+// scan walked (n_updates != NULL resets the statistic before the scan)
+int vgx_tsdf_integrator_longest_walk(vgx_tsdf_integrator I, int64_t* steps) {
+  if (!I || !steps) return VGX_ERR_INVALID;
+  std::lock_guard<std::mutex> own(I->mu);
+  vgx_ctx ctx = I->ctx;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  VGX_HIP(ctx, hipSetDevice(ctx->device));
+  unsigned long long u = 0;
+  VGX_HIP(ctx, hipMemcpyAsync(&u, I->dev.n_updates + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
+  VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *steps = (int64_t)u;
+  return VGX_OK;
 }
 
 int vgx_tsdf_integrate(vgx_tsdf_integrator I, const float T[7], const float* points, const uint8_t* rgba,
