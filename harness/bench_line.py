@@ -37,7 +37,8 @@ def _tsdf(t):
     return {"ms_per_scan": t.get("ms_per_scan"), "Mpoints_per_s": t.get("Mpoints_per_s"),
             "Mvoxel_updates_per_s": t.get("Mvoxel_updates_per_s"), "dropped_updates": t.get("dropped_updates"),
             "roofline": _pick(rf, ("bound", "kernel_ms", "longest_walk_steps", "roundtrip_ns_unloaded",
-                                   "roundtrip_ns_loaded", "achieved", "peak", "unit", "frac", "hbm_frac")),
+                                   "latency_chain_ms", "atomic_peak_Gops", "atomic_achieved_Gops",
+                                   "atomic_throughput_ms", "achieved", "peak", "unit", "frac", "hbm_frac")),
             "merged_ms_per_scan": mg.get("ms_per_scan"), "merged_launches_per_scan": mg.get("launches_per_scan"),
             "reproducible_ms_per_scan": rm.get("ms_per_scan"),
             "reproducible_bit_identical_to_oracle": (rm.get("parity_vs_oracle") or {}).get("bit_identical"),

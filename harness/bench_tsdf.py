@@ -91,13 +91,25 @@ def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=8):
             u_ = integ.integrate_device(poses[k], dev[k].data_ptr(), None, n_pts, count=True)
             updates += u_ if k >= 1 else 0
             if k >= 1:
-                walks.append(integ.longest_walk())     # dependent exchanges on this scan's longest ray
+                # (longest chain of dependent exchanges, exchanges of all rays, colour blends) of this scan
+                walks.append(integ.walk_stats() + (u_,))
         n_blocks, dropped = layer.stats()
-        # the operation a ray waits for once per voxel step, by itself: a chain of dependent device-scope
-        # exchanges on an 8 MiB table (an approximate hash set), one wavefront alone and as many wavefronts
-        # as this scan launches side by side
+        # The two ceilings of a kernel made of device-scope atomics on scattered 8-byte words (DESIGN.md 3 "TSDF
+        # latency model"), measured on this GPU with the operation by itself -- a chain of dependent exchanges on
+        # an 8 MiB table (an approximate hash set):
+        #   * one wavefront alone: the round trip a ray waits for once per voxel step (it learns whether to take
+        #     step k + 1 only when the exchange of step k has come back),
+        #   * 8192 wavefronts side by side: what the memory system sustains, in operations per second.
         rt_unloaded_ns = capi.atomic_roundtrip_ns(ctx, 8 << 20, 1, 2000)
-        rt_loaded_ns = capi.atomic_roundtrip_ns(ctx, 8 << 20, max(n_pts // 64, 1), 200)
+        sat_waves = 8192
+        rt_saturated_ns = capi.atomic_roundtrip_ns(ctx, 8 << 20, sat_waves, 100)
+        atomic_peak_gops = sat_waves * 64 / rt_saturated_ns
+        longest = float(np.mean([w_[0] for w_ in walks]))
+        # memory operations of a scan: one exchange per voxel step + per update a load and a CAS of {distance,
+        # weight} + a load and a CAS of the colour where it blends
+        ops_scan = float(np.mean([w_[1] + 2 * w_[3] + 2 * w_[2] for w_ in walks]))
+        chain_ms = longest * rt_unloaded_ns * 1e-6
+        throughput_ms = ops_scan / atomic_peak_gops * 1e-6
         # heaviest case: the first scan into an empty layer with a fresh integrator (no
         # previously observed voxels: every ray runs to its early-out or to the sensor)
         layer3 = new_layer()
@@ -227,21 +239,24 @@ def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=8):
                      "voxel_updates_per_scan": updates / timed, "blocks": n_blocks,
                      "dropped_updates": dropped, "layer_enlargements_in_timed_region": grew,
                      "algorithmic_GBs": alg_bytes_scan * timed / ms / 1e6,
-                     # The racing kernel is LATENCY bound: a ray knows whether to take step k + 1 only when the
-                     # exchange of step k has come back, so a scan cannot finish before its longest ray's
-                     # chain of dependent exchanges has (DESIGN.md 3 "TSDF latency model").  bound = longest
-                     # walk (counted by the kernel) x the measured round trip of one such exchange on an idle
-                     # GPU; `frac` = that lower bound / the kernel's measured time.  The HBM figures
-                     # (SURVEY 8d's 16 B / point + 24 B / update) stay beside it: a scan is 1-8 MB, a
-                     # microsecond of HBM time, which is why hbm_frac reads 0.005.
-                     "roofline": {"bound": "latency", "kernel": "tsdf_integrate_kernel<true>",
+                     # The racing kernel is made of scattered device-scope atomics; a scan is 1-8 MB, a microsecond of
+                     # HBM time (hbm_frac reads 0.005: the wrong yardstick).  Its two ceilings, measured on this
+                     # GPU: the LATENCY chain of the longest ray (dependent exchanges x idle round trip) and the
+                     # THROUGHPUT of such operations (all of the scan's / what the memory system sustains).
+                     # `peak` = the larger of the two lower bounds on the kernel's time, `frac` = peak / measured.
+                     "roofline": {"bound": "latency" if chain_ms >= throughput_ms else "atomic-throughput",
+                                  "kernel": "tsdf_integrate_kernel<true>",
                                   "kernel_ms": kernel_ms,
                                   "kernel_ms_how": "HIP events around each scan's launch, stream drained before",
-                                  "longest_walk_steps": float(np.mean(walks)), "longest_walk_steps_max": int(max(walks)),
-                                  "roundtrip_ns_unloaded": rt_unloaded_ns, "roundtrip_ns_loaded": rt_loaded_ns,
-                                  "achieved": kernel_ms, "peak": float(np.mean(walks)) * rt_unloaded_ns * 1e-6, "unit": "ms",
-                                  "frac": float(np.mean(walks)) * rt_unloaded_ns * 1e-6 / kernel_ms,
-                                  "frac_at_loaded_roundtrip": float(np.mean(walks)) * rt_loaded_ns * 1e-6 / kernel_ms,
+                                  "longest_walk_steps": longest, "longest_walk_steps_max": int(max(w_[0] for w_ in walks)),
+                                  "roundtrip_ns_unloaded": rt_unloaded_ns, "latency_chain_ms": chain_ms,
+                                  "memory_operations_per_scan": ops_scan,
+                                  "atomic_peak_Gops": atomic_peak_gops, "atomic_peak_how":
+                                      f"{sat_waves} wavefronts x 64 chains of dependent exchanges on an 8 MiB table",
+                                  "atomic_achieved_Gops": ops_scan / kernel_ms * 1e-6,
+                                  "atomic_throughput_ms": throughput_ms,
+                                  "achieved": kernel_ms, "peak": max(chain_ms, throughput_ms), "unit": "ms",
+                                  "frac": max(chain_ms, throughput_ms) / kernel_ms,
                                   "traffic": None,
                                   "bytes_per_launch": alg_bytes_scan,
                                   "hbm_achieved_GBs": alg_bytes_scan / kernel_ms / 1e6, "hbm_peak_GBs": HBM_PEAK_GBS,

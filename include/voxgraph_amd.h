@@ -383,8 +383,10 @@ typedef struct vgx_tsdf_integrator_s* vgx_tsdf_integrator; /* voxblox::FastTsdfI
 
 /* voxblox::TsdfIntegratorBase::Config (voxblox defaults; voxgraph_mapper.yaml:21-28
  * overrides truncation 0.60, max ray 16 m, const weight, drop-off, sparsity
- * compensation 20).  integrator_threads / integration_order_mode /
- * max_integration_time_s have no meaning on the GPU: every ray is its own thread. */
+ * compensation 20).  integrator_threads / max_integration_time_s have no meaning on the GPU: every ray is
+ * its own thread; integration_order_mode (voxgraph_mapper.yaml:29) is `integration_order` below. */
+#define VGX_TSDF_ORDER_MIXED 0  /* integration_order_mode "mixed" (voxblox's and voxgraph's default) */
+#define VGX_TSDF_ORDER_SORTED 1 /* "sorted": points visited by ascending squared norm of point_C    */
 typedef struct vgx_tsdf_config {
   float default_truncation_distance;    /* 0.1   */
   float max_weight;                     /* 10000 */
@@ -408,6 +410,13 @@ typedef struct vgx_tsdf_config {
    * run (and the layer oracle/tsdf_oracle.c computes).  Slower (several sorts and a fixed-point
    * iteration per scan instead of one kernel); meant for regression tests and reproducible maps. */
   int32_t deterministic;                /* 0     */
+  /* voxblox's integration_order_mode: VGX_TSDF_ORDER_MIXED (1024-point groups visited round-robin) or
+   * VGX_TSDF_ORDER_SORTED (ascending f32 squaredNorm() of the sensor-frame point; voxblox sorts with the
+   * unstable std::sort, so the order of points at EQUAL range is unspecified there: here, and in the
+   * oracle, equal ranges are visited by ascending point index).  The visiting order is what the
+   * reproducible mode reproduces and what the merged integrator merges a group's points in; the racing
+   * fast integrator (deterministic = 0) has no visiting order and ignores it. */
+  int32_t integration_order;            /* 0     */
 } vgx_tsdf_config;
 VGX_API void vgx_tsdf_config_default(vgx_tsdf_config* cfg);
 

@@ -43,9 +43,10 @@ VGX_API int vgx_synth_city_scan(vgx_ctx ctx, const double sensor_pose[4], int32_
 VGX_API int vgx_bench_atomic_roundtrip(vgx_ctx ctx, int64_t table_bytes, int32_t waves, int32_t chain,
                                        float* ns_per_step);
 
-/* The longest chain of dependent approximate-set exchanges any ray of the last COUNTED racing scan walked
- * (vgx_tsdf_integrate[_device] with n_updates != NULL resets the statistic before the scan). */
-VGX_API int vgx_tsdf_integrator_longest_walk(vgx_tsdf_integrator integrator, int64_t* steps);
+/* What the rays of the last COUNTED racing scan did (vgx_tsdf_integrate[_device] with n_updates != NULL resets
+ * the statistics before the scan): stats[0] = the longest chain of dependent approximate-set exchanges any ray
+ * walked, stats[1] = exchanges of all rays together, stats[2] = voxel updates that also blended a colour. */
+VGX_API int vgx_tsdf_integrator_walk_stats(vgx_tsdf_integrator integrator, int64_t stats[3]);
 
 #ifdef __cplusplus
 }

@@ -282,7 +282,7 @@ class TsdfConfig(C.Structure):
                 ("sparsity_compensation_factor", C.c_float),
                 ("start_voxel_subsampling_factor", C.c_float),
                 ("max_consecutive_ray_collisions", C.c_int),
-                ("clear_checks_every_n_frames", C.c_int), ("integration_order_mixed", C.c_int),
+                ("clear_checks_every_n_frames", C.c_int), ("integration_order", C.c_int),
                 ("enable_anti_grazing", C.c_int)]
 
 

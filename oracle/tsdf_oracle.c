@@ -27,7 +27,7 @@ void orc_tsdf_config_default(orc_tsdf_config* c) {
   c->start_voxel_subsampling_factor = 2.0f;
   c->max_consecutive_ray_collisions = 2;
   c->clear_checks_every_n_frames = 1;
-  c->integration_order_mixed = 1;
+  c->integration_order = 1;
   c->enable_anti_grazing = 0;
 }
 
@@ -260,6 +260,51 @@ static void update_voxel(orc_tsdf_integrator* I, const float origin[3], const fl
   *v_weight = fminf(c->max_weight, new_weight);
 }
 
+/* ---- ThreadSafeIndex [recalled, voxblox utils/ thread-safe index]: the order points are visited in ------ */
+typedef struct {
+  uint32_t key; /* bit pattern of the f32 squared norm (non-negative: orders like the float; NaN last) */
+  int64_t idx;
+} sorted_entry;
+
+static int sorted_cmp(const void* a, const void* b) {
+  const sorted_entry* x = (const sorted_entry*)a;
+  const sorted_entry* y = (const sorted_entry*)b;
+  if (x->key != y->key) return x->key < y->key ? -1 : 1;
+  return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0); /* the tie rule: ascending point index */
+}
+
+/* order[seq] = index of the point visited seq-th; caller frees.  mode 1: MixedThreadSafeIndex (1024-point
+ * groups visited round-robin, the tail in order); mode 2: SortedThreadSafeIndex (std::sort by
+ * point_C.squaredNorm(), an f32 Eigen reduction (x*x + y*y) + z*z, ascending); else input order. */
+static int64_t* visiting_order(int mode, const float* points_C, int64_t n) {
+  int64_t* order = (int64_t*)malloc((size_t)(n > 0 ? n : 1) * sizeof(int64_t));
+  if (mode == 2) {
+    sorted_entry* e = (sorted_entry*)malloc((size_t)(n > 0 ? n : 1) * sizeof(sorted_entry));
+    for (int64_t i = 0; i < n; ++i) {
+      const float* p = &points_C[3 * i];
+      const float sq = (p[0] * p[0] + p[1] * p[1]) + p[2] * p[2];
+      memcpy(&e[i].key, &sq, 4);
+      e[i].idx = i;
+    }
+    qsort(e, (size_t)n, sizeof(sorted_entry), sorted_cmp);
+    for (int64_t i = 0; i < n; ++i) order[i] = e[i].idx;
+    free(e);
+    return order;
+  }
+  const int64_t step_size = 1024;
+  const int64_t number_of_groups = n / step_size;
+  for (int64_t seq = 0; seq < n; ++seq) {
+    int64_t pi = seq;
+    if (mode == 1 && seq < number_of_groups * step_size) {
+      const int64_t group_num = seq % number_of_groups;
+      const int64_t position_in_group = seq / number_of_groups;
+      pi = group_num * step_size + position_in_group;
+    }
+    order[seq] = pi;
+  }
+  return order;
+}
+
 int64_t orc_tsdf_integrate(orc_tsdf_integrator* I, const float T_G_C[7], const float* points_C,
                            const uint8_t* rgba, int64_t n, int freespace_points) {
   const orc_tsdf_config* c = &I->cfg;
@@ -274,18 +319,11 @@ int64_t orc_tsdf_integrate(orc_tsdf_integrator* I, const float T_G_C[7], const f
     approx_set_reset(&I->start_set);
     approx_set_reset(&I->observed_set);
   }
-  /* MixedThreadSafeIndex: 1024-point groups visited round-robin, tail in order */
-  const int64_t step_size = 1024;
-  const int64_t number_of_groups = n / step_size;
+  int64_t* order = visiting_order(c->integration_order, points_C, n);
   const float origin[3] = {T_G_C[4], T_G_C[5], T_G_C[6]};
 
   for (int64_t seq = 0; seq < n; ++seq) {
-    int64_t pi = seq;
-    if (c->integration_order_mixed && seq < number_of_groups * step_size) {
-      int64_t group_num = seq % number_of_groups;
-      int64_t position_in_group = seq / number_of_groups;
-      pi = group_num * step_size + position_in_group;
-    }
+    const int64_t pi = order[seq];
     const float* point_C = &points_C[3 * pi];
     const uint8_t* color = rgba ? &rgba[4 * pi] : zero_color;
     /* isPointValid */
@@ -400,6 +438,7 @@ int64_t orc_tsdf_integrate(orc_tsdf_integrator* I, const float T_G_C[7], const f
       ++updates;
     }
   }
+  free(order);
   return updates;
 }
 
@@ -453,15 +492,9 @@ int64_t orc_tsdf_merged_integrate(orc_tsdf_integrator* I, const float T_G_C[7], 
   merged_entry* e = (merged_entry*)malloc((size_t)(n > 0 ? n : 1) * sizeof(merged_entry));
   int64_t m = 0, n_surface = 0, updates = 0;
   /* bundleRays */
-  const int64_t step_size = 1024;
-  const int64_t number_of_groups = n / step_size;
+  int64_t* order = visiting_order(c->integration_order, points_C, n);
   for (int64_t seq = 0; seq < n; ++seq) {
-    int64_t pi = seq;
-    if (c->integration_order_mixed && seq < number_of_groups * step_size) {
-      int64_t group_num = seq % number_of_groups;
-      int64_t position_in_group = seq / number_of_groups;
-      pi = group_num * step_size + position_in_group;
-    }
+    const int64_t pi = order[seq];
     const float* point_C = &points_C[3 * pi];
     int is_clearing;
     const float ray_distance = norm3(point_C);
@@ -482,6 +515,7 @@ int64_t orc_tsdf_merged_integrate(orc_tsdf_integrator* I, const float T_G_C[7], 
     ++m;
     if (!is_clearing) ++n_surface;
   }
+  free(order);
   qsort(e, (size_t)m, sizeof(merged_entry), merged_cmp);
   /* integrateRays(clearing_ray = false), then (true): the sort put the surface groups first */
   for (int64_t i0 = 0; i0 < m;) {

@@ -12,7 +12,8 @@
  * (integrator/tsdf_integrator.cc FastTsdfIntegrator, integrator/
  * integrator_utils.h RayCaster, utils/approx_hash_array.h) with
  * integrator_threads = 1, i.e. one of the orders the multi-threaded reference
- * may produce.  There are no golden vectors for it anywhere.
+ * may produce, in either integration_order_mode ("mixed", "sorted":
+ * voxgraph/config/voxgraph_mapper.yaml:29).  There are no golden vectors for it anywhere.
  */
 #ifndef VOXGRAPH_AMD_ORACLE_TSDF_ORACLE_H_
 #define VOXGRAPH_AMD_ORACLE_TSDF_ORACLE_H_
@@ -39,7 +40,11 @@ typedef struct orc_tsdf_config {
   float start_voxel_subsampling_factor;   /* 2.0          */
   int max_consecutive_ray_collisions;     /* 2            */
   int clear_checks_every_n_frames;        /* 1            */
-  int integration_order_mixed;            /* 1: "mixed" (default), 0: sequential */
+  int integration_order;                  /* ThreadSafeIndexFactory [recalled]: 1 = "mixed" (default: 1024-point
+                                           * groups round-robin), 2 = "sorted" (ascending f32 squaredNorm of
+                                           * point_C; voxblox uses the unstable std::sort, the order at EQUAL
+                                           * range is unspecified there: here ascending point index),
+                                           * 0 = plain input order (not a voxblox mode; used by tests) */
   int enable_anti_grazing;                /* 0 (MergedTsdfIntegrator only)        */
 } orc_tsdf_config;
 

@@ -38,11 +38,12 @@ def main():
                   max_consecutive_ray_collisions=int(rng.integers(0, 4)),
                   start_voxel_subsampling_factor=float(rng.choice([1.0, 2.0, 4.0])),
                   enable_anti_grazing=int(rng.integers(0, 2)))
+        order = int(rng.integers(0, 2))          # integration_order_mode: 0 "mixed", 1 "sorted" (the oracle counts 1 / 2)
         for kind in ("fast", "merged", "merged racing"):
             det = 0 if kind == "merged racing" else 1
             ol, gl = orc.TsdfLayer(vs, vps), capi.TsdfLayer(ctx, vs, vps)
-            oi = orc.FastTsdfIntegrator(orc.tsdf_config(**kw), ol)
-            gi = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(deterministic=det, **kw), gl)
+            oi = orc.FastTsdfIntegrator(orc.tsdf_config(integration_order=order + 1, **kw), ol)
+            gi = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(deterministic=det, integration_order=order, **kw), gl)
             room = ((-30 * vs, -24 * vs, -6 * vs), (32 * vs, 50 * vs, 14 * vs))
             srng = np.random.default_rng(seed * 7 + 1)
             for k in range(8 if big else 3):
@@ -79,7 +80,7 @@ def main():
                         assert np.array_equal(ow[o_ord].view(np.uint32), gw[g_ord].view(np.uint32)), "weight"
                         assert np.array_equal(oc[o_ord], gc[g_ord]), "colour"
                 except AssertionError as e:
-                    print("MISMATCH", kind, "seed", seed, "scan", k, "free", free, kw, "vps", vps, "vs", vs)
+                    print("MISMATCH", kind, "seed", seed, "scan", k, "free", free, kw, "vps", vps, "vs", vs, "integration_order", order)
                     print(str(e)[:600])
                     return 1
             tally[kind] += 1

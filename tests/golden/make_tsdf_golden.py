@@ -41,7 +41,15 @@ def sessions():
                                                           sparsity_compensation_factor=20.0), False),
                              ("fast_voxblox_defaults", dict(default_truncation_distance=0.4, max_ray_length_m=6.0), False),
                              ("merged_anti_grazing", dict(default_truncation_distance=0.6, max_ray_length_m=8.0,
-                                                          enable_anti_grazing=1), True)):
+                                                          enable_anti_grazing=1), True),
+                             # integration_order_mode "sorted" (voxgraph_mapper.yaml:29): `integration_order` is the
+                             # device's field (VGX_TSDF_ORDER_SORTED = 1); run() maps it to the oracle's (2)
+                             ("fast_voxgraph_yaml_sorted_order", dict(default_truncation_distance=0.6, max_ray_length_m=8.0,
+                                                                      use_const_weight=1, use_weight_dropoff=1,
+                                                                      use_sparsity_compensation_factor=1,
+                                                                      sparsity_compensation_factor=20.0, integration_order=1), False),
+                             ("merged_sorted_order", dict(default_truncation_distance=0.6, max_ray_length_m=8.0,
+                                                          integration_order=1), True)):
         scans = []
         for k in range(3):
             origin = np.array([0.3 * k - 0.2, -0.25 * k, 0.05 * k])
@@ -53,6 +61,14 @@ def sessions():
             scans.append((T, pts, col))
         out.append((name, kw, merged, scans))
     return out
+
+
+def oracle_kw(kw):
+    """the sessions carry the DEVICE's integration_order (0 mixed, 1 sorted); the oracle's field counts
+    0 = input order, 1 = mixed, 2 = sorted"""
+    kw = dict(kw)
+    kw["integration_order"] = {0: 1, 1: 2}[kw.get("integration_order", 0)]
+    return kw
 
 
 def digest(layer_download):
@@ -75,8 +91,8 @@ def main():
     from oracle import pyoracle as orc
     out = {}
     for name, kw, merged, scans in sessions():
-        out[name] = run(lambda vs, vps: orc.TsdfLayer(vs, vps), lambda kw_, l: orc.FastTsdfIntegrator(orc.tsdf_config(**kw_), l),
-                        kw, merged, scans)
+        out[name] = run(lambda vs, vps: orc.TsdfLayer(vs, vps),
+                        lambda kw_, l: orc.FastTsdfIntegrator(orc.tsdf_config(**oracle_kw(kw_)), l), kw, merged, scans)
         print(name, out[name])
     json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tsdf_oracle_digests.json"), "w"), indent=1)
 

@@ -102,7 +102,7 @@ def test_min_max_ray_length_clearing_and_freespace():
 def test_start_voxel_dedup_and_ray_collision_early_out():
     vs = 0.1
     cfg = orc.tsdf_config(default_truncation_distance=0.2, use_const_weight=1, use_weight_dropoff=0,
-                          integration_order_mixed=0)
+                          integration_order=0)
     T = IDENT.copy(); T[4:] = (0.05, 0.05, 0.05)
     layer = orc.TsdfLayer(vs)
     integ = orc.FastTsdfIntegrator(cfg, layer)
@@ -165,6 +165,44 @@ def test_oracle_reproduces_its_committed_digests(golden_dir):
     from tests.golden import make_tsdf_golden as G
     want = json.load(open(os.path.join(golden_dir, "tsdf_oracle_digests.json")))
     for name, kw, merged, scans in G.sessions():
-        got = G.run(lambda vs, vps: orc.TsdfLayer(vs, vps), lambda kw_, l: orc.FastTsdfIntegrator(orc.tsdf_config(**kw_), l),
-                    kw, merged, scans)
+        got = G.run(lambda vs, vps: orc.TsdfLayer(vs, vps),
+                    lambda kw_, l: orc.FastTsdfIntegrator(orc.tsdf_config(**G.oracle_kw(kw_)), l), kw, merged, scans)
         assert got == want[name], (name, got, want[name])
+
+
+def test_sorted_integration_order_is_ascending_squared_norm_with_index_ties():
+    """integration_order_mode "sorted" (voxgraph_mapper.yaml:29; voxblox SortedThreadSafeIndex [recalled]): the
+    points are visited by ascending f32 squaredNorm() of point_C, equal ranges by ascending index (the tie rule
+    stated in oracle/tsdf_oracle.h).  Check against an independent numpy statement of that order: the oracle in
+    plain input order, fed the points pre-sorted by numpy's STABLE argsort, must produce the same layer bit for
+    bit -- fast and merged integrators, a scan with many exact ties (duplicated points with other colours) --
+    and the sorted order must not be the mixed one."""
+    import hashlib
+    rng = np.random.default_rng(12)
+    az, el = np.meshgrid(np.linspace(-np.pi, np.pi, 700, endpoint=False), np.linspace(-0.4, 0.4, 9))
+    d = np.stack([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)], -1).reshape(-1, 3)
+    lo, hi = np.array([-4.0, -3.0, -1.0]), np.array([4.5, 3.5, 2.0])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t = np.where(d > 0, hi / d, np.where(d < 0, lo / d, np.inf)).min(1)
+    pts = (d * t[:, None]).astype(F)
+    pts = np.concatenate([pts, pts[::5], pts[::7]])[rng.permutation(len(pts) + len(pts[::5]) + len(pts[::7]))]
+    col = rng.integers(0, 256, (len(pts), 4)).astype(np.uint8)
+    x, y, z = pts[:, 0], pts[:, 1], pts[:, 2]
+    sq = (x * x + y * y) + z * z                                     # f32, Eigen's reduction order
+    assert sq.dtype == np.float32 and len(np.unique(sq)) < len(sq) - 100          # exact ties exist
+    order = np.argsort(sq.view(np.uint32), kind="stable")
+    T = np.array([0.9950042, 0, 0, 0.0998334, 0.1, -0.05, 0.02], F)
+    kw = dict(default_truncation_distance=0.3, max_ray_length_m=6.0, use_const_weight=0)
+
+    def digest(order_mode, points, colours, merged):
+        layer = orc.TsdfLayer(0.1, 16)
+        integ = orc.FastTsdfIntegrator(orc.tsdf_config(integration_order=order_mode, **kw), layer)
+        n = (integ.integratePointCloudMerged if merged else integ.integratePointCloud)(T, points, colours)
+        h = hashlib.sha256()
+        for a in layer.download():
+            h.update(np.ascontiguousarray(a).tobytes())
+        return n, h.hexdigest()
+    for merged in (False, True):
+        got = digest(2, pts, col, merged)
+        assert got == digest(0, pts[order], col[order], merged), merged
+        assert got[0] > 10000 and got != digest(1, pts, col, merged), merged

@@ -161,8 +161,12 @@ def test_five_runs_give_the_same_layer(capi, ctx):
         print(kind, "reproducible mode: 5 runs, 1 digest; racing mode:", len(racing), "digest(s) in 3 runs")
 
 
-def test_randomised_configurations_multi_ray_scans(capi, ctx):
-    """eight random integrator configurations (vps 8/16, voxel 5-30 cm, carving on/off, constant or 1/z^2
+ORDERS = {"mixed": (0, 1), "sorted": (1, 2)}     # name -> (vgx_tsdf_config.integration_order, the oracle's)
+
+
+@pytest.mark.parametrize("order", ["mixed", "sorted"])
+def test_randomised_configurations_multi_ray_scans(capi, ctx, order):
+    """(both integration_order_mode settings) eight random integrator configurations (vps 8/16, voxel 5-30 cm, carving on/off, constant or 1/z^2
     weights, drop-off, sparsity compensation, low max_weight, max_consecutive_ray_collisions 0-3,
     start-voxel subsampling 1/2/4, allow_clear on/off with returns beyond the maximum range, freespace
     scans, points at the origin / too close / non-finite), four dense scans each."""
@@ -180,7 +184,8 @@ def test_randomised_configurations_multi_ray_scans(capi, ctx):
                   allow_clear=int(rng.integers(0, 2)), max_weight=float(rng.choice([3.0, 50.0, 10000.0])),
                   max_consecutive_ray_collisions=int(rng.integers(0, 4)),
                   start_voxel_subsampling_factor=float(rng.choice([1.0, 2.0, 4.0])))
-        ocfg, gcfg = orc.tsdf_config(**kw), capi.tsdf_config(deterministic=1, **kw)
+        ocfg = orc.tsdf_config(integration_order=ORDERS[order][1], **kw)
+        gcfg = capi.tsdf_config(deterministic=1, integration_order=ORDERS[order][0], **kw)
         ol, gl = orc.TsdfLayer(vs, vps), capi.TsdfLayer(ctx, vs, vps)
         oi, gi = orc.FastTsdfIntegrator(ocfg, ol), capi.FastTsdfIntegrator(ctx, gcfg, gl)
         room = ((-30 * vs, -24 * vs, -6 * vs), (32 * vs, 50 * vs, 14 * vs))   # partly beyond max range
@@ -291,8 +296,9 @@ def test_merged_integrator_reproducible_mode_fullsize(capi, ctx):
             o.destroy()
 
 
-def test_small_scans_and_sets_that_are_not_reset_every_frame(capi, ctx):
-    """clear_checks_every_n_frames = 3: the approximate sets keep their contents (and their offset) over
+@pytest.mark.parametrize("order", ["mixed", "sorted"])
+def test_small_scans_and_sets_that_are_not_reset_every_frame(capi, ctx, order):
+    """(both visiting orders) clear_checks_every_n_frames = 3: the approximate sets keep their contents (and their offset) over
     three scans, so what a ray finds in a slot may have been written by an EARLIER scan -- the
     reproducible mode reads the sets' state where its own scan has no predecessor in a slot and leaves them
     as the single thread would.  Scans of 0, 1, 2, 5, 1023, 1024, 1025 and 3000 points (the mixed
@@ -301,8 +307,8 @@ def test_small_scans_and_sets_that_are_not_reset_every_frame(capi, ctx):
     kw = dict(default_truncation_distance=0.3, max_ray_length_m=8.0, use_const_weight=1,
               clear_checks_every_n_frames=3, max_consecutive_ray_collisions=1)
     ol, gl = orc.TsdfLayer(vs, vps), capi.TsdfLayer(ctx, vs, vps)
-    oi = orc.FastTsdfIntegrator(orc.tsdf_config(**kw), ol)
-    gi = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(deterministic=1, **kw), gl)
+    oi = orc.FastTsdfIntegrator(orc.tsdf_config(integration_order=ORDERS[order][1], **kw), ol)
+    gi = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(deterministic=1, integration_order=ORDERS[order][0], **kw), gl)
     rng = np.random.default_rng(5)
     full = _lidar_scan(300, 10, 77, room=((-3.0, -2.5, -1.0), (3.5, 2.0, 1.5)), el=0.4)
     for k, n in enumerate([0, 1, 2, 5, 1023, 1024, 1025, 3000, 3000, 3000, 1, 3000]):
@@ -320,6 +326,79 @@ def test_small_scans_and_sets_that_are_not_reset_every_frame(capi, ctx):
     assert gl.stats()[1] == 0 and ol.num_blocks() > 20
     for o in (gi, gl):
         o.destroy()
+
+
+@pytest.mark.parametrize("kind", ["lidar", "rgbd"])
+@pytest.mark.parametrize("merged", [False, True])
+def test_sorted_integration_order_bit_for_bit(capi, ctx, kind, merged):
+    """integration_order_mode "sorted" (voxgraph/config/voxgraph_mapper.yaml:29): points visited
+    by ascending f32 squaredNorm of point_C, equal ranges by ascending index.  The two BASELINE sensor shapes at
+    full size -- a 64 x 1024 LiDAR sweep with the shipped yaml (plus 3000 duplicated returns with other colours:
+    exact ties) and a 640 x 480 depth image at 0.05 m -- two scans each, fast and merged integrators, in BOTH
+    orders: block list, distances, weights and colours equal the oracle's bit for bit after every scan, and the
+    two orders give different layers (the option is not ignored)."""
+    import hashlib
+    digests = {}
+    for order in ("mixed", "sorted"):
+        if kind == "lidar":
+            vs = 0.2
+            ocfg = orc.voxgraph_tsdf_config(integration_order=ORDERS[order][1])
+            gcfg = capi.voxgraph_tsdf_config(deterministic=1, integration_order=ORDERS[order][0])
+        else:
+            vs = 0.05
+            kw = dict(default_truncation_distance=0.15, max_ray_length_m=5.0)
+            ocfg = orc.tsdf_config(integration_order=ORDERS[order][1], **kw)
+            gcfg = capi.tsdf_config(deterministic=1, integration_order=ORDERS[order][0], **kw)
+        ol, gl = orc.TsdfLayer(vs, 16), capi.TsdfLayer(ctx, vs, 16)
+        oi, gi = orc.FastTsdfIntegrator(ocfg, ol), capi.FastTsdfIntegrator(ctx, gcfg, gl)
+        rng = np.random.default_rng(31)
+        for k in range(2):
+            if kind == "lidar":
+                origin = np.array([0.4 * k, -0.2 * k, 0.0], F)
+                pts = _lidar_scan(1024, 64, 80 + k, origin=origin.astype(np.float64))
+                pts = np.concatenate([pts, pts[rng.integers(0, len(pts), 3000)]])      # exact ties in range
+            else:
+                pts, origin = _rgbd_scan(k)
+            T = np.r_[np.array([1, 0, 0, 0], F), origin].astype(F)
+            col = rng.integers(0, 256, (len(pts), 4)).astype(np.uint8)
+            a = (oi.integratePointCloudMerged if merged else oi.integratePointCloud)(T, pts, col)
+            b = (gi.integratePointCloudMerged if merged else gi.integratePointCloud)(T, pts, col)
+            assert a == b > 0, (kind, merged, order, k, a, b)
+            _assert_layers_identical(ol, gl, f"{kind} merged={merged} order={order} scan {k}")
+        assert gl.stats()[1] == 0
+        h = hashlib.sha256()
+        for arr in gl.download():
+            h.update(np.ascontiguousarray(arr).tobytes())
+        digests[order] = h.hexdigest()
+        for o in (gi, gl):
+            o.destroy()
+    assert digests["mixed"] != digests["sorted"], (kind, merged)
+
+
+def test_racing_mode_ignores_the_integration_order_and_bad_values_are_refused(capi, ctx):
+    """the racing fast integrator has no visiting order: integration_order sorted changes nothing it can be held
+    to (single-ray scans are order independent: equal to the oracle either way); a value that is neither mixed
+    nor sorted is refused by the modes that use it"""
+    vs = 0.2
+    pts = _lidar_scan(64, 4, 3)
+    T = np.array([1, 0, 0, 0, 0, 0, 0], F)
+    for order in (0, 1):
+        ol, gl = orc.TsdfLayer(vs, 16), capi.TsdfLayer(ctx, vs, 16)
+        oi = orc.FastTsdfIntegrator(orc.voxgraph_tsdf_config(), ol)
+        gi = capi.FastTsdfIntegrator(ctx, capi.voxgraph_tsdf_config(integration_order=order), gl)
+        for p in pts[:40]:
+            assert oi.integratePointCloud(T, p[None]) == gi.integratePointCloud(T, p[None])
+        _assert_layers_identical(ol, gl, f"racing mode, integration_order {order}")
+        for o in (gi, gl):
+            o.destroy()
+    gl = capi.TsdfLayer(ctx, vs, 16)
+    for det, merged in ((1, False), (0, True)):
+        gi = capi.FastTsdfIntegrator(ctx, capi.voxgraph_tsdf_config(deterministic=det, integration_order=7), gl)
+        with pytest.raises(capi.VgxError) as e:
+            (gi.integratePointCloudMerged if merged else gi.integratePointCloud)(T, pts)
+        assert e.value.code == -1 and "integration_order" in str(e.value)        # VGX_ERR_INVALID
+        gi.destroy()
+    gl.destroy()
 
 
 def test_reproducible_mode_matches_the_committed_oracle_digests(capi, ctx, golden_dir):

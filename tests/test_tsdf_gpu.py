@@ -186,7 +186,7 @@ def test_full_scan_with_shipped_config_agrees_statistically(capi, ctx):
     the same algorithm."""
     vs, vps, trunc = 0.2, 16, 0.6
     ocfg, gcfg = orc.voxgraph_tsdf_config(), capi.voxgraph_tsdf_config()
-    ocfg_seq = orc.voxgraph_tsdf_config(integration_order_mixed=0)
+    ocfg_seq = orc.voxgraph_tsdf_config(integration_order=0)
     ol, ol2 = orc.TsdfLayer(vs, vps), orc.TsdfLayer(vs, vps)
     oi, oi2 = orc.FastTsdfIntegrator(ocfg, ol), orc.FastTsdfIntegrator(ocfg_seq, ol2)
     gl = capi.TsdfLayer(ctx, vs, vps, (-3, -3, -2), (6, 6, 4), 144)

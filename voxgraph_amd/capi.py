@@ -71,8 +71,10 @@ class TsdfConfig(C.Structure):
                 ("start_voxel_subsampling_factor", C.c_float),
                 ("max_consecutive_ray_collisions", C.c_int32),
                 ("clear_checks_every_n_frames", C.c_int32), ("enable_anti_grazing", C.c_int32),
-                ("deterministic", C.c_int32)]
+                ("deterministic", C.c_int32), ("integration_order", C.c_int32)]
 
+
+TSDF_ORDER_MIXED, TSDF_ORDER_SORTED = 0, 1
 
 # every symbol include/voxgraph_amd.h declares: name -> (restype, argtypes)
 SIGNATURES = {
@@ -108,7 +110,7 @@ SIGNATURES = {
     "vgx_synth_city_scan": (C.c_int, [vp, f64p, C.c_int32, C.c_int32, C.c_float, C.c_float,
                                       C.c_uint32, vp]),
     "vgx_bench_atomic_roundtrip": (C.c_int, [vp, C.c_int64, C.c_int32, C.c_int32, f32p]),
-    "vgx_tsdf_integrator_longest_walk": (C.c_int, [vp, i64p]),
+    "vgx_tsdf_integrator_walk_stats": (C.c_int, [vp, i64p]),
     "vgx_reg_config_default": (None, [C.POINTER(RegConfig)]),
     "vgx_reg_create": (C.c_int, [vp, vp, vp, C.POINTER(RegConfig), C.POINTER(vp)]),
     "vgx_reg_destroy": (C.c_int, [vp]),
@@ -752,11 +754,12 @@ class FastTsdfIntegrator:
             int(freespace_points), C.byref(out) if count else None))
         return out.value
 
-    def longest_walk(self):
-        """bench tooling: longest chain of dependent approximate-set exchanges of the last counted racing scan"""
-        out = C.c_int64()
-        self.ctx.check(self.ctx.lib.vgx_tsdf_integrator_longest_walk(self.h, C.byref(out)))
-        return out.value
+    def walk_stats(self):
+        """bench tooling, last counted racing scan: (longest chain of dependent approximate-set exchanges,
+        exchanges of all rays, updates that blended a colour)"""
+        out = (C.c_int64 * 3)()
+        self.ctx.check(self.ctx.lib.vgx_tsdf_integrator_walk_stats(self.h, out))
+        return int(out[0]), int(out[1]), int(out[2])
 
     def destroy(self):
         if self.h:

@@ -79,6 +79,13 @@ int launch_brickify(vgx_submap sm, int which) {
   const uint8_t* obs = which == 0 ? nullptr : sm->d_esdf_observed;
   const int layout = ctx->brick_layout;
   const size_t cells = brick_cells(sm->vps, layout);
+  // the fused REG kernel addresses a brick cell with a 32-bit `slot * cells + offset` (vgx_reg.hip,
+  // reg_eval_reduce_lean_kernel): a submap whose bricks do not fit that range is refused here, at upload
+  // time (apron bricks, vps 16: 874 K blocks = a 1500^3-voxel dense cube; quad bricks: 246 K blocks)
+  if ((unsigned long long)sm->n_blocks * cells >= (1ull << 32))
+    return set_error(ctx, VGX_ERR_UNSUPPORTED,
+                     "submap too large for 32-bit brick addressing: " + std::to_string(sm->n_blocks) + " blocks x " +
+                         std::to_string(cells) + " cells per brick");
   size_t bytes = (size_t)sm->n_blocks * cells * sizeof(float);
   VGX_HIP(ctx, hipMalloc(&sm->grid[which].d_bricks, bytes));
   sm->grid[which].layout = layout;

@@ -22,7 +22,25 @@
 #include <numeric>
 #include <thread>
 
-#include <rccl/rccl.h>  // types and prototypes only: the library is opened at run time (RcclApi)
+// RCCL: types and prototypes only -- the library is opened at run time (RcclApi), so the build must not
+// depend on its header being installed either
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+typedef enum { ncclFloat64 = 8, ncclDouble = 8 } ncclDataType_t;
+ncclResult_t ncclCommInitAll(ncclComm_t* comms, int ndev, const int* devlist);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op,
+                           ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclGroupStart();
+ncclResult_t ncclGroupEnd();
+const char* ncclGetErrorString(ncclResult_t result);
+}
+#endif
 
 #include "vgx_internal.h"
 
@@ -377,13 +395,23 @@ int vgx_reg_multi_evaluate_fused(vgx_reg_multi m, const double* poses, int32_t n
     // (behind that context's evaluation and assembly); context 0's copy goes to the host
     RcclApi& api = rccl_api();
     ncclResult_t r = api.GroupStart();
-    for (size_t k = 0; k < m->shards.size() && r == ncclSuccess; ++k) {
+    const bool group_open = r == ncclSuccess;
+    bool device_failed = false;
+    for (size_t k = 0; k < m->shards.size() && r == ncclSuccess && !device_failed; ++k) {
       vgx_reg_multi_s::Shard& s = *m->shards[k];
-      if (hipSetDevice(s.ctx->device) != hipSuccess) return set_error(ctx0, VGX_ERR_HIP, "hipSetDevice");
+      // the stream belongs to the shard's context: nobody else enqueues on it while the collective goes in
+      std::lock_guard<std::mutex> lk(s.ctx->mu);
+      if (hipSetDevice(s.ctx->device) != hipSuccess) {
+        device_failed = true;  // (no early return: an open RCCL group would stay open for the whole process)
+        break;
+      }
       r = api.AllReduce(s.d_fused, s.d_fused, (size_t)size, ncclDouble, ncclSum, m->comms[k], s.ctx->stream);
     }
-    ncclResult_t r2 = api.GroupEnd();
-    if (r == ncclSuccess) r = r2;
+    if (group_open) {
+      const ncclResult_t r2 = api.GroupEnd();
+      if (r == ncclSuccess) r = r2;
+    }
+    if (device_failed) return set_error(ctx0, VGX_ERR_HIP, "vgx_reg_multi: hipSetDevice failed while enqueuing the all-reduce");
     if (r != ncclSuccess) return set_error(ctx0, VGX_ERR_HIP, std::string("ncclAllReduce: ") + api.GetErrorString(r));
     VGX_HIP(ctx0, hipSetDevice(ctx0->device));
     d_result = m->shards[0]->d_fused;

@@ -808,7 +808,7 @@ __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_ker
       if (kBallotSkip && !count_misses && __builtin_amdgcn_ballot_w64(any) == 0ull) continue;
 #pragma unroll
       for (int j = 0; j < PPT; ++j) {
-        // 32-bit offsets: a grid holds < 2^31 floats (4096 quad bricks of 17 408 floats = 71 M)
+        // 32-bit offsets: launch_brickify (vgx_context.hip) refuses a submap with n_blocks * CELLS >= 2^32
         const unsigned off = (unsigned)(have[j] ? slot[j] : 0) * (unsigned)CELLS + (unsigned)loc[j].cell_off;
         load_neighbours<VPS, LAYOUT>(g.bricks + off, d[j]);
       }

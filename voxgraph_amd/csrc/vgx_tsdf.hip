@@ -28,7 +28,7 @@
 #include <rocprim/rocprim.hpp>  // device radix sort (MergedTsdfIntegrator's bundleRays)
 
 #include "vgx_tsdf_internal.h"
-#include "voxgraph_amd_bench.h"  // vgx_tsdf_integrator_longest_walk
+#include "voxgraph_amd_bench.h"  // vgx_tsdf_integrator_walk_stats
 
 #pragma clang fp contract(off)
 
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(TsdfLayerDev L, Tsd
                                                             long long n, int freespace_points) {
   const vgx_tsdf_config& c = I.cfg;
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned long long my_updates = 0, my_dropped = 0, my_walk = 0;
+  unsigned long long my_updates = 0, my_dropped = 0, my_walk = 0, my_blends = 0;
   if (i < n) {
     float px = points_C[3 * i], py = points_C[3 * i + 1], pz = points_C[3 * i + 2];
     uint32_t color = rgba ? rgba[i] : 0u;
@@ -328,9 +328,10 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(TsdfLayerDev L, Tsd
             }
             size_t at = (size_t)last_slot * ((size_t)vps * vps * vps) +
                         (size_t)((vx & mask) + vps * ((vy & mask) + vps * (vz & mask)));
-            if (PIPELINED)
+            if (PIPELINED) {
               s1 = make_update(L, c, at, tx, ty, tz, gx, gy, gz, vx, vy, vz, weight);
-            else
+              my_blends += s1.blend ? 1u : 0u;
+            } else
               update_voxel(L, c, at, tx, ty, tz, gx, gy, gz, vx, vy, vz, color, weight);
             ++my_updates;
           }
@@ -344,17 +345,24 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(TsdfLayerDev L, Tsd
     }
   }
   // one atomic per wave for the statistics
+  unsigned long long my_total = my_walk;
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
     my_updates += __shfl_xor(my_updates, off, 64);
     my_dropped += __shfl_xor(my_dropped, off, 64);
+    my_blends += __shfl_xor(my_blends, off, 64);
+    my_total += __shfl_xor(my_total, off, 64);
     const unsigned long long other = __shfl_xor(my_walk, off, 64);
     my_walk = other > my_walk ? other : my_walk;
   }
   if ((threadIdx.x & 63) == 0) {
     if (my_updates) atomicAdd(I.n_updates, my_updates);
     if (my_dropped) atomicAdd(L.dropped, my_dropped);
-    if (my_walk) atomicMax(I.n_updates + 1, my_walk);  // vgx_tsdf_integrator_longest_walk (bench header)
+    if (my_walk) {  // vgx_tsdf_integrator_walk_stats (bench header)
+      atomicMax(I.n_updates + 1, my_walk);
+      atomicAdd(I.n_updates + 2, my_total);
+      if (my_blends) atomicAdd(I.n_updates + 3, my_blends);
+    }
   }
 }
 
@@ -379,6 +387,7 @@ __device__ __forceinline__ unsigned long long merged_key(int x, int y, int z, bo
 __global__ __launch_bounds__(256) void merged_bundle_kernel(vgx_tsdf_config c, float vsi, float qw, float qx, float qy,
                                                            float qz, float tx, float ty, float tz,
                                                            const float* __restrict__ points_C, long long n,
+                                                           const uint32_t* __restrict__ order,
                                                            int freespace_points, unsigned long long* __restrict__ keys,
                                                            unsigned int* __restrict__ idx,
                                                            unsigned int* __restrict__ counters,
@@ -391,10 +400,7 @@ __global__ __launch_bounds__(256) void merged_bundle_kernel(vgx_tsdf_config c, f
     g_count[n] = 0u;
     counters[0] = counters[1] = counters[2] = counters[3] = 0u;
   }
-  // MixedThreadSafeIndex: 1024-point groups visited round-robin, tail in order
-  const long long step_size = 1024, number_of_groups = n / step_size;
-  long long pi = seq;
-  if (seq < number_of_groups * step_size) pi = (seq % number_of_groups) * step_size + seq / number_of_groups;
+  const long long pi = visiting_order_point(order, seq, n);  // ThreadSafeIndex: "mixed" or "sorted"
   const float px = points_C[3 * pi], py = points_C[3 * pi + 1], pz = points_C[3 * pi + 2];
   bool valid = true, is_clearing = false;
   const float ray_distance = norm3(px, py, pz);
@@ -599,6 +605,7 @@ void vgx_tsdf_config_default(vgx_tsdf_config* c) {
   c->clear_checks_every_n_frames = 1;
   c->enable_anti_grazing = 0;
   c->deterministic = 0;
+  c->integration_order = VGX_TSDF_ORDER_MIXED;
 }
 
 // ---------------------------------------------------------------------------
@@ -1076,12 +1083,12 @@ int vgx_tsdf_integrator_create(vgx_ctx ctx, const vgx_tsdf_config* cfg, vgx_tsdf
   const size_t set_bytes = ((size_t)1 << kSetBits) * 8;
   bool ok = hipMalloc(&I->dev.start_set, set_bytes) == hipSuccess &&
             hipMalloc(&I->dev.observed_set, set_bytes) == hipSuccess &&
-            hipMalloc(&I->dev.n_updates, 16) == hipSuccess;
+            hipMalloc(&I->dev.n_updates, 32) == hipSuccess;
   const unsigned long long poison = ~0ull;
   if (ok)
     ok = hipMemset(I->dev.start_set, 0, set_bytes) == hipSuccess &&
          hipMemset(I->dev.observed_set, 0, set_bytes) == hipSuccess &&
-         hipMemset(I->dev.n_updates, 0, 16) == hipSuccess &&
+         hipMemset(I->dev.n_updates, 0, 32) == hipSuccess &&
          // the zero hash would look present in every zeroed slot (ApproxHashSet ctor)
          hipMemcpy(I->dev.start_set, &poison, 8, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(I->dev.observed_set, &poison, 8, hipMemcpyHostToDevice) == hipSuccess;
@@ -1099,7 +1106,8 @@ int vgx_tsdf_integrator_destroy(vgx_tsdf_integrator I) {
   (void)hipStreamSynchronize(I->ctx->stream);
   void* ptrs[] = {I->dev.start_set, I->dev.observed_set, I->dev.n_updates, I->d_points, I->d_rgba,
                   I->d_mkeys[0], I->d_mkeys[1], I->d_midx[0], I->d_midx[1], I->d_mstart, I->d_mcounters, I->d_msort,
-                  I->d_mrank, I->d_gpg, I->d_gcolor, I->d_gflags, I->d_gcount};
+                  I->d_mrank, I->d_gpg, I->d_gcolor, I->d_gflags, I->d_gcount, I->d_okey[0], I->d_okey[1], I->d_oidx[0],
+                  I->d_oidx[1], I->d_osort};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (I->det) det_scratch_free(I->det);
@@ -1125,6 +1133,57 @@ static int reset_set(vgx_ctx ctx, unsigned long long* set, unsigned long long* o
   return VGX_OK;
 }
 
+// SortedThreadSafeIndex [recalled]: std::sort of (index, point_C.squaredNorm()) by ascending squared norm.
+// The key is the bit pattern of the f32 Eigen reduction (x*x + y*y) + z*z (non-negative, so it orders like
+// the float; NaN last); the radix sort is stable, so points at equal range stay in index order -- the tie
+// rule include/voxgraph_amd.h and oracle/tsdf_oracle.c state (std::sort leaves it unspecified).
+__global__ __launch_bounds__(256) void sorted_order_keys_kernel(const float* __restrict__ points_C, long long n,
+                                                               uint32_t* __restrict__ key, uint32_t* __restrict__ idx) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float x = points_C[3 * i], y = points_C[3 * i + 1], z = points_C[3 * i + 2];
+  key[i] = __float_as_uint((x * x + y * y) + z * z);
+  idx[i] = (uint32_t)i;
+}
+
+// The scan's visiting order: *order = nullptr for "mixed" (the kernels compute it), else the sorted table.
+// The caller holds I->mu and ctx->mu.
+static int visiting_order(vgx_tsdf_integrator I, const void* d_points, int64_t n, const uint32_t** order) {
+  vgx_ctx ctx = I->ctx;
+  *order = nullptr;
+  if (I->dev.cfg.integration_order == VGX_TSDF_ORDER_MIXED || n <= 0) return VGX_OK;
+  if (I->dev.cfg.integration_order != VGX_TSDF_ORDER_SORTED)
+    return set_error(ctx, VGX_ERR_INVALID, "vgx_tsdf_config.integration_order: neither VGX_TSDF_ORDER_MIXED nor VGX_TSDF_ORDER_SORTED");
+  if (n >= (1ll << 32)) return set_error(ctx, VGX_ERR_UNSUPPORTED, "integration_order sorted: more than 2^32 points in a scan");
+  if (n > I->order_cap) {
+    VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    void* old[] = {I->d_okey[0], I->d_okey[1], I->d_oidx[0], I->d_oidx[1], I->d_osort};
+    for (void* q : old)
+      if (q) (void)hipFree(q);
+    I->d_okey[0] = I->d_okey[1] = I->d_oidx[0] = I->d_oidx[1] = nullptr;
+    I->d_osort = nullptr;
+    I->order_cap = 0;
+    for (int k = 0; k < 2; ++k) {
+      VGX_HIP(ctx, hipMalloc(&I->d_okey[k], (size_t)n * 4));
+      VGX_HIP(ctx, hipMalloc(&I->d_oidx[k], (size_t)n * 4));
+    }
+    size_t bytes = 0;
+    VGX_HIP(ctx, rocprim::radix_sort_pairs(nullptr, bytes, I->d_okey[0], I->d_okey[1], I->d_oidx[0], I->d_oidx[1], (size_t)n, 0,
+                                           32, ctx->stream));
+    VGX_HIP(ctx, hipMalloc(&I->d_osort, std::max<size_t>(bytes, 16)));
+    I->osort_bytes = bytes;
+    I->order_cap = n;
+  }
+  hipLaunchKernelGGL(sorted_order_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                     (const float*)d_points, (long long)n, I->d_okey[0], I->d_oidx[0]);
+  VGX_HIP(ctx, hipGetLastError());
+  size_t bytes = I->osort_bytes;
+  VGX_HIP(ctx, rocprim::radix_sort_pairs(I->d_osort, bytes, I->d_okey[0], I->d_okey[1], I->d_oidx[0], I->d_oidx[1], (size_t)n, 0, 32,
+                                         ctx->stream));
+  *order = I->d_oidx[1];
+  return VGX_OK;
+}
+
 // integratePointCloud with the scan already in device memory; the caller holds I->mu.
 static int integrate_locked(vgx_tsdf_integrator I, const float T[7], const void* d_points, const void* d_rgba,
                             int64_t n, int32_t freespace, int64_t* n_updates) {
@@ -1139,7 +1198,7 @@ static int integrate_locked(vgx_tsdf_integrator I, const float T[7], const void*
     if (rc == VGX_OK) rc = reset_set(ctx, I->dev.observed_set, &I->dev.observed_offset);
     if (rc != VGX_OK) return rc;
   }
-  if (n_updates) VGX_HIP(ctx, hipMemsetAsync(I->dev.n_updates, 0, 16, ctx->stream));
+  if (n_updates) VGX_HIP(ctx, hipMemsetAsync(I->dev.n_updates, 0, 32, ctx->stream));
   if (n > 0) {
     // Every voxel a ray of this scan can touch lies within max_ray_length + truncation of the
     // sensor origin (a longer return is a clearing ray cut at max_ray_length, RayCaster [recalled]);
@@ -1151,7 +1210,10 @@ static int integrate_locked(vgx_tsdf_integrator I, const float T[7], const void*
     if (rc != VGX_OK) return rc;
     if (c.deterministic) {
       // reproducible mode: the single-thread visiting order of the reference, resolved in parallel
-      rc = det_integrate(I, T, d_points, d_rgba, n, freespace, n_updates);
+      const uint32_t* order = nullptr;
+      rc = visiting_order(I, d_points, n, &order);
+      if (rc != VGX_OK) return rc;
+      rc = det_integrate(I, T, d_points, d_rgba, n, freespace, order, n_updates);
       if (rc == VGX_OK) request_readback(I->layer);
       return rc;
     }
@@ -1232,9 +1294,12 @@ static int merged_integrate_locked(vgx_tsdf_integrator I, const float T[7], cons
     const float reach = c.max_ray_length_m + c.default_truncation_distance + 2.0f * I->layer->dev.voxel_size;
     int rc = reserve_for_scan(I->layer, origin, reach);
     if (rc != VGX_OK) return rc;
+    const uint32_t* order = nullptr;  // the order a group's points are merged in
+    rc = visiting_order(I, d_points, n, &order);
+    if (rc != VGX_OK) return rc;
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
     hipLaunchKernelGGL(merged_bundle_kernel, grid, block, 0, ctx->stream, c, I->layer->dev.voxel_size_inv, T[0], T[1],
-                       T[2], T[3], T[4], T[5], T[6], (const float*)d_points, (long long)n, (int)freespace,
+                       T[2], T[3], T[4], T[5], T[6], (const float*)d_points, (long long)n, order, (int)freespace,
                        I->d_mkeys[0], I->d_midx[0], I->d_mcounters, I->d_gcount);
     VGX_HIP(ctx, hipGetLastError());
     size_t bytes = I->msort_bytes;
@@ -1327,18 +1392,19 @@ int vgx_tsdf_integrate_device(vgx_tsdf_integrator I, const float T[7], const voi
   return integrate_locked(I, T, d_points, d_rgba, n, freespace, n_updates);
 }
 
-// bench header: the longest chain of dependent approximate-set exchanges any ray of the last COUNTED racing
-// scan walked (n_updates != NULL resets the statistic before the scan)
-int vgx_tsdf_integrator_longest_walk(vgx_tsdf_integrator I, int64_t* steps) {
-  if (!I || !steps) return VGX_ERR_INVALID;
+// bench header: what the rays of the last COUNTED racing scan did (n_updates != NULL resets the statistics
+// before the scan): stats[0] = the longest chain of dependent approximate-set exchanges any ray walked,
+// stats[1] = exchanges of all rays together, stats[2] = updates that also blended a colour
+int vgx_tsdf_integrator_walk_stats(vgx_tsdf_integrator I, int64_t stats[3]) {
+  if (!I || !stats) return VGX_ERR_INVALID;
   std::lock_guard<std::mutex> own(I->mu);
   vgx_ctx ctx = I->ctx;
   std::lock_guard<std::mutex> lk(ctx->mu);
   VGX_HIP(ctx, hipSetDevice(ctx->device));
-  unsigned long long u = 0;
-  VGX_HIP(ctx, hipMemcpyAsync(&u, I->dev.n_updates + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
+  unsigned long long u[3] = {0, 0, 0};
+  VGX_HIP(ctx, hipMemcpyAsync(u, I->dev.n_updates + 1, 24, hipMemcpyDeviceToHost, ctx->stream));
   VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  *steps = (int64_t)u;
+  for (int k = 0; k < 3; ++k) stats[k] = (int64_t)u[k];
   return VGX_OK;
 }
 

@@ -1,6 +1,7 @@
 // TSDF path, REPRODUCIBLE mode (vgx_tsdf_config.deterministic): voxblox::FastTsdfIntegrator::
-// integratePointCloud as it runs with integrator_threads = 1 and integration_order_mode "mixed"
-// (the order oracle/tsdf_oracle.c restates; call site voxgraph/src/frontend/measurement_processors/
+// integratePointCloud as it runs with integrator_threads = 1 in either integration_order_mode -- "mixed"
+// (computed in the kernels) or "sorted" (a table built by a stable radix sort, vgx_tsdf.hip visiting_order)
+// (the orders oracle/tsdf_oracle.c restates; call site voxgraph/src/frontend/measurement_processors/
 // pointcloud_integrator.cpp:83), resolved in parallel.
 //
 // What makes the integrator order dependent is (a) the two approximate hash sets -- whether a ray is
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(256) void det_points_kernel(vgx_tsdf_config c, floa
                                                         float qz, float tx, float ty, float tz,
                                                         const float* __restrict__ points_C,
                                                         const uint32_t* __restrict__ rgba, long long n,
+                                                        const uint32_t* __restrict__ order,
                                                         int freespace_points, unsigned long long start_offset,
                                                         float4* __restrict__ ray_pg, uint32_t* __restrict__ ray_color,
                                                         uint32_t* __restrict__ ray_flags,
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(256) void det_points_kernel(vgx_tsdf_config c, floa
                                                         uint32_t* __restrict__ start_key) {
   const long long seq = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (seq >= n) return;
-  const long long pi = mixed_order_point(seq, n);
+  const long long pi = visiting_order_point(order, seq, n);
   const float px = points_C[3 * pi], py = points_C[3 * pi + 1], pz = points_C[3 * pi + 2];
   // isPointValid
   bool valid = true, is_clearing = false;
@@ -957,7 +959,7 @@ static int det_commit(vgx_tsdf_integrator I, DetScratch* S, const float T[7], si
 }
 
 int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points, const void* d_rgba, int64_t n,
-                  int32_t freespace, int64_t* n_updates) {
+                  int32_t freespace, const uint32_t* order, int64_t* n_updates) {
   vgx_ctx ctx = I->ctx;
   vgx_tsdf_layer layer = I->layer;
   const vgx_tsdf_config& c = I->dev.cfg;
@@ -982,7 +984,7 @@ int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points,
   DET_TRY(grow(ctx, S->broke, np));
   VGX_HIP(ctx, hipMemsetAsync(S->d_ctr, 0, kCtrCount * 8, st));
   hipLaunchKernelGGL(det_points_kernel, dim3(blocks_for(np)), dim3(256), 0, st, c, vsi, T[0], T[1], T[2], T[3], T[4], T[5],
-                     T[6], (const float*)d_points, (const uint32_t*)d_rgba, (long long)n, (int)freespace,
+                     T[6], (const float*)d_points, (const uint32_t*)d_rgba, (long long)n, order, (int)freespace,
                      I->dev.start_offset, S->ray_pg.as<float4>(), S->ray_color.as<uint32_t>(), S->ray_flags.as<uint32_t>(),
                      S->start_val.as<unsigned long long>(), S->start_key.as<uint32_t>());
   VGX_HIP(ctx, hipGetLastError());

@@ -177,6 +177,11 @@ __device__ __forceinline__ long long mixed_order_point(long long seq, long long 
   if (seq < number_of_groups * step_size) return (seq % number_of_groups) * step_size + seq / number_of_groups;
   return seq;
 }
+// ThreadSafeIndex::getNextIndex: the point visited seq-th -- SortedThreadSafeIndex's table when there is one
+// (vgx_tsdf_config.integration_order = VGX_TSDF_ORDER_SORTED), else MixedThreadSafeIndex
+__device__ __forceinline__ long long visiting_order_point(const uint32_t* __restrict__ order, long long seq, long long n) {
+  return order ? (long long)order[seq] : mixed_order_point(seq, n);
+}
 
 // kindr::minimal transform of a sensor-frame point: Eigen _transformVector + translation
 __device__ __forceinline__ void transform_point(float qw, float qx, float qy, float qz, float tx, float ty, float tz,
@@ -244,6 +249,12 @@ struct vgx_tsdf_integrator_s {
   size_t msort_bytes = 0;
   long long merged_cap = 0;
   vgx::DetScratch* det = nullptr;  // reproducible mode's buffers (vgx_tsdf_det.hip), grown on demand
+  // integration_order "sorted": squared-norm keys / point indices (double-buffered) + radix-sort workspace
+  uint32_t* d_okey[2] = {nullptr, nullptr};
+  uint32_t* d_oidx[2] = {nullptr, nullptr};
+  void* d_osort = nullptr;
+  size_t osort_bytes = 0;
+  long long order_cap = 0;
 };
 
 namespace vgx {
@@ -253,8 +264,9 @@ int64_t tsdf_last_scan_bound(vgx_tsdf_layer L);
 void tsdf_request_readback(vgx_tsdf_layer L);
 // vgx_tsdf_det.hip: one scan in the reproducible mode (vgx_tsdf_config.deterministic); the caller
 // holds the integrator's and the context's locks, the approximate sets have been reset for the scan
+// `order`: order[seq] = index of the point visited seq-th (integration_order "sorted"), nullptr = "mixed"
 int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points, const void* d_rgba, int64_t n,
-                  int32_t freespace, int64_t* n_updates);
+                  int32_t freespace, const uint32_t* order, int64_t* n_updates);
 // the merged integrator's rays (merged point / colour / flags / ray length per group, groups in key order)
 // applied voxel by voxel in group order
 int det_merged_commit(vgx_tsdf_integrator I, const float T[7], long long n, const float4* g_pg, const uint32_t* g_color,
