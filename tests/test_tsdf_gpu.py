@@ -163,6 +163,10 @@ def test_dense_scan_invariants_with_early_out_disabled(capi, ctx):
     gD, gW, gA = _grids(*gl.download()[:3], vps, lo, hi)
     assert np.array_equal(oA, gA)
     assert np.array_equal(oW, gW)                   # exact: integer ray counts
+    # a voxel crossed by exactly ONE ray took one update: no order to depend on -- bit for bit (an
+    # exactness check the racing mode can be held to on a dense scan)
+    one = oW == 1
+    assert one.sum() > 1000 and np.array_equal(oD[one].view(np.uint32), gD[one].view(np.uint32)), one.sum()
     diff = np.abs(gD - oD)[oW > 0]
     print("dense scan: updates", a, b, "voxels", (oW > 0).sum(), "p99/p99.9/max |dd|",
           np.percentile(diff, 99), np.percentile(diff, 99.9), diff.max())
@@ -189,41 +193,52 @@ def test_full_scan_with_shipped_config_agrees_statistically(capi, ctx):
     ocfg_seq = orc.voxgraph_tsdf_config(integration_order=0)
     ol, ol2 = orc.TsdfLayer(vs, vps), orc.TsdfLayer(vs, vps)
     oi, oi2 = orc.FastTsdfIntegrator(ocfg, ol), orc.FastTsdfIntegrator(ocfg_seq, ol2)
-    gl = capi.TsdfLayer(ctx, vs, vps, (-3, -3, -2), (6, 6, 4), 144)
-    gi = capi.FastTsdfIntegrator(ctx, gcfg, gl)
-    tot_o = tot_o2 = tot_g = 0
+    scans = []
+    tot_o = tot_o2 = 0
     for k in range(5):
         pts = _lidar_scan(1024, 64, 10 + k)
         T = np.array([1, 0, 0, 0, 0.15 * k, -0.1 * k, 0.02 * k], F)
         pts = (pts - T[4:]).astype(F)               # same room seen from the moved sensor
+        scans.append((T, pts))
         tot_o += oi.integratePointCloud(T, pts)
         tot_o2 += oi2.integratePointCloud(T, pts[::-1].copy())   # another legal order
-        tot_g += gi.integratePointCloud(T, pts)
-    assert gl.stats()[1] == 0
     lo, hi = (-48, -48, -32), (48, 48, 32)
     oD, oW, oA = _grids(*ol.download()[:3], vps, lo, hi)
     pD, pW, pA = _grids(*ol2.download()[:3], vps, lo, hi)
-    gD, gW, gA = _grids(*gl.download()[:3], vps, lo, hi)
-    print("updates oracle/oracle2/gpu:", tot_o, tot_o2, tot_g, "blocks:", oA.sum() // 4096, gA.sum() // 4096)
-    assert np.array_equal(oA, gA)                               # same blocks allocated
-    assert abs(tot_g - tot_o) < max(0.25 * tot_o, 2 * abs(tot_o2 - tot_o))
-    both, ref_both = (oW > 0) & (gW > 0), (oW > 0) & (pW > 0)
-    print("observed voxels oracle/oracle2/gpu:", (oW > 0).sum(), (pW > 0).sum(), (gW > 0).sum(),
-          "common with oracle:", ref_both.sum(), both.sum())
-    # which free-space voxels a ray still reaches before its early-out depends on the
-    # interleaving; the observed regions overlap, they are not identical
-    assert both.sum() > 0.90 * ref_both.sum()
-    band = both & ref_both & (np.abs(oD) < 0.9 * trunc)
-    err, ref = np.abs(gD - oD)[band], np.abs(pD - oD)[band]
+    ref_both = (oW > 0) & (pW > 0)
     q = [50, 90, 99]
-    print("band voxels", band.sum(), "GPU-vs-oracle p50/p90/p99:", np.percentile(err, q),
-          "oracle-vs-reordered-oracle:", np.percentile(ref, q))
-    assert band.sum() > 10000
-    # the GPU may differ from the single-thread oracle by no more than another legal
-    # order of the same oracle does (x2 + 2 % of a voxel: measured ratios 0.7-0.95 over many runs; the
-    # exact comparison of this scan is tests/test_tsdf_deterministic_gpu.py's, in the reproducible mode)
-    for p in q:
-        assert np.percentile(err, p) <= 2.0 * np.percentile(ref, p) + 0.02 * vs, p
+    # THREE racing sessions of the same scans (a race comes out differently every time): every one must pass the
+    # structural checks, and the MEDIAN of their error percentiles the tight bound (the bound was
+    # loosened to 2 x + 2 % in round 3 to keep single runs green; the median of three holds 1.5 x + 1 %)
+    runs = []
+    for run in range(3):
+        gl = capi.TsdfLayer(ctx, vs, vps, (-3, -3, -2), (6, 6, 4), 144)
+        gi = capi.FastTsdfIntegrator(ctx, gcfg, gl)
+        tot_g = sum(gi.integratePointCloud(T, pts) for T, pts in scans)
+        assert gl.stats()[1] == 0
+        gD, gW, gA = _grids(*gl.download()[:3], vps, lo, hi)
+        print("run", run, "updates oracle/oracle2/gpu:", tot_o, tot_o2, tot_g, "blocks:", oA.sum() // 4096, gA.sum() // 4096)
+        assert np.array_equal(oA, gA)                               # same blocks allocated
+        assert abs(tot_g - tot_o) < max(0.25 * tot_o, 2 * abs(tot_o2 - tot_o))
+        both = (oW > 0) & (gW > 0)
+        # which free-space voxels a ray still reaches before its early-out depends on the
+        # interleaving; the observed regions overlap, they are not identical
+        assert both.sum() > 0.90 * ref_both.sum()
+        band = both & ref_both & (np.abs(oD) < 0.9 * trunc)
+        assert band.sum() > 10000
+        err, ref = np.abs(gD - oD)[band], np.abs(pD - oD)[band]
+        runs.append((np.percentile(err, q), np.percentile(ref, q)))
+        print("band voxels", band.sum(), "GPU-vs-oracle p50/p90/p99:", runs[-1][0], "oracle-vs-reordered-oracle:", runs[-1][1])
+        if run < 2:
+            for o in (gi, gl):
+                o.destroy()
+    # the GPU may differ from the single-thread oracle by no more than another legal order of the same oracle
+    # does (measured ratios 0.7-0.95; the exact comparison of this scan is tests/test_tsdf_deterministic_gpu.py's)
+    med_err = np.median([r_[0] for r_ in runs], axis=0)
+    med_ref = np.median([r_[1] for r_ in runs], axis=0)
+    for j, p in enumerate(q):
+        assert med_err[j] <= 1.5 * med_ref[j] + 0.01 * vs, (p, med_err, med_ref)
+        assert all(r_[0][j] <= 2.0 * r_[1][j] + 0.02 * vs for r_ in runs), (p, runs)     # and no single run far out
     # the reconstructed wall x = +5 m (projective distance, near-normal rays)
     xs = (np.arange(lo[0], hi[0]) + 0.5) * vs
     sl = (slice(None), slice(40, 56), slice(30, 40))
@@ -320,6 +335,8 @@ def test_rgbd_fullsize_scan_invariants(capi, ctx):
     gD, gW, gA = _grids(*gl.download()[:3], vps, lo_v, hi_v)
     assert np.array_equal(oA, gA)
     assert np.array_equal(oW, gW)                    # integer ray counts: exact
+    one = oW == 1                                    # crossed by exactly one ray: order independent, bit for bit
+    assert one.sum() > 1000 and np.array_equal(oD[one].view(np.uint32), gD[one].view(np.uint32)), one.sum()
     diff = np.abs(gD - oD)[oW > 0]
     assert np.percentile(diff, 99) < 1e-4 and diff.max() <= 2 * trunc
     for o in (gi, gl):

@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256) void merged_bundle_kernel(vgx_tsdf_config c, f
   g_count[seq] = 0u;
   if (seq == 0) {
     g_count[n] = 0u;
-    counters[0] = counters[1] = counters[2] = counters[3] = 0u;
+    counters[0] = counters[1] = counters[2] = counters[3] = counters[4] = 0u;  // [4]: a group's ray too long
   }
   const long long pi = visiting_order_point(order, seq, n);  // ThreadSafeIndex: "mixed" or "sorted"
   const float px = points_C[3 * pi], py = points_C[3 * pi + 1], pz = points_C[3 * pi + 2];
@@ -476,7 +476,8 @@ __global__ __launch_bounds__(256) void merged_merge_kernel(vgx_tsdf_config c, fl
                                                           const unsigned int* __restrict__ counters,
                                                           float4* __restrict__ g_pg, uint32_t* __restrict__ g_color,
                                                           uint32_t* __restrict__ g_flags,
-                                                          uint32_t* __restrict__ g_count) {
+                                                          uint32_t* __restrict__ g_count,
+                                                          unsigned int* __restrict__ too_long) {
   const int lane = threadIdx.x & (L - 1);
   const unsigned int n_sub = gridDim.x * (blockDim.x / L);
   const unsigned int G = counters[0], n_valid = counters[3];
@@ -526,6 +527,8 @@ __global__ __launch_bounds__(256) void merged_merge_kernel(vgx_tsdf_config c, fl
         if (!r.bad && r.steps + 1 < (1ll << 24)) {
           flags |= kGroupValid;
           count = (uint32_t)(r.steps + 1);
+        } else if (!r.bad) {
+          *too_long = 1u;  // the step index is packed into 24 bits: the scan is refused (as the fast path does)
         }
       }
       g_pg[g] = make_float4(gx, gy, gz, mw);
@@ -1214,7 +1217,18 @@ static int integrate_locked(vgx_tsdf_integrator I, const float T[7], const void*
       rc = visiting_order(I, d_points, n, &order);
       if (rc != VGX_OK) return rc;
       rc = det_integrate(I, T, d_points, d_rgba, n, freespace, order, n_updates);
-      if (rc == VGX_OK) request_readback(I->layer);
+      if (rc == VGX_OK) {
+        request_readback(I->layer);
+      } else {
+        // The scan stopped half way: its start set is written, its observed set and its voxels are not.  With
+        // clear_checks_every_n_frames > 1 a retried scan would find its own start cells present and cast
+        // nothing.  Forget both sets -- what the next resetApproxSet would do -- and keep the error.
+        const std::string why = vgx_last_error(ctx);
+        I->reset_counter = 0;
+        (void)reset_set(ctx, I->dev.start_set, &I->dev.start_offset);
+        (void)reset_set(ctx, I->dev.observed_set, &I->dev.observed_offset);
+        set_error(ctx, rc, why);
+      }
       return rc;
     }
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
@@ -1276,7 +1290,7 @@ static int merged_integrate_locked(vgx_tsdf_integrator I, const float T[7], cons
       VGX_HIP(ctx, hipMalloc(&I->d_gcolor, (size_t)n * 4));
       VGX_HIP(ctx, hipMalloc(&I->d_gflags, (size_t)n * 4));
       VGX_HIP(ctx, hipMalloc(&I->d_gcount, ((size_t)n + 1) * 4));
-      if (!I->d_mcounters) VGX_HIP(ctx, hipMalloc(&I->d_mcounters, 16));
+      if (!I->d_mcounters) VGX_HIP(ctx, hipMalloc(&I->d_mcounters, 32));
       size_t bytes = 0, b2 = 0;
       VGX_HIP(ctx, rocprim::radix_sort_pairs(nullptr, bytes, I->d_mkeys[0], I->d_mkeys[1], I->d_midx[0], I->d_midx[1],
                                              (size_t)n, 0, 64, ctx->stream));
@@ -1321,7 +1335,8 @@ static int merged_integrate_locked(vgx_tsdf_integrator I, const float T[7], cons
     const unsigned work_groups = (unsigned)std::min<long long>(((long long)n * kLanes + 255) / 256, (long long)ctx->cu_count * 16);
     hipLaunchKernelGGL(merged_merge_kernel<kLanes>, dim3(work_groups), block, 0, ctx->stream, c, I->layer->dev.voxel_size_inv,
                        T[0], T[1], T[2], T[3], T[4], T[5], T[6], (const float*)d_points, (const uint32_t*)d_rgba, keys_sorted,
-                       idx_sorted, I->d_mstart, I->d_mcounters, I->d_gpg, I->d_gcolor, I->d_gflags, I->d_gcount);
+                       idx_sorted, I->d_mstart, I->d_mcounters, I->d_gpg, I->d_gcolor, I->d_gflags, I->d_gcount,
+                       I->d_mcounters + 4);
     VGX_HIP(ctx, hipGetLastError());
     // integrateRays.  Every ray crosses the sensor's own neighbourhood, so those voxels take one update
     // per group: thousands of rays contending for one compare-and-swap (measured: 30 ms per RGB-D

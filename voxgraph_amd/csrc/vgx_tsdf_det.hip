@@ -1170,13 +1170,24 @@ int det_merged_commit(vgx_tsdf_integrator I, const float T[7], long long n, cons
     bytes = S->tmp.bytes;
     VGX_HIP(ctx, rocprim::exclusive_scan(S->tmp.p, bytes, g_count, S->off.as<uint32_t>(), 0u, G + 1, rocprim::plus<uint32_t>(), st));
   }
-  uint32_t total = 0;
+  uint32_t total = 0, too_long = 0;
   VGX_HIP(ctx, hipMemcpyAsync(&total, S->off.as<uint32_t>() + G, 4, hipMemcpyDeviceToHost, st));
+  VGX_HIP(ctx, hipMemcpyAsync(&too_long, counters + 4, 4, hipMemcpyDeviceToHost, st));
   VGX_HIP(ctx, hipStreamSynchronize(st));
+  if (too_long)  // (merged_merge_kernel: the fast path raises the same error for the same condition)
+    return set_error(ctx, VGX_ERR_UNSUPPORTED, "TSDF merged integrator: a ray longer than 2^24 voxel steps");
   {
+    // the 32-bit total wraps silently.  Cheap bound first -- no ray is longer than max_steps, and there are
+    // at most n groups; only when that does not settle it, the exact 64-bit sum of the groups' ray lengths
     const double max_steps = 3.0 * ((double)c.max_ray_length_m + 2.0 * c.default_truncation_distance) * I->layer->dev.voxel_size_inv + 8.0;
-    if ((double)G * max_steps >= 4.0e9)
-      return set_error(ctx, VGX_ERR_UNSUPPORTED, "TSDF merged integrator: more than 2^32 voxel steps in a scan");
+    if ((double)G * max_steps >= 4.0e9) {
+      std::vector<uint32_t> cnt(G);
+      VGX_HIP(ctx, hipMemcpy(cnt.data(), g_count, G * 4, hipMemcpyDeviceToHost));
+      unsigned long long sum = 0;
+      for (uint32_t v : cnt) sum += v;
+      if (sum >= (1ull << 32) - 2)
+        return set_error(ctx, VGX_ERR_UNSUPPORTED, "TSDF merged integrator: more than 2^32 voxel steps in a scan");
+    }
   }
   const size_t N = total;
   if (N == 0) return VGX_OK;

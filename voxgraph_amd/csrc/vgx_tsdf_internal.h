@@ -240,7 +240,7 @@ struct vgx_tsdf_integrator_s {
   unsigned int* d_midx[2] = {nullptr, nullptr};
   unsigned int* d_mstart = nullptr;
   unsigned int* d_mrank = nullptr;     // rank of every sorted entry's group
-  unsigned int* d_mcounters = nullptr; // {groups, surface entries, surface groups, valid entries}
+  unsigned int* d_mcounters = nullptr; // {groups, surface entries, surface groups, valid entries, a ray too long}
   float4* d_gpg = nullptr;             // per group: merged point (layer frame) + merged weight
   uint32_t* d_gcolor = nullptr;
   uint32_t* d_gflags = nullptr;
