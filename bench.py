@@ -428,17 +428,26 @@ def main():
         parity_entries.append(e)
 
     # ---- fused pass + all-reduce (solver-iteration form), reported separately --
-    def fused_bench(bt, ps, n_nodes, n_global, corr_total, evals_total, ref_cost, traffic_key):
+    def fused_bench(bt, ps, n_nodes, n_global, corr_total, evals_total, ref_cost, traffic_key, pairs_global):
         size = capi.fused_size(n_nodes, n_global)
         tr = (PROFILE_TRAFFIC.get("fused") or {}).get(traffic_key) or {}
         tr_bytes = tr.get("hbm_bytes_per_launch") if (tr.get("evaluations") == evals_total and world == 1) else None
         buf = torch.zeros(size, dtype=torch.float64, device="cuda")
+        # N ranks: ONE all-reduce of the [n_global][45] array of per-constraint blocks (a row is written by exactly
+        # one rank: the sum is exact in any order), then every rank assembles the fused buffer in list order --
+        # the single-GPU buffer bit for bit at every N (include/voxgraph_amd.h "Sharding-independent assembly")
+        blocks = torch.zeros((n_global, capi.NORMAL_SIZE), dtype=torch.float64, device="cuda") if use_dist else None
+        assembler = capi.RegistrationAssembler(ctx, pairs_global) if use_dist else None
+        torch.cuda.synchronize()
 
         def fused_step():
             bt.evaluate_normal(ps, to_host=False)
-            bt.assemble(n_nodes, buf.data_ptr(), zero_first=True)
             if use_dist:
-                dist.all_reduce(buf)
+                bt.scatter_normal(blocks.data_ptr(), zero_first=True)
+                dist.all_reduce(blocks)
+                assembler.assemble(blocks.data_ptr(), n_nodes, buf.data_ptr())
+            else:
+                bt.assemble(n_nodes, buf.data_ptr(), zero_first=True)
 
         for _ in range(2):
             fused_step()
@@ -487,8 +496,11 @@ def main():
                "traffic_from_profiles": tr_bytes,
                "hbm_frac": (tr_bytes / (f_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr_bytes else None,
                "value_with_correspondence": corr_total * n_f / fdt / 1e6,
-               "allreduce_bytes": int(size * 8) if use_dist else 0,
-               "cost": float(buf[0].item()), "cost_vs_materialised": None}
+               "allreduce_bytes": int(n_global * capi.NORMAL_SIZE * 8) if use_dist else 0,
+               "cost": float(buf[0].item()), "cost_vs_materialised": None,
+               "fused_sha256": __import__("hashlib").sha256(buf.cpu().numpy().tobytes()).hexdigest()}
+        if assembler:
+            assembler.destroy()
         if world == 1 and ref_cost is not None:
             out["cost_vs_materialised"] = abs(out["cost"] - ref_cost) / max(ref_cost, 1e-30)
         return out
@@ -496,11 +508,11 @@ def main():
     fused = None
     fused_fo = None
     if not args.no_fused:
-        fused = fused_bench(batch, poses, n_sub, n_con, with_corr_total, total_evals, checksum, "config3")
+        fused = fused_bench(batch, poses, n_sub, n_con, with_corr_total, total_evals, checksum, "config3", pairs)
         if fo:
             fo_cost = float(residuals[:fo["R"]].double().pow(2).sum().item()) if world == 1 else None
             fused_fo = fused_bench(fo["batch"], fo["poses"], len(fo["poses"]), fo["n"],
-                                   fo_out["with_corr_total"], fo_out["R_total"], fo_cost, "full_overlap")
+                                   fo_out["with_corr_total"], fo_out["R_total"], fo_cost, "full_overlap", pairs_fo)
 
     # ---- the reference's SHIPPED configuration (voxgraph_mapper.yaml:34-35): explicit_to_implicit =
     # isosurface points, sampling_ratio 0.05, both directions of every pair (pose_graph.cpp:62-71),
@@ -513,16 +525,23 @@ def main():
         pairs_s = [(int(a), int(b)) for c in shard for a, b in (pairs[c], pairs[c][::-1])]
         gidx_s = [2 * c + k for c in shard for k in (0, 1)]
         buf_s = torch.zeros(capi.fused_size(n_sub, 2 * n_con), dtype=torch.float64, device="cuda")
+        pairs_s_global = [(int(a), int(b)) for c in range(n_con) for a, b in (pairs[c], pairs[c][::-1])]
+        blocks_s = torch.zeros((2 * n_con, capi.NORMAL_SIZE), dtype=torch.float64, device="cuda") if use_dist else None
 
         def shipped_eval(ctx_s, submaps_s):
             cfs_s = [capi.RegistrationCostFunction(ctx_s, submaps_s[a], submaps_s[b], cfg_s) for a, b in pairs_s]
             batch_s = capi.RegistrationBatch(ctx_s, cfs_s, pairs_s, global_index=gidx_s, n_global=2 * n_con)
 
+            asm_s = capi.RegistrationAssembler(ctx_s, pairs_s_global) if use_dist else None
+
             def shipped_step():
                 batch_s.evaluate_normal(poses, to_host=False)
-                batch_s.assemble(n_sub, buf_s.data_ptr(), zero_first=True)
                 if use_dist:
-                    dist.all_reduce(buf_s)
+                    batch_s.scatter_normal(blocks_s.data_ptr(), zero_first=True)
+                    dist.all_reduce(blocks_s)
+                    asm_s.assemble(blocks_s.data_ptr(), n_sub, buf_s.data_ptr())
+                else:
+                    batch_s.assemble(n_sub, buf_s.data_ptr(), zero_first=True)
 
             for _ in range(2):
                 shipped_step()
@@ -546,7 +565,7 @@ def main():
                  "stream_ms_per_evaluation": stream_ms,
                  "Mresiduals_per_s": float(rs.item()) * n_s / float(sdt.item()) / 1e6,
                  "cost": float(buf_s[0].item())}
-            for o in [batch_s] + cfs_s:
+            for o in [batch_s] + cfs_s + ([asm_s] if asm_s else []):
                 o.destroy()
             return e
         shipped = {"config": "registration_method explicit_to_implicit (isosurface points), sampling_ratio 0.05, "
@@ -626,7 +645,7 @@ def main():
         info = [1.0, 1.0, 2500.0, 2500.0]                       # voxgraph_mapper.yaml:41-47
         edges = [lm.RelativePoseEdge.from_poses(k, k + 1, poses[k], poses[k + 1], info)
                  for k in range(n_sub - 1)]
-        backend = GpuBackend(capi, ctx, batch, n_sub, dist if use_dist else None)
+        backend = GpuBackend(capi, ctx, batch, n_sub, dist if use_dist else None, node_pair_global=pairs)
         backend(poses)                                           # warm
 
         def rmse(p):

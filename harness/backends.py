@@ -4,14 +4,25 @@ import numpy as np
 
 
 class GpuBackend:
-    """vgx_reg_batch_evaluate_normal -> vgx_reg_batch_assemble -> (RCCL all-reduce)."""
+    """One solver evaluation of the registration constraints of this rank's shard:
+    vgx_reg_batch_evaluate_normal -> vgx_reg_batch_scatter_normal -> ONE all-reduce(sum, f64) of the
+    [n_global][45] array of per-constraint blocks (RCCL under torch.distributed) -> vgx_reg_assembler_assemble.
+    Every row of the array is written by exactly one rank, so the sum is exact in any order and every rank
+    assembles the single-GPU buffer bit for bit, whatever the number of ranks (include/voxgraph_amd.h).
+    Without torch.distributed the batch holds the whole list and assembles directly."""
 
-    def __init__(self, capi, ctx, batch, n_nodes, dist=None):
+    def __init__(self, capi, ctx, batch, n_nodes, dist=None, node_pair_global=None):
         import torch
         self.torch, self.ctx, self.batch, self.n_nodes, self.dist = torch, ctx, batch, n_nodes, dist
         self.buf = torch.zeros(capi.fused_size(n_nodes, batch.n_global), dtype=torch.float64,
                                device="cuda")
         self.host = torch.zeros_like(self.buf, device="cpu").pin_memory()
+        self.sharded = dist is not None and dist.is_initialized()
+        if self.sharded:
+            if node_pair_global is None or len(node_pair_global) != batch.n_global:
+                raise ValueError("a sharded backend needs the whole list's node pairs (node_pair_global)")
+            self.assembler = capi.RegistrationAssembler(ctx, node_pair_global)
+            self.blocks = torch.zeros((batch.n_global, capi.NORMAL_SIZE), dtype=torch.float64, device="cuda")
         # the zero-fill above ran on torch's stream; the library writes the buffer on ITS stream
         torch.cuda.current_stream().synchronize()
 
@@ -20,14 +31,20 @@ class GpuBackend:
 
     def __call__(self, poses):
         self.batch.evaluate_normal(poses, to_host=False)
-        self.batch.assemble(self.n_nodes, self.buf.data_ptr(), zero_first=True)
-        if self.dist is not None and self.dist.is_initialized():
-            # the all-reduce is ordered after torch's current stream; the assembly ran on the
+        if self.sharded:
+            self.batch.scatter_normal(self.blocks.data_ptr(), zero_first=True)
+            # the all-reduce is ordered after torch's current stream; the scatter ran on the
             # library's stream.  Same stream (ctx.set_stream(torch's), as bench.py does): stream
-            # order suffices.  Otherwise the buffer must be complete before RCCL reads it.
-            if not self._library_stream_is_torchs():
+            # order suffices.  Otherwise the array must be complete before RCCL reads it.
+            same = self._library_stream_is_torchs()
+            if not same:
                 self.ctx.synchronize()
-            self.dist.all_reduce(self.buf)
+            self.dist.all_reduce(self.blocks)
+            if not same:
+                self.torch.cuda.current_stream().synchronize()
+            self.assembler.assemble(self.blocks.data_ptr(), self.n_nodes, self.buf.data_ptr())
+        else:
+            self.batch.assemble(self.n_nodes, self.buf.data_ptr(), zero_first=True)
         # order the copy after the library's kernels (no-op wait when everything is drained)
         self.ctx.synchronize()
         self.host.copy_(self.buf, non_blocking=True)

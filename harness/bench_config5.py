@@ -83,7 +83,7 @@ def config5_bench(capi, ctx, torch, dist, use_dist, rank, world, args):
     mine = lpt_shards([n_points[a] for a, _ in pairs], world)[rank]
     cfs = [capi.RegistrationCostFunction(ctx, submaps[pairs[c][0]], submaps[pairs[c][1]], cfg) for c in mine]
     batch = capi.RegistrationBatch(ctx, cfs, pairs[mine], global_index=mine, n_global=len(pairs))
-    backend = GpuBackend(capi, ctx, batch, n, dist if use_dist else None)
+    backend = GpuBackend(capi, ctx, batch, n, dist if use_dist else None, node_pair_global=pairs)
 
     def barrier():
         if use_dist:
@@ -186,7 +186,7 @@ def config5_bench(capi, ctx, torch, dist, use_dist, rank, world, args):
                         "except through submap 0's own few constraints)",
            "stop_rule": "function_tolerance 1e-6 (Ceres default) in both stages, parameter_tolerance off",
            "parallelism": f"pair-sharded x{world} (LPT), submaps replicated, one all-reduce of "
-                          f"{capi.fused_size(n, len(pairs)) * 8} B per evaluation",
+                          f"{len(pairs) * capi.NORMAL_SIZE * 8} B (the per-constraint blocks) per evaluation",
            "setup_s": setup_s,
            "solver": "harness/lm.py (LM, banded Cholesky on the host; Ceres absent)"}
     if rank == 0 and not args.no_parity:

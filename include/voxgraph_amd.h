@@ -44,6 +44,7 @@ typedef struct vgx_submap_s* vgx_submap;
 typedef struct vgx_reg_s* vgx_reg;
 typedef struct vgx_reg_batch_s* vgx_reg_batch;
 typedef struct vgx_reg_multi_s* vgx_reg_multi;
+typedef struct vgx_reg_assembler_s* vgx_reg_assembler;
 
 /* ---- context ----------------------------------------------------------- */
 /* One context per process per GPU (one process per GPU is the multi-GPU
@@ -306,6 +307,26 @@ VGX_API int vgx_reg_batch_assemble(vgx_reg_batch batch, const void* d_normal,
                                    int32_t zero_first);
 VGX_API int64_t vgx_reg_fused_size(int32_t n_nodes, int32_t n_global);
 
+/* Sharding-independent assembly (round 4).  vgx_reg_batch_assemble sums a node's entries over the shard's
+ * own constraints, so a sum of per-shard fused buffers depends, in its last bits, on how the list was
+ * sharded and on the order a collective adds in.  Exchanging the per-constraint BLOCKS instead makes the
+ * result the single-GPU one bit for bit, for any number of shards:
+ *   1. every shard:  vgx_reg_batch_evaluate_normal, then vgx_reg_batch_scatter_normal writes its [n][45]
+ *      blocks (d_normal NULL: the batch's own) into rows global_index[c] of a DEVICE [n_global][45] f64
+ *      array, zeroed first when zero_first != 0;
+ *   2. ONE all-reduce(sum, f64) of that array (n_global x 360 B: 423 KB for 1176 constraints).  Every row
+ *      is written by exactly one shard and is zero everywhere else, so the sum is exact in ANY order;
+ *   3. vgx_reg_assembler_assemble builds the fused buffer (layout above, vgx_reg_fused_size(n_nodes, n))
+ *      from the complete array in list order -- what a single vgx_reg_batch over the whole list computes.
+ * The assembler holds the list's node structure (node_pair[n][2], the caller's constraint order) on `ctx`. */
+VGX_API int vgx_reg_batch_scatter_normal(vgx_reg_batch batch, const void* d_normal, void* d_normal_all,
+                                         int32_t zero_first);
+VGX_API int vgx_reg_assembler_create(vgx_ctx ctx, int32_t n, const int32_t* node_pair /* [n][2] */,
+                                     vgx_reg_assembler* out);
+VGX_API int vgx_reg_assembler_assemble(vgx_reg_assembler assembler, const void* d_normal_all, int32_t n_nodes,
+                                       void* d_fused);
+VGX_API int vgx_reg_assembler_destroy(vgx_reg_assembler assembler);
+
 /* Host-side helper for solvers that want residual blocks (Ceres), not normal equations:
  * turns one constraint's 45-number block N = [J r]^T [J r] into a 9-residual block with
  * the same normal equations, r_c[9] and J_c[9][8] row-major (J_c^T J_c = J^T J,
@@ -331,20 +352,24 @@ VGX_API int vgx_reg_multi_create(int32_t n_ctx, const vgx_ctx* ctxs, int32_t n, 
                                  const int32_t* node_pair /* [n][2] */, vgx_reg_multi* out);
 VGX_API int vgx_reg_multi_destroy(vgx_reg_multi multi);
 VGX_API int32_t vgx_reg_multi_num_shards(vgx_reg_multi multi);
-/* How the contexts' fused buffers meet (default VGX_REDUCE_PEER_SUM: context 0 sums them in context
- * order through peer mappings -- bitwise reproducible).  VGX_REDUCE_RCCL: ONE ncclAllReduce(sum, f64)
- * of the buffer per solver evaluation over xGMI (BASELINE north_star; librccl.so is opened at run time,
- * one communicator per context from ncclCommInitAll, so every context needs its own device);
- * VGX_ERR_UNSUPPORTED if RCCL cannot be opened or two contexts share a device. */
+/* How the contexts' results meet on context 0.  Default VGX_REDUCE_PEER_SUM (the name is round 2's: since
+ * round 4 nothing is summed): context 0 GATHERS every constraint's [45] block from the context that computed
+ * it, through xGMI peer mappings, and assembles the fused buffer once, in list order.
+ * VGX_REDUCE_RCCL: ONE ncclAllReduce(sum, f64) per solver evaluation over xGMI (BASELINE north_star) of the
+ * [n][45] array of blocks, every context contributing its own rows and zeros elsewhere -- exact in any order
+ * -- then the same assembly (librccl.so is opened at run time, one communicator per context from
+ * ncclCommInitAll, so every context needs its own device; VGX_ERR_UNSUPPORTED if RCCL cannot be opened or two
+ * contexts share a device).  Either way the buffer is the one a single vgx_reg_batch over the whole list
+ * assembles, BIT FOR BIT, whatever the number of contexts and the placement. */
 #define VGX_REDUCE_PEER_SUM 0
 #define VGX_REDUCE_RCCL 1
 VGX_API int vgx_reg_multi_set_reduction(vgx_reg_multi multi, int32_t reduction);
 VGX_API int vgx_reg_multi_shard_of(vgx_reg_multi multi, int32_t* shard_of /* [n] */);
-/* One solver evaluation: every context runs vgx_reg_batch_evaluate_normal + vgx_reg_batch_assemble on
- * its share concurrently (own thread, own stream); context 0 then sums the per-context buffers in
- * context order, reading the other GPUs' buffers through xGMI peer mappings, and returns the fused
- * buffer of vgx_reg_batch_assemble's layout (vgx_reg_fused_size(n_nodes, n) doubles) to the host.
- * Fixed-order sum of deterministic partial buffers: bitwise reproducible.  status: [n], nullable. */
+/* One solver evaluation: every context runs vgx_reg_batch_evaluate_normal on its share concurrently (own
+ * thread, own stream); the per-constraint blocks meet on context 0 (see vgx_reg_multi_set_reduction), which
+ * assembles the fused buffer of vgx_reg_batch_assemble's layout (vgx_reg_fused_size(n_nodes, n) doubles) in
+ * list order and returns it to the host.  Bitwise reproducible and independent of the sharding.
+ * status: [n], nullable.  A context whose evaluation fails fails the call with that context's message. */
 VGX_API int vgx_reg_multi_evaluate_fused(vgx_reg_multi multi, const double* poses, int32_t n_nodes,
                                          double* fused_host, int32_t* status);
 /* The same pass for solvers that want residual blocks (Ceres through vgx_reg_compress_normal): the

@@ -36,12 +36,23 @@ def main():
     shards = lpt_shards([len(pts[a][2]) for a, _ in pairs], world)
     assert sorted(sum(shards, [])) == list(range(len(pairs)))
     mine = shards[rank]
+    full = assemble_fused([normal(c) for c in range(len(pairs))], pairs, 4)
+    # round 1-3 scheme: every rank assembles its shard, the fused buffers are summed -- equal to 1e-12 only
+    # (the association of a node's sum depends on the sharding)
     buf = assemble_fused([normal(c) for c in mine], [pairs[c] for c in mine], 4,
                          n_global=len(pairs), global_index=mine)
     t = torch.from_numpy(buf)
     dist.all_reduce(t)
-    full = assemble_fused([normal(c) for c in range(len(pairs))], pairs, 4)
     np.testing.assert_allclose(t.numpy(), full, rtol=1e-12, atol=1e-12)
+    # round 4 scheme (include/voxgraph_amd.h "Sharding-independent assembly", harness/backends.py GpuBackend):
+    # all-reduce the per-constraint BLOCKS -- every row written by exactly one rank, zero elsewhere, so the
+    # sum is exact in any order -- then assemble in list order on every rank: the unsharded buffer BIT FOR BIT
+    blocks = np.zeros((len(pairs), 45))
+    for c in mine:
+        blocks[c] = normal(c)
+    tb = torch.from_numpy(blocks)
+    dist.all_reduce(tb)
+    assert np.array_equal(assemble_fused(list(tb.numpy()), pairs, 4), full)
     dist.barrier()
     if rank == 0:
         print("SHARD_ALLREDUCE_OK")

@@ -129,6 +129,10 @@ SIGNATURES = {
     "vgx_reg_batch_count_live_each": (C.c_int, [vp, f64p, C.c_int32, i64p]),
     "vgx_reg_batch_assemble": (C.c_int, [vp, vp, C.c_int32, vp, C.c_int32]),
     "vgx_reg_fused_size": (C.c_int64, [C.c_int32, C.c_int32]),
+    "vgx_reg_batch_scatter_normal": (C.c_int, [vp, vp, vp, C.c_int32]),
+    "vgx_reg_assembler_create": (C.c_int, [vp, C.c_int32, i32p, C.POINTER(vp)]),
+    "vgx_reg_assembler_assemble": (C.c_int, [vp, vp, C.c_int32, vp]),
+    "vgx_reg_assembler_destroy": (C.c_int, [vp]),
     "vgx_lpt_shards": (C.c_int, [C.c_int32, i64p, C.c_int32, i32p]),
     "vgx_reg_multi_create": (C.c_int, [C.c_int32, C.POINTER(vp), C.c_int32, C.POINTER(vp), i32p, C.POINTER(vp)]),
     "vgx_reg_multi_destroy": (C.c_int, [vp]),
@@ -518,9 +522,36 @@ class RegistrationBatch:
         self.ctx.check(self.ctx.lib.vgx_reg_batch_assemble(
             self.h, vp(d_normal) if d_normal else None, n_nodes, vp(d_fused), int(zero_first)))
 
+    def scatter_normal(self, d_normal_all, d_normal=None, zero_first=True):
+        """this shard's [n][45] blocks into rows global_index[c] of the DEVICE [n_global][45] array"""
+        self.ctx.check(self.ctx.lib.vgx_reg_batch_scatter_normal(
+            self.h, vp(d_normal) if d_normal else None, vp(d_normal_all), int(zero_first)))
+
     def destroy(self):
         if self.h:
             self.ctx.lib.vgx_reg_batch_destroy(self.h)
+            self.h = None
+
+
+class RegistrationAssembler:
+    """vgx_reg_assembler: the whole constraint list's node structure on one context; builds the fused buffer from
+    the complete [n][45] array in list order (the sharding-independent assembly, include/voxgraph_amd.h)."""
+
+    def __init__(self, ctx, node_pair):
+        self.ctx = ctx
+        np_pair = np.ascontiguousarray(node_pair, dtype=np.int32).reshape(-1, 2)
+        self.n = len(np_pair)
+        h = vp()
+        ctx.check(ctx.lib.vgx_reg_assembler_create(ctx.h, self.n, _ptr(np_pair, i32p), C.byref(h)))
+        self.h = h
+
+    def assemble(self, d_normal_all, n_nodes, d_fused):
+        self.ctx.check(self.ctx.lib.vgx_reg_assembler_assemble(self.h, vp(d_normal_all) if d_normal_all else None,
+                                                               n_nodes, vp(d_fused)))
+
+    def destroy(self):
+        if self.h:
+            self.ctx.lib.vgx_reg_assembler_destroy(self.h)
             self.h = None
 
 
@@ -562,7 +593,7 @@ class RegistrationMulti:
         return out, status[:self.n]
 
     def set_reduction(self, rccl):
-        """False: fixed-order sum over peer mappings (default); True: one ncclAllReduce per evaluation"""
+        """False: the blocks gathered over peer mappings (default); True: one ncclAllReduce per evaluation"""
         self.ctxs[0].check(self.ctxs[0].lib.vgx_reg_multi_set_reduction(self.h, 1 if rccl else 0))
 
     def evaluate_normal(self, poses):

@@ -48,23 +48,18 @@ namespace vgx {
 
 constexpr int kMaxShards = 16;
 
-struct SumArgs {
-  const double* src[kMaxShards];
-  int n_src;
-};
-
-// out[i] = src[0][i] + src[1][i] + ... in that order
-__global__ void multi_sum_kernel(SumArgs a, long long n, double* __restrict__ out) {
+// all[g][.] = the block of global constraint g, read where its shard left it (src[g]: a pointer into that
+// shard's [n_local][45] array -- on another GPU it is reached through the xGMI peer mapping).  A copy, not a
+// sum: the complete array is the same whatever the placement was.
+__global__ void multi_gather_kernel(const double* const* __restrict__ src, long long n, double* __restrict__ all) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  double v = a.src[0][i];
-  for (int k = 1; k < a.n_src; ++k) v += a.src[k][i];
-  out[i] = v;
+  if (i >= n * kNormalSize) return;
+  all[i] = src[i / kNormalSize][i % kNormalSize];
 }
 
 // RCCL, opened on demand (VGX_REDUCE_RCCL): the alternative reduction SURVEY.md 8(e) asks to compare --
-// ONE ncclAllReduce(sum, f64) of the fused buffer per solver evaluation over xGMI, every context
-// contributing its own assembled buffer in place.  No link-time dependency: librccl.so.1 is whatever
+// ONE ncclAllReduce(sum, f64) per solver evaluation over xGMI of the [n][45] array of per-constraint blocks,
+// every context contributing its own rows in place (all other rows zero: the sum is exact in any order).  No link-time dependency: librccl.so.1 is whatever
 // copy the process already has (PyTorch's, when the bench drives this) or the ROCm one.
 struct RcclApi {
   void* handle = nullptr;
@@ -119,9 +114,8 @@ struct vgx_reg_multi_s {
     vgx_reg_batch batch = nullptr;
     std::vector<int32_t> global;   // global constraint index of local constraint c
     std::vector<int32_t> status;   // per local constraint
-    double* d_fused = nullptr;     // this shard's assembled buffer
+    double* d_all = nullptr;       // VGX_REDUCE_RCCL: [n][45], this shard's rows filled, the rest zero
     double* h_normal = nullptr;    // pinned [n_local][45]
-    int64_t fused_cap = 0;
     hipEvent_t done = nullptr;
     int rc = VGX_OK;
     std::thread th;
@@ -138,7 +132,11 @@ struct vgx_reg_multi_s {
   int mode = 0;                    // 0 fused, 1 per-constraint normal blocks to the host
   const double* poses = nullptr;
   int32_t n_nodes = 0;
-  // reduction on shard 0
+  // context 0: the complete [n][45] array (gathered from the shards), the list's node structure, the fused
+  // buffer it assembles and its pinned mirror
+  double* d_normal_all = nullptr;
+  const double** d_src = nullptr;  // [n] where each constraint's block lies (peer pointers)
+  vgx_reg_assembler assembler = nullptr;
   double* d_sum = nullptr;
   double* h_sum = nullptr;         // pinned
   int64_t sum_cap = 0;
@@ -154,7 +152,8 @@ static void run_shard(vgx_reg_multi_s* m, vgx_reg_multi_s::Shard& s) {
   if (m->mode == 0) {
     s.rc = vgx_reg_batch_evaluate_normal(s.batch, m->poses, m->n_nodes, nullptr, nullptr,
                                          nl ? s.status.data() : nullptr);
-    if (s.rc == VGX_OK) s.rc = vgx_reg_batch_assemble(s.batch, nullptr, m->n_nodes, s.d_fused, 1);
+    if (s.rc == VGX_OK && m->reduction == VGX_REDUCE_RCCL)
+      s.rc = vgx_reg_batch_scatter_normal(s.batch, nullptr, s.d_all, 1);
     if (s.rc == VGX_OK && (hipSetDevice(s.ctx->device) != hipSuccess ||
                            hipEventRecord(s.done, s.ctx->stream) != hipSuccess))
       s.rc = VGX_ERR_HIP;
@@ -235,11 +234,14 @@ int vgx_reg_multi_destroy(vgx_reg_multi m) {
   for (auto& s : m->shards) {
     (void)hipSetDevice(s->ctx->device);
     if (s->batch) vgx_reg_batch_destroy(s->batch);
-    if (s->d_fused) (void)hipFree(s->d_fused);
+    if (s->d_all) (void)hipFree(s->d_all);
     if (s->h_normal) (void)hipHostFree(s->h_normal);
     if (s->done) (void)hipEventDestroy(s->done);
   }
   if (!m->shards.empty()) (void)hipSetDevice(m->shards[0]->ctx->device);
+  if (m->assembler) vgx_reg_assembler_destroy(m->assembler);
+  if (m->d_normal_all) (void)hipFree(m->d_normal_all);
+  if (m->d_src) (void)hipFree((void*)m->d_src);
   if (m->d_sum) (void)hipFree(m->d_sum);
   if (m->h_sum) (void)hipHostFree(m->h_sum);
   delete m;
@@ -309,6 +311,21 @@ int vgx_reg_multi_create(int32_t n_ctx, const vgx_ctx* ctxs, int32_t n, const vg
       }
     }
   }
+  // context 0: the list's node structure and the table of where every constraint's block will lie
+  if (rc == VGX_OK) {
+    rc = vgx_reg_assembler_create(ctx0, n, node_pair, &m->assembler);
+    if (rc == VGX_OK && n > 0) {
+      std::vector<const double*> src((size_t)n, nullptr);
+      for (auto& sp : m->shards)
+        for (size_t c = 0; c < sp->global.size(); ++c)
+          src[(size_t)sp->global[c]] = sp->batch->d_normal + c * kNormalSize;
+      if (hipSetDevice(ctx0->device) != hipSuccess ||
+          hipMalloc((void**)&m->d_src, (size_t)n * sizeof(double*)) != hipSuccess ||
+          hipMemcpy((void*)m->d_src, src.data(), (size_t)n * sizeof(double*), hipMemcpyHostToDevice) != hipSuccess ||
+          hipMalloc(&m->d_normal_all, (size_t)n * kNormalSize * sizeof(double)) != hipSuccess)
+        rc = set_error(ctx0, VGX_ERR_NOMEM, "vgx_reg_multi_create: context 0's gather buffers");
+    }
+  }
   if (rc != VGX_OK) {
     vgx_reg_multi_destroy(m);
     return rc;
@@ -342,6 +359,12 @@ int vgx_reg_multi_set_reduction(vgx_reg_multi m, int32_t reduction) {
       return set_error(ctx0, VGX_ERR_HIP, std::string("ncclCommInitAll: ") + api.GetErrorString(r));
     }
   }
+  if (reduction == VGX_REDUCE_RCCL)
+    for (auto& sp : m->shards)
+      if (!sp->d_all) {
+        VGX_HIP(ctx0, hipSetDevice(sp->ctx->device));
+        VGX_HIP(ctx0, hipMalloc(&sp->d_all, std::max<size_t>((size_t)m->n * kNormalSize * sizeof(double), 8)));
+      }
   m->reduction = reduction;
   return VGX_OK;
 }
@@ -359,18 +382,6 @@ int vgx_reg_multi_evaluate_fused(vgx_reg_multi m, const double* poses, int32_t n
   std::lock_guard<std::mutex> call(m->call_mu);
   vgx_ctx ctx0 = m->shards[0]->ctx;
   const int64_t size = vgx_reg_fused_size(n_nodes, m->n);
-  // (re)size the per-shard buffers and the reduction buffers
-  for (auto& sp : m->shards) {
-    vgx_reg_multi_s::Shard& s = *sp;
-    if (s.fused_cap >= size) continue;
-    VGX_HIP(ctx0, hipSetDevice(s.ctx->device));
-    VGX_HIP(ctx0, hipStreamSynchronize(s.ctx->stream));
-    if (s.d_fused) (void)hipFree(s.d_fused);
-    s.d_fused = nullptr;
-    s.fused_cap = 0;
-    VGX_HIP(ctx0, hipMalloc(&s.d_fused, (size_t)size * sizeof(double)));
-    s.fused_cap = size;
-  }
   VGX_HIP(ctx0, hipSetDevice(ctx0->device));
   if (m->sum_cap < size) {
     VGX_HIP(ctx0, hipStreamSynchronize(ctx0->stream));
@@ -389,10 +400,14 @@ int vgx_reg_multi_evaluate_fused(vgx_reg_multi m, const double* poses, int32_t n
       if (s->rc != VGX_OK) return set_error(ctx0, s->rc, std::string("vgx_reg_multi: shard failed: ") + vgx_last_error(s->ctx));
     return rc;
   }
-  const double* d_result = m->d_sum;
+  // The per-constraint blocks meet on context 0 -- copied, not summed -- and the fused buffer is assembled
+  // there ONCE, in list order: bit for bit what one vgx_reg_batch over the whole list computes, whatever the
+  // number of contexts and the placement (tests/test_multi_gpu.py: 8 contexts == 2 contexts == single batch).
+  const double* d_all = m->d_normal_all;
   if (m->reduction == VGX_REDUCE_RCCL) {
-    // one all-reduce per solver evaluation: every context's buffer in place, each on its own stream
-    // (behind that context's evaluation and assembly); context 0's copy goes to the host
+    // one all-reduce per solver evaluation: every context's [n][45] array in place, each on its own stream
+    // (behind that context's evaluation and scatter).  A row is non-zero on exactly one context, so the sum is
+    // exact in whatever order RCCL adds: the same bits as the gather.
     RcclApi& api = rccl_api();
     ncclResult_t r = api.GroupStart();
     const bool group_open = r == ncclSuccess;
@@ -405,7 +420,7 @@ int vgx_reg_multi_evaluate_fused(vgx_reg_multi m, const double* poses, int32_t n
         device_failed = true;  // (no early return: an open RCCL group would stay open for the whole process)
         break;
       }
-      r = api.AllReduce(s.d_fused, s.d_fused, (size_t)size, ncclDouble, ncclSum, m->comms[k], s.ctx->stream);
+      r = api.AllReduce(s.d_all, s.d_all, (size_t)m->n * kNormalSize, ncclDouble, ncclSum, m->comms[k], s.ctx->stream);
     }
     if (group_open) {
       const ncclResult_t r2 = api.GroupEnd();
@@ -414,20 +429,20 @@ int vgx_reg_multi_evaluate_fused(vgx_reg_multi m, const double* poses, int32_t n
     if (device_failed) return set_error(ctx0, VGX_ERR_HIP, "vgx_reg_multi: hipSetDevice failed while enqueuing the all-reduce");
     if (r != ncclSuccess) return set_error(ctx0, VGX_ERR_HIP, std::string("ncclAllReduce: ") + api.GetErrorString(r));
     VGX_HIP(ctx0, hipSetDevice(ctx0->device));
-    d_result = m->shards[0]->d_fused;
-  } else {
-    // one reduction per solver evaluation, on shard 0's stream, in shard order
+    d_all = m->shards[0]->d_all;
+  } else if (m->n > 0) {
+    // one gather per solver evaluation, on context 0's stream, behind every context's evaluation
     VGX_HIP(ctx0, hipSetDevice(ctx0->device));
-    SumArgs a{};
-    a.n_src = (int)m->shards.size();
-    for (int k = 0; k < a.n_src; ++k) {
-      a.src[k] = m->shards[(size_t)k]->d_fused;
-      if (k > 0) VGX_HIP(ctx0, hipStreamWaitEvent(ctx0->stream, m->shards[(size_t)k]->done, 0));
-    }
-    hipLaunchKernelGGL(multi_sum_kernel, dim3((unsigned)((size + 255) / 256)), dim3(256), 0, ctx0->stream, a,
-                       (long long)size, m->d_sum);
+    for (size_t k = 1; k < m->shards.size(); ++k)
+      VGX_HIP(ctx0, hipStreamWaitEvent(ctx0->stream, m->shards[k]->done, 0));
+    const long long work = (long long)m->n * kNormalSize;
+    hipLaunchKernelGGL(multi_gather_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, ctx0->stream, m->d_src,
+                       (long long)m->n, m->d_normal_all);
     VGX_HIP(ctx0, hipGetLastError());
   }
+  rc = vgx_reg_assembler_assemble(m->assembler, d_all, n_nodes, m->d_sum);
+  if (rc != VGX_OK) return rc;
+  const double* d_result = m->d_sum;
   VGX_HIP(ctx0, hipMemcpyAsync(m->h_sum, d_result, (size_t)size * sizeof(double), hipMemcpyDeviceToHost, ctx0->stream));
   VGX_HIP(ctx0, hipStreamSynchronize(ctx0->stream));
   std::memcpy(fused_host, m->h_sum, (size_t)size * sizeof(double));

@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <numeric>
 
 #include "vgx_internal.h"
 
@@ -1295,6 +1296,17 @@ __global__ void reg_assemble_kernel(const double* __restrict__ normal, int n, in
   }
 }
 
+// This shard's [n][45] blocks into rows global_index[c] of the [n_global][45] array every shard all-reduces:
+// a row is written by exactly one shard and is zero everywhere else, so the SUM of the shards' arrays is
+// exact whatever order a collective adds them in.
+__global__ void reg_scatter_normal_kernel(const double* __restrict__ normal, int n, const int32_t* __restrict__ global_index,
+                                          double* __restrict__ all) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= (int64_t)n * kNormalSize) return;
+  const int c = (int)(tid / kNormalSize), e = (int)(tid % kNormalSize);
+  all[(size_t)global_index[c] * kNormalSize + e] = normal[tid];
+}
+
 // ---------------------------------------------------------------------------
 // launch helpers
 // ---------------------------------------------------------------------------
@@ -1444,6 +1456,19 @@ int vgx_reg_s::draw_raw(uint32_t* out) {
   const int64_t m = 2 * num_residuals;
   for (int64_t k = 0; k < m; ++k) out[k] = e.host();
   return VGX_OK;
+}
+
+// node -> incident (constraint << 1 | side), constraints in list order: the order reg_assemble_kernel sums in
+static void build_node_csr(int n, const int32_t* node_pair, int csr_nodes, std::vector<int32_t>& first,
+                           std::vector<int32_t>& items) {
+  first.assign((size_t)csr_nodes + 1, 0);
+  items.assign(2 * (size_t)n, 0);
+  for (int c = 0; c < n; ++c)
+    for (int s = 0; s < 2; ++s) first[(size_t)node_pair[2 * c + s] + 1]++;
+  for (int i = 0; i < csr_nodes; ++i) first[(size_t)i + 1] += first[(size_t)i];
+  std::vector<int32_t> cur(first.begin(), first.end() - 1);
+  for (int c = 0; c < n; ++c)
+    for (int s = 0; s < 2; ++s) items[(size_t)cur[(size_t)node_pair[2 * c + s]]++] = (c << 1) | s;
 }
 
 extern "C" {
@@ -1870,15 +1895,8 @@ int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs, const int3
   ex->host_points_tile_first = points_tile_first;
   // CSR: node -> (constraint << 1 | side)
   ex->csr_nodes = max_node + 1;
-  std::vector<int32_t> first((size_t)ex->csr_nodes + 1, 0), items(2 * (size_t)n);
-  for (int c = 0; c < n; ++c)
-    for (int s = 0; s < 2; ++s) first[(size_t)node_pair[2 * c + s] + 1]++;
-  for (int i = 0; i < ex->csr_nodes; ++i) first[(size_t)i + 1] += first[(size_t)i];
-  {
-    std::vector<int32_t> cur(first.begin(), first.end() - 1);
-    for (int c = 0; c < n; ++c)
-      for (int s = 0; s < 2; ++s) items[(size_t)cur[(size_t)node_pair[2 * c + s]]++] = (c << 1) | s;
-  }
+  std::vector<int32_t> first, items;
+  build_node_csr(n, node_pair, ex->csr_nodes, first, items);
   auto up = [&](const void* src, size_t bytes, void** dst) -> int {
     *dst = nullptr;
     if (bytes == 0) return VGX_OK;
@@ -2240,6 +2258,98 @@ int vgx_reg_batch_assemble(vgx_reg_batch b, const void* d_normal, int32_t n_node
   hipLaunchKernelGGL(reg_assemble_kernel, dim3(blocks), dim3(threads), 0, ctx->stream, nb, b->n,
                      ex->csr_nodes, n_nodes, b->d_node_pair, b->d_global_index, ex->d_node_first, ex->d_node_items,
                      (double*)d_fused, zero_first ? 0 : 1);
+  VGX_HIP(ctx, hipGetLastError());
+  return VGX_OK;
+}
+
+int vgx_reg_batch_scatter_normal(vgx_reg_batch b, const void* d_normal, void* d_normal_all, int32_t zero_first) {
+  if (!b || !d_normal_all) return VGX_ERR_INVALID;
+  vgx_ctx ctx = b->ctx;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  VGX_HIP(ctx, hipSetDevice(ctx->device));
+  if (zero_first)
+    VGX_HIP(ctx, hipMemsetAsync(d_normal_all, 0, (size_t)b->n_global * kNormalSize * sizeof(double), ctx->stream));
+  if (b->n == 0) return VGX_OK;
+  const double* nb = d_normal ? (const double*)d_normal : b->d_normal;
+  const int64_t work = (int64_t)b->n * kNormalSize;
+  hipLaunchKernelGGL(reg_scatter_normal_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, ctx->stream, nb, b->n,
+                     b->d_global_index, (double*)d_normal_all);
+  VGX_HIP(ctx, hipGetLastError());
+  return VGX_OK;
+}
+
+}  // extern "C"
+
+// The whole constraint list's node structure on one context: assembles the fused buffer from the COMPLETE
+// [n][45] array in list order -- the order a single vgx_reg_batch over the same list sums in, so the result
+// does not depend on how the list was sharded (include/voxgraph_amd.h).
+struct vgx_reg_assembler_s {
+  vgx_ctx ctx = nullptr;
+  int32_t n = 0, csr_nodes = 0;
+  int32_t* d_node_pair = nullptr;
+  int32_t* d_identity = nullptr;
+  int32_t* d_node_first = nullptr;
+  int32_t* d_node_items = nullptr;
+};
+
+extern "C" {
+
+int vgx_reg_assembler_destroy(vgx_reg_assembler a) {
+  if (!a) return VGX_ERR_INVALID;
+  (void)hipSetDevice(a->ctx->device);
+  (void)hipStreamSynchronize(a->ctx->stream);
+  for (void* p : {(void*)a->d_node_pair, (void*)a->d_identity, (void*)a->d_node_first, (void*)a->d_node_items})
+    if (p) (void)hipFree(p);
+  delete a;
+  return VGX_OK;
+}
+
+int vgx_reg_assembler_create(vgx_ctx ctx, int32_t n, const int32_t* node_pair, vgx_reg_assembler* out) {
+  if (!ctx || !out || n < 0 || (n > 0 && !node_pair)) return VGX_ERR_INVALID;
+  *out = nullptr;
+  int max_node = -1;
+  for (int c = 0; c < 2 * n; ++c) {
+    if (node_pair[c] < 0) return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_assembler_create: negative node index");
+    max_node = std::max(max_node, node_pair[c]);
+  }
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  VGX_HIP(ctx, hipSetDevice(ctx->device));
+  vgx_reg_assembler a = new (std::nothrow) vgx_reg_assembler_s();
+  if (!a) return set_error(ctx, VGX_ERR_NOMEM, "vgx_reg_assembler_create: out of host memory");
+  a->ctx = ctx;
+  a->n = n;
+  a->csr_nodes = max_node + 1;
+  std::vector<int32_t> first, items, identity((size_t)n);
+  build_node_csr(n, node_pair, a->csr_nodes, first, items);
+  std::iota(identity.begin(), identity.end(), 0);
+  auto up = [&](const void* src, size_t bytes, int32_t** dst) -> bool {
+    if (bytes == 0) return true;
+    return hipMalloc((void**)dst, bytes) == hipSuccess && hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
+  };
+  if (!up(node_pair, 2 * (size_t)n * 4, &a->d_node_pair) || !up(identity.data(), (size_t)n * 4, &a->d_identity) ||
+      !up(first.data(), first.size() * 4, &a->d_node_first) || !up(items.data(), items.size() * 4, &a->d_node_items)) {
+    (void)hipGetLastError();
+    vgx_reg_assembler_destroy(a);
+    return set_error(ctx, VGX_ERR_NOMEM, "vgx_reg_assembler_create: device allocation failed");
+  }
+  *out = a;
+  return VGX_OK;
+}
+
+int vgx_reg_assembler_assemble(vgx_reg_assembler a, const void* d_normal_all, int32_t n_nodes, void* d_fused) {
+  if (!a || !d_fused || (a->n > 0 && !d_normal_all)) return VGX_ERR_INVALID;
+  vgx_ctx ctx = a->ctx;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (n_nodes < a->csr_nodes)
+    return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_assembler_assemble: n_nodes smaller than the largest node index");
+  VGX_HIP(ctx, hipSetDevice(ctx->device));
+  VGX_HIP(ctx, hipMemsetAsync(d_fused, 0, (size_t)vgx_reg_fused_size(n_nodes, a->n) * sizeof(double), ctx->stream));
+  int64_t work = (int64_t)a->csr_nodes * 20 + (int64_t)a->n * 16;
+  if (work == 0) work = 1;
+  const int blocks = (int)((work + 255) / 256) + 1;  // + the cost-summing workgroup
+  hipLaunchKernelGGL(reg_assemble_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const double*)d_normal_all, a->n,
+                     a->csr_nodes, n_nodes, a->d_node_pair, a->d_identity, a->d_node_first, a->d_node_items,
+                     (double*)d_fused, 0);
   VGX_HIP(ctx, hipGetLastError());
   return VGX_OK;
 }
