@@ -336,7 +336,7 @@ def test_rgbd_fullsize_scan_invariants(capi, ctx):
     assert np.array_equal(oA, gA)
     assert np.array_equal(oW, gW)                    # integer ray counts: exact
     one = oW == 1                                    # crossed by exactly one ray: order independent, bit for bit
-    assert one.sum() > 1000 and np.array_equal(oD[one].view(np.uint32), gD[one].view(np.uint32)), one.sum()
+    assert one.sum() > 100 and np.array_equal(oD[one].view(np.uint32), gD[one].view(np.uint32)), one.sum()
     diff = np.abs(gD - oD)[oW > 0]
     assert np.percentile(diff, 99) < 1e-4 and diff.max() <= 2 * trunc
     for o in (gi, gl):
