@@ -7,19 +7,17 @@ import numpy as np
 
 from harness.bench_common import HBM_PEAK_GBS, lpt_shards  # noqa: F401
 
-def config5_bench(capi, ctx, torch, dist, use_dist, rank, world, args):
-    """BASELINE configs[4]: 1000 submaps @ 128^3 on a loop (serpentine) trajectory, odometry edges
-    with accumulated drift, 20 injected loop-closure relative-pose edges
-    (PoseGraphInterface::addLoopClosureMeasurement, pose_graph_interface.cpp:68-92) and the
-    reference's two-stage optimisation (PoseGraphInterface::optimize, :177-198: loop closures are
-    new, so first optimise WITHOUT the registration constraints, then with all of them).
-    Constraints pair-sharded over the ranks; one all-reduce per solver evaluation."""
+C5_VOXEL_SIZE, C5_BLOCK_DIMS, C5_BLOCK_MIN = 0.2, (8, 8, 8), (-4, -4, -2)      # 128^3 voxels, 25.6 m cubes
+
+
+def build_config5_graph(n_lanes, per_lane):
+    """BASELINE configs[4]'s pose graph: n_lanes x per_lane submaps on a serpentine trajectory (50 % overlap along
+    a lane, 25 % across), registration constraints between consecutive submaps and across neighbouring lanes,
+    odometry edges with accumulated drift, 20 injected loop closures (seed 4).
+    Returns (true poses, registration pairs, odometry poses, edges, number of loop closures)."""
     from harness import lm
-    from harness.backends import GpuBackend
-    n_lanes, per_lane = args.config5_grid
     n = n_lanes * per_lane
     rng = np.random.default_rng(4)                                 # SURVEY.md 8d: seed 4
-    vs, dims, bmin = 0.2, (8, 8, 8), (-4, -4, -2)                   # 128^3 voxels, 25.6 m cubes
     dx, dy = 12.8, 19.2                                             # 50 % overlap along a lane, 25 % across
 
     def idx(lane, q):                                               # path index of x-position q in a lane
@@ -68,6 +66,22 @@ def config5_bench(capi, ctx, torch, dist, use_dist, rank, world, args):
         # a usable one is accurate to a fraction of that
         delta = between(true[a], true[b]) + rng.normal(0, [0.03, 0.03, 0.005, 1e-4])
         edges.append(lm.RelativePoseEdge(a, b, delta[:3], delta[3], info_lc))
+    return true, pairs, poses0, edges, n_lc
+
+
+def config5_bench(capi, ctx, torch, dist, use_dist, rank, world, args):
+    """BASELINE configs[4]: 1000 submaps @ 128^3 on a loop (serpentine) trajectory, odometry edges
+    with accumulated drift, 20 injected loop-closure relative-pose edges
+    (PoseGraphInterface::addLoopClosureMeasurement, pose_graph_interface.cpp:68-92) and the
+    reference's two-stage optimisation (PoseGraphInterface::optimize, :177-198: loop closures are
+    new, so first optimise WITHOUT the registration constraints, then with all of them).
+    Constraints pair-sharded over the ranks; one all-reduce per solver evaluation."""
+    from harness import lm
+    from harness.backends import GpuBackend
+    n_lanes, per_lane = args.config5_grid
+    n = n_lanes * per_lane
+    vs, dims, bmin = C5_VOXEL_SIZE, C5_BLOCK_DIMS, C5_BLOCK_MIN
+    true, pairs, poses0, edges, n_lc = build_config5_graph(n_lanes, per_lane)
 
     t0 = time.perf_counter()
     submaps, n_points = [], []

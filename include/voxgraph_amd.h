@@ -348,6 +348,13 @@ VGX_API int vgx_reg_compress_normal(const double normal[45], double residuals9[9
  * vgx_reg_multi_create sorts the constraints by owning context, builds one vgx_reg_batch per
  * context and starts one host thread per context.  Contexts may share a device (testing). */
 VGX_API int vgx_lpt_shards(int32_t n, const int64_t* weight, int32_t n_shards, int32_t* shard_of /* [n] */);
+/* The locality-aware alternative: the list cut into n_shards CONSECUTIVE runs of (nearly) equal weight
+ * (constraint c goes to the shard its weight midpoint falls in).  voxgraph creates constraints in submap
+ * order, i.e. along the trajectory, so a shard then touches the submaps of one stretch of the map and only
+ * those need to be resident on its GPU -- a third of the map instead of three quarters at N = 8 on the bench
+ * graphs, for a balance a few per cent behind LPT's (profiles/r04_shard_balance.json).
+ * Results never depend on the placement (see "Sharding-independent assembly"). */
+VGX_API int vgx_contiguous_shards(int32_t n, const int64_t* weight, int32_t n_shards, int32_t* shard_of /* [n] */);
 VGX_API int vgx_reg_multi_create(int32_t n_ctx, const vgx_ctx* ctxs, int32_t n, const vgx_reg* regs,
                                  const int32_t* node_pair /* [n][2] */, vgx_reg_multi* out);
 VGX_API int vgx_reg_multi_destroy(vgx_reg_multi multi);

@@ -108,3 +108,30 @@ def test_lpt_shards_is_the_greedy_longest_processing_time_partition(capi):
         assert np.array_equal(got, want)
         if n >= k:
             assert load.max() - load.min() <= w.max()
+
+
+def test_contiguous_shards_cut_the_list_into_consecutive_runs_of_equal_weight(capi):
+    """vgx_contiguous_shards (pure host arithmetic): the locality-aware placement -- monotone in the list order,
+    every shard's weight within one constraint of the mean, and on the bench's config-3 graph a shard touches
+    a third of the submaps where LPT touches three quarters."""
+    import types
+    import numpy as np
+    import bench
+    rng = np.random.default_rng(1)
+    for n, k in ((0, 3), (1, 4), (50, 8), (1176, 8), (7, 1), (5, 8)):
+        w = rng.integers(1, 500000, n)
+        got = capi.contiguous_shards(w, k)
+        assert len(got) == n and (n == 0 or (got.min() >= 0 and got.max() < k))
+        assert np.all(np.diff(got) >= 0)                                       # consecutive runs
+        if n >= 4 * k:
+            load = np.bincount(got, weights=w, minlength=k)
+            assert np.abs(load - w.sum() / k).max() <= w.max()                  # within one constraint of the mean
+    assert np.array_equal(capi.contiguous_shards(np.zeros(6, np.int64), 3), [0, 0, 1, 1, 2, 2])
+    args = types.SimpleNamespace(grid=[20, 10], block_dims=[16, 16, 16], voxel_size=0.2, seed=2, pose_sigma=0.3, yaw_sigma=0.05)
+    _, _, pairs = bench.build_graph(args)
+    w = np.full(len(pairs), 1000, np.int64)
+
+    def touched(shard_of):
+        return [len({int(s) for c in np.flatnonzero(shard_of == r) for s in pairs[c]}) for r in range(8)]
+    lpt, cont = touched(capi.lpt_shards(w, 8)), touched(capi.contiguous_shards(w, 8))
+    assert max(cont) <= 0.4 * 200 and min(lpt) >= 0.6 * 200, (lpt, cont)

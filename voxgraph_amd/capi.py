@@ -134,6 +134,7 @@ SIGNATURES = {
     "vgx_reg_assembler_assemble": (C.c_int, [vp, vp, C.c_int32, vp]),
     "vgx_reg_assembler_destroy": (C.c_int, [vp]),
     "vgx_lpt_shards": (C.c_int, [C.c_int32, i64p, C.c_int32, i32p]),
+    "vgx_contiguous_shards": (C.c_int, [C.c_int32, i64p, C.c_int32, i32p]),
     "vgx_reg_multi_create": (C.c_int, [C.c_int32, C.POINTER(vp), C.c_int32, C.POINTER(vp), i32p, C.POINTER(vp)]),
     "vgx_reg_multi_destroy": (C.c_int, [vp]),
     "vgx_reg_multi_num_shards": (C.c_int32, [vp]),
@@ -562,6 +563,16 @@ def lpt_shards(weights, n_shards):
     rc = load().vgx_lpt_shards(len(w), _ptr(w, i64p), int(n_shards), _ptr(out, i32p))
     if rc != OK:
         raise VgxError(rc, "vgx_lpt_shards")
+    return out
+
+
+def contiguous_shards(weights, n_shards):
+    """vgx_contiguous_shards: the list cut into n_shards consecutive runs of (nearly) equal weight"""
+    w = np.ascontiguousarray(weights, np.int64)
+    out = np.zeros(len(w), np.int32)
+    rc = load().vgx_contiguous_shards(len(w), _ptr(w, i64p), int(n_shards), _ptr(out, i32p))
+    if rc != OK:
+        raise VgxError(rc, "vgx_contiguous_shards")
     return out
 
 

@@ -219,6 +219,27 @@ int vgx_lpt_shards(int32_t n, const int64_t* weight, int32_t n_shards, int32_t* 
   return VGX_OK;
 }
 
+int vgx_contiguous_shards(int32_t n, const int64_t* weight, int32_t n_shards, int32_t* shard_of) {
+  if (n < 0 || n_shards <= 0 || (n > 0 && (!weight || !shard_of))) return VGX_ERR_INVALID;
+  // the list cut into n_shards consecutive runs of (nearly) equal weight: constraint c goes to the shard its
+  // weight MIDPOINT falls in, k = floor((prefix(c) + w(c) / 2) * n_shards / total).  voxgraph creates
+  // constraints in submap order, i.e. along the trajectory, so a run touches the submaps of one stretch of
+  // the map (+ what it overlaps): a shard needs only those resident.
+  long double total = 0;
+  for (int32_t c = 0; c < n; ++c) {
+    if (weight[c] < 0) return VGX_ERR_INVALID;
+    total += (long double)weight[c];
+  }
+  long double prefix = 0;
+  for (int32_t c = 0; c < n; ++c) {
+    int k = total > 0 ? (int)(((prefix + 0.5L * (long double)weight[c]) * n_shards) / total)
+                      : (int)(((long long)c * n_shards) / std::max(n, 1));
+    shard_of[c] = std::min(std::max(k, 0), n_shards - 1);
+    prefix += (long double)weight[c];
+  }
+  return VGX_OK;
+}
+
 int vgx_reg_multi_destroy(vgx_reg_multi m) {
   if (!m) return VGX_ERR_INVALID;
   DeviceGuard guard;
