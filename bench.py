@@ -42,7 +42,8 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 from harness.bench_common import (HBM_PEAK_GBS, BYTES_PER_EVAL, BYTES_NO_CORR, BYTES_OUT, BYTES_POINT,  # noqa: E402
-                                   BYTES_NEIGHBOURS, BYTES_PER_EVAL_FUSED, BYTES_NO_CORR_FUSED, lpt_shards)
+                                   BYTES_NEIGHBOURS, BYTES_PER_EVAL_FUSED, BYTES_NO_CORR_FUSED, lpt_shards, shards)
+from harness import bench_common  # noqa: E402
 from harness.bench_cpu import cpu_baseline  # noqa: E402
 from harness.bench_tsdf import tsdf_bench, finish_bench  # noqa: E402
 from harness.bench_config5 import config5_bench  # noqa: E402
@@ -139,7 +140,7 @@ def main():
     ap.add_argument("--no-config2", action="store_true")
     ap.add_argument("--no-multi-ctx", action="store_true")
     ap.add_argument("--no-quad", action="store_true",
-                    help="skip the shipped configuration's second measurement on quad bricks")
+                    help="skip the shipped configuration's second measurement (apron bricks, for comparison)")
     ap.add_argument("--inprocess", action="store_true",
                     help="ONE process drives --gpus N devices through vgx_reg_multi_* (the product's in-process "
                          "multi-GPU component); launch WITHOUT torch.distributed.run.  The headline loop then "
@@ -148,6 +149,10 @@ def main():
     ap.add_argument("--config", type=int, default=3, choices=[3, 5],
                     help="5: only BASELINE configs[4] (1000 submaps @ 128^3, loop closures, two-stage solve)")
     ap.add_argument("--config5-grid", type=int, nargs=2, default=[25, 40], help="lanes x submaps per lane")
+    ap.add_argument("--placement", choices=["contiguous", "lpt"], default="contiguous",
+                    help="how the constraint list is sharded over ranks / contexts: vgx_contiguous_shards (consecutive "
+                         "runs of equal weight: better measured balance and a third of the submaps per shard, "
+                         "profiles/r04_shard_balance.json) or vgx_lpt_shards.  Results do not depend on it.")
     ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"),
                     help="where the FULL result object goes (every block with its notes); the stdout line is the "
                          "compact summary of harness/bench_line.py")
@@ -158,6 +163,7 @@ def main():
                     help="PMC calibration: first launch evaluates poses 10 km apart, so every "
                          "evaluation reads exactly 20 B and writes exactly 36 B (profiles/README.md)")
     args = ap.parse_args()
+    bench_common.PLACEMENT = args.placement
 
     lib_path = os.path.join(ROOT, "voxgraph_amd", "lib", "libvoxgraph_amd.so")
     if not os.path.exists(lib_path):            # checkout without the (git-ignored) built library
@@ -262,7 +268,7 @@ def main():
         for cf in cfs_all:
             cf.destroy()
     weights_bytes = weights
-    mine = lpt_shards(weights, world)[rank]
+    mine = shards(weights, world)[rank]
     cfs = [capi.RegistrationCostFunction(ctx, submaps[pairs[c][0]], submaps[pairs[c][1]], cfg)
            for c in mine]
     batch = capi.RegistrationBatch(ctx, cfs, pairs[mine], global_index=mine, n_global=n_con)
@@ -280,7 +286,7 @@ def main():
                                          rng_fo.normal(0, args.yaw_sigma, (n_sub, 1))], axis=1)
             for _ in range(K)])
         pairs_fo = np.array([(k, n_sub * (1 + p) + k) for p in range(K) for k in range(n_sub)], np.int32)
-        mine_fo = lpt_shards([n_points[a] for a, _ in pairs_fo], world)[rank]
+        mine_fo = shards([n_points[a] for a, _ in pairs_fo], world)[rank]
         cfs_fo = [capi.RegistrationCostFunction(ctx, submaps[pairs_fo[c][0]], submaps[pairs_fo[c][0]], cfg)
                   for c in mine_fo]
         batch_fo = capi.RegistrationBatch(ctx, cfs_fo, pairs_fo[mine_fo], global_index=mine_fo,
@@ -521,7 +527,7 @@ def main():
     shipped = None
     if not args.no_shipped and not args.no_fused:
         cfg_s = capi.default_config(registration_point_type=capi.POINTS_ISOSURFACE, sampling_ratio=0.05)
-        shard = lpt_shards([n_iso[a] + n_iso[b] for a, b in pairs], world)[rank]
+        shard = shards([n_iso[a] + n_iso[b] for a, b in pairs], world)[rank]
         pairs_s = [(int(a), int(b)) for c in shard for a, b in (pairs[c], pairs[c][::-1])]
         gidx_s = [2 * c + k for c in shard for k in (0, 1)]
         buf_s = torch.zeros(capi.fused_size(n_sub, 2 * n_con), dtype=torch.float64, device="cuda")
@@ -571,7 +577,8 @@ def main():
         shipped = {"config": "registration_method explicit_to_implicit (isosurface points), sampling_ratio 0.05, "
                              "mirrored constraints, ESDF distance (voxgraph_mapper.yaml:34-35, pose_graph.cpp:62-71)",
                    "constraints": 2 * n_con, "isosurface_points_per_submap": float(np.mean(n_iso)),
-                   "brick_layout": "apron (the headline's submaps)",
+                   "brick_layout_chosen": "quad, made on demand from the headline's apron submaps "
+                                          "(VGX_SAMPLING_BRICKS_QUAD, the default: every constraint of the batch samples)",
                    "what": "one solver evaluation: device mt19937 streams + fused normal equations of every "
                            "constraint + assembly" + (" + RCCL all-reduce" if use_dist else "")}
         shipped.update(shipped_eval(ctx, submaps))
@@ -583,31 +590,32 @@ def main():
         shipped["hbm_frac"] = (tr_bytes / (tr["avg_ms_rocprof"] * 1e-3) / 1e9 / HBM_PEAK_GBS) \
             if (tr_bytes and tr.get("avg_ms_rocprof")) else None
         shipped["hbm_frac_note"] = "fused kernel alone: counter bytes / its rocprofv3 average duration / 8 TB/s (profiles/)"
+        if tr_bytes:
+            shipped["traffic_over_algorithmic"] = tr_bytes / (52.0 * shipped["residuals_per_evaluation"])
         if not args.no_quad:
-            # what a sampling session would configure: vgx_ctx_set_brick_layout(VGX_BRICKS_QUAD) -- the same
-            # submaps with a 2x2x2 neighbourhood in 32 contiguous bytes (scattered evaluations are bound by the
-            # 64-byte lines they touch); same draws, same results
-            ctx_q = capi.Context(local_rank)
-            ctx_q.set_stream(stream.cuda_stream)
-            ctx_q.set_brick_layout(capi.BRICKS_QUAD)
-            subs_q = []
+            # for comparison: the same evaluation on the bricks everything else reads (a context set to
+            # VGX_SAMPLING_BRICKS_SAME: apron bricks); fresh default-seeded engines, so the same draws
+            ctx_a = capi.Context(local_rank)
+            ctx_a.set_stream(stream.cuda_stream)
+            ctx_a.set_sampling_bricks(capi.SAMPLING_BRICKS_SAME)
+            subs_a = []
             for k in range(n_sub):
-                sm = capi.Submap.synth_city(ctx_q, k, args.voxel_size, 16, args.block_min, args.block_dims,
+                sm = capi.Submap.synth_city(ctx_a, k, args.voxel_size, 16, args.block_min, args.block_dims,
                                             args.truncation, args.esdf_max, 10.0, true_poses[k], args.seed)
                 sm.extract_isosurface_points(1.0)
                 sm.release_raw_layers()
-                subs_q.append(sm)
-            q = shipped_eval(ctx_q, subs_q)
-            q["brick_layout"] = "quad (vgx_ctx_set_brick_layout(VGX_BRICKS_QUAD): 4.25 x the grid memory)"
-            trq = (PROFILE_TRAFFIC.get("fused") or {}).get("shipped_quad") or {}
+                subs_a.append(sm)
+            q = shipped_eval(ctx_a, subs_a)
+            q["brick_layout"] = "apron (vgx_ctx_set_sampling_bricks(VGX_SAMPLING_BRICKS_SAME))"
+            trq = (PROFILE_TRAFFIC.get("fused") or {}).get("shipped_apron") or {}
             okq = trq.get("evaluations") == q["residuals_per_evaluation"] and world == 1 and trq.get("avg_ms_rocprof")
             q["traffic_from_profiles"] = trq.get("hbm_bytes_per_launch") if okq else None
             q["hbm_frac"] = (trq["hbm_bytes_per_launch"] / (trq["avg_ms_rocprof"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if okq else None
-            q["cost_equals_apron"] = bool(q["cost"] == shipped["cost"])
-            shipped["quad_bricks"] = q
-            for sm in subs_q:
+            q["cost_equals_default"] = bool(q["cost"] == shipped["cost"])
+            shipped["apron_bricks"] = q
+            for sm in subs_a:
                 sm.destroy()
-            ctx_q.close()
+            ctx_a.close()
 
     # ---- the in-process multi-GPU component (vgx_reg_multi_*: one process, one vgx_ctx + host thread per
     # GPU, fixed-order sum over xGMI peer mappings) -- the PRODUCT's multi-GPU path (voxgraph is one process).
@@ -730,7 +738,7 @@ def main():
                        "passes_per_step": args.inner,
                        "step": f"{args.inner} consecutive passes over all {n_con} constraints "
                                "(one batched launch per pass per rank)",
-                       "parallelism": f"pair-sharded x{world} (LPT" + (" on bytes moved at the initial poses" if world > 1 else "")
+                       "parallelism": f"pair-sharded x{world} ({args.placement}" + (", weights = bytes moved at the initial poses" if world > 1 else "")
                                       + "), submaps replicated",
                        "point_order": "extraction (block, then voxel linear index)",
                        "solve_stop_rule": "solve.ms: Ceres-default function_tolerance 1e-6 (NOT the reference's "

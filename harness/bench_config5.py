@@ -5,7 +5,7 @@ import time
 
 import numpy as np
 
-from harness.bench_common import HBM_PEAK_GBS, lpt_shards  # noqa: F401
+from harness.bench_common import HBM_PEAK_GBS, shards  # noqa: F401
 
 C5_VOXEL_SIZE, C5_BLOCK_DIMS, C5_BLOCK_MIN = 0.2, (8, 8, 8), (-4, -4, -2)      # 128^3 voxels, 25.6 m cubes
 
@@ -94,7 +94,7 @@ def config5_bench(capi, ctx, torch, dist, use_dist, rank, world, args):
     ctx.synchronize()
     setup_s = time.perf_counter() - t0
     cfg = capi.default_config(registration_point_type=capi.POINTS_VOXELS)
-    mine = lpt_shards([n_points[a] for a, _ in pairs], world)[rank]
+    mine = shards([n_points[a] for a, _ in pairs], world)[rank]
     cfs = [capi.RegistrationCostFunction(ctx, submaps[pairs[c][0]], submaps[pairs[c][1]], cfg) for c in mine]
     batch = capi.RegistrationBatch(ctx, cfs, pairs[mine], global_index=mine, n_global=len(pairs))
     backend = GpuBackend(capi, ctx, batch, n, dist if use_dist else None, node_pair_global=pairs)
@@ -199,7 +199,7 @@ def config5_bench(capi, ctx, torch, dist, use_dist, rank, world, args):
                         "whole estimate onto the truth (the registration cost is invariant to that transform "
                         "except through submap 0's own few constraints)",
            "stop_rule": "function_tolerance 1e-6 (Ceres default) in both stages, parameter_tolerance off",
-           "parallelism": f"pair-sharded x{world} (LPT), submaps replicated, one all-reduce of "
+           "parallelism": f"pair-sharded x{world}, submaps replicated, one all-reduce of "
                           f"{len(pairs) * capi.NORMAL_SIZE * 8} B (the per-constraint blocks) per evaluation",
            "setup_s": setup_s,
            "solver": "harness/lm.py (LM, banded Cholesky on the host; Ceres absent)"}

@@ -7,7 +7,7 @@ import time
 
 import numpy as np
 
-from harness.bench_common import HBM_PEAK_GBS, lpt_shards  # noqa: F401
+from harness.bench_common import effective_cores
 
 def cpu_baseline(capi, ctx, args, true_poses, poses, pairs, seconds):
     """The CPU oracle ("port") timed on this host on ONE constraint of the same
@@ -27,7 +27,7 @@ def cpu_baseline(capi, ctx, args, true_poses, poses, pairs, seconds):
     xyz, dist, w = orc.find_relevant_voxels(args.voxel_size, 16, bi, td, tw, ed)
     bi, td, tw, ed, eo = subs[b]
     layer = orc.Layer(args.voxel_size, 16, bi, ed, eo)
-    cores = os.cpu_count() or 1
+    cores, cores_info = effective_cores()      # threads that can really run at once (affinity, cgroup quota)
     n = len(w)
 
     def task(_):
@@ -47,7 +47,7 @@ def cpu_baseline(capi, ctx, args, true_poses, poses, pairs, seconds):
             done4 += sum(ex.map(task, range(4)))
     dt4 = time.perf_counter() - t4
     out = {"value": done / dt / 1e6, "unit": "Mresiduals+Jacobians/s", "cores": cores,
-           "value_4_threads": done4 / dt4 / 1e6,
+           "value_4_threads": done4 / dt4 / 1e6, "host_cpus": cores_info,
            "kind": "port",
            "sample": f"constraint 0 of the same graph ({n} residuals, one 256^3 pair) evaluated "
                      f"{done // n} times, one evaluation per task on {cores} threads, {dt:.1f} s; "

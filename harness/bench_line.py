@@ -92,8 +92,8 @@ def compact(full, detail_path):
     if sh:
         o = _pick(sh, ("constraints", "residuals_per_evaluation", "ms_per_evaluation", "stream_ms_per_evaluation",
                        "Mresiduals_per_s", "hbm_frac", "traffic_over_algorithmic", "brick_layout_chosen"))
-        if sh.get("quad_bricks"):
-            o["quad_bricks"] = _pick(sh["quad_bricks"], ("ms_per_evaluation", "hbm_frac", "cost_equals_apron"))
+        if sh.get("apron_bricks"):
+            o["apron_bricks"] = _pick(sh["apron_bricks"], ("ms_per_evaluation", "hbm_frac", "cost_equals_default"))
         out["shipped_config"] = o
     mc = d.get("multi_context")
     if mc:

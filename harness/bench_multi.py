@@ -5,7 +5,7 @@ import time
 
 import numpy as np
 
-from harness.bench_common import HBM_PEAK_GBS, lpt_shards  # noqa: F401
+from harness.bench_common import HBM_PEAK_GBS, place  # noqa: F401
 
 class GpuBackendLite:
     """single batch: fused pass + assembly + copy of the fused buffer to the host (what
@@ -34,7 +34,7 @@ def multi_context_bench(capi, ctx0, torch, args, devices, submaps0, true_poses, 
     n_ctx = len(devices)
     t_setup = time.perf_counter()
     ctxs = [ctx0] + [capi.Context(d) for d in devices[1:]]
-    shard_of = capi.lpt_shards(weights, n_ctx)
+    shard_of = place(weights, n_ctx)
     subs = [dict(enumerate(submaps0))] + [dict() for _ in range(n_ctx - 1)]
     for k_ctx in range(1, n_ctx):
         need = sorted({int(s_) for c in range(n_con) if shard_of[c] == k_ctx for s_ in pairs[c]})
@@ -55,8 +55,8 @@ def multi_context_bench(capi, ctx0, torch, args, devices, submaps0, true_poses, 
         fused_m, _ = multi.evaluate_fused(poses)
     m_ms = (time.perf_counter() - m0) / args.steps * 1e3
     out = {"contexts": n_ctx, "devices": len(set(devices)), "device_ids": devices,
-           "what": "vgx_reg_multi_evaluate_fused (LPT shard by bytes moved, one host thread per context, event-ordered "
-                   "fixed-order sum on context 0 over peer mappings, result on the host)",
+           "what": "vgx_reg_multi_evaluate_fused (shards by bytes moved, one host thread per context, the per-constraint "
+                   "blocks gathered on context 0 over peer mappings in event order, ONE assembly, result on the host)",
            "ms_per_evaluation": m_ms,
            "Mresiduals_per_s": float(sum(cf.num_residuals() for cf in cfs_m)) / m_ms / 1e3,
            "constraints_per_context": [int((shard_of == k).sum()) for k in range(n_ctx)],

@@ -5,7 +5,7 @@ import time
 
 import numpy as np
 
-from harness.bench_common import HBM_PEAK_GBS, lpt_shards  # noqa: F401
+from harness.bench_common import HBM_PEAK_GBS, effective_cores  # noqa: F401
 
 def _room_points(dirs, origin):
     """first hit of unit rays from `origin` with the inside of a 10 x 8 x 4 m room"""
@@ -193,7 +193,7 @@ def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=8):
         # orc_tsdf_integrate_sequence: no interpreter lock between scans); rate = total points / wall clock
         # from the barrier's release to the LAST replica's finish.
         import threading
-        cores = os.cpu_count() or 1
+        cores, cores_info = effective_cores()
         one_scan_s = cdt / cpu_scans
         seq_scans = min(scans - 1, 8)
         repeats = max(int(np.ceil(50 / seq_scans)), int(np.ceil(0.4 / max(one_scan_s * seq_scans, 1e-6))))
@@ -204,8 +204,7 @@ def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=8):
 
         def replica(j):
             # every replica builds and warms its own integrator + layer on its own thread, so that its pages are
-            # first touched where it runs (built on the main thread they all land on one NUMA node and the 256
-            # replicas queue on that node's memory: measured 45 x slower per core)
+            # first touched where it runs
             l_ = orc.TsdfLayer(vs, 16)
             i_ = orc.FastTsdfIntegrator(orc.tsdf_config(**kw), l_)
             i_.integrate_sequence(seq_poses[:1], seq_clouds[:1], 1)      # untimed: the layer exists, pages are touched
@@ -221,7 +220,8 @@ def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=8):
         wall = max(t_end) - min(t_begin)
         one_core = n_pts * cpu_scans / cdt / 1e6
         all_rate = n_pts * seq_scans * repeats * cores / wall / 1e6
-        cpu_all = {"Mpoints_per_s": all_rate, "cores": cores, "kind": "port", "replicas": cores, "wall_s": wall,
+        cpu_all = {"Mpoints_per_s": all_rate, "cores": cores, "host_cpus": cores_info, "kind": "port", "replicas": cores,
+                   "wall_s": wall,
                    "scans_per_replica": seq_scans * repeats,
                    "slowest_replica_s": max(e_ - b_ for b_, e_ in zip(t_begin, t_end)),
                    "fastest_replica_s": min(e_ - b_ for b_, e_ in zip(t_begin, t_end)),

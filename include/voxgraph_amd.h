@@ -70,6 +70,19 @@ VGX_API void* vgx_ctx_get_stream(vgx_ctx ctx);
 #define VGX_BRICKS_APRON 0
 #define VGX_BRICKS_QUAD 1
 VGX_API int vgx_ctx_set_brick_layout(vgx_ctx ctx, int32_t layout);
+/* Sampling sessions (round 4).  A vgx_reg_batch whose constraints ALL sample (sampling_ratio != -1: the
+ * reference's shipped 0.05, voxgraph_mapper.yaml:34) evaluates scattered points, where every 128-byte line a
+ * neighbourhood touches is an HBM fetch of its own; on a context whose submaps hold apron bricks such a batch
+ * therefore reads QUAD bricks, made on demand from the apron bricks of the submaps it reads (a device-side
+ * copy at batch creation, kept with the submap: + 4.25 x the grid memory of those submaps only) -- the
+ * all-points passes of the same context keep their apron bricks.  Results never depend on it.
+ *   VGX_SAMPLING_BRICKS_QUAD (default)   as described
+ *   VGX_SAMPLING_BRICKS_SAME             sampling batches read the bricks everything else reads */
+#define VGX_SAMPLING_BRICKS_SAME 0
+#define VGX_SAMPLING_BRICKS_QUAD 1
+VGX_API int vgx_ctx_set_sampling_bricks(vgx_ctx ctx, int32_t mode);
+/* which bricks a batch reads (VGX_BRICKS_APRON / VGX_BRICKS_QUAD); -1 for a NULL handle */
+VGX_API int32_t vgx_reg_batch_brick_layout(vgx_reg_batch batch);
 VGX_API int vgx_ctx_synchronize(vgx_ctx ctx);
 /* hipEvent-based timer on the context's stream (used by bench.py so that
  * the kernel time is measured on the stream the kernels run on). */

@@ -116,8 +116,9 @@ def test_single_gpu_line_has_the_contract_fields(single):
     # the shipped yaml's configuration (sampled, mirrored isosurface constraints) in one batched pass
     assert d["shipped_config"]["constraints"] == 2 * d["config"]["constraints"]
     assert d["shipped_config"]["ms_per_evaluation"] > 0 and d["shipped_config"]["cost"] > 0
-    # ... and on quad bricks (what a sampling session would configure): same draws, same sums
-    assert d["shipped_config"]["quad_bricks"]["cost_equals_apron"] and d["shipped_config"]["quad_bricks"]["ms_per_evaluation"] > 0
+    # ... by default on quad bricks made on demand; on the apron bricks for comparison: same draws, same sums
+    assert "quad" in d["shipped_config"]["brick_layout_chosen"]
+    assert d["shipped_config"]["apron_bricks"]["cost_equals_default"] and d["shipped_config"]["apron_bricks"]["ms_per_evaluation"] > 0
     # the in-process multi-GPU component, two contexts on this GPU: same buffer as the single batch
     assert d["multi_context"]["max_rel_diff_vs_single_batch"] == 0.0 and d["multi_context"]["ms_per_evaluation"] > 0
     # configs[4] in miniature: loop closures + two-stage optimisation improve on the odometry

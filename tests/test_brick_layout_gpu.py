@@ -18,9 +18,11 @@ def capi():
     return capi
 
 
-def _world(capi, layout, asymmetric=True):
+def _world(capi, layout, asymmetric=True, sampling_bricks=None):
     ctx = capi.Context(0)
     ctx.set_brick_layout(layout)
+    if sampling_bricks is not None:
+        ctx.set_sampling_bricks(sampling_bricks)
     ref, read = synth.config1_pair(asymmetric=asymmetric)
     subs = [H.gpu_submap(capi, ctx, sm, k) for k, sm in enumerate((ref, read))]
     for g in subs:
@@ -32,8 +34,12 @@ def test_every_kernel_gives_the_same_bits_on_both_layouts(capi):
     import torch
     poses = np.array([[0.02, -0.01, 0.03, 0.01], [0.31, -0.2, 0.08, 0.12]])
     out = {}
-    for layout in (capi.BRICKS_APRON, capi.BRICKS_QUAD):
-        ctx, (ref, read), subs = _world(capi, layout)
+    # three set-ups: apron bricks with quad bricks made on demand for all-sampling batches (the default), quad
+    # bricks throughout, apron bricks throughout (VGX_SAMPLING_BRICKS_SAME)
+    setups = (("default", capi.BRICKS_APRON, None), ("quad", capi.BRICKS_QUAD, None),
+              ("apron_only", capi.BRICKS_APRON, capi.SAMPLING_BRICKS_SAME))
+    for name, layout, sampling_bricks in setups:
+        ctx, (ref, read), subs = _world(capi, layout, sampling_bricks=sampling_bricks)
         res = {}
         for use_esdf in (1, 0):
             cfg = capi.default_config(registration_point_type=capi.POINTS_VOXELS, use_esdf_distance=use_esdf,
@@ -49,6 +55,9 @@ def test_every_kernel_gives_the_same_bits_on_both_layouts(capi):
             cfg = capi.default_config(registration_point_type=capi.POINTS_VOXELS, sampling_ratio=ratio)
             cfs = [capi.RegistrationCostFunction(ctx, subs[a], subs[b], cfg) for a, b in ((0, 1), (1, 0), (0, 0))]
             batch = capi.RegistrationBatch(ctx, cfs, [(0, 1), (1, 0), (0, 0)])
+            # which bricks the batch reads: quad on a quad context, and by default where every constraint samples
+            want_quad = name == "quad" or (name == "default" and ratio != -1.0)
+            assert batch.brick_layout() == (capi.BRICKS_QUAD if want_quad else capi.BRICKS_APRON), (name, ratio)
             R = batch.num_residuals()
             tr = torch.full((R,), float("nan"), dtype=torch.float32, device="cuda:0")
             tjo = torch.full((R, 4), float("nan"), dtype=torch.float32, device="cuda:0")
@@ -61,8 +70,19 @@ def test_every_kernel_gives_the_same_bits_on_both_layouts(capi):
             batch.destroy()
             for cf in cfs:
                 cf.destroy()
-        out[layout] = res
-        if layout == capi.BRICKS_APRON:
+        if name == "default":
+            # a batch that mixes sampling and all-points constraints keeps the apron bricks
+            cfg_all = capi.default_config(registration_point_type=capi.POINTS_VOXELS)
+            cfg_smp = capi.default_config(registration_point_type=capi.POINTS_VOXELS, sampling_ratio=0.3, sampler_seed=5)
+            mixed = [capi.RegistrationCostFunction(ctx, subs[0], subs[1], cfg_all),
+                     capi.RegistrationCostFunction(ctx, subs[1], subs[0], cfg_smp)]
+            mb = capi.RegistrationBatch(ctx, mixed, [(0, 1), (1, 0)])
+            assert mb.brick_layout() == capi.BRICKS_APRON
+            mb.destroy()
+            for cf in mixed:
+                cf.destroy()
+        out[name] = res
+        if name == "default":
             # ... and they are the oracle's (all points, ESDF distance, no_correspondence_cost 0.25)
             layer = H.oracle_layer(read)
             xyz, dist, w = H.oracle_points(ref)
@@ -73,10 +93,11 @@ def test_every_kernel_gives_the_same_bits_on_both_layouts(capi):
         for g in subs:
             g.destroy()
         ctx.close()
-    a, q = out[capi.BRICKS_APRON], out[capi.BRICKS_QUAD]
-    for key in a:
-        for x, y in zip(a[key], q[key]):
-            assert np.array_equal(x, y, equal_nan=True), key
+    a = out["default"]
+    for other in ("quad", "apron_only"):
+        for key in a:
+            for x, y in zip(a[key], out[other][key]):
+                assert np.array_equal(x, y, equal_nan=True), (other, key)
 
 
 def test_vps8_grids_on_both_layouts(capi):

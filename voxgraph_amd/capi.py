@@ -18,6 +18,7 @@ EVALUATE_FALSE = 1
 ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_UNSUPPORTED, ERR_NO_DEVICE = -1, -2, -3, -4, -5
 
 BRICKS_APRON, BRICKS_QUAD = 0, 1
+SAMPLING_BRICKS_SAME, SAMPLING_BRICKS_QUAD = 0, 1
 POINTS_ISOSURFACE = 0
 POINTS_VOXELS = 1
 POINTS_KEEP_ORDER = 0
@@ -85,6 +86,7 @@ SIGNATURES = {
     "vgx_ctx_get_stream": (vp, [vp]),
     "vgx_ctx_synchronize": (C.c_int, [vp]),
     "vgx_ctx_set_brick_layout": (C.c_int, [vp, C.c_int32]),
+    "vgx_ctx_set_sampling_bricks": (C.c_int, [vp, C.c_int32]),
     "vgx_ctx_timer_start": (C.c_int, [vp]),
     "vgx_ctx_timer_stop": (C.c_int, [vp, f32p]),
     "vgx_submap_create": (C.c_int, [vp, C.c_int32, C.c_float, C.c_int32, C.c_int32, i32p, f32p,
@@ -130,6 +132,7 @@ SIGNATURES = {
     "vgx_reg_batch_assemble": (C.c_int, [vp, vp, C.c_int32, vp, C.c_int32]),
     "vgx_reg_fused_size": (C.c_int64, [C.c_int32, C.c_int32]),
     "vgx_reg_batch_scatter_normal": (C.c_int, [vp, vp, vp, C.c_int32]),
+    "vgx_reg_batch_brick_layout": (C.c_int32, [vp]),
     "vgx_reg_assembler_create": (C.c_int, [vp, C.c_int32, i32p, C.POINTER(vp)]),
     "vgx_reg_assembler_assemble": (C.c_int, [vp, vp, C.c_int32, vp]),
     "vgx_reg_assembler_destroy": (C.c_int, [vp]),
@@ -256,6 +259,10 @@ class Context:
     def set_brick_layout(self, layout):
         """BRICKS_APRON (default) or BRICKS_QUAD, for the submaps created from now on"""
         self.check(self.lib.vgx_ctx_set_brick_layout(self.h, int(layout)))
+
+    def set_sampling_bricks(self, mode):
+        """SAMPLING_BRICKS_QUAD (default: all-sampling batches read quad bricks made on demand) or _SAME"""
+        self.check(self.lib.vgx_ctx_set_sampling_bricks(self.h, int(mode)))
 
     def timer_start(self):
         self.check(self.lib.vgx_ctx_timer_start(self.h))
@@ -522,6 +529,10 @@ class RegistrationBatch:
     def assemble(self, n_nodes, d_fused, d_normal=None, zero_first=True):
         self.ctx.check(self.ctx.lib.vgx_reg_batch_assemble(
             self.h, vp(d_normal) if d_normal else None, n_nodes, vp(d_fused), int(zero_first)))
+
+    def brick_layout(self):
+        """BRICKS_APRON / BRICKS_QUAD: the bricks this batch reads (quad on demand when all its constraints sample)"""
+        return int(self.ctx.lib.vgx_reg_batch_brick_layout(self.h))
 
     def scatter_normal(self, d_normal_all, d_normal=None, zero_first=True):
         """this shard's [n][45] blocks into rows global_index[c] of the DEVICE [n_global][45] array"""

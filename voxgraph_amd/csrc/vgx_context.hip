@@ -105,6 +105,19 @@ int launch_brickify(vgx_submap sm, int which) {
   return VGX_OK;
 }
 
+// apron bricks -> quad bricks (same values: a copy, cell by cell)
+template <int VPS>
+__global__ __launch_bounds__(256) void requad_kernel(const float* __restrict__ apron, float* __restrict__ quad) {
+  constexpr int CA = BrickLayout<VPS, 0>::cells, CQ = BrickLayout<VPS, 1>::cells, B = VPS + 1;
+  const float* in = apron + (size_t)blockIdx.x * CA;
+  float* out = quad + (size_t)blockIdx.x * CQ;
+  for (int i = threadIdx.x; i < CQ; i += blockDim.x) {
+    int cx, cy, cz;
+    BrickLayout<VPS, 1>::decode(i, cx, cy, cz);
+    out[i] = in[cx + B * (cy + B * cz)];
+  }
+}
+
 // Bounding sphere of every kChunkPoints consecutive registration points (one
 // wavefront per chunk).  The fused REG pass tests a chunk's sphere against the reading
 // grid's box before it requests the chunk's points at all.
@@ -244,6 +257,28 @@ int engine_to_device(vgx_ctx ctx, SamplerEngine& e) {
 
 using namespace vgx;
 
+int vgx_submap_s::ensure_quad_grid(int which) {
+  Grid& g = grid[which];
+  if (!g.present || !g.d_bricks || g.layout != VGX_BRICKS_APRON || g.d_quad) return VGX_OK;
+  const size_t cells = brick_cells(vps, VGX_BRICKS_QUAD);
+  if ((unsigned long long)n_blocks * cells >= (1ull << 32))
+    return set_error(ctx, VGX_ERR_UNSUPPORTED, "submap too large for 32-bit addressing of its quad bricks: " +
+                                                   std::to_string(n_blocks) + " blocks");
+  if (hipMalloc(&g.d_quad, (size_t)n_blocks * cells * sizeof(float)) != hipSuccess) {
+    (void)hipGetLastError();
+    g.d_quad = nullptr;
+    return set_error(ctx, VGX_ERR_NOMEM, "quad bricks for a sampling session: device allocation failed (" +
+                                             std::to_string((size_t)n_blocks * cells * sizeof(float)) + " bytes; "
+                                             "vgx_ctx_set_sampling_bricks(ctx, VGX_SAMPLING_BRICKS_SAME) does without)");
+  }
+  if (vps == 16)
+    hipLaunchKernelGGL(requad_kernel<16>, dim3(n_blocks), dim3(256), 0, ctx->stream, g.d_bricks, g.d_quad);
+  else
+    hipLaunchKernelGGL(requad_kernel<8>, dim3(n_blocks), dim3(256), 0, ctx->stream, g.d_bricks, g.d_quad);
+  VGX_HIP(ctx, hipGetLastError());
+  return VGX_OK;
+}
+
 vgx::GridDev vgx_submap_s::grid_dev(int which) const {
   GridDev g;
   g.bricks = grid[which].d_bricks;
@@ -352,6 +387,15 @@ int vgx_ctx_set_brick_layout(vgx_ctx ctx, int32_t layout) {
     return set_error(ctx, VGX_ERR_INVALID, "vgx_ctx_set_brick_layout: unknown layout");
   std::lock_guard<std::mutex> lk(ctx->mu);
   ctx->brick_layout = layout;
+  return VGX_OK;
+}
+
+int vgx_ctx_set_sampling_bricks(vgx_ctx ctx, int32_t mode) {
+  if (!ctx) return VGX_ERR_INVALID;
+  if (mode != VGX_SAMPLING_BRICKS_SAME && mode != VGX_SAMPLING_BRICKS_QUAD)
+    return set_error(ctx, VGX_ERR_INVALID, "vgx_ctx_set_sampling_bricks: unknown mode");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  ctx->sampling_bricks = mode;
   return VGX_OK;
 }
 
@@ -486,6 +530,7 @@ int vgx_submap_destroy(vgx_submap sm) {
   if (sm->d_iso_block_index) (void)hipFree(sm->d_iso_block_index);
   for (int k = 0; k < 2; ++k) {
     if (sm->grid[k].d_bricks) (void)hipFree(sm->grid[k].d_bricks);
+    if (sm->grid[k].d_quad) (void)hipFree(sm->grid[k].d_quad);
     reset_point_set(sm->points[k]);
   }
   delete sm;

@@ -211,6 +211,10 @@ int vgx_submap_generate_esdf(vgx_submap sm, const vgx_esdf_config* cfg_in, int32
     sm->grid[1].d_bricks = nullptr;
     sm->grid[1].present = false;
   }
+  if (sm->grid[1].d_quad) {  // (made on demand from the bricks just dropped: made again when next asked for)
+    (void)hipFree(sm->grid[1].d_quad);
+    sm->grid[1].d_quad = nullptr;
+  }
   return launch_brickify(sm, 1);
 }
 

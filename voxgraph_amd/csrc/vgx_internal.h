@@ -108,7 +108,7 @@ struct alignas(16) ConstraintDev {
   const double* cumulative;   // [n_points] WeightedSampler::cumulative_item_weights_
   const int32_t* search_lut;  // [search_buckets + 1] first index of every draw bucket, or null
   int32_t search_buckets;     // K: a power of two
-  const int32_t* sample_idx;  // batch: this evaluation's draws, indexed by row (row0 + i); null: draw in place
+  const float4* sample_pts;   // batch: this evaluation's DRAWN POINTS {x,y,z,d}, by row (row0 + i); null: draw in place
   const int32_t* inv_order;   // uploaded index -> device index, or null
   int64_t n_points;
   const float4* chunk_bounds; // bounding spheres of consecutive kChunkPoints-point chunks
@@ -149,6 +149,7 @@ struct Context {
   std::string last_error;
   int cu_count = 256;
   int brick_layout = VGX_BRICK_LAYOUT_DEFAULT;  // of the submaps created from now on (vgx_ctx_set_brick_layout)
+  int sampling_bricks = 1;  // VGX_SAMPLING_BRICKS_QUAD: all-sampling batches read quad bricks made on demand
   // Evaluation slots of the drop-in Evaluate path.  A call takes a free slot for its duration
   // (stream, ordering event, device staging for the f64 outputs, pinned + device staging for the
   // sampler's engine outputs -- all grown on demand and reused), so constructing a cost function
@@ -238,6 +239,9 @@ struct Grid {
   float* d_bricks = nullptr;
   bool present = false;
   int layout = 0;  // the context's brick layout when this grid was built
+  // the same grid as quad bricks, made on demand from the apron bricks for a batch whose constraints all
+  // SAMPLE (scattered evaluations: a neighbourhood in 32 contiguous bytes; vgx_ctx_set_sampling_bricks)
+  float* d_quad = nullptr;
 };
 
 }  // namespace vgx
@@ -265,6 +269,7 @@ struct vgx_submap_s {
   std::vector<int32_t> isosurface_blocks;  // block slots holding isosurface vertices (VSM:237-240)
   int32_t* d_iso_block_index = nullptr;    // [isosurface_blocks.size()][3]
   vgx::GridDev grid_dev(int which) const;
+  int ensure_quad_grid(int which);  // apron bricks -> quad bricks, once (vgx_context.hip)
 };
 
 struct vgx_reg_s {
@@ -308,7 +313,7 @@ struct vgx_reg_batch_s {
   vgx::Tile* d_tiles = nullptr;
   vgx::Tile* d_draw_tiles = nullptr;     // the sampling constraints' tiles in the draw kernel's launch order
   int32_t n_draw_tiles = 0;
-  int32_t* d_drawn = nullptr;            // sampling: the point every row uses in this evaluation (reg_draw_kernel)
+  float4* d_drawn = nullptr;             // sampling: the point {x,y,z,d} every row uses in this evaluation (reg_draw_kernel)
   unsigned char* d_tile_dead = nullptr;  // per materialising-pass tile, per launch: every chunk culled (rows are zeros)
   int32_t* d_tile_first = nullptr;    // [n+1] first tile of each constraint
   double* d_partials = nullptr;       // [n_tiles][kPartialSize]

@@ -422,9 +422,14 @@ __device__ __forceinline__ int32_t weighted_draw(const ConstraintDev& C, int64_t
 // result coalesced.  Shipped configuration (19.3 M draws): 2.49 ms fused kernel with the draw inside ->
 // 0.38 ms draw kernel + 0.97 ms fused kernel (2.90 -> 1.63 ms per solver evaluation with the faster
 // mt_generate_kernel).
+// Round 4: the kernel also FETCHES the drawn point and writes {x, y, z, d} itself (16 B per row, coalesced).
+// The draws of one point set run on one XCD (make_draw_order), so its point table (16 B x n: 2.6 MB for a
+// 256^3 submap's isosurface points) is pulled through that L2 once per point set instead of once per draw by
+// the evaluation kernels (every 128-byte line of it is hit by ~5 of the ~12 constraints' draws), and the
+// evaluation kernels STREAM their points like the all-points passes do.
 __global__ __launch_bounds__(256) void reg_draw_kernel(const ConstraintDev* __restrict__ cons,
                                                       const Tile* __restrict__ tiles, int n_tiles,
-                                                      int32_t* __restrict__ drawn) {
+                                                      float4* __restrict__ drawn) {
   const int t = blockIdx.x;
   if (t >= n_tiles) return;
   const Tile tile = tiles[t];
@@ -444,17 +449,21 @@ __global__ __launch_bounds__(256) void reg_draw_kernel(const ConstraintDev* __re
   int32_t s[D];
 #pragma unroll
   for (int j = 0; j < D; ++j) s[j] = draw_finish(C, d[j]);
+  f32x4 p[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) p[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[s[j]];
 #pragma unroll
   for (int j = 0; j < D; ++j) {
     const int local = j * 256 + (int)threadIdx.x;
-    if (local < tile.count) drawn[C.row0 + tile.start + local] = s[j];
+    if (local < tile.count) reinterpret_cast<f32x4*>(drawn)[C.row0 + tile.start + local] = p[j];
   }
 }
 
 // the point residual i of a sampling constraint uses: the batch's precomputed draw, or (one-constraint
 // drop-in launch) the draw itself
-__device__ __forceinline__ int32_t sampled_index(const ConstraintDev& C, int64_t i) {
-  return C.sample_idx ? as_global(C.sample_idx)[C.row0 + i] : weighted_draw(C, i);
+__device__ __forceinline__ f32x4 sampled_point(const ConstraintDev& C, int64_t i) {
+  if (C.sample_pts) return as_global(reinterpret_cast<const f32x4*>(C.sample_pts))[C.row0 + i];
+  return as_global(reinterpret_cast<const f32x4*>(C.xyzd))[weighted_draw(C, i)];
 }
 
 
@@ -532,8 +541,7 @@ __device__ __forceinline__ void reg_eval_points_body(
     bool active = local < tile.count;
     int64_t i = tile.start + (active ? local : 0);
     if (sampled) {
-      int32_t s = sampled_index(C, i);
-      pt[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[s];
+      pt[j] = sampled_point(C, i);
       w[j] = 1.0f;  // RCF:121
     } else {
       pt[j] = load_stream<NTL>(as_global(reinterpret_cast<const f32x4*>(C.xyzd)) + i);
@@ -724,7 +732,7 @@ __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_ker
   const GridDev g = C.grid;
   const bool count_misses = C.no_corr_cost != 0.0;
   // sampling mode (RCF:113-122): residual i uses the point its weighted draw selects (made by
-  // reg_draw_kernel before this launch: a batch always has sample_idx), with weight 1; draws are
+  // reg_draw_kernel before this launch: a batch always has sample_pts), with weight 1; draws are
   // scattered over the whole set, so there is nothing to cull
   const bool sampled = C.sample_raw != nullptr;
   const float4* bounds = (!count_misses && !sampled && C.chunk_bounds) ? C.chunk_bounds : nullptr;
@@ -749,7 +757,7 @@ __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_ker
       int local = j * kBlockThreads + (int)threadIdx.x;
       int64_t i = tile.start + (local < tile.count ? local : 0);
       if (sampled) {
-        pt_next[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[as_global(C.sample_idx)[C.row0 + i]];
+        pt_next[j] = as_global(reinterpret_cast<const f32x4*>(C.sample_pts))[C.row0 + i];
         w_next[j] = 1.0f;  // RCF:121
       } else {
         pt_next[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[i];
@@ -775,7 +783,7 @@ __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_ker
           int local = base + kIterPoints + j * kBlockThreads + (int)threadIdx.x;
           int64_t i = tile.start + (local < tile.count ? local : 0);
           if (sampled) {
-            pt_next[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[as_global(C.sample_idx)[C.row0 + i]];
+            pt_next[j] = as_global(reinterpret_cast<const f32x4*>(C.sample_pts))[C.row0 + i];
             w_next[j] = 1.0f;
           } else {
             pt_next[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[i];
@@ -1792,6 +1800,19 @@ int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs, const int3
                        "vgx_reg_batch_create: submaps with different brick layouts (vgx_ctx_set_brick_layout was "
                        "changed between their creation)");
   }
+  // A batch whose constraints ALL sample evaluates scattered points: every line a neighbourhood touches is a
+  // fetch of its own, so it reads QUAD bricks (a neighbourhood in 32 contiguous bytes), made on demand from
+  // the submaps' apron bricks and kept with them (vgx_ctx_set_sampling_bricks; results never depend on it).
+  bool quad_on_demand = n > 0 && layout == VGX_BRICKS_APRON && ctx->sampling_bricks == VGX_SAMPLING_BRICKS_QUAD;
+  for (int c = 0; c < n && quad_on_demand; ++c) quad_on_demand = regs[c]->sampling();
+  if (quad_on_demand) {
+    VGX_HIP(ctx, hipSetDevice(ctx->device));
+    for (int c = 0; c < n; ++c) {
+      const int rc_q = regs[c]->reading->ensure_quad_grid(regs[c]->cfg.use_esdf_distance ? 1 : 0);
+      if (rc_q != VGX_OK) return rc_q;
+    }
+    layout = VGX_BRICKS_QUAD;
+  }
   vgx_reg_batch b = new (std::nothrow) vgx_reg_batch_s();
   if (!b) return set_error(ctx, VGX_ERR_NOMEM, "vgx_reg_batch_create: out of host memory");
   vgx_reg_batch ex = b;
@@ -1826,6 +1847,13 @@ int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs, const int3
   int max_node = -1;
   for (int c = 0; c < n; ++c) {
     desc[(size_t)c] = regs[c]->describe();
+    if (quad_on_demand) {
+      const Grid& gq = regs[c]->reading->grid[regs[c]->cfg.use_esdf_distance ? 1 : 0];
+      if (gq.d_bricks) {  // (a reading submap without blocks keeps its null grid)
+        desc[(size_t)c].grid.bricks = gq.d_quad;
+        desc[(size_t)c].grid.layout = VGX_BRICKS_QUAD;
+      }
+    }
     desc[(size_t)c].row0 = b->row_offset[(size_t)c];
     b->row_offset[(size_t)c + 1] = b->row_offset[(size_t)c] + regs[c]->num_residuals;
     std::vector<Tile> t = make_tiles(c, regs[c]->num_residuals, kTilePoints);
@@ -1863,7 +1891,7 @@ int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs, const int3
     b->any_sampling = total > 0;
     if (b->any_sampling) {
       if (hipMalloc(&b->d_raw, (size_t)total * sizeof(uint32_t)) != hipSuccess ||
-          hipMalloc(&b->d_drawn, (size_t)b->row_offset[(size_t)n] * sizeof(int32_t)) != hipSuccess) {
+          hipMalloc(&b->d_drawn, (size_t)b->row_offset[(size_t)n] * sizeof(float4)) != hipSuccess) {
         vgx_reg_batch_destroy(b);
         return set_error(ctx, VGX_ERR_NOMEM, "vgx_reg_batch_create: sampler stream buffer allocation failed");
       }
@@ -1872,7 +1900,7 @@ int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs, const int3
         const int j = job_of[(size_t)c];
         if (j < 0) continue;
         desc[(size_t)c].sample_raw = b->d_raw + b->stream_jobs[(size_t)j].offset + used[(size_t)j];
-        desc[(size_t)c].sample_idx = b->d_drawn;  // this evaluation's draws, by row (reg_draw_kernel)
+        desc[(size_t)c].sample_pts = b->d_drawn;  // this evaluation's drawn points, by row (reg_draw_kernel)
         used[(size_t)j] += 2 * regs[c]->num_residuals;
       }
       std::vector<StreamJobDev> jd(b->stream_jobs.size());
@@ -2261,6 +2289,8 @@ int vgx_reg_batch_assemble(vgx_reg_batch b, const void* d_normal, int32_t n_node
   VGX_HIP(ctx, hipGetLastError());
   return VGX_OK;
 }
+
+int32_t vgx_reg_batch_brick_layout(vgx_reg_batch b) { return b ? (int32_t)b->layout : -1; }
 
 int vgx_reg_batch_scatter_normal(vgx_reg_batch b, const void* d_normal, void* d_normal_all, int32_t zero_first) {
   if (!b || !d_normal_all) return VGX_ERR_INVALID;
