@@ -313,7 +313,8 @@ struct vgx_reg_batch_s {
   vgx::Tile* d_tiles = nullptr;
   vgx::Tile* d_draw_tiles = nullptr;     // the sampling constraints' tiles in the draw kernel's launch order
   int32_t n_draw_tiles = 0;
-  float4* d_drawn = nullptr;             // sampling: the point {x,y,z,d} every row uses in this evaluation (reg_draw_kernel)
+  float4* d_drawn = nullptr;             // sampling: the point {x,y,z,d} every row uses in this evaluation (reg_gather_points_kernel)
+  int32_t* d_drawn_idx = nullptr;        // ... and its index in the point set (reg_draw_kernel)
   unsigned char* d_tile_dead = nullptr;  // per materialising-pass tile, per launch: every chunk culled (rows are zeros)
   int32_t* d_tile_first = nullptr;    // [n+1] first tile of each constraint
   double* d_partials = nullptr;       // [n_tiles][kPartialSize]

@@ -54,7 +54,8 @@ constexpr int kMaxShards = 16;
 __global__ void multi_gather_kernel(const double* const* __restrict__ src, long long n, double* __restrict__ all) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * kNormalSize) return;
-  all[i] = src[i / kNormalSize][i % kNormalSize];
+  // (pointers out of a table are generic to the compiler: say global, or the load goes out as a FLAT one)
+  all[i] = ((const __attribute__((address_space(1))) double*)src[i / kNormalSize])[i % kNormalSize];
 }
 
 // RCCL, opened on demand (VGX_REDUCE_RCCL): the alternative reduction SURVEY.md 8(e) asks to compare --

@@ -362,9 +362,20 @@ struct DrawState {
   double target;
   int64_t first, len;
 };
+// What bounds the draw is the number of SCATTERED lane addresses its loads present to the CU's address /
+// tag pipeline (one per clock: measured 52 G draws/s with 6 scattered 4- and 8-byte loads per draw, whatever
+// the occupancy and the HBM traffic), so neighbouring words are fetched by ONE wider load each: the bucket
+// pair {lut[k], lut[k + 1]} as 8 bytes, the cumulative weights as 16-byte pairs (4- / 8-byte aligned
+// addresses: gfx950 global loads need dword alignment only).
+typedef uint32_t u32x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+typedef int32_t i32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+typedef double f64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+
 __device__ __forceinline__ double draw_uniform(const ConstraintDev& C, int64_t i) {
-  const double lo = (double)as_global(C.sample_raw)[2 * i];
-  const double hi = (double)as_global(C.sample_raw)[2 * i + 1];
+  // (2 words per residual from an even offset of a 256-byte aligned stream: 8-byte aligned)
+  const u32x2_a8 raw = *reinterpret_cast<const VGX_GLOBAL u32x2_a8*>(as_global(C.sample_raw) + 2 * i);
+  const double lo = (double)raw.x;
+  const double hi = (double)raw.y;
   // ... / 2^64 as a multiplication: an exact scaling either way
   double u = (lo + hi * 4294967296.0) * 0x1p-64;
   if (u >= 1.0) u = 0x1.fffffffffffffp-1;  // std::nextafter(1.0, 0.0)
@@ -380,22 +391,27 @@ __device__ __forceinline__ DrawState draw_bucket(const ConstraintDev& C, double 
     // and of upper_bound); searching that sub-range returns exactly what the full search returns.
     // K is a power of two >= n: u * K is exact, the range holds about one element.
     const int k = (int)(u * (double)C.search_buckets);
-    d.first = as_global(C.search_lut)[k];
-    d.len = as_global(C.search_lut)[k + 1] - d.first;
+    const i32x2_a4 b = *reinterpret_cast<const VGX_GLOBAL i32x2_a4*>(as_global(C.search_lut) + k);
+    d.first = b.x;
+    d.len = b.y - b.x;
   }
   return d;
 }
 __device__ __forceinline__ int32_t draw_finish(const ConstraintDev& C, DrawState d) {
   const double* cum = C.cumulative;
   if (d.len <= 4) {
-    // the elements <= target are a prefix of the sorted range: count them, four independent loads
-    const int64_t last = C.n_points - 1;
-    const double c0 = as_global(cum)[d.first < last ? d.first : last];
-    const double c1 = as_global(cum)[d.first + 1 < last ? d.first + 1 : last];
-    const double c2 = as_global(cum)[d.first + 2 < last ? d.first + 2 : last];
-    const double c3 = as_global(cum)[d.first + 3 < last ? d.first + 3 : last];
-    d.first += (int64_t)((d.len > 0) & !(d.target < c0)) + (int64_t)((d.len > 1) & !(d.target < c1)) +
-               (int64_t)((d.len > 2) & !(d.target < c2)) + (int64_t)((d.len > 3) & !(d.target < c3));
+    // the elements <= target are a prefix of the sorted range: count them.  cum[first .. first + 3] in two
+    // 16-byte loads (the table carries 3 entries of padding; entries beyond the range are not used); a
+    // wavefront whose ranges all hold at most two elements -- the usual case, the table has >= n buckets --
+    // issues only the first
+    const int64_t at = d.first < C.n_points ? d.first : C.n_points - 1;  // (first == n: empty range at the end)
+    const f64x2_a8 c01 = *reinterpret_cast<const VGX_GLOBAL f64x2_a8*>(as_global(cum) + at);
+    int64_t below = (int64_t)((d.len > 0) & !(d.target < c01.x)) + (int64_t)((d.len > 1) & !(d.target < c01.y));
+    if (__builtin_amdgcn_ballot_w64(d.len > 2) != 0ull) {
+      const f64x2_a8 c23 = *reinterpret_cast<const VGX_GLOBAL f64x2_a8*>(as_global(cum) + at + 2);
+      below += (int64_t)((d.len > 2) & !(d.target < c23.x)) + (int64_t)((d.len > 3) & !(d.target < c23.y));
+    }
+    d.first += below;
     d.len = 0;
   }
   while (d.len > 0) {
@@ -422,40 +438,78 @@ __device__ __forceinline__ int32_t weighted_draw(const ConstraintDev& C, int64_t
 // result coalesced.  Shipped configuration (19.3 M draws): 2.49 ms fused kernel with the draw inside ->
 // 0.38 ms draw kernel + 0.97 ms fused kernel (2.90 -> 1.63 ms per solver evaluation with the faster
 // mt_generate_kernel).
-// Round 4: the kernel also FETCHES the drawn point and writes {x, y, z, d} itself (16 B per row, coalesced).
-// The draws of one point set run on one XCD (make_draw_order), so its point table (16 B x n: 2.6 MB for a
-// 256^3 submap's isosurface points) is pulled through that L2 once per point set instead of once per draw by
-// the evaluation kernels (every 128-byte line of it is hit by ~5 of the ~12 constraints' draws), and the
-// evaluation kernels STREAM their points like the all-points passes do.
+// Round 4: the draws come to the evaluation kernels as POINTS {x, y, z, d} (16 B per row, coalesced), so those
+// kernels stream their points like the all-points passes do.  Two kernels, both PERSISTENT and XCD-aware:
+// workgroup b serves XCD b % 8 (the dispatcher deals workgroups round the XCDs) and walks that XCD's share
+// of the tile sequence (make_draw_order: one point set after the other) together with the XCD's other
+// workgroups, `wgs_per_xcd` tiles at a time -- about ONE point set is in flight per XCD, so
+//   reg_draw_kernel           finds the set's cumulative weights (8 B x n) and bucket table in that L2
+//                             (2.4 MB for a 256^3 submap's isosurface points; a plain launch keeps ~3 sets
+//                             in flight per XCD and thrashes: 3.1 GB of HBM reads per 19.3 M draws measured),
+//   reg_gather_points_kernel  finds the set's points (16 B x n, 2.6 MB) there: every 128-byte line of it is
+//                             wanted by ~5 of the ~12 constraints that draw from the set.
+// Together the tables would not fit one 4 MB L2: hence two passes with a 4-byte index in between.
+constexpr int kDrawWgsPerXcdDefault = 96;
+
 __global__ __launch_bounds__(256) void reg_draw_kernel(const ConstraintDev* __restrict__ cons,
-                                                      const Tile* __restrict__ tiles, int n_tiles,
-                                                      float4* __restrict__ drawn) {
-  const int t = blockIdx.x;
-  if (t >= n_tiles) return;
-  const Tile tile = tiles[t];
-  const ConstraintDev& C = cons[tile.constraint];
-  if (!C.sample_raw) return;
-  const double total = as_global(C.cumulative)[C.n_points - 1];
-  constexpr int D = kTilePoints / 256;
-  double u[D];
-  DrawState d[D];
+                                                      const Tile* __restrict__ tiles, int n_tiles, int wgs_per_xcd,
+                                                      int32_t* __restrict__ drawn_idx) {
+  const int xcd = blockIdx.x & 7, local_wg = blockIdx.x >> 3;
+  for (int q = local_wg;; q += wgs_per_xcd) {
+    const int t = q * 8 + xcd;
+    if (t >= n_tiles) break;
+    const Tile tile = tiles[t];
+    const ConstraintDev& C = cons[tile.constraint];
+    if (!C.sample_raw) continue;
+    const double total = as_global(C.cumulative)[C.n_points - 1];
+    constexpr int D = kTilePoints / 256;
+    double u[D];
+    DrawState d[D];
 #pragma unroll
-  for (int j = 0; j < D; ++j) {
-    const int local = j * 256 + (int)threadIdx.x;
-    u[j] = draw_uniform(C, tile.start + (local < tile.count ? local : 0));
+    for (int j = 0; j < D; ++j) {
+      const int local = j * 256 + (int)threadIdx.x;
+      u[j] = draw_uniform(C, tile.start + (local < tile.count ? local : 0));
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) d[j] = draw_bucket(C, u[j], total);
+    int32_t s[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) s[j] = draw_finish(C, d[j]);
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const int local = j * 256 + (int)threadIdx.x;
+      if (local < tile.count) drawn_idx[C.row0 + tile.start + local] = s[j];
+    }
   }
+}
+
+__global__ __launch_bounds__(256) void reg_gather_points_kernel(const ConstraintDev* __restrict__ cons,
+                                                               const Tile* __restrict__ tiles, int n_tiles,
+                                                               int wgs_per_xcd, const int32_t* __restrict__ drawn_idx,
+                                                               float4* __restrict__ drawn) {
+  const int xcd = blockIdx.x & 7, local_wg = blockIdx.x >> 3;
+  for (int q = local_wg;; q += wgs_per_xcd) {
+    const int t = q * 8 + xcd;
+    if (t >= n_tiles) break;
+    const Tile tile = tiles[t];
+    const ConstraintDev& C = cons[tile.constraint];
+    if (!C.sample_raw) continue;
+    constexpr int D = kTilePoints / 256;
+    int32_t s[D];
 #pragma unroll
-  for (int j = 0; j < D; ++j) d[j] = draw_bucket(C, u[j], total);
-  int32_t s[D];
+    for (int j = 0; j < D; ++j) {
+      const int local = j * 256 + (int)threadIdx.x;
+      s[j] = __builtin_nontemporal_load(drawn_idx + C.row0 + tile.start + (local < tile.count ? local : 0));
+    }
+    f32x4 p[D];
 #pragma unroll
-  for (int j = 0; j < D; ++j) s[j] = draw_finish(C, d[j]);
-  f32x4 p[D];
+    for (int j = 0; j < D; ++j) p[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[s[j]];
 #pragma unroll
-  for (int j = 0; j < D; ++j) p[j] = as_global(reinterpret_cast<const f32x4*>(C.xyzd))[s[j]];
-#pragma unroll
-  for (int j = 0; j < D; ++j) {
-    const int local = j * 256 + (int)threadIdx.x;
-    if (local < tile.count) reinterpret_cast<f32x4*>(drawn)[C.row0 + tile.start + local] = p[j];
+    for (int j = 0; j < D; ++j) {
+      const int local = j * 256 + (int)threadIdx.x;
+      if (local < tile.count)
+        __builtin_nontemporal_store(p[j], reinterpret_cast<f32x4*>(drawn) + C.row0 + tile.start + local);
+    }
   }
 }
 
@@ -845,19 +899,17 @@ __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_ker
       accumulate21<ACC>(acc, u);
     }
   }
-  double accd[21];
+  // every sum goes to LDS as soon as its wavefront tree is done (kept in an array until all 21 were reduced,
+  // the f64 copies spilled 8 registers to scratch in every tile's epilogue: 9 KB of scratch traffic per tile,
+  // a tenth of the bytes of the shipped configuration's 1.6 K-residual tiles)
+  __shared__ double lds[kBlockThreads / 64][kPartialSize];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
   for (int k = 0; k < 21; ++k) {
     double v = (double)acc[k];
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    accd[k] = v;
-  }
-  __shared__ double lds[kBlockThreads / 64][kPartialSize];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (lane == 0) {
-#pragma unroll
-    for (int k = 0; k < 21; ++k) lds[wave][k] = accd[k];
+    if (lane == 0) lds[wave][k] = v;
   }
   __syncthreads();
   if (threadIdx.x < 21) {
@@ -895,7 +947,7 @@ __device__ __forceinline__ uint32_t mt_twist_word(uint32_t cur, uint32_t next, u
 // LDS buffer (nobody's old value is overwritten), hence ONE barrier per twist -- it was three dependent
 // LDS phases and seven barriers in place: 363 -> 216 us for the shipped configuration's 200 engines x
 // 193 K outputs (a single-wave version without any s_barrier was slower, 709 us: too few lanes per phase).  Word 623 needs the new word 0: its owner recomputes that one itself.
-constexpr int kMtThreads = 256;
+constexpr int kMtThreads = 227;  // = H: one thread per word of a range, nobody idles behind an exec mask
 // workgroup barrier that orders LDS accesses only (__syncthreads() also drains the global stores)
 __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -913,63 +965,86 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
 __global__ __launch_bounds__(kMtThreads) void mt_generate_kernel(const StreamJobDev* __restrict__ jobs) {
   constexpr int N = Mt19937::kN, M = 397, H = N - M;  // H = 227
   constexpr int kLastOwner = N - 1 - 2 * H;            // thread 169 owns word 623 as its third
-  static_assert(kMtThreads >= H, "one thread per word of a range");
+  constexpr int kStride = 3 * H + 3;                   // a block plus padding: threads 170 .. 226 "own" a third word too
+  static_assert(kMtThreads == H, "one thread per word of a range");
   const StreamJobDev job = jobs[blockIdx.x];
-  __shared__ uint32_t buf[2][N];
+  // The pointers come out of a struct in memory: generic as far as the compiler knows; told that they are
+  // global, the stores go out as global_store_dword (a FLAT store also counts on lgkmcnt, which every
+  // twist's barrier waits for).
+  VGX_GLOBAL uint32_t* const g_out = (VGX_GLOBAL uint32_t*)job.out;
+  VGX_GLOBAL uint32_t* const g_state = (VGX_GLOBAL uint32_t*)job.state;
+  __shared__ uint32_t buf[2][kStride];
   const int t = threadIdx.x;
-  for (int k = t; k < N; k += kMtThreads) buf[0][k] = job.state[k];
-  int idx = (int)job.state[N];  // uniform; N = block used up
+  for (int k = t; k < N; k += kMtThreads) buf[0][k] = g_state[k];
+  for (int k = N + t; k < kStride; k += kMtThreads) buf[0][k] = buf[1][k] = 0u;
+  int idx = (int)g_state[N];  // uniform; N = block used up
   int cur = 0;
   __syncthreads();
-  const bool owner = t < H;
   const bool third = t <= kLastOwner;
-  uint32_t a = 0, b = 0, c = 0;  // this thread's words t, H + t, 2 H + t of the current block
-  if (owner) {
-    a = buf[0][t];
-    b = buf[0][H + t];
-    if (third) c = buf[0][2 * H + t];
-  }
+  // this thread's words t, H + t, 2 H + t of the current block (2 H + t > 623: padding, never stored)
+  uint32_t a = buf[0][t], b = buf[0][H + t], c = buf[0][2 * H + t];
+  // One twist: this thread's three words of the next block from the current one (see above).  The loop a
+  // single wavefront per SIMD issues instruction by instruction (nothing else runs on the CU), so it is kept
+  // short and branch-free: every thread runs the third chain (threads beyond 169 on padding), and the one
+  // special word -- 623 needs the NEW word 0 -- is a select: every thread recomputes word 0 from three
+  // broadcast reads.
+  auto twist = [&]() {
+    const uint32_t* o = buf[cur];
+    uint32_t* w = buf[cur ^ 1];
+    const uint32_t a1 = o[t + 1], b1 = o[H + t + 1], far = o[t + M], c1 = o[2 * H + t + 1];
+    const uint32_t new0 = mt_twist_word(o[0], o[1], o[M]);
+    a = mt_twist_word(a, a1, far);
+    b = mt_twist_word(b, b1, a);
+    c = mt_twist_word(c, t == kLastOwner ? new0 : c1, b);  // (word 623: far = new word 396 = b, next = new word 0)
+    w[t] = a;
+    w[H + t] = b;
+    w[2 * H + t] = c;
+    lds_barrier();
+    cur ^= 1;
+  };
+  // positions [idx, idx + take) of the current block go to out[produced ...] (a partial block: bounds checked)
+  auto store_part = [&](long long produced, int take) {
+    const int pa = t - idx, pb = H + t - idx, pc = 2 * H + t - idx;
+    if (pa >= 0 && pa < take) g_out[produced + pa] = mt_temper(a);
+    if (pb >= 0 && pb < take) g_out[produced + pb] = mt_temper(b);
+    if (third && pc >= 0 && pc < take) g_out[produced + pc] = mt_temper(c);
+  };
   long long produced = 0;
-  while (produced < job.count) {
-    if (idx >= N) {
-      const uint32_t* o = buf[cur];
-      uint32_t* w = buf[cur ^ 1];
-      if (owner) {
-        const uint32_t a1 = o[t + 1], b1 = o[H + t + 1], far = o[t + M];
-        const uint32_t c1 = t < kLastOwner ? o[2 * H + t + 1] : 0u;
-        uint32_t o0 = 0, o1 = 0, oM = 0;
-        if (t == kLastOwner) {
-          o0 = o[0];
-          o1 = o[1];
-          oM = o[M];
-        }
-        a = mt_twist_word(a, a1, far);
-        b = mt_twist_word(b, b1, a);
-        if (t < kLastOwner) c = mt_twist_word(c, c1, b);
-        if (t == kLastOwner) c = mt_twist_word(c, mt_twist_word(o0, o1, oM), b);  // far = new word 396 = b
-        w[t] = a;
-        w[H + t] = b;
-        if (third) w[2 * H + t] = c;
-      }
-      lds_barrier();
-      cur ^= 1;
-      idx = 0;
-    }
+  // head: what is left of the block the engine stands in
+  if (idx < N && produced < job.count) {
     const long long left = job.count - produced;
     const int take = (int)(left < (long long)(N - idx) ? left : (long long)(N - idx));
-    if (owner) {
-      // positions [idx, idx + take) of the block go to out[produced ...]
-      const int pa = t - idx, pb = H + t - idx, pc = 2 * H + t - idx;
-      if (pa >= 0 && pa < take) job.out[produced + pa] = mt_temper(a);
-      if (pb >= 0 && pb < take) job.out[produced + pb] = mt_temper(b);
-      if (third && pc >= 0 && pc < take) job.out[produced + pc] = mt_temper(c);
+    store_part(produced, take);
+    idx += take;
+    produced += take;
+  }
+  // whole blocks: the loop a single wavefront per SIMD issues instruction by instruction (nothing else runs
+  // on the CU), so it is kept short -- no bounds, one running pointer, the three stores at fixed offsets
+  {
+    VGX_GLOBAL uint32_t* p = g_out + produced + t;
+    const long long blocks = (job.count - produced) / N;
+    for (long long k = 0; k < blocks; ++k) {
+      twist();
+      p[0] = mt_temper(a);
+      p[H] = mt_temper(b);
+      if (third) p[2 * H] = mt_temper(c);
+      p += N;
     }
+    if (blocks > 0) idx = N;  // the last whole block is used up
+    produced += blocks * N;
+  }
+  // tail: the first words of one more block
+  if (produced < job.count) {
+    twist();
+    idx = 0;
+    const int take = (int)(job.count - produced);
+    store_part(produced, take);
     idx += take;
     produced += take;
   }
   __syncthreads();
-  for (int k = t; k < N; k += kMtThreads) job.state[k] = buf[cur][k];
-  if (t == 0) job.state[N] = (uint32_t)idx;
+  for (int k = t; k < N; k += kMtThreads) g_state[k] = buf[cur][k];
+  if (t == 0) g_state[N] = (uint32_t)idx;
 }
 
 // Points a fused tile will really load at these poses (its chunks that survive the bounding-sphere
@@ -1552,10 +1627,13 @@ int vgx_reg_create(vgx_ctx ctx, vgx_submap reference, vgx_submap reading, const 
     PointSet& mps = reference->points[cfg->registration_point_type];
     hipError_t e = hipSuccess;
     if (!mps.d_cumulative) {
-      e = hipMalloc(&mps.d_cumulative, (size_t)mps.n * sizeof(double));
+      // + 3 entries of padding (+inf): the draw probes cum[first .. first + 3] with two 16-byte loads and uses
+      // only the entries inside its range, so it never has to clamp the addresses
+      std::vector<double> padded(mps.cumulative_weight);
+      padded.insert(padded.end(), 3, INFINITY);
+      e = hipMalloc(&mps.d_cumulative, padded.size() * sizeof(double));
       if (e == hipSuccess)
-        e = hipMemcpy(mps.d_cumulative, mps.cumulative_weight.data(), (size_t)mps.n * sizeof(double),
-                      hipMemcpyHostToDevice);
+        e = hipMemcpy(mps.d_cumulative, padded.data(), padded.size() * sizeof(double), hipMemcpyHostToDevice);
     }
     if (e == hipSuccess && !mps.d_search_lut) {
       // lut[k] = upper_bound(cumulative, (k / K) * total), k = 0 .. K, in the draw's own f64 arithmetic;
@@ -1891,7 +1969,8 @@ int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs, const int3
     b->any_sampling = total > 0;
     if (b->any_sampling) {
       if (hipMalloc(&b->d_raw, (size_t)total * sizeof(uint32_t)) != hipSuccess ||
-          hipMalloc(&b->d_drawn, (size_t)b->row_offset[(size_t)n] * sizeof(float4)) != hipSuccess) {
+          hipMalloc(&b->d_drawn, (size_t)b->row_offset[(size_t)n] * sizeof(float4)) != hipSuccess ||
+          hipMalloc(&b->d_drawn_idx, (size_t)b->row_offset[(size_t)n] * sizeof(int32_t)) != hipSuccess) {
         vgx_reg_batch_destroy(b);
         return set_error(ctx, VGX_ERR_NOMEM, "vgx_reg_batch_create: sampler stream buffer allocation failed");
       }
@@ -1980,6 +2059,7 @@ int vgx_reg_batch_destroy(vgx_reg_batch b) {
   if (b->d_tiles) (void)hipFree(b->d_tiles);
   if (b->d_tile_dead) (void)hipFree(b->d_tile_dead);
   if (b->d_drawn) (void)hipFree(b->d_drawn);
+  if (b->d_drawn_idx) (void)hipFree(b->d_drawn_idx);
   if (b->d_draw_tiles) (void)hipFree(b->d_draw_tiles);
   if (b->d_tile_first) (void)hipFree(b->d_tile_first);
   if (b->d_partials) (void)hipFree(b->d_partials);
@@ -2021,8 +2101,19 @@ static int batch_begin(vgx_reg_batch b) {
   hipLaunchKernelGGL(mt_generate_kernel, dim3((unsigned)b->stream_jobs.size()), dim3(kMtThreads), 0, ctx->stream,
                      (const StreamJobDev*)b->d_stream_jobs);
   VGX_HIP(ctx, hipGetLastError());
-  hipLaunchKernelGGL(reg_draw_kernel, dim3((unsigned)b->n_draw_tiles), dim3(256), 0, ctx->stream,
-                     (const ConstraintDev*)b->d_desc, (const Tile*)b->d_draw_tiles, (int)b->n_draw_tiles, b->d_drawn);
+  static const int wgs_per_xcd = [] {
+    const char* e = getenv("VGX_DRAW_WGS_PER_XCD");  // A/B switch: tiles in flight per XCD (0: one workgroup per tile)
+    return e ? atoi(e) : kDrawWgsPerXcdDefault;
+  }();
+  // persistent: 8 x wgs_per_xcd workgroups walk the tile sequence; 0 / more workgroups than tiles: one per tile
+  const int per_xcd = (wgs_per_xcd > 0 && 8 * wgs_per_xcd < b->n_draw_tiles) ? wgs_per_xcd : (b->n_draw_tiles + 7) / 8;
+  const dim3 grid((unsigned)(8 * per_xcd));
+  hipLaunchKernelGGL(reg_draw_kernel, grid, dim3(256), 0, ctx->stream, (const ConstraintDev*)b->d_desc,
+                     (const Tile*)b->d_draw_tiles, (int)b->n_draw_tiles, per_xcd, b->d_drawn_idx);
+  VGX_HIP(ctx, hipGetLastError());
+  hipLaunchKernelGGL(reg_gather_points_kernel, grid, dim3(256), 0, ctx->stream, (const ConstraintDev*)b->d_desc,
+                     (const Tile*)b->d_draw_tiles, (int)b->n_draw_tiles, per_xcd, (const int32_t*)b->d_drawn_idx,
+                     b->d_drawn);
   VGX_HIP(ctx, hipGetLastError());
   return VGX_OK;
 }
