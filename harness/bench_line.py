@@ -39,7 +39,7 @@ def _tsdf(t):
             "roofline": _pick(rf, ("bound", "kernel_ms", "longest_walk_steps", "roundtrip_ns_unloaded",
                                    "latency_chain_ms", "atomic_peak_Gops", "atomic_achieved_Gops",
                                    "atomic_throughput_ms", "achieved", "peak", "unit", "frac", "hbm_frac")),
-            "merged_ms_per_scan": mg.get("ms_per_scan"), "merged_launches_per_scan": mg.get("launches_per_scan"),
+            "merged_ms_per_scan": mg.get("ms_per_scan"),
             "reproducible_ms_per_scan": rm.get("ms_per_scan"),
             "reproducible_bit_identical_to_oracle": (rm.get("parity_vs_oracle") or {}).get("bit_identical"),
             "sorted_order_bit_identical_to_oracle": (rm.get("parity_vs_oracle_sorted_order") or {}).get("bit_identical"),

@@ -187,6 +187,24 @@ def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=8):
                       "checker": "oracle/tsdf_oracle.c (single thread, mixed order) [recalled: parity unpinned]"}
         for o in (integ8, layer8):
             o.destroy()
+        # ... and in integration_order_mode "sorted" (voxgraph_mapper.yaml:29), three scans
+        ol_s = orc.TsdfLayer(vs, 16)
+        oi_s = orc.FastTsdfIntegrator(orc.tsdf_config(integration_order=2, **kw), ol_s)
+        layer9 = capi.TsdfLayer(ctx, vs, 16)
+        integ9 = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(deterministic=1, integration_order=capi.TSDF_ORDER_SORTED, **kw), layer9)
+        cu_s = gu_s = 0
+        for k in range(3):
+            cu_s += oi_s.integratePointCloud(poses[k], clouds[k])
+            gu_s += integ9.integrate_device(poses[k], dev[k].data_ptr(), None, n_pts, count=True)
+        sbi, sd, sw, sc = ol_s.download()
+        tbi, td_, tw_, tc = layer9.download()
+        det_parity_sorted = {"scans": 3, "voxel_updates_equal": bool(gu_s == cu_s), "blocks": int(len(sbi)),
+                             "bit_identical": bool(np.array_equal(sbi, tbi) and np.array_equal(sd.view(np.uint32), td_.view(np.uint32))
+                                                   and np.array_equal(sw.view(np.uint32), tw_.view(np.uint32)) and np.array_equal(sc, tc)),
+                             "differs_from_mixed_order": bool(not (np.array_equal(sbi, obi[:len(sbi)]) and len(sbi) == len(obi)
+                                                                   and np.array_equal(sd.view(np.uint32), od.view(np.uint32)))) if cpu_scans == 2 else None}
+        for o in (integ9, layer9):
+            o.destroy()
         # the same port on all host cores: the path does not shard (one active submap), so this is
         # REPLICAS -- one integrator + layer per thread, every thread the same scans.  All replicas start
         # behind a barrier and run their whole sequence inside ONE foreign call (oracle/tsdf_oracle.c
@@ -267,10 +285,14 @@ def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=8):
                                            "note": "vgx_tsdf_integrate into an unreserved layer: pageable host "
                                                    "points, PCIe upload, enlargements and completion wait included"},
                      "merged_integrator": {"ms_per_scan": merged_ms, "Mpoints_per_s": n_pts / merged_ms / 1e3,
-                                           "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                                           # launch / read-back bound: ~30 (LiDAR) to ~50 (depth image) small kernels -- two
+                                                           # stable sorts of rocprim's (7-9 launches each at these sizes) -- and one host
+                                                           # read-back per scan (profiles/r04_tsdf_launches.txt); the HBM figure is kept for
+                                                           # SURVEY 8d's pricing and is NOT what bounds it
+                                                           "roofline": {"bound": "launch", "unit": "GB/s", "hbm_peak_GBs": HBM_PEAK_GBS,
                                                         "bytes_per_launch": 16.0 * n_pts + 24.0 * merged_updates,
-                                                        "achieved": (16.0 * n_pts + 24.0 * merged_updates) / merged_ms / 1e6,
-                                                        "frac": (16.0 * n_pts + 24.0 * merged_updates) / merged_ms / 1e6 / HBM_PEAK_GBS,
+                                                        "hbm_achieved_GBs": (16.0 * n_pts + 24.0 * merged_updates) / merged_ms / 1e6,
+                                                        "hbm_frac": (16.0 * n_pts + 24.0 * merged_updates) / merged_ms / 1e6 / HBM_PEAK_GBS,
                                                         "time": "back-to-back scans, all kernels of a scan (keys, sort, "
                                                                 "heads, rays)"},
                                            "voxel_updates_per_scan": merged_updates, "dropped_updates": merged_dropped,
@@ -283,6 +305,7 @@ def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=8):
                                            "voxel_updates_per_scan": det_updates,
                                            "over_racing_kernel": det_ms / (ms / timed),
                                            "parity_vs_oracle": det_parity,
+                                           "parity_vs_oracle_sorted_order": det_parity_sorted,
                                            "note": "vgx_tsdf_config.deterministic = 1: the single-thread visiting "
                                                    "order resolved in parallel (sort by approximate-set slot, "
                                                    "fixed-point sweeps, ordered per-voxel updates); wall clock incl. "

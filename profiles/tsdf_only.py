@@ -21,7 +21,7 @@ def main():
     out = bench.tsdf_bench(capi, ctx, torch, cpu_scans=int(os.environ.get("CPU_SCANS", "8")))
     brief = {k: {"racing_ms": v["ms_per_scan"], "racing_kernel_ms": v["roofline"]["kernel_ms"],
                  "merged_ms": v["merged_integrator"]["ms_per_scan"], "merged_updates": v["merged_integrator"]["voxel_updates_per_scan"],
-                 "merged_frac": v["merged_integrator"]["roofline"]["frac"],
+                 "merged_hbm_frac": v["merged_integrator"]["roofline"]["hbm_frac"],
                  "reproducible_ms": v["reproducible_mode"]["ms_per_scan"],
                  "reproducible_bit_identical": v["reproducible_mode"]["parity_vs_oracle"]["bit_identical"],
                  "updates": v["voxel_updates_per_scan"], "roofline": v["roofline"],

@@ -73,7 +73,10 @@ struct DetScratch {
   unsigned long long* h_ctr = nullptr;
 };
 
-enum { kCtrChanged = 0, kCtrNew = 1, kCtrError = 2, kCtrDropped = 3, kCtrLong = 4, kCtrOverflow = 5, kCtrCount = 8 };
+// kCtrChanged + (sweep & 1): did sweep `sweep` move a stopping step?  (two flags in turn: a sweep's ray kernel
+// clears the NEXT sweep's flag, so no fill is launched between sweeps)
+enum { kCtrChanged = 0, kCtrNew = 1, kCtrError = 2, kCtrDropped = 3, kCtrLong = 4, kCtrOverflow = 5, kCtrChanged1 = 6, kCtrCount = 8 };
+static_assert(kCtrChanged1 == kCtrChanged + 6, "flag of odd sweeps");
 enum { kRayValid = 1u, kRayClearing = 2u, kRayCast = 4u };
 constexpr uint32_t kInvalidStartKey = 1u << kSetBits;
 constexpr long long kVoxBias = 1ll << 20;  // 21 bits per axis
@@ -118,8 +121,12 @@ __global__ __launch_bounds__(256) void det_points_kernel(vgx_tsdf_config c, floa
                                                         float4* __restrict__ ray_pg, uint32_t* __restrict__ ray_color,
                                                         uint32_t* __restrict__ ray_flags,
                                                         unsigned long long* __restrict__ start_val,
-                                                        uint32_t* __restrict__ start_key) {
+                                                        uint32_t* __restrict__ start_key, uint8_t* __restrict__ ext,
+                                                        unsigned long long* __restrict__ ctr) {
   const long long seq = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  // this scan's counters and "written out completely" marks start here (the scan's first kernel: two fills saved)
+  if (seq < kCtrCount) ctr[seq] = 0ull;
+  if (seq <= n) ext[seq] = 1;
   if (seq >= n) return;
   const long long pi = visiting_order_point(order, seq, n);
   const float px = points_C[3 * pi], py = points_C[3 * pi + 1], pz = points_C[3 * pi + 2];
@@ -316,8 +323,9 @@ __global__ __launch_bounds__(256) void det_seen_kernel(size_t N, const uint32_t*
 __global__ __launch_bounds__(256) void det_ray_kernel(long long n, int max_collisions, const uint32_t* __restrict__ count,
                                                      const uint32_t* __restrict__ off, const uint8_t* __restrict__ seen,
                                                      int32_t* __restrict__ T, uint8_t* __restrict__ broke,
-                                                     unsigned long long* __restrict__ ctr) {
+                                                     unsigned long long* __restrict__ ctr, int parity) {
   const long long seq = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (seq == 0) ctr[parity ? kCtrChanged : kCtrChanged1] = 0ull;  // the next sweep's flag
   if (seq >= n) return;
   const uint32_t cnt = count[seq];
   if (cnt == 0) return;
@@ -336,7 +344,7 @@ __global__ __launch_bounds__(256) void det_ray_kernel(long long n, int max_colli
   if (t != T[seq] || b != broke[seq]) {
     T[seq] = t;
     broke[seq] = b;
-    ctr[kCtrChanged] = 1ull;
+    ctr[parity ? kCtrChanged1 : kCtrChanged] = 1ull;
   }
 }
 
@@ -372,7 +380,9 @@ __device__ __forceinline__ long long lut_cell(const TsdfLayerDev& L, int bx, int
   return rx + (long long)L.lut_dim[0] * (ry + (long long)L.lut_dim[1] * rz);
 }
 
-__global__ __launch_bounds__(256) void det_blocks_kernel(TsdfLayerDev L, size_t M, const uint32_t* __restrict__ c_idx,
+// (M_dev: the number of updates where only the device knows it yet -- the launch covers an upper bound)
+__global__ __launch_bounds__(256) void det_blocks_kernel(TsdfLayerDev L, size_t M, const uint32_t* __restrict__ M_dev,
+                                                        const uint32_t* __restrict__ c_idx,
                                                         const unsigned long long* __restrict__ acc_vox,
                                                         const uint32_t* __restrict__ acc_ray,
                                                         const uint32_t* __restrict__ off,
@@ -380,7 +390,7 @@ __global__ __launch_bounds__(256) void det_blocks_kernel(TsdfLayerDev L, size_t 
                                                         int32_t* __restrict__ new_cells, uint32_t new_cap,
                                                         unsigned long long* __restrict__ ctr) {
   const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= M) return;
+  if (q >= (M_dev ? (size_t)*M_dev : M)) return;
   const uint32_t idx = c_idx[q];
   int x, y, z;
   unpack_vox(acc_vox[idx], x, y, z);
@@ -844,6 +854,7 @@ static int det_commit(vgx_tsdf_integrator I, DetScratch* S, const float T[7], si
   size_t M = N;
   const uint32_t* c_idx = S->s_idx.as<uint32_t>();  // without a filter every sorted access is an update
   const uint32_t* c_key = S->s_key.as<uint32_t>();
+  const uint32_t* M_dev = nullptr;  // where the device keeps the number of updates (cpos[N]) until it has been read back
   if (update) {
     {
       size_t b2 = 0;
@@ -863,15 +874,15 @@ static int det_commit(vgx_tsdf_integrator I, DetScratch* S, const float T[7], si
                        S->c_idx.as<uint32_t>(), S->c_key.as<uint32_t>(), update_set ? I->dev.observed_set : nullptr,
                        I->dev.observed_offset);
     VGX_HIP(ctx, hipGetLastError());
-    uint32_t M32 = 0;
-    VGX_HIP(ctx, hipMemcpyAsync(&M32, cpos + N, 4, hipMemcpyDeviceToHost, st));
-    VGX_HIP(ctx, hipStreamSynchronize(st));
-    M = M32;
+    M_dev = cpos + N;
     c_idx = S->c_idx.as<uint32_t>();
     c_key = S->c_key.as<uint32_t>();
   }
-  if (M == 0) return VGX_OK;
   TsdfLayerDev& L = layer->dev;
+  // ONE read-back for the whole commit (round 3: three, each a stream round trip of 20-40 us): the number of
+  // updates M, the new blocks they need, the layer's block count.  What has to run before it is launched over
+  // the upper bound N and looks M up on the device.
+  size_t new_cap = 0;
   if (ordered_blocks) {
     // new blocks take their pool slots in the order of their first update (the table may have been
     // re-boxed since the last scan)
@@ -883,21 +894,30 @@ static int det_commit(vgx_tsdf_integrator I, DetScratch* S, const float T[7], si
                          cells, ~0ull);
       VGX_HIP(ctx, hipGetLastError());
     }
-    const size_t new_cap = (size_t)std::max<int64_t>(tsdf_last_scan_bound(layer), 1);
+    new_cap = (size_t)std::max<int64_t>(tsdf_last_scan_bound(layer), 1);
     DET_TRY(grow(ctx, S->new_cells, new_cap * 4));
     DET_TRY(grow(ctx, S->new_cells_sorted, new_cap * 4));
     DET_TRY(grow(ctx, S->new_keys, new_cap * 8));
     DET_TRY(grow(ctx, S->new_keys_sorted, new_cap * 8));
-    hipLaunchKernelGGL(det_blocks_kernel, dim3(blocks_for(M)), dim3(256), 0, st, L, M, c_idx,
+    hipLaunchKernelGGL(det_blocks_kernel, dim3(blocks_for(N)), dim3(256), 0, st, L, N, M_dev, c_idx,
                        S->acc_vox.as<unsigned long long>(), S->acc_ray.as<uint32_t>(), S->off.as<uint32_t>(),
                        S->first_touch.as<unsigned long long>(), S->new_cells.as<int32_t>(), (uint32_t)new_cap, S->d_ctr);
     VGX_HIP(ctx, hipGetLastError());
     // from here until det_assign_kernel has put the marked cells back to ~0, a failure leaves marks behind:
     // the next scan refills the table
     S->first_touch_dirty = true;
-    int32_t n_blocks_now = 0;
-    VGX_HIP(ctx, hipMemcpyAsync(&n_blocks_now, L.n_blocks, 4, hipMemcpyDeviceToHost, st));
-    DET_TRY(read_counters(ctx, S));
+  }
+  int32_t n_blocks_now = 0;
+  uint32_t M32 = (uint32_t)N;
+  if (M_dev) VGX_HIP(ctx, hipMemcpyAsync(&M32, M_dev, 4, hipMemcpyDeviceToHost, st));
+  if (ordered_blocks) VGX_HIP(ctx, hipMemcpyAsync(&n_blocks_now, L.n_blocks, 4, hipMemcpyDeviceToHost, st));
+  if (M_dev || ordered_blocks) DET_TRY(read_counters(ctx, S));
+  M = M32;
+  if (M == 0) {
+    S->first_touch_dirty = false;  // nothing was marked
+    return VGX_OK;
+  }
+  if (ordered_blocks) {
     const size_t n_new = (size_t)S->h_ctr[kCtrNew];
     if (n_new > new_cap)
       return set_error(ctx, VGX_ERR_HIP, "TSDF reproducible mode: more new blocks than the scan's reach allows (internal error)");
@@ -982,11 +1002,12 @@ int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points,
   DET_TRY(grow(ctx, S->off, (np + 1) * 4));
   DET_TRY(grow(ctx, S->T, np * 4));
   DET_TRY(grow(ctx, S->broke, np));
-  VGX_HIP(ctx, hipMemsetAsync(S->d_ctr, 0, kCtrCount * 8, st));
-  hipLaunchKernelGGL(det_points_kernel, dim3(blocks_for(np)), dim3(256), 0, st, c, vsi, T[0], T[1], T[2], T[3], T[4], T[5],
+  DET_TRY(grow(ctx, S->full_count, np * 4));
+  DET_TRY(grow(ctx, S->ext, np + 1));
+  hipLaunchKernelGGL(det_points_kernel, dim3(blocks_for(np + 1)), dim3(256), 0, st, c, vsi, T[0], T[1], T[2], T[3], T[4], T[5],
                      T[6], (const float*)d_points, (const uint32_t*)d_rgba, (long long)n, order, (int)freespace,
                      I->dev.start_offset, S->ray_pg.as<float4>(), S->ray_color.as<uint32_t>(), S->ray_flags.as<uint32_t>(),
-                     S->start_val.as<unsigned long long>(), S->start_key.as<uint32_t>());
+                     S->start_val.as<unsigned long long>(), S->start_key.as<uint32_t>(), S->ext.as<uint8_t>(), S->d_ctr);
   VGX_HIP(ctx, hipGetLastError());
   {
     size_t bytes = 0;
@@ -1006,13 +1027,11 @@ int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points,
     VGX_HIP(ctx, hipGetLastError());
   }
   // ---- 2. walks written out (bounded speculation: see det_count_kernel), sorted, swept to the fixed point ----
-  DET_TRY(grow(ctx, S->full_count, np * 4));
-  DET_TRY(grow(ctx, S->ext, np + 1));
-  // The first count is of the COMPLETE walks.  Small scans (a LiDAR sweep at 0.2 m: < 1 M steps) are swept as
+  // The first count is of the COMPLETE walks (det_points_kernel marked every ray "written out completely").  Small scans (a LiDAR sweep at 0.2 m: < 1 M steps) are swept as
   // they are -- an attempt costs a dozen launches and two read-backs, more than the steps saved; large ones
   // (a depth image at 0.05 m: 18 M steps) are cut to `kSpeculationCap` steps per ray and extended on demand.
   // With the early-out switched off every ray runs its full length anyway.
-  VGX_HIP(ctx, hipMemsetAsync(S->ext.p, 1, np + 1, st));
+  bool capped = false;  // this attempt cut rays short: whether one of them ran on has to be looked at afterwards
   bool may_cap = c.max_consecutive_ray_collisions < (1 << 20);
   constexpr uint32_t kCapThreshold = 4u << 20;
   size_t N = 0;
@@ -1058,6 +1077,7 @@ int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points,
       may_cap = false;
       if (total > kCapThreshold) {  // count again, this time cut to the cap
         VGX_HIP(ctx, hipMemsetAsync(S->ext.p, 0, np + 1, st));
+        capped = true;
         continue;
       }
     }
@@ -1118,7 +1138,6 @@ int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points,
       for (long long sweep = 0;; ++sweep) {
         if (sweep > n + 1 + kSweepsPerLook)
           return set_error(ctx, VGX_ERR_HIP, "TSDF reproducible mode: the sweeps did not settle (internal error)");
-        VGX_HIP(ctx, hipMemsetAsync(S->d_ctr + kCtrChanged, 0, 8, st));
         size_t bytes = S->tmp.bytes;
         VGX_HIP(ctx, rocprim::exclusive_scan(S->tmp.p, bytes, rocprim::make_transform_iterator(pos, happened),
                                              S->last.as<uint32_t>(), 0u, N, rocprim::maximum<uint32_t>(), st));
@@ -1128,15 +1147,16 @@ int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points,
         VGX_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL(det_ray_kernel, dim3(blocks_for(np)), dim3(256), 0, st, (long long)n,
                            (int)c.max_consecutive_ray_collisions, S->count.as<uint32_t>(), S->off.as<uint32_t>(),
-                           S->seen.as<uint8_t>(), S->T.as<int32_t>(), S->broke.as<uint8_t>(), S->d_ctr);
+                           S->seen.as<uint8_t>(), S->T.as<int32_t>(), S->broke.as<uint8_t>(), S->d_ctr, (int)(sweep & 1));
         VGX_HIP(ctx, hipGetLastError());
         if ((sweep + 1) % kSweepsPerLook != 0) continue;
-        DET_TRY(read_counters(ctx, S));  // kCtrChanged: of the last sweep
+        DET_TRY(read_counters(ctx, S));  // the flag of the last sweep
         if (S->h_ctr[kCtrError]) break;
-        if (!S->h_ctr[kCtrChanged]) break;
+        if (!S->h_ctr[(sweep & 1) ? kCtrChanged1 : kCtrChanged]) break;
       }
     }
     if (S->h_ctr[kCtrError]) break;
+    if (!capped) break;  // every ray was written out completely: nothing can have been cut short
     VGX_HIP(ctx, hipMemsetAsync(S->d_ctr + kCtrOverflow, 0, 8, st));
     hipLaunchKernelGGL(det_extend_kernel, dim3(blocks_for(np)), dim3(256), 0, st, (long long)n, S->count.as<uint32_t>(),
                        S->full_count.as<uint32_t>(), S->broke.as<uint8_t>(), S->ext.as<uint8_t>(), S->d_ctr);
