@@ -450,7 +450,7 @@ def main():
             bt.evaluate_normal(ps, to_host=False)
             if use_dist:
                 bt.scatter_normal(blocks.data_ptr(), zero_first=True)
-                dist.all_reduce(blocks)
+                dist.all_reduce(blocks.view(torch.int64))      # integer sum of disjoint rows: the bit patterns, in any order
                 assembler.assemble(blocks.data_ptr(), n_nodes, buf.data_ptr())
             else:
                 bt.assemble(n_nodes, buf.data_ptr(), zero_first=True)
@@ -544,7 +544,7 @@ def main():
                 batch_s.evaluate_normal(poses, to_host=False)
                 if use_dist:
                     batch_s.scatter_normal(blocks_s.data_ptr(), zero_first=True)
-                    dist.all_reduce(blocks_s)
+                    dist.all_reduce(blocks_s.view(torch.int64))
                     asm_s.assemble(blocks_s.data_ptr(), n_sub, buf_s.data_ptr())
                 else:
                     batch_s.assemble(n_sub, buf_s.data_ptr(), zero_first=True)

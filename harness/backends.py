@@ -5,8 +5,8 @@ import numpy as np
 
 class GpuBackend:
     """One solver evaluation of the registration constraints of this rank's shard:
-    vgx_reg_batch_evaluate_normal -> vgx_reg_batch_scatter_normal -> ONE all-reduce(sum, f64) of the
-    [n_global][45] array of per-constraint blocks (RCCL under torch.distributed) -> vgx_reg_assembler_assemble.
+    vgx_reg_batch_evaluate_normal -> vgx_reg_batch_scatter_normal -> ONE all-reduce(sum, the words taken as
+    int64) of the [n_global][45] array of per-constraint blocks (RCCL under torch.distributed) -> vgx_reg_assembler_assemble.
     Every row of the array is written by exactly one rank, so the sum is exact in any order and every rank
     assembles the single-GPU buffer bit for bit, whatever the number of ranks (include/voxgraph_amd.h).
     Without torch.distributed the batch holds the whole list and assembles directly."""
@@ -39,7 +39,9 @@ class GpuBackend:
             same = self._library_stream_is_torchs()
             if not same:
                 self.ctx.synchronize()
-            self.dist.all_reduce(self.blocks)
+            # summed as int64 words: a word is non-zero on exactly one rank, so the sum is that rank's BIT PATTERN
+            # whatever order the collective adds in (an f64 sum would also turn a -0.0 into +0.0)
+            self.dist.all_reduce(self.blocks.view(self.torch.int64))
             if not same:
                 self.torch.cuda.current_stream().synchronize()
             self.assembler.assemble(self.blocks.data_ptr(), self.n_nodes, self.buf.data_ptr())

@@ -327,8 +327,10 @@ VGX_API int64_t vgx_reg_fused_size(int32_t n_nodes, int32_t n_global);
  *   1. every shard:  vgx_reg_batch_evaluate_normal, then vgx_reg_batch_scatter_normal writes its [n][45]
  *      blocks (d_normal NULL: the batch's own) into rows global_index[c] of a DEVICE [n_global][45] f64
  *      array, zeroed first when zero_first != 0;
- *   2. ONE all-reduce(sum, f64) of that array (n_global x 360 B: 423 KB for 1176 constraints).  Every row
- *      is written by exactly one shard and is zero everywhere else, so the sum is exact in ANY order;
+ *   2. ONE all-reduce(sum) of that array (n_global x 360 B: 423 KB for 1176 constraints), its words taken as
+ *      64-bit INTEGERS: every row is written by exactly one shard and is all-zero-bits everywhere else, so
+ *      the integer sum is that shard's bit pattern in ANY order (an f64 sum is exact too, but turns a -0.0
+ *      into +0.0);
  *   3. vgx_reg_assembler_assemble builds the fused buffer (layout above, vgx_reg_fused_size(n_nodes, n))
  *      from the complete array in list order -- what a single vgx_reg_batch over the whole list computes.
  * The assembler holds the list's node structure (node_pair[n][2], the caller's constraint order) on `ctx`. */
@@ -375,8 +377,9 @@ VGX_API int32_t vgx_reg_multi_num_shards(vgx_reg_multi multi);
 /* How the contexts' results meet on context 0.  Default VGX_REDUCE_PEER_SUM (the name is round 2's: since
  * round 4 nothing is summed): context 0 GATHERS every constraint's [45] block from the context that computed
  * it, through xGMI peer mappings, and assembles the fused buffer once, in list order.
- * VGX_REDUCE_RCCL: ONE ncclAllReduce(sum, f64) per solver evaluation over xGMI (BASELINE north_star) of the
- * [n][45] array of blocks, every context contributing its own rows and zeros elsewhere -- exact in any order
+ * VGX_REDUCE_RCCL: ONE ncclAllReduce(sum) per solver evaluation over xGMI (BASELINE north_star) of the
+ * [n][45] array of blocks (words summed as int64), every context contributing its own rows and zero bits
+ * elsewhere -- the contributing context's bit pattern in any order
  * -- then the same assembly (librccl.so is opened at run time, one communicator per context from
  * ncclCommInitAll, so every context needs its own device; VGX_ERR_UNSUPPORTED if RCCL cannot be opened or two
  * contexts share a device).  Either way the buffer is the one a single vgx_reg_batch over the whole list

@@ -50,9 +50,14 @@ def main():
     blocks = np.zeros((len(pairs), 45))
     for c in mine:
         blocks[c] = normal(c)
+    blocks[mine[0], 7] = -0.0                       # a negative zero must come through as one
     tb = torch.from_numpy(blocks)
-    dist.all_reduce(tb)
-    assert np.array_equal(assemble_fused(list(tb.numpy()), pairs, 4), full)
+    dist.all_reduce(tb.view(torch.int64))           # integer sum of disjoint rows: the bit patterns themselves
+    want = np.stack([normal(c) for c in range(len(pairs))])
+    want[shards[0][0], 7] = -0.0
+    want[shards[1][0], 7] = -0.0
+    assert np.array_equal(tb.numpy().view(np.uint64), want.view(np.uint64))
+    assert np.array_equal(assemble_fused(list(tb.numpy()), pairs, 4), assemble_fused(list(want), pairs, 4))
     dist.barrier()
     if rank == 0:
         print("SHARD_ALLREDUCE_OK")

@@ -31,7 +31,7 @@ extern "C" {
 typedef struct ncclComm* ncclComm_t;
 typedef enum { ncclSuccess = 0 } ncclResult_t;
 typedef enum { ncclSum = 0 } ncclRedOp_t;
-typedef enum { ncclFloat64 = 8, ncclDouble = 8 } ncclDataType_t;
+typedef enum { ncclInt64 = 4, ncclFloat64 = 8, ncclDouble = 8 } ncclDataType_t;
 ncclResult_t ncclCommInitAll(ncclComm_t* comms, int ndev, const int* devlist);
 ncclResult_t ncclCommDestroy(ncclComm_t comm);
 ncclResult_t ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op,
@@ -442,7 +442,9 @@ int vgx_reg_multi_evaluate_fused(vgx_reg_multi m, const double* poses, int32_t n
         device_failed = true;  // (no early return: an open RCCL group would stay open for the whole process)
         break;
       }
-      r = api.AllReduce(s.d_all, s.d_all, (size_t)m->n * kNormalSize, ncclDouble, ncclSum, m->comms[k], s.ctx->stream);
+      // summed as 64-bit INTEGERS: every word is non-zero on at most one context, so the integer sum IS that
+      // context's bit pattern whatever the order -- an f64 sum would also turn a -0.0 into +0.0
+      r = api.AllReduce(s.d_all, s.d_all, (size_t)m->n * kNormalSize, ncclInt64, ncclSum, m->comms[k], s.ctx->stream);
     }
     if (group_open) {
       const ncclResult_t r2 = api.GroupEnd();
