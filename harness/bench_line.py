@@ -129,6 +129,9 @@ def compact(full, detail_path):
         out["pipeline_config2"] = _pick(c2, ("submaps", "scans", "tsdf_integrate_ms_per_scan", "finish_submap_ms",
                                              "solves", "solve_ms_total", "xy_rmse_m_odometry_only",
                                              "xy_rmse_m_optimised", "dropped_updates"))
+        rep = c2.get("reproducible_tsdf_mode") or {}
+        out["pipeline_config2"]["xy_rmse_m_optimised_reproducible_tsdf"] = rep.get("xy_rmse_m_optimised")
+        out["pipeline_config2"]["tsdf_ms_per_scan_reproducible"] = rep.get("tsdf_integrate_ms_per_scan")
     out["detail"] = detail_path
     out = _r(out)
     line = json.dumps(out, separators=(",", ":"))

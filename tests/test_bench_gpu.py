@@ -129,6 +129,8 @@ def test_single_gpu_line_has_the_contract_fields(single):
     # configs[1] stand-in, bounded cut
     c2 = d["pipeline_config2"]
     assert c2["submaps"] == 10 and c2["dropped_updates"] == 0 and c2["solves"] == 9
+    # ... and once more with the scans integrated in the reproducible mode: the same number on every run
+    assert 0 < c2["reproducible_tsdf_mode"]["xy_rmse_m_optimised"] < c2["xy_rmse_m_odometry_only"]
 
 
 def c5_headline(c5):

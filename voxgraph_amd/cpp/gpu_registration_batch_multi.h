@@ -14,8 +14,9 @@
 //
 // Per solver evaluation every GPU runs the fused pass on its share from its own host thread; the
 // per-constraint normal blocks come back to the host (no collective is needed for residual
-// blocks).  Solvers that consume normal equations directly use EvaluateFused(): one fixed-order
-// sum of the per-GPU buffers on GPU 0 through xGMI peer mappings (vgx_reg_multi_evaluate_fused).
+// blocks).  Solvers that consume normal equations directly use EvaluateFused(): the per-constraint
+// blocks are gathered on GPU 0 through xGMI peer mappings and assembled once, in list order -- the
+// single-GPU buffer bit for bit, whatever the placement (vgx_reg_multi_evaluate_fused).
 #ifndef VOXGRAPH_AMD_CPP_GPU_REGISTRATION_BATCH_MULTI_H_
 #define VOXGRAPH_AMD_CPP_GPU_REGISTRATION_BATCH_MULTI_H_
 
@@ -34,13 +35,16 @@ class GpuRegistrationBatchMulti : public GpuRegistrationBlocks {
   GpuRegistrationBatchMulti(const GpuRegistrationBatchMulti&) = delete;
   GpuRegistrationBatchMulti& operator=(const GpuRegistrationBatchMulti&) = delete;
 
-  // Greedy longest-processing-time placement: shard[c] = index into the context list on which
-  // constraint c's cost function must be created.
-  std::vector<int32_t> PlanShards(const std::vector<int64_t>& residuals_per_constraint) const {
-    std::vector<int32_t> shard(residuals_per_constraint.size());
-    if (vgx_lpt_shards(static_cast<int32_t>(shard.size()), residuals_per_constraint.data(),
-                       static_cast<int32_t>(gpus_.size()), shard.data()) != VGX_OK)
-      throw std::runtime_error("vgx_lpt_shards failed");
+  // Placement: shard[c] = index into the context list on which constraint c's cost function must be
+  // created.  contiguous = true (default): the list cut into consecutive runs of equal weight
+  // (vgx_contiguous_shards) -- voxgraph creates constraints in submap order, so a GPU then needs only
+  // the submaps of one stretch of the map (a third of them at 8 GPUs) and balances as well as LPT;
+  // false: greedy longest-processing-time (vgx_lpt_shards).  Results do not depend on the choice.
+  std::vector<int32_t> PlanShards(const std::vector<int64_t>& weight_per_constraint, bool contiguous = true) const {
+    std::vector<int32_t> shard(weight_per_constraint.size());
+    const int rc = (contiguous ? vgx_contiguous_shards : vgx_lpt_shards)(
+        static_cast<int32_t>(shard.size()), weight_per_constraint.data(), static_cast<int32_t>(gpus_.size()), shard.data());
+    if (rc != VGX_OK) throw std::runtime_error("constraint placement failed");
     return shard;
   }
 
