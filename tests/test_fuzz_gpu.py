@@ -52,3 +52,9 @@ def test_reg_at_128_cubed_every_row_equal_and_fused_sums_close():
 
 def test_sampling_at_128_cubed_follows_the_oracles_streams():
     assert _run("fuzz_sampling_large", 3, 300) == 0
+
+
+def test_sharded_evaluation_is_the_single_batch_bit_for_bit():
+    """random pose graphs sharded over 1-8 contexts by LPT / contiguous / arbitrary placements: fused buffer,
+    per-constraint blocks and the scatter -> int64 sum -> assemble route equal the single batch's bits (25 graphs)"""
+    assert _run("fuzz_multi", 25, 700) == 0
