@@ -27,7 +27,8 @@ def _run(cmd, tmp, env=None, timeout=900):
     assert r.returncode == 0, r.stderr[-3000:]
     # (the gloo backend of the dry runs announces itself on stdout; RCCL's banner goes to stderr)
     lines = [l for l in r.stdout.splitlines() if l.strip() and not l.startswith("[Gloo]")]
-    assert len(lines) == 1 and lines[0].startswith("{") and r.stdout.rstrip().endswith(lines[0]), r.stdout[-2000:]
+    assert len(lines) == 1 and lines[0].startswith("{") and r.stdout.rstrip().endswith(lines[0]), \
+        [l[:200] for l in lines[:-1]] + [r.stdout[-300:]]
     assert len(lines[0]) < LINE_LIMIT, len(lines[0])
     line = json.loads(lines[0])
     full = json.load(open(detail))
