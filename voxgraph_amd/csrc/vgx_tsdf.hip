@@ -1171,8 +1171,8 @@ static int visiting_order(vgx_tsdf_integrator I, const void* d_points, int64_t n
       VGX_HIP(ctx, hipMalloc(&I->d_oidx[k], (size_t)n * 4));
     }
     size_t bytes = 0;
-    VGX_HIP(ctx, rocprim::radix_sort_pairs(nullptr, bytes, I->d_okey[0], I->d_okey[1], I->d_oidx[0], I->d_oidx[1], (size_t)n, 0,
-                                           32, ctx->stream));
+    VGX_HIP(ctx, stable_sort_pairs(nullptr, bytes, I->d_okey[0], I->d_okey[1], I->d_oidx[0], I->d_oidx[1], (size_t)n, 32,
+                                   ctx->stream));
     VGX_HIP(ctx, hipMalloc(&I->d_osort, std::max<size_t>(bytes, 16)));
     I->osort_bytes = bytes;
     I->order_cap = n;
@@ -1181,8 +1181,8 @@ static int visiting_order(vgx_tsdf_integrator I, const void* d_points, int64_t n
                      (const float*)d_points, (long long)n, I->d_okey[0], I->d_oidx[0]);
   VGX_HIP(ctx, hipGetLastError());
   size_t bytes = I->osort_bytes;
-  VGX_HIP(ctx, rocprim::radix_sort_pairs(I->d_osort, bytes, I->d_okey[0], I->d_okey[1], I->d_oidx[0], I->d_oidx[1], (size_t)n, 0, 32,
-                                         ctx->stream));
+  VGX_HIP(ctx, stable_sort_pairs(I->d_osort, bytes, I->d_okey[0], I->d_okey[1], I->d_oidx[0], I->d_oidx[1], (size_t)n, 32,
+                                 ctx->stream));
   *order = I->d_oidx[1];
   return VGX_OK;
 }
@@ -1292,8 +1292,8 @@ static int merged_integrate_locked(vgx_tsdf_integrator I, const float T[7], cons
       VGX_HIP(ctx, hipMalloc(&I->d_gcount, ((size_t)n + 1) * 4));
       if (!I->d_mcounters) VGX_HIP(ctx, hipMalloc(&I->d_mcounters, 32));
       size_t bytes = 0, b2 = 0;
-      VGX_HIP(ctx, rocprim::radix_sort_pairs(nullptr, bytes, I->d_mkeys[0], I->d_mkeys[1], I->d_midx[0], I->d_midx[1],
-                                             (size_t)n, 0, 64, ctx->stream));
+      VGX_HIP(ctx, stable_sort_pairs(nullptr, bytes, I->d_mkeys[0], I->d_mkeys[1], I->d_midx[0], I->d_midx[1], (size_t)n, 64,
+                                     ctx->stream));
       VGX_HIP(ctx, rocprim::exclusive_scan(nullptr, b2,
                                            rocprim::make_transform_iterator(rocprim::make_counting_iterator<unsigned int>(0u),
                                                                             MergedHeadOp{I->d_mkeys[1]}),
@@ -1318,8 +1318,8 @@ static int merged_integrate_locked(vgx_tsdf_integrator I, const float T[7], cons
     VGX_HIP(ctx, hipGetLastError());
     size_t bytes = I->msort_bytes;
     // stable: equal keys keep the visiting order they were written in
-    VGX_HIP(ctx, rocprim::radix_sort_pairs(I->d_msort, bytes, I->d_mkeys[0], I->d_mkeys[1], I->d_midx[0], I->d_midx[1],
-                                           (size_t)n, 0, 64, ctx->stream));
+    VGX_HIP(ctx, stable_sort_pairs(I->d_msort, bytes, I->d_mkeys[0], I->d_mkeys[1], I->d_midx[0], I->d_midx[1], (size_t)n, 64,
+                                   ctx->stream));
     keys_sorted = I->d_mkeys[1];
     idx_sorted = I->d_midx[1];
     bytes = I->msort_bytes;

@@ -32,6 +32,7 @@
 // HBM traffic is a few sorts and scans over the speculative accesses (~60 B each); the mode trades
 // 10-50 x the racing kernel's time for a layer that is the same bit for bit on every run.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -61,22 +62,41 @@ struct Buf {
 struct DetScratch {
   // per point, indexed by position in the visiting order
   Buf ray_pg, ray_color, ray_flags, start_val, start_key, start_key_sorted, start_seq_sorted, count, off, T, broke,
-      full_count, ext;
+      full_count, ext, walked;
   // per speculative access
   Buf acc_vox, acc_key, acc_ray, s_key, s_idx, s_r, s_k, s_h, last, seen, c_idx, c_key;
   Buf tmp;  // rocprim temporary storage
   // block allocation
   Buf first_touch, new_cells, new_cells_sorted, new_keys, new_keys_sorted, long_runs, t_at, t_sdf, t_w, t_color, t_far;
   bool first_touch_dirty = false;  // a scan failed between marking and assigning: refill
-  // device counters {changed, n_new, error, pad, total accesses, total updates (u64 each)} + pinned mirror
+  // device counters (u64 each, enum below) + a pinned mirror; behind the mirror, pinned too, the other small
+  // values a scan reads back (kHost*): every copy of a read-back queues behind the previous one and only the
+  // last synchronise waits (a copy into pageable memory is a stream round trip of its own)
   unsigned long long* d_ctr = nullptr;
   unsigned long long* h_ctr = nullptr;
+  // the sweeps (det_sweep_kernel): one 8-byte state per tile of the sorted accesses, tagged with the sweep's
+  // epoch so that nothing has to be cleared between sweeps; zeroed when (re)allocated
+  Buf tile_state;
+  uint32_t sweep_epoch = 0;
+  // what the sweep's last block tells the host (pinned, written from the kernel): sweep sequence number << 2 |
+  // error << 1 | "a stopping step moved"
+  unsigned long long* h_flag = nullptr;
+  unsigned long long* d_flag = nullptr;  // the same word as the device addresses it
+  unsigned long long flag_seq = 0;
+  bool start_capped = false;  // the previous scan's complete walks were too many to write out: count capped at once
+  long long ext_points = -1;  // ext[] holds the previous scan's marks for a scan of this many points (-1: nothing to keep)
 };
 
-// kCtrChanged + (sweep & 1): did sweep `sweep` move a stopping step?  (two flags in turn: a sweep's ray kernel
-// clears the NEXT sweep's flag, so no fill is launched between sweeps)
-enum { kCtrChanged = 0, kCtrNew = 1, kCtrError = 2, kCtrDropped = 3, kCtrLong = 4, kCtrOverflow = 5, kCtrChanged1 = 6, kCtrCount = 8 };
-static_assert(kCtrChanged1 == kCtrChanged + 6, "flag of odd sweeps");
+// kCtrArrive: the ray kernel's blocks as they finish (low word) and how many of them moved a stopping step
+// (high word); kCtrTicket: the sweep kernel's tiles in the order they start.  Both are back at zero when a
+// sweep's ray kernel ends (its last block) and at the start of every scan (det_points_kernel).
+// kCtrTotal: the accesses det_count_kernel counted (64 bits: an overflowing scan is seen, not wrapped); kCtrM /
+// kCtrBlocks: the updates and the layer's block count as det_blocks_kernel found them (so that one copy of the
+// counters is the whole read-back of a commit).
+enum { kCtrChanged = 0, kCtrNew = 1, kCtrError = 2, kCtrDropped = 3, kCtrLong = 4, kCtrOverflow = 5, kCtrArrive = 6, kCtrTicket = 7,
+       kCtrTotal = 8, kCtrM = 9, kCtrBlocks = 10,
+       kCtrCount = 12,
+       kHostTotal = kCtrCount, kHostM, kHostTooLong, kHostWords };
 enum { kRayValid = 1u, kRayClearing = 2u, kRayCast = 4u };
 constexpr uint32_t kInvalidStartKey = 1u << kSetBits;
 constexpr long long kVoxBias = 1ll << 20;  // 21 bits per axis
@@ -84,14 +104,15 @@ constexpr long long kVoxBias = 1ll << 20;  // 21 bits per axis
 void det_scratch_free(DetScratch* s) {
   if (!s) return;
   Buf* all[] = {&s->ray_pg, &s->ray_color, &s->ray_flags, &s->start_val, &s->start_key, &s->start_key_sorted,
-                &s->start_seq_sorted, &s->count, &s->off, &s->T, &s->broke, &s->full_count, &s->ext, &s->acc_vox, &s->acc_key, &s->acc_ray,
+                &s->start_seq_sorted, &s->count, &s->off, &s->T, &s->broke, &s->full_count, &s->ext, &s->walked, &s->acc_vox, &s->acc_key, &s->acc_ray,
                 &s->s_key, &s->s_idx, &s->s_r, &s->s_k, &s->s_h, &s->last, &s->seen, &s->c_idx, &s->c_key, &s->tmp,
                 &s->first_touch, &s->new_cells, &s->new_cells_sorted, &s->new_keys, &s->new_keys_sorted, &s->long_runs,
-                &s->t_at, &s->t_sdf, &s->t_w, &s->t_color, &s->t_far};
+                &s->t_at, &s->t_sdf, &s->t_w, &s->t_color, &s->t_far, &s->tile_state};
   for (Buf* b : all)
     if (b->p) (void)hipFree(b->p);
   if (s->d_ctr) (void)hipFree(s->d_ctr);
   if (s->h_ctr) (void)hipHostFree(s->h_ctr);
+  if (s->h_flag) (void)hipHostFree(s->h_flag);
   delete s;
 }
 
@@ -122,11 +143,14 @@ __global__ __launch_bounds__(256) void det_points_kernel(vgx_tsdf_config c, floa
                                                         uint32_t* __restrict__ ray_flags,
                                                         unsigned long long* __restrict__ start_val,
                                                         uint32_t* __restrict__ start_key, uint8_t* __restrict__ ext,
-                                                        unsigned long long* __restrict__ ctr) {
+                                                        int ext_init, unsigned long long* __restrict__ ctr) {
   const long long seq = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   // this scan's counters and "written out completely" marks start here (the scan's first kernel: two fills saved)
-  if (seq < kCtrCount) ctr[seq] = 0ull;
-  if (seq <= n) ext[seq] = 1;
+  if (seq == 0) {
+#pragma unroll
+    for (int i = 0; i < kCtrCount; ++i) ctr[i] = 0ull;  // (one thread: a scan may have fewer points than counters)
+  }
+  if (seq <= n && ext_init < 2) ext[seq] = (uint8_t)ext_init;  // (2: the previous scan's marks stay, det_extend_kernel)
   if (seq >= n) return;
   const long long pi = visiting_order_point(order, seq, n);
   const float px = points_C[3 * pi], py = points_C[3 * pi + 1], pz = points_C[3 * pi + 2];
@@ -165,24 +189,29 @@ __global__ __launch_bounds__(256) void det_points_kernel(vgx_tsdf_config c, floa
 }
 
 // ---- start set: "already present" = the previous point that hit this slot wrote the same value ----
-// pass 0 decides which rays are cast; pass 1 leaves the slot holding what its last point wrote
+// Which rays are cast.  (What the slot holds afterwards -- what its last point wrote -- is stored by
+// start_set_after, from the next kernel: every thread of this one has to have read the old value first.)
 __global__ __launch_bounds__(256) void det_start_kernel(long long n, const uint32_t* __restrict__ key_sorted,
                                                        const uint32_t* __restrict__ seq_sorted,
                                                        const unsigned long long* __restrict__ start_val,
-                                                       unsigned long long* __restrict__ start_set,
-                                                       uint32_t* __restrict__ ray_flags, int pass) {
+                                                       const unsigned long long* __restrict__ start_set,
+                                                       uint32_t* __restrict__ ray_flags) {
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   const uint32_t key = key_sorted[p];
   if (key == kInvalidStartKey) return;
   const uint32_t seq = seq_sorted[p];
   const unsigned long long mine = start_val[seq];
-  if (pass == 0) {
-    const unsigned long long prev = (p > 0 && key_sorted[p - 1] == key) ? start_val[seq_sorted[p - 1]] : start_set[key];
-    if (prev != mine) ray_flags[seq] |= kRayCast;
-  } else if (p == n - 1 || key_sorted[p + 1] != key) {
-    start_set[key] = mine;
-  }
+  const unsigned long long prev = (p > 0 && key_sorted[p - 1] == key) ? start_val[seq_sorted[p - 1]] : start_set[key];
+  if (prev != mine) ray_flags[seq] |= kRayCast;
+}
+__device__ __forceinline__ void start_set_after(long long p, long long n, const uint32_t* __restrict__ key_sorted,
+                                                const uint32_t* __restrict__ seq_sorted,
+                                                const unsigned long long* __restrict__ start_val,
+                                                unsigned long long* __restrict__ start_set) {
+  if (p >= n) return;
+  const uint32_t key = key_sorted[p];
+  if (key != kInvalidStartKey && (p == n - 1 || key_sorted[p + 1] != key)) start_set[key] = start_val[seq_sorted[p]];
 }
 
 // ---- 2a. how far every cast ray is written out --------------------------------------------------------
@@ -199,10 +228,16 @@ __global__ __launch_bounds__(256) void det_count_kernel(vgx_tsdf_config c, float
                                                        const uint32_t* __restrict__ ray_flags,
                                                        const uint8_t* __restrict__ ext, uint32_t* __restrict__ count,
                                                        uint32_t* __restrict__ full_count,
+                                                       const uint32_t* __restrict__ key_sorted,
+                                                       const uint32_t* __restrict__ seq_sorted,
+                                                       const unsigned long long* __restrict__ start_val,
+                                                       unsigned long long* __restrict__ start_set,
                                                        unsigned long long* __restrict__ ctr) {
   const long long seq = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (seq > n) return;
-  uint32_t full = 0;
+  // (a second job for the same thread index: the start set's state after this scan; a repeated count stores the
+  // same values again)
+  start_set_after(seq, n, key_sorted, seq_sorted, start_val, start_set);
+  uint32_t full = 0, written = 0;
   if (seq < n && (ray_flags[seq] & kRayCast)) {
     const float4 g = ray_pg[seq];
     const RayDda r = ray_setup(c, vsi, tx, ty, tz, g.x, g.y, g.z, (ray_flags[seq] & kRayClearing) != 0, false);
@@ -211,22 +246,37 @@ __global__ __launch_bounds__(256) void det_count_kernel(vgx_tsdf_config c, float
       else full = (uint32_t)(r.steps + 1);
     }
   }
-  const bool complete = seq < n && ext[seq] != 0;
-  count[seq] = complete ? full : min(full, kSpeculationCap);  // count[n] = 0: the scan's last output is the total
-  if (seq < n) full_count[seq] = full;
+  if (seq <= n) {
+    const bool complete = seq < n && ext[seq] != 0;
+    written = complete ? full : min(full, kSpeculationCap);
+    count[seq] = written;  // count[n] = 0: the scan's last output is the total
+    if (seq < n) full_count[seq] = full;
+  }
+  // the scan's total, in 64 bits (the 32-bit offsets wrap silently): one atomic per wave
+  unsigned long long sum = written;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) sum += __shfl_down(sum, d);
+  if ((threadIdx.x & 63) == 0 && sum) atomicAdd(&ctr[kCtrTotal], sum);
 }
 
-// after the sweeps of an attempt: rays that did not stop within what was written out of them
+// After the sweeps of an attempt: rays that did not stop within what was written out of them have to be written
+// out completely (overflow: another attempt).  The marks also stay for the NEXT scan of as many points: the rays
+// that run on are the "pioneers" of their neighbourhood in the visiting order, and a sensor that moves a few
+// centimetres between scans has the same pioneers -- so the next scan writes them out completely at once and, as
+// a rule, settles in one attempt (measured on the bench's depth camera: 2 attempts -> 1 for three scans in four).
+// A mark is dropped again when its ray stopped well inside the cap after all.  Nothing depends on the marks but time.
 __global__ __launch_bounds__(256) void det_extend_kernel(long long n, const uint32_t* __restrict__ count,
                                                         const uint32_t* __restrict__ full_count,
-                                                        const uint8_t* __restrict__ broke, uint8_t* __restrict__ ext,
-                                                        unsigned long long* __restrict__ ctr) {
+                                                        const uint8_t* __restrict__ broke, const int32_t* __restrict__ T,
+                                                        uint8_t* __restrict__ ext, unsigned long long* __restrict__ ctr) {
   const long long seq = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (seq == 0) ctr[kCtrTotal] = 0ull;  // (the next attempt counts again)
   if (seq >= n) return;
-  if (count[seq] < full_count[seq] && !broke[seq]) {
-    ext[seq] = 1;
-    ctr[kCtrOverflow] = 1ull;
-  }
+  const bool ran_on = count[seq] < full_count[seq] && !broke[seq];
+  // (half the cap: a ray that got that far is as good as a pioneer for the next scan)
+  const bool far = full_count[seq] > kSpeculationCap && T[seq] >= (int32_t)(kSpeculationCap / 2);
+  ext[seq] = (ran_on || far) ? 1 : 0;
+  if (ran_on) ctr[kCtrOverflow] = 1ull;
 }
 
 // ---- 2b. the complete walks, written out ---------------------------------------------------------
@@ -239,12 +289,21 @@ __global__ __launch_bounds__(256) void det_walk_kernel(vgx_tsdf_config c, float 
                                                       unsigned long long* __restrict__ acc_vox,
                                                       uint32_t* __restrict__ acc_key, uint32_t* __restrict__ acc_ray,
                                                       int32_t* __restrict__ T, uint8_t* __restrict__ broke,
+                                                      uint32_t* __restrict__ walked, int warm,
                                                       unsigned long long* __restrict__ ctr) {
   const long long seq = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (seq == 0) ctr[kCtrOverflow] = 0ull;  // (what det_extend_kernel reports at the end of this attempt)
   if (seq >= n) return;
   const uint32_t cnt = count[seq];
-  T[seq] = (int32_t)cnt - 1;  // speculation: nobody stops early
-  broke[seq] = 0;
+  // Speculation: nobody stops early.  In a later attempt of the same scan (`warm`) a ray that is written out as far
+  // as before starts from where the previous attempt left it: the iteration reaches its one fixed point from any
+  // start (a ray's first wrong step is corrected by the next sweep once the rays before it are right), and most
+  // rays are not touched by what the few extended ones add.
+  if (!(warm && walked[seq] == cnt)) {
+    T[seq] = (int32_t)cnt - 1;
+    broke[seq] = 0;
+  }
+  walked[seq] = cnt;
   if (cnt == 0) return;
   const float4 g = ray_pg[seq];
   RayDda r = ray_setup(c, vsi, tx, ty, tz, g.x, g.y, g.z, (ray_flags[seq] & kRayClearing) != 0, false);
@@ -304,6 +363,7 @@ struct UpdateOp {  // 1 for an access that updates its voxel
 };
 
 // ---- 2c. one sweep: what every access finds in its slot ... ---------------------------------------
+// (the two-kernel form over a rocprim scan: kept for the 1 / 4 of the comparison in profiles/ -- VGX_DET_SWEEP=scan)
 __global__ __launch_bounds__(256) void det_seen_kernel(size_t N, const uint32_t* __restrict__ s_key,
                                                       const uint32_t* __restrict__ s_idx,
                                                       const uint32_t* __restrict__ s_h,
@@ -319,32 +379,178 @@ __global__ __launch_bounds__(256) void det_seen_kernel(size_t N, const uint32_t*
   seen[s_idx[p]] = present ? 1 : 0;
 }
 
+// The sweep in ONE launch: the exclusive max-scan of "position + 1 if the access happened" and what it is used
+// for, without the scan's output ever reaching memory.  Tiles of 2048 consecutive sorted accesses, taken in
+// the order the workgroups start (a ticket), chained by one 8-byte state per tile:
+//     epoch << 34 | status << 32 | value       status 1: the tile's own last happened access (0: none),
+//                                               status 2: the last happened access up to the tile's end
+// Positions only grow, so "max" is "the nearest one before": a tile that holds a happened access publishes its
+// status-2 word before it looks at anybody, and a look back ends at the first earlier tile whose value is not 0
+// -- one step on everything but pathological input (a tile waits only for tiles that started before it, which
+// never wait for it).  The words are the whole exchange between workgroups (relaxed agent-scope 8-byte loads
+// and stores, tag and value in one word); the epoch is the sweep's number, so no word is ever cleared.
+// Also written, for det_finish_kernel: `last` at the end of every slot run.
+constexpr int kSweepIpt = 8;
+constexpr uint32_t kSweepTile = 256u * kSweepIpt;
+constexpr unsigned long long kSweepEpochMax = (1ull << 30) - 1;
+
+__device__ __forceinline__ void load8(const uint32_t* __restrict__ a, uint32_t base, uint32_t N, uint32_t (&v)[kSweepIpt]) {
+  if (base + kSweepIpt <= N) {  // base is a multiple of 8: two aligned 16-byte loads
+    const uint4 lo = *(const uint4*)(a + base), hi = *(const uint4*)(a + base + 4);
+    v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
+    v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < kSweepIpt; ++e) v[e] = base + e < N ? a[base + e] : 0u;
+  }
+}
+
+__global__ __launch_bounds__(256) void det_sweep_kernel(uint32_t N, unsigned long long epoch,
+                                                       unsigned long long* __restrict__ ctr,
+                                                       unsigned long long* __restrict__ tile_state,
+                                                       const uint32_t* __restrict__ s_key,
+                                                       const uint32_t* __restrict__ s_idx,
+                                                       const uint32_t* __restrict__ s_h,
+                                                       const uint32_t* __restrict__ s_r,
+                                                       const uint32_t* __restrict__ s_k, const int32_t* __restrict__ T,
+                                                       const unsigned long long* __restrict__ observed_set,
+                                                       unsigned long long observed_offset, uint8_t* __restrict__ seen,
+                                                       uint32_t* __restrict__ last) {
+  __shared__ uint32_t sh_tile, sh_prefix, sh_wave[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) sh_tile = (uint32_t)atomicAdd(&ctr[kCtrTicket], 1ull);
+  __syncthreads();
+  const uint32_t tile = sh_tile;
+  const uint32_t base = tile * kSweepTile + (uint32_t)tid * kSweepIpt;
+  // (every gather of a batch is issued before the first one is waited for: the loads are unconditional -- entries
+  // beyond N read element 0 -- and what they return is selected afterwards)
+  uint32_t r[kSweepIpt], k[kSweepIpt], hp[kSweepIpt];
+  int32_t stop[kSweepIpt];
+  load8(s_r, base, N, r);
+  load8(s_k, base, N, k);
+#pragma unroll
+  for (int e = 0; e < kSweepIpt; ++e) stop[e] = T[r[e]];
+  uint32_t own = 0;  // this thread's last happened access (position + 1)
+#pragma unroll
+  for (int e = 0; e < kSweepIpt; ++e) {
+    const uint32_t p = base + e;
+    hp[e] = (p < N && (int32_t)k[e] <= stop[e]) ? p + 1u : 0u;
+    own = hp[e] ? hp[e] : own;
+  }
+  uint32_t inc = own;  // inclusive over the wave's threads
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_up((int)inc, d);
+    if (lane >= d) inc = max(inc, o);
+  }
+  if (lane == 63) sh_wave[wave] = inc;
+  uint32_t before = (uint32_t)__shfl_up((int)inc, 1);  // exclusive: the threads before this one, in the tile
+  if (lane == 0) before = 0;
+  __syncthreads();
+  uint32_t tile_last = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    if (w < wave) before = max(before, sh_wave[w]);
+    tile_last = max(tile_last, sh_wave[w]);
+  }
+  if (tid == 0) {
+    const unsigned long long tag = epoch << 34;
+    unsigned long long* mine = tile_state + tile;
+    uint32_t prefix = 0;
+    if (tile_last != 0 || tile == 0) __hip_atomic_store(mine, tag | (2ull << 32) | tile_last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_store(mine, tag | (1ull << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t t = tile; t-- > 0;) {
+      unsigned long long x;
+      unsigned spins = 0;
+      while (((x = __hip_atomic_load(tile_state + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 34) != epoch) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1u << 22)) {  // (seconds: the tile before this one never ran -- internal error, not a hang)
+          ctr[kCtrError] = 3ull;
+          x = tag | (2ull << 32);
+          break;
+        }
+      }
+      prefix = (uint32_t)x;
+      if (prefix != 0 || ((x >> 32) & 3ull) == 2ull) break;
+    }
+    if (tile_last == 0 && tile != 0) __hip_atomic_store(mine, tag | (2ull << 32) | prefix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sh_prefix = prefix;
+  }
+  __syncthreads();
+  uint32_t run = before ? before : sh_prefix;  // the last happened access before this thread's first one
+  uint32_t key[kSweepIpt], h[kSweepIpt], idx[kSweepIpt], prev[kSweepIpt], prev_key[kSweepIpt], prev_h[kSweepIpt];
+  unsigned long long left[kSweepIpt];
+  load8(s_key, base, N, key);
+  load8(s_h, base, N, h);
+  load8(s_idx, base, N, idx);
+  const uint32_t after = base + kSweepIpt < N ? s_key[base + kSweepIpt] : 0xffffffffu;  // (keys are < 2^20)
+#pragma unroll
+  for (int e = 0; e < kSweepIpt; ++e) {
+    prev[e] = run;
+    run = hp[e] ? hp[e] : run;
+  }
+#pragma unroll
+  for (int e = 0; e < kSweepIpt; ++e) {
+    const uint32_t at = prev[e] ? prev[e] - 1u : 0u;
+    prev_key[e] = s_key[at];
+    prev_h[e] = s_h[at];
+    left[e] = observed_set[key[e]];  // (sorted by key: neighbours read the same or the next entries)
+  }
+#pragma unroll
+  for (int e = 0; e < kSweepIpt; ++e) {
+    const uint32_t p = base + e;
+    const bool earlier = prev[e] > 0 && prev_key[e] == key[e];  // an earlier access of this scan, or what earlier scans left
+    const bool present = earlier ? prev_h[e] == h[e] : left[e] == (unsigned long long)h[e] + observed_offset;
+    const uint32_t next_key = e + 1 < kSweepIpt ? key[e + 1] : after;
+    if (p < N) {
+      seen[idx[e]] = present ? 1 : 0;
+      if (p == N - 1 || next_key != key[e]) last[p] = prev[e];  // end of a slot run: what det_finish_kernel looks at
+    }
+  }
+}
+
 // ---- ... and where every ray stops, given that -------------------------------------------------------
+// The last block to finish reports: to the host through a pinned word (the host polls it instead of
+// synchronising the stream: it can keep sweeps queued meanwhile), and it puts the two counters back.
 __global__ __launch_bounds__(256) void det_ray_kernel(long long n, int max_collisions, const uint32_t* __restrict__ count,
                                                      const uint32_t* __restrict__ off, const uint8_t* __restrict__ seen,
                                                      int32_t* __restrict__ T, uint8_t* __restrict__ broke,
-                                                     unsigned long long* __restrict__ ctr, int parity) {
+                                                     unsigned long long* __restrict__ ctr, unsigned long long seq_no,
+                                                     unsigned long long* __restrict__ host_flag) {
   const long long seq = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (seq == 0) ctr[parity ? kCtrChanged : kCtrChanged1] = 0ull;  // the next sweep's flag
-  if (seq >= n) return;
-  const uint32_t cnt = count[seq];
-  if (cnt == 0) return;
-  const uint8_t* s = seen + off[seq];
-  int collisions = 0;
-  int32_t t = (int32_t)cnt - 1;
-  uint8_t b = 0;
-  for (uint32_t k = 0; k < cnt; ++k) {
-    if (s[k]) ++collisions; else collisions = 0;
-    if (collisions > max_collisions) {
-      t = (int32_t)k;
-      b = 1;
-      break;
+  int moved = 0;
+  const uint32_t cnt = seq < n ? count[seq] : 0u;
+  if (cnt != 0) {
+    const uint8_t* s = seen + off[seq];
+    int collisions = 0;
+    int32_t t = (int32_t)cnt - 1;
+    uint8_t b = 0;
+    for (uint32_t k = 0; k < cnt; ++k) {
+      if (s[k]) ++collisions; else collisions = 0;
+      if (collisions > max_collisions) {
+        t = (int32_t)k;
+        b = 1;
+        break;
+      }
+    }
+    if (t != T[seq] || b != broke[seq]) {
+      T[seq] = t;
+      broke[seq] = b;
+      moved = 1;
     }
   }
-  if (t != T[seq] || b != broke[seq]) {
-    T[seq] = t;
-    broke[seq] = b;
-    ctr[parity ? kCtrChanged1 : kCtrChanged] = 1ull;
+  const int any = __syncthreads_or(moved);
+  if (threadIdx.x == 0) {
+    const unsigned long long add = 1ull + (any ? (1ull << 32) : 0ull);
+    const unsigned long long old = atomicAdd(&ctr[kCtrArrive], add);
+    if ((uint32_t)old == gridDim.x - 1u) {  // the sweep's last block
+      const unsigned long long changed = ((old + add) >> 32) != 0ull ? 1ull : 0ull;
+      const unsigned long long err = __hip_atomic_load(&ctr[kCtrError], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 2ull : 0ull;
+      __hip_atomic_store(&ctr[kCtrArrive], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&ctr[kCtrTicket], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&ctr[kCtrChanged], changed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(host_flag, (seq_no << 2) | err | changed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (the word is all the host reads)
+    }
   }
 }
 
@@ -390,7 +596,12 @@ __global__ __launch_bounds__(256) void det_blocks_kernel(TsdfLayerDev L, size_t 
                                                         int32_t* __restrict__ new_cells, uint32_t new_cap,
                                                         unsigned long long* __restrict__ ctr) {
   const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= (M_dev ? (size_t)*M_dev : M)) return;
+  const size_t m = M_dev ? (size_t)*M_dev : M;
+  if (q == 0) {  // what the host reads back with the counters
+    ctr[kCtrM] = (unsigned long long)m;
+    ctr[kCtrBlocks] = (unsigned long long)(uint32_t)*L.n_blocks;
+  }
+  if (q >= m) return;
   const uint32_t idx = c_idx[q];
   int x, y, z;
   unpack_vox(acc_vox[idx], x, y, z);
@@ -821,6 +1032,89 @@ inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
     if (rc_ != VGX_OK) return rc_; \
   } while (0)
 
+// experiment aid (VGX_DET_PHASES=1): host-side time between the points of a scan where the host has waited for
+// the stream, so what is queued in between is charged to the wait after it
+struct PhaseClock {
+  bool on;
+  std::chrono::steady_clock::time_point t;
+  double us[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long sweeps = 0, attempts = 0;
+  PhaseClock() {
+    static const bool enabled = getenv("VGX_DET_PHASES") != nullptr;
+    on = enabled;
+    if (on) t = std::chrono::steady_clock::now();
+  }
+  void mark(int phase) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    us[phase] += std::chrono::duration<double, std::micro>(now - t).count();
+    t = now;
+  }
+  void print(size_t N) const {
+    if (!on) return;
+    fprintf(stderr, "[vgx det phases] to count read-back %.0f us | walk+sort+gather+first sweep %.0f | other sweeps %.0f | "
+                    "extend %.0f | commit to its read-back %.0f | rest queued %.0f   (%lld attempts, %lld sweeps, %zu accesses)\n",
+            us[0], us[1], us[2], us[3], us[4], us[5], attempts, sweeps, N);
+  }
+};
+
+// a 4-byte device value into one of the pinned words behind the counters' mirror (valid after read_counters)
+int fetch_u32(vgx_ctx ctx, DetScratch* S, int word, const void* dev) {
+  S->h_ctr[word] = 0ull;
+  VGX_HIP(ctx, hipMemcpyAsync(&S->h_ctr[word], dev, 4, hipMemcpyDeviceToHost, ctx->stream));
+  return VGX_OK;
+}
+
+int grow_zeroed(vgx_ctx ctx, Buf& b, size_t bytes) {
+  if (b.bytes >= bytes) return VGX_OK;
+  int rc = grow(ctx, b, bytes);
+  if (rc != VGX_OK) return rc;
+  VGX_HIP(ctx, hipMemsetAsync(b.p, 0, b.bytes, ctx->stream));
+  return VGX_OK;
+}
+
+// Until the sweep numbered `seq`, or a later one, has reported through the pinned word.  No stream call on the
+// way as long as the report arrives; a stream that has gone idle without it (or has failed) ends the wait.
+int wait_for_sweep(vgx_ctx ctx, DetScratch* S, unsigned long long seq, unsigned long long* word) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 1;; ++spins) {
+    const unsigned long long w = __atomic_load_n(S->h_flag, __ATOMIC_ACQUIRE);
+    if ((w >> 2) >= seq) {
+      *word = w;
+      return VGX_OK;
+    }
+    if (spins % 8192u != 0) {
+      __builtin_ia32_pause();
+      continue;
+    }
+    const hipError_t e = hipStreamQuery(ctx->stream);
+    if (e == hipSuccess) {  // everything queued has run: the report is there, or it never will be
+      const unsigned long long w2 = __atomic_load_n(S->h_flag, __ATOMIC_ACQUIRE);
+      if ((w2 >> 2) >= seq) {
+        *word = w2;
+        return VGX_OK;
+      }
+      return set_error(ctx, VGX_ERR_HIP, "TSDF reproducible mode: a sweep ended without reporting (internal error)");
+    }
+    if (e != hipErrorNotReady) VGX_HIP(ctx, e);
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30))
+      return set_error(ctx, VGX_ERR_HIP, "TSDF reproducible mode: no report from a sweep within 30 s");
+  }
+}
+
+// keys (end_bit bits) -> keys_sorted, and where every sorted key came from; stable
+int sort_by_slot(vgx_ctx ctx, DetScratch* S, const uint32_t* keys, uint32_t* keys_sorted, uint32_t* idx_sorted, size_t n,
+                 unsigned end_bit) {
+  size_t bytes = 0;
+  auto iota = rocprim::make_counting_iterator<uint32_t>(0u);
+  VGX_HIP(ctx, stable_sort_pairs(nullptr, bytes, keys, keys_sorted, iota, idx_sorted, n, end_bit, ctx->stream));
+  int rc = grow(ctx, S->tmp, bytes);
+  if (rc != VGX_OK) return rc;
+  bytes = S->tmp.bytes;
+  VGX_HIP(ctx, stable_sort_pairs(S->tmp.p, bytes, keys, keys_sorted, iota, idx_sorted, n, end_bit, ctx->stream));
+  return VGX_OK;
+}
+
 int read_counters(vgx_ctx ctx, DetScratch* S) {
   VGX_HIP(ctx, hipMemcpyAsync(S->h_ctr, S->d_ctr, kCtrCount * 8, hipMemcpyDeviceToHost, ctx->stream));
   VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -834,9 +1128,25 @@ static int ensure_scratch(vgx_tsdf_integrator I) {
   if (I->det) return VGX_OK;
   I->det = new (std::nothrow) DetScratch();
   if (!I->det) return set_error(ctx, VGX_ERR_NOMEM, "TSDF reproducible mode: out of host memory");
-  if (hipMalloc(&I->det->d_ctr, kCtrCount * 8) != hipSuccess ||
-      hipHostMalloc((void**)&I->det->h_ctr, kCtrCount * 8, hipHostMallocDefault) != hipSuccess)
+  DetScratch* S = I->det;
+  if (hipMalloc(&S->d_ctr, kCtrCount * 8) != hipSuccess ||
+      hipHostMalloc((void**)&S->h_ctr, kHostWords * 8, hipHostMallocDefault) != hipSuccess)
     return set_error(ctx, VGX_ERR_NOMEM, "TSDF reproducible mode: counter allocation failed");
+  // the word the sweeps report through: host memory the kernel writes while it runs and the host reads while
+  // the stream is busy, so it has to be coherent (fine-grained), not merely pinned
+  if (hipHostMalloc((void**)&S->h_flag, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+    (void)hipGetLastError();
+    S->h_flag = nullptr;
+    if (hipHostMalloc((void**)&S->h_flag, 64, hipHostMallocMapped) != hipSuccess)
+      return set_error(ctx, VGX_ERR_NOMEM, "TSDF reproducible mode: flag allocation failed");
+  }
+  S->h_flag[0] = 0ull;
+  void* dp = nullptr;
+  if (hipHostGetDevicePointer(&dp, S->h_flag, 0) != hipSuccess || !dp) {
+    (void)hipGetLastError();
+    dp = S->h_flag;  // (unified addressing: the same pointer)
+  }
+  S->d_flag = (unsigned long long*)dp;
   return VGX_OK;
 }
 
@@ -845,7 +1155,7 @@ static int ensure_scratch(vgx_tsdf_integrator I) {
 // indexed by acc_ray, their point / weight / colour live in ray_pg / ray_color)
 static int det_commit(vgx_tsdf_integrator I, DetScratch* S, const float T[7], size_t N, const HappenedOp& happened,
                       const UpdateOp* update, bool update_set, bool ordered_blocks, const float4* ray_pg,
-                      const uint32_t* ray_color, int64_t* n_updates) {
+                      const uint32_t* ray_color, int64_t* n_updates, PhaseClock* pc = nullptr) {
   vgx_ctx ctx = I->ctx;
   vgx_tsdf_layer layer = I->layer;
   const vgx_tsdf_config& c = I->dev.cfg;
@@ -908,11 +1218,15 @@ static int det_commit(vgx_tsdf_integrator I, DetScratch* S, const float T[7], si
     S->first_touch_dirty = true;
   }
   int32_t n_blocks_now = 0;
-  uint32_t M32 = (uint32_t)N;
-  if (M_dev) VGX_HIP(ctx, hipMemcpyAsync(&M32, M_dev, 4, hipMemcpyDeviceToHost, st));
-  if (ordered_blocks) VGX_HIP(ctx, hipMemcpyAsync(&n_blocks_now, L.n_blocks, 4, hipMemcpyDeviceToHost, st));
+  if (M_dev && !ordered_blocks) DET_TRY(fetch_u32(ctx, S, kHostM, M_dev));  // (else: det_blocks_kernel left it in the counters)
   if (M_dev || ordered_blocks) DET_TRY(read_counters(ctx, S));
-  M = M32;
+  if (pc) pc->mark(4);
+  if (ordered_blocks) {
+    M = (size_t)S->h_ctr[kCtrM];
+    n_blocks_now = (int32_t)(uint32_t)S->h_ctr[kCtrBlocks];
+  } else if (M_dev) {
+    M = (uint32_t)S->h_ctr[kHostM];
+  }
   if (M == 0) {
     S->first_touch_dirty = false;  // nothing was marked
     return VGX_OK;
@@ -975,6 +1289,10 @@ static int det_commit(vgx_tsdf_integrator I, DetScratch* S, const float T[7], si
     DET_TRY(read_counters(ctx, S));
     *n_updates = (int64_t)M - (int64_t)S->h_ctr[kCtrDropped];
   }
+  if (pc) {
+    pc->mark(5);
+    pc->print(N);
+  }
   return VGX_OK;
 }
 
@@ -988,6 +1306,7 @@ int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points,
   if (n >= (1ll << 31)) return set_error(ctx, VGX_ERR_UNSUPPORTED, "TSDF reproducible mode: more than 2^31 points in a scan");
   DET_TRY(ensure_scratch(I));
   DetScratch* S = I->det;
+  PhaseClock pc;
   const float vsi = layer->dev.voxel_size_inv;
   const size_t np = (size_t)n;
   // ---- 1. points, start set ----
@@ -1004,47 +1323,49 @@ int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points,
   DET_TRY(grow(ctx, S->broke, np));
   DET_TRY(grow(ctx, S->full_count, np * 4));
   DET_TRY(grow(ctx, S->ext, np + 1));
+  DET_TRY(grow(ctx, S->walked, np * 4));
+  // (a scan whose complete walks were too many to write out is usually followed by another one: a depth camera
+  // stays a depth camera.  Then the walks are cut at once and the count of the complete ones is skipped; the
+  // result does not depend on where rays are cut, det_count_kernel.)
+  const bool may_cap_at_all = c.max_consecutive_ray_collisions < (1 << 20);
+  const bool start_capped = may_cap_at_all && S->start_capped;
+  const bool keep_marks = start_capped && S->ext_points == n;  // the previous scan's pioneers: written out completely at once
+  S->ext_points = -1;  // (until this scan has left its own)
   hipLaunchKernelGGL(det_points_kernel, dim3(blocks_for(np + 1)), dim3(256), 0, st, c, vsi, T[0], T[1], T[2], T[3], T[4], T[5],
                      T[6], (const float*)d_points, (const uint32_t*)d_rgba, (long long)n, order, (int)freespace,
                      I->dev.start_offset, S->ray_pg.as<float4>(), S->ray_color.as<uint32_t>(), S->ray_flags.as<uint32_t>(),
-                     S->start_val.as<unsigned long long>(), S->start_key.as<uint32_t>(), S->ext.as<uint8_t>(), S->d_ctr);
+                     S->start_val.as<unsigned long long>(), S->start_key.as<uint32_t>(), S->ext.as<uint8_t>(),
+                     keep_marks ? 2 : start_capped ? 0 : 1, S->d_ctr);
   VGX_HIP(ctx, hipGetLastError());
-  {
-    size_t bytes = 0;
-    auto iota = rocprim::make_counting_iterator<uint32_t>(0u);
-    VGX_HIP(ctx, rocprim::radix_sort_pairs(nullptr, bytes, S->start_key.as<uint32_t>(), S->start_key_sorted.as<uint32_t>(), iota,
-                                           S->start_seq_sorted.as<uint32_t>(), np, 0, kSetBits + 1, st));
-    DET_TRY(grow(ctx, S->tmp, bytes));
-    bytes = S->tmp.bytes;
-    // stable: equal slots keep the visiting order they were written in
-    VGX_HIP(ctx, rocprim::radix_sort_pairs(S->tmp.p, bytes, S->start_key.as<uint32_t>(), S->start_key_sorted.as<uint32_t>(), iota,
-                                           S->start_seq_sorted.as<uint32_t>(), np, 0, kSetBits + 1, st));
-  }
-  for (int pass = 0; pass < 2; ++pass) {
-    hipLaunchKernelGGL(det_start_kernel, dim3(blocks_for(np)), dim3(256), 0, st, (long long)n,
-                       S->start_key_sorted.as<uint32_t>(), S->start_seq_sorted.as<uint32_t>(),
-                       S->start_val.as<unsigned long long>(), I->dev.start_set, S->ray_flags.as<uint32_t>(), pass);
-    VGX_HIP(ctx, hipGetLastError());
-  }
+  // stable: equal slots keep the visiting order they were written in
+  DET_TRY(sort_by_slot(ctx, S, S->start_key.as<uint32_t>(), S->start_key_sorted.as<uint32_t>(), S->start_seq_sorted.as<uint32_t>(),
+                       np, kSetBits + 1));
+  hipLaunchKernelGGL(det_start_kernel, dim3(blocks_for(np)), dim3(256), 0, st, (long long)n, S->start_key_sorted.as<uint32_t>(),
+                     S->start_seq_sorted.as<uint32_t>(), S->start_val.as<unsigned long long>(),
+                     (const unsigned long long*)I->dev.start_set, S->ray_flags.as<uint32_t>());
+  VGX_HIP(ctx, hipGetLastError());
   // ---- 2. walks written out (bounded speculation: see det_count_kernel), sorted, swept to the fixed point ----
   // The first count is of the COMPLETE walks (det_points_kernel marked every ray "written out completely").  Small scans (a LiDAR sweep at 0.2 m: < 1 M steps) are swept as
   // they are -- an attempt costs a dozen launches and two read-backs, more than the steps saved; large ones
   // (a depth image at 0.05 m: 18 M steps) are cut to `kSpeculationCap` steps per ray and extended on demand.
   // With the early-out switched off every ray runs its full length anyway.
-  bool capped = false;  // this attempt cut rays short: whether one of them ran on has to be looked at afterwards
-  bool may_cap = c.max_consecutive_ray_collisions < (1 << 20);
+  bool capped = start_capped;  // this attempt cut rays short: whether one of them ran on has to be looked at afterwards
+  bool may_cap = may_cap_at_all && !start_capped;
   constexpr uint32_t kCapThreshold = 4u << 20;
+  static const bool scan_sweeps = getenv("VGX_DET_SWEEP") && !strcmp(getenv("VGX_DET_SWEEP"), "scan");  // A/B aid
   size_t N = 0;
+  int walks_done = 0;
+  bool range_error = false;
   HappenedOp happened{nullptr, nullptr, nullptr};
   UpdateOp update{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
   for (int attempt = 0;; ++attempt) {
     if (attempt > 64) return set_error(ctx, VGX_ERR_HIP, "TSDF reproducible mode: speculation did not settle (internal error)");
     hipLaunchKernelGGL(det_count_kernel, dim3(blocks_for(np + 1)), dim3(256), 0, st, c, vsi, T[4], T[5], T[6], (long long)n,
                        S->ray_pg.as<float4>(), S->ray_flags.as<uint32_t>(), S->ext.as<uint8_t>(), S->count.as<uint32_t>(),
-                       S->full_count.as<uint32_t>(), S->d_ctr);
+                       S->full_count.as<uint32_t>(), S->start_key_sorted.as<uint32_t>(), S->start_seq_sorted.as<uint32_t>(),
+                       S->start_val.as<unsigned long long>(), I->dev.start_set, S->d_ctr);
     VGX_HIP(ctx, hipGetLastError());
     {
-      // 64-bit accumulation so that an overflowing total is seen, not wrapped
       size_t bytes = 0;
       VGX_HIP(ctx, rocprim::exclusive_scan(nullptr, bytes, S->count.as<uint32_t>(), S->off.as<uint32_t>(), 0u, np + 1,
                                            rocprim::plus<uint32_t>(), st));
@@ -1053,34 +1374,28 @@ int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points,
       VGX_HIP(ctx, rocprim::exclusive_scan(S->tmp.p, bytes, S->count.as<uint32_t>(), S->off.as<uint32_t>(), 0u, np + 1,
                                            rocprim::plus<uint32_t>(), st));
     }
-    uint32_t total = 0;
-    VGX_HIP(ctx, hipMemcpyAsync(&total, S->off.as<uint32_t>() + np, 4, hipMemcpyDeviceToHost, st));
     DET_TRY(read_counters(ctx, S));
+    pc.mark(0);
+    ++pc.attempts;
     if (S->h_ctr[kCtrError])
       return set_error(ctx, VGX_ERR_UNSUPPORTED, "TSDF reproducible mode: a ray longer than 2^24 voxel steps");
-    // the 32-bit total wraps silently: bound it by what a ray can be
-    {
-      const double max_steps = 3.0 * ((double)c.max_ray_length_m + 2.0 * c.default_truncation_distance) * vsi + 8.0;
-      if ((double)n * max_steps >= 4.0e9) {
-        // exact check only when the cheap bound does not settle it
-        std::vector<uint32_t> cnt(np);
-        VGX_HIP(ctx, hipMemcpy(cnt.data(), S->count.p, np * 4, hipMemcpyDeviceToHost));
-        unsigned long long sum = 0;
-        for (uint32_t v : cnt) sum += v;
-        if (sum >= (1ull << 32) - 2)
-          return set_error(ctx, VGX_ERR_UNSUPPORTED, "TSDF reproducible mode: more than 2^32 voxel steps in a scan");
-      }
-    }
-    N = total;
-    if (N == 0) return VGX_OK;  // nothing was cast (the start set has been updated)
+    const unsigned long long total = S->h_ctr[kCtrTotal];
     if (may_cap) {
       may_cap = false;
       if (total > kCapThreshold) {  // count again, this time cut to the cap
         VGX_HIP(ctx, hipMemsetAsync(S->ext.p, 0, np + 1, st));
+        VGX_HIP(ctx, hipMemsetAsync(S->d_ctr + kCtrTotal, 0, 8, st));
         capped = true;
+        S->start_capped = true;
         continue;
       }
+    } else if (attempt == 0 && start_capped && total < kCapThreshold / 16) {
+      S->start_capped = false;  // little even when cut: the next scan looks at its complete walks first again
     }
+    if (total >= (1ull << 32) - 2)  // (the offsets are 32 bits wide)
+      return set_error(ctx, VGX_ERR_UNSUPPORTED, "TSDF reproducible mode: more than 2^32 voxel steps in a scan");
+    N = (size_t)total;
+    if (N == 0) return VGX_OK;  // nothing was cast (the start set has been updated)
     DET_TRY(grow(ctx, S->acc_vox, N * 8));
     DET_TRY(grow(ctx, S->acc_key, (N + 1) * 4));  // + 1: reused for the compaction offsets
     DET_TRY(grow(ctx, S->acc_ray, N * 4));
@@ -1096,19 +1411,12 @@ int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points,
     hipLaunchKernelGGL(det_walk_kernel, dim3(blocks_for(np)), dim3(256), 0, st, c, vsi, T[4], T[5], T[6], (long long)n,
                        S->ray_pg.as<float4>(), S->ray_flags.as<uint32_t>(), S->count.as<uint32_t>(), S->off.as<uint32_t>(),
                        I->dev.observed_offset, S->acc_vox.as<unsigned long long>(), S->acc_key.as<uint32_t>(),
-                       S->acc_ray.as<uint32_t>(), S->T.as<int32_t>(), S->broke.as<uint8_t>(), S->d_ctr);
+                       S->acc_ray.as<uint32_t>(), S->T.as<int32_t>(), S->broke.as<uint8_t>(), S->walked.as<uint32_t>(),
+                       walks_done > 0 ? 1 : 0, S->d_ctr);
     VGX_HIP(ctx, hipGetLastError());
-    {
-      size_t bytes = 0;
-      auto iota = rocprim::make_counting_iterator<uint32_t>(0u);
-      VGX_HIP(ctx, rocprim::radix_sort_pairs(nullptr, bytes, S->acc_key.as<uint32_t>(), S->s_key.as<uint32_t>(), iota,
-                                             S->s_idx.as<uint32_t>(), N, 0, kSetBits, st));
-      DET_TRY(grow(ctx, S->tmp, bytes));
-      bytes = S->tmp.bytes;
-      // stable: inside a slot the accesses stay in (ray, step) = visiting order
-      VGX_HIP(ctx, rocprim::radix_sort_pairs(S->tmp.p, bytes, S->acc_key.as<uint32_t>(), S->s_key.as<uint32_t>(), iota,
-                                             S->s_idx.as<uint32_t>(), N, 0, kSetBits, st));
-    }
+    ++walks_done;
+    // stable: inside a slot the accesses stay in (ray, step) = visiting order
+    DET_TRY(sort_by_slot(ctx, S, S->acc_key.as<uint32_t>(), S->s_key.as<uint32_t>(), S->s_idx.as<uint32_t>(), N, kSetBits));
     hipLaunchKernelGGL(det_gather_kernel, dim3(blocks_for(N)), dim3(256), 0, st, N, S->s_idx.as<uint32_t>(),
                        S->acc_vox.as<unsigned long long>(), S->acc_ray.as<uint32_t>(), S->off.as<uint32_t>(),
                        S->s_r.as<uint32_t>(), S->s_k.as<uint32_t>(), S->s_h.as<uint32_t>());
@@ -1128,45 +1436,89 @@ int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points,
       scan_bytes = std::max(scan_bytes, b2);
     }
     DET_TRY(grow(ctx, S->tmp, scan_bytes));
+    const uint32_t tiles = (uint32_t)((N + kSweepTile - 1) / kSweepTile);
+    DET_TRY(grow_zeroed(ctx, S->tile_state, (size_t)tiles * 8));
     {
-      // a sweep that changes no stopping step is the fixed point (and so is every sweep after it); n + 1
-      // sweeps always suffice.  On small scans the flag comes to the host only every fourth sweep: a look
-      // costs a stream round trip, more than a sweep over < 1 M accesses does, and up to three sweeps past
-      // the fixed point change nothing (measured: LiDAR 0.55 -> 0.51 ms per scan; on a depth image's 4 M
-      // accesses the wasted sweeps cost more than the looks, 1.49 -> 1.62 ms, so there every sweep is looked at).
-      const int kSweepsPerLook = N <= (1u << 20) ? 4 : 1;
-      for (long long sweep = 0;; ++sweep) {
-        if (sweep > n + 1 + kSweepsPerLook)
+      // A sweep that changes no stopping step is the fixed point (and so is every sweep after it); n + 1 sweeps
+      // always suffice.  A sweep is two launches -- det_sweep_kernel, det_ray_kernel -- and the ray kernel's last
+      // block writes {sweep number, "something moved"} into a pinned word.  The host never waits for the stream:
+      // it keeps `ahead` sweeps queued beyond the one it is waiting to hear from and polls the word (round 3: a
+      // copy + stream synchronise every look, 20-40 us each, and four launches a sweep).  Sweeps past the fixed
+      // point change nothing, so what was queued in vain costs their run time only: on small scans (a sweep over
+      // < 1 M accesses is ~10 us, less than the bubble of waiting) two are kept queued, on large ones none.
+      const int ahead = N <= (1u << 20) ? 2 : 0;
+      const unsigned long long seq0 = S->flag_seq;  // sweep j of this attempt reports as seq0 + j + 1
+      long long issued = 0, heard = -1;              // sweeps launched; the latest sweep the host has heard from
+      bool settled = false;
+      struct Tally {  // (experiment aid)
+        PhaseClock& pc;
+        long long& issued;
+        ~Tally() { pc.sweeps += issued; }
+      } tally{pc, issued};
+      while (!settled) {
+        if (issued > n + 2 + ahead + (walks_done > 1 ? (long long)N : 0))  // (a warm start: at least a step a sweep)
           return set_error(ctx, VGX_ERR_HIP, "TSDF reproducible mode: the sweeps did not settle (internal error)");
-        size_t bytes = S->tmp.bytes;
-        VGX_HIP(ctx, rocprim::exclusive_scan(S->tmp.p, bytes, rocprim::make_transform_iterator(pos, happened),
-                                             S->last.as<uint32_t>(), 0u, N, rocprim::maximum<uint32_t>(), st));
-        hipLaunchKernelGGL(det_seen_kernel, dim3(blocks_for(N)), dim3(256), 0, st, N, S->s_key.as<uint32_t>(),
-                           S->s_idx.as<uint32_t>(), S->s_h.as<uint32_t>(), S->last.as<uint32_t>(), I->dev.observed_set,
-                           I->dev.observed_offset, S->seen.as<uint8_t>());
-        VGX_HIP(ctx, hipGetLastError());
-        hipLaunchKernelGGL(det_ray_kernel, dim3(blocks_for(np)), dim3(256), 0, st, (long long)n,
-                           (int)c.max_consecutive_ray_collisions, S->count.as<uint32_t>(), S->off.as<uint32_t>(),
-                           S->seen.as<uint8_t>(), S->T.as<int32_t>(), S->broke.as<uint8_t>(), S->d_ctr, (int)(sweep & 1));
-        VGX_HIP(ctx, hipGetLastError());
-        if ((sweep + 1) % kSweepsPerLook != 0) continue;
-        DET_TRY(read_counters(ctx, S));  // the flag of the last sweep
-        if (S->h_ctr[kCtrError]) break;
-        if (!S->h_ctr[(sweep & 1) ? kCtrChanged1 : kCtrChanged]) break;
+        while (issued <= heard + 1 + ahead) {
+          if (scan_sweeps) {
+            size_t bytes = S->tmp.bytes;
+            VGX_HIP(ctx, rocprim::exclusive_scan(S->tmp.p, bytes, rocprim::make_transform_iterator(pos, happened),
+                                                 S->last.as<uint32_t>(), 0u, N, rocprim::maximum<uint32_t>(), st));
+            hipLaunchKernelGGL(det_seen_kernel, dim3(blocks_for(N)), dim3(256), 0, st, N, S->s_key.as<uint32_t>(),
+                               S->s_idx.as<uint32_t>(), S->s_h.as<uint32_t>(), S->last.as<uint32_t>(), I->dev.observed_set,
+                               I->dev.observed_offset, S->seen.as<uint8_t>());
+          } else {
+            if (S->sweep_epoch >= kSweepEpochMax) {  // (after 2^30 sweeps: start the tags over)
+              VGX_HIP(ctx, hipMemsetAsync(S->tile_state.p, 0, S->tile_state.bytes, st));
+              S->sweep_epoch = 0;
+            }
+            ++S->sweep_epoch;
+            hipLaunchKernelGGL(det_sweep_kernel, dim3(tiles), dim3(256), 0, st, (uint32_t)N, (unsigned long long)S->sweep_epoch,
+                               S->d_ctr, S->tile_state.as<unsigned long long>(), S->s_key.as<uint32_t>(),
+                               S->s_idx.as<uint32_t>(), S->s_h.as<uint32_t>(), S->s_r.as<uint32_t>(), S->s_k.as<uint32_t>(),
+                               S->T.as<int32_t>(), I->dev.observed_set, I->dev.observed_offset, S->seen.as<uint8_t>(),
+                               S->last.as<uint32_t>());
+          }
+          VGX_HIP(ctx, hipGetLastError());
+          ++S->flag_seq;
+          hipLaunchKernelGGL(det_ray_kernel, dim3(blocks_for(np)), dim3(256), 0, st, (long long)n,
+                             (int)c.max_consecutive_ray_collisions, S->count.as<uint32_t>(), S->off.as<uint32_t>(),
+                             S->seen.as<uint8_t>(), S->T.as<int32_t>(), S->broke.as<uint8_t>(), S->d_ctr, S->flag_seq,
+                             S->d_flag);
+          VGX_HIP(ctx, hipGetLastError());
+          ++issued;
+        }
+        unsigned long long word = 0;
+        DET_TRY(wait_for_sweep(ctx, S, seq0 + (unsigned long long)heard + 2ull, &word));  // ... at least the next one
+        pc.mark(heard < 0 ? 1 : 2);
+        heard = (long long)((word >> 2) - seq0) - 1;
+        if (word & 2ull) range_error = true;
+        if (range_error || !(word & 1ull)) settled = true;
       }
     }
-    if (S->h_ctr[kCtrError]) break;
+    if (range_error) break;
     if (!capped) break;  // every ray was written out completely: nothing can have been cut short
-    VGX_HIP(ctx, hipMemsetAsync(S->d_ctr + kCtrOverflow, 0, 8, st));
     hipLaunchKernelGGL(det_extend_kernel, dim3(blocks_for(np)), dim3(256), 0, st, (long long)n, S->count.as<uint32_t>(),
-                       S->full_count.as<uint32_t>(), S->broke.as<uint8_t>(), S->ext.as<uint8_t>(), S->d_ctr);
+                       S->full_count.as<uint32_t>(), S->broke.as<uint8_t>(), S->T.as<int32_t>(), S->ext.as<uint8_t>(), S->d_ctr);
     VGX_HIP(ctx, hipGetLastError());
     DET_TRY(read_counters(ctx, S));
-    if (!S->h_ctr[kCtrOverflow]) break;  // no ray was cut short: this is the sequential execution
+    pc.mark(3);
+    if (S->h_ctr[kCtrError]) {
+      range_error = true;
+      break;
+    }
+    if (!S->h_ctr[kCtrOverflow]) {  // no ray was cut short: this is the sequential execution
+      S->ext_points = n;
+      break;
+    }
   }
-  if (S->h_ctr[kCtrError])
+  if (range_error) {
+    DET_TRY(read_counters(ctx, S));  // (also: what the sweeps queued ahead were still writing is off the stream)
+    if (S->h_ctr[kCtrError] == 3ull)
+      return set_error(ctx, VGX_ERR_HIP, "TSDF reproducible mode: a sweep's tile never reported (internal error)");
     return set_error(ctx, VGX_ERR_UNSUPPORTED, "TSDF reproducible mode: a voxel index beyond +-2^20 voxels of the layer origin");
-  return det_commit(I, S, T, N, happened, &update, true, true, S->ray_pg.as<float4>(), S->ray_color.as<uint32_t>(), n_updates);
+  }
+  return det_commit(I, S, T, N, happened, &update, true, true, S->ray_pg.as<float4>(), S->ray_color.as<uint32_t>(), n_updates,
+                    &pc);
 }
 
 int det_merged_commit(vgx_tsdf_integrator I, const float T[7], long long n, const float4* g_pg, const uint32_t* g_color,
@@ -1190,10 +1542,10 @@ int det_merged_commit(vgx_tsdf_integrator I, const float T[7], long long n, cons
     bytes = S->tmp.bytes;
     VGX_HIP(ctx, rocprim::exclusive_scan(S->tmp.p, bytes, g_count, S->off.as<uint32_t>(), 0u, G + 1, rocprim::plus<uint32_t>(), st));
   }
-  uint32_t total = 0, too_long = 0;
-  VGX_HIP(ctx, hipMemcpyAsync(&total, S->off.as<uint32_t>() + G, 4, hipMemcpyDeviceToHost, st));
-  VGX_HIP(ctx, hipMemcpyAsync(&too_long, counters + 4, 4, hipMemcpyDeviceToHost, st));
+  DET_TRY(fetch_u32(ctx, S, kHostTotal, S->off.as<uint32_t>() + G));
+  DET_TRY(fetch_u32(ctx, S, kHostTooLong, counters + 4));
   VGX_HIP(ctx, hipStreamSynchronize(st));
+  const uint32_t total = (uint32_t)S->h_ctr[kHostTotal], too_long = (uint32_t)S->h_ctr[kHostTooLong];
   if (too_long)  // (merged_merge_kernel: the fast path raises the same error for the same condition)
     return set_error(ctx, VGX_ERR_UNSUPPORTED, "TSDF merged integrator: a ray longer than 2^24 voxel steps");
   {
@@ -1227,17 +1579,8 @@ int det_merged_commit(vgx_tsdf_integrator I, const float T[7], long long n, cons
                      (int)c.enable_anti_grazing, S->acc_vox.as<unsigned long long>(),
                      S->acc_key.as<uint32_t>(), S->acc_ray.as<uint32_t>(), S->seen.as<uint8_t>(), S->d_ctr);
   VGX_HIP(ctx, hipGetLastError());
-  {
-    size_t bytes = 0;
-    auto iota = rocprim::make_counting_iterator<uint32_t>(0u);
-    VGX_HIP(ctx, rocprim::radix_sort_pairs(nullptr, bytes, S->acc_key.as<uint32_t>(), S->s_key.as<uint32_t>(), iota,
-                                           S->s_idx.as<uint32_t>(), N, 0, kSetBits, st));
-    DET_TRY(grow(ctx, S->tmp, bytes));
-    bytes = S->tmp.bytes;
-    // stable: a voxel's updates stay in (group, step) order
-    VGX_HIP(ctx, rocprim::radix_sort_pairs(S->tmp.p, bytes, S->acc_key.as<uint32_t>(), S->s_key.as<uint32_t>(), iota,
-                                           S->s_idx.as<uint32_t>(), N, 0, kSetBits, st));
-  }
+  // stable: a voxel's updates stay in (group, step) order
+  DET_TRY(sort_by_slot(ctx, S, S->acc_key.as<uint32_t>(), S->s_key.as<uint32_t>(), S->s_idx.as<uint32_t>(), N, kSetBits));
   {
     // Every voxel a ray visits lies between the sensor and its (clipped) end point plus the truncation
     // band: when that box is inside +-2^20 voxels the walk kernel's range flag cannot be set and does not

@@ -4,8 +4,12 @@
 #define VGX_TSDF_INTERNAL_H_
 
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 #include <utility>
 #include <vector>
+
+#include <rocprim/rocprim.hpp>
 
 #include "vgx_internal.h"
 
@@ -196,6 +200,26 @@ __device__ __forceinline__ void transform_point(float qw, float qx, float qy, fl
 
 struct DetScratch;  // vgx_tsdf_det.hip
 void det_scratch_free(DetScratch* s);
+
+// The stable sorts of the sort-based paths.  A scan is 10^4 .. 10^6 records: below 2^20 items rocprim's radix
+// sort is a merge sort -- blocks of 1024 sorted items merged pairwise, and above 201 072 items every pass is
+// two launches (partition + merge path).  At these sizes a pass is a launch's latency, not bandwidth
+// (profiles/r04_tsdf_launches.txt: 17 launches of 4-7 us for 237 568 records), so: 4096 items per sorted block
+// (two passes fewer) and the one-launch odd-even merge all the way to 2^20 items (7 launches for the same
+// records).  Above 2^20 items: rocprim's onesweep, as before.  VGX_TSDF_SORT=default switches back (A/B aid).
+using FewPassSort = rocprim::radix_sort_config<rocprim::default_config, rocprim::merge_sort_config<256, 512, 8, 128, 128, 4, (1u << 20)>,
+                                               rocprim::default_config, (1u << 20)>;
+inline bool few_pass_sort() {
+  static const bool on = !(getenv("VGX_TSDF_SORT") && !strcmp(getenv("VGX_TSDF_SORT"), "default"));
+  return on;
+}
+template <class KeyIn, class KeyOut, class ValIn, class ValOut>
+inline hipError_t stable_sort_pairs(void* tmp, size_t& bytes, KeyIn keys_in, KeyOut keys_out, ValIn vals_in, ValOut vals_out,
+                                    size_t n, unsigned end_bit, hipStream_t st) {
+  if (few_pass_sort())
+    return rocprim::radix_sort_pairs<FewPassSort>(tmp, bytes, keys_in, keys_out, vals_in, vals_out, n, 0, end_bit, st);
+  return rocprim::radix_sort_pairs(tmp, bytes, keys_in, keys_out, vals_in, vals_out, n, 0, end_bit, st);
+}
 
 }  // namespace vgx
 
