@@ -1,7 +1,10 @@
 #!/bin/bash
-# A/B of the sort-based TSDF paths' launch diet (round 4): un-profiled ms per scan of profiles/merged_only.py with
+# A/B of the sort-based TSDF paths' launch diet (round 4, second half): un-profiled ms per scan of
+# profiles/merged_only.py (10-scan sessions of bench.py's two sensor shapes), same box, back to back:
+#   BASE=<lib>            a library built from the commit before (make SUFFIX=_base in a checkout of it), if present
 #   VGX_DET_SWEEP=scan    the sweep as rocprim scan + det_seen_kernel (4 launches) instead of det_sweep_kernel (2)
-#   VGX_TSDF_SORT=default rocprim's default radix_sort config instead of FewPassSort
+#   VGX_TSDF_SORT=default rocprim's default radix_sort configuration instead of FewPassSort
+#   VGX_DET_PHASES=1      host-side time between the points of a scan where the host waits
 #   gpurun -- 'bash profiles/tsdf_ab.sh'  -> gpurun_out/tsdf_ab.txt
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -12,13 +15,22 @@ run() {  # label, env...
   local label=$1; shift
   for rep in 1 2; do
     echo "--- $label (run $rep)" >> $OUT/tsdf_ab.txt
-    env "$@" python $REPO/profiles/merged_only.py >> $OUT/tsdf_ab.txt 2>&1
+    env "$@" python $REPO/profiles/merged_only.py 2>&1 | grep "ms per scan" >> $OUT/tsdf_ab.txt
   done
 }
-run "fast det: new"                   INTEGRATOR=fast DET=1
-run "fast det: scan sweeps"           INTEGRATOR=fast DET=1 VGX_DET_SWEEP=scan
-run "fast det: default sort"          INTEGRATOR=fast DET=1 VGX_TSDF_SORT=default
-run "fast det: scan + default sort"   INTEGRATOR=fast DET=1 VGX_DET_SWEEP=scan VGX_TSDF_SORT=default
-run "merged: new"                     INTEGRATOR=merged DET=0
-run "merged: default sort"            INTEGRATOR=merged DET=0 VGX_TSDF_SORT=default
-run "merged det: new"                 INTEGRATOR=merged DET=1
+BASE=${BASE:-$REPO/voxgraph_amd/lib/libvoxgraph_amd_base.so}
+if [ -f $BASE ]; then
+  run "reproducible: library of the commit before"   VGX_LIB=$BASE INTEGRATOR=fast DET=1
+  run "merged: library of the commit before"         VGX_LIB=$BASE INTEGRATOR=merged DET=0
+  run "merged, reproducible: library of the commit before" VGX_LIB=$BASE INTEGRATOR=merged DET=1
+fi
+run "reproducible: this tree"                 INTEGRATOR=fast DET=1
+run "reproducible: scan sweeps"               INTEGRATOR=fast DET=1 VGX_DET_SWEEP=scan
+run "reproducible: default sort"              INTEGRATOR=fast DET=1 VGX_TSDF_SORT=default
+run "merged: this tree"                       INTEGRATOR=merged DET=0
+run "merged: default sort"                    INTEGRATOR=merged DET=0 VGX_TSDF_SORT=default
+run "merged, reproducible: this tree"         INTEGRATOR=merged DET=1
+echo "--- phases, reproducible, this tree" >> $OUT/tsdf_ab.txt
+for w in lidar rgbd; do
+  VGX_DET_PHASES=1 INTEGRATOR=fast DET=1 WHICH=$w python $REPO/profiles/merged_only.py 2>&1 | grep -v amdgpu.ids >> $OUT/tsdf_ab.txt
+done

@@ -1446,7 +1446,8 @@ int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points,
       // copy + stream synchronise every look, 20-40 us each, and four launches a sweep).  Sweeps past the fixed
       // point change nothing, so what was queued in vain costs their run time only: on small scans (a sweep over
       // < 1 M accesses is ~10 us, less than the bubble of waiting) two are kept queued, on large ones none.
-      const int ahead = N <= (1u << 20) ? 2 : 0;
+      static const int ahead_env = getenv("VGX_DET_AHEAD") ? atoi(getenv("VGX_DET_AHEAD")) : -1;  // experiment aid
+      const int ahead = ahead_env >= 0 ? ahead_env : N <= (1u << 20) ? 2 : 0;
       const unsigned long long seq0 = S->flag_seq;  // sweep j of this attempt reports as seq0 + j + 1
       long long issued = 0, heard = -1;              // sweeps launched; the latest sweep the host has heard from
       bool settled = false;

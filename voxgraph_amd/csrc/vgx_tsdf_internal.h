@@ -207,6 +207,9 @@ void det_scratch_free(DetScratch* s);
 // (profiles/r04_tsdf_launches.txt: 17 launches of 4-7 us for 237 568 records), so: 4096 items per sorted block
 // (two passes fewer) and the one-launch odd-even merge all the way to 2^20 items (7 launches for the same
 // records).  Above 2^20 items: rocprim's onesweep, as before.  VGX_TSDF_SORT=default switches back (A/B aid).
+// (An own LSD radix sort -- one counting launch + one launch per 8 key bits, tiles chained by epoch-tagged words or
+// by a count matrix -- was written, is correct, and is NOT faster: fewer launches, but three dependent memory
+// round trips in each against the merge passes' two.  profiles/dropped/vgx_slot_sort.hip, profiles/README.md.)
 using FewPassSort = rocprim::radix_sort_config<rocprim::default_config, rocprim::merge_sort_config<256, 512, 8, 128, 128, 4, (1u << 20)>,
                                                rocprim::default_config, (1u << 20)>;
 inline bool few_pass_sort() {
