@@ -527,7 +527,13 @@ VGX_API int vgx_tsdf_integrate_device(vgx_tsdf_integrator integrator, const floa
  * grouped by the voxel their end point falls in (clearing rays separately), every group is merged
  * into one weighted-mean point in the reference's visiting order and ONE ray is cast for it through
  * all its voxels with the summed weight; with enable_anti_grazing a ray skips voxels that are the end
- * voxel of another group.  Same argument conventions as vgx_tsdf_integrate[_device]. */
+ * voxel of another group.  Same argument conventions as vgx_tsdf_integrate[_device].
+ * Inputs the reference leaves undefined (all integrators): a coordinate that is NaN indexes voxel 0 on its axis,
+ * one beyond +-2^31 voxels saturates (getGridIndexFromPoint's cast, defined the same way in oracle/tsdf_oracle.c);
+ * such points pass isPointValid as in the reference and, where they are clearing rays (allow_clear / freespace
+ * scans), carve along their direction up to max_ray_length_m like any other return beyond the range.
+ * VGX_ERR_UNSUPPORTED: a ray of more than 2^24 voxel steps; a voxel beyond +-2^20 voxels of the layer origin on a
+ * ray's walk (reproducible mode and merged integrator). */
 VGX_API int vgx_tsdf_integrate_merged(vgx_tsdf_integrator integrator, const float T_G_C[7],
                                       const float* points_C, const uint8_t* rgba, int64_t n,
                                       int32_t freespace_points, int64_t* n_updates);

@@ -10,6 +10,18 @@
 #include <string.h>
 
 static const float kCoordinateEpsilon = 1e-6f; /* voxblox::kCoordinateEpsilon */
+
+/* getGridIndexFromPoint's static_cast<IndexElement>(std::floor(x)) [recalled].  The reference's cast is undefined
+ * for NaN and beyond the integer range; here -- and in the product, csrc/vgx_tsdf_internal.h grid_index -- it is
+ * DEFINED: NaN -> 0, saturating at the 32-bit limits (a point 2^31 voxels away is a driver's "no return" code, not
+ * a measurement; NaN points pass isPointValid in the reference too).  Everything within +-2^31 voxels: the cast. */
+static int64_t grid_index(float x) {
+  x = floorf(x);
+  if (!(x == x)) return 0;
+  if (x >= 2147483648.0f) return 2147483647;
+  if (x < -2147483648.0f) return -2147483647 - 1;
+  return (int64_t)x;
+}
 static const float kFloatEpsilon = 1e-6f;      /* voxblox::kFloatEpsilon */
 static const float kEpsilon = 1e-6f;           /* voxblox::kEpsilon */
 
@@ -341,7 +353,7 @@ int64_t orc_tsdf_integrate(orc_tsdf_integrator* I, const float T_G_C[7], const f
     /* start-voxel dedup on a grid start_voxel_subsampling_factor times finer */
     int64_t gidx[3];
     const float sub_inv = c->start_voxel_subsampling_factor * vsi;
-    for (int a = 0; a < 3; ++a) gidx[a] = (int64_t)floorf(point_G[a] * sub_inv + kCoordinateEpsilon);
+    for (int a = 0; a < 3; ++a) gidx[a] = grid_index(point_G[a] * sub_inv + kCoordinateEpsilon);
     if (!approx_set_replace(&I->start_set, gidx)) continue;
 
     /* RayCaster(origin, point_G, is_clearing, carving, max_ray, voxel_size_inv, trunc, false) */
@@ -376,8 +388,8 @@ int64_t orc_tsdf_integrate(orc_tsdf_integrator* I, const float T_G_C[7], const f
       if (isnan(start_scaled[a]) || isnan(end_scaled[a])) bad = 1;
     if (bad) continue;
     for (int a = 0; a < 3; ++a) {
-      curr[a] = (int64_t)floorf(start_scaled[a] + kCoordinateEpsilon);
-      int64_t end_index = (int64_t)floorf(end_scaled[a] + kCoordinateEpsilon);
+      curr[a] = grid_index(start_scaled[a] + kCoordinateEpsilon);
+      int64_t end_index = grid_index(end_scaled[a] + kCoordinateEpsilon);
       int64_t diff = end_index - curr[a];
       ray_length_in_steps += diff < 0 ? -diff : diff;
       float ray_scaled = end_scaled[a] - start_scaled[a];
@@ -508,7 +520,7 @@ int64_t orc_tsdf_merged_integrate(orc_tsdf_integrator* I, const float T_G_C[7], 
     float point_G[3];
     transform_point(T_G_C, point_C, point_G);
     int64_t v[3];
-    for (int a = 0; a < 3; ++a) v[a] = (int64_t)floorf(point_G[a] * vsi + kCoordinateEpsilon);
+    for (int a = 0; a < 3; ++a) v[a] = grid_index(point_G[a] * vsi + kCoordinateEpsilon);
     e[m].key = pack_voxel_key(v, is_clearing);
     e[m].rank = seq;
     e[m].pi = pi;
@@ -586,8 +598,8 @@ int64_t orc_tsdf_merged_integrate(orc_tsdf_integrator* I, const float T_G_C[7], 
     int step_sign[3];
     float t_to_next[3], t_step[3];
     for (int a = 0; a < 3; ++a) {
-      curr[a] = (int64_t)floorf(start_scaled[a] + kCoordinateEpsilon);
-      int64_t end_index = (int64_t)floorf(end_scaled[a] + kCoordinateEpsilon);
+      curr[a] = grid_index(start_scaled[a] + kCoordinateEpsilon);
+      int64_t end_index = grid_index(end_scaled[a] + kCoordinateEpsilon);
       int64_t diff = end_index - curr[a];
       ray_length_in_steps += diff < 0 ? -diff : diff;
       float ray_scaled = end_scaled[a] - start_scaled[a];

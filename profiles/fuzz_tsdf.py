@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """One-off differential fuzzing of the reproducible TSDF mode against oracle/tsdf_oracle.c: many more random
 integrator configurations than tests/test_tsdf_deterministic_gpu.py runs, both integrators (fast / merged),
-both modes of the merged one.  Prints the first mismatch with its configuration, or a tally.
+both modes of the merged one; the fast integrator's reproducible mode with a random speculation depth / threshold
+(vgx_tsdf_integrator_set_speculation: 1-32 steps, from "always cut" to the default) and, every other session, the
+same number of points in every scan, so that the extension marks kept between scans and the warm second attempt
+are in play.  Prints the first mismatch with its configuration, or a tally.
     gpurun -- 'SEEDS=60 python profiles/fuzz_tsdf.py'"""
 import os
 import sys
@@ -39,20 +42,26 @@ def main():
                   start_voxel_subsampling_factor=float(rng.choice([1.0, 2.0, 4.0])),
                   enable_anti_grazing=int(rng.integers(0, 2)))
         order = int(rng.integers(0, 2))          # integration_order_mode: 0 "mixed", 1 "sorted" (the oracle counts 1 / 2)
+        spec = (int(rng.choice([1, 2, 3, 5, 9, 32])), int(rng.choice([0, 0, 500, 4 << 20])))
+        same_size = bool(rng.integers(0, 2))
         for kind in ("fast", "merged", "merged racing"):
             det = 0 if kind == "merged racing" else 1
             ol, gl = orc.TsdfLayer(vs, vps), capi.TsdfLayer(ctx, vs, vps)
             oi = orc.FastTsdfIntegrator(orc.tsdf_config(integration_order=order + 1, **kw), ol)
             gi = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(deterministic=det, integration_order=order, **kw), gl)
+            if kind == "fast":
+                gi.set_speculation(*spec)
             room = ((-30 * vs, -24 * vs, -6 * vs), (32 * vs, 50 * vs, 14 * vs))
             srng = np.random.default_rng(seed * 7 + 1)
+            size = None
             for k in range(8 if big else 3):
                 origin = (srng.uniform(-3, 3, 3) * vs).astype(F)
                 if big:
                     origin = (origin + np.array([10.0 * k, -6.0 * k, 0.5 * k]) * vs).astype(F)   # the layer grows, the table is re-boxed
-                pts = _lidar_scan(int(srng.integers(400, 1100)) if big else int(srng.integers(40, 400)),
-                                  int(srng.integers(16, 40)) if big else int(srng.integers(4, 30)), seed * 10 + k, room=room,
-                                  origin=origin.astype(np.float64), el=0.5)
+                if size is None or not same_size:
+                    size = (int(srng.integers(400, 1100)) if big else int(srng.integers(40, 400)),
+                            int(srng.integers(16, 40)) if big else int(srng.integers(4, 30)))
+                pts = _lidar_scan(size[0], size[1], seed * 10 + k, room=room, origin=origin.astype(np.float64), el=0.5)
                 pts = pts[srng.permutation(len(pts))]
                 pts[:3] = 0.0
                 pts[3] = [np.nan, 1.0, 1.0]
@@ -80,7 +89,8 @@ def main():
                         assert np.array_equal(ow[o_ord].view(np.uint32), gw[g_ord].view(np.uint32)), "weight"
                         assert np.array_equal(oc[o_ord], gc[g_ord]), "colour"
                 except AssertionError as e:
-                    print("MISMATCH", kind, "seed", seed, "scan", k, "free", free, kw, "vps", vps, "vs", vs, "integration_order", order)
+                    print("MISMATCH", kind, "seed", seed, "scan", k, "free", free, kw, "vps", vps, "vs", vs, "integration_order", order,
+                          "speculation", spec, "same_size", same_size)
                     print(str(e)[:600])
                     return 1
             tally[kind] += 1

@@ -35,7 +35,8 @@ def test_library_exports_every_declared_symbol(capi):
     boundary = _declared_symbols(("voxgraph_amd.h",))
     assert not [n for n in boundary if "synth" in n]
     assert sorted(set(declared) - set(boundary)) == ["vgx_bench_atomic_roundtrip", "vgx_synth_city_scan",
-                                                     "vgx_synth_city_submap", "vgx_tsdf_integrator_walk_stats"]
+                                                     "vgx_synth_city_submap", "vgx_tsdf_integrator_set_speculation",
+                                                     "vgx_tsdf_integrator_walk_stats"]
 
 
 def test_only_c_abi_symbols_are_exported(capi):

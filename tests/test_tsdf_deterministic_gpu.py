@@ -188,6 +188,10 @@ def test_randomised_configurations_multi_ray_scans(capi, ctx, order):
         gcfg = capi.tsdf_config(deterministic=1, integration_order=ORDERS[order][0], **kw)
         ol, gl = orc.TsdfLayer(vs, vps), capi.TsdfLayer(ctx, vs, vps)
         oi, gi = orc.FastTsdfIntegrator(ocfg, ol), capi.FastTsdfIntegrator(ctx, gcfg, gl)
+        # every other configuration: rays cut after 1-9 steps whatever the scan's size, so that these four scans of
+        # equal size go through the extension, the marks kept from scan to scan and the warm second attempt
+        if seed % 2:
+            gi.set_speculation(int(rng.choice([1, 2, 4, 9])), 0)
         room = ((-30 * vs, -24 * vs, -6 * vs), (32 * vs, 50 * vs, 14 * vs))   # partly beyond max range
         for k in range(4):
             origin = (rng.uniform(-3, 3, 3) * vs).astype(F)
@@ -209,6 +213,76 @@ def test_randomised_configurations_multi_ray_scans(capi, ctx, order):
         assert gl.stats()[1] == 0
         for o in (gi, gl):
             o.destroy()
+
+
+@pytest.mark.parametrize("depth,threshold", [(1, 0), (2, 0), (3, 0), (6, 0), (12, 0), (32, 0), (4, 20_000), (32, 4 << 20)])
+def test_the_layer_does_not_depend_on_how_deep_rays_are_speculated(capi, ctx, depth, threshold):
+    """Bounded speculation (det_count_kernel / det_extend_kernel): rays written out `depth` steps deep, extended where
+    they ran on; the marks of one scan kept for the next scan of as many points (scans 0-2 here; scan 3 has another
+    size and starts without them; scan 4 sees a different scene with stale marks); a second attempt starting from
+    the first one's stopping steps.  Whatever the setting, the layer is the oracle's bit for bit after every scan."""
+    vs, vps = 0.1, 16
+    kw = dict(default_truncation_distance=0.3, max_ray_length_m=6.0, min_ray_length_m=0.1, use_const_weight=0,
+              max_consecutive_ray_collisions=2, start_voxel_subsampling_factor=2.0)
+    ol, gl = orc.TsdfLayer(vs, vps), capi.TsdfLayer(ctx, vs, vps)
+    oi = orc.FastTsdfIntegrator(orc.tsdf_config(**kw), ol)
+    gi = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(deterministic=1, **kw), gl)
+    gi.set_speculation(depth, threshold)
+    rooms = [((-3.0, -2.5, -1.0), (3.5, 2.8, 1.6))] * 4 + [((-1.2, -1.0, -0.6), (1.4, 1.1, 0.9))]
+    sizes = [(360, 24)] * 3 + [(301, 17), (301, 17)]
+    for k, (room, (n_az, n_el)) in enumerate(zip(rooms, sizes)):
+        origin = np.array([0.07 * k, -0.05 * k, 0.02 * k])
+        pts = _lidar_scan(n_az, n_el, 40 + k, room=room, origin=origin, el=0.6)
+        T = np.r_[np.array([1, 0, 0, 0], F), origin.astype(F)].astype(F)
+        col = np.full((len(pts), 4), 200, np.uint8)
+        a = oi.integratePointCloud(T, pts, col)
+        b = gi.integratePointCloud(T, pts, col)
+        assert a == b, (k, a, b)
+        _assert_layers_identical(ol, gl, f"speculation {depth}/{threshold}, scan {k}")
+    for o in (gi, gl):
+        o.destroy()
+
+
+@pytest.mark.parametrize("merged", [False, True])
+@pytest.mark.parametrize("freespace", [False, True])
+def test_returns_far_beyond_the_map_are_clipped_not_lost(capi, ctx, merged, freespace):
+    """A driver's "no return" codes among the points -- 276 km (beyond the merged integrator's 21-bit voxel keys: such
+    points were silently dropped until round 4, found by profiles/fuzz_tsdf.py BIG=1 FIRST=5000), 1e9 m (beyond
+    32-bit voxel indices), inf, NaN.  With allow_clear (or in a freespace scan) they are clearing rays clipped to
+    max_ray_length_m: both integrators, reproducible mode, equal the oracle bit for bit; getGridIndexFromPoint's
+    cast is defined the same way on both sides (NaN -> 0, saturating; oracle/tsdf_oracle.c grid_index)."""
+    vs, vps = 0.2, 16
+    kw = dict(default_truncation_distance=0.6, max_ray_length_m=6.0, min_ray_length_m=0.2, use_const_weight=1,
+              allow_clear=1, enable_anti_grazing=1, max_weight=100.0)
+    ol, gl = orc.TsdfLayer(vs, vps), capi.TsdfLayer(ctx, vs, vps)
+    oi = orc.FastTsdfIntegrator(orc.tsdf_config(**kw), ol)
+    gi = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(deterministic=1, **kw), gl)
+    rng = np.random.default_rng(3)
+    for k in range(3):
+        origin = np.array([0.3 * k, -0.2 * k, 0.1])
+        pts = _lidar_scan(256, 12, 70 + k, origin=origin)
+        far = rng.choice(len(pts), 40, replace=False)
+        unit = pts[far] / np.linalg.norm(pts[far], axis=1, keepdims=True)
+        pts[far[:10]] = unit[:10] * F(2.76e5)     # > 2^20 voxels of 0.2 m
+        pts[far[10:20]] = unit[10:20] * F(1.0e9)  # > 2^31 voxels
+        pts[far[20:25]] = unit[20:25] * F(3.0e30)
+        pts[far[25]] = [np.inf, 0.0, 0.0]
+        pts[far[26]] = [0.0, -np.inf, 0.0]
+        pts[far[27]] = [np.nan, 1.0, 1.0]
+        pts[far[28]] = [1.0, np.nan, np.nan]
+        pts[far[29:31]] = pts[far[0]]             # the same far voxel three times: one group, its first point
+        ang = 0.4 * k
+        T = np.r_[np.cos(ang / 2), 0, 0, np.sin(ang / 2), origin].astype(F)
+        col = rng.integers(0, 256, (len(pts), 4)).astype(np.uint8)
+        if merged:
+            a, b = oi.integratePointCloudMerged(T, pts, col, freespace), gi.integratePointCloudMerged(T, pts, col, freespace)
+        else:
+            a, b = oi.integratePointCloud(T, pts, col, freespace), gi.integratePointCloud(T, pts, col, freespace)
+        assert a == b, (k, a, b)
+        _assert_layers_identical(ol, gl, f"far returns, merged={merged} freespace={freespace} scan {k}")
+    assert gl.stats()[1] == 0
+    for o in (gi, gl):
+        o.destroy()
 
 
 def test_layer_grows_under_the_reproducible_mode(capi, ctx):

@@ -113,6 +113,7 @@ SIGNATURES = {
                                       C.c_uint32, vp]),
     "vgx_bench_atomic_roundtrip": (C.c_int, [vp, C.c_int64, C.c_int32, C.c_int32, f32p]),
     "vgx_tsdf_integrator_walk_stats": (C.c_int, [vp, i64p]),
+    "vgx_tsdf_integrator_set_speculation": (C.c_int, [vp, C.c_int32, C.c_int64]),
     "vgx_reg_config_default": (None, [C.POINTER(RegConfig)]),
     "vgx_reg_create": (C.c_int, [vp, vp, vp, C.POINTER(RegConfig), C.POINTER(vp)]),
     "vgx_reg_destroy": (C.c_int, [vp]),
@@ -806,6 +807,11 @@ class FastTsdfIntegrator:
             self.h, _ptr(T, f32p), vp(d_points), vp(d_rgba) if d_rgba else None, n,
             int(freespace_points), C.byref(out) if count else None))
         return out.value
+
+    def set_speculation(self, depth=32, threshold=4 << 20):
+        """test tooling (reproducible mode): write rays out `depth` steps deep at first when a scan's complete
+        walks exceed `threshold` steps; the layer does not depend on either"""
+        self.ctx.check(self.ctx.lib.vgx_tsdf_integrator_set_speculation(self.h, depth, threshold))
 
     def walk_stats(self):
         """bench tooling, last counted racing scan: (longest chain of dependent approximate-set exchanges,

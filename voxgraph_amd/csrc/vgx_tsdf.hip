@@ -240,8 +240,8 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(TsdfLayerDev L, Tsd
       float gz = (pz + qw * uvz + ccz) + tz;
       const float vsi = L.voxel_size_inv;
       const float sub_inv = c.start_voxel_subsampling_factor * vsi;
-      int sx = (int)floorf(gx * sub_inv + 1e-6f), sy = (int)floorf(gy * sub_inv + 1e-6f),
-          sz = (int)floorf(gz * sub_inv + 1e-6f);
+      int sx = grid_index(gx * sub_inv + 1e-6f), sy = grid_index(gy * sub_inv + 1e-6f),
+          sz = grid_index(gz * sub_inv + 1e-6f);
       if (approx_replace(I.start_set, I.start_offset, sx, sy, sz)) {
         // RayCaster(origin, point_G, is_clearing, carving, max_ray, vsi, trunc, cast_from_origin=false)
         float dx = gx - tx, dy = gy - ty, dz = gz - tz;
@@ -271,8 +271,8 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(TsdfLayerDev L, Tsd
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
           bad |= (ss[a] != ss[a]) | (es[a] != es[a]);
-          curr[a] = (int)floorf(ss[a] + 1e-6f);
-          int end_index = (int)floorf(es[a] + 1e-6f);
+          curr[a] = grid_index(ss[a] + 1e-6f);
+          int end_index = grid_index(es[a] + 1e-6f);
           int diff = end_index - curr[a];
           steps += diff < 0 ? -diff : diff;
           float ray_scaled = es[a] - ss[a];
@@ -415,11 +415,15 @@ __global__ __launch_bounds__(256) void merged_bundle_kernel(vgx_tsdf_config c, f
   uvx += uvx; uvy += uvy; uvz += uvz;
   const float ccx = qy * uvz - qz * uvy, ccy = qz * uvx - qx * uvz, ccz = qx * uvy - qy * uvx;
   const float gx = (px + qw * uvx + ccx) + tx, gy = (py + qw * uvy + ccy) + ty, gz = (pz + qw * uvz + ccz) + tz;
-  const int vx = (int)floorf(gx * vsi + 1e-6f), vy = (int)floorf(gy * vsi + 1e-6f), vz = (int)floorf(gz * vsi + 1e-6f);
-  // (strictly inside: the all-ones key is the invalid marker)
-  const bool in_range = vx > -kMergedBias && vx < kMergedBias - 1 && vy > -kMergedBias && vy < kMergedBias - 1 &&
-                        vz > -kMergedBias && vz < kMergedBias - 1;
-  keys[seq] = (valid && in_range) ? merged_key(vx, vy, vz, is_clearing) : kMergedInvalid;
+  const int vx = grid_index(gx * vsi + 1e-6f), vy = grid_index(gy * vsi + 1e-6f), vz = grid_index(gz * vsi + 1e-6f);
+  // The key holds 21 bits per axis and WRAPS beyond, as the oracle's does (a point beyond +-2^20 voxels is a clearing
+  // ray or nothing; its ray is clipped to max_ray_length_m and walks next to the sensor -- it must not be lost: a
+  // freespace scan with a 276 km return lost 859 updates here until round 4, profiles/probes/merged_free_repro.py).
+  // The one key that cannot be told from the invalid marker -- a clearing point whose three fields are all ones --
+  // is reported (counters[5], folded into the scan's error word by merged_merge_kernel): the scan is refused.
+  const unsigned long long key = merged_key(vx, vy, vz, is_clearing);
+  if (valid && key == kMergedInvalid) counters[5] = 1u;
+  keys[seq] = valid ? key : kMergedInvalid;
   idx[seq] = (unsigned int)pi;
 }
 
@@ -480,6 +484,10 @@ __global__ __launch_bounds__(256) void merged_merge_kernel(vgx_tsdf_config c, fl
                                                           unsigned int* __restrict__ too_long) {
   const int lane = threadIdx.x & (L - 1);
   const unsigned int n_sub = gridDim.x * (blockDim.x / L);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && too_long[1]) {  // merged_bundle_kernel: a key equal to the invalid marker
+    too_long[0] = 2u;
+    too_long[1] = 0u;
+  }
   const unsigned int G = counters[0], n_valid = counters[3];
   for (unsigned int g = blockIdx.x * (blockDim.x / L) + threadIdx.x / L; g < G; g += n_sub) {
     const unsigned int i0 = group_start[g], i1 = g + 1 < G ? group_start[g + 1] : n_valid;
@@ -1290,7 +1298,10 @@ static int merged_integrate_locked(vgx_tsdf_integrator I, const float T[7], cons
       VGX_HIP(ctx, hipMalloc(&I->d_gcolor, (size_t)n * 4));
       VGX_HIP(ctx, hipMalloc(&I->d_gflags, (size_t)n * 4));
       VGX_HIP(ctx, hipMalloc(&I->d_gcount, ((size_t)n + 1) * 4));
-      if (!I->d_mcounters) VGX_HIP(ctx, hipMalloc(&I->d_mcounters, 32));
+      if (!I->d_mcounters) {
+        VGX_HIP(ctx, hipMalloc(&I->d_mcounters, 32));
+        VGX_HIP(ctx, hipMemsetAsync(I->d_mcounters, 0, 32, ctx->stream));  // ([5]: set by a scan, cleared by the same scan)
+      }
       size_t bytes = 0, b2 = 0;
       VGX_HIP(ctx, stable_sort_pairs(nullptr, bytes, I->d_mkeys[0], I->d_mkeys[1], I->d_midx[0], I->d_midx[1], (size_t)n, 64,
                                      ctx->stream));
@@ -1405,6 +1416,18 @@ int vgx_tsdf_integrate_device(vgx_tsdf_integrator I, const float T[7], const voi
   if (!I || !T || n < 0 || (n > 0 && !d_points)) return VGX_ERR_INVALID;
   std::lock_guard<std::mutex> own(I->mu);
   return integrate_locked(I, T, d_points, d_rgba, n, freespace, n_updates);
+}
+
+// test tooling (include/voxgraph_amd_bench.h): the reproducible mode's bounded speculation.  A scan whose complete
+// walks exceed `threshold` steps is written out `depth` steps per ray at first and extended where a ray ran on;
+// defaults 32 and 4 Mi.  Results do not depend on either (vgx_tsdf_det.hip); small values make small test scans
+// go through the extension, the marks kept between scans and the warm second attempt.
+int vgx_tsdf_integrator_set_speculation(vgx_tsdf_integrator I, int32_t depth, int64_t threshold) {
+  if (!I || depth < 1 || threshold < 0 || threshold >= (1ll << 32)) return VGX_ERR_INVALID;
+  std::lock_guard<std::mutex> own(I->mu);
+  I->det_cap = (uint32_t)depth;
+  I->det_cap_threshold = (uint32_t)threshold;
+  return VGX_OK;
 }
 
 // bench header: what the rays of the last COUNTED racing scan did (n_updates != NULL resets the statistics

@@ -178,8 +178,8 @@ __global__ __launch_bounds__(256) void det_points_kernel(vgx_tsdf_config c, floa
     weight = dist_z > 1e-6f ? 1.0f / (dist_z * dist_z) : 0.0f;
   }
   const float sub_inv = c.start_voxel_subsampling_factor * vsi;
-  const int sx = (int)floorf(gx * sub_inv + 1e-6f), sy = (int)floorf(gy * sub_inv + 1e-6f),
-            sz = (int)floorf(gz * sub_inv + 1e-6f);
+  const int sx = grid_index(gx * sub_inv + 1e-6f), sy = grid_index(gy * sub_inv + 1e-6f),
+            sz = grid_index(gz * sub_inv + 1e-6f);
   const unsigned long long v = (unsigned long long)index_hash(sx, sy, sz) + start_offset;
   ray_pg[seq] = make_float4(gx, gy, gz, weight);
   ray_color[seq] = rgba ? rgba[pi] : 0u;
@@ -221,7 +221,7 @@ __device__ __forceinline__ void start_set_after(long long p, long long n, const 
 // (ext[] set by det_extend_kernel) get their complete walk in the next attempt, the others keep theirs.
 // The fixed point of an attempt in which no ray is cut short is the fixed point of the complete system
 // (same accesses happen, same decisions; it is unique), so the result does not depend on `cap`.
-constexpr uint32_t kSpeculationCap = 32;
+// (the depth is vgx_tsdf_integrator_s::det_cap, 32 unless a test says otherwise)
 
 __global__ __launch_bounds__(256) void det_count_kernel(vgx_tsdf_config c, float vsi, float tx, float ty, float tz,
                                                        long long n, const float4* __restrict__ ray_pg,
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void det_count_kernel(vgx_tsdf_config c, float
                                                        const uint32_t* __restrict__ key_sorted,
                                                        const uint32_t* __restrict__ seq_sorted,
                                                        const unsigned long long* __restrict__ start_val,
-                                                       unsigned long long* __restrict__ start_set,
+                                                       unsigned long long* __restrict__ start_set, uint32_t cap,
                                                        unsigned long long* __restrict__ ctr) {
   const long long seq = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   // (a second job for the same thread index: the start set's state after this scan; a repeated count stores the
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void det_count_kernel(vgx_tsdf_config c, float
   }
   if (seq <= n) {
     const bool complete = seq < n && ext[seq] != 0;
-    written = complete ? full : min(full, kSpeculationCap);
+    written = complete ? full : min(full, cap);
     count[seq] = written;  // count[n] = 0: the scan's last output is the total
     if (seq < n) full_count[seq] = full;
   }
@@ -268,13 +268,14 @@ __global__ __launch_bounds__(256) void det_count_kernel(vgx_tsdf_config c, float
 __global__ __launch_bounds__(256) void det_extend_kernel(long long n, const uint32_t* __restrict__ count,
                                                         const uint32_t* __restrict__ full_count,
                                                         const uint8_t* __restrict__ broke, const int32_t* __restrict__ T,
-                                                        uint8_t* __restrict__ ext, unsigned long long* __restrict__ ctr) {
+                                                        uint8_t* __restrict__ ext, uint32_t cap,
+                                                        unsigned long long* __restrict__ ctr) {
   const long long seq = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (seq == 0) ctr[kCtrTotal] = 0ull;  // (the next attempt counts again)
   if (seq >= n) return;
   const bool ran_on = count[seq] < full_count[seq] && !broke[seq];
   // (half the cap: a ray that got that far is as good as a pioneer for the next scan)
-  const bool far = full_count[seq] > kSpeculationCap && T[seq] >= (int32_t)(kSpeculationCap / 2);
+  const bool far = full_count[seq] > cap && T[seq] >= (int32_t)(cap / 2);
   ext[seq] = (ran_on || far) ? 1 : 0;
   if (ran_on) ctr[kCtrOverflow] = 1ull;
 }
@@ -1347,11 +1348,11 @@ int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points,
   // ---- 2. walks written out (bounded speculation: see det_count_kernel), sorted, swept to the fixed point ----
   // The first count is of the COMPLETE walks (det_points_kernel marked every ray "written out completely").  Small scans (a LiDAR sweep at 0.2 m: < 1 M steps) are swept as
   // they are -- an attempt costs a dozen launches and two read-backs, more than the steps saved; large ones
-  // (a depth image at 0.05 m: 18 M steps) are cut to `kSpeculationCap` steps per ray and extended on demand.
+  // (a depth image at 0.05 m: 18 M steps) are cut to `det_cap` (32) steps per ray and extended on demand.
   // With the early-out switched off every ray runs its full length anyway.
   bool capped = start_capped;  // this attempt cut rays short: whether one of them ran on has to be looked at afterwards
   bool may_cap = may_cap_at_all && !start_capped;
-  constexpr uint32_t kCapThreshold = 4u << 20;
+  const uint32_t kCapThreshold = I->det_cap_threshold, cap = std::max<uint32_t>(I->det_cap, 1u);
   static const bool scan_sweeps = getenv("VGX_DET_SWEEP") && !strcmp(getenv("VGX_DET_SWEEP"), "scan");  // A/B aid
   size_t N = 0;
   int walks_done = 0;
@@ -1363,7 +1364,7 @@ int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points,
     hipLaunchKernelGGL(det_count_kernel, dim3(blocks_for(np + 1)), dim3(256), 0, st, c, vsi, T[4], T[5], T[6], (long long)n,
                        S->ray_pg.as<float4>(), S->ray_flags.as<uint32_t>(), S->ext.as<uint8_t>(), S->count.as<uint32_t>(),
                        S->full_count.as<uint32_t>(), S->start_key_sorted.as<uint32_t>(), S->start_seq_sorted.as<uint32_t>(),
-                       S->start_val.as<unsigned long long>(), I->dev.start_set, S->d_ctr);
+                       S->start_val.as<unsigned long long>(), I->dev.start_set, cap, S->d_ctr);
     VGX_HIP(ctx, hipGetLastError());
     {
       size_t bytes = 0;
@@ -1499,7 +1500,7 @@ int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points,
     if (range_error) break;
     if (!capped) break;  // every ray was written out completely: nothing can have been cut short
     hipLaunchKernelGGL(det_extend_kernel, dim3(blocks_for(np)), dim3(256), 0, st, (long long)n, S->count.as<uint32_t>(),
-                       S->full_count.as<uint32_t>(), S->broke.as<uint8_t>(), S->T.as<int32_t>(), S->ext.as<uint8_t>(), S->d_ctr);
+                       S->full_count.as<uint32_t>(), S->broke.as<uint8_t>(), S->T.as<int32_t>(), S->ext.as<uint8_t>(), cap, S->d_ctr);
     VGX_HIP(ctx, hipGetLastError());
     DET_TRY(read_counters(ctx, S));
     pc.mark(3);
@@ -1547,6 +1548,9 @@ int det_merged_commit(vgx_tsdf_integrator I, const float T[7], long long n, cons
   DET_TRY(fetch_u32(ctx, S, kHostTooLong, counters + 4));
   VGX_HIP(ctx, hipStreamSynchronize(st));
   const uint32_t total = (uint32_t)S->h_ctr[kHostTotal], too_long = (uint32_t)S->h_ctr[kHostTooLong];
+  if (too_long == 2u)  // (merged_bundle_kernel)
+    return set_error(ctx, VGX_ERR_UNSUPPORTED,
+                     "TSDF merged integrator: a clearing point whose end voxel is 2^20 - 1 (mod 2^21) on all three axes cannot be keyed");
   if (too_long)  // (merged_merge_kernel: the fast path raises the same error for the same condition)
     return set_error(ctx, VGX_ERR_UNSUPPORTED, "TSDF merged integrator: a ray longer than 2^24 voxel steps");
   {

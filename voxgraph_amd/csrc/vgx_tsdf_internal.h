@@ -109,6 +109,17 @@ __device__ __forceinline__ uint32_t blended_color(uint32_t oc, uint32_t color, f
 // layer frame): ray_start / ray_end as the constructor computes them, then setupRayCaster on the
 // scaled ends -- from the far end towards the origin (cast_from_origin = false, the fast
 // integrator) or from the origin outwards (true, the merged and simple integrators).
+// getGridIndexFromPoint's cast (oracle/tsdf_oracle.c grid_index): floor to int, NaN -> 0, saturating.  The reference's
+// cast is undefined for such input; here both sides define it the same way, so a driver's "no return" code (inf, 1e30)
+// gives the same start-set slot / group key in the oracle and on the device.
+__device__ __forceinline__ int grid_index(float x) {
+  x = floorf(x);
+  if (!(x == x)) return 0;
+  if (x >= 2147483648.0f) return 2147483647;
+  if (x < -2147483648.0f) return -2147483647 - 1;
+  return (int)x;
+}
+
 struct RayDda {
   int curr[3], sign[3];
   float t_next[3], t_step[3];
@@ -146,8 +157,8 @@ __device__ __forceinline__ RayDda ray_setup(const vgx_tsdf_config& c, float vsi,
     const float ss = cast_from_origin ? a_[a] : b_[a];
     const float es = cast_from_origin ? b_[a] : a_[a];
     r.bad |= (ss != ss) | (es != es);
-    r.curr[a] = (int)floorf(ss + 1e-6f);
-    const int end_index = (int)floorf(es + 1e-6f);
+    r.curr[a] = grid_index(ss + 1e-6f);
+    const int end_index = grid_index(es + 1e-6f);
     const int diff = end_index - r.curr[a];
     r.steps += diff < 0 ? -diff : diff;
     const float ray_scaled = es - ss;
@@ -276,6 +287,11 @@ struct vgx_tsdf_integrator_s {
   size_t msort_bytes = 0;
   long long merged_cap = 0;
   vgx::DetScratch* det = nullptr;  // reproducible mode's buffers (vgx_tsdf_det.hip), grown on demand
+  // reproducible mode, bounded speculation (vgx_tsdf_det.hip det_count_kernel): a scan whose complete walks are more
+  // than det_cap_threshold steps is written out det_cap steps deep at first.  Nothing but time depends on either;
+  // vgx_tsdf_integrator_set_speculation (bench header) lets the tests drive the extension logic on small scans.
+  uint32_t det_cap = 32;
+  uint32_t det_cap_threshold = 4u << 20;
   // integration_order "sorted": squared-norm keys / point indices (double-buffered) + radix-sort workspace
   uint32_t* d_okey[2] = {nullptr, nullptr};
   uint32_t* d_oidx[2] = {nullptr, nullptr};
