@@ -1,67 +1,72 @@
-// Which rocprim sort configuration is cheapest at the sizes of a LiDAR scan's two sorts (merged TSDF
-// integrator): 65 536 x (u64 key, u32 value) and 140 000 x (u32 key of 20 bits, u32 value)?
-//   hipcc --offload-arch=gfx950 -O3 -o profiles/probes/sort_probe profiles/probes/sort_probe.hip
-//   gpurun -- './profiles/probes/sort_probe'
+// Which rocprim stable sort is fastest at the sort-based TSDF paths' sizes?  HIP events over 200 sorts each.
+//   hipcc --offload-arch=gfx950 -O2 -o build/sort_probe profiles/probes/sort_probe.hip && gpurun -- build/sort_probe
+#include <cstdint>
+#include <cstdio>
 #include <cstring>
+#include <vector>
+
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
-#include <cstdio>
-#include <vector>
-#include <random>
 
-template <class Config, class K>
-float time_sort(const char* name, size_t n, int end_bit, const std::vector<K>& h) {
-  K *k0, *k1;
-  uint32_t *v0, *v1;
-  hipMalloc(&k0, n * sizeof(K)); hipMalloc(&k1, n * sizeof(K));
-  hipMalloc(&v0, n * 4); hipMalloc(&v1, n * 4);
-  hipMemcpy(k0, h.data(), n * sizeof(K), hipMemcpyHostToDevice);
-  hipMemset(v0, 0, n * 4);
-  size_t bytes = 0;
-  rocprim::radix_sort_pairs<Config>(nullptr, bytes, k0, k1, v0, v1, n, 0, end_bit, 0);
-  void* tmp;
-  hipMalloc(&tmp, bytes);
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %d line %d\n", (int)e_, __LINE__); return 1; } } while (0)
+
+template <unsigned OE, unsigned SB, unsigned SI>
+using Few = rocprim::radix_sort_config<rocprim::default_config, rocprim::merge_sort_config<OE, SB, SI, 128, 128, 4, (1u << 20)>,
+                                       rocprim::default_config, (1u << 20)>;
+template <unsigned OE, unsigned SB, unsigned SI>
+using Msc = rocprim::merge_sort_config<OE, SB, SI, 128, 128, 4, (1u << 20)>;
+
+template <class F>
+float time_it(F f, hipStream_t st) {
   hipEvent_t a, b;
-  hipEventCreate(&a); hipEventCreate(&b);
-  for (int i = 0; i < 5; ++i) rocprim::radix_sort_pairs<Config>(tmp, bytes, k0, k1, v0, v1, n, 0, end_bit, 0);
-  hipEventRecord(a, 0);
-  const int R = 50;
-  for (int i = 0; i < R; ++i) rocprim::radix_sort_pairs<Config>(tmp, bytes, k0, k1, v0, v1, n, 0, end_bit, 0);
-  hipEventRecord(b, 0);
-  hipEventSynchronize(b);
+  (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+  for (int i = 0; i < 5; ++i) f();
+  (void)hipEventRecord(a, st);
+  for (int i = 0; i < 200; ++i) f();
+  (void)hipEventRecord(b, st);
+  (void)hipEventSynchronize(b);
   float ms = 0;
-  hipEventElapsedTime(&ms, a, b);
-  std::vector<K> out(n);
-  hipMemcpy(out.data(), k1, n * sizeof(K), hipMemcpyDeviceToHost);
-  bool sorted = true;
-  for (size_t i = 1; i < n; ++i) sorted &= out[i - 1] <= out[i];
-  printf("%-44s n=%7zu bits=%2d  %7.1f us  %s\n", name, n, end_bit, ms / R * 1e3, sorted ? "sorted" : "NOT SORTED");
-  hipFree(k0); hipFree(k1); hipFree(v0); hipFree(v1); hipFree(tmp);
-  return ms / R;
+  (void)hipEventElapsedTime(&ms, a, b);
+  return ms * 1000.0f / 200.0f;
+}
+
+template <class K>
+int run(size_t n, unsigned bits, const char* what) {
+  hipStream_t st = nullptr;
+  std::vector<K> h(n);
+  uint64_t s = 88172645463325252ull;
+  for (size_t i = 0; i < n; ++i) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; h[i] = (K)(bits >= 64 ? s : (s & ((1ull << bits) - 1))); }
+  K *k_in, *k_out; uint32_t *v_in, *v_out; void* tmp;
+  CK(hipMalloc(&k_in, n * sizeof(K))); CK(hipMalloc(&k_out, n * sizeof(K)));
+  CK(hipMalloc(&v_in, n * 4)); CK(hipMalloc(&v_out, n * 4));
+  size_t cap = 256u << 20;
+  CK(hipMalloc(&tmp, cap));
+  CK(hipMemcpy(k_in, h.data(), n * sizeof(K), hipMemcpyHostToDevice));
+  CK(hipMemset(v_in, 0, n * 4));
+  printf("%-34s n=%8zu bits=%2u:", what, n, bits);
+  auto radix_default = [&] { size_t b = cap; (void)rocprim::radix_sort_pairs(tmp, b, k_in, k_out, v_in, v_out, n, 0, bits, st); };
+  auto few_512_8 = [&] { size_t b = cap; (void)rocprim::radix_sort_pairs<Few<256, 512, 8>>(tmp, b, k_in, k_out, v_in, v_out, n, 0, bits, st); };
+  auto few_256_8 = [&] { size_t b = cap; (void)rocprim::radix_sort_pairs<Few<256, 256, 8>>(tmp, b, k_in, k_out, v_in, v_out, n, 0, bits, st); };
+  auto few_256_4 = [&] { size_t b = cap; (void)rocprim::radix_sort_pairs<Few<256, 256, 4>>(tmp, b, k_in, k_out, v_in, v_out, n, 0, bits, st); };
+  auto few_1024_4 = [&] { size_t b = cap; (void)rocprim::radix_sort_pairs<Few<256, 1024, 4>>(tmp, b, k_in, k_out, v_in, v_out, n, 0, bits, st); };
+  auto merge_default = [&] { size_t b = cap; (void)rocprim::merge_sort(tmp, b, k_in, k_out, v_in, v_out, n, rocprim::less<K>(), st); };
+  auto merge_512_8 = [&] { size_t b = cap; (void)rocprim::merge_sort<Msc<256, 512, 8>>(tmp, b, k_in, k_out, v_in, v_out, n, rocprim::less<K>(), st); };
+  auto merge_256_8 = [&] { size_t b = cap; (void)rocprim::merge_sort<Msc<256, 256, 8>>(tmp, b, k_in, k_out, v_in, v_out, n, rocprim::less<K>(), st); };
+  auto merge_256_4 = [&] { size_t b = cap; (void)rocprim::merge_sort<Msc<256, 256, 4>>(tmp, b, k_in, k_out, v_in, v_out, n, rocprim::less<K>(), st); };
+  printf(" radix default %6.1f | radix few(512x8) %6.1f (256x8) %6.1f (256x4) %6.1f (1024x4) %6.1f | merge_sort default %6.1f (512x8) %6.1f (256x8) %6.1f (256x4) %6.1f us\n",
+         time_it(radix_default, st), time_it(few_512_8, st), time_it(few_256_8, st), time_it(few_256_4, st), time_it(few_1024_4, st),
+         time_it(merge_default, st), time_it(merge_512_8, st), time_it(merge_256_8, st), time_it(merge_256_4, st));
+  (void)hipFree(k_in); (void)hipFree(k_out); (void)hipFree(v_in); (void)hipFree(v_out); (void)hipFree(tmp);
+  return 0;
 }
 
 int main() {
-  using namespace rocprim;
-  std::mt19937_64 g(1);
-  for (size_t n : {65536ul, 20000ul}) {
-    std::vector<unsigned long long> h(n);
-    for (auto& x : h) x = g() & ((1ull << 63) - 1);
-    time_sort<default_config>("u64 default", n, 64, h);
-    time_sort<radix_sort_config<default_config, merge_sort_config<512, 256, 8>>>("u64 merge 2048/block", n, 64, h);
-    time_sort<radix_sort_config<default_config, merge_sort_config<512, 256, 16>>>("u64 merge 4096/block", n, 64, h);
-    time_sort<radix_sort_config<default_config, merge_sort_config<512, 512, 16>>>("u64 merge 8192/block", n, 64, h);
-    for (auto& x : h) x &= (1ull << 26) - 1;
-    time_sort<radix_sort_config<default_config, default_config, default_config, 0>>("u64 onesweep, 26 key bits", n, 26, h);
-    time_sort<default_config>("u64 default, 26 key bits", n, 26, h);
-  }
-  for (size_t n : {140000ul, 40000ul, 1000000ul}) {
-    std::vector<uint32_t> h(n);
-    for (auto& x : h) x = (uint32_t)g() & ((1u << 20) - 1);
-    time_sort<default_config>("u32 default", n, 20, h);
-    time_sort<radix_sort_config<default_config, merge_sort_config<512, 256, 8>>>("u32 merge 2048/block", n, 20, h);
-    time_sort<radix_sort_config<default_config, merge_sort_config<512, 256, 16>>>("u32 merge 4096/block", n, 20, h);
-    time_sort<radix_sort_config<default_config, merge_sort_config<512, 512, 16>>>("u32 merge 8192/block", n, 20, h);
-    time_sort<radix_sort_config<default_config, default_config, default_config, 0>>("u32 onesweep", n, 20, h);
-  }
+  if (run<unsigned long long>(65536, 64, "merged LiDAR points (64-bit keys)")) return 1;
+  if (run<unsigned long long>(307200, 64, "merged depth points (64-bit keys)")) return 1;
+  if (run<uint32_t>(65536, 21, "LiDAR points by start slot")) return 1;
+  if (run<uint32_t>(138000, 20, "merged LiDAR records")) return 1;
+  if (run<uint32_t>(237568, 20, "LiDAR accesses")) return 1;
+  if (run<uint32_t>(307200, 21, "depth-image points by start slot")) return 1;
+  if (run<uint32_t>(65536, 32, "sorted visiting order (f32 bits)")) return 1;
   return 0;
 }

@@ -391,14 +391,17 @@ __global__ __launch_bounds__(256) void merged_bundle_kernel(vgx_tsdf_config c, f
                                                            int freespace_points, unsigned long long* __restrict__ keys,
                                                            unsigned int* __restrict__ idx,
                                                            unsigned int* __restrict__ counters,
-                                                           uint32_t* __restrict__ g_count) {
+                                                           uint32_t* __restrict__ g_count,
+                                                           unsigned long long* __restrict__ scan_ctr) {
   const long long seq = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (seq >= n) return;
-  // (this scan's group counters and per-group ray lengths start from zero: two memsets saved)
+  // (this scan's group counters, per-group ray lengths and kCtr* counters start from zero: three memsets saved)
   g_count[seq] = 0u;
   if (seq == 0) {
     g_count[n] = 0u;
-    counters[0] = counters[1] = counters[2] = counters[3] = counters[4] = 0u;  // [4]: a group's ray too long
+    counters[0] = counters[1] = counters[2] = counters[3] = 0u;
+#pragma unroll
+    for (int i = 0; i < kCtrCount; ++i) scan_ctr[i] = 0ull;
   }
   const long long pi = visiting_order_point(order, seq, n);  // ThreadSafeIndex: "mixed" or "sorted"
   const float px = points_C[3 * pi], py = points_C[3 * pi + 1], pz = points_C[3 * pi + 2];
@@ -420,7 +423,8 @@ __global__ __launch_bounds__(256) void merged_bundle_kernel(vgx_tsdf_config c, f
   // ray or nothing; its ray is clipped to max_ray_length_m and walks next to the sensor -- it must not be lost: a
   // freespace scan with a 276 km return lost 859 updates here until round 4, profiles/probes/merged_free_repro.py).
   // The one key that cannot be told from the invalid marker -- a clearing point whose three fields are all ones --
-  // is reported (counters[5], folded into the scan's error word by merged_merge_kernel): the scan is refused.
+  // is reported (counters[5], folded into the scan's error word by merged_merge_kernel -- this kernel's thread 0 is
+  // zeroing that word): the scan is refused.
   const unsigned long long key = merged_key(vx, vy, vz, is_clearing);
   if (valid && key == kMergedInvalid) counters[5] = 1u;
   keys[seq] = valid ? key : kMergedInvalid;
@@ -481,13 +485,15 @@ __global__ __launch_bounds__(256) void merged_merge_kernel(vgx_tsdf_config c, fl
                                                           float4* __restrict__ g_pg, uint32_t* __restrict__ g_color,
                                                           uint32_t* __restrict__ g_flags,
                                                           uint32_t* __restrict__ g_count,
-                                                          unsigned int* __restrict__ too_long) {
+                                                          unsigned int* __restrict__ key_corner,
+                                                          unsigned long long* __restrict__ scan_ctr) {
   const int lane = threadIdx.x & (L - 1);
   const unsigned int n_sub = gridDim.x * (blockDim.x / L);
-  if (blockIdx.x == 0 && threadIdx.x == 0 && too_long[1]) {  // merged_bundle_kernel: a key equal to the invalid marker
-    too_long[0] = 2u;
-    too_long[1] = 0u;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && *key_corner) {  // merged_bundle_kernel: a key equal to the invalid marker
+    scan_ctr[kCtrError] = kErrMergedKeyCorner;
+    *key_corner = 0u;
   }
+  unsigned long long my_steps = 0;  // ray steps of the groups this thread finished (lane 0 of a group)
   const unsigned int G = counters[0], n_valid = counters[3];
   for (unsigned int g = blockIdx.x * (blockDim.x / L) + threadIdx.x / L; g < G; g += n_sub) {
     const unsigned int i0 = group_start[g], i1 = g + 1 < G ? group_start[g + 1] : n_valid;
@@ -536,15 +542,20 @@ __global__ __launch_bounds__(256) void merged_merge_kernel(vgx_tsdf_config c, fl
           flags |= kGroupValid;
           count = (uint32_t)(r.steps + 1);
         } else if (!r.bad) {
-          *too_long = 1u;  // the step index is packed into 24 bits: the scan is refused (as the fast path does)
+          scan_ctr[kCtrError] = kErrMergedRayTooLong;  // the step index is packed into 24 bits: the scan is refused (as the fast path does)
         }
       }
       g_pg[g] = make_float4(gx, gy, gz, mw);
       g_color[g] = mcol;
       g_flags[g] = flags;
       g_count[g] = count;
+      my_steps += count;
     }
   }
+  // the scan's ray steps, in 64 bits (the host sizes the write-out by it; the 32-bit offsets would wrap silently)
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) my_steps += __shfl_down(my_steps, d);
+  if ((threadIdx.x & 63) == 0 && my_steps) atomicAdd(&scan_ctr[kCtrTotal], my_steps);
 }
 
 __global__ __launch_bounds__(256) void tsdf_unpack_kernel(const unsigned long long* __restrict__ voxels,
@@ -1303,8 +1314,8 @@ static int merged_integrate_locked(vgx_tsdf_integrator I, const float T[7], cons
         VGX_HIP(ctx, hipMemsetAsync(I->d_mcounters, 0, 32, ctx->stream));  // ([5]: set by a scan, cleared by the same scan)
       }
       size_t bytes = 0, b2 = 0;
-      VGX_HIP(ctx, stable_sort_pairs(nullptr, bytes, I->d_mkeys[0], I->d_mkeys[1], I->d_midx[0], I->d_midx[1], (size_t)n, 64,
-                                     ctx->stream));
+      VGX_HIP(ctx, stable_sort_pairs_u64(nullptr, bytes, I->d_mkeys[0], I->d_mkeys[1], I->d_midx[0], I->d_midx[1], (size_t)n,
+                                         ctx->stream));
       VGX_HIP(ctx, rocprim::exclusive_scan(nullptr, b2,
                                            rocprim::make_transform_iterator(rocprim::make_counting_iterator<unsigned int>(0u),
                                                                             MergedHeadOp{I->d_mkeys[1]}),
@@ -1322,15 +1333,18 @@ static int merged_integrate_locked(vgx_tsdf_integrator I, const float T[7], cons
     const uint32_t* order = nullptr;  // the order a group's points are merged in
     rc = visiting_order(I, d_points, n, &order);
     if (rc != VGX_OK) return rc;
+    unsigned long long* scan_ctr = nullptr;  // kCtr*: zeroed by the bundle kernel, read back once in det_merged_commit
+    rc = det_counters(I, &scan_ctr);
+    if (rc != VGX_OK) return rc;
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
     hipLaunchKernelGGL(merged_bundle_kernel, grid, block, 0, ctx->stream, c, I->layer->dev.voxel_size_inv, T[0], T[1],
                        T[2], T[3], T[4], T[5], T[6], (const float*)d_points, (long long)n, order, (int)freespace,
-                       I->d_mkeys[0], I->d_midx[0], I->d_mcounters, I->d_gcount);
+                       I->d_mkeys[0], I->d_midx[0], I->d_mcounters, I->d_gcount, scan_ctr);
     VGX_HIP(ctx, hipGetLastError());
     size_t bytes = I->msort_bytes;
     // stable: equal keys keep the visiting order they were written in
-    VGX_HIP(ctx, stable_sort_pairs(I->d_msort, bytes, I->d_mkeys[0], I->d_mkeys[1], I->d_midx[0], I->d_midx[1], (size_t)n, 64,
-                                   ctx->stream));
+    VGX_HIP(ctx, stable_sort_pairs_u64(I->d_msort, bytes, I->d_mkeys[0], I->d_mkeys[1], I->d_midx[0], I->d_midx[1], (size_t)n,
+                                       ctx->stream));
     keys_sorted = I->d_mkeys[1];
     idx_sorted = I->d_midx[1];
     bytes = I->msort_bytes;
@@ -1347,7 +1361,7 @@ static int merged_integrate_locked(vgx_tsdf_integrator I, const float T[7], cons
     hipLaunchKernelGGL(merged_merge_kernel<kLanes>, dim3(work_groups), block, 0, ctx->stream, c, I->layer->dev.voxel_size_inv,
                        T[0], T[1], T[2], T[3], T[4], T[5], T[6], (const float*)d_points, (const uint32_t*)d_rgba, keys_sorted,
                        idx_sorted, I->d_mstart, I->d_mcounters, I->d_gpg, I->d_gcolor, I->d_gflags, I->d_gcount,
-                       I->d_mcounters + 4);
+                       I->d_mcounters + 5, scan_ctr);
     VGX_HIP(ctx, hipGetLastError());
     // integrateRays.  Every ray crosses the sensor's own neighbourhood, so those voxels take one update
     // per group: thousands of rays contending for one compare-and-swap (measured: 30 ms per RGB-D

@@ -87,16 +87,6 @@ struct DetScratch {
   long long ext_points = -1;  // ext[] holds the previous scan's marks for a scan of this many points (-1: nothing to keep)
 };
 
-// kCtrArrive: the ray kernel's blocks as they finish (low word) and how many of them moved a stopping step
-// (high word); kCtrTicket: the sweep kernel's tiles in the order they start.  Both are back at zero when a
-// sweep's ray kernel ends (its last block) and at the start of every scan (det_points_kernel).
-// kCtrTotal: the accesses det_count_kernel counted (64 bits: an overflowing scan is seen, not wrapped); kCtrM /
-// kCtrBlocks: the updates and the layer's block count as det_blocks_kernel found them (so that one copy of the
-// counters is the whole read-back of a commit).
-enum { kCtrChanged = 0, kCtrNew = 1, kCtrError = 2, kCtrDropped = 3, kCtrLong = 4, kCtrOverflow = 5, kCtrArrive = 6, kCtrTicket = 7,
-       kCtrTotal = 8, kCtrM = 9, kCtrBlocks = 10,
-       kCtrCount = 12,
-       kHostTotal = kCtrCount, kHostM, kHostTooLong, kHostWords };
 enum { kRayValid = 1u, kRayClearing = 2u, kRayCast = 4u };
 constexpr uint32_t kInvalidStartKey = 1u << kSetBits;
 constexpr long long kVoxBias = 1ll << 20;  // 21 bits per axis
@@ -1151,6 +1141,13 @@ static int ensure_scratch(vgx_tsdf_integrator I) {
   return VGX_OK;
 }
 
+// the scan's counters where vgx_tsdf.hip's merged-integrator kernels write them (the scratch object is made on demand)
+int det_counters(vgx_tsdf_integrator I, unsigned long long** d_ctr) {
+  DET_TRY(ensure_scratch(I));
+  *d_ctr = I->det->d_ctr;
+  return VGX_OK;
+}
+
 // ---- 3. the updates that happen, in sorted order -> compaction, new blocks, ordered application ----
 // (shared by both integrators: `update` says which of the N sorted accesses update their voxel; rays are
 // indexed by acc_ray, their point / weight / colour live in ray_pg / ray_color)
@@ -1535,7 +1532,8 @@ int det_merged_commit(vgx_tsdf_integrator I, const float T[7], long long n, cons
   // g_count is zero beyond the last group (the caller cleared it): the scan runs over n + 1 entries and
   // the number of groups never has to come to the host
   const size_t G = (size_t)n;
-  VGX_HIP(ctx, hipMemsetAsync(S->d_ctr, 0, kCtrCount * 8, st));
+  // (the counters were zeroed by merged_bundle_kernel; merged_merge_kernel left the number of ray steps -- 64 bits:
+  // the 32-bit offsets below wrap silently -- and its error code in them: ONE copy is the scan's whole read-back)
   DET_TRY(grow(ctx, S->off, (G + 1) * 4));
   {
     size_t bytes = 0;
@@ -1544,28 +1542,15 @@ int det_merged_commit(vgx_tsdf_integrator I, const float T[7], long long n, cons
     bytes = S->tmp.bytes;
     VGX_HIP(ctx, rocprim::exclusive_scan(S->tmp.p, bytes, g_count, S->off.as<uint32_t>(), 0u, G + 1, rocprim::plus<uint32_t>(), st));
   }
-  DET_TRY(fetch_u32(ctx, S, kHostTotal, S->off.as<uint32_t>() + G));
-  DET_TRY(fetch_u32(ctx, S, kHostTooLong, counters + 4));
-  VGX_HIP(ctx, hipStreamSynchronize(st));
-  const uint32_t total = (uint32_t)S->h_ctr[kHostTotal], too_long = (uint32_t)S->h_ctr[kHostTooLong];
-  if (too_long == 2u)  // (merged_bundle_kernel)
+  DET_TRY(read_counters(ctx, S));
+  if (S->h_ctr[kCtrError] == kErrMergedKeyCorner)  // (merged_bundle_kernel)
     return set_error(ctx, VGX_ERR_UNSUPPORTED,
                      "TSDF merged integrator: a clearing point whose end voxel is 2^20 - 1 (mod 2^21) on all three axes cannot be keyed");
-  if (too_long)  // (merged_merge_kernel: the fast path raises the same error for the same condition)
+  if (S->h_ctr[kCtrError])  // (merged_merge_kernel: the fast path raises the same error for the same condition)
     return set_error(ctx, VGX_ERR_UNSUPPORTED, "TSDF merged integrator: a ray longer than 2^24 voxel steps");
-  {
-    // the 32-bit total wraps silently.  Cheap bound first -- no ray is longer than max_steps, and there are
-    // at most n groups; only when that does not settle it, the exact 64-bit sum of the groups' ray lengths
-    const double max_steps = 3.0 * ((double)c.max_ray_length_m + 2.0 * c.default_truncation_distance) * I->layer->dev.voxel_size_inv + 8.0;
-    if ((double)G * max_steps >= 4.0e9) {
-      std::vector<uint32_t> cnt(G);
-      VGX_HIP(ctx, hipMemcpy(cnt.data(), g_count, G * 4, hipMemcpyDeviceToHost));
-      unsigned long long sum = 0;
-      for (uint32_t v : cnt) sum += v;
-      if (sum >= (1ull << 32) - 2)
-        return set_error(ctx, VGX_ERR_UNSUPPORTED, "TSDF merged integrator: more than 2^32 voxel steps in a scan");
-    }
-  }
+  if (S->h_ctr[kCtrTotal] >= (1ull << 32) - 2)
+    return set_error(ctx, VGX_ERR_UNSUPPORTED, "TSDF merged integrator: more than 2^32 voxel steps in a scan");
+  const uint32_t total = (uint32_t)S->h_ctr[kCtrTotal];
   const size_t N = total;
   if (N == 0) return VGX_OK;
   DET_TRY(grow(ctx, S->acc_vox, N * 8));

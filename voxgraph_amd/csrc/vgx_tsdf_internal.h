@@ -209,6 +209,22 @@ __device__ __forceinline__ void transform_point(float qw, float qx, float qy, fl
   gz = (pz + qw * uvz + ccz) + tz;
 }
 
+// ---- the reproducible mode's / merged integrator's per-scan counters (u64 each; DetScratch::d_ctr) ----
+// kCtrArrive: the ray kernel's blocks as they finish (low word) and how many of them moved a stopping step
+// (high word); kCtrTicket: the sweep kernel's tiles in the order they start.  Both are back at zero when a
+// sweep's ray kernel ends (its last block) and at the start of every scan (det_points_kernel).
+// kCtrTotal: the accesses det_count_kernel counted (64 bits: an overflowing scan is seen, not wrapped); kCtrM /
+// kCtrBlocks: the updates and the layer's block count as det_blocks_kernel found them (so that one copy of the
+// counters is the whole read-back of a commit).
+enum { kCtrChanged = 0, kCtrNew = 1, kCtrError = 2, kCtrDropped = 3, kCtrLong = 4, kCtrOverflow = 5, kCtrArrive = 6, kCtrTicket = 7,
+       kCtrTotal = 8, kCtrM = 9, kCtrBlocks = 10,
+       kCtrCount = 12,
+       kHostM = kCtrCount, kHostWords };
+// kCtrError: 1 a ray of more than 2^24 steps (reproducible mode), 2 a voxel beyond +-2^20 on a walk, 3 a sweep's tile never
+// reported, and from the merged integrator's kernels:
+enum { kErrMergedRayTooLong = 4, kErrMergedKeyCorner = 5 };
+
+
 struct DetScratch;  // vgx_tsdf_det.hip
 void det_scratch_free(DetScratch* s);
 
@@ -233,6 +249,20 @@ inline hipError_t stable_sort_pairs(void* tmp, size_t& bytes, KeyIn keys_in, Key
   if (few_pass_sort())
     return rocprim::radix_sort_pairs<FewPassSort>(tmp, bytes, keys_in, keys_out, vals_in, vals_out, n, 0, end_bit, st);
   return rocprim::radix_sort_pairs(tmp, bytes, keys_in, keys_out, vals_in, vals_out, n, 0, end_bit, st);
+}
+// 64-bit keys (the merged integrator's {clearing, end voxel} keys): the radix block sort of the configuration above
+// walks all 64 bits (30 us for 65 536 records); a comparison sort does not care how wide the key is.  rocprim's
+// merge_sort is stable; blocks of 1024 / 2048 records, odd-even merges (profiles/probes/sort_probe.hip: 65 536
+// records 41.6 us against 57.7, 307 200 records 84.7 against 103.2).
+using WideKeySortSmall = rocprim::merge_sort_config<256, 256, 4, 128, 128, 4, (1u << 20)>;
+using WideKeySortLarge = rocprim::merge_sort_config<256, 256, 8, 128, 128, 4, (1u << 20)>;
+inline hipError_t stable_sort_pairs_u64(void* tmp, size_t& bytes, const unsigned long long* keys_in, unsigned long long* keys_out,
+                                        const unsigned int* vals_in, unsigned int* vals_out, size_t n, hipStream_t st) {
+  if (!few_pass_sort() || n > (1u << 20))
+    return rocprim::radix_sort_pairs(tmp, bytes, keys_in, keys_out, vals_in, vals_out, n, 0, 64, st);
+  if (n > (1u << 17))
+    return rocprim::merge_sort<WideKeySortLarge>(tmp, bytes, keys_in, keys_out, vals_in, vals_out, n, rocprim::less<unsigned long long>(), st);
+  return rocprim::merge_sort<WideKeySortSmall>(tmp, bytes, keys_in, keys_out, vals_in, vals_out, n, rocprim::less<unsigned long long>(), st);
 }
 
 }  // namespace vgx
@@ -310,6 +340,8 @@ void tsdf_request_readback(vgx_tsdf_layer L);
 // `order`: order[seq] = index of the point visited seq-th (integration_order "sorted"), nullptr = "mixed"
 int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points, const void* d_rgba, int64_t n,
                   int32_t freespace, const uint32_t* order, int64_t* n_updates);
+// the scan's counters (kCtr*) for the merged integrator's own kernels; makes the scratch object on demand
+int det_counters(vgx_tsdf_integrator I, unsigned long long** d_ctr);
 // the merged integrator's rays (merged point / colour / flags / ray length per group, groups in key order)
 // applied voxel by voxel in group order
 int det_merged_commit(vgx_tsdf_integrator I, const float T[7], long long n, const float4* g_pg, const uint32_t* g_color,
