@@ -17,8 +17,10 @@
 //     early), (slot, ray, step) stable-sorted by slot.  Given a stopping step T_r per ray, an
 //     access happens iff step <= T_r, and what an access finds in its slot is the value of the last
 //     access that HAPPENED before it in the slot's run: an exclusive max-scan over "position if
-//     happened" gives that for all accesses at once; every ray then re-reads its own flags and
-//     recomputes T_r.  Iterated from T_r = full length this is a fixed-point iteration whose
+//     happened" gives that for all accesses at once (det_sweep_kernel: tiles chained by one tagged
+//     word each, the scan itself never stored); every ray then re-reads its own flags and
+//     recomputes T_r (det_ray_kernel, whose last workgroup tells the host through a pinned word).
+//     Iterated from T_r = full length this is a fixed-point iteration whose
 //     unique fixed point is the sequential execution (by induction over the visiting order: the
 //     first ray whose T is wrong has only correct predecessors and is corrected by the next
 //     sweep), reached when a sweep changes no T.  Measured: 15-25 sweeps on dense LiDAR scans
@@ -29,8 +31,9 @@
 //     run allocates them), and one thread per slot run applies its updates one after another with
 //     plain loads and stores -- updateTsdfVoxel's arithmetic, no atomics.
 //
-// HBM traffic is a few sorts and scans over the speculative accesses (~60 B each); the mode trades
-// 10-50 x the racing kernel's time for a layer that is the same bit for bit on every run.
+// HBM traffic is a few sorts and scans over the speculative accesses (~60 B each); what the mode costs is
+// launches and host waits (44 launches and two waits outside the sweeps per LiDAR scan): it
+// trades 5-6 x the racing kernel's time for a layer that is the same bit for bit on every run.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
