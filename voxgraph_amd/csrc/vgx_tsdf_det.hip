@@ -1346,10 +1346,12 @@ int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points,
                      (const unsigned long long*)I->dev.start_set, S->ray_flags.as<uint32_t>());
   VGX_HIP(ctx, hipGetLastError());
   // ---- 2. walks written out (bounded speculation: see det_count_kernel), sorted, swept to the fixed point ----
-  // The first count is of the COMPLETE walks (det_points_kernel marked every ray "written out completely").  Small scans (a LiDAR sweep at 0.2 m: < 1 M steps) are swept as
-  // they are -- an attempt costs a dozen launches and two read-backs, more than the steps saved; large ones
-  // (a depth image at 0.05 m: 18 M steps) are cut to `det_cap` (32) steps per ray and extended on demand.
-  // With the early-out switched off every ray runs its full length anyway.
+  // The first count is of the COMPLETE walks (det_points_kernel marked every ray "written out completely").  Small
+  // scans (a LiDAR sweep at 0.2 m: < 1 M steps) are swept as they are -- an attempt costs a dozen launches and a
+  // read-back, more than the steps saved; large ones (a depth image at 0.05 m: 18 M steps) are cut to `det_cap`
+  // (32) steps per ray and extended on demand.  With the early-out switched off every ray runs its full length
+  // anyway.  Once a scan had to be cut, the next ones are cut from the start (S->start_capped), with the marks of
+  // the rays that ran on kept from scan to scan (det_extend_kernel).
   bool capped = start_capped;  // this attempt cut rays short: whether one of them ran on has to be looked at afterwards
   bool may_cap = may_cap_at_all && !start_capped;
   const uint32_t kCapThreshold = I->det_cap_threshold, cap = std::max<uint32_t>(I->det_cap, 1u);
