@@ -261,15 +261,17 @@ __global__ __launch_bounds__(256) void det_count_kernel(vgx_tsdf_config c, float
 __global__ __launch_bounds__(256) void det_extend_kernel(long long n, const uint32_t* __restrict__ count,
                                                         const uint32_t* __restrict__ full_count,
                                                         const uint8_t* __restrict__ broke, const int32_t* __restrict__ T,
-                                                        uint8_t* __restrict__ ext, uint32_t cap,
+                                                        uint8_t* __restrict__ ext, uint32_t cap, int mark_life,
                                                         unsigned long long* __restrict__ ctr) {
   const long long seq = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (seq == 0) ctr[kCtrTotal] = 0ull;  // (the next attempt counts again)
   if (seq >= n) return;
   const bool ran_on = count[seq] < full_count[seq] && !broke[seq];
-  // (half the cap: a ray that got that far is as good as a pioneer for the next scan)
+  // (half the cap: a ray that got that far is as good as a pioneer for the next scan; a mark outlives a few scans in
+  // which its ray stopped early: the pioneers of a moving sensor come and go)
   const bool far = full_count[seq] > cap && T[seq] >= (int32_t)(cap / 2);
-  ext[seq] = (ran_on || far) ? 1 : 0;
+  const uint8_t old = ext[seq];
+  ext[seq] = (ran_on || far) ? (uint8_t)mark_life : (old > 0 ? old - 1 : 0);
   if (ran_on) ctr[kCtrOverflow] = 1ull;
 }
 
@@ -1355,6 +1357,7 @@ int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points,
   bool capped = start_capped;  // this attempt cut rays short: whether one of them ran on has to be looked at afterwards
   bool may_cap = may_cap_at_all && !start_capped;
   const uint32_t kCapThreshold = I->det_cap_threshold, cap = std::max<uint32_t>(I->det_cap, 1u);
+  static const int mark_life = getenv("VGX_DET_MARK_LIFE") ? std::max(1, std::min(200, atoi(getenv("VGX_DET_MARK_LIFE")))) : 2;  // (depth image, ms per scan: 1 -> 1.25, 2 -> 1.17, 4 -> 1.18, 8 -> 1.21)
   static const bool scan_sweeps = getenv("VGX_DET_SWEEP") && !strcmp(getenv("VGX_DET_SWEEP"), "scan");  // A/B aid
   size_t N = 0;
   int walks_done = 0;
@@ -1502,7 +1505,7 @@ int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points,
     if (range_error) break;
     if (!capped) break;  // every ray was written out completely: nothing can have been cut short
     hipLaunchKernelGGL(det_extend_kernel, dim3(blocks_for(np)), dim3(256), 0, st, (long long)n, S->count.as<uint32_t>(),
-                       S->full_count.as<uint32_t>(), S->broke.as<uint8_t>(), S->T.as<int32_t>(), S->ext.as<uint8_t>(), cap, S->d_ctr);
+                       S->full_count.as<uint32_t>(), S->broke.as<uint8_t>(), S->T.as<int32_t>(), S->ext.as<uint8_t>(), cap, mark_life, S->d_ctr);
     VGX_HIP(ctx, hipGetLastError());
     DET_TRY(read_counters(ctx, S));
     pc.mark(3);
