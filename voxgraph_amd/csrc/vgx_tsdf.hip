@@ -436,35 +436,51 @@ __global__ __launch_bounds__(256) void merged_bundle_kernel(vgx_tsdf_config c, f
 // reference's single thread walks its two voxel maps in, oracle/tsdf_oracle.c), and
 //   counters[0] = number of groups            counters[1] = number of surface (non-clearing) entries
 //   counters[2] = number of surface groups    counters[3] = number of valid entries
-struct MergedHeadOp {
-  const unsigned long long* keys;
-  __host__ __device__ unsigned int operator()(unsigned int i) const {
-    const unsigned long long k = keys[i];
-    return (k != kMergedInvalid && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
-  }
-};
-
+// (the ranks -- the exclusive prefix of "is a group's first entry" -- are taken inside the launch: TileChain; tiles of
+// 1024 sorted entries, four consecutive ones per thread)
+constexpr int kHeadsIpt = 4;
 __global__ __launch_bounds__(256) void merged_heads_kernel(const unsigned long long* __restrict__ keys, long long n,
-                                                          const unsigned int* __restrict__ rank,
-                                                          unsigned int* __restrict__ group_start,
+                                                          TileChain chain, unsigned int* __restrict__ group_start,
                                                           unsigned int* __restrict__ counters) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const unsigned long long k = keys[i];
-  const bool valid = k != kMergedInvalid;
-  const bool head = valid && (i == 0 || keys[i - 1] != k);
-  if (head) group_start[rank[i]] = (unsigned int)i;
-  const bool next_valid = i + 1 < n && keys[i + 1] != kMergedInvalid;
-  if (valid && !next_valid) {  // the last valid entry
-    counters[0] = rank[i] + (head ? 1u : 0u);
-    counters[3] = (unsigned int)(i + 1);
+  __shared__ uint32_t sh_word, sh4[4];
+  const uint32_t tile = chain_tile(chain, &sh_word);
+  const long long base = ((long long)tile * 256 + threadIdx.x) * kHeadsIpt;
+  unsigned long long k[kHeadsIpt + 2];  // k[0]: the entry before this thread's, k[kHeadsIpt + 1]: the one after
+#pragma unroll
+  for (int e = 0; e < kHeadsIpt + 2; ++e) {
+    const long long i = base - 1 + e;
+    k[e] = (i >= 0 && i < n) ? keys[i] : kMergedInvalid;
   }
-  if (valid && !(k >> 63)) {
-    const bool next_surface = next_valid && !(keys[i + 1] >> 63);
-    if (!next_surface) {  // the last surface entry
-      counters[1] = (unsigned int)(i + 1);
-      counters[2] = rank[i] + (head ? 1u : 0u);
+  uint32_t head[kHeadsIpt], mine = 0;
+#pragma unroll
+  for (int e = 0; e < kHeadsIpt; ++e) {
+    const long long i = base + e;
+    head[e] = (i < n && k[e + 1] != kMergedInvalid && (i == 0 || k[e] != k[e + 1])) ? 1u : 0u;
+    mine += head[e];
+  }
+  uint32_t in_tile = 0;
+  const uint32_t before = block_exclusive_sum(mine, sh4, in_tile);
+  uint32_t rank = chain_exclusive_sum(chain, tile, in_tile, &sh_word) + before;
+#pragma unroll
+  for (int e = 0; e < kHeadsIpt; ++e) {
+    const long long i = base + e;
+    if (i >= n) break;
+    const unsigned long long key = k[e + 1];
+    const bool valid = key != kMergedInvalid;
+    if (head[e]) group_start[rank] = (unsigned int)i;
+    const bool next_valid = i + 1 < n && k[e + 2] != kMergedInvalid;
+    if (valid && !next_valid) {  // the last valid entry
+      counters[0] = rank + head[e];
+      counters[3] = (unsigned int)(i + 1);
     }
+    if (valid && !(key >> 63)) {
+      const bool next_surface = next_valid && !(k[e + 2] >> 63);
+      if (!next_surface) {  // the last surface entry
+        counters[1] = (unsigned int)(i + 1);
+        counters[2] = rank + head[e];
+      }
+    }
+    rank += head[e];
   }
 }
 
@@ -1304,7 +1320,6 @@ static int merged_integrate_locked(vgx_tsdf_integrator I, const float T[7], cons
         VGX_HIP(ctx, hipMalloc(&I->d_midx[k], (size_t)n * 4));
       }
       VGX_HIP(ctx, hipMalloc(&I->d_mstart, (size_t)n * 4));
-      VGX_HIP(ctx, hipMalloc(&I->d_mrank, (size_t)n * 4));
       VGX_HIP(ctx, hipMalloc(&I->d_gpg, (size_t)n * 16));
       VGX_HIP(ctx, hipMalloc(&I->d_gcolor, (size_t)n * 4));
       VGX_HIP(ctx, hipMalloc(&I->d_gflags, (size_t)n * 4));
@@ -1313,14 +1328,9 @@ static int merged_integrate_locked(vgx_tsdf_integrator I, const float T[7], cons
         VGX_HIP(ctx, hipMalloc(&I->d_mcounters, 32));
         VGX_HIP(ctx, hipMemsetAsync(I->d_mcounters, 0, 32, ctx->stream));  // ([5]: set by a scan, cleared by the same scan)
       }
-      size_t bytes = 0, b2 = 0;
+      size_t bytes = 0;
       VGX_HIP(ctx, stable_sort_pairs_u64(nullptr, bytes, I->d_mkeys[0], I->d_mkeys[1], I->d_midx[0], I->d_midx[1], (size_t)n,
                                          ctx->stream));
-      VGX_HIP(ctx, rocprim::exclusive_scan(nullptr, b2,
-                                           rocprim::make_transform_iterator(rocprim::make_counting_iterator<unsigned int>(0u),
-                                                                            MergedHeadOp{I->d_mkeys[1]}),
-                                           I->d_mrank, 0u, (size_t)n, rocprim::plus<unsigned int>(), ctx->stream));
-      bytes = std::max(bytes, b2);
       VGX_HIP(ctx, hipMalloc(&I->d_msort, std::max<size_t>(bytes, 16)));
       I->msort_bytes = bytes;
       I->merged_cap = n;
@@ -1347,14 +1357,16 @@ static int merged_integrate_locked(vgx_tsdf_integrator I, const float T[7], cons
                                        ctx->stream));
     keys_sorted = I->d_mkeys[1];
     idx_sorted = I->d_midx[1];
-    bytes = I->msort_bytes;
-    VGX_HIP(ctx, rocprim::exclusive_scan(I->d_msort, bytes,
-                                         rocprim::make_transform_iterator(rocprim::make_counting_iterator<unsigned int>(0u),
-                                                                          MergedHeadOp{keys_sorted}),
-                                         I->d_mrank, 0u, (size_t)n, rocprim::plus<unsigned int>(), ctx->stream));
-    hipLaunchKernelGGL(merged_heads_kernel, grid, block, 0, ctx->stream, keys_sorted, (long long)n, I->d_mrank, I->d_mstart,
-                       I->d_mcounters);
-    VGX_HIP(ctx, hipGetLastError());
+    {
+      // group heads and their ranks in ONE launch (the prefix sum inside it: TileChain)
+      const uint32_t head_tiles = (uint32_t)((n + 256 * kHeadsIpt - 1) / (256 * kHeadsIpt));
+      TileChain chain;
+      rc = det_next_chain(I, head_tiles, &chain);
+      if (rc != VGX_OK) return rc;
+      hipLaunchKernelGGL(merged_heads_kernel, dim3(head_tiles), block, 0, ctx->stream, keys_sorted, (long long)n, chain, I->d_mstart,
+                         I->d_mcounters);
+      VGX_HIP(ctx, hipGetLastError());
+    }
     // one L-lane sub-group per group, grid-stride (the number of groups stays on the device)
     constexpr int kLanes = 16;
     const unsigned work_groups = (unsigned)std::min<long long>(((long long)n * kLanes + 255) / 256, (long long)ctx->cu_count * 16);

@@ -80,7 +80,8 @@ struct DetScratch {
   // the sweeps (det_sweep_kernel): one 8-byte state per tile of the sorted accesses, tagged with the sweep's
   // epoch so that nothing has to be cleared between sweeps; zeroed when (re)allocated
   Buf tile_state;
-  uint32_t sweep_epoch = 0;
+  uint32_t sweep_epoch = 0;      // ... and of every TileChain launch (one counter: the words are shared)
+  uint32_t chain_tickets = 0;    // TileChain workgroups launched since the scan's first kernel zeroed kCtrChainTicket
   // what the sweep's last block tells the host (pinned, written from the kernel): sweep sequence number << 2 |
   // error << 1 | "a stopping step moved"
   unsigned long long* h_flag = nullptr;
@@ -216,6 +217,7 @@ __device__ __forceinline__ void start_set_after(long long p, long long n, const 
 // (same accesses happen, same decisions; it is unique), so the result does not depend on `cap`.
 // (the depth is vgx_tsdf_integrator_s::det_cap, 32 unless a test says otherwise)
 
+// (also the rays' offsets into the write-out: the exclusive prefix of the counts, taken inside this launch -- TileChain)
 __global__ __launch_bounds__(256) void det_count_kernel(vgx_tsdf_config c, float vsi, float tx, float ty, float tz,
                                                        long long n, const float4* __restrict__ ray_pg,
                                                        const uint32_t* __restrict__ ray_flags,
@@ -225,8 +227,11 @@ __global__ __launch_bounds__(256) void det_count_kernel(vgx_tsdf_config c, float
                                                        const uint32_t* __restrict__ seq_sorted,
                                                        const unsigned long long* __restrict__ start_val,
                                                        unsigned long long* __restrict__ start_set, uint32_t cap,
-                                                       unsigned long long* __restrict__ ctr) {
-  const long long seq = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+                                                       unsigned long long* __restrict__ ctr, TileChain chain,
+                                                       uint32_t* __restrict__ off) {
+  __shared__ uint32_t sh_word, sh4[4];
+  const uint32_t tile = chain_tile(chain, &sh_word);
+  const long long seq = (long long)tile * 256 + threadIdx.x;
   // (a second job for the same thread index: the start set's state after this scan; a repeated count stores the
   // same values again)
   start_set_after(seq, n, key_sorted, seq_sorted, start_val, start_set);
@@ -242,14 +247,15 @@ __global__ __launch_bounds__(256) void det_count_kernel(vgx_tsdf_config c, float
   if (seq <= n) {
     const bool complete = seq < n && ext[seq] != 0;
     written = complete ? full : min(full, cap);
-    count[seq] = written;  // count[n] = 0: the scan's last output is the total
+    count[seq] = written;  // count[n] = 0
     if (seq < n) full_count[seq] = full;
   }
-  // the scan's total, in 64 bits (the 32-bit offsets wrap silently): one atomic per wave
-  unsigned long long sum = written;
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) sum += __shfl_down(sum, d);
-  if ((threadIdx.x & 63) == 0 && sum) atomicAdd(&ctr[kCtrTotal], sum);
+  uint32_t in_tile = 0;
+  const uint32_t before = block_exclusive_sum(written, sh4, in_tile);
+  const uint32_t prefix = chain_exclusive_sum(chain, tile, in_tile, &sh_word);
+  if (seq <= n) off[seq] = prefix + before;  // (32 bits: a scan of 2^32 steps or more is refused by the 64-bit total below)
+  // the scan's total, in 64 bits: one atomic per workgroup
+  if (threadIdx.x == 0 && in_tile) atomicAdd(&ctr[kCtrTotal], (unsigned long long)in_tile);
 }
 
 // After the sweeps of an attempt: rays that did not stop within what was written out of them have to be written
@@ -551,26 +557,44 @@ __global__ __launch_bounds__(256) void det_ray_kernel(long long n, int max_colli
 }
 
 // ---- 3a. compaction of the updates (sorted order kept) + the set's state after the scan ---------
+// (the compaction offsets -- the exclusive prefix of `update` -- are taken inside this launch: TileChain; tiles of
+// 2048 sorted accesses, eight consecutive ones per thread.  *n_updates = how many accesses update their voxel.)
 __global__ __launch_bounds__(256) void det_finish_kernel(size_t N, const uint32_t* __restrict__ s_key,
                                                         const uint32_t* __restrict__ s_idx,
                                                         const uint32_t* __restrict__ s_h,
                                                         const uint32_t* __restrict__ last, HappenedOp happened,
-                                                        UpdateOp update, const uint32_t* __restrict__ cpos,
+                                                        UpdateOp update, TileChain chain, uint32_t* __restrict__ n_updates,
                                                         uint32_t* __restrict__ c_idx, uint32_t* __restrict__ c_key,
                                                         unsigned long long* __restrict__ observed_set,
                                                         unsigned long long observed_offset) {
-  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= N) return;
-  const uint32_t key = s_key[p];
-  if (update((uint32_t)p)) {
-    const uint32_t q = cpos[p];
-    c_idx[q] = s_idx[p];
-    c_key[q] = key;
+  __shared__ uint32_t sh_word, sh4[4];
+  const uint32_t tile = chain_tile(chain, &sh_word);
+  const size_t base = (size_t)tile * kSweepTile + (size_t)threadIdx.x * kSweepIpt;
+  uint32_t u[kSweepIpt], mine = 0;
+#pragma unroll
+  for (int e = 0; e < kSweepIpt; ++e) {
+    u[e] = base + e < N ? update((uint32_t)(base + e)) : 0u;
+    mine += u[e];
   }
-  if (!observed_set) return;  // merged integrator: no approximate sets
-  if (p == N - 1 || s_key[p + 1] != key) {  // the slot keeps what the last exchange of its run wrote
-    const uint32_t li = happened((uint32_t)p) ? (uint32_t)p + 1u : last[p];
-    if (li > 0 && s_key[li - 1] == key) observed_set[key] = (unsigned long long)s_h[li - 1] + observed_offset;
+  uint32_t in_tile = 0;
+  const uint32_t before = block_exclusive_sum(mine, sh4, in_tile);
+  uint32_t q = chain_exclusive_sum(chain, tile, in_tile, &sh_word) + before;
+#pragma unroll
+  for (int e = 0; e < kSweepIpt; ++e) {
+    const size_t p = base + e;
+    if (p >= N) break;
+    const uint32_t key = s_key[p];
+    if (u[e]) {
+      c_idx[q] = s_idx[p];
+      c_key[q] = key;
+      ++q;
+    }
+    if (p == N - 1) *n_updates = q;
+    if (!observed_set) continue;  // merged integrator: no approximate sets
+    if (p == N - 1 || s_key[p + 1] != key) {  // the slot keeps what the last exchange of its run wrote
+      const uint32_t li = happened((uint32_t)p) ? (uint32_t)p + 1u : last[p];
+      if (li > 0 && s_key[li - 1] == key) observed_set[key] = (unsigned long long)s_h[li - 1] + observed_offset;
+    }
   }
 }
 
@@ -929,6 +953,29 @@ __global__ __launch_bounds__(64) void det_apply_long_kernel(TsdfLayerDev L, vgx_
   }
 }
 
+// out[i] = in[0] + ... + in[i - 1], i < n, in one launch (TileChain; tiles of 1024, four consecutive items per thread)
+constexpr int kScanIpt = 4;
+__global__ __launch_bounds__(256) void det_offsets_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n,
+                                                         TileChain chain) {
+  __shared__ uint32_t sh_word, sh4[4];
+  const uint32_t tile = chain_tile(chain, &sh_word);
+  const size_t base = ((size_t)tile * 256 + threadIdx.x) * kScanIpt;
+  uint32_t v[kScanIpt], mine = 0;
+#pragma unroll
+  for (int e = 0; e < kScanIpt; ++e) {
+    v[e] = base + e < n ? in[base + e] : 0u;
+    mine += v[e];
+  }
+  uint32_t in_tile = 0;
+  const uint32_t before = block_exclusive_sum(mine, sh4, in_tile);
+  uint32_t run = chain_exclusive_sum(chain, tile, in_tile, &sh_word) + before;
+#pragma unroll
+  for (int e = 0; e < kScanIpt; ++e) {
+    if (base + e < n) out[base + e] = run;
+    run += v[e];
+  }
+}
+
 __global__ void det_fill_u64_kernel(unsigned long long* p, size_t n, unsigned long long v) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
@@ -1111,6 +1158,24 @@ int sort_by_slot(vgx_ctx ctx, DetScratch* S, const uint32_t* keys, uint32_t* key
   return VGX_OK;
 }
 
+// the chain of the next prefix-sum launch over `tiles` workgroups: room for its words, its epoch, its ticket base
+int next_chain(vgx_ctx ctx, DetScratch* S, uint32_t tiles, TileChain* ch) {
+  int rc = grow_zeroed(ctx, S->tile_state, (size_t)tiles * 8);
+  if (rc != VGX_OK) return rc;
+  if (S->sweep_epoch >= kChainEpochMax) {  // (after 2^30 launches: start the tags over)
+    VGX_HIP(ctx, hipMemsetAsync(S->tile_state.p, 0, S->tile_state.bytes, ctx->stream));
+    S->sweep_epoch = 0;
+  }
+  ++S->sweep_epoch;
+  ch->state = S->tile_state.as<unsigned long long>();
+  ch->epoch = S->sweep_epoch;
+  ch->ticket = S->d_ctr + kCtrChainTicket;
+  ch->ticket_base = S->chain_tickets;
+  ch->error = S->d_ctr + kCtrError;
+  S->chain_tickets += tiles;
+  return VGX_OK;
+}
+
 int read_counters(vgx_ctx ctx, DetScratch* S) {
   VGX_HIP(ctx, hipMemcpyAsync(S->h_ctr, S->d_ctr, kCtrCount * 8, hipMemcpyDeviceToHost, ctx->stream));
   VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1150,7 +1215,13 @@ static int ensure_scratch(vgx_tsdf_integrator I) {
 int det_counters(vgx_tsdf_integrator I, unsigned long long** d_ctr) {
   DET_TRY(ensure_scratch(I));
   *d_ctr = I->det->d_ctr;
+  I->det->chain_tickets = 0;  // (the caller's first kernel zeroes the counters)
   return VGX_OK;
+}
+
+// the TileChain of the merged integrator's next prefix-sum launch (vgx_tsdf.hip), after det_counters
+int det_next_chain(vgx_tsdf_integrator I, uint32_t tiles, TileChain* chain) {
+  return next_chain(I->ctx, I->det, tiles, chain);
 }
 
 // ---- 3. the updates that happen, in sorted order -> compaction, new blocks, ordered application ----
@@ -1163,31 +1234,22 @@ static int det_commit(vgx_tsdf_integrator I, DetScratch* S, const float T[7], si
   vgx_tsdf_layer layer = I->layer;
   const vgx_tsdf_config& c = I->dev.cfg;
   hipStream_t st = ctx->stream;
-  auto pos = rocprim::make_counting_iterator<uint32_t>(0u);
   size_t M = N;
   const uint32_t* c_idx = S->s_idx.as<uint32_t>();  // without a filter every sorted access is an update
   const uint32_t* c_key = S->s_key.as<uint32_t>();
   const uint32_t* M_dev = nullptr;  // where the device keeps the number of updates (cpos[N]) until it has been read back
   if (update) {
-    {
-      size_t b2 = 0;
-      VGX_HIP(ctx, rocprim::exclusive_scan(nullptr, b2, rocprim::make_transform_iterator(pos, *update), S->last.as<uint32_t>(),
-                                           0u, N + 1, rocprim::plus<uint32_t>(), st));
-      DET_TRY(grow(ctx, S->tmp, b2));
-    }
-    // `last` is consumed by the finish kernel (set state) and cannot hold the compaction offsets too
-    uint32_t* cpos = S->acc_key.as<uint32_t>();  // free since the sort: the compaction offsets live there
-    {
-      size_t bytes = S->tmp.bytes;
-      VGX_HIP(ctx, rocprim::exclusive_scan(S->tmp.p, bytes, rocprim::make_transform_iterator(pos, *update), cpos, 0u, N + 1,
-                                           rocprim::plus<uint32_t>(), st));
-    }
-    hipLaunchKernelGGL(det_finish_kernel, dim3(blocks_for(N)), dim3(256), 0, st, N, S->s_key.as<uint32_t>(),
-                       S->s_idx.as<uint32_t>(), S->s_h.as<uint32_t>(), S->last.as<uint32_t>(), happened, *update, cpos,
+    // `last` is consumed by the finish kernel (set state); the number of updates lands behind the sort's input keys
+    uint32_t* m_word = S->acc_key.as<uint32_t>() + N;  // (free since the sort)
+    const uint32_t finish_tiles = (uint32_t)((N + kSweepTile - 1) / kSweepTile);
+    TileChain chain;
+    DET_TRY(next_chain(ctx, S, finish_tiles, &chain));
+    hipLaunchKernelGGL(det_finish_kernel, dim3(finish_tiles), dim3(256), 0, st, N, S->s_key.as<uint32_t>(),
+                       S->s_idx.as<uint32_t>(), S->s_h.as<uint32_t>(), S->last.as<uint32_t>(), happened, *update, chain, m_word,
                        S->c_idx.as<uint32_t>(), S->c_key.as<uint32_t>(), update_set ? I->dev.observed_set : nullptr,
                        I->dev.observed_offset);
     VGX_HIP(ctx, hipGetLastError());
-    M_dev = cpos + N;
+    M_dev = m_word;
     c_idx = S->c_idx.as<uint32_t>();
     c_key = S->c_key.as<uint32_t>();
   }
@@ -1334,6 +1396,7 @@ int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points,
   const bool start_capped = may_cap_at_all && S->start_capped;
   const bool keep_marks = start_capped && S->ext_points == n;  // the previous scan's pioneers: written out completely at once
   S->ext_points = -1;  // (until this scan has left its own)
+  S->chain_tickets = 0;  // (det_points_kernel zeroes the counters)
   hipLaunchKernelGGL(det_points_kernel, dim3(blocks_for(np + 1)), dim3(256), 0, st, c, vsi, T[0], T[1], T[2], T[3], T[4], T[5],
                      T[6], (const float*)d_points, (const uint32_t*)d_rgba, (long long)n, order, (int)freespace,
                      I->dev.start_offset, S->ray_pg.as<float4>(), S->ray_color.as<uint32_t>(), S->ray_flags.as<uint32_t>(),
@@ -1366,19 +1429,15 @@ int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points,
   UpdateOp update{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
   for (int attempt = 0;; ++attempt) {
     if (attempt > 64) return set_error(ctx, VGX_ERR_HIP, "TSDF reproducible mode: speculation did not settle (internal error)");
-    hipLaunchKernelGGL(det_count_kernel, dim3(blocks_for(np + 1)), dim3(256), 0, st, c, vsi, T[4], T[5], T[6], (long long)n,
-                       S->ray_pg.as<float4>(), S->ray_flags.as<uint32_t>(), S->ext.as<uint8_t>(), S->count.as<uint32_t>(),
-                       S->full_count.as<uint32_t>(), S->start_key_sorted.as<uint32_t>(), S->start_seq_sorted.as<uint32_t>(),
-                       S->start_val.as<unsigned long long>(), I->dev.start_set, cap, S->d_ctr);
-    VGX_HIP(ctx, hipGetLastError());
     {
-      size_t bytes = 0;
-      VGX_HIP(ctx, rocprim::exclusive_scan(nullptr, bytes, S->count.as<uint32_t>(), S->off.as<uint32_t>(), 0u, np + 1,
-                                           rocprim::plus<uint32_t>(), st));
-      DET_TRY(grow(ctx, S->tmp, bytes));
-      bytes = S->tmp.bytes;
-      VGX_HIP(ctx, rocprim::exclusive_scan(S->tmp.p, bytes, S->count.as<uint32_t>(), S->off.as<uint32_t>(), 0u, np + 1,
-                                           rocprim::plus<uint32_t>(), st));
+      const uint32_t count_tiles = blocks_for(np + 1);
+      TileChain chain;
+      DET_TRY(next_chain(ctx, S, count_tiles, &chain));
+      hipLaunchKernelGGL(det_count_kernel, dim3(count_tiles), dim3(256), 0, st, c, vsi, T[4], T[5], T[6], (long long)n,
+                         S->ray_pg.as<float4>(), S->ray_flags.as<uint32_t>(), S->ext.as<uint8_t>(), S->count.as<uint32_t>(),
+                         S->full_count.as<uint32_t>(), S->start_key_sorted.as<uint32_t>(), S->start_seq_sorted.as<uint32_t>(),
+                         S->start_val.as<unsigned long long>(), I->dev.start_set, cap, S->d_ctr, chain, S->off.as<uint32_t>());
+      VGX_HIP(ctx, hipGetLastError());
     }
     DET_TRY(read_counters(ctx, S));
     pc.mark(0);
@@ -1432,16 +1491,12 @@ int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points,
     update = UpdateOp{S->s_r.as<uint32_t>(), S->s_k.as<uint32_t>(), S->T.as<int32_t>(), S->broke.as<uint8_t>(),
                       nullptr, nullptr, (uint32_t)N};
     auto pos = rocprim::make_counting_iterator<uint32_t>(0u);
-    size_t scan_bytes = 0;
-    VGX_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, rocprim::make_transform_iterator(pos, happened),
-                                         S->last.as<uint32_t>(), 0u, N, rocprim::maximum<uint32_t>(), st));
-    {
-      size_t b2 = 0;
-      VGX_HIP(ctx, rocprim::exclusive_scan(nullptr, b2, rocprim::make_transform_iterator(pos, update), S->last.as<uint32_t>(),
-                                           0u, N + 1, rocprim::plus<uint32_t>(), st));
-      scan_bytes = std::max(scan_bytes, b2);
+    if (scan_sweeps) {  // (A/B aid: the sweep over a rocprim scan)
+      size_t scan_bytes = 0;
+      VGX_HIP(ctx, rocprim::exclusive_scan(nullptr, scan_bytes, rocprim::make_transform_iterator(pos, happened),
+                                           S->last.as<uint32_t>(), 0u, N, rocprim::maximum<uint32_t>(), st));
+      DET_TRY(grow(ctx, S->tmp, scan_bytes));
     }
-    DET_TRY(grow(ctx, S->tmp, scan_bytes));
     const uint32_t tiles = (uint32_t)((N + kSweepTile - 1) / kSweepTile);
     DET_TRY(grow_zeroed(ctx, S->tile_state, (size_t)tiles * 8));
     {
@@ -1544,11 +1599,12 @@ int det_merged_commit(vgx_tsdf_integrator I, const float T[7], long long n, cons
   // the 32-bit offsets below wrap silently -- and its error code in them: ONE copy is the scan's whole read-back)
   DET_TRY(grow(ctx, S->off, (G + 1) * 4));
   {
-    size_t bytes = 0;
-    VGX_HIP(ctx, rocprim::exclusive_scan(nullptr, bytes, g_count, S->off.as<uint32_t>(), 0u, G + 1, rocprim::plus<uint32_t>(), st));
-    DET_TRY(grow(ctx, S->tmp, bytes));
-    bytes = S->tmp.bytes;
-    VGX_HIP(ctx, rocprim::exclusive_scan(S->tmp.p, bytes, g_count, S->off.as<uint32_t>(), 0u, G + 1, rocprim::plus<uint32_t>(), st));
+    const uint32_t scan_tiles = (uint32_t)((G + 1 + 256 * kScanIpt - 1) / (256 * kScanIpt));
+    TileChain chain;
+    DET_TRY(next_chain(ctx, S, scan_tiles, &chain));
+    hipLaunchKernelGGL(det_offsets_kernel, dim3(scan_tiles), dim3(256), 0, st, (const uint32_t*)g_count, S->off.as<uint32_t>(),
+                       (uint32_t)(G + 1), chain);
+    VGX_HIP(ctx, hipGetLastError());
   }
   DET_TRY(read_counters(ctx, S));
   if (S->h_ctr[kCtrError] == kErrMergedKeyCorner)  // (merged_bundle_kernel)

@@ -209,15 +209,111 @@ __device__ __forceinline__ void transform_point(float qw, float qx, float qy, fl
   gz = (pz + qw * uvz + ccz) + tz;
 }
 
+// ---- prefix sums inside ONE launch: workgroups chained by epoch-tagged words ------------------------------------
+// A scan at these sizes (10^4 .. 10^6 items) is a launch's latency, and rocprim's is two launches; the kernels that
+// need a prefix (ray offsets, group ranks, compaction offsets) take it from here and go straight on with what
+// the prefix was for.  Tiles are taken in the order the workgroups start (a ticket: a tile only waits for tiles
+// that are already running), every tile publishes one 8-byte word
+//     epoch << 34 | status << 32 | value        status 1: the tile's own sum, 2: the sum up to the tile's end
+// and wave 0 looks back over the 64 tiles before it at a time until it meets a status-2 word.  The epoch is the
+// launch's number (one counter per scratch object), so no word is ever cleared; the ticket counts on from `base`,
+// what the host has launched on that counter since the scan's first kernel zeroed it.  (CDNA4: the words are the
+// whole exchange between workgroups -- relaxed agent-scope 8-byte loads / stores, tag and value in one word.)
+struct TileChain {
+  unsigned long long* state;   // [tiles]
+  unsigned long long epoch;    // 1 .. 2^30 - 1
+  unsigned long long* ticket;  // counts workgroups as they start
+  uint32_t ticket_base;
+  unsigned long long* error;   // set to 3 if a tile that started before this one never reported (internal error)
+};
+constexpr unsigned long long kChainEpochMax = (1ull << 30) - 1;
+
+// this workgroup's tile; every thread calls it (sh: one shared word)
+__device__ __forceinline__ uint32_t chain_tile(const TileChain& ch, uint32_t* sh) {
+  if (threadIdx.x == 0) *sh = (uint32_t)atomicAdd(ch.ticket, 1ull) - ch.ticket_base;
+  __syncthreads();
+  const uint32_t tile = *sh;
+  __syncthreads();  // (sh is free again)
+  return tile;
+}
+
+// the sum of `aggregate` over the tiles before `tile`; every thread of a 256-thread workgroup calls it with the
+// same arguments (sh: one shared word)
+__device__ __forceinline__ uint32_t chain_exclusive_sum(const TileChain& ch, uint32_t tile, uint32_t aggregate, uint32_t* sh) {
+  if (threadIdx.x < 64) {
+    const int lane = (int)threadIdx.x;
+    const unsigned long long tag = ch.epoch << 34;
+    if (lane == 0)
+      __hip_atomic_store(ch.state + tile, tag | ((tile == 0 ? 2ull : 1ull) << 32) | aggregate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t prefix = 0;
+    for (long long hi = (long long)tile - 1; hi >= 0; hi -= 64) {
+      const long long t = hi - lane;
+      unsigned long long x = 0;
+      if (t >= 0) {
+        unsigned spins = 0;
+        while (((x = __hip_atomic_load(ch.state + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 34) != ch.epoch) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1u << 22)) {  // (seconds)
+            *ch.error = 3ull;
+            x = tag | (2ull << 32);
+            break;
+          }
+        }
+      }
+      const bool inclusive = t >= 0 && ((x >> 32) & 3ull) == 2ull;
+      const unsigned long long m = __ballot(inclusive);
+      uint32_t c = t >= 0 ? (uint32_t)x : 0u;
+      if (m != 0ull && lane > __ffsll((long long)m) - 1) c = 0u;  // beyond the nearest inclusive word: already in it
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) c += (uint32_t)__shfl_xor((int)c, d);
+      prefix += c;
+      if (m != 0ull) break;
+    }
+    if (lane == 0) {
+      if (tile != 0)
+        __hip_atomic_store(ch.state + tile, tag | (2ull << 32) | (unsigned long long)(uint32_t)(prefix + aggregate), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      *sh = prefix;
+    }
+  }
+  __syncthreads();
+  const uint32_t prefix = *sh;
+  __syncthreads();
+  return prefix;
+}
+
+// exclusive prefix of v over the 256 threads of the workgroup, and their total (sh4: four shared words)
+__device__ __forceinline__ uint32_t block_exclusive_sum(uint32_t v, uint32_t* sh4, uint32_t& total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_up((int)inc, d);
+    if (lane >= d) inc += o;
+  }
+  if (lane == 63) sh4[wave] = inc;
+  __syncthreads();
+  uint32_t before = inc - v;
+  total = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    if (w < wave) before += sh4[w];
+    total += sh4[w];
+  }
+  __syncthreads();
+  return before;
+}
+
 // ---- the reproducible mode's / merged integrator's per-scan counters (u64 each; DetScratch::d_ctr) ----
 // kCtrArrive: the ray kernel's blocks as they finish (low word) and how many of them moved a stopping step
 // (high word); kCtrTicket: the sweep kernel's tiles in the order they start.  Both are back at zero when a
 // sweep's ray kernel ends (its last block) and at the start of every scan (det_points_kernel).
 // kCtrTotal: the accesses det_count_kernel counted (64 bits: an overflowing scan is seen, not wrapped); kCtrM /
 // kCtrBlocks: the updates and the layer's block count as det_blocks_kernel found them (so that one copy of the
-// counters is the whole read-back of a commit).
+// counters is the whole read-back of a commit).  kCtrChainTicket: TileChain's ticket for the scan's prefix-sum
+// kernels (never reset inside a scan: the host passes what it has launched so far as the base).
 enum { kCtrChanged = 0, kCtrNew = 1, kCtrError = 2, kCtrDropped = 3, kCtrLong = 4, kCtrOverflow = 5, kCtrArrive = 6, kCtrTicket = 7,
-       kCtrTotal = 8, kCtrM = 9, kCtrBlocks = 10,
+       kCtrTotal = 8, kCtrM = 9, kCtrBlocks = 10, kCtrChainTicket = 11,
        kCtrCount = 12,
        kHostM = kCtrCount, kHostWords };
 // kCtrError: 1 a ray of more than 2^24 steps (reproducible mode), 2 a voxel beyond +-2^20 on a walk, 3 a sweep's tile never
@@ -342,6 +438,7 @@ int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points,
                   int32_t freespace, const uint32_t* order, int64_t* n_updates);
 // the scan's counters (kCtr*) for the merged integrator's own kernels; makes the scratch object on demand
 int det_counters(vgx_tsdf_integrator I, unsigned long long** d_ctr);
+int det_next_chain(vgx_tsdf_integrator I, uint32_t tiles, TileChain* chain);
 // the merged integrator's rays (merged point / colour / flags / ray length per group, groups in key order)
 // applied voxel by voxel in group order
 int det_merged_commit(vgx_tsdf_integrator I, const float T[7], long long n, const float4* g_pg, const uint32_t* g_color,
