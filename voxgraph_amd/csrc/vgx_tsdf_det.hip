@@ -558,43 +558,88 @@ __global__ __launch_bounds__(256) void det_ray_kernel(long long n, int max_colli
 
 // ---- 3a. compaction of the updates (sorted order kept) + the set's state after the scan ---------
 // (the compaction offsets -- the exclusive prefix of `update` -- are taken inside this launch: TileChain; tiles of
-// 2048 sorted accesses, eight consecutive ones per thread.  *n_updates = how many accesses update their voxel.)
-__global__ __launch_bounds__(256) void det_finish_kernel(size_t N, const uint32_t* __restrict__ s_key,
+// 2048 sorted accesses, eight consecutive ones per thread; every batch of gathers is issued before the first one is
+// waited for, as in det_sweep_kernel: entries beyond N read element 0.  *n_updates = how many accesses update their
+// voxel.  FLAGS: the merged integrator's form of `update` -- the decision was taken when the ray was written out.)
+template <bool FLAGS>
+__global__ __launch_bounds__(256) void det_finish_kernel(uint32_t N, const uint32_t* __restrict__ s_key,
                                                         const uint32_t* __restrict__ s_idx,
                                                         const uint32_t* __restrict__ s_h,
-                                                        const uint32_t* __restrict__ last, HappenedOp happened,
-                                                        UpdateOp update, TileChain chain, uint32_t* __restrict__ n_updates,
-                                                        uint32_t* __restrict__ c_idx, uint32_t* __restrict__ c_key,
+                                                        const uint32_t* __restrict__ last, UpdateOp update, TileChain chain,
+                                                        uint32_t* __restrict__ n_updates, uint32_t* __restrict__ c_idx,
+                                                        uint32_t* __restrict__ c_key,
                                                         unsigned long long* __restrict__ observed_set,
                                                         unsigned long long observed_offset) {
   __shared__ uint32_t sh_word, sh4[4];
   const uint32_t tile = chain_tile(chain, &sh_word);
-  const size_t base = (size_t)tile * kSweepTile + (size_t)threadIdx.x * kSweepIpt;
-  uint32_t u[kSweepIpt], mine = 0;
+  const uint32_t base = tile * kSweepTile + (uint32_t)threadIdx.x * kSweepIpt;
+  uint32_t idx[kSweepIpt], u[kSweepIpt], hp[kSweepIpt], mine = 0;
+  load8(s_idx, base, N, idx);
+  if (FLAGS) {
+    uint8_t f[kSweepIpt];
 #pragma unroll
-  for (int e = 0; e < kSweepIpt; ++e) {
-    u[e] = base + e < N ? update((uint32_t)(base + e)) : 0u;
-    mine += u[e];
+    for (int e = 0; e < kSweepIpt; ++e) f[e] = update.flags[idx[e]];
+#pragma unroll
+    for (int e = 0; e < kSweepIpt; ++e) {
+      u[e] = (base + e < N && f[e]) ? 1u : 0u;
+      hp[e] = 0u;  // (no approximate sets: unused)
+    }
+  } else {
+    uint32_t r[kSweepIpt], k[kSweepIpt];
+    int32_t stop[kSweepIpt];
+    uint8_t broke[kSweepIpt];
+    load8(update.s_r, base, N, r);
+    load8(update.s_k, base, N, k);
+#pragma unroll
+    for (int e = 0; e < kSweepIpt; ++e) {
+      stop[e] = update.T[r[e]];
+      broke[e] = update.broke[r[e]];
+    }
+#pragma unroll
+    for (int e = 0; e < kSweepIpt; ++e) {
+      const bool in = base + e < N;
+      const int32_t step = (int32_t)k[e];
+      // the exchange happened and did not stop the ray (UpdateOp); it happened at all (HappenedOp)
+      u[e] = (in && (step < stop[e] || (step == stop[e] && !broke[e]))) ? 1u : 0u;
+      hp[e] = (in && step <= stop[e]) ? base + e + 1u : 0u;
+    }
   }
+#pragma unroll
+  for (int e = 0; e < kSweepIpt; ++e) mine += u[e];
   uint32_t in_tile = 0;
   const uint32_t before = block_exclusive_sum(mine, sh4, in_tile);
   uint32_t q = chain_exclusive_sum(chain, tile, in_tile, &sh_word) + before;
+  uint32_t key[kSweepIpt];
+  load8(s_key, base, N, key);
+  // the slot keeps what the last exchange of its run wrote: at the end of every run, the run's last happened access
+  uint32_t li[kSweepIpt], li_key[kSweepIpt], li_h[kSweepIpt];
+  if (observed_set) {
+    uint32_t before_p[kSweepIpt];
+    load8(last, base, N, before_p);  // (written at run ends by the last sweep; elsewhere unused)
+#pragma unroll
+    for (int e = 0; e < kSweepIpt; ++e) li[e] = hp[e] ? hp[e] : before_p[e];
+#pragma unroll
+    for (int e = 0; e < kSweepIpt; ++e) {
+      const uint32_t at = li[e] ? li[e] - 1u : 0u;
+      li_key[e] = s_key[at < N ? at : 0u];
+      li_h[e] = s_h[at < N ? at : 0u];
+    }
+  }
+  const uint32_t after = base + kSweepIpt < N ? s_key[base + kSweepIpt] : 0xffffffffu;
 #pragma unroll
   for (int e = 0; e < kSweepIpt; ++e) {
-    const size_t p = base + e;
+    const uint32_t p = base + e;
     if (p >= N) break;
-    const uint32_t key = s_key[p];
     if (u[e]) {
-      c_idx[q] = s_idx[p];
-      c_key[q] = key;
+      c_idx[q] = idx[e];
+      c_key[q] = key[e];
       ++q;
     }
     if (p == N - 1) *n_updates = q;
     if (!observed_set) continue;  // merged integrator: no approximate sets
-    if (p == N - 1 || s_key[p + 1] != key) {  // the slot keeps what the last exchange of its run wrote
-      const uint32_t li = happened((uint32_t)p) ? (uint32_t)p + 1u : last[p];
-      if (li > 0 && s_key[li - 1] == key) observed_set[key] = (unsigned long long)s_h[li - 1] + observed_offset;
-    }
+    const uint32_t next_key = e + 1 < kSweepIpt ? key[e + 1] : after;
+    if ((p == N - 1 || next_key != key[e]) && li[e] > 0 && li_key[e] == key[e])
+      observed_set[key[e]] = (unsigned long long)li_h[e] + observed_offset;
   }
 }
 
@@ -1244,10 +1289,16 @@ static int det_commit(vgx_tsdf_integrator I, DetScratch* S, const float T[7], si
     const uint32_t finish_tiles = (uint32_t)((N + kSweepTile - 1) / kSweepTile);
     TileChain chain;
     DET_TRY(next_chain(ctx, S, finish_tiles, &chain));
-    hipLaunchKernelGGL(det_finish_kernel, dim3(finish_tiles), dim3(256), 0, st, N, S->s_key.as<uint32_t>(),
-                       S->s_idx.as<uint32_t>(), S->s_h.as<uint32_t>(), S->last.as<uint32_t>(), happened, *update, chain, m_word,
-                       S->c_idx.as<uint32_t>(), S->c_key.as<uint32_t>(), update_set ? I->dev.observed_set : nullptr,
-                       I->dev.observed_offset);
+    if (update->flags)
+      hipLaunchKernelGGL(det_finish_kernel<true>, dim3(finish_tiles), dim3(256), 0, st, (uint32_t)N, S->s_key.as<uint32_t>(),
+                         S->s_idx.as<uint32_t>(), S->s_h.as<uint32_t>(), S->last.as<uint32_t>(), *update, chain, m_word,
+                         S->c_idx.as<uint32_t>(), S->c_key.as<uint32_t>(), update_set ? I->dev.observed_set : nullptr,
+                         I->dev.observed_offset);
+    else
+      hipLaunchKernelGGL(det_finish_kernel<false>, dim3(finish_tiles), dim3(256), 0, st, (uint32_t)N, S->s_key.as<uint32_t>(),
+                         S->s_idx.as<uint32_t>(), S->s_h.as<uint32_t>(), S->last.as<uint32_t>(), *update, chain, m_word,
+                         S->c_idx.as<uint32_t>(), S->c_key.as<uint32_t>(), update_set ? I->dev.observed_set : nullptr,
+                         I->dev.observed_offset);
     VGX_HIP(ctx, hipGetLastError());
     M_dev = m_word;
     c_idx = S->c_idx.as<uint32_t>();
