@@ -511,6 +511,10 @@ __global__ __launch_bounds__(256) void merged_merge_kernel(vgx_tsdf_config c, fl
   }
   unsigned long long my_steps = 0;  // ray steps of the groups this thread finished (lane 0 of a group)
   const unsigned int G = counters[0], n_valid = counters[3];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // (for the host: how many lanes a group deserves in the next scan)
+    scan_ctr[kCtrGroups] = G;
+    scan_ctr[kCtrGroupPoints] = n_valid;
+  }
   for (unsigned int g = blockIdx.x * (blockDim.x / L) + threadIdx.x / L; g < G; g += n_sub) {
     const unsigned int i0 = group_start[g], i1 = g + 1 < G ? group_start[g + 1] : n_valid;
     const bool clearing_ray = (keys[i0] >> 63) != 0;
@@ -1368,12 +1372,18 @@ static int merged_integrate_locked(vgx_tsdf_integrator I, const float T[7], cons
       VGX_HIP(ctx, hipGetLastError());
     }
     // one L-lane sub-group per group, grid-stride (the number of groups stays on the device)
-    constexpr int kLanes = 16;
-    const unsigned work_groups = (unsigned)std::min<long long>(((long long)n * kLanes + 255) / 256, (long long)ctx->cu_count * 16);
-    hipLaunchKernelGGL(merged_merge_kernel<kLanes>, dim3(work_groups), block, 0, ctx->stream, c, I->layer->dev.voxel_size_inv,
-                       T[0], T[1], T[2], T[3], T[4], T[5], T[6], (const float*)d_points, (const uint32_t*)d_rgba, keys_sorted,
-                       idx_sorted, I->d_mstart, I->d_mcounters, I->d_gpg, I->d_gcolor, I->d_gflags, I->d_gcount,
-                       I->d_mcounters + 5, scan_ctr);
+    // `lanes` per group (the merge itself is the same sequence of operations whatever the width: det_merged_commit
+    // chooses it for the next scan from this scan's points per group)
+    const int lanes = I->merged_lanes;
+    const unsigned work_groups = (unsigned)std::min<long long>(((long long)n * lanes + 255) / 256, (long long)ctx->cu_count * 16);
+#define VGX_LAUNCH_MERGE(L)                                                                                                        \
+    hipLaunchKernelGGL(merged_merge_kernel<L>, dim3(work_groups), block, 0, ctx->stream, c, I->layer->dev.voxel_size_inv, T[0],    \
+                       T[1], T[2], T[3], T[4], T[5], T[6], (const float*)d_points, (const uint32_t*)d_rgba, keys_sorted, idx_sorted, \
+                       I->d_mstart, I->d_mcounters, I->d_gpg, I->d_gcolor, I->d_gflags, I->d_gcount, I->d_mcounters + 5, scan_ctr)
+    if (lanes == 4) VGX_LAUNCH_MERGE(4);
+    else if (lanes == 8) VGX_LAUNCH_MERGE(8);
+    else VGX_LAUNCH_MERGE(16);
+#undef VGX_LAUNCH_MERGE
     VGX_HIP(ctx, hipGetLastError());
     // integrateRays.  Every ray crosses the sensor's own neighbourhood, so those voxels take one update
     // per group: thousands of rays contending for one compare-and-swap (measured: 30 ms per RGB-D

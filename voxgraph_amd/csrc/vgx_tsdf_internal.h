@@ -311,10 +311,12 @@ __device__ __forceinline__ uint32_t block_exclusive_sum(uint32_t v, uint32_t* sh
 // kCtrTotal: the accesses det_count_kernel counted (64 bits: an overflowing scan is seen, not wrapped); kCtrM /
 // kCtrBlocks: the updates and the layer's block count as det_blocks_kernel found them (so that one copy of the
 // counters is the whole read-back of a commit).  kCtrChainTicket: TileChain's ticket for the scan's prefix-sum
-// kernels (never reset inside a scan: the host passes what it has launched so far as the base).
+// kernels (never reset inside a scan: the host passes what it has launched so far as the base).  kCtrGroups /
+// kCtrGroupPoints: the merged integrator's groups and the valid points in them (how many lanes the NEXT scan's
+// merge kernel gives a group: vgx_tsdf_integrator_s::merged_lanes).
 enum { kCtrChanged = 0, kCtrNew = 1, kCtrError = 2, kCtrDropped = 3, kCtrLong = 4, kCtrOverflow = 5, kCtrArrive = 6, kCtrTicket = 7,
-       kCtrTotal = 8, kCtrM = 9, kCtrBlocks = 10, kCtrChainTicket = 11,
-       kCtrCount = 12,
+       kCtrTotal = 8, kCtrM = 9, kCtrBlocks = 10, kCtrChainTicket = 11, kCtrGroups = 12, kCtrGroupPoints = 13,
+       kCtrCount = 14,
        kHostM = kCtrCount, kHostWords };
 // kCtrError: 1 a ray of more than 2^24 steps (reproducible mode), 2 a voxel beyond +-2^20 on a walk, 3 a sweep's tile never
 // reported, and from the merged integrator's kernels:
@@ -418,6 +420,9 @@ struct vgx_tsdf_integrator_s {
   // vgx_tsdf_integrator_set_speculation (bench header) lets the tests drive the extension logic on small scans.
   uint32_t det_cap = 32;
   uint32_t det_cap_threshold = 4u << 20;
+  // merged integrator: lanes per group in merged_merge_kernel (4 / 8 / 16), chosen from the previous scan's points per
+  // group -- a LiDAR scan's groups hold one or two points, a depth image's five to ten.  Results do not depend on it.
+  int merged_lanes = 4;
   // integration_order "sorted": squared-norm keys / point indices (double-buffered) + radix-sort workspace
   uint32_t* d_okey[2] = {nullptr, nullptr};
   uint32_t* d_oidx[2] = {nullptr, nullptr};
