@@ -1,7 +1,9 @@
 #!/bin/bash
 # A/B of the sort-based TSDF paths' launch diet (round 4, second half): un-profiled ms per scan of
 # profiles/merged_only.py (10-scan sessions of bench.py's two sensor shapes), same box, back to back:
-#   BASE=<lib>            a library built from the commit before (make SUFFIX=_base in a checkout of it), if present
+#   BASE_DIR=<checkout>   a built checkout of the commit before the diet (git worktree add build/base_wt 40355f6;
+#                         python -c "import __graft_entry__ as g; g.build()" in it), default build/base_wt if present:
+#                         its own profiles/merged_only.py, library and bindings
 #   VGX_DET_SWEEP=scan    the sweep as rocprim scan + det_seen_kernel (4 launches) instead of det_sweep_kernel (2)
 #   VGX_TSDF_SORT=default rocprim's default radix_sort configuration instead of FewPassSort
 #   VGX_DET_PHASES=1      host-side time between the points of a scan where the host waits
@@ -18,11 +20,15 @@ run() {  # label, env...
     env "$@" python $REPO/profiles/merged_only.py 2>&1 | grep "ms per scan" >> $OUT/tsdf_ab.txt
   done
 }
-BASE=${BASE:-$REPO/voxgraph_amd/lib/libvoxgraph_amd_base.so}
-if [ -f $BASE ]; then
-  run "reproducible: library of the commit before"   VGX_LIB=$BASE INTEGRATOR=fast DET=1
-  run "merged: library of the commit before"         VGX_LIB=$BASE INTEGRATOR=merged DET=0
-  run "merged, reproducible: library of the commit before" VGX_LIB=$BASE INTEGRATOR=merged DET=1
+BASE_DIR=${BASE_DIR:-$REPO/build/base_wt}
+if [ -f $BASE_DIR/voxgraph_amd/lib/libvoxgraph_amd.so ]; then
+  for cfg in "fast 1 reproducible" "merged 0 merged" "merged 1 merged+reproducible"; do
+    set -- $cfg
+    for rep in 1 2; do
+      echo "--- $3: the commit before the diet (run $rep)" >> $OUT/tsdf_ab.txt
+      (cd $BASE_DIR && INTEGRATOR=$1 DET=$2 python profiles/merged_only.py 2>&1 | grep "ms per scan") >> $OUT/tsdf_ab.txt
+    done
+  done
 fi
 run "reproducible: this tree"                 INTEGRATOR=fast DET=1
 run "reproducible: scan sweeps"               INTEGRATOR=fast DET=1 VGX_DET_SWEEP=scan
