@@ -41,7 +41,7 @@ for c in rd write; do
       > $OUT/prof_${c}_plain_bench.json 2> $OUT/prof_${c}_plain.err
 done
 timeout 240 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES \
-    --kernel-trace -f csv --kernel-include-regex "reg_eval_points_kernel|reg_eval_reduce|tsdf_integrate|det_apply|det_seen" \
+    --kernel-trace -f csv --kernel-include-regex "reg_eval_points_kernel|reg_eval_reduce|tsdf_integrate|det_apply|det_sweep|det_ray" \
     -d $OUT/prof_sq -o sq -- python $REPO/bench.py --steps 2 --inner 1 --warmup 1 --no-cpu-baseline --no-solve --no-shipped --no-config5 --no-config2 --no-multi-ctx --no-parity \
     > /dev/null 2> $OUT/prof_sq.err
 # un-profiled, the driver's EXACT command from the repo root (what BENCH_rNN.json will hold): stdout = the one
