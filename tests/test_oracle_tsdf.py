@@ -206,3 +206,25 @@ def test_sorted_integration_order_is_ascending_squared_norm_with_index_ties():
         got = digest(2, pts, col, merged)
         assert got == digest(0, pts[order], col[order], merged), merged
         assert got[0] > 10000 and got != digest(1, pts, col, merged), merged
+
+
+def test_far_returns_carve_like_any_return_beyond_the_range():
+    """getGridIndexFromPoint's cast is DEFINED here where the reference leaves it undefined (grid_index: NaN -> 0,
+    saturating at 32 bits): a return 3 km, 276 km (beyond the merged integrator's 21-bit voxel keys), 10^9 m
+    (beyond 32-bit indices) or 10^18 m away along +x is a clearing ray clipped to max_ray_length_m -- the
+    same voxels, distances and weights whichever it was, for both integrators; NaN points pass isPointValid as in
+    the reference and the scan goes on."""
+    vs = 0.1
+    cfg = orc.tsdf_config(default_truncation_distance=0.2, max_ray_length_m=1.0, use_const_weight=1, use_weight_dropoff=0)
+    T = IDENT.copy(); T[4:] = (0.05, 0.05, 0.05)
+    for merged in (False, True):
+        layers = []
+        for far in (3.0e3, 2.76e5, 1.0e9, 1.0e18):           # (beyond ~1.8e19 m the f32 norm itself overflows)
+            layer = orc.TsdfLayer(vs)
+            integ = orc.FastTsdfIntegrator(cfg, layer)
+            pts = np.array([[far, 0, 0], [np.nan, 1.0, 1.0], [0.4, 0.3, 0.0]], F)
+            n = integ.integratePointCloudMerged(T, pts) if merged else integ.integratePointCloud(T, pts)
+            assert n > 10
+            layers.append(_layer_dict(layer))
+        assert all(l == layers[0] for l in layers[1:]), merged
+        assert max(k[0] for k in layers[0] if k[1] == 0 and k[2] == 0) == 10     # origin 0.05 + 1.0 m along +x
