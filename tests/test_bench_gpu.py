@@ -25,8 +25,9 @@ def _run(cmd, tmp, env=None, timeout=900):
     detail = os.path.join(tmp, "detail.json")
     r = subprocess.run(cmd + ["--detail", detail], capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
-    # (the gloo backend of the dry runs announces itself on stdout; RCCL's banner goes to stderr)
-    lines = [l for l in r.stdout.splitlines() if l.strip() and not l.startswith("[Gloo]")]
+    # (the gloo backend of the dry runs announces itself on stdout, from C++, once per rank -- two ranks' announcements
+    # can interleave into fragments; RCCL's banner goes to stderr)
+    lines = [l for l in r.stdout.splitlines() if l.strip() and "[Gloo]" not in l and "peer ranks" not in l]
     assert len(lines) == 1 and lines[0].startswith("{") and r.stdout.rstrip().endswith(lines[0]), \
         [l[:200] for l in lines[:-1]] + [r.stdout[-300:]]
     assert len(lines[0]) < LINE_LIMIT, len(lines[0])
