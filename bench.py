@@ -82,6 +82,21 @@ def build_graph(args):
 
 
 
+# stdout belongs to the ONE line the driver parses.  Libraries write there too -- RCCL prints a five-line version banner
+# on stdout when its communicator is created (seen under torch.distributed.run on the GPU box), gloo announces every
+# rank -- so file descriptor 1 is pointed at stderr for the whole run and the line goes to a saved copy of the real
+# stdout at the end.
+_REAL_STDOUT = None
+
+
+def claim_stdout():
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
 def emit(full, detail_path, full_line=False):
     """Everything measured -> `detail_path` (and stderr); ONE compact line -> stdout (harness/bench_line.py:
     contract keys first, numbers only, below bench_line.LINE_LIMIT bytes so that the driver can parse it)."""
@@ -97,8 +112,13 @@ def emit(full, detail_path, full_line=False):
     print(text, file=sys.stderr)
     sys.stderr.flush()
     _, line = bench_line.compact(full, where)
-    print(json.dumps(full) if full_line else line)
+    out = (json.dumps(full) if full_line else line) + "\n"
     sys.stdout.flush()
+    if _REAL_STDOUT is not None:
+        os.write(_REAL_STDOUT, out.encode())
+    else:
+        sys.stdout.write(out)
+        sys.stdout.flush()
 
 
 def main():
@@ -163,6 +183,7 @@ def main():
                     help="PMC calibration: first launch evaluates poses 10 km apart, so every "
                          "evaluation reads exactly 20 B and writes exactly 36 B (profiles/README.md)")
     args = ap.parse_args()
+    claim_stdout()           # (after --help had its chance to print)
     bench_common.PLACEMENT = args.placement
 
     lib_path = os.path.join(ROOT, "voxgraph_amd", "lib", "libvoxgraph_amd.so")

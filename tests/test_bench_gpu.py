@@ -25,11 +25,10 @@ def _run(cmd, tmp, env=None, timeout=900):
     detail = os.path.join(tmp, "detail.json")
     r = subprocess.run(cmd + ["--detail", detail], capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
-    # (the gloo backend of the dry runs announces itself on stdout, from C++, once per rank -- two ranks' announcements
-    # can interleave into fragments; RCCL's banner goes to stderr)
-    lines = [l for l in r.stdout.splitlines() if l.strip() and "[Gloo]" not in l and "peer ranks" not in l]
-    assert len(lines) == 1 and lines[0].startswith("{") and r.stdout.rstrip().endswith(lines[0]), \
-        [l[:200] for l in lines[:-1]] + [r.stdout[-300:]]
+    # (libraries print on stdout too -- RCCL's version banner, gloo's rank announcements: bench.py points fd 1 at stderr
+    # for the run and writes its line to the real stdout, so NOTHING else may arrive here, under any launcher)
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), [l[:200] for l in lines[:-1]] + [r.stdout[-300:]]
     assert len(lines[0]) < LINE_LIMIT, len(lines[0])
     line = json.loads(lines[0])
     full = json.load(open(detail))
@@ -166,6 +165,25 @@ def test_two_rank_path_dry_run_on_one_gpu(single, tmp_path):
     for k in ("stage1_without_registration", "stage2_all_constraints"):
         assert d["config5"][k] == single["config5"][k], k
     assert d["config5"]["position_rmse_m_aligned_after"] == single["config5"]["position_rmse_m_aligned_after"]
+
+
+def test_one_rank_under_torchrun_goes_through_rccl(single, tmp_path):
+    """The driver's launch form for N > 1 -- `python -m torch.distributed.run ... bench.py --gpus N` -- with N = 1: the
+    RCCL group is created (backend "nccl"), the barriers and the int64 all-reduce of the per-constraint blocks run
+    through it (a communicator of one rank: what a one-GPU box can show), and the result is the plain run's bit for
+    bit."""
+    env = {k: v for k, v in os.environ.items() if k != "VGX_BENCH_DRYRUN"}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "1",
+           "--cpu-seconds", "1"] + SMALL
+    d, line, _ = _run(cmd, str(tmp_path), env=env)
+    assert line["n_gpus"] == 1 and line["rccl_ranks"] == 1
+    assert "DRY RUN" not in d["data"]
+    assert d["fused"]["fused_sha256"] == single["fused"]["fused_sha256"]
+    assert d["fused"]["cost"] == single["fused"]["cost"]
+    assert d["fused"]["allreduce_bytes"] == 45 * 8 * d["config"]["constraints"]
+    for k in ("iterations", "evaluations", "termination", "final_cost", "position_rmse_m_after"):
+        assert d["solve"][k] == single["solve"][k], k
 
 
 def test_inprocess_flag_dry_run_on_one_gpu(single, tmp_path):
