@@ -1272,7 +1272,7 @@ int det_next_chain(vgx_tsdf_integrator I, uint32_t tiles, TileChain* chain) {
 // ---- 3. the updates that happen, in sorted order -> compaction, new blocks, ordered application ----
 // (shared by both integrators: `update` says which of the N sorted accesses update their voxel; rays are
 // indexed by acc_ray, their point / weight / colour live in ray_pg / ray_color)
-static int det_commit(vgx_tsdf_integrator I, DetScratch* S, const float T[7], size_t N, const HappenedOp& happened,
+static int det_commit(vgx_tsdf_integrator I, DetScratch* S, const float T[7], size_t N,
                       const UpdateOp* update, bool update_set, bool ordered_blocks, const float4* ray_pg,
                       const uint32_t* ray_color, int64_t* n_updates, PhaseClock* pc = nullptr) {
   vgx_ctx ctx = I->ctx;
@@ -1630,7 +1630,7 @@ int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points,
       return set_error(ctx, VGX_ERR_HIP, "TSDF reproducible mode: a sweep's tile never reported (internal error)");
     return set_error(ctx, VGX_ERR_UNSUPPORTED, "TSDF reproducible mode: a voxel index beyond +-2^20 voxels of the layer origin");
   }
-  return det_commit(I, S, T, N, happened, &update, true, true, S->ray_pg.as<float4>(), S->ray_color.as<uint32_t>(), n_updates,
+  return det_commit(I, S, T, N, &update, true, true, S->ray_pg.as<float4>(), S->ray_color.as<uint32_t>(), n_updates,
                     &pc);
 }
 
@@ -1707,11 +1707,10 @@ int det_merged_commit(vgx_tsdf_integrator I, const float T[7], long long n, cons
         return set_error(ctx, VGX_ERR_UNSUPPORTED, "TSDF merged integrator: a voxel index beyond +-2^20 voxels of the layer origin");
     }
   }
-  const HappenedOp happened{nullptr, nullptr, nullptr};  // unused: no approximate sets
   // only anti-grazing removes updates; blocks in order of first update only in the reproducible mode
   // (otherwise on demand: the VALUES are order-exact either way, only the pool order is arrival order)
   const UpdateOp update{nullptr, nullptr, nullptr, nullptr, S->s_idx.as<uint32_t>(), S->seen.as<uint8_t>(), (uint32_t)N};
-  return det_commit(I, S, T, N, happened, c.enable_anti_grazing ? &update : nullptr, false, c.deterministic != 0, g_pg,
+  return det_commit(I, S, T, N, c.enable_anti_grazing ? &update : nullptr, false, c.deterministic != 0, g_pg,
                     g_color, n_updates);
 }
 
