@@ -95,6 +95,7 @@ def run(capi, ctx, torch, n_submaps=30, scans_per_submap=20, n_az=1024, n_el=64,
     t_integrate = t_finish = 0.0
     n_updates_total = 0
     stats = []
+    integ, retired = None, []
     for m in range(n_submaps):
         first = m * scans_per_submap
         P = sensor_poses[first].copy()
@@ -105,7 +106,12 @@ def run(capi, ctx, torch, n_submaps=30, scans_per_submap=20, n_az=1024, n_el=64,
         layer = capi.TsdfLayer(ctx, voxel_size, 16)
         for j in (first, first + scans_per_submap - 1):
             layer.reserve(_inv_compose(P, sensor_poses[j])[4:7], 16.0 + 0.6 + 2 * voxel_size)
-        integ = capi.FastTsdfIntegrator(ctx, cfg, layer)
+        # ONE integrator for the session, pointed at every new submap's layer (pointcloud_integrator.cpp:66-77:
+        # `tsdf_integrator_->setLayer(...)`): its scratch buffers and approximate sets live as long as the mapper
+        if integ is None:
+            integ = capi.FastTsdfIntegrator(ctx, cfg, layer)
+        else:
+            integ.setLayer(layer)
         for j in range(first, first + scans_per_submap):
             capi.synth_city_scan(ctx, sensor_poses[j], n_az, n_el, el_span, 40.0, 2, pts.data_ptr())
             ctx.synchronize()
@@ -122,9 +128,12 @@ def run(capi, ctx, torch, n_submaps=30, scans_per_submap=20, n_az=1024, n_el=64,
         ctx.synchronize()
         t_finish += time.perf_counter() - t0
         stats.append((layer.stats()[0], nv, ni, layer.stats()[1]))
-        integ.destroy()
-        layer.destroy()
+        retired.append(layer)                                 # (the integrator still points at it until the next setLayer)
         submaps.append(sm)
+    if integ is not None:
+        integ.destroy()
+    for layer in retired:
+        layer.destroy()
     true_poses = np.array(true_poses)
 
     def compose(pose, delta):

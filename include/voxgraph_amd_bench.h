@@ -50,7 +50,7 @@ VGX_API int vgx_tsdf_integrator_walk_stats(vgx_tsdf_integrator integrator, int64
 
 /* Reproducible TSDF mode, bounded speculation (csrc/vgx_tsdf_det.hip): a scan whose rays' complete walks are more
  * than `threshold` voxel steps is written out `depth` steps per ray at first; rays that ran on are extended in a
- * further attempt.  Defaults 32 and 4 Mi.  The integrated layer does NOT depend on either value -- the tests use
+ * further attempt.  Defaults 32 and 8 Mi.  The integrated layer does NOT depend on either value -- the tests use
  * small ones so that small scans exercise the extension logic (tests/test_tsdf_deterministic_gpu.py). */
 VGX_API int vgx_tsdf_integrator_set_speculation(vgx_tsdf_integrator integrator, int32_t depth, int64_t threshold);
 

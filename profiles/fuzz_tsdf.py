@@ -42,7 +42,7 @@ def main():
                   start_voxel_subsampling_factor=float(rng.choice([1.0, 2.0, 4.0])),
                   enable_anti_grazing=int(rng.integers(0, 2)))
         order = int(rng.integers(0, 2))          # integration_order_mode: 0 "mixed", 1 "sorted" (the oracle counts 1 / 2)
-        spec = (int(rng.choice([1, 2, 3, 5, 9, 32])), int(rng.choice([0, 0, 500, 4 << 20])))
+        spec = (int(rng.choice([1, 2, 3, 5, 9, 32])), int(rng.choice([0, 0, 500, 8 << 20])))
         same_size = bool(rng.integers(0, 2))
         for kind in ("fast", "merged", "merged racing"):
             det = 0 if kind == "merged racing" else 1

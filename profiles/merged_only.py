@@ -48,7 +48,7 @@ def main():
         layer = capi.TsdfLayer(ctx, vs, 16)
         integ = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(deterministic=det, **kw), layer)
         if os.environ.get("SPEC_DEPTH"):   # experiment: the reproducible mode's speculation depth (default 32)
-            integ.set_speculation(int(os.environ["SPEC_DEPTH"]), int(os.environ.get("SPEC_THRESHOLD", str(4 << 20))))
+            integ.set_speculation(int(os.environ["SPEC_DEPTH"]), int(os.environ.get("SPEC_THRESHOLD", str(8 << 20))))
         n = dev[0].shape[0]
         call = integ.integrate_device if fast else integ.integrate_merged_device
         call(poses[0], dev[0].data_ptr(), None, n)

@@ -215,7 +215,7 @@ def test_randomised_configurations_multi_ray_scans(capi, ctx, order):
             o.destroy()
 
 
-@pytest.mark.parametrize("depth,threshold", [(1, 0), (2, 0), (3, 0), (6, 0), (12, 0), (32, 0), (4, 20_000), (32, 4 << 20)])
+@pytest.mark.parametrize("depth,threshold", [(1, 0), (2, 0), (3, 0), (6, 0), (12, 0), (32, 0), (4, 20_000), (32, 8 << 20)])
 def test_the_layer_does_not_depend_on_how_deep_rays_are_speculated(capi, ctx, depth, threshold):
     """Bounded speculation (det_count_kernel / det_extend_kernel): rays written out `depth` steps deep, extended where
     they ran on; the marks of one scan kept for the next scan of as many points (scans 0-2 here; scan 3 has another

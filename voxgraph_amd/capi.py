@@ -808,7 +808,7 @@ class FastTsdfIntegrator:
             int(freespace_points), C.byref(out) if count else None))
         return out.value
 
-    def set_speculation(self, depth=32, threshold=4 << 20):
+    def set_speculation(self, depth=32, threshold=8 << 20):
         """test tooling (reproducible mode): write rays out `depth` steps deep at first when a scan's complete
         walks exceed `threshold` steps; the layer does not depend on either"""
         self.ctx.check(self.ctx.lib.vgx_tsdf_integrator_set_speculation(self.h, depth, threshold))

@@ -1456,7 +1456,7 @@ int vgx_tsdf_integrate_device(vgx_tsdf_integrator I, const float T[7], const voi
 
 // test tooling (include/voxgraph_amd_bench.h): the reproducible mode's bounded speculation.  A scan whose complete
 // walks exceed `threshold` steps is written out `depth` steps per ray at first and extended where a ray ran on;
-// defaults 32 and 4 Mi.  Results do not depend on either (vgx_tsdf_det.hip); small values make small test scans
+// defaults 32 and 8 Mi.  Results do not depend on either (vgx_tsdf_det.hip); small values make small test scans
 // go through the extension, the marks kept between scans and the warm second attempt.
 int vgx_tsdf_integrator_set_speculation(vgx_tsdf_integrator I, int32_t depth, int64_t threshold) {
   if (!I || depth < 1 || threshold < 0 || threshold >= (1ll << 32)) return VGX_ERR_INVALID;

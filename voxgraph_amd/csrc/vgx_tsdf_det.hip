@@ -1470,7 +1470,11 @@ int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points,
   // the rays that ran on kept from scan to scan (det_extend_kernel).
   bool capped = start_capped;  // this attempt cut rays short: whether one of them ran on has to be looked at afterwards
   bool may_cap = may_cap_at_all && !start_capped;
-  const uint32_t kCapThreshold = I->det_cap_threshold, cap = std::max<uint32_t>(I->det_cap, 1u);
+  // (experiment aids: VGX_DET_CAP / VGX_DET_CAP_THRESHOLD override the integrator's speculation depth / threshold)
+  static const long long cap_env = getenv("VGX_DET_CAP") ? atoll(getenv("VGX_DET_CAP")) : 0;
+  static const long long thr_env = getenv("VGX_DET_CAP_THRESHOLD") ? atoll(getenv("VGX_DET_CAP_THRESHOLD")) : -1;
+  const uint32_t kCapThreshold = thr_env >= 0 ? (uint32_t)std::min<long long>(thr_env, 0xffffffffll) : I->det_cap_threshold;
+  const uint32_t cap = std::max<uint32_t>(cap_env > 0 ? (uint32_t)cap_env : I->det_cap, 1u);
   static const int mark_life = getenv("VGX_DET_MARK_LIFE") ? std::max(1, std::min(200, atoi(getenv("VGX_DET_MARK_LIFE")))) : 2;  // (depth image, ms per scan: 1 -> 1.25, 2 -> 1.17, 4 -> 1.18, 8 -> 1.21)
   static const bool scan_sweeps = getenv("VGX_DET_SWEEP") && !strcmp(getenv("VGX_DET_SWEEP"), "scan");  // A/B aid
   size_t N = 0;

@@ -419,7 +419,8 @@ struct vgx_tsdf_integrator_s {
   // than det_cap_threshold steps is written out det_cap steps deep at first.  Nothing but time depends on either;
   // vgx_tsdf_integrator_set_speculation (bench header) lets the tests drive the extension logic on small scans.
   uint32_t det_cap = 32;
-  uint32_t det_cap_threshold = 4u << 20;
+  uint32_t det_cap_threshold = 8u << 20;  // (a city LiDAR scan's 5 M steps: 1.54 ms swept as they are, 2.0-2.1 ms cut to 32 and extended twice;
+                                          //  a depth image's 18 M: cut.  profiles/probes/pipeline_det.sh)
   // merged integrator: lanes per group in merged_merge_kernel (4 / 8 / 16), chosen from the previous scan's points per
   // group -- a LiDAR scan's groups hold one or two points, a depth image's five to ten.  Results do not depend on it.
   int merged_lanes = 4;
