@@ -523,16 +523,28 @@ __global__ __launch_bounds__(256) void det_ray_kernel(long long n, int max_colli
   int moved = 0;
   const uint32_t cnt = seq < n ? count[seq] : 0u;
   if (cnt != 0) {
-    const uint8_t* s = seen + off[seq];
+    // the ray's flags, four at a time: aligned words around its (byte-aligned) run, shifted into place -- a ray of a
+    // city scan has 80 of them, and a dependent byte load each made this kernel as long as the sweep kernel's third
+    const size_t at = off[seq];
+    const uint32_t* words = (const uint32_t*)seen + (at >> 2);  // (seen comes from hipMalloc: 256-byte aligned)
+    const int shift = (int)(at & 3u) * 8;
     int collisions = 0;
     int32_t t = (int32_t)cnt - 1;
     uint8_t b = 0;
-    for (uint32_t k = 0; k < cnt; ++k) {
-      if (s[k]) ++collisions; else collisions = 0;
-      if (collisions > max_collisions) {
-        t = (int32_t)k;
-        b = 1;
-        break;
+    uint32_t lo = words[0];
+    for (uint32_t k0 = 0; k0 < cnt && !b; k0 += 4) {
+      const uint32_t hi = words[(k0 >> 2) + 1];  // (at most 4 bytes past the ray's last flag: the buffer has slack)
+      uint32_t four = shift ? (lo >> shift) | (hi << (32 - shift)) : lo;
+      lo = hi;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (b || k0 + j >= cnt) break;
+        if (four & 0xffu) ++collisions; else collisions = 0;
+        if (collisions > max_collisions) {
+          t = (int32_t)(k0 + j);
+          b = 1;
+        }
+        four >>= 8;
       }
     }
     if (t != T[seq] || b != broke[seq]) {
@@ -1525,7 +1537,7 @@ int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points,
     DET_TRY(grow(ctx, S->s_k, N * 4));
     DET_TRY(grow(ctx, S->s_h, N * 4));
     DET_TRY(grow(ctx, S->last, (N + 1) * 4));
-    DET_TRY(grow(ctx, S->seen, N));
+    DET_TRY(grow(ctx, S->seen, N + 16));  // (+ 16: det_ray_kernel reads whole words around a ray's flags)
     DET_TRY(grow(ctx, S->c_idx, N * 4));
     DET_TRY(grow(ctx, S->c_key, N * 4));
     hipLaunchKernelGGL(det_walk_kernel, dim3(blocks_for(np)), dim3(256), 0, st, c, vsi, T[4], T[5], T[6], (long long)n,
