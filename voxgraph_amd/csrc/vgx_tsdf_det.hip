@@ -392,15 +392,21 @@ __global__ __launch_bounds__(256) void det_seen_kernel(size_t N, const uint32_t*
 // never wait for it).  The words are the whole exchange between workgroups (relaxed agent-scope 8-byte loads
 // and stores, tag and value in one word); the epoch is the sweep's number, so no word is ever cleared.
 // Also written, for det_finish_kernel: `last` at the end of every slot run.
-constexpr int kSweepIpt = 8;
+#ifndef VGX_SWEEP_IPT
+#define VGX_SWEEP_IPT 8  // (A/B builds: make SUFFIX=_ipt16 EXTRA=-DVGX_SWEEP_IPT=16)
+#endif
+constexpr int kSweepIpt = VGX_SWEEP_IPT;
+static_assert(kSweepIpt % 4 == 0, "whole 16-byte loads");
 constexpr uint32_t kSweepTile = 256u * kSweepIpt;
 constexpr unsigned long long kSweepEpochMax = (1ull << 30) - 1;
 
 __device__ __forceinline__ void load8(const uint32_t* __restrict__ a, uint32_t base, uint32_t N, uint32_t (&v)[kSweepIpt]) {
-  if (base + kSweepIpt <= N) {  // base is a multiple of 8: two aligned 16-byte loads
-    const uint4 lo = *(const uint4*)(a + base), hi = *(const uint4*)(a + base + 4);
-    v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
-    v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+  if (base + kSweepIpt <= N) {  // base is a multiple of kSweepIpt: aligned 16-byte loads
+#pragma unroll
+    for (int q = 0; q < kSweepIpt / 4; ++q) {
+      const uint4 w = *(const uint4*)(a + base + 4 * q);
+      v[4 * q] = w.x; v[4 * q + 1] = w.y; v[4 * q + 2] = w.z; v[4 * q + 3] = w.w;
+    }
   } else {
 #pragma unroll
     for (int e = 0; e < kSweepIpt; ++e) v[e] = base + e < N ? a[base + e] : 0u;
