@@ -15,6 +15,27 @@ def _room_points(dirs, origin):
     return (dirs * t.min(1)[:, None]).astype(np.float32)
 
 
+def profiled_launches():
+    """kernel launches per scan of the sort-based paths, from the committed rocprofv3 trace of the same sensor shapes
+    (profiles/r04b_tsdf_launches.txt, profiles/tsdf_launches.sh): {("fast" | "merged", "lidar" | "rgbd"): launches}"""
+    import os
+    import re
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r04b_tsdf_launches.txt")
+    out, key = {}, None
+    try:
+        for line in open(path):
+            m = re.match(r"=== (fast|merged) det=\d (lidar|rgbd)", line)
+            if m:
+                key = (m.group(1), m.group(2))
+            m = re.match(r"(\d+) launches, period", line)
+            if m and key:
+                out[key] = int(m.group(1))
+                key = None
+    except OSError:
+        pass
+    return out
+
+
 def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=8):
     """Second hot path (TSDF): whole scans resident in HBM, one integratePointCloud per
     scan into the active layer, HIP-event timed.  Two sensor shapes from BASELINE.json:
@@ -37,7 +58,9 @@ def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=8):
             use_weight_dropoff=1, use_sparsity_compensation_factor=1,
             sparsity_compensation_factor=20.0), (-3, -3, -2), (6, 6, 4)),
     }
+    launches = profiled_launches()
     for name, (dirs, vs, kw, bmin, bdim) in cases.items():
+        sensor = "rgbd" if name.startswith("rgbd") else "lidar"
         poses, clouds = [], []
         for k in range(scans):
             origin = np.array([-2.0 + 0.15 * k, 0.5 - 0.05 * k, 0.3 + 0.01 * k])
@@ -300,6 +323,9 @@ def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=8):
                                                            # read-back per scan (profiles/r04_tsdf_launches.txt); the HBM figure is kept for
                                                            # SURVEY 8d's pricing and is NOT what bounds it
                                                            "roofline": {"bound": "launch", "unit": "GB/s", "hbm_peak_GBs": HBM_PEAK_GBS,
+                                                        "launches_per_scan_from_profiles": launches.get(("merged", sensor)),
+                                                        "us_per_launch": (merged_ms * 1e3 / launches[("merged", sensor)]
+                                                                          if ("merged", sensor) in launches else None),
                                                         "bytes_per_launch": 16.0 * n_pts + 24.0 * merged_updates,
                                                         "hbm_achieved_GBs": (16.0 * n_pts + 24.0 * merged_updates) / merged_ms / 1e6,
                                                         "hbm_frac": (16.0 * n_pts + 24.0 * merged_updates) / merged_ms / 1e6 / HBM_PEAK_GBS,
@@ -312,6 +338,13 @@ def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=8):
                                                    "voxel by voxel in group order (no early-out: the voxels next to the sensor "
                                                    "take one update per group, a sequential f32 chain)"},
                      "reproducible_mode": {"ms_per_scan": det_ms, "Mpoints_per_s": n_pts / det_ms / 1e3,
+                                           # launch / latency bound like the merged integrator
+                                           "roofline": {"bound": "launch",
+                                                        "launches_per_scan_from_profiles": launches.get(("fast", sensor)),
+                                                        "us_per_launch": (det_ms * 1e3 / launches[("fast", sensor)]
+                                                                          if ("fast", sensor) in launches else None),
+                                                        "host_waits_per_scan": "2 (the count, the commit) + 1 per extra attempt; "
+                                                                               "the sweeps report through a pinned word"},
                                            "voxel_updates_per_scan": det_updates,
                                            "over_racing_kernel": det_ms / (ms / timed),
                                            "parity_vs_oracle": det_parity,
