@@ -227,3 +227,15 @@ def test_parity_gate_picks_culled_and_live_constraints():
                                 **{"fused_blocks_within_1e-6": False}, checker="x", rule="y"), None])
     assert m["checked"] == 15 and not m["exact"] and m["max_rel"] == 1e-3 and not m["fused_blocks_within_1e-6"]
     assert parity_gate.merge([None]) is None
+
+
+def test_profiled_launch_counts_come_from_the_committed_trace():
+    """bench.py's `tsdf.*.{reproducible_mode,merged_integrator}.roofline.launches_per_scan_from_profiles`: parsed from
+    profiles/r04b_tsdf_launches.txt (rocprofv3 kernel trace of one scan of each sort-based path, tsdf_launches.sh)"""
+    from harness import bench_tsdf
+    got = bench_tsdf.profiled_launches()
+    assert set(got) == {("fast", "lidar"), ("fast", "rgbd"), ("merged", "lidar"), ("merged", "rgbd")}
+    # the paths are launch bound: these are the numbers the round worked on (78 / 93 / 30 / 49 when it began)
+    assert got[("fast", "lidar")] <= 44 and got[("fast", "rgbd")] <= 55
+    assert got[("merged", "lidar")] <= 26 and got[("merged", "rgbd")] <= 38
+    assert all(v > 10 for v in got.values())
