@@ -97,6 +97,37 @@ def claim_stdout():
         os.dup2(2, 1)
 
 
+def multi_context_child(args, n_devices, timeout_s=420):
+    """`bench.py --gpus N --inprocess` (ONE process, N contexts, vgx_reg_multi_*) as a child process on the same graph;
+    returns its `multi_context` block (or what went wrong).  Called by rank 0 of a torchrun launch while the other
+    ranks wait at the barrier."""
+    import subprocess
+    import tempfile
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE",
+                        "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT",
+                        "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_USE_AGENT_STORE", "TORCH_NCCL_ASYNC_ERROR_HANDLING")}
+    with tempfile.TemporaryDirectory() as tmp:
+        detail = os.path.join(tmp, "inprocess.json")
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(n_devices), "--inprocess", "--no-cpu-baseline", "--no-tsdf",
+               "--no-solve", "--no-config5", "--no-config2", "--no-parity", "--no-full-overlap", "--no-shipped",
+               "--steps", str(max(min(args.steps, 5), 1)), "--warmup", "1", "--inner", str(args.inner),
+               "--grid", *map(str, args.grid), "--block-dims", *map(str, args.block_dims), "--block-min", *map(str, args.block_min),
+               "--voxel-size", str(args.voxel_size), "--truncation", str(args.truncation), "--esdf-max", str(args.esdf_max),
+               "--pose-sigma", str(args.pose_sigma), "--yaw-sigma", str(args.yaw_sigma), "--seed", str(args.seed),
+               "--placement", args.placement, "--detail", detail]
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            return {"error": f"the child process did not finish within {timeout_s} s", "child": True, "contexts": n_devices}
+        if r.returncode != 0 or not os.path.exists(detail):
+            return {"error": f"child process exit code {r.returncode}", "stderr_tail": r.stderr[-1500:], "child": True,
+                    "contexts": n_devices}
+        block = json.load(open(detail)).get("multi_context") or {"error": "the child wrote no multi_context block"}
+    block["child"] = True
+    return block
+
+
 def emit(full, detail_path, full_line=False):
     """Everything measured -> `detail_path` (and stderr); ONE compact line -> stdout (harness/bench_line.py:
     contract keys first, numbers only, below bench_line.LINE_LIMIT bytes so that the driver can parse it)."""
@@ -656,8 +687,14 @@ def main():
             else:
                 devices = [local_rank, local_rank]
             try:
-                multi_ctx = multi_context_bench(capi, ctx, torch, args, devices, submaps, true_poses, pairs, weights_bytes,
-                                                poses, cfg, batch if world == 1 else None, n_sub, n_con)
+                if world > 1:
+                    # Under torchrun the component runs in a CHILD process (this same script, --inprocess): peer access
+                    # and cross-device events over N real devices have never run on hardware, and a fault there must
+                    # cost this optional block, not the line the other ranks are waiting to contribute to.
+                    multi_ctx = multi_context_child(args, world)
+                else:
+                    multi_ctx = multi_context_bench(capi, ctx, torch, args, devices, submaps, true_poses, pairs, weights_bytes,
+                                                    poses, cfg, batch if world == 1 else None, n_sub, n_con)
             except Exception as e:       # an optional section must never cost the line (peer access, memory, ...)
                 multi_ctx = {"error": repr(e), "device_ids": devices}
             finally:

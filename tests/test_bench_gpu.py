@@ -159,6 +159,8 @@ def test_two_rank_path_dry_run_on_one_gpu(single, tmp_path):
     # the driver's N > 1 runs also drive the in-process multi-GPU component (rank 0, all N devices; here both
     # contexts on the one GPU): same fused buffer as the all-reduced one
     mc = d["multi_context"]
+    assert mc.get("child") is True, mc         # (under torchrun the component runs in a child process: a fault there -- N real
+    assert "error" not in mc, mc               #  devices have never run it -- must not cost the ranks' line)
     assert mc["contexts"] == 2 and mc["ms_per_evaluation"] > 0
     assert mc["cost"] == d["fused"]["cost"]
     # config 5 sharded over two ranks is the single-rank solve, bit for bit
