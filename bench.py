@@ -97,7 +97,7 @@ def claim_stdout():
         os.dup2(2, 1)
 
 
-def multi_context_child(args, n_devices, timeout_s=420):
+def multi_context_child(args, n_devices, timeout_s=240):
     """`bench.py --gpus N --inprocess` (ONE process, N contexts, vgx_reg_multi_*) as a child process on the same graph;
     returns its `multi_context` block (or what went wrong).  Called by rank 0 of a torchrun launch while the other
     ranks wait at the barrier."""
