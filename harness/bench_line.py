@@ -57,8 +57,18 @@ def compact(full, detail_path):
     cfg = d.get("config") or {}
     out["config"] = _pick(cfg, ("workload", "submaps", "constraints", "residuals_per_pass", "passes_per_step", "parallelism"))
     rf = d.get("roofline") or {}
-    out["roofline"] = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "hbm_frac", "contract_88B_frac",
+    out["roofline"] = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "hbm_frac",
+                                 "contract_88B_frac", "copy_ceiling_GBs", "fill_ceiling_GBs", "kernel_shaped_ceiling_GBs",
+                                 "frac_of_copy_ceiling", "traffic_frac_of_copy_ceiling", "frac_of_kernel_shaped_ceiling",
                                  "kernel", "kernel_ms", "units_per_launch", "bytes_per_launch", "with_correspondence_frac"))
+    bx = d.get("box") or {}
+    sy = (bx.get("before") or {}).get("sysfs") or {}
+    du = bx.get("during_timed_region") or {}
+    out["box"] = {"sclk_MHz_during": (du.get("sclk_MHz") or {}).get("median"),
+                  "mclk_MHz_during": (du.get("mclk_MHz") or {}).get("median"),
+                  "power_W_during": (du.get("power_W") or du.get("power_in_W") or {}).get("median"),
+                  "power_cap_W": sy.get("power_cap_W"), "compute_partition": sy.get("compute_partition"),
+                  "memory_partition": sy.get("memory_partition")}
     cb = d.get("cpu_baseline")
     if cb:
         c = _pick(cb, ("value", "unit", "cores", "kind", "value_4_threads"))

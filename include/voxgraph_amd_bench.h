@@ -43,6 +43,13 @@ VGX_API int vgx_synth_city_scan(vgx_ctx ctx, const double sensor_pose[4], int32_
 VGX_API int vgx_bench_atomic_roundtrip(vgx_ctx ctx, int64_t table_bytes, int32_t waves, int32_t chain,
                                        float* ns_per_step);
 
+/* Same-run memory ceiling for the REG rooflines (bench.py `roofline.copy_ceiling_GBs`): `launches` launches that stream
+ * read_bytes in (float4 loads from d_src) and write_bytes out (non-temporal float4 stores to d_dst) -- both DEVICE
+ * pointers, sizes multiples of 16; read_bytes == write_bytes is a float4 copy, read_bytes == 0 a fill.  Returns the
+ * average duration of one launch (HIP events on the context's stream). */
+VGX_API int vgx_bench_stream_ceiling(vgx_ctx ctx, const void* d_src, int64_t read_bytes, void* d_dst,
+                                     int64_t write_bytes, int32_t launches, float* ms_per_launch);
+
 /* What the rays of the last COUNTED racing scan did (vgx_tsdf_integrate[_device] with n_updates != NULL resets
  * the statistics before the scan): stats[0] = the longest chain of dependent approximate-set exchanges any ray
  * walked, stats[1] = exchanges of all rays together, stats[2] = voxel updates that also blended a colour. */

@@ -112,6 +112,7 @@ SIGNATURES = {
     "vgx_synth_city_scan": (C.c_int, [vp, f64p, C.c_int32, C.c_int32, C.c_float, C.c_float,
                                       C.c_uint32, vp]),
     "vgx_bench_atomic_roundtrip": (C.c_int, [vp, C.c_int64, C.c_int32, C.c_int32, f32p]),
+    "vgx_bench_stream_ceiling": (C.c_int, [vp, vp, C.c_int64, vp, C.c_int64, C.c_int32, f32p]),
     "vgx_tsdf_integrator_walk_stats": (C.c_int, [vp, i64p]),
     "vgx_tsdf_integrator_set_speculation": (C.c_int, [vp, C.c_int32, C.c_int64]),
     "vgx_reg_config_default": (None, [C.POINTER(RegConfig)]),
@@ -637,6 +638,14 @@ def atomic_roundtrip_ns(ctx, table_bytes=8 << 20, waves=1, chain=2000):
     """bench tooling (vgx_bench_atomic_roundtrip): ns per step of a chain of dependent device-scope exchanges"""
     out = C.c_float()
     ctx.check(ctx.lib.vgx_bench_atomic_roundtrip(ctx.h, table_bytes, waves, chain, C.byref(out)))
+    return out.value
+
+
+def stream_ceiling_ms(ctx, d_src, read_bytes, d_dst, write_bytes, launches=5):
+    """bench tooling (vgx_bench_stream_ceiling): ms per launch that streams read_bytes in and write_bytes out"""
+    out = C.c_float()
+    ctx.check(ctx.lib.vgx_bench_stream_ceiling(ctx.h, d_src, int(read_bytes) & ~15, d_dst, int(write_bytes) & ~15,
+                                               launches, C.byref(out)))
     return out.value
 
 

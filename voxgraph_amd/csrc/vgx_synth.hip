@@ -125,6 +125,43 @@ __global__ __launch_bounds__(256) void atomic_chain_kernel(unsigned long long* _
   if (acc == 0x123456789abcdefull) *sink = acc;  // keeps the chain alive
 }
 
+// vgx_bench_stream_ceiling: what this box's memory system sustains for a launch shaped like the headline kernel --
+// `read_bytes` streamed in as float4, `write_bytes` streamed out as non-temporal float4 (the rows are written once and
+// never re-read) -- measured in the same process, minutes before the timed region, so that a roofline fraction can be
+// read against the box it ran on and not only against the 8 TB/s of the data sheet.  One workgroup walks a contiguous
+// slice of both ranges; read_bytes == 0 is a pure fill, write_bytes == read_bytes a float4 copy.
+typedef float nt_float4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void stream_ceiling_kernel(const nt_float4* __restrict__ src, size_t n_read,
+                                                            nt_float4* __restrict__ dst, size_t n_write) {
+  const size_t nb = gridDim.x, b = blockIdx.x;
+  const size_t r0 = n_read * b / nb, r1 = n_read * (b + 1) / nb;
+  const size_t w0 = n_write * b / nb, w1 = n_write * (b + 1) / nb;
+  nt_float4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+  size_t r = r0 + threadIdx.x, w = w0 + threadIdx.x;
+  // reads and writes interleaved in the proportion of the two ranges
+  const size_t steps_r = (r1 - r0 + 255) / 256, steps_w = (w1 - w0 + 255) / 256;
+  const size_t steps = steps_r > steps_w ? steps_r : steps_w;
+  size_t er = 0, ew = 0;
+  for (size_t s = 0; s < steps; ++s) {
+    er += steps_r;
+    if (er >= steps) {
+      er -= steps;
+      if (r < r1) acc += __builtin_nontemporal_load(&src[r]);
+      r += 256;
+    }
+    ew += steps_w;
+    if (ew >= steps) {
+      ew -= steps;
+      if (w < w1) {
+        nt_float4 v = acc;
+        v.x += (float)s;
+        __builtin_nontemporal_store(v, &dst[w]);
+      }
+      w += 256;
+    }
+  }
+}
+
 }  // namespace vgx
 
 using namespace vgx;
@@ -161,6 +198,37 @@ extern "C" int vgx_bench_atomic_roundtrip(vgx_ctx ctx, int64_t table_bytes, int3
   if (rc != VGX_OK) return set_error(ctx, rc, "vgx_bench_atomic_roundtrip: HIP failure");
   // two launches of `chain` and 3 x `chain` steps: the difference cancels the launch itself
   *ns_per_step = (ms2 - ms1) * 1e6f / (2.0f * (float)chain);
+  return VGX_OK;
+}
+
+extern "C" int vgx_bench_stream_ceiling(vgx_ctx ctx, const void* d_src, int64_t read_bytes, void* d_dst,
+                                        int64_t write_bytes, int32_t launches, float* ms_per_launch) {
+  if (!ctx || !ms_per_launch || read_bytes < 0 || write_bytes < 0 || ((read_bytes | write_bytes) & 15) || launches <= 0 ||
+      (read_bytes > 0 && !d_src) || (write_bytes > 0 && !d_dst) || read_bytes + write_bytes == 0)
+    return VGX_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  VGX_HIP(ctx, hipSetDevice(ctx->device));
+  hipEvent_t e[2];
+  for (auto& ev : e) (void)hipEventCreate(&ev);
+  int rc = VGX_OK;
+  // as many workgroups as the headline kernel keeps resident (8 per CU), each with a long contiguous slice
+  int cus = 256;
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+  const dim3 grid((unsigned)(cus * 8)), block(256);
+  float ms = 0.0f;
+  hipLaunchKernelGGL(stream_ceiling_kernel, grid, block, 0, ctx->stream, (const nt_float4*)d_src, (size_t)read_bytes / 16,
+                     (nt_float4*)d_dst, (size_t)write_bytes / 16);  // warm
+  (void)hipEventRecord(e[0], ctx->stream);
+  for (int k = 0; k < launches; ++k)
+    hipLaunchKernelGGL(stream_ceiling_kernel, grid, block, 0, ctx->stream, (const nt_float4*)d_src,
+                       (size_t)read_bytes / 16, (nt_float4*)d_dst, (size_t)write_bytes / 16);
+  (void)hipEventRecord(e[1], ctx->stream);
+  if (hipGetLastError() != hipSuccess || hipEventSynchronize(e[1]) != hipSuccess ||
+      hipEventElapsedTime(&ms, e[0], e[1]) != hipSuccess)
+    rc = VGX_ERR_HIP;
+  for (auto& ev : e) (void)hipEventDestroy(ev);
+  if (rc != VGX_OK) return set_error(ctx, rc, "vgx_bench_stream_ceiling: HIP failure");
+  *ms_per_launch = ms / (float)launches;
   return VGX_OK;
 }
 
