@@ -31,6 +31,48 @@ def _amd_cards():
     return out
 
 
+def hip_device_sysfs(device_index=0):
+    """sysfs directory of HIP device `device_index`: a box of the pool has 8 cards and shows the container ONE of them,
+    so `card0` is usually somebody else's GPU (seen in round 5: an idle 95 MHz next to a kernel at full tilt).  The
+    PCI bus id of the HIP device names the right directory."""
+    bdf = None
+    try:
+        import ctypes
+        hip = None
+        # the HIP runtime this process already runs on (torch ships its own copy: never load a second one beside it)
+        loaded = []
+        try:
+            with open("/proc/self/maps") as f:
+                loaded = sorted({l.split()[-1] for l in f if "libamdhip64" in l})
+        except OSError:
+            pass
+        for name in loaded + ["libamdhip64.so", "/opt/rocm/lib/libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6"]:
+            try:
+                hip = ctypes.CDLL(name)
+                break
+            except OSError:
+                continue
+        if hip is not None:
+            buf = ctypes.create_string_buffer(64)
+            if hip.hipDeviceGetPCIBusId(buf, 64, int(device_index)) == 0:
+                bdf = buf.value.decode().lower()
+    except Exception:
+        bdf = None
+    if bdf:
+        path = os.path.join("/sys/bus/pci/devices", bdf)
+        if os.path.isdir(path):
+            return path, bdf
+    return None, bdf
+
+
+def _device_dir(device_index=0):
+    path, _ = hip_device_sysfs(device_index)
+    if path:
+        return path
+    cards = _amd_cards()
+    return cards[min(device_index, len(cards) - 1)] if cards else None
+
+
 def _hwmon(dev):
     h = sorted(glob.glob(os.path.join(dev, "hwmon", "hwmon*")))
     return h[0] if h else None
@@ -47,14 +89,14 @@ def _active_level(txt):
 
 def sysfs_state(card_index=0):
     cards = _amd_cards()
-    if not cards:
+    dev = _device_dir(card_index)
+    if not dev:
         return {"available": False}
-    dev = cards[min(card_index, len(cards) - 1)]
     hw = _hwmon(dev)
     sclk, sclk_levels = _active_level(_read(os.path.join(dev, "pp_dpm_sclk")))
     mclk, mclk_levels = _active_level(_read(os.path.join(dev, "pp_dpm_mclk")))
     fclk, _ = _active_level(_read(os.path.join(dev, "pp_dpm_fclk")))
-    st = {"available": True, "device": dev, "cards": len(cards),
+    st = {"available": True, "device": dev, "pci_bus_id": hip_device_sysfs(card_index)[1], "cards": len(cards),
           "sclk_active": sclk, "sclk_levels": sclk_levels, "mclk_active": mclk, "mclk_levels": mclk_levels,
           "fclk_active": fclk,
           "perf_level": _read(os.path.join(dev, "power_dpm_force_performance_level")),
@@ -113,8 +155,8 @@ class Sampler:
     """with Sampler() as s: <timed region>;  s.summary() -> {sclk_MHz: {min, median, max}, ...}"""
 
     def __init__(self, card_index=0, period_s=0.02):
-        cards = _amd_cards()
-        self.hw = _hwmon(cards[min(card_index, len(cards) - 1)]) if cards else None
+        dev = _device_dir(card_index)
+        self.hw = _hwmon(dev) if dev else None
         self.period = period_s
         self.rows = []
         self._stop = threading.Event()
