@@ -36,13 +36,8 @@ def profiled_launches():
     return out
 
 
-def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=8):
-    """Second hot path (TSDF): whole scans resident in HBM, one integratePointCloud per
-    scan into the active layer, HIP-event timed.  Two sensor shapes from BASELINE.json:
-    RGB-D 640x480 @ 0.05 m voxels (config 4) and OS1-64-shaped LiDAR 64x1024 @ 0.20 m with
-    the shipped yaml (config 2's integrator settings)."""
-    from oracle import pyoracle as orc
-    out = {}
+def sensor_cases():
+    """the two sensor shapes of BASELINE.json: name -> (unit ray directions, voxel size, integrator settings, block box)"""
     u, v = np.meshgrid((np.arange(640) - 319.5) / 525.0, (np.arange(480) - 239.5) / 525.0)
     d_rgbd = np.stack([np.ones_like(u), -u, -v], -1).reshape(-1, 3)
     d_rgbd /= np.linalg.norm(d_rgbd, axis=1, keepdims=True)
@@ -50,7 +45,7 @@ def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=8):
     el = np.deg2rad(np.linspace(-16.6, 16.6, 64))
     A, E = np.meshgrid(az, el)
     d_lidar = np.stack([np.cos(E) * np.cos(A), np.cos(E) * np.sin(A), np.sin(E)], -1).reshape(-1, 3)
-    cases = {
+    return {
         "rgbd_640x480_0.05m": (d_rgbd, 0.05, dict(default_truncation_distance=0.15, max_ray_length_m=5.0),
                                (-8, -6, -2), (16, 12, 7)),
         "lidar_64x1024_0.20m_voxgraph_yaml": (d_lidar, 0.20, dict(
@@ -58,19 +53,35 @@ def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=8):
             use_weight_dropoff=1, use_sparsity_compensation_factor=1,
             sparsity_compensation_factor=20.0), (-3, -3, -2), (6, 6, 4)),
     }
+
+
+def session_scans(dirs, scans):
+    """`scans` sensor poses along a short path through the room and the clouds seen from them (sensor frame)"""
+    poses, clouds = [], []
+    for k in range(scans):
+        origin = np.array([-2.0 + 0.15 * k, 0.5 - 0.05 * k, 0.3 + 0.01 * k])
+        yaw = 0.05 * k
+        c, s_ = np.cos(yaw), np.sin(yaw)
+        R = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1.0]])
+        pts_w = _room_points(dirs @ R.T, origin)            # hits, relative to the sensor, world axes
+        pts_c = (pts_w @ R).astype(np.float32)              # sensor frame
+        poses.append(np.array([np.cos(yaw / 2), 0, 0, np.sin(yaw / 2), *origin], np.float32))
+        clouds.append(pts_c)
+    return poses, clouds
+
+
+def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=8):
+    """Second hot path (TSDF): whole scans resident in HBM, one integratePointCloud per
+    scan into the active layer, HIP-event timed.  Two sensor shapes from BASELINE.json:
+    RGB-D 640x480 @ 0.05 m voxels (config 4) and OS1-64-shaped LiDAR 64x1024 @ 0.20 m with
+    the shipped yaml (config 2's integrator settings)."""
+    from oracle import pyoracle as orc
+    out = {}
+    cases = sensor_cases()
     launches = profiled_launches()
     for name, (dirs, vs, kw, bmin, bdim) in cases.items():
         sensor = "rgbd" if name.startswith("rgbd") else "lidar"
-        poses, clouds = [], []
-        for k in range(scans):
-            origin = np.array([-2.0 + 0.15 * k, 0.5 - 0.05 * k, 0.3 + 0.01 * k])
-            yaw = 0.05 * k
-            c, s_ = np.cos(yaw), np.sin(yaw)
-            R = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1.0]])
-            pts_w = _room_points(dirs @ R.T, origin)            # hits, relative to the sensor, world axes
-            pts_c = (pts_w @ R).astype(np.float32)              # sensor frame
-            poses.append(np.array([np.cos(yaw / 2), 0, 0, np.sin(yaw / 2), *origin], np.float32))
-            clouds.append(pts_c)
+        poses, clouds = session_scans(dirs, scans)
         n_pts = clouds[0].shape[0]
         reach = kw["max_ray_length_m"] + kw["default_truncation_distance"] + 2 * vs
 
@@ -114,8 +125,8 @@ def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=8):
             u_ = integ.integrate_device(poses[k], dev[k].data_ptr(), None, n_pts, count=True)
             updates += u_ if k >= 1 else 0
             if k >= 1:
-                # (longest chain of dependent exchanges, exchanges of all rays, colour blends) of this scan
-                walks.append(integ.walk_stats() + (u_,))
+                # what this scan's rays did (vgx_tsdf_integrator_walk_stats) + its voxel updates
+                walks.append(dict(integ.walk_stats(), updates=u_))
         n_blocks, dropped = layer.stats()
         # The two ceilings of a kernel made of device-scope atomics on scattered 8-byte words (DESIGN.md 3 "TSDF
         # latency model"), measured on this GPU with the operation by itself -- a chain of dependent exchanges on
@@ -127,11 +138,22 @@ def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=8):
         sat_waves = 8192
         rt_saturated_ns = capi.atomic_roundtrip_ns(ctx, 8 << 20, sat_waves, 100)
         atomic_peak_gops = sat_waves * 64 / rt_saturated_ns
-        longest = float(np.mean([w_[0] for w_ in walks]))
-        # memory operations of a scan: one exchange per voxel step + per update a load and a CAS of {distance,
-        # weight} + a load and a CAS of the colour where it blends
-        ops_scan = float(np.mean([w_[1] + 2 * w_[3] + 2 * w_[2] for w_ in walks]))
-        chain_ms = longest * rt_unloaded_ns * 1e-6
+        v1 = os.environ.get("VGX_TSDF_KERNEL") == "v1"
+        longest = float(np.mean([w_["longest_chain"] for w_ in walks]))
+        if v1:
+            # one-thread-per-point kernel: one exchange per voxel step + per update a load and a CAS of {distance,
+            # weight} + a load and a CAS of the colour where it blends; the chain is the longest ray's steps
+            ops_scan = float(np.mean([w_["exchanges"] + 2 * w_["updates"] + 2 * w_["colour_blends"] for w_ in walks]))
+            chain_trips = longest
+        else:
+            # cooperative kernel (vgx_tsdf_coop.hip): exchanges + peeks of the walk; per distinct voxel and workgroup one
+            # block-table load, one load each of {distance, weight} and colour, one CAS (+ one of the colour where a
+            # record blends: counted as one per fold, an upper bound) + the folds that had to be repeated.  The chain a
+            # scan cannot be shorter than: the point load and the start-set exchange, the longest ray's rounds, then
+            # table load -> voxel load -> CAS -> colour CAS.
+            ops_scan = float(np.mean([w_["exchanges"] + w_["peeks"] + 5 * w_["voxel_folds"] + w_["cas_retries"] for w_ in walks]))
+            chain_trips = 2.0 + longest + 4.0
+        chain_ms = chain_trips * rt_unloaded_ns * 1e-6
         throughput_ms = ops_scan / atomic_peak_gops * 1e-6
         # heaviest case: the first scan into an empty layer with a fresh integrator (no
         # previously observed voxels: every ray runs to its early-out or to the sensor)
@@ -295,10 +317,13 @@ def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=8):
                      # THROUGHPUT of such operations (all of the scan's / what the memory system sustains).
                      # `peak` = the larger of the two lower bounds on the kernel's time, `frac` = peak / measured.
                      "roofline": {"bound": "latency" if chain_ms >= throughput_ms else "atomic-throughput",
-                                  "kernel": "tsdf_integrate_kernel<true>",
+                                  "kernel": "tsdf_integrate_kernel<true> (VGX_TSDF_KERNEL=v1)" if v1 else "tsdf_integrate_coop_kernel<false>",
                                   "kernel_ms": kernel_ms,
                                   "kernel_ms_how": "HIP events around each scan's launch, stream drained before",
-                                  "longest_walk_steps": longest, "longest_walk_steps_max": int(max(w_[0] for w_ in walks)),
+                                  "longest_walk_steps": longest, "longest_walk_steps_max": int(max(w_["longest_chain"] for w_ in walks)),
+                                  "longest_walk_unit": "voxel steps" if v1 else "rounds of the cooperative walk (one round trip each)",
+                                  "dependent_round_trips": chain_trips,
+                                  "per_scan": {k_: float(np.mean([w_[k_] for w_ in walks])) for k_ in walks[0]},
                                   "roundtrip_ns_unloaded": rt_unloaded_ns, "latency_chain_ms": chain_ms,
                                   "memory_operations_per_scan": ops_scan,
                                   "atomic_peak_Gops": atomic_peak_gops, "atomic_peak_how":

@@ -50,10 +50,16 @@ VGX_API int vgx_bench_atomic_roundtrip(vgx_ctx ctx, int64_t table_bytes, int32_t
 VGX_API int vgx_bench_stream_ceiling(vgx_ctx ctx, const void* d_src, int64_t read_bytes, void* d_dst,
                                      int64_t write_bytes, int32_t launches, float* ms_per_launch);
 
-/* What the rays of the last COUNTED racing scan did (vgx_tsdf_integrate[_device] with n_updates != NULL resets
- * the statistics before the scan): stats[0] = the longest chain of dependent approximate-set exchanges any ray
- * walked, stats[1] = exchanges of all rays together, stats[2] = voxel updates that also blended a colour. */
-VGX_API int vgx_tsdf_integrator_walk_stats(vgx_tsdf_integrator integrator, int64_t stats[3]);
+/* What the rays of the last COUNTED racing scan did (vgx_tsdf_integrate[_device] with n_updates != NULL resets the
+ * statistics before the scan and makes the kernel gather them; an uncounted scan gathers nothing):
+ *   stats[0]  the longest chain of DEPENDENT round trips to the observed set any ray needed (rounds of the cooperative
+ *             walk; with VGX_TSDF_KERNEL=v1: voxel steps, one exchange each)
+ *   stats[1]  exchanges on the observed set, all rays together       stats[2]  voxel updates that also blended a colour
+ *   stats[3]  peeks (plain loads of an observed-set slot ahead of the exchanges)
+ *   stats[4]  per-voxel folds (one block lookup + one {distance, weight} load + one compare-and-swap each, + colour)
+ *   stats[5]  compare-and-swaps that found another workgroup's update and were folded again
+ *   stats[6]  exchanges issued behind a ray's stopping step because a peeked slot changed before the exchange */
+VGX_API int vgx_tsdf_integrator_walk_stats(vgx_tsdf_integrator integrator, int64_t stats[7]);
 
 /* Reproducible TSDF mode, bounded speculation (csrc/vgx_tsdf_det.hip): a scan whose rays' complete walks are more
  * than `threshold` voxel steps is written out `depth` steps per ray at first; rays that ran on are extended in a

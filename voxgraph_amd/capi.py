@@ -823,11 +823,11 @@ class FastTsdfIntegrator:
         self.ctx.check(self.ctx.lib.vgx_tsdf_integrator_set_speculation(self.h, depth, threshold))
 
     def walk_stats(self):
-        """bench tooling, last counted racing scan: (longest chain of dependent approximate-set exchanges,
-        exchanges of all rays, updates that blended a colour)"""
-        out = (C.c_int64 * 3)()
+        """bench tooling, last counted racing scan (include/voxgraph_amd_bench.h): dict of the seven numbers"""
+        out = (C.c_int64 * 7)()
         self.ctx.check(self.ctx.lib.vgx_tsdf_integrator_walk_stats(self.h, out))
-        return int(out[0]), int(out[1]), int(out[2])
+        names = ("longest_chain", "exchanges", "colour_blends", "peeks", "voxel_folds", "cas_retries", "overrun_exchanges")
+        return {k: int(v) for k, v in zip(names, out)}
 
     def destroy(self):
         if self.h:

@@ -1125,12 +1125,12 @@ int vgx_tsdf_integrator_create(vgx_ctx ctx, const vgx_tsdf_config* cfg, vgx_tsdf
   const size_t set_bytes = ((size_t)1 << kSetBits) * 8;
   bool ok = hipMalloc(&I->dev.start_set, set_bytes) == hipSuccess &&
             hipMalloc(&I->dev.observed_set, set_bytes) == hipSuccess &&
-            hipMalloc(&I->dev.n_updates, 32) == hipSuccess;
+            hipMalloc(&I->dev.n_updates, 8 * kScanStatWords) == hipSuccess;
   const unsigned long long poison = ~0ull;
   if (ok)
     ok = hipMemset(I->dev.start_set, 0, set_bytes) == hipSuccess &&
          hipMemset(I->dev.observed_set, 0, set_bytes) == hipSuccess &&
-         hipMemset(I->dev.n_updates, 0, 32) == hipSuccess &&
+         hipMemset(I->dev.n_updates, 0, 8 * kScanStatWords) == hipSuccess &&
          // the zero hash would look present in every zeroed slot (ApproxHashSet ctor)
          hipMemcpy(I->dev.start_set, &poison, 8, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(I->dev.observed_set, &poison, 8, hipMemcpyHostToDevice) == hipSuccess;
@@ -1240,7 +1240,7 @@ static int integrate_locked(vgx_tsdf_integrator I, const float T[7], const void*
     if (rc == VGX_OK) rc = reset_set(ctx, I->dev.observed_set, &I->dev.observed_offset);
     if (rc != VGX_OK) return rc;
   }
-  if (n_updates) VGX_HIP(ctx, hipMemsetAsync(I->dev.n_updates, 0, 32, ctx->stream));
+  if (n_updates) VGX_HIP(ctx, hipMemsetAsync(I->dev.n_updates, 0, 8 * kScanStatWords, ctx->stream));
   if (n > 0) {
     // Every voxel a ray of this scan can touch lies within max_ray_length + truncation of the
     // sensor origin (a longer return is a clearing ray cut at max_ray_length, RayCaster [recalled]);
@@ -1270,19 +1270,29 @@ static int integrate_locked(vgx_tsdf_integrator I, const float T[7], const void*
       }
       return rc;
     }
-    dim3 grid((unsigned)((n + 255) / 256)), block(256);
-    static const bool pipelined = [] {
-      const char* e = getenv("VGX_TSDF_PIPELINED");  // A/B switch (profiles/ab_tsdf.sh)
-      return e ? atoi(e) != 0 : true;
+    // VGX_TSDF_KERNEL=v1: the one-thread-per-point kernel of rounds 1-4 (A/B runs: profiles/ab_tsdf_coop.sh)
+    static const int kernel_version = [] {
+      const char* e = getenv("VGX_TSDF_KERNEL");
+      return (e && !strcmp(e, "v1")) ? 1 : 2;
     }();
-    if (pipelined)
-      hipLaunchKernelGGL(tsdf_integrate_kernel<true>, grid, block, 0, ctx->stream, I->layer->dev, I->dev,
-                         T[0], T[1], T[2], T[3], T[4], T[5], T[6], (const float*)d_points,
-                         (const uint32_t*)d_rgba, (long long)n, (int)freespace);
-    else
-      hipLaunchKernelGGL(tsdf_integrate_kernel<false>, grid, block, 0, ctx->stream, I->layer->dev, I->dev,
-                         T[0], T[1], T[2], T[3], T[4], T[5], T[6], (const float*)d_points,
-                         (const uint32_t*)d_rgba, (long long)n, (int)freespace);
+    if (kernel_version == 2) {
+      VGX_HIP(ctx, launch_racing_scan(ctx->stream, I->layer->dev, I->dev, T, (const float*)d_points, (const uint32_t*)d_rgba,
+                                      (long long)n, (int)freespace, n_updates != nullptr));
+    } else {
+      dim3 grid((unsigned)((n + 255) / 256)), block(256);
+      static const bool pipelined = [] {
+        const char* e = getenv("VGX_TSDF_PIPELINED");  // A/B switch (profiles/ab_tsdf.sh)
+        return e ? atoi(e) != 0 : true;
+      }();
+      if (pipelined)
+        hipLaunchKernelGGL(tsdf_integrate_kernel<true>, grid, block, 0, ctx->stream, I->layer->dev, I->dev,
+                           T[0], T[1], T[2], T[3], T[4], T[5], T[6], (const float*)d_points,
+                           (const uint32_t*)d_rgba, (long long)n, (int)freespace);
+      else
+        hipLaunchKernelGGL(tsdf_integrate_kernel<false>, grid, block, 0, ctx->stream, I->layer->dev, I->dev,
+                           T[0], T[1], T[2], T[3], T[4], T[5], T[6], (const float*)d_points,
+                           (const uint32_t*)d_rgba, (long long)n, (int)freespace);
+    }
     VGX_HIP(ctx, hipGetLastError());
     request_readback(I->layer);
   }
@@ -1466,19 +1476,18 @@ int vgx_tsdf_integrator_set_speculation(vgx_tsdf_integrator I, int32_t depth, in
   return VGX_OK;
 }
 
-// bench header: what the rays of the last COUNTED racing scan did (n_updates != NULL resets the statistics
-// before the scan): stats[0] = the longest chain of dependent approximate-set exchanges any ray walked,
-// stats[1] = exchanges of all rays together, stats[2] = updates that also blended a colour
-int vgx_tsdf_integrator_walk_stats(vgx_tsdf_integrator I, int64_t stats[3]) {
+// bench header: what the rays of the last COUNTED racing scan did (n_updates != NULL resets the statistics before the
+// scan and makes the kernel gather them): see include/voxgraph_amd_bench.h for the seven numbers
+int vgx_tsdf_integrator_walk_stats(vgx_tsdf_integrator I, int64_t stats[7]) {
   if (!I || !stats) return VGX_ERR_INVALID;
   std::lock_guard<std::mutex> own(I->mu);
   vgx_ctx ctx = I->ctx;
   std::lock_guard<std::mutex> lk(ctx->mu);
   VGX_HIP(ctx, hipSetDevice(ctx->device));
-  unsigned long long u[3] = {0, 0, 0};
-  VGX_HIP(ctx, hipMemcpyAsync(u, I->dev.n_updates + 1, 24, hipMemcpyDeviceToHost, ctx->stream));
+  unsigned long long u[kScanStatWords - 1] = {};
+  VGX_HIP(ctx, hipMemcpyAsync(u, I->dev.n_updates + 1, sizeof(u), hipMemcpyDeviceToHost, ctx->stream));
   VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  for (int k = 0; k < 3; ++k) stats[k] = (int64_t)u[k];
+  for (int k = 0; k < kScanStatWords - 1; ++k) stats[k] = (int64_t)u[k];
   return VGX_OK;
 }
 

@@ -1,0 +1,467 @@
+// TSDF path, racing mode (the default): voxblox::FastTsdfIntegrator::integratePointCloud as its worker threads run
+// it -- every ray its own thread, rays racing on the two approximate sets and on the voxels -- laid out for a
+// wavefront machine (round 5; the one-thread-per-point kernel it replaces is tsdf_integrate_kernel in vgx_tsdf.hip,
+// still reachable with VGX_TSDF_KERNEL=v1 for A/B runs).
+//
+// What the one-thread-per-point kernel paid for (profiles/r04_sq_breakdown.json: waves wait on memory 81-91 % of
+// their cycles; 52 us for a LiDAR scan whose longest chain of exchanges is 4 us):
+//   * 95 % of the lanes die at the start-set test and the survivors stay scattered over 1024 wavefronts;
+//   * a ray learns whether to take step k + 1 only when the exchange of step k is back: one round trip per voxel;
+//   * neighbouring beams walk the SAME voxels in lock step, so their per-voxel compare-and-swaps fail against each
+//     other and are retried one round trip at a time (2-4 rays per voxel and step).
+// Here one workgroup takes 256 points through three phases:
+//   1. START SET.  Every lane tests its start cell; lanes of a wavefront that hold the same cell as their left
+//      neighbour do not exchange at all -- had they, right behind the run's first lane, they would have found their
+//      own value: "already present", the result one serial order of voxblox's threads gives.  Survivors set up their
+//      ray and are compacted (ballot + prefix) into a queue in LDS.
+//   2. WALK.  Eight lanes per ray, lane j on voxel step pos + j of the ray's DDA (each lane advances the ray's state j
+//      times: the same f32 additions in the same order as a sequential walk).  The early-out needs more than
+//      max_consecutive_ray_collisions observed voxels IN A ROW, so with a current run of c the next mc + 1 - c
+//      exchanges happen whatever they return: those lanes exchange together -- one round trip for up to mc + 1 steps,
+//      and nothing is written that the sequential ray would not have written.  The lanes behind them PEEK at their
+//      slot with a plain load; a peeked prefix that cannot contain the stop is exchanged together with the
+//      unconditional steps of the next round (up to eight steps per round trip).  Only exchanges decide: a peek
+//      merely selects which exchanges to issue, so a slot that changes between peek and exchange costs, at worst, a
+//      few exchanges behind the stop (a window of one round trip; counted, `overrun` in the statistics).
+//   3. UPDATES.  Every voxel step that survives becomes a record {sdf, weight, colour} chained to its voxel in a hash
+//      table in LDS.  When the workgroup's rays are done (or the table is nearly full) ONE lane per distinct voxel
+//      looks the block up (allocating it if new), loads {distance, weight} and the colour, folds the chain over them
+//      in registers -- updateTsdfVoxel for each record in turn -- and publishes with one compare-and-swap: rays of
+//      one workgroup no longer collide on a voxel, only workgroups do (adjacent rings / image rows), and those are
+//      not in lock step.
+// Every ordering this produces is one voxblox's threads can produce, with one stated exception: the exchanges a ray
+// issues in one round reach the L2 in no particular order, where a CPU thread's are sequentially consistent (another
+// ray can see step k + 1 observed and step k not yet, for the ~100 ns between two arrivals).
+// HBM is not what bounds this (a scan is a few MB): round trips of device-scope atomics are; see DESIGN.md 3.
+#include "vgx_tsdf_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace vgx {
+
+namespace {
+
+constexpr int kLanesPerRay = 8;
+constexpr int kMaxRecs = 768;                 // update records pending in LDS
+constexpr int kTable = 1024;                  // voxel hash table (power of two, load factor <= 0.75)
+constexpr int kFlushAt = kMaxRecs - 256;      // a round adds at most 256 records
+constexpr unsigned long long kEmptyKey = ~0ull;
+constexpr uint32_t kNil = 0xffffffffu;
+constexpr int kBias = 1 << 20;                // 21 bits per axis in a voxel key
+
+struct RayRec {           // a cast ray, as phase 1 leaves it
+  int curr[3];
+  int sign_bits;          // (sign + 1) of the three axes, two bits each
+  float t_next[3], t_step[3];
+  uint32_t steps_lo, steps_hi;
+  float gx, gy, gz, weight;
+  uint32_t color;
+};
+
+struct UpdateRec {        // one voxel step of one ray
+  float sdf, w;
+  uint32_t color, next;
+};
+
+__device__ __forceinline__ unsigned long long voxel_key(int x, int y, int z) {
+  return (((unsigned long long)(x + kBias) & 0x1fffffull) << 42) | (((unsigned long long)(y + kBias) & 0x1fffffull) << 21) |
+         ((unsigned long long)(z + kBias) & 0x1fffffull);
+}
+
+// updateTsdfVoxel's geometry (computeDistance + weight drop-off + sparsity compensation) [recalled]: the same
+// operations as make_update in vgx_tsdf.hip
+__device__ __forceinline__ void update_terms(float vs, const vgx_tsdf_config& c, float ox, float oy, float oz, float gx, float gy,
+                                             float gz, int vx, int vy, int vz, float weight, float& sdf_out, float& w_out) {
+  const float cx = ((float)vx + 0.5f) * vs, cy = ((float)vy + 0.5f) * vs, cz = ((float)vz + 0.5f) * vs;
+  const float vvx = cx - ox, vvy = cy - oy, vvz = cz - oz;
+  const float vpx = gx - ox, vpy = gy - oy, vpz = gz - oz;
+  const float dist_G = norm3(vpx, vpy, vpz);
+  const float dot = (vvx * vpx + vvy * vpy) + vvz * vpz;
+  const float dist_G_V = dot / dist_G;
+  const float sdf = dist_G - dist_G_V;
+  float updated_weight = weight;
+  const float trunc = c.default_truncation_distance;
+  if (c.use_weight_dropoff && sdf < -vs) {
+    updated_weight = weight * (trunc + sdf) / (trunc - vs);
+    updated_weight = fmaxf(updated_weight, 0.0f);
+  }
+  if (c.use_sparsity_compensation_factor && fabsf(sdf) < trunc) updated_weight *= c.sparsity_compensation_factor;
+  sdf_out = sdf;
+  w_out = updated_weight;
+}
+
+}  // namespace
+
+template <bool STATS>
+__global__ __launch_bounds__(256) void tsdf_integrate_coop_kernel(TsdfLayerDev L, TsdfIntegratorDev I, float qw, float qx, float qy,
+                                                                 float qz, float tx, float ty, float tz,
+                                                                 const float* __restrict__ points_C,
+                                                                 const uint32_t* __restrict__ rgba, long long n,
+                                                                 int freespace_points) {
+  __shared__ RayRec rays[256];
+  __shared__ UpdateRec recs[kMaxRecs];
+  __shared__ unsigned long long tkey[kTable];
+  __shared__ uint32_t thead[kTable];
+  __shared__ uint16_t occ[kMaxRecs];
+  __shared__ uint32_t sh_n_rays, sh_next_ray, sh_n_recs, sh_n_occ;
+
+  const vgx_tsdf_config& c = I.cfg;
+  const int tid = (int)threadIdx.x, lane = tid & 63;
+  unsigned long long st_updates = 0, st_dropped = 0, st_exch = 0, st_peeks = 0, st_blends = 0, st_voxels = 0, st_retries = 0,
+                     st_overrun = 0, st_rounds_max = 0;
+
+  for (int e = tid; e < kTable; e += 256) {
+    tkey[e] = kEmptyKey;
+    thead[e] = kNil;
+  }
+  if (tid == 0) {
+    sh_n_rays = 0;
+    sh_next_ray = 0;
+    sh_n_recs = 0;
+    sh_n_occ = 0;
+  }
+  __syncthreads();
+
+  // ---------------------------------------------------------------- phase 1: validity, start set, ray set-up
+  {
+    const long long i = (long long)blockIdx.x * 256 + tid;
+    bool cast = false;
+    RayRec r;
+    if (i < n) {
+      const float px = points_C[3 * i], py = points_C[3 * i + 1], pz = points_C[3 * i + 2];
+      // isPointValid
+      bool valid = true, is_clearing = false;
+      const float ray_distance = norm3(px, py, pz);
+      if (ray_distance < c.min_ray_length_m) {
+        valid = false;
+      } else if (ray_distance > c.max_ray_length_m) {
+        if (c.allow_clear || freespace_points) is_clearing = true; else valid = false;
+      } else {
+        is_clearing = freespace_points != 0;
+      }
+      float gx, gy, gz;
+      transform_point(qw, qx, qy, qz, tx, ty, tz, px, py, pz, gx, gy, gz);
+      const float vsi = L.voxel_size_inv;
+      const float sub_inv = c.start_voxel_subsampling_factor * vsi;
+      const int sx = grid_index(gx * sub_inv + 1e-6f), sy = grid_index(gy * sub_inv + 1e-6f), sz = grid_index(gz * sub_inv + 1e-6f);
+      const unsigned int h = (unsigned int)sx + (unsigned int)sy * 17191u + (unsigned int)sz * 295530481u;
+      const unsigned long long v = (unsigned long long)h + I.start_offset;
+      // a lane whose left neighbour holds the same value would find it present: it does not exchange
+      const unsigned long long vkey = valid ? v : kEmptyKey;  // (h + offset < 2^33: never the marker)
+      const unsigned int left_lo = (unsigned int)__shfl_up((int)(unsigned int)vkey, 1);
+      const unsigned int left_hi = (unsigned int)__shfl_up((int)(unsigned int)(vkey >> 32), 1);
+      const bool same_as_left = lane > 0 && (((unsigned long long)left_hi << 32) | left_lo) == vkey;
+      if (valid && !same_as_left) {
+        const unsigned long long old = atomicExch(&I.start_set[v & kSetMask], v);
+        cast = old != v;
+      }
+      if (cast) {
+        const RayDda d = ray_setup(c, vsi, tx, ty, tz, gx, gy, gz, is_clearing, false);
+        cast = !d.bad;
+        float weight = 1.0f;  // getVoxelWeight
+        if (!c.use_const_weight) {
+          const float dist_z = fabsf(pz);
+          weight = dist_z > 1e-6f ? 1.0f / (dist_z * dist_z) : 0.0f;
+        }
+        r.curr[0] = d.curr[0]; r.curr[1] = d.curr[1]; r.curr[2] = d.curr[2];
+        r.sign_bits = (d.sign[0] + 1) | ((d.sign[1] + 1) << 2) | ((d.sign[2] + 1) << 4);
+        r.t_next[0] = d.t_next[0]; r.t_next[1] = d.t_next[1]; r.t_next[2] = d.t_next[2];
+        r.t_step[0] = d.t_step[0]; r.t_step[1] = d.t_step[1]; r.t_step[2] = d.t_step[2];
+        r.steps_lo = (uint32_t)(unsigned long long)d.steps;
+        r.steps_hi = (uint32_t)((unsigned long long)d.steps >> 32);
+        r.gx = gx; r.gy = gy; r.gz = gz; r.weight = weight;
+        r.color = rgba ? rgba[i] : 0u;
+      }
+    }
+    const unsigned long long m = __ballot(cast);
+    uint32_t base = 0;
+    if (lane == 0 && m) base = atomicAdd(&sh_n_rays, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, 0);
+    if (cast) rays[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r;
+  }
+  __syncthreads();
+  const uint32_t n_rays = sh_n_rays;
+
+  // ---------------------------------------------------------------- phases 2 + 3: walk in rounds, flush
+  const int j = lane & (kLanesPerRay - 1);          // this lane's step within the group's window
+  const int gb = lane & ~(kLanesPerRay - 1);        // first lane of the group
+  // (a run of 2^24 observed voxels does not exist: the clamp only keeps mc + 1 - carry inside an int)
+  const int mc = c.max_consecutive_ray_collisions < (1 << 24) ? c.max_consecutive_ray_collisions : (1 << 24);
+  const int shift = L.vps_shift, vmask = L.vps - 1;
+  const size_t vps3 = (size_t)L.vps * L.vps * L.vps;
+  const float trunc = c.default_truncation_distance;
+
+  // the group's ray (replicated over its lanes)
+  int ray = -1;
+  int cur[3] = {0, 0, 0}, sg[3] = {0, 0, 0};
+  float tn[3] = {0, 0, 0}, ts[3] = {0, 0, 0};
+  long long steps_left = 0;   // voxels of the walk not yet exchanged (the walk visits steps + 1 voxels)
+  int carry = 0;
+  uint32_t peekbits = 0;
+  int nvalid = 0;
+  float rgx = 0, rgy = 0, rgz = 0, rweight = 0;
+  uint32_t rcolor = 0;
+  unsigned long long rounds = 0;
+
+  bool more = n_rays > 0;
+  while (more) {
+    // (A) a group without a ray takes the next one
+    if (ray < 0) {
+      uint32_t k = 0;
+      if (j == 0) k = atomicAdd(&sh_next_ray, 1u);
+      k = (uint32_t)__shfl((int)k, gb);
+      if (k < n_rays) {
+        const RayRec& q = rays[k];
+        ray = (int)k;
+        cur[0] = q.curr[0]; cur[1] = q.curr[1]; cur[2] = q.curr[2];
+        sg[0] = (q.sign_bits & 3) - 1; sg[1] = ((q.sign_bits >> 2) & 3) - 1; sg[2] = ((q.sign_bits >> 4) & 3) - 1;
+        tn[0] = q.t_next[0]; tn[1] = q.t_next[1]; tn[2] = q.t_next[2];
+        ts[0] = q.t_step[0]; ts[1] = q.t_step[1]; ts[2] = q.t_step[2];
+        const long long steps = (long long)(((unsigned long long)q.steps_hi << 32) | q.steps_lo);
+        steps_left = steps + 1;
+        carry = 0;
+        peekbits = 0;
+        nvalid = 0;
+        rgx = q.gx; rgy = q.gy; rgz = q.gz; rweight = q.weight; rcolor = q.color;
+        rounds = 0;
+      }
+    }
+    // (B) one round of the group's ray
+    bool emit = false;
+    int vx = 0, vy = 0, vz = 0;
+    if (ray >= 0) {
+      const int remaining = steps_left < (long long)kLanesPerRay ? (int)steps_left : kLanesPerRay;
+      // exchanges that happen whatever they return: the stop needs a run of more than mc
+      int must = mc + 1 - carry;
+      must = must < 1 ? 1 : must;
+      must = must > remaining ? remaining : must;
+      int w = must;
+      if (nvalid > must) {  // extend over the peeked prefix up to (and including) the step the peeks say stops the ray
+        int run = carry, cut = -1;
+        for (int k = 0; k < nvalid; ++k) {
+          run = ((peekbits >> k) & 1u) ? run + 1 : 0;
+          if (run > mc) {
+            cut = k;
+            break;
+          }
+        }
+        w = cut >= 0 ? (cut + 1 > must ? cut + 1 : must) : nvalid;
+        w = w > remaining ? remaining : w;
+      }
+      // this lane's voxel: the ray's state advanced j times (RayCaster::nextRayIndex, the same additions in the same order)
+      int c0 = cur[0], c1 = cur[1], c2 = cur[2];
+      float t0 = tn[0], t1 = tn[1], t2 = tn[2];
+#pragma unroll
+      for (int k = 0; k < kLanesPerRay; ++k) {
+        if (k == j) {
+          vx = c0; vy = c1; vz = c2;
+        }
+        if (k <= j) {  // (lane j also takes step j: its state afterwards is the ray's at pos + j + 1)
+          int mm = 0;
+          float tm = t0;
+          if (t1 < tm) { mm = 1; tm = t1; }
+          if (t2 < tm) { mm = 2; }
+          c0 += mm == 0 ? sg[0] : 0; c1 += mm == 1 ? sg[1] : 0; c2 += mm == 2 ? sg[2] : 0;
+          t0 += mm == 0 ? ts[0] : 0.0f; t1 += mm == 1 ? ts[1] : 0.0f; t2 += mm == 2 ? ts[2] : 0.0f;
+        }
+      }
+      const bool in_window = j < remaining;
+      const bool do_x = j < w, do_peek = in_window && !do_x;
+      const unsigned int h = (unsigned int)vx + (unsigned int)vy * 17191u + (unsigned int)vz * 295530481u;
+      const unsigned long long v = (unsigned long long)h + I.observed_offset;
+      unsigned long long got = 0ull;
+      if (do_x) got = atomicExch(&I.observed_set[v & kSetMask], v);
+      else if (do_peek) got = __hip_atomic_load(&I.observed_set[v & kSetMask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool seen = (do_x || do_peek) && got == v;
+      const uint32_t xbits = (uint32_t)((__ballot(do_x && seen) >> gb) & 0xffull);
+      const uint32_t pbits = (uint32_t)((__ballot(do_peek && seen) >> gb) & 0xffull);
+      if (STATS) {
+        st_exch += do_x ? 1u : 0u;
+        st_peeks += do_peek ? 1u : 0u;
+      }
+      ++rounds;
+      // what the exchanges say
+      int run = carry, cut = -1;
+      for (int k = 0; k < w; ++k) {
+        run = ((xbits >> k) & 1u) ? run + 1 : 0;
+        if (run > mc) {
+          cut = k;
+          break;
+        }
+      }
+      const int n_upd = cut >= 0 ? cut : w;
+      if (STATS && cut >= 0 && j == 0) st_overrun += (unsigned)(w - 1 - cut);  // exchanges behind the stop (a peek went stale)
+      emit = j < n_upd;
+      const bool finished = cut >= 0 || (long long)w == steps_left;
+      if (finished) {
+        if (STATS && j == 0) st_rounds_max = rounds > st_rounds_max ? rounds : st_rounds_max;
+        ray = -1;
+      } else {
+        carry = run;
+        steps_left -= w;
+        // the ray's state at pos + w: lane w - 1's state after its own step
+        const int src = gb + w - 1;
+        cur[0] = __shfl(c0, src); cur[1] = __shfl(c1, src); cur[2] = __shfl(c2, src);
+        tn[0] = __shfl(t0, src); tn[1] = __shfl(t1, src); tn[2] = __shfl(t2, src);
+        peekbits = pbits >> w;     // peeks of window positions w .. remaining - 1 become positions 0 ..
+        nvalid = remaining - w;
+      }
+    }
+    // (C) the round's surviving steps become records chained to their voxel
+    if (emit) {
+      float sdf, uw;
+      update_terms(L.voxel_size, c, tx, ty, tz, rgx, rgy, rgz, vx, vy, vz, rweight, sdf, uw);
+      const bool in_range = (unsigned)(vx + kBias) < (2u << 20) && (unsigned)(vy + kBias) < (2u << 20) &&
+                            (unsigned)(vz + kBias) < (2u << 20);
+      if (!in_range) {
+        ++st_dropped;  // beyond +-2^20 voxels: no block table reaches there
+      } else {
+        const unsigned long long key = voxel_key(vx, vy, vz);
+        const uint32_t rec = atomicAdd(&sh_n_recs, 1u);
+        uint32_t slot = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & (kTable - 1);
+        while (true) {
+          const unsigned long long prev = atomicCAS(&tkey[slot], kEmptyKey, key);
+          if (prev == kEmptyKey) {
+            occ[atomicAdd(&sh_n_occ, 1u)] = (uint16_t)slot;
+            break;
+          }
+          if (prev == key) break;
+          slot = (slot + 1) & (kTable - 1);
+        }
+        UpdateRec u;
+        u.sdf = sdf; u.w = uw; u.color = rcolor;
+        u.next = atomicExch(&thead[slot], rec);
+        recs[rec] = u;
+      }
+    }
+    __syncthreads();
+    // (D) all rays handed out and finished?  table nearly full?
+    const bool busy = ray >= 0 || sh_next_ray < n_rays;
+    more = __syncthreads_or(busy ? 1 : 0) != 0;
+    if (!more || sh_n_recs > (uint32_t)kFlushAt) {
+      // ------------------------------------------------------------ phase 3: one lane per distinct voxel
+      const uint32_t n_occ = sh_n_occ;
+      for (uint32_t o = (uint32_t)tid; o < n_occ; o += 256) {
+        const uint32_t slot = occ[o];
+        const unsigned long long key = tkey[slot];
+        const uint32_t head = thead[slot];
+        tkey[slot] = kEmptyKey;
+        thead[slot] = kNil;
+        const int kx = (int)((key >> 42) & 0x1fffffull) - kBias, ky = (int)((key >> 21) & 0x1fffffull) - kBias,
+                  kz = (int)(key & 0x1fffffull) - kBias;
+        const int bslot = get_or_allocate_block(L, kx >> shift, ky >> shift, kz >> shift);
+        uint32_t chain = 0;
+        for (uint32_t q = head; q != kNil; q = recs[q].next) ++chain;
+        if (bslot < 0) {
+          st_dropped += chain;
+          continue;
+        }
+        st_updates += chain;
+        const size_t at = (size_t)bslot * vps3 + (size_t)((kx & vmask) + L.vps * ((ky & vmask) + L.vps * (kz & vmask)));
+        unsigned long long* vaddr = &L.voxels[at];
+        uint32_t* caddr = &L.rgba[at];
+        unsigned long long old = __hip_atomic_load(vaddr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t oc = __hip_atomic_load(caddr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // updateTsdfVoxel for every record of the chain in turn, on registers
+        while (true) {
+          float d = __uint_as_float((unsigned)(old & 0xffffffffull)), W = __uint_as_float((unsigned)(old >> 32));
+          uint32_t col = oc;
+          bool any = false, any_blend = false;
+          for (uint32_t q = head; q != kNil; q = recs[q].next) {
+            const UpdateRec u = recs[q];
+            const float new_weight = W + u.w;
+            if (new_weight < 1e-6f) continue;  // kFloatEpsilon: the voxel is left alone
+            const float new_sdf = (u.sdf * u.w + d * W) / new_weight;
+            d = (new_sdf > 0.0f) ? fminf(trunc, new_sdf) : fmaxf(-trunc, new_sdf);
+            if (fabsf(u.sdf) < trunc) {
+              col = blended_color(col, u.color, W, u.w);
+              any_blend = true;
+            }
+            W = fminf(c.max_weight, new_weight);
+            any = true;
+          }
+          if (!any) break;
+          const unsigned long long prev = atomicCAS(vaddr, old, pack_voxel(d, W));
+          if (prev != old) {  // another workgroup got in between: fold again over what it left
+            old = prev;
+            if (STATS) ++st_retries;
+            continue;
+          }
+          if (any_blend) {
+            if (STATS) {
+              for (uint32_t q = head; q != kNil; q = recs[q].next) st_blends += fabsf(recs[q].sdf) < trunc ? 1u : 0u;
+            }
+            uint32_t prevc = atomicCAS(caddr, oc, col);
+            while (prevc != oc) {  // blend again over the colour found, with the weights this fold saw
+              oc = prevc;
+              float W2 = __uint_as_float((unsigned)(old >> 32));
+              col = oc;
+              for (uint32_t q = head; q != kNil; q = recs[q].next) {
+                const UpdateRec u = recs[q];
+                const float new_weight = W2 + u.w;
+                if (new_weight < 1e-6f) continue;
+                if (fabsf(u.sdf) < trunc) col = blended_color(col, u.color, W2, u.w);
+                W2 = fminf(c.max_weight, new_weight);
+              }
+              if (STATS) ++st_retries;
+              prevc = atomicCAS(caddr, oc, col);
+            }
+          }
+          break;
+        }
+        if (STATS) ++st_voxels;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        sh_n_recs = 0;
+        sh_n_occ = 0;
+      }
+      __syncthreads();
+    }
+  }
+
+  // one atomic per wave and counter
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    st_updates += __shfl_xor(st_updates, off, 64);
+    st_dropped += __shfl_xor(st_dropped, off, 64);
+    if (STATS) {
+      st_exch += __shfl_xor(st_exch, off, 64);
+      st_peeks += __shfl_xor(st_peeks, off, 64);
+      st_blends += __shfl_xor(st_blends, off, 64);
+      st_voxels += __shfl_xor(st_voxels, off, 64);
+      st_retries += __shfl_xor(st_retries, off, 64);
+      st_overrun += __shfl_xor(st_overrun, off, 64);
+      const unsigned long long other = __shfl_xor(st_rounds_max, off, 64);
+      st_rounds_max = other > st_rounds_max ? other : st_rounds_max;
+    }
+  }
+  if (lane == 0) {
+    if (st_updates) atomicAdd(I.n_updates, st_updates);
+    if (st_dropped) atomicAdd(L.dropped, st_dropped);
+    if (STATS) {  // vgx_tsdf_integrator_walk_stats (bench header)
+      if (st_rounds_max) atomicMax(I.n_updates + 1, st_rounds_max);
+      if (st_exch) atomicAdd(I.n_updates + 2, st_exch);
+      if (st_blends) atomicAdd(I.n_updates + 3, st_blends);
+      if (st_peeks) atomicAdd(I.n_updates + 4, st_peeks);
+      if (st_voxels) atomicAdd(I.n_updates + 5, st_voxels);
+      if (st_retries) atomicAdd(I.n_updates + 6, st_retries);
+      if (st_overrun) atomicAdd(I.n_updates + 7, st_overrun);
+    }
+  }
+}
+
+// the racing scan's launch (vgx_tsdf.hip integrate_locked); stats: the scan is a counted one (n_updates != NULL)
+hipError_t launch_racing_scan(hipStream_t stream, const TsdfLayerDev& L, const TsdfIntegratorDev& I, const float T[7],
+                              const float* d_points, const uint32_t* d_rgba, long long n, int freespace, bool stats) {
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  if (stats)
+    hipLaunchKernelGGL(tsdf_integrate_coop_kernel<true>, grid, block, 0, stream, L, I, T[0], T[1], T[2], T[3], T[4], T[5], T[6],
+                       d_points, d_rgba, n, freespace);
+  else
+    hipLaunchKernelGGL(tsdf_integrate_coop_kernel<false>, grid, block, 0, stream, L, I, T[0], T[1], T[2], T[3], T[4], T[5], T[6],
+                       d_points, d_rgba, n, freespace);
+  return hipGetLastError();
+}
+
+}  // namespace vgx

@@ -32,8 +32,9 @@ struct TsdfIntegratorDev {
   unsigned long long* start_set;     // [2^20]
   unsigned long long* observed_set;  // [2^20]
   unsigned long long start_offset, observed_offset;
-  unsigned long long* n_updates;
+  unsigned long long* n_updates;  // [kScanStatWords]: voxel updates, then the walk statistics of a counted scan
 };
+constexpr int kScanStatWords = 8;
 
 constexpr unsigned kSetBits = 20;
 constexpr unsigned kSetMask = (1u << kSetBits) - 1u;
@@ -437,6 +438,10 @@ namespace vgx {
 int tsdf_reserve_for_scan(vgx_tsdf_layer L, const float origin[3], float reach);
 int64_t tsdf_last_scan_bound(vgx_tsdf_layer L);
 void tsdf_request_readback(vgx_tsdf_layer L);
+// vgx_tsdf_coop.hip: the racing scan (one workgroup per 256 points: start set, cooperative walk, per-voxel folds);
+// stats: gather vgx_tsdf_integrator_walk_stats' numbers (a counted scan)
+hipError_t launch_racing_scan(hipStream_t stream, const TsdfLayerDev& L, const TsdfIntegratorDev& I, const float T[7],
+                              const float* d_points, const uint32_t* d_rgba, long long n, int freespace, bool stats);
 // vgx_tsdf_det.hip: one scan in the reproducible mode (vgx_tsdf_config.deterministic); the caller
 // holds the integrator's and the context's locks, the approximate sets have been reset for the scan
 // `order`: order[seq] = index of the point visited seq-th (integration_order "sorted"), nullptr = "mixed"
