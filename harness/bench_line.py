@@ -36,9 +36,10 @@ def _tsdf(t):
     rm = t.get("reproducible_mode") or {}
     return {"ms_per_scan": t.get("ms_per_scan"), "Mpoints_per_s": t.get("Mpoints_per_s"),
             "Mvoxel_updates_per_s": t.get("Mvoxel_updates_per_s"), "dropped_updates": t.get("dropped_updates"),
-            "roofline": _pick(rf, ("bound", "kernel", "kernel_ms", "longest_walk_steps", "dependent_round_trips", "roundtrip_ns_unloaded",
+            "roofline": _pick(rf, ("bound", "kernel", "kernel_ms", "one_point_scan_ms", "longest_walk_steps", "dependent_round_trips", "roundtrip_ns_unloaded",
                                    "latency_chain_ms", "atomic_peak_Gops", "atomic_achieved_Gops",
                                    "atomic_throughput_ms", "achieved", "peak", "unit", "frac", "hbm_frac")),
+            "organised_cloud_ms_per_scan": (rf.get("organised_cloud") or {}).get("back_to_back_ms_per_scan"),
             "merged_ms_per_scan": mg.get("ms_per_scan"),
             "reproducible_ms_per_scan": rm.get("ms_per_scan"),
             "reproducible_bit_identical_to_oracle": (rm.get("parity_vs_oracle") or {}).get("bit_identical"),

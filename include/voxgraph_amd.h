@@ -507,6 +507,13 @@ VGX_API int vgx_tsdf_integrator_create(vgx_ctx ctx, const vgx_tsdf_config* cfg,
 VGX_API int vgx_tsdf_integrator_destroy(vgx_tsdf_integrator integrator);
 /* FastTsdfIntegrator::setLayer (pointcloud_integrator.cpp:77) */
 VGX_API int vgx_tsdf_integrator_set_layer(vgx_tsdf_integrator integrator, vgx_tsdf_layer layer);
+/* Optional hint: the scans to come are ORGANISED clouds of `width` points per row (sensor_msgs/PointCloud2.width, which
+ * voxgraph's callback receives -- pointcloud_integrator.cpp:23 -- and voxblox's flat Pointcloud drops; 0 = unorganised, the
+ * default).  The racing integrator then gives a workgroup a 16 x 16 tile of beams instead of 256 consecutive ones: the
+ * beams that end in one voxel are neighbours in both directions, so most of a voxel's updates meet inside one workgroup.
+ * Only the assignment of points to workgroups depends on it -- which rays are cast and what they write is one of voxblox's
+ * legal orders either way; a scan whose length is not a multiple of `width` is treated as unorganised. */
+VGX_API int vgx_tsdf_integrator_set_cloud_width(vgx_tsdf_integrator integrator, int32_t width);
 /* integratePointCloud(T_G_C, points_C, colors, freespace_points)
  * (pointcloud_integrator.cpp:83).  T_G_C = {qw,qx,qy,qz, tx,ty,tz} f32
  * (voxblox::Transformation); points_C [n][3] sensor frame; rgba [n][4] or NULL.

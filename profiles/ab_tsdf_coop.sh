@@ -1,22 +1,33 @@
 #!/bin/bash
 # racing TSDF kernel, round 5: the cooperative kernel (vgx_tsdf_coop.hip) against the one-thread-per-point kernel
-# (VGX_TSDF_KERNEL=v1) on one lease; the TSDF test files first (parity before speed)
+# (VGX_TSDF_KERNEL=v1) on one lease, and where its time goes: the same kernel with its last phases cut off
+# (VGX_TSDF_ABLATE: 1 = no per-voxel folds, 2 = no walk either -- attribution runs only, the layer is wrong)
+#   /usr/local/graft/bin/gpurun --timeout 900 -- bash profiles/ab_tsdf_coop.sh   -> profiles/r05_tsdf_racing.txt
 OUT=gpurun_out/r05_tsdf
 mkdir -p $OUT
-timeout 900 python -m pytest tests/test_tsdf_gpu.py tests/test_tsdf_dropin_gpu.py tests/test_errors_gpu.py -x -q -m gpu > $OUT/pytest_tsdf.txt 2>&1
-tail -5 $OUT/pytest_tsdf.txt
-for i in 1 2; do
-  VGX_TSDF_KERNEL=v1 timeout 300 python profiles/probes/tsdf_racing_probe.py > $OUT/probe_v1_$i.json 2> $OUT/probe_v1_$i.err
-  timeout 300 python profiles/probes/tsdf_racing_probe.py > $OUT/probe_v2_$i.json 2> $OUT/probe_v2_$i.err
-done
+P="timeout 100 python profiles/probes/tsdf_racing_probe.py"
+VGX_TSDF_KERNEL=v1 $P > $OUT/v1.json 2> $OUT/v1.err
+$P > $OUT/coop.json 2> $OUT/coop.err
+VGX_PROBE_ORGANISED=1 $P > $OUT/coop_organised.json 2> $OUT/coop_organised.err
+VGX_TSDF_ABLATE=1 $P > $OUT/coop_nofolds.json 2> $OUT/coop_nofolds.err
+VGX_TSDF_ABLATE=2 $P > $OUT/coop_nowalk.json 2> $OUT/coop_nowalk.err
 python - <<'PY'
 import json
-for n in ("v1_1", "v2_1", "v1_2", "v2_2"):
+print("racing TSDF kernel by itself (HIP events around each scan's launch, stream drained before; 19 scans of the bench sessions)")
+print(f"{'variant':26s} {'sensor':6s} {'one-point us':>12s} {'median us':>10s} {'min':>7s} {'max':>9s} {'back-to-back us':>16s}")
+for n in ("v1", "coop", "coop_organised", "coop_nofolds", "coop_nowalk"):
     try:
-        j = json.load(open(f"gpurun_out/r05_tsdf/probe_{n}.json"))
+        j = json.load(open(f"gpurun_out/r05_tsdf/{n}.json"))
     except Exception as e:
-        print(n, "failed", e); continue
+        print(n, "failed:", e)
+        continue
     for k, v in j.items():
         if isinstance(v, dict):
-            print(n, k[:5], "kernel us %.1f (min %.1f max %.1f first %.1f) b2b %.1f" % (v["kernel_us"], v["kernel_us_min"], v["kernel_us_max"], v["kernel_us_first_scan"], v["back_to_back_us"]), v["per_scan"])
+            print(f"{n:26s} {k[:5]:6s} {v['one_point_scan_us']:12.1f} {v['kernel_us_median']:10.1f} {v['kernel_us_min']:7.1f} {v['kernel_us_max']:9.1f} {v['back_to_back_us']:16.1f}")
+    if n in ("v1", "coop", "coop_organised"):
+        for k, v in j.items():
+            if isinstance(v, dict):
+                print("    per scan:", k[:5], {a: round(b, 1) for a, b in v["per_scan"].items()})
+                if v.get("trace"):
+                    print("    workgroup stamps (counted scans, us):", {a: round(b, 2) for a, b in v["trace"].items()})
 PY

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(capi):
     boundary = _declared_symbols(("voxgraph_amd.h",))
     assert not [n for n in boundary if "synth" in n]
     assert sorted(set(declared) - set(boundary)) == ["vgx_bench_atomic_roundtrip", "vgx_bench_stream_ceiling", "vgx_synth_city_scan",
-                                                     "vgx_synth_city_submap", "vgx_tsdf_integrator_set_speculation",
+                                                     "vgx_synth_city_submap", "vgx_tsdf_integrator_read_trace", "vgx_tsdf_integrator_set_speculation",
                                                      "vgx_tsdf_integrator_walk_stats"]
 
 

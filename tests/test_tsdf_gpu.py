@@ -137,10 +137,14 @@ def _lidar_scan(n_az, n_el, seed):
     return (d * r[:, None]).astype(F)
 
 
-def test_dense_scan_invariants_with_early_out_disabled(capi, ctx):
+@pytest.mark.parametrize("cloud_width", [0, 40])
+def test_dense_scan_invariants_with_early_out_disabled(capi, ctx, cloud_width):
     """max_consecutive_ray_collisions = huge, constant weight, no drop-off / sparsity:
     every ray updates every voxel it crosses, so weight(v) = #rays through v exactly
-    (integer sums: order-independent) and free space is exactly +truncation."""
+    (integer sums: order-independent) and free space is exactly +truncation.
+    cloud_width != 0: the same scan declared an organised cloud of that many points per row
+    (vgx_tsdf_integrator_set_cloud_width: 16 x 16 tiles of beams per workgroup, here with ragged tiles at the
+    right and bottom edges) -- only the assignment of points to workgroups may change, none of the facts below."""
     vs, vps, trunc = 0.1, 16, 0.3
     kw = dict(default_truncation_distance=trunc, max_ray_length_m=20.0, use_const_weight=1,
               use_weight_dropoff=0, max_consecutive_ray_collisions=1 << 30)
@@ -150,11 +154,16 @@ def test_dense_scan_invariants_with_early_out_disabled(capi, ctx):
     cells = np.floor(pts * np.float32(2.0 / vs) + 1e-6).astype(np.int64)
     _, first = np.unique(cells, axis=0, return_index=True)
     pts = pts[np.sort(first)]
+    if cloud_width:
+        # whole rows: padded with points the integrator skips (shorter than min_ray_length_m)
+        pad = (-len(pts)) % cloud_width
+        pts = np.concatenate([pts, np.zeros((pad, 3), F)])
     T = np.array([1, 0, 0, 0, 0, 0, 0], F)
     ol = orc.TsdfLayer(vs, vps)
     a = orc.FastTsdfIntegrator(ocfg, ol).integratePointCloud(T, pts)
     gl = capi.TsdfLayer(ctx, vs, vps, (-5, -4, -2), (10, 8, 5), 400)
     gi = capi.FastTsdfIntegrator(ctx, gcfg, gl)
+    gi.set_cloud_width(cloud_width)
     b = gi.integratePointCloud(T, pts)
     assert gl.stats()[1] == 0
     assert a == b                                   # same number of voxel updates

@@ -114,6 +114,7 @@ SIGNATURES = {
     "vgx_bench_atomic_roundtrip": (C.c_int, [vp, C.c_int64, C.c_int32, C.c_int32, f32p]),
     "vgx_bench_stream_ceiling": (C.c_int, [vp, vp, C.c_int64, vp, C.c_int64, C.c_int32, f32p]),
     "vgx_tsdf_integrator_walk_stats": (C.c_int, [vp, i64p]),
+    "vgx_tsdf_integrator_read_trace": (C.c_int, [vp, i64p, C.c_int64, i64p, i64p]),
     "vgx_tsdf_integrator_set_speculation": (C.c_int, [vp, C.c_int32, C.c_int64]),
     "vgx_reg_config_default": (None, [C.POINTER(RegConfig)]),
     "vgx_reg_create": (C.c_int, [vp, vp, vp, C.POINTER(RegConfig), C.POINTER(vp)]),
@@ -163,6 +164,7 @@ SIGNATURES = {
     "vgx_tsdf_integrator_create": (C.c_int, [vp, C.POINTER(TsdfConfig), vp, C.POINTER(vp)]),
     "vgx_tsdf_integrator_destroy": (C.c_int, [vp]),
     "vgx_tsdf_integrator_set_layer": (C.c_int, [vp, vp]),
+    "vgx_tsdf_integrator_set_cloud_width": (C.c_int, [vp, C.c_int32]),
     "vgx_tsdf_integrate": (C.c_int, [vp, f32p, f32p, u8p, C.c_int64, C.c_int32, i64p]),
     "vgx_tsdf_integrate_device": (C.c_int, [vp, f32p, vp, vp, C.c_int64, C.c_int32, i64p]),
     "vgx_tsdf_integrate_merged": (C.c_int, [vp, f32p, f32p, u8p, C.c_int64, C.c_int32, i64p]),
@@ -817,10 +819,28 @@ class FastTsdfIntegrator:
             int(freespace_points), C.byref(out) if count else None))
         return out.value
 
+    def set_cloud_width(self, width):
+        """organised clouds: points per row (sensor_msgs/PointCloud2.width); 0 = unorganised"""
+        self.ctx.check(self.ctx.lib.vgx_tsdf_integrator_set_cloud_width(self.h, int(width)))
+
     def set_speculation(self, depth=32, threshold=8 << 20):
         """test tooling (reproducible mode): write rays out `depth` steps deep at first when a scan's complete
         walks exceed `threshold` steps; the layer does not depend on either"""
         self.ctx.check(self.ctx.lib.vgx_tsdf_integrator_set_speculation(self.h, depth, threshold))
+
+    def read_trace(self, max_workgroups):
+        """last counted racing scan -> [workgroups][16] float64: four stamps in microseconds relative to the first start,
+        then rays, rounds, per-voxel folds, longest chain of repeated folds, and the workgroup's eight statistics"""
+        buf = np.zeros((int(max_workgroups), 24), np.int64)
+        n, khz = C.c_int64(), C.c_int64()
+        self.ctx.check(self.ctx.lib.vgx_tsdf_integrator_read_trace(self.h, _ptr(buf, i64p), int(max_workgroups),
+                                                                   C.byref(n), C.byref(khz)))
+        t = buf[:min(n.value, int(max_workgroups))].astype(np.float64)
+        if len(t):
+            t0 = t[:, 0].min()
+            t[:, :4] = (t[:, :4] - t0) * 1e3 / max(khz.value, 1)
+            t[:, 16:20] = t[:, 16:20] * 1e3 / max(khz.value, 1)     # the slowest lane's microseconds per flush stage
+        return t
 
     def walk_stats(self):
         """bench tooling, last counted racing scan (include/voxgraph_amd_bench.h): dict of the seven numbers"""

@@ -1146,7 +1146,7 @@ int vgx_tsdf_integrator_destroy(vgx_tsdf_integrator I) {
   if (!I) return VGX_ERR_INVALID;
   (void)hipSetDevice(I->ctx->device);
   (void)hipStreamSynchronize(I->ctx->stream);
-  void* ptrs[] = {I->dev.start_set, I->dev.observed_set, I->dev.n_updates, I->d_points, I->d_rgba,
+  void* ptrs[] = {I->dev.start_set, I->dev.observed_set, I->dev.n_updates, I->d_points, I->d_rgba, I->d_wg_stats,
                   I->d_mkeys[0], I->d_mkeys[1], I->d_midx[0], I->d_midx[1], I->d_mstart, I->d_mcounters, I->d_msort,
                   I->d_mrank, I->d_gpg, I->d_gcolor, I->d_gflags, I->d_gcount, I->d_okey[0], I->d_okey[1], I->d_oidx[0],
                   I->d_oidx[1], I->d_osort};
@@ -1154,6 +1154,13 @@ int vgx_tsdf_integrator_destroy(vgx_tsdf_integrator I) {
     if (p) (void)hipFree(p);
   if (I->det) det_scratch_free(I->det);
   delete I;
+  return VGX_OK;
+}
+
+int vgx_tsdf_integrator_set_cloud_width(vgx_tsdf_integrator I, int32_t width) {
+  if (!I || width < 0) return VGX_ERR_INVALID;
+  std::lock_guard<std::mutex> own(I->mu);
+  I->cloud_width = width;
   return VGX_OK;
 }
 
@@ -1276,8 +1283,22 @@ static int integrate_locked(vgx_tsdf_integrator I, const float T[7], const void*
       return (e && !strcmp(e, "v1")) ? 1 : 2;
     }();
     if (kernel_version == 2) {
+      I->dev.wg_stats = nullptr;
+      if (n_updates) {  // a counted scan: one row of statistics per workgroup
+        const long long wgs = racing_scan_workgroups((long long)n, I->cloud_width);
+        if (wgs > I->wg_stats_cap) {
+          VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+          if (I->d_wg_stats) (void)hipFree(I->d_wg_stats);
+          I->d_wg_stats = nullptr;
+          I->wg_stats_cap = 0;
+          VGX_HIP(ctx, hipMalloc(&I->d_wg_stats, (size_t)wgs * kWgStatWords * 8));
+          I->wg_stats_cap = wgs;
+        }
+        I->dev.wg_stats = I->d_wg_stats;
+        I->wg_stats_rows = wgs;
+      }
       VGX_HIP(ctx, launch_racing_scan(ctx->stream, I->layer->dev, I->dev, T, (const float*)d_points, (const uint32_t*)d_rgba,
-                                      (long long)n, (int)freespace, n_updates != nullptr));
+                                      (long long)n, (int)freespace, n_updates != nullptr, I->cloud_width));
     } else {
       dim3 grid((unsigned)((n + 255) / 256)), block(256);
       static const bool pipelined = [] {
@@ -1488,6 +1509,28 @@ int vgx_tsdf_integrator_walk_stats(vgx_tsdf_integrator I, int64_t stats[7]) {
   VGX_HIP(ctx, hipMemcpyAsync(u, I->dev.n_updates + 1, sizeof(u), hipMemcpyDeviceToHost, ctx->stream));
   VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (int k = 0; k < kScanStatWords - 1; ++k) stats[k] = (int64_t)u[k];
+  return VGX_OK;
+}
+
+// bench header: the rows the workgroups of the last counted racing scan left (stamps + work counts)
+int vgx_tsdf_integrator_read_trace(vgx_tsdf_integrator I, int64_t* rows, int64_t max_workgroups, int64_t* n_workgroups,
+                                   int64_t* clock_khz) {
+  if (!I || !n_workgroups || max_workgroups < 0) return VGX_ERR_INVALID;
+  std::lock_guard<std::mutex> own(I->mu);
+  vgx_ctx ctx = I->ctx;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  VGX_HIP(ctx, hipSetDevice(ctx->device));
+  *n_workgroups = I->wg_stats_rows;
+  if (clock_khz) {
+    int khz = 100000;
+    (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device);
+    *clock_khz = khz;
+  }
+  const long long take = I->wg_stats_rows < max_workgroups ? I->wg_stats_rows : max_workgroups;
+  if (rows && take > 0) {
+    VGX_HIP(ctx, hipMemcpyAsync(rows, I->d_wg_stats, (size_t)take * kWgStatWords * 8, hipMemcpyDeviceToHost, ctx->stream));
+    VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
   return VGX_OK;
 }
 

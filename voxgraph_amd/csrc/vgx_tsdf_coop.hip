@@ -14,15 +14,16 @@
 //      neighbour do not exchange at all -- had they, right behind the run's first lane, they would have found their
 //      own value: "already present", the result one serial order of voxblox's threads gives.  Survivors set up their
 //      ray and are compacted (ballot + prefix) into a queue in LDS.
-//   2. WALK.  Eight lanes per ray, lane j on voxel step pos + j of the ray's DDA (each lane advances the ray's state j
-//      times: the same f32 additions in the same order as a sequential walk).  The early-out needs more than
-//      max_consecutive_ray_collisions observed voxels IN A ROW, so with a current run of c the next mc + 1 - c
-//      exchanges happen whatever they return: those lanes exchange together -- one round trip for up to mc + 1 steps,
-//      and nothing is written that the sequential ray would not have written.  The lanes behind them PEEK at their
-//      slot with a plain load; a peeked prefix that cannot contain the stop is exchanged together with the
-//      unconditional steps of the next round (up to eight steps per round trip).  Only exchanges decide: a peek
-//      merely selects which exchanges to issue, so a slot that changes between peek and exchange costs, at worst, a
-//      few exchanges behind the stop (a window of one round trip; counted, `overrun` in the statistics).
+//   2. WALK.  Up to eight lanes per ray (four / two / one where a workgroup has more than 32 / 64 / 128 rays), lane j on
+//      voxel step pos + j of the ray's DDA (each lane advances the ray's state j times: the same f32 additions in the same
+//      order as a sequential walk).  The early-out needs more than max_consecutive_ray_collisions observed voxels IN A
+//      ROW, so with a current run of c the next mc + 1 - c exchanges happen whatever they return: those lanes exchange
+//      together -- one round trip for up to mc + 1 steps, and nothing is written that the sequential ray would not have
+//      written.  The lanes behind them PEEK at their slot with a plain load; a peeked prefix that cannot contain the
+//      stop is exchanged together with the unconditional steps of the next round (up to eight steps per round trip).
+//      Only exchanges decide: a peek merely selects which exchanges to issue, so a slot that changes between peek and
+//      exchange costs, at worst, a few exchanges behind the stop (a window of one round trip; counted, `overrun` in the
+//      statistics).  A wavefront runs its rounds without waiting for the other three.
 //   3. UPDATES.  Every voxel step that survives becomes a record {sdf, weight, colour} chained to its voxel in a hash
 //      table in LDS.  When the workgroup's rays are done (or the table is nearly full) ONE lane per distinct voxel
 //      looks the block up (allocating it if new), loads {distance, weight} and the colour, folds the chain over them
@@ -32,7 +33,11 @@
 // Every ordering this produces is one voxblox's threads can produce, with one stated exception: the exchanges a ray
 // issues in one round reach the L2 in no particular order, where a CPU thread's are sequentially consistent (another
 // ray can see step k + 1 observed and step k not yet, for the ~100 ns between two arrivals).
-// HBM is not what bounds this (a scan is a few MB): round trips of device-scope atomics are; see DESIGN.md 3.
+// HBM is not what bounds this (a scan is a few MB).  Measured (profiles/r05_tsdf_racing.txt; 64 x 1024 LiDAR scan, kernel
+// alone): launch + an almost empty kernel 7 us; + phase 1 10 us; + the walk 26 us; + the folds 29 us -- against 47-52 us
+// for the one-thread-per-point kernel; a 640 x 480 depth image 50 us against 174.  What is left of the walk is the
+// instruction stream of a round (~600 instructions and a dozen LDS trips around one memory round trip, one wavefront per
+// SIMD: nothing hides any of it), not memory.
 #include "vgx_tsdf_internal.h"
 
 #pragma clang fp contract(off)
@@ -97,7 +102,7 @@ __global__ __launch_bounds__(256) void tsdf_integrate_coop_kernel(TsdfLayerDev L
                                                                  float qz, float tx, float ty, float tz,
                                                                  const float* __restrict__ points_C,
                                                                  const uint32_t* __restrict__ rgba, long long n,
-                                                                 int freespace_points) {
+                                                                 int freespace_points, int cloud_width, int ablate) {
   __shared__ RayRec rays[256];
   __shared__ UpdateRec recs[kMaxRecs];
   __shared__ unsigned long long tkey[kTable];
@@ -110,6 +115,8 @@ __global__ __launch_bounds__(256) void tsdf_integrate_coop_kernel(TsdfLayerDev L
   unsigned long long st_updates = 0, st_dropped = 0, st_exch = 0, st_peeks = 0, st_blends = 0, st_voxels = 0, st_retries = 0,
                      st_overrun = 0, st_rounds_max = 0;
 
+  const bool tracing = STATS && I.wg_stats != nullptr;
+  if (tracing && tid == 0) I.wg_stats[(size_t)blockIdx.x * kWgStatWords + 0] = wall_clock64();
   for (int e = tid; e < kTable; e += 256) {
     tkey[e] = kEmptyKey;
     thead[e] = kNil;
@@ -124,10 +131,25 @@ __global__ __launch_bounds__(256) void tsdf_integrate_coop_kernel(TsdfLayerDev L
 
   // ---------------------------------------------------------------- phase 1: validity, start set, ray set-up
   {
-    const long long i = (long long)blockIdx.x * 256 + tid;
+    // Which point is this lane's?  An unorganised cloud: 256 consecutive points per workgroup.  An organised one
+    // (cloud_width = points per row: sensor_msgs/PointCloud2.width): a tile of 16 x 16 beams, a wavefront = 4 rows of 16 --
+    // the beams that end in one voxel are neighbours in BOTH directions, so a tile folds most of a voxel's updates in
+    // its own LDS, where 256 consecutive beams of one ring share every voxel with the rings above and below, i.e. with
+    // other workgroups (the per-voxel compare-and-swap chains of phase 3).  Which rays are cast and what they write is a
+    // legal order either way.
+    long long i = (long long)blockIdx.x * 256 + tid;
+    bool have_point = i < n;
+    if (cloud_width > 0) {
+      const int tiles_x = (cloud_width + 15) >> 4;
+      const int tile_y = (int)blockIdx.x / tiles_x, tile_x = (int)blockIdx.x - tile_y * tiles_x;
+      const int col = tile_x * 16 + (tid & 15);
+      const long long row = (long long)tile_y * 16 + (tid >> 4);
+      i = row * cloud_width + col;
+      have_point = col < cloud_width && i < n;
+    }
     bool cast = false;
     RayRec r;
-    if (i < n) {
+    if (have_point) {
       const float px = points_C[3 * i], py = points_C[3 * i + 1], pz = points_C[3 * i + 2];
       // isPointValid
       bool valid = true, is_clearing = false;
@@ -181,10 +203,19 @@ __global__ __launch_bounds__(256) void tsdf_integrate_coop_kernel(TsdfLayerDev L
   }
   __syncthreads();
   const uint32_t n_rays = sh_n_rays;
+  if (tracing && tid == 0) {
+    I.wg_stats[(size_t)blockIdx.x * kWgStatWords + 1] = wall_clock64();
+    I.wg_stats[(size_t)blockIdx.x * kWgStatWords + 2] = 0ull;
+  }
 
   // ---------------------------------------------------------------- phases 2 + 3: walk in rounds, flush
-  const int j = lane & (kLanesPerRay - 1);          // this lane's step within the group's window
-  const int gb = lane & ~(kLanesPerRay - 1);        // first lane of the group
+  // Lanes per ray: eight while the workgroup's rays all fit side by side (32 groups); a workgroup with more rays -- far
+  // walls, where every beam has its own start cell -- gives each ray fewer lanes rather than walking them 32 at a time
+  // (the unconditional window is mc + 1 = 3 steps with voxblox's default: four lanes lose little).
+  const int lpr = n_rays <= 32u ? 8 : (n_rays <= 64u ? 4 : (n_rays <= 128u ? 2 : 1));
+  const int j = lane & (lpr - 1);                   // this lane's step within the group's window
+  const int gb = lane & ~(lpr - 1);                 // first lane of the group
+  const uint32_t wmask = (1u << lpr) - 1u;
   // (a run of 2^24 observed voxels does not exist: the clamp only keeps mc + 1 - carry inside an int)
   const int mc = c.max_consecutive_ray_collisions < (1 << 24) ? c.max_consecutive_ray_collisions : (1 << 24);
   const int shift = L.vps_shift, vmask = L.vps - 1;
@@ -203,145 +234,175 @@ __global__ __launch_bounds__(256) void tsdf_integrate_coop_kernel(TsdfLayerDev L
   uint32_t rcolor = 0;
   unsigned long long rounds = 0;
 
-  bool more = n_rays > 0;
-  while (more) {
-    // (A) a group without a ray takes the next one
-    if (ray < 0) {
-      uint32_t k = 0;
-      if (j == 0) k = atomicAdd(&sh_next_ray, 1u);
-      k = (uint32_t)__shfl((int)k, gb);
-      if (k < n_rays) {
-        const RayRec& q = rays[k];
-        ray = (int)k;
-        cur[0] = q.curr[0]; cur[1] = q.curr[1]; cur[2] = q.curr[2];
-        sg[0] = (q.sign_bits & 3) - 1; sg[1] = ((q.sign_bits >> 2) & 3) - 1; sg[2] = ((q.sign_bits >> 4) & 3) - 1;
-        tn[0] = q.t_next[0]; tn[1] = q.t_next[1]; tn[2] = q.t_next[2];
-        ts[0] = q.t_step[0]; ts[1] = q.t_step[1]; ts[2] = q.t_step[2];
-        const long long steps = (long long)(((unsigned long long)q.steps_hi << 32) | q.steps_lo);
-        steps_left = steps + 1;
-        carry = 0;
-        peekbits = 0;
-        nvalid = 0;
-        rgx = q.gx; rgy = q.gy; rgz = q.gz; rweight = q.weight; rcolor = q.color;
-        rounds = 0;
+  // Rounds are a wavefront's own business: its groups fetch rays, exchange, decide and queue records without waiting
+  // for the other three (a round is ~600 instructions and a dozen LDS trips around ONE memory round trip, and with one
+  // wavefront per SIMD nothing hides any of it: a barrier per round made every wavefront pay for the slowest).  The
+  // workgroup meets only to fold: when every wavefront has run out of rays, or when the record pool may not take
+  // another round of all four (each checks the count BEFORE a round and adds at most 64 records: 512 + 4 x 64 fit).
+  bool all_done = n_rays == 0 || ablate >= 2;  // (ablate: attribution runs only, profiles/probes/run_racing_probe.sh)
+  uint32_t wg_rounds = 0, wg_folds = 0, my_retry_max = 0;
+  unsigned long long tk_lut = 0, tk_load = 0, tk_cas = 0, tk_ccas = 0;  // (tracing) this lane's ticks per flush stage
+  while (!all_done) {
+    while (true) {
+      const uint32_t pending = *(volatile uint32_t*)&sh_n_recs;
+      // (A) a group without a ray takes the next one
+      if (ray < 0 && *(volatile uint32_t*)&sh_next_ray < n_rays) {
+        uint32_t k = 0;
+        if (j == 0) k = atomicAdd(&sh_next_ray, 1u);
+        k = (uint32_t)__shfl((int)k, gb);
+        if (k < n_rays) {
+          const RayRec& q = rays[k];
+          ray = (int)k;
+          cur[0] = q.curr[0]; cur[1] = q.curr[1]; cur[2] = q.curr[2];
+          sg[0] = (q.sign_bits & 3) - 1; sg[1] = ((q.sign_bits >> 2) & 3) - 1; sg[2] = ((q.sign_bits >> 4) & 3) - 1;
+          tn[0] = q.t_next[0]; tn[1] = q.t_next[1]; tn[2] = q.t_next[2];
+          ts[0] = q.t_step[0]; ts[1] = q.t_step[1]; ts[2] = q.t_step[2];
+          const long long steps = (long long)(((unsigned long long)q.steps_hi << 32) | q.steps_lo);
+          steps_left = steps + 1;
+          carry = 0;
+          peekbits = 0;
+          nvalid = 0;
+          rgx = q.gx; rgy = q.gy; rgz = q.gz; rweight = q.weight; rcolor = q.color;
+          rounds = 0;
+        }
       }
-    }
-    // (B) one round of the group's ray
-    bool emit = false;
-    int vx = 0, vy = 0, vz = 0;
-    if (ray >= 0) {
-      const int remaining = steps_left < (long long)kLanesPerRay ? (int)steps_left : kLanesPerRay;
-      // exchanges that happen whatever they return: the stop needs a run of more than mc
-      int must = mc + 1 - carry;
-      must = must < 1 ? 1 : must;
-      must = must > remaining ? remaining : must;
-      int w = must;
-      if (nvalid > must) {  // extend over the peeked prefix up to (and including) the step the peeks say stops the ray
+      if (!__any(ray >= 0) || pending > (uint32_t)kFlushAt) break;
+      ++wg_rounds;
+      // (B) one round of the group's ray
+      bool emit = false;
+      int vx = 0, vy = 0, vz = 0;
+      float sdf = 0.0f, uw = 0.0f;
+      if (ray >= 0) {
+        const int remaining = steps_left < (long long)lpr ? (int)steps_left : lpr;
+        // exchanges that happen whatever they return: the stop needs a run of more than mc
+        int must = mc + 1 - carry;
+        must = must < 1 ? 1 : must;
+        must = must > remaining ? remaining : must;
+        int w = must;
+        if (nvalid > must) {  // extend over the peeked prefix up to (and including) the step the peeks say stops the ray
+          int run = carry, cut = -1;
+          for (int k = 0; k < nvalid; ++k) {
+            run = ((peekbits >> k) & 1u) ? run + 1 : 0;
+            if (run > mc) {
+              cut = k;
+              break;
+            }
+          }
+          w = cut >= 0 ? (cut + 1 > must ? cut + 1 : must) : nvalid;
+          w = w > remaining ? remaining : w;
+        }
+        // this lane's voxel: the ray's state advanced j times (RayCaster::nextRayIndex, the same additions in the same order)
+        int c0 = cur[0], c1 = cur[1], c2 = cur[2];
+        float t0 = tn[0], t1 = tn[1], t2 = tn[2];
+#pragma unroll
+        for (int k = 0; k < kLanesPerRay; ++k) {
+          if (k < lpr) {  // (uniform)
+            if (k == j) {
+              vx = c0; vy = c1; vz = c2;
+            }
+            if (k <= j) {  // (lane j also takes step j: its state afterwards is the ray's at pos + j + 1)
+              int mm = 0;
+              float tm = t0;
+              if (t1 < tm) { mm = 1; tm = t1; }
+              if (t2 < tm) { mm = 2; }
+              c0 += mm == 0 ? sg[0] : 0; c1 += mm == 1 ? sg[1] : 0; c2 += mm == 2 ? sg[2] : 0;
+              t0 += mm == 0 ? ts[0] : 0.0f; t1 += mm == 1 ? ts[1] : 0.0f; t2 += mm == 2 ? ts[2] : 0.0f;
+            }
+          }
+        }
+        const bool in_window = j < remaining;
+        const bool do_x = j < w, do_peek = in_window && !do_x;
+        const unsigned int h = (unsigned int)vx + (unsigned int)vy * 17191u + (unsigned int)vz * 295530481u;
+        const unsigned long long v = (unsigned long long)h + I.observed_offset;
+        unsigned long long got = 0ull;
+        if (do_x) got = atomicExch(&I.observed_set[v & kSetMask], v);
+        else if (do_peek) got = __hip_atomic_load(&I.observed_set[v & kSetMask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (while that is in flight: what this step would write, should it survive)
+        if (do_x) update_terms(L.voxel_size, c, tx, ty, tz, rgx, rgy, rgz, vx, vy, vz, rweight, sdf, uw);
+        const bool seen = (do_x || do_peek) && got == v;
+        const uint32_t xbits = (uint32_t)(__ballot(do_x && seen) >> gb) & wmask;
+        const uint32_t pbits = (uint32_t)(__ballot(do_peek && seen) >> gb) & wmask;
+        if (STATS) {
+          st_exch += do_x ? 1u : 0u;
+          st_peeks += do_peek ? 1u : 0u;
+        }
+        ++rounds;
+        // what the exchanges say
         int run = carry, cut = -1;
-        for (int k = 0; k < nvalid; ++k) {
-          run = ((peekbits >> k) & 1u) ? run + 1 : 0;
+        for (int k = 0; k < w; ++k) {
+          run = ((xbits >> k) & 1u) ? run + 1 : 0;
           if (run > mc) {
             cut = k;
             break;
           }
         }
-        w = cut >= 0 ? (cut + 1 > must ? cut + 1 : must) : nvalid;
-        w = w > remaining ? remaining : w;
-      }
-      // this lane's voxel: the ray's state advanced j times (RayCaster::nextRayIndex, the same additions in the same order)
-      int c0 = cur[0], c1 = cur[1], c2 = cur[2];
-      float t0 = tn[0], t1 = tn[1], t2 = tn[2];
-#pragma unroll
-      for (int k = 0; k < kLanesPerRay; ++k) {
-        if (k == j) {
-          vx = c0; vy = c1; vz = c2;
-        }
-        if (k <= j) {  // (lane j also takes step j: its state afterwards is the ray's at pos + j + 1)
-          int mm = 0;
-          float tm = t0;
-          if (t1 < tm) { mm = 1; tm = t1; }
-          if (t2 < tm) { mm = 2; }
-          c0 += mm == 0 ? sg[0] : 0; c1 += mm == 1 ? sg[1] : 0; c2 += mm == 2 ? sg[2] : 0;
-          t0 += mm == 0 ? ts[0] : 0.0f; t1 += mm == 1 ? ts[1] : 0.0f; t2 += mm == 2 ? ts[2] : 0.0f;
+        const int n_upd = cut >= 0 ? cut : w;
+        if (STATS && cut >= 0 && j == 0) st_overrun += (unsigned)(w - 1 - cut);  // exchanges behind the stop (a peek went stale)
+        emit = j < n_upd;
+        const bool finished = cut >= 0 || (long long)w == steps_left;
+        if (finished) {
+          if (STATS && j == 0) st_rounds_max = rounds > st_rounds_max ? rounds : st_rounds_max;
+          ray = -1;
+        } else {
+          carry = run;
+          steps_left -= w;
+          // the ray's state at pos + w: lane w - 1's state after its own step
+          const int src = gb + w - 1;
+          cur[0] = __shfl(c0, src); cur[1] = __shfl(c1, src); cur[2] = __shfl(c2, src);
+          tn[0] = __shfl(t0, src); tn[1] = __shfl(t1, src); tn[2] = __shfl(t2, src);
+          peekbits = pbits >> w;     // peeks of window positions w .. remaining - 1 become positions 0 ..
+          nvalid = remaining - w;
         }
       }
-      const bool in_window = j < remaining;
-      const bool do_x = j < w, do_peek = in_window && !do_x;
-      const unsigned int h = (unsigned int)vx + (unsigned int)vy * 17191u + (unsigned int)vz * 295530481u;
-      const unsigned long long v = (unsigned long long)h + I.observed_offset;
-      unsigned long long got = 0ull;
-      if (do_x) got = atomicExch(&I.observed_set[v & kSetMask], v);
-      else if (do_peek) got = __hip_atomic_load(&I.observed_set[v & kSetMask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const bool seen = (do_x || do_peek) && got == v;
-      const uint32_t xbits = (uint32_t)((__ballot(do_x && seen) >> gb) & 0xffull);
-      const uint32_t pbits = (uint32_t)((__ballot(do_peek && seen) >> gb) & 0xffull);
-      if (STATS) {
-        st_exch += do_x ? 1u : 0u;
-        st_peeks += do_peek ? 1u : 0u;
-      }
-      ++rounds;
-      // what the exchanges say
-      int run = carry, cut = -1;
-      for (int k = 0; k < w; ++k) {
-        run = ((xbits >> k) & 1u) ? run + 1 : 0;
-        if (run > mc) {
-          cut = k;
-          break;
+      // (C) the round's surviving steps become records chained to their voxel
+      {
+        bool do_rec = false;
+        if (emit) {
+          do_rec = (unsigned)(vx + kBias) < (2u << 20) && (unsigned)(vy + kBias) < (2u << 20) && (unsigned)(vz + kBias) < (2u << 20);
+          if (!do_rec) ++st_dropped;  // beyond +-2^20 voxels: no block table reaches there
         }
-      }
-      const int n_upd = cut >= 0 ? cut : w;
-      if (STATS && cut >= 0 && j == 0) st_overrun += (unsigned)(w - 1 - cut);  // exchanges behind the stop (a peek went stale)
-      emit = j < n_upd;
-      const bool finished = cut >= 0 || (long long)w == steps_left;
-      if (finished) {
-        if (STATS && j == 0) st_rounds_max = rounds > st_rounds_max ? rounds : st_rounds_max;
-        ray = -1;
-      } else {
-        carry = run;
-        steps_left -= w;
-        // the ray's state at pos + w: lane w - 1's state after its own step
-        const int src = gb + w - 1;
-        cur[0] = __shfl(c0, src); cur[1] = __shfl(c1, src); cur[2] = __shfl(c2, src);
-        tn[0] = __shfl(t0, src); tn[1] = __shfl(t1, src); tn[2] = __shfl(t2, src);
-        peekbits = pbits >> w;     // peeks of window positions w .. remaining - 1 become positions 0 ..
-        nvalid = remaining - w;
-      }
-    }
-    // (C) the round's surviving steps become records chained to their voxel
-    if (emit) {
-      float sdf, uw;
-      update_terms(L.voxel_size, c, tx, ty, tz, rgx, rgy, rgz, vx, vy, vz, rweight, sdf, uw);
-      const bool in_range = (unsigned)(vx + kBias) < (2u << 20) && (unsigned)(vy + kBias) < (2u << 20) &&
-                            (unsigned)(vz + kBias) < (2u << 20);
-      if (!in_range) {
-        ++st_dropped;  // beyond +-2^20 voxels: no block table reaches there
-      } else {
-        const unsigned long long key = voxel_key(vx, vy, vz);
-        const uint32_t rec = atomicAdd(&sh_n_recs, 1u);
-        uint32_t slot = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & (kTable - 1);
-        while (true) {
-          const unsigned long long prev = atomicCAS(&tkey[slot], kEmptyKey, key);
-          if (prev == kEmptyKey) {
-            occ[atomicAdd(&sh_n_occ, 1u)] = (uint16_t)slot;
-            break;
+        // one LDS atomic per wavefront for the records' slots
+        const unsigned long long rm = __ballot(do_rec);
+        uint32_t rec_base = 0;
+        if (rm) {
+          if (lane == (int)__ffsll((long long)rm) - 1) rec_base = atomicAdd(&sh_n_recs, (uint32_t)__popcll(rm));
+          rec_base = (uint32_t)__shfl((int)rec_base, (int)__ffsll((long long)rm) - 1);
+        }
+        if (do_rec) {
+          const unsigned long long key = voxel_key(vx, vy, vz);
+          const uint32_t rec = rec_base + (uint32_t)__popcll(rm & ((1ull << lane) - 1ull));
+          uint32_t slot = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & (kTable - 1);
+          while (true) {
+            const unsigned long long prev = atomicCAS(&tkey[slot], kEmptyKey, key);
+            if (prev == kEmptyKey) {
+              occ[atomicAdd(&sh_n_occ, 1u)] = (uint16_t)slot;
+              break;
+            }
+            if (prev == key) break;
+            slot = (slot + 1) & (kTable - 1);
           }
-          if (prev == key) break;
-          slot = (slot + 1) & (kTable - 1);
+          UpdateRec u;
+          u.sdf = sdf; u.w = uw; u.color = rcolor;
+          u.next = atomicExch(&thead[slot], rec);
+          recs[rec] = u;
         }
-        UpdateRec u;
-        u.sdf = sdf; u.w = uw; u.color = rcolor;
-        u.next = atomicExch(&thead[slot], rec);
-        recs[rec] = u;
       }
     }
-    __syncthreads();
-    // (D) all rays handed out and finished?  table nearly full?
+    // (D) the workgroup meets: all rays handed out and finished?
     const bool busy = ray >= 0 || sh_next_ray < n_rays;
-    more = __syncthreads_or(busy ? 1 : 0) != 0;
-    if (!more || sh_n_recs > (uint32_t)kFlushAt) {
+    all_done = __syncthreads_or(busy ? 1 : 0) == 0;
+    {
+      if (tracing && tid == 0 && all_done) I.wg_stats[(size_t)blockIdx.x * kWgStatWords + 2] = wall_clock64();
       // ------------------------------------------------------------ phase 3: one lane per distinct voxel
       const uint32_t n_occ = sh_n_occ;
-      for (uint32_t o = (uint32_t)tid; o < n_occ; o += 256) {
+      wg_folds += n_occ;
+      if (ablate >= 1)
+        for (uint32_t o = (uint32_t)tid; o < n_occ; o += 256) {
+          tkey[occ[o]] = kEmptyKey;
+          thead[occ[o]] = kNil;
+        }
+      for (uint32_t o = (uint32_t)tid; o < n_occ && ablate < 1; o += 256) {
+        uint32_t my_retries = 0;
         const uint32_t slot = occ[o];
         const unsigned long long key = tkey[slot];
         const uint32_t head = thead[slot];
@@ -349,7 +410,22 @@ __global__ __launch_bounds__(256) void tsdf_integrate_coop_kernel(TsdfLayerDev L
         thead[slot] = kNil;
         const int kx = (int)((key >> 42) & 0x1fffffull) - kBias, ky = (int)((key >> 21) & 0x1fffffull) - kBias,
                   kz = (int)(key & 0x1fffffull) - kBias;
-        const int bslot = get_or_allocate_block(L, kx >> shift, ky >> shift, kz >> shift);
+        // the block: a plain (cacheable) look at the table first -- an entry >= 0 never changes inside a kernel, anything
+        // else (free, being allocated, stale in this XCD's L2) goes through the atomic path
+        int bslot = -1;
+        unsigned long long tk0 = tracing ? wall_clock64() : 0ull;
+        {
+          const int bx = kx >> shift, by = ky >> shift, bz = kz >> shift;
+          const int rx = bx - L.lut_min[0], ry = by - L.lut_min[1], rz = bz - L.lut_min[2];
+          if ((unsigned)rx < (unsigned)L.lut_dim[0] && (unsigned)ry < (unsigned)L.lut_dim[1] && (unsigned)rz < (unsigned)L.lut_dim[2])
+            bslot = L.lut[rx + L.lut_dim[0] * (ry + L.lut_dim[1] * rz)];
+          if (bslot < 0) bslot = get_or_allocate_block(L, bx, by, bz);
+        }
+        if (tracing) {
+          const unsigned long long now = wall_clock64() + (unsigned long long)(bslot & 0);  // (after the table value is in)
+          tk_lut += now - tk0;
+          tk0 = now;
+        }
         uint32_t chain = 0;
         for (uint32_t q = head; q != kNil; q = recs[q].next) ++chain;
         if (bslot < 0) {
@@ -362,6 +438,11 @@ __global__ __launch_bounds__(256) void tsdf_integrate_coop_kernel(TsdfLayerDev L
         uint32_t* caddr = &L.rgba[at];
         unsigned long long old = __hip_atomic_load(vaddr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint32_t oc = __hip_atomic_load(caddr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tracing) {
+          const unsigned long long now = wall_clock64() + (old & 0ull) + (unsigned long long)(oc & 0u);
+          tk_load += now - tk0;
+          tk0 = now;
+        }
         // updateTsdfVoxel for every record of the chain in turn, on registers
         while (true) {
           float d = __uint_as_float((unsigned)(old & 0xffffffffull)), W = __uint_as_float((unsigned)(old >> 32));
@@ -385,7 +466,13 @@ __global__ __launch_bounds__(256) void tsdf_integrate_coop_kernel(TsdfLayerDev L
           if (prev != old) {  // another workgroup got in between: fold again over what it left
             old = prev;
             if (STATS) ++st_retries;
+            ++my_retries;
             continue;
+          }
+          if (tracing) {
+            const unsigned long long now = wall_clock64() + (prev & 0ull);
+            tk_cas += now - tk0;
+            tk0 = now;
           }
           if (any_blend) {
             if (STATS) {
@@ -404,12 +491,15 @@ __global__ __launch_bounds__(256) void tsdf_integrate_coop_kernel(TsdfLayerDev L
                 W2 = fminf(c.max_weight, new_weight);
               }
               if (STATS) ++st_retries;
+              ++my_retries;
               prevc = atomicCAS(caddr, oc, col);
             }
+            if (tracing) tk_ccas += wall_clock64() + (unsigned long long)(prevc & 0u) - tk0;
           }
           break;
         }
         if (STATS) ++st_voxels;
+        my_retry_max = my_retries > my_retry_max ? my_retries : my_retry_max;
       }
       __syncthreads();
       if (tid == 0) {
@@ -420,47 +510,94 @@ __global__ __launch_bounds__(256) void tsdf_integrate_coop_kernel(TsdfLayerDev L
     }
   }
 
-  // one atomic per wave and counter
+  // Nothing is counted on an uncounted scan (every wavefront adding to ONE word at the end of a 300 000-point scan is
+  // 4800 same-address atomics: tens of microseconds by themselves); dropped updates -- the GPU ran out of memory --
+  // are reported in both modes.
+  if (__any(st_dropped != 0ull)) {
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    st_updates += __shfl_xor(st_updates, off, 64);
-    st_dropped += __shfl_xor(st_dropped, off, 64);
-    if (STATS) {
-      st_exch += __shfl_xor(st_exch, off, 64);
-      st_peeks += __shfl_xor(st_peeks, off, 64);
-      st_blends += __shfl_xor(st_blends, off, 64);
-      st_voxels += __shfl_xor(st_voxels, off, 64);
-      st_retries += __shfl_xor(st_retries, off, 64);
-      st_overrun += __shfl_xor(st_overrun, off, 64);
-      const unsigned long long other = __shfl_xor(st_rounds_max, off, 64);
-      st_rounds_max = other > st_rounds_max ? other : st_rounds_max;
-    }
+    for (int off = 32; off >= 1; off >>= 1) st_dropped += __shfl_xor(st_dropped, off, 64);
+    if (lane == 0) atomicAdd(L.dropped, st_dropped);
   }
-  if (lane == 0) {
-    if (st_updates) atomicAdd(I.n_updates, st_updates);
-    if (st_dropped) atomicAdd(L.dropped, st_dropped);
-    if (STATS) {  // vgx_tsdf_integrator_walk_stats (bench header)
-      if (st_rounds_max) atomicMax(I.n_updates + 1, st_rounds_max);
-      if (st_exch) atomicAdd(I.n_updates + 2, st_exch);
-      if (st_blends) atomicAdd(I.n_updates + 3, st_blends);
-      if (st_peeks) atomicAdd(I.n_updates + 4, st_peeks);
-      if (st_voxels) atomicAdd(I.n_updates + 5, st_voxels);
-      if (st_retries) atomicAdd(I.n_updates + 6, st_retries);
-      if (st_overrun) atomicAdd(I.n_updates + 7, st_overrun);
+  if (STATS) {
+    // a counted scan: one row per workgroup, summed by reduce_wg_stats_kernel (no two workgroups share a word)
+    __shared__ unsigned long long sh_stat[8];
+    __shared__ uint32_t sh_retry_max;
+    if (tid < 8) sh_stat[tid] = 0ull;
+    if (tid == 0) sh_retry_max = 0;
+    __syncthreads();
+    if (st_updates) atomicAdd(&sh_stat[0], st_updates);
+    if (st_rounds_max) atomicMax(&sh_stat[1], st_rounds_max);
+    if (st_exch) atomicAdd(&sh_stat[2], st_exch);
+    if (st_blends) atomicAdd(&sh_stat[3], st_blends);
+    if (st_peeks) atomicAdd(&sh_stat[4], st_peeks);
+    if (st_voxels) atomicAdd(&sh_stat[5], st_voxels);
+    if (st_retries) atomicAdd(&sh_stat[6], st_retries);
+    if (st_overrun) atomicAdd(&sh_stat[7], st_overrun);
+    if (my_retry_max) atomicMax(&sh_retry_max, my_retry_max);
+    __syncthreads();
+    if (tracing) {
+      __shared__ unsigned long long sh_tk[4];
+      if (tid < 4) sh_tk[tid] = 0ull;
+      __syncthreads();
+      atomicMax(&sh_tk[0], tk_lut); atomicMax(&sh_tk[1], tk_load); atomicMax(&sh_tk[2], tk_cas); atomicMax(&sh_tk[3], tk_ccas);
+      __syncthreads();
+      if (tid < 4) I.wg_stats[(size_t)blockIdx.x * kWgStatWords + 16 + tid] = sh_tk[tid];
+    }
+    if (tracing && tid < 8) I.wg_stats[(size_t)blockIdx.x * kWgStatWords + 8 + tid] = sh_stat[tid];
+    if (tracing && tid == 0) {
+      unsigned long long* t = I.wg_stats + (size_t)blockIdx.x * kWgStatWords;
+      t[3] = wall_clock64();
+      t[4] = n_rays; t[5] = wg_rounds; t[6] = wg_folds; t[7] = sh_retry_max;
     }
   }
 }
 
+// counted scans: the workgroups' rows (words 8..15: updates, longest chain of rounds, exchanges, colour blends, peeks,
+// per-voxel folds, repeated folds, exchanges behind a stop) -> I.n_updates[0..7]
+__global__ __launch_bounds__(256) void reduce_wg_stats_kernel(const unsigned long long* __restrict__ rows, long long n_rows,
+                                                             unsigned long long* __restrict__ out) {
+  __shared__ unsigned long long sh[8];
+  if (threadIdx.x < 8) sh[threadIdx.x] = 0ull;
+  __syncthreads();
+  unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (long long r = threadIdx.x; r < n_rows; r += 256) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const unsigned long long v = rows[r * kWgStatWords + 8 + k];
+      acc[k] = k == 1 ? (v > acc[k] ? v : acc[k]) : acc[k] + v;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (k == 1) atomicMax(&sh[k], acc[k]); else atomicAdd(&sh[k], acc[k]);
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) out[threadIdx.x] = sh[threadIdx.x];
+}
+
 // the racing scan's launch (vgx_tsdf.hip integrate_locked); stats: the scan is a counted one (n_updates != NULL)
+long long racing_scan_workgroups(long long n, int cloud_width) {
+  if (cloud_width > 0 && n % cloud_width == 0)
+    return (long long)((cloud_width + 15) / 16) * ((n / cloud_width + 15) / 16);
+  return (n + 255) / 256;
+}
+
 hipError_t launch_racing_scan(hipStream_t stream, const TsdfLayerDev& L, const TsdfIntegratorDev& I, const float T[7],
-                              const float* d_points, const uint32_t* d_rgba, long long n, int freespace, bool stats) {
-  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-  if (stats)
+                              const float* d_points, const uint32_t* d_rgba, long long n, int freespace, bool stats,
+                              int cloud_width) {
+  // an organised cloud (cloud_width points per row, n a whole number of rows): one workgroup per 16 x 16 tile of beams
+  const bool tiled = cloud_width > 0 && n % cloud_width == 0;
+  const long long wgs = racing_scan_workgroups(n, tiled ? cloud_width : 0);
+  const dim3 grid((unsigned)wgs), block(256);
+  const int cw = tiled ? cloud_width : 0;
+  static const int ablate = getenv("VGX_TSDF_ABLATE") ? atoi(getenv("VGX_TSDF_ABLATE")) : 0;
+  if (stats) {
     hipLaunchKernelGGL(tsdf_integrate_coop_kernel<true>, grid, block, 0, stream, L, I, T[0], T[1], T[2], T[3], T[4], T[5], T[6],
-                       d_points, d_rgba, n, freespace);
-  else
+                       d_points, d_rgba, n, freespace, cw, ablate);
+    hipLaunchKernelGGL(reduce_wg_stats_kernel, dim3(1), block, 0, stream, I.wg_stats, (long long)grid.x, I.n_updates);
+  } else
     hipLaunchKernelGGL(tsdf_integrate_coop_kernel<false>, grid, block, 0, stream, L, I, T[0], T[1], T[2], T[3], T[4], T[5], T[6],
-                       d_points, d_rgba, n, freespace);
+                       d_points, d_rgba, n, freespace, cw, ablate);
   return hipGetLastError();
 }
 

@@ -33,7 +33,11 @@ struct TsdfIntegratorDev {
   unsigned long long* observed_set;  // [2^20]
   unsigned long long start_offset, observed_offset;
   unsigned long long* n_updates;  // [kScanStatWords]: voxel updates, then the walk statistics of a counted scan
+  unsigned long long* wg_stats;   // counted scans of the cooperative kernel: [workgroups][kWgStatWords]
 };
+// a workgroup's row: 0..3 wall_clock64 at its start / rays queued / walk done / end, 4 rays, 5 rounds, 6 per-voxel folds,
+// 7 longest chain of repeated folds, 8..15 what reduce_wg_stats_kernel sums into n_updates[0..7]
+constexpr int kWgStatWords = 24;  // 16..19: the slowest lane's ticks in the block lookup / the two loads / the {d,w} CAS loop / the colour CAS loop
 constexpr int kScanStatWords = 8;
 
 constexpr unsigned kSetBits = 20;
@@ -415,6 +419,9 @@ struct vgx_tsdf_integrator_s {
   void* d_msort = nullptr;
   size_t msort_bytes = 0;
   long long merged_cap = 0;
+  unsigned long long* d_wg_stats = nullptr;  // counted racing scans: one row per workgroup (grown on demand)
+  long long wg_stats_cap = 0, wg_stats_rows = 0;
+  int cloud_width = 0;  // vgx_tsdf_integrator_set_cloud_width: points per row of the scans to come (0: unorganised)
   vgx::DetScratch* det = nullptr;  // reproducible mode's buffers (vgx_tsdf_det.hip), grown on demand
   // reproducible mode, bounded speculation (vgx_tsdf_det.hip det_count_kernel): a scan whose complete walks are more
   // than det_cap_threshold steps is written out det_cap steps deep at first.  Nothing but time depends on either;
@@ -439,9 +446,12 @@ int tsdf_reserve_for_scan(vgx_tsdf_layer L, const float origin[3], float reach);
 int64_t tsdf_last_scan_bound(vgx_tsdf_layer L);
 void tsdf_request_readback(vgx_tsdf_layer L);
 // vgx_tsdf_coop.hip: the racing scan (one workgroup per 256 points: start set, cooperative walk, per-voxel folds);
-// stats: gather vgx_tsdf_integrator_walk_stats' numbers (a counted scan)
+// stats: gather vgx_tsdf_integrator_walk_stats' numbers (a counted scan: I.wg_stats must hold a row per workgroup)
+// cloud_width: points per row of an organised cloud (0: unorganised) -- only which workgroup takes which point
 hipError_t launch_racing_scan(hipStream_t stream, const TsdfLayerDev& L, const TsdfIntegratorDev& I, const float T[7],
-                              const float* d_points, const uint32_t* d_rgba, long long n, int freespace, bool stats);
+                              const float* d_points, const uint32_t* d_rgba, long long n, int freespace, bool stats,
+                              int cloud_width);
+long long racing_scan_workgroups(long long n, int cloud_width);
 // vgx_tsdf_det.hip: one scan in the reproducible mode (vgx_tsdf_config.deterministic); the caller
 // holds the integrator's and the context's locks, the approximate sets have been reset for the scan
 // `order`: order[seq] = index of the point visited seq-th (integration_order "sorted"), nullptr = "mixed"
