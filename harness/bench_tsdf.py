@@ -126,7 +126,7 @@ def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=8):
         kernel_ms = float(np.median(per_scan_ms[1:]))
         # the floor of that measurement: a one-point scan timed the same way (launch + an almost empty kernel)
         one_point_ms = []
-        for k in range(1, 6):
+        for k in range(1, min(6, scans)):
             ctx.synchronize()
             ctx.timer_start()
             integ.integrate_device(poses[k], dev[k].data_ptr(), None, 1)

@@ -61,9 +61,9 @@ VGX_API int vgx_bench_stream_ceiling(vgx_ctx ctx, const void* d_src, int64_t rea
  *   stats[6]  exchanges issued behind a ray's stopping step because a peeked slot changed before the exchange */
 VGX_API int vgx_tsdf_integrator_walk_stats(vgx_tsdf_integrator integrator, int64_t stats[7]);
 
-/* Where the racing kernel's time goes: every COUNTED racing scan leaves one row of 24 words per workgroup (256 points):
+/* Where the racing kernel's time goes: every COUNTED racing scan leaves one row of 16 words per workgroup (256 points):
  * four wall_clock64 stamps -- start, rays queued (phase 1 done), walk done, end -- then its rays, rounds, per-voxel folds
- * and longest chain of repeated folds, then the eight sums behind vgx_tsdf_integrator_walk_stats.  rows[workgroup][24] (16..19: the slowest lane's ticks in the block lookup, the loads, the two compare-and-swap loops);
+ * and longest chain of repeated folds, then the eight sums behind vgx_tsdf_integrator_walk_stats.  rows[workgroup][16];
  * *clock_khz = the counter's rate. */
 VGX_API int vgx_tsdf_integrator_read_trace(vgx_tsdf_integrator integrator, int64_t* rows, int64_t max_workgroups,
                                            int64_t* n_workgroups, int64_t* clock_khz);

@@ -79,8 +79,7 @@ def main(scans=20):
                 if k == 5:
                     worst = np.argsort(t[:, 3] - t[:, 0])[::-1][:6]
                     slowest = [{"wg": int(w_), "us": [round(float(x), 2) for x in t[w_, :4]], "rays": int(t[w_, 4]), "rounds": int(t[w_, 5]),
-                                "folds": int(t[w_, 6]), "retry_chain": int(t[w_, 7]),
-                                "slowest_lane_us_lut_load_cas_ccas": [round(float(x), 2) for x in t[w_, 16:20]]} for w_ in worst]
+                                "folds": int(t[w_, 6]), "retry_chain": int(t[w_, 7])} for w_ in worst]
         # the floor of the measurement itself: a one-point scan timed the same way
         one = []
         for k in range(1, 8):

@@ -831,7 +831,7 @@ class FastTsdfIntegrator:
     def read_trace(self, max_workgroups):
         """last counted racing scan -> [workgroups][16] float64: four stamps in microseconds relative to the first start,
         then rays, rounds, per-voxel folds, longest chain of repeated folds, and the workgroup's eight statistics"""
-        buf = np.zeros((int(max_workgroups), 24), np.int64)
+        buf = np.zeros((int(max_workgroups), 16), np.int64)
         n, khz = C.c_int64(), C.c_int64()
         self.ctx.check(self.ctx.lib.vgx_tsdf_integrator_read_trace(self.h, _ptr(buf, i64p), int(max_workgroups),
                                                                    C.byref(n), C.byref(khz)))
@@ -839,7 +839,6 @@ class FastTsdfIntegrator:
         if len(t):
             t0 = t[:, 0].min()
             t[:, :4] = (t[:, :4] - t0) * 1e3 / max(khz.value, 1)
-            t[:, 16:20] = t[:, 16:20] * 1e3 / max(khz.value, 1)     # the slowest lane's microseconds per flush stage
         return t
 
     def walk_stats(self):

@@ -49,6 +49,7 @@ namespace {
 constexpr int kLanesPerRay = 8;
 constexpr int kMaxRecs = 768;                 // update records pending in LDS
 constexpr int kTable = 1024;                  // voxel hash table (power of two, load factor <= 0.75)
+static_assert(kTable == 0x400, "phase 3 keeps a flag above the slot bits of occ[]: occ[o] & 0x3ff");
 constexpr int kFlushAt = kMaxRecs - 256;      // a round adds at most 256 records
 constexpr unsigned long long kEmptyKey = ~0ull;
 constexpr uint32_t kNil = 0xffffffffu;
@@ -241,7 +242,6 @@ __global__ __launch_bounds__(256) void tsdf_integrate_coop_kernel(TsdfLayerDev L
   // another round of all four (each checks the count BEFORE a round and adds at most 64 records: 512 + 4 x 64 fit).
   bool all_done = n_rays == 0 || ablate >= 2;  // (ablate: attribution runs only, profiles/probes/run_racing_probe.sh)
   uint32_t wg_rounds = 0, wg_folds = 0, my_retry_max = 0;
-  unsigned long long tk_lut = 0, tk_load = 0, tk_cas = 0, tk_ccas = 0;  // (tracing) this lane's ticks per flush stage
   while (!all_done) {
     while (true) {
       const uint32_t pending = *(volatile uint32_t*)&sh_n_recs;
@@ -368,19 +368,32 @@ __global__ __launch_bounds__(256) void tsdf_integrate_coop_kernel(TsdfLayerDev L
           if (lane == (int)__ffsll((long long)rm) - 1) rec_base = atomicAdd(&sh_n_recs, (uint32_t)__popcll(rm));
           rec_base = (uint32_t)__shfl((int)rec_base, (int)__ffsll((long long)rm) - 1);
         }
+        uint32_t slot = 0;
+        bool is_new = false;
         if (do_rec) {
           const unsigned long long key = voxel_key(vx, vy, vz);
-          const uint32_t rec = rec_base + (uint32_t)__popcll(rm & ((1ull << lane) - 1ull));
-          uint32_t slot = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & (kTable - 1);
+          slot = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & (kTable - 1);
           while (true) {
             const unsigned long long prev = atomicCAS(&tkey[slot], kEmptyKey, key);
             if (prev == kEmptyKey) {
-              occ[atomicAdd(&sh_n_occ, 1u)] = (uint16_t)slot;
+              is_new = true;
               break;
             }
             if (prev == key) break;
             slot = (slot + 1) & (kTable - 1);
           }
+        }
+        // the voxels this round meets for the first time, listed in lane order = ray by ray, step by step: phase 3
+        // allocates new blocks in list order, so a scan of ONE ray allocates them in the order a sequential walk does
+        const unsigned long long nm = __ballot(is_new);
+        uint32_t occ_base = 0;
+        if (nm) {
+          if (lane == (int)__ffsll((long long)nm) - 1) occ_base = atomicAdd(&sh_n_occ, (uint32_t)__popcll(nm));
+          occ_base = (uint32_t)__shfl((int)occ_base, (int)__ffsll((long long)nm) - 1);
+        }
+        if (is_new) occ[occ_base + (uint32_t)__popcll(nm & ((1ull << lane) - 1ull))] = (uint16_t)slot;
+        if (do_rec) {
+          const uint32_t rec = rec_base + (uint32_t)__popcll(rm & ((1ull << lane) - 1ull));
           UpdateRec u;
           u.sdf = sdf; u.w = uw; u.color = rcolor;
           u.next = atomicExch(&thead[slot], rec);
@@ -401,9 +414,39 @@ __global__ __launch_bounds__(256) void tsdf_integrate_coop_kernel(TsdfLayerDev L
           tkey[occ[o]] = kEmptyKey;
           thead[occ[o]] = kNil;
         }
+      // New blocks first, in list order (one lane; a plain look at the table tells which voxels need one -- a handful per
+      // scan once the layer exists): the order a sequential walk allocates them in when the scan is a single ray, and
+      // SOME serial order otherwise, as under voxblox's block mutex.
+      {
+        bool need = false;
+        for (uint32_t o = (uint32_t)tid; o < n_occ && ablate < 1; o += 256) {
+          const unsigned long long key = tkey[occ[o] & 0x3ffu];
+          const int bx = ((int)((key >> 42) & 0x1fffffull) - kBias) >> shift, by = ((int)((key >> 21) & 0x1fffffull) - kBias) >> shift,
+                    bz = ((int)(key & 0x1fffffull) - kBias) >> shift;
+          const int rx = bx - L.lut_min[0], ry = by - L.lut_min[1], rz = bz - L.lut_min[2];
+          int e = -1;
+          if ((unsigned)rx < (unsigned)L.lut_dim[0] && (unsigned)ry < (unsigned)L.lut_dim[1] && (unsigned)rz < (unsigned)L.lut_dim[2])
+            e = L.lut[rx + L.lut_dim[0] * (ry + L.lut_dim[1] * rz)];
+          if (e < 0) {
+            occ[o] |= 0x8000u;
+            need = true;
+          }
+        }
+        if (__syncthreads_or(need ? 1 : 0)) {
+          if (tid == 0)
+            for (uint32_t o = 0; o < n_occ; ++o)
+              if (occ[o] & 0x8000u) {
+                const unsigned long long key = tkey[occ[o] & 0x3ffu];
+                (void)get_or_allocate_block(L, ((int)((key >> 42) & 0x1fffffull) - kBias) >> shift,
+                                            ((int)((key >> 21) & 0x1fffffull) - kBias) >> shift,
+                                            ((int)(key & 0x1fffffull) - kBias) >> shift);
+              }
+          __syncthreads();
+        }
+      }
       for (uint32_t o = (uint32_t)tid; o < n_occ && ablate < 1; o += 256) {
         uint32_t my_retries = 0;
-        const uint32_t slot = occ[o];
+        const uint32_t slot = occ[o] & 0x3ffu;
         const unsigned long long key = tkey[slot];
         const uint32_t head = thead[slot];
         tkey[slot] = kEmptyKey;
@@ -413,18 +456,12 @@ __global__ __launch_bounds__(256) void tsdf_integrate_coop_kernel(TsdfLayerDev L
         // the block: a plain (cacheable) look at the table first -- an entry >= 0 never changes inside a kernel, anything
         // else (free, being allocated, stale in this XCD's L2) goes through the atomic path
         int bslot = -1;
-        unsigned long long tk0 = tracing ? wall_clock64() : 0ull;
         {
           const int bx = kx >> shift, by = ky >> shift, bz = kz >> shift;
           const int rx = bx - L.lut_min[0], ry = by - L.lut_min[1], rz = bz - L.lut_min[2];
           if ((unsigned)rx < (unsigned)L.lut_dim[0] && (unsigned)ry < (unsigned)L.lut_dim[1] && (unsigned)rz < (unsigned)L.lut_dim[2])
             bslot = L.lut[rx + L.lut_dim[0] * (ry + L.lut_dim[1] * rz)];
           if (bslot < 0) bslot = get_or_allocate_block(L, bx, by, bz);
-        }
-        if (tracing) {
-          const unsigned long long now = wall_clock64() + (unsigned long long)(bslot & 0);  // (after the table value is in)
-          tk_lut += now - tk0;
-          tk0 = now;
         }
         uint32_t chain = 0;
         for (uint32_t q = head; q != kNil; q = recs[q].next) ++chain;
@@ -438,11 +475,6 @@ __global__ __launch_bounds__(256) void tsdf_integrate_coop_kernel(TsdfLayerDev L
         uint32_t* caddr = &L.rgba[at];
         unsigned long long old = __hip_atomic_load(vaddr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint32_t oc = __hip_atomic_load(caddr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tracing) {
-          const unsigned long long now = wall_clock64() + (old & 0ull) + (unsigned long long)(oc & 0u);
-          tk_load += now - tk0;
-          tk0 = now;
-        }
         // updateTsdfVoxel for every record of the chain in turn, on registers
         while (true) {
           float d = __uint_as_float((unsigned)(old & 0xffffffffull)), W = __uint_as_float((unsigned)(old >> 32));
@@ -469,11 +501,6 @@ __global__ __launch_bounds__(256) void tsdf_integrate_coop_kernel(TsdfLayerDev L
             ++my_retries;
             continue;
           }
-          if (tracing) {
-            const unsigned long long now = wall_clock64() + (prev & 0ull);
-            tk_cas += now - tk0;
-            tk0 = now;
-          }
           if (any_blend) {
             if (STATS) {
               for (uint32_t q = head; q != kNil; q = recs[q].next) st_blends += fabsf(recs[q].sdf) < trunc ? 1u : 0u;
@@ -494,7 +521,6 @@ __global__ __launch_bounds__(256) void tsdf_integrate_coop_kernel(TsdfLayerDev L
               ++my_retries;
               prevc = atomicCAS(caddr, oc, col);
             }
-            if (tracing) tk_ccas += wall_clock64() + (unsigned long long)(prevc & 0u) - tk0;
           }
           break;
         }
@@ -535,14 +561,6 @@ __global__ __launch_bounds__(256) void tsdf_integrate_coop_kernel(TsdfLayerDev L
     if (st_overrun) atomicAdd(&sh_stat[7], st_overrun);
     if (my_retry_max) atomicMax(&sh_retry_max, my_retry_max);
     __syncthreads();
-    if (tracing) {
-      __shared__ unsigned long long sh_tk[4];
-      if (tid < 4) sh_tk[tid] = 0ull;
-      __syncthreads();
-      atomicMax(&sh_tk[0], tk_lut); atomicMax(&sh_tk[1], tk_load); atomicMax(&sh_tk[2], tk_cas); atomicMax(&sh_tk[3], tk_ccas);
-      __syncthreads();
-      if (tid < 4) I.wg_stats[(size_t)blockIdx.x * kWgStatWords + 16 + tid] = sh_tk[tid];
-    }
     if (tracing && tid < 8) I.wg_stats[(size_t)blockIdx.x * kWgStatWords + 8 + tid] = sh_stat[tid];
     if (tracing && tid == 0) {
       unsigned long long* t = I.wg_stats + (size_t)blockIdx.x * kWgStatWords;

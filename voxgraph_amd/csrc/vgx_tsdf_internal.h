@@ -37,7 +37,7 @@ struct TsdfIntegratorDev {
 };
 // a workgroup's row: 0..3 wall_clock64 at its start / rays queued / walk done / end, 4 rays, 5 rounds, 6 per-voxel folds,
 // 7 longest chain of repeated folds, 8..15 what reduce_wg_stats_kernel sums into n_updates[0..7]
-constexpr int kWgStatWords = 24;  // 16..19: the slowest lane's ticks in the block lookup / the two loads / the {d,w} CAS loop / the colour CAS loop
+constexpr int kWgStatWords = 16;
 constexpr int kScanStatWords = 8;
 
 constexpr unsigned kSetBits = 20;
