@@ -55,10 +55,30 @@ VGX_API int vgx_ctx_destroy(vgx_ctx ctx);
 /* Human-readable description of the last error on this context (or of the
  * last failed vgx_ctx_create when ctx == NULL). Never NULL. */
 VGX_API const char* vgx_last_error(vgx_ctx ctx);
-/* Launch all work of this context on an existing hipStream_t (e.g. the
- * caller's PyTorch stream).  NULL restores the context's own stream. */
+/* THREADING AND STREAMS.  A context has two sides, each with its own HIP stream and its own lock, as the reference has
+ * two threads (voxgraph_mapper.cpp:218-238: the ROS thread integrates scans while optimizePoseGraph runs on a
+ * std::async thread):
+ *   registration side   everything on FINISHED submaps -- vgx_submap_*, vgx_reg_*, vgx_find_overlapping_pairs,
+ *                       vgx_map_file_load_submap ...; stream: vgx_ctx_set_stream / _get_stream.
+ *   TSDF side           the ACTIVE submap -- vgx_tsdf_layer_*, vgx_tsdf_integrator_*, vgx_tsdf_integrate*;
+ *                       stream: vgx_ctx_set_tsdf_stream / _get_tsdf_stream.
+ * A scan therefore neither queues behind a solver evaluation nor waits for its lock: one thread may integrate while
+ * another evaluates, on the same context (tests/test_concurrency_gpu.py).  What makes that safe is the reference's own
+ * invariant (voxgraph_mapper.cpp:464-471): a finished submap is immutable, and only the active layer is written.  The
+ * two sides meet in vgx_submap_from_tsdf_layer (finishSubmap(), voxgraph_submap.cpp:84-107), which orders the
+ * registration stream behind the TSDF stream with an event; the layer must not be integrated into while that call
+ * runs (the reference finishes a submap on the thread that integrates).  Any entry point may be called from any
+ * thread; calls on one side are serialised among themselves (except the drop-in vgx_reg_evaluate, which overlaps on up
+ * to eight evaluation streams).  DEVICE pointers handed to vgx_tsdf_integrate*_device must be ready with respect to the
+ * TSDF stream (complete, or produced on / ordered before vgx_ctx_get_tsdf_stream()).
+ *
+ * vgx_ctx_set_stream: launch the registration side on an existing hipStream_t (e.g. the caller's PyTorch stream);
+ * vgx_ctx_set_tsdf_stream: the same for the TSDF side (waits for what that side has queued so far).  NULL restores
+ * the context's own stream.  vgx_ctx_synchronize waits for both. */
 VGX_API int vgx_ctx_set_stream(vgx_ctx ctx, void* hip_stream);
 VGX_API void* vgx_ctx_get_stream(vgx_ctx ctx);
+VGX_API int vgx_ctx_set_tsdf_stream(vgx_ctx ctx, void* hip_stream);
+VGX_API void* vgx_ctx_get_tsdf_stream(vgx_ctx ctx);
 /* How the sampling grids of the submaps created on this context FROM NOW ON are laid out in HBM (set it
  * once, before the first submap; a batch refuses to mix layouts).  Results never depend on it.
  *   VGX_BRICKS_APRON (default)  17^3 floats per block; fewest bytes: fastest where every registration

@@ -1,0 +1,180 @@
+"""Integrate while optimising -- the reference's defining overlap (voxgraph_mapper.cpp:218-238: optimizePoseGraph runs on a
+std::async thread while the ROS thread keeps integrating scans; invariant :464-471: finished submaps are immutable).
+
+Thread A integrates a session of scans into the ACTIVE layer (reproducible mode: the result is defined bit for bit) while
+thread B evaluates the pose graph's registration constraints on FINISHED submaps of the SAME context -- fused passes and
+drop-in Evaluate calls.  The two sides have their own stream and lock (include/voxgraph_amd.h "THREADING AND STREAMS"):
+both results must equal the serial run's bit for bit, nothing may deadlock, and the two together must take less wall
+clock than one after the other."""
+import threading
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from voxgraph_amd import capi
+    capi.load()
+    return capi
+
+
+def _scans(n_scans, n_az=256, n_el=24):
+    """a LiDAR-like sensor walking through a 10 x 8 x 4 m room; no axis-aligned rays (azimuths offset by a third of a step)"""
+    az = np.linspace(-np.pi, np.pi, n_az, endpoint=False) + (2 * np.pi / n_az) / 3.0
+    el = np.linspace(-0.3, 0.3, n_el) + 0.004
+    A, E = np.meshgrid(az, el)
+    d = np.stack([np.cos(E) * np.cos(A), np.cos(E) * np.sin(A), np.sin(E)], -1).reshape(-1, 3)
+    out = []
+    for k in range(n_scans):
+        origin = np.array([-2.0 + 0.02 * k, 0.5 - 0.005 * k, 0.3 + 0.001 * k])
+        lo, hi = np.array([-5.0, -4.0, -1.0]) - origin, np.array([5.0, 4.0, 3.0]) - origin
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = np.where(d > 0, hi / d, np.where(d < 0, lo / d, np.inf)).min(1)
+        out.append((np.array([1, 0, 0, 0, *origin], F), (d * t[:, None]).astype(F)))
+    return out
+
+
+def _graph(capi, ctx, n_sub=6):
+    """finished submaps of the analytic city and the registration constraints between neighbours"""
+    from harness.bench_common import BYTES_PER_EVAL  # noqa: F401  (the harness is importable: same scene as bench.py)
+    poses = np.array([[6.4 * k, 0.4 * (k % 2), 0.0, 0.02 * k] for k in range(n_sub)])
+    subs = []
+    for k in range(n_sub):
+        sm = capi.Submap.synth_city(ctx, k, 0.2, 16, (-4, -4, -2), (8, 8, 4), 0.6, 2.0, 10.0, poses[k], 2)
+        sm.extract_voxel_points(1.0, 0.3, True)
+        sm.release_raw_layers()
+        subs.append(sm)
+    pairs = np.array([(a, a + 1) for a in range(n_sub - 1)] + [(a, a + 2) for a in range(n_sub - 2)], np.int32)
+    cfg = capi.default_config(registration_point_type=capi.POINTS_VOXELS)
+    cfs = [capi.RegistrationCostFunction(ctx, subs[a], subs[b], cfg) for a, b in pairs]
+    batch = capi.RegistrationBatch(ctx, cfs, pairs)
+    guess = poses + np.array([0.05, -0.03, 0.01, 0.004]) * (np.arange(n_sub)[:, None] % 3)
+    return subs, cfs, batch, pairs, guess
+
+
+def _evaluate(capi, batch, cfs, pairs, guess, n_normal, n_dropin):
+    """thread B's work: n_normal fused passes (the per-constraint [45] blocks to the host) and n_dropin drop-in Evaluates"""
+    blocks = []
+    for it in range(n_normal):
+        p = guess + 1e-3 * it
+        status, host = batch.evaluate_normal(p, to_host=True)
+        assert not status.any()
+        blocks.append(host.copy())
+    rows = []
+    for it in range(n_dropin):
+        c = it % len(cfs)
+        a, b = pairs[c]
+        n = cfs[c].num_residuals()
+        r, jo, je = np.zeros(n), np.zeros((n, 4)), np.zeros((n, 4))
+        assert cfs[c].Evaluate([guess[a], guess[b]], r, [jo, je])
+        rows.append((r, jo, je))
+    return blocks, rows
+
+
+def _integrate(capi, ctx, scans):
+    """thread A's work: the whole session into a fresh layer, reproducible mode; returns the layer's download"""
+    layer = capi.TsdfLayer(ctx, 0.2, 16)
+    integ = capi.FastTsdfIntegrator(ctx, capi.voxgraph_tsdf_config(deterministic=1), layer)
+    for T, pts in scans:
+        integ.integratePointCloud(T, pts)
+    out = layer.download()
+    dropped = layer.stats()[1]
+    integ.destroy()
+    layer.destroy()
+    return out, dropped
+
+
+def test_scans_integrate_while_the_pose_graph_is_evaluated(capi):
+    ctx = capi.Context(0)
+    try:
+        assert ctx.get_tsdf_stream() != ctx.get_stream() and ctx.get_tsdf_stream() != 0
+        scans = _scans(200)
+        subs, cfs, batch, pairs, guess = _graph(capi, ctx)
+        n_normal, n_dropin = 50, 10
+        # warm both sides (allocations, first-use initialisation)
+        _integrate(capi, ctx, scans[:3])
+        _evaluate(capi, batch, cfs, pairs, guess, 2, 2)
+        ctx.synchronize()
+        # ---- one after the other
+        t0 = time.perf_counter()
+        layer_serial, dropped = _integrate(capi, ctx, scans)
+        t_a = time.perf_counter() - t0
+        assert dropped == 0
+        t0 = time.perf_counter()
+        blocks_serial, rows_serial = _evaluate(capi, batch, cfs, pairs, guess, n_normal, n_dropin)
+        t_b = time.perf_counter() - t0
+        # ---- together, on two threads
+        res, err = {}, []
+
+        def run(name, fn):
+            try:
+                res[name] = fn()
+            except BaseException as e:    # noqa: BLE001  (a failed assertion in a thread must fail the test)
+                err.append((name, repr(e)))
+        ta = threading.Thread(target=run, args=("layer", lambda: _integrate(capi, ctx, scans)))
+        tb = threading.Thread(target=run, args=("reg", lambda: _evaluate(capi, batch, cfs, pairs, guess, n_normal, n_dropin)))
+        t0 = time.perf_counter()
+        ta.start()
+        tb.start()
+        ta.join(timeout=300)
+        tb.join(timeout=300)
+        t_both = time.perf_counter() - t0
+        assert not ta.is_alive() and not tb.is_alive(), "deadlock: a thread did not finish within 300 s"
+        assert not err, err
+        # ---- the same bits
+        (layer_conc, dropped_c), (blocks_conc, rows_conc) = res["layer"], res["reg"]
+        assert dropped_c == 0
+        for x, y in zip(layer_serial, layer_conc):
+            assert np.array_equal(x.view(np.uint8), y.view(np.uint8))
+        assert len(layer_serial[0]) > 50
+        for x, y in zip(blocks_serial, blocks_conc):
+            assert np.array_equal(x.view(np.uint64), y.view(np.uint64))
+        for (r0, a0, b0), (r1, a1, b1) in zip(rows_serial, rows_conc):
+            assert np.array_equal(r0, r1) and np.array_equal(a0, a1) and np.array_equal(b0, b1)
+        assert any(np.abs(b).max() > 0 for b in blocks_serial)
+        print(f"serial: scans {t_a * 1e3:.1f} ms + evaluations {t_b * 1e3:.1f} ms = {(t_a + t_b) * 1e3:.1f} ms; "
+              f"concurrent: {t_both * 1e3:.1f} ms")
+        # ---- and an overlap: less than one after the other (the reproducible mode waits for the device several times
+        # per scan -- the other side's kernels run meanwhile)
+        assert t_both < 0.97 * (t_a + t_b), (t_a, t_b, t_both)
+        for o in [batch] + cfs + subs:
+            o.destroy()
+    finally:
+        ctx.close()
+
+
+def test_finish_submap_hands_over_across_the_two_streams(capi):
+    """vgx_submap_from_tsdf_layer right behind the last scan, no host synchronisation in between: the registration side's
+    kernels (brick building, ESDF, point extraction) must see the layer as the TSDF stream left it"""
+    ctx = capi.Context(0)
+    try:
+        scans = _scans(6)
+
+        def build(sync):
+            layer = capi.TsdfLayer(ctx, 0.2, 16)
+            integ = capi.FastTsdfIntegrator(ctx, capi.voxgraph_tsdf_config(deterministic=1), layer)
+            import torch
+            dev = [torch.from_numpy(p).cuda() for _, p in scans]
+            torch.cuda.synchronize()
+            for (T, p), d in zip(scans, dev):
+                integ.integrate_device(T, d.data_ptr(), None, len(p))        # asynchronous
+            if sync:
+                ctx.synchronize()
+            sm = capi.Submap.from_tsdf_layer(ctx, layer, 7)
+            sm.generate_esdf()
+            n = sm.extract_voxel_points(1.0, 0.3, True)
+            xyz, dist, w = sm.download_points(capi.POINTS_VOXELS)
+            for o in (sm, integ, layer):
+                o.destroy()
+            return n, xyz, dist, w
+        n0, x0, d0, w0 = build(True)
+        n1, x1, d1, w1 = build(False)
+        assert n0 == n1 > 100
+        assert np.array_equal(x0, x1) and np.array_equal(d0, d1) and np.array_equal(w0, w1)
+    finally:
+        ctx.close()

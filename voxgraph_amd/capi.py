@@ -84,6 +84,8 @@ SIGNATURES = {
     "vgx_last_error": (C.c_char_p, [vp]),
     "vgx_ctx_set_stream": (C.c_int, [vp, vp]),
     "vgx_ctx_get_stream": (vp, [vp]),
+    "vgx_ctx_set_tsdf_stream": (C.c_int, [vp, vp]),
+    "vgx_ctx_get_tsdf_stream": (vp, [vp]),
     "vgx_ctx_synchronize": (C.c_int, [vp]),
     "vgx_ctx_set_brick_layout": (C.c_int, [vp, C.c_int32]),
     "vgx_ctx_set_sampling_bricks": (C.c_int, [vp, C.c_int32]),
@@ -256,6 +258,13 @@ class Context:
     def get_stream(self):
         """the hipStream_t (as an int) the library launches on"""
         return int(self.lib.vgx_ctx_get_stream(self.h) or 0)
+
+    def set_tsdf_stream(self, stream_ptr):
+        """the TSDF side's stream (layers, integrators, scans); None restores the context's own"""
+        self.check(self.lib.vgx_ctx_set_tsdf_stream(self.h, vp(stream_ptr) if stream_ptr else None))
+
+    def get_tsdf_stream(self):
+        return int(self.lib.vgx_ctx_get_tsdf_stream(self.h) or 0)
 
     def synchronize(self):
         self.check(self.lib.vgx_ctx_synchronize(self.h))

@@ -325,12 +325,21 @@ int vgx_ctx_create(int device, vgx_ctx* out) {
   ctx->cu_count = prop.multiProcessorCount;
   if (hipSetDevice(device) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->tsdf_own_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&ctx->ev_start) != hipSuccess ||
-      hipEventCreate(&ctx->ev_stop) != hipSuccess) {
+      hipEventCreate(&ctx->ev_stop) != hipSuccess ||
+      hipEventCreate(&ctx->ev_tsdf_start) != hipSuccess ||
+      hipEventCreate(&ctx->ev_tsdf_stop) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_handover, hipEventDisableTiming) != hipSuccess) {
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    if (ctx->tsdf_own_stream) (void)hipStreamDestroy(ctx->tsdf_own_stream);
+    for (hipEvent_t ev : {ctx->ev_start, ctx->ev_stop, ctx->ev_tsdf_start, ctx->ev_tsdf_stop, ctx->ev_handover})
+      if (ev) (void)hipEventDestroy(ev);
     delete ctx;
     return set_error(nullptr, VGX_ERR_HIP, "vgx_ctx_create: stream/event creation failed");
   }
   ctx->stream = ctx->own_stream;
+  ctx->tsdf_stream = ctx->tsdf_own_stream;
   ctx->last_error = "no error";
   *out = ctx;
   return VGX_OK;
@@ -340,8 +349,9 @@ int vgx_ctx_destroy(vgx_ctx ctx) {
   if (!ctx) return VGX_ERR_INVALID;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
-  if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+  (void)hipStreamSynchronize(ctx->tsdf_stream);
+  for (hipEvent_t ev : {ctx->ev_start, ctx->ev_stop, ctx->ev_tsdf_start, ctx->ev_tsdf_stop, ctx->ev_handover})
+    if (ev) (void)hipEventDestroy(ev);
   for (int k = 0; k < Context::kEvalSlots; ++k) {
     Context::EvalSlot& sl = ctx->eval_slot[k];
     if (sl.stream) {
@@ -355,6 +365,7 @@ int vgx_ctx_destroy(vgx_ctx ctx) {
     if (sl.h_out) (void)hipHostFree(sl.h_out);
   }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  if (ctx->tsdf_own_stream) (void)hipStreamDestroy(ctx->tsdf_own_stream);
   delete ctx;
   return VGX_OK;
 }
@@ -381,6 +392,17 @@ int vgx_ctx_set_stream(vgx_ctx ctx, void* hip_stream) {
 
 void* vgx_ctx_get_stream(vgx_ctx ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
+int vgx_ctx_set_tsdf_stream(vgx_ctx ctx, void* hip_stream) {
+  if (!ctx) return VGX_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->tsdf_mu);
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->tsdf_stream);  // what was queued on the old stream is done before the new one is used
+  ctx->tsdf_stream = hip_stream ? (hipStream_t)hip_stream : ctx->tsdf_own_stream;
+  return VGX_OK;
+}
+
+void* vgx_ctx_get_tsdf_stream(vgx_ctx ctx) { return ctx ? (void*)ctx->tsdf_stream : nullptr; }
+
 int vgx_ctx_set_brick_layout(vgx_ctx ctx, int32_t layout) {
   if (!ctx) return VGX_ERR_INVALID;
   if (layout != VGX_BRICKS_APRON && layout != VGX_BRICKS_QUAD)
@@ -402,20 +424,29 @@ int vgx_ctx_set_sampling_bricks(vgx_ctx ctx, int32_t mode) {
 int vgx_ctx_synchronize(vgx_ctx ctx) {
   if (!ctx) return VGX_ERR_INVALID;
   VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  VGX_HIP(ctx, hipStreamSynchronize(ctx->tsdf_stream));
   return VGX_OK;
 }
 
+// The timer brackets BOTH streams of the context (registration side and TSDF side): elapsed = the longer of the two
+// start-to-stop intervals, i.e. the time until everything enqueued in between is done, whichever stream it went to.
 int vgx_ctx_timer_start(vgx_ctx ctx) {
   if (!ctx) return VGX_ERR_INVALID;
   VGX_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+  VGX_HIP(ctx, hipEventRecord(ctx->ev_tsdf_start, ctx->tsdf_stream));
   return VGX_OK;
 }
 
 int vgx_ctx_timer_stop(vgx_ctx ctx, float* elapsed_ms) {
   if (!ctx || !elapsed_ms) return VGX_ERR_INVALID;
   VGX_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+  VGX_HIP(ctx, hipEventRecord(ctx->ev_tsdf_stop, ctx->tsdf_stream));
   VGX_HIP(ctx, hipEventSynchronize(ctx->ev_stop));
-  VGX_HIP(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev_start, ctx->ev_stop));
+  VGX_HIP(ctx, hipEventSynchronize(ctx->ev_tsdf_stop));
+  float a = 0.0f, b = 0.0f;
+  VGX_HIP(ctx, hipEventElapsedTime(&a, ctx->ev_start, ctx->ev_stop));
+  VGX_HIP(ctx, hipEventElapsedTime(&b, ctx->ev_tsdf_start, ctx->ev_tsdf_stop));
+  *elapsed_ms = a > b ? a : b;
   return VGX_OK;
 }
 

@@ -145,6 +145,16 @@ struct Context {
   hipStream_t stream = nullptr;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   std::mutex mu;
+  // The TSDF path (the ACTIVE submap: layers, integrators, scans) has its own stream and its own lock, so that a scan
+  // neither queues behind a solver evaluation on `stream` nor waits for `mu` while another thread evaluates -- the
+  // reference integrates on the ROS thread while optimizePoseGraph runs on a std::async thread (voxgraph_mapper.cpp:
+  // 236-238), and what makes that safe is the same here: finished submaps are immutable (voxgraph_mapper.cpp:464-471).
+  // The two sides meet in vgx_submap_from_tsdf_layer (finishSubmap: the TSDF side's stream is waited for by an event).
+  // Lock order where both are taken: integrator -> tsdf_mu -> mu.
+  hipStream_t tsdf_own_stream = nullptr;
+  hipStream_t tsdf_stream = nullptr;
+  hipEvent_t ev_tsdf_start = nullptr, ev_tsdf_stop = nullptr, ev_handover = nullptr;
+  std::mutex tsdf_mu;
   std::mutex err_mu;       // guards last_error only (set_error is called with and without `mu`)
   std::string last_error;
   int cu_count = 256;

@@ -254,10 +254,10 @@ extern "C" int vgx_bench_stream_ceiling(vgx_ctx ctx, const void* d_src, int64_t 
 extern "C" int vgx_synth_city_scan(vgx_ctx ctx, const double pose[4], int32_t n_az, int32_t n_el,
                                    float el_span, float max_range, uint32_t seed, void* d_points) {
   if (!ctx || !pose || !d_points || n_az <= 0 || n_el <= 0) return VGX_ERR_INVALID;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::mutex> lk(ctx->tsdf_mu);
   VGX_HIP(ctx, hipSetDevice(ctx->device));
   const int n = n_az * n_el;
-  hipLaunchKernelGGL(synth_city_scan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+  hipLaunchKernelGGL(synth_city_scan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->tsdf_stream,
                      (float)pose[0], (float)pose[1], (float)pose[2], (float)std::cos(pose[3]),
                      (float)std::sin(pose[3]), n_az, n_el, el_span, max_range, seed, (float*)d_points);
   VGX_HIP(ctx, hipGetLastError());

@@ -674,12 +674,12 @@ int grow_pool(vgx_tsdf_layer L, int32_t blocks, int32_t used) {
             hipMalloc(&block_index, (size_t)blocks * 12) == hipSuccess;
   if (ok) {
     const size_t keep = (size_t)used * vpb;
-    ok = (keep == 0 || (hipMemcpyAsync(voxels, d.voxels, keep * 8, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess &&
-                        hipMemcpyAsync(rgba, d.rgba, keep * 4, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess &&
-                        hipMemcpyAsync(block_index, d.block_index, (size_t)used * 12, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess)) &&
-         hipMemsetAsync(voxels + keep, 0, ((size_t)blocks * vpb - keep) * 8, ctx->stream) == hipSuccess &&
-         hipMemsetAsync(rgba + keep, 0, ((size_t)blocks * vpb - keep) * 4, ctx->stream) == hipSuccess &&
-         hipStreamSynchronize(ctx->stream) == hipSuccess;
+    ok = (keep == 0 || (hipMemcpyAsync(voxels, d.voxels, keep * 8, hipMemcpyDeviceToDevice, ctx->tsdf_stream) == hipSuccess &&
+                        hipMemcpyAsync(rgba, d.rgba, keep * 4, hipMemcpyDeviceToDevice, ctx->tsdf_stream) == hipSuccess &&
+                        hipMemcpyAsync(block_index, d.block_index, (size_t)used * 12, hipMemcpyDeviceToDevice, ctx->tsdf_stream) == hipSuccess)) &&
+         hipMemsetAsync(voxels + keep, 0, ((size_t)blocks * vpb - keep) * 8, ctx->tsdf_stream) == hipSuccess &&
+         hipMemsetAsync(rgba + keep, 0, ((size_t)blocks * vpb - keep) * 4, ctx->tsdf_stream) == hipSuccess &&
+         hipStreamSynchronize(ctx->tsdf_stream) == hipSuccess;
   }
   if (!ok) {
     void* fresh[] = {voxels, rgba, block_index};
@@ -709,15 +709,15 @@ int rebox(vgx_tsdf_layer L, const int32_t mn[3], const int32_t dm[3]) {
   int32_t* lut = nullptr;
   if (hipMalloc(&lut, cells * 4) != hipSuccess)
     return set_error(ctx, VGX_ERR_NOMEM, "TSDF layer: block table allocation failed");
-  hipError_t e = hipMemsetAsync(lut, 0xff, cells * 4, ctx->stream);
+  hipError_t e = hipMemsetAsync(lut, 0xff, cells * 4, ctx->tsdf_stream);
   if (e == hipSuccess && d.lut && L->lut_cells > 0) {
-    hipLaunchKernelGGL(tsdf_lut_remap_kernel, dim3((unsigned)((L->lut_cells + 255) / 256)), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(tsdf_lut_remap_kernel, dim3((unsigned)((L->lut_cells + 255) / 256)), dim3(256), 0, ctx->tsdf_stream,
                        d.lut, make_int3(d.lut_min[0], d.lut_min[1], d.lut_min[2]),
                        make_int3(d.lut_dim[0], d.lut_dim[1], d.lut_dim[2]), lut, make_int3(mn[0], mn[1], mn[2]),
                        make_int3(dm[0], dm[1], dm[2]));
     e = hipGetLastError();
   }
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->tsdf_stream);
   if (e != hipSuccess) {
     (void)hipFree(lut);
     return set_error(ctx, VGX_ERR_HIP, std::string("TSDF layer: re-boxing failed: ") + hipGetErrorString(e));
@@ -736,7 +736,7 @@ int rebox(vgx_tsdf_layer L, const int32_t mn[3], const int32_t dm[3]) {
 int read_stats_sync(vgx_tsdf_layer L, TsdfStats* out) {
   vgx_ctx ctx = L->ctx;
   VGX_HIP(ctx, hipSetDevice(ctx->device));
-  VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  VGX_HIP(ctx, hipStreamSynchronize(ctx->tsdf_stream));
   VGX_HIP(ctx, hipMemcpy(out, L->d_stats, sizeof(TsdfStats), hipMemcpyDeviceToHost));
   L->known_blocks = out->n_blocks;
   L->known_seq = L->scan_seq;
@@ -839,7 +839,7 @@ int reserve_for_scan(vgx_tsdf_layer L, const float origin[3], float reach) {
       rc = grow_pool(L, (int32_t)want, st.n_blocks);
       if (rc != VGX_OK) return rc;
       hipLaunchKernelGGL(tsdf_lut_clear_exhausted_kernel, dim3((unsigned)((L->lut_cells + 255) / 256)), dim3(256), 0,
-                         ctx->stream, d.lut, (long long)L->lut_cells);
+                         ctx->tsdf_stream, d.lut, (long long)L->lut_cells);
       VGX_HIP(ctx, hipGetLastError());
       ++L->growths;
     }
@@ -857,8 +857,8 @@ void request_readback(vgx_tsdf_layer L) {
   for (auto& r : L->recent) pending += r.second;
   if (2 * pending < (int64_t)L->dev.max_blocks - L->known_blocks) return;
   vgx_ctx ctx = L->ctx;
-  if (hipMemcpyAsync(L->h_stats, L->d_stats, sizeof(TsdfStats), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-      hipEventRecord(L->readback_done, ctx->stream) != hipSuccess) {
+  if (hipMemcpyAsync(L->h_stats, L->d_stats, sizeof(TsdfStats), hipMemcpyDeviceToHost, ctx->tsdf_stream) != hipSuccess ||
+      hipEventRecord(L->readback_done, ctx->tsdf_stream) != hipSuccess) {
     (void)hipGetLastError();
     return;  // the synchronous path still works
   }
@@ -882,7 +882,7 @@ int vgx_tsdf_layer_create(vgx_ctx ctx, float voxel_size, int32_t vps, const int3
                           const int32_t lut_dim[3], int32_t max_blocks, vgx_tsdf_layer* out) {
   if (!ctx || !out) return VGX_ERR_INVALID;
   *out = nullptr;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::mutex> lk(ctx->tsdf_mu);
   if (vps != 8 && vps != 16)
     return set_error(ctx, VGX_ERR_UNSUPPORTED, "vgx_tsdf_layer_create: voxels_per_side must be 8 or 16");
   if ((lut_min == nullptr) != (lut_dim == nullptr))
@@ -905,7 +905,7 @@ int vgx_tsdf_layer_create(vgx_ctx ctx, float voxel_size, int32_t vps, const int3
   if (hipMalloc(&L->d_stats, sizeof(TsdfStats)) != hipSuccess ||
       hipHostMalloc((void**)&L->h_stats, sizeof(TsdfStats), hipHostMallocDefault) != hipSuccess ||
       hipEventCreateWithFlags(&L->readback_done, hipEventDisableTiming) != hipSuccess ||
-      hipMemsetAsync(L->d_stats, 0, sizeof(TsdfStats), ctx->stream) != hipSuccess)
+      hipMemsetAsync(L->d_stats, 0, sizeof(TsdfStats), ctx->tsdf_stream) != hipSuccess)
     rc = set_error(ctx, VGX_ERR_NOMEM, "vgx_tsdf_layer_create: device allocation failed");
   if (rc == VGX_OK) {
     d.n_blocks = &L->d_stats->n_blocks;
@@ -925,7 +925,7 @@ int vgx_tsdf_layer_create(vgx_ctx ctx, float voxel_size, int32_t vps, const int3
 int vgx_tsdf_layer_destroy(vgx_tsdf_layer L) {
   if (!L) return VGX_ERR_INVALID;
   (void)hipSetDevice(L->ctx->device);
-  (void)hipStreamSynchronize(L->ctx->stream);
+  (void)hipStreamSynchronize(L->ctx->tsdf_stream);
   TsdfLayerDev& d = L->dev;
   void* ptrs[] = {d.voxels, d.rgba, d.lut, d.block_index, L->d_stats};
   for (void* p : ptrs)
@@ -938,7 +938,7 @@ int vgx_tsdf_layer_destroy(vgx_tsdf_layer L) {
 
 int vgx_tsdf_layer_stats(vgx_tsdf_layer L, int32_t* n_blocks, int64_t* dropped) {
   if (!L) return VGX_ERR_INVALID;
-  std::lock_guard<std::mutex> lk(L->ctx->mu);
+  std::lock_guard<std::mutex> lk(L->ctx->tsdf_mu);
   TsdfStats st{};
   int rc = read_stats_sync(L, &st);
   if (rc != VGX_OK) return rc;
@@ -952,11 +952,11 @@ int64_t vgx_tsdf_layer_growths(vgx_tsdf_layer L) { return L ? L->growths : -1; }
 int vgx_tsdf_layer_clear_dropped(vgx_tsdf_layer L) {
   if (!L) return VGX_ERR_INVALID;
   vgx_ctx ctx = L->ctx;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::mutex> lk(ctx->tsdf_mu);
   VGX_HIP(ctx, hipSetDevice(ctx->device));
-  VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  VGX_HIP(ctx, hipMemsetAsync(L->dev.dropped, 0, 8, ctx->stream));
-  VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  VGX_HIP(ctx, hipStreamSynchronize(ctx->tsdf_stream));
+  VGX_HIP(ctx, hipMemsetAsync(L->dev.dropped, 0, 8, ctx->tsdf_stream));
+  VGX_HIP(ctx, hipStreamSynchronize(ctx->tsdf_stream));
   L->dropped_seen = 0;
   L->readback_inflight = false;  // a read-back in flight may still carry the old count
   return VGX_OK;
@@ -964,7 +964,7 @@ int vgx_tsdf_layer_clear_dropped(vgx_tsdf_layer L) {
 
 int vgx_tsdf_layer_reserve(vgx_tsdf_layer L, const float origin[3], float reach_m) {
   if (!L || !origin || !(reach_m >= 0)) return VGX_ERR_INVALID;
-  std::lock_guard<std::mutex> lk(L->ctx->mu);
+  std::lock_guard<std::mutex> lk(L->ctx->tsdf_mu);
   VGX_HIP(L->ctx, hipSetDevice(L->ctx->device));
   int rc = reserve_for_scan(L, origin, reach_m);
   // nothing was launched: the bound just booked must not count as a scan in flight
@@ -980,7 +980,7 @@ int vgx_tsdf_layer_download(vgx_tsdf_layer L, int32_t* block_index, float* dista
   int rc = vgx_tsdf_layer_stats(L, &nb, nullptr);
   if (rc != VGX_OK) return rc;
   if (nb == 0) return VGX_OK;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::mutex> lk(ctx->tsdf_mu);
   const size_t nvox = voxels_per_block(L->dev);
   if (block_index)
     VGX_HIP(ctx, hipMemcpy(block_index, L->dev.block_index, (size_t)nb * 12, hipMemcpyDeviceToHost));
@@ -1003,11 +1003,11 @@ int vgx_tsdf_layer_upload(vgx_tsdf_layer L, int32_t n_blocks, const int32_t* blo
                           const float* weight, const uint8_t* rgba) {
   if (!L || n_blocks < 0) return VGX_ERR_INVALID;
   vgx_ctx ctx = L->ctx;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::mutex> lk(ctx->tsdf_mu);
   if (n_blocks > 0 && (!block_index || !distance || !weight))
     return set_error(ctx, VGX_ERR_INVALID, "vgx_tsdf_layer_upload: NULL arrays");
   VGX_HIP(ctx, hipSetDevice(ctx->device));
-  VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  VGX_HIP(ctx, hipStreamSynchronize(ctx->tsdf_stream));
   TsdfLayerDev& d = L->dev;
   const size_t vpb = voxels_per_block(d);
   // box of the uploaded blocks (with a little slack); the old table is dropped, not remapped
@@ -1041,17 +1041,17 @@ int vgx_tsdf_layer_upload(vgx_tsdf_layer L, int32_t n_blocks, const int32_t* blo
     VGX_HIP(ctx, hipMemcpy(sw.p, weight, nv * 4, hipMemcpyHostToDevice));
     VGX_HIP(ctx, hipMemcpy(d.block_index, block_index, (size_t)n_blocks * 12, hipMemcpyHostToDevice));
     if (rgba) VGX_HIP(ctx, hipMemcpy(d.rgba, rgba, nv * 4, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(tsdf_pack_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(tsdf_pack_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, ctx->tsdf_stream,
                        sd.as<float>(), sw.as<float>(), nv, d.voxels);
-    hipLaunchKernelGGL(tsdf_lut_from_blocks_kernel, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(tsdf_lut_from_blocks_kernel, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, ctx->tsdf_stream,
                        d.block_index, (int)n_blocks, make_int3(d.lut_min[0], d.lut_min[1], d.lut_min[2]),
                        make_int3(d.lut_dim[0], d.lut_dim[1], d.lut_dim[2]), d.lut);
     VGX_HIP(ctx, hipGetLastError());
   }
   TsdfStats st{};
   st.n_blocks = n_blocks;
-  VGX_HIP(ctx, hipMemcpyAsync(L->d_stats, &st, sizeof(st), hipMemcpyHostToDevice, ctx->stream));
-  VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  VGX_HIP(ctx, hipMemcpyAsync(L->d_stats, &st, sizeof(st), hipMemcpyHostToDevice, ctx->tsdf_stream));
+  VGX_HIP(ctx, hipStreamSynchronize(ctx->tsdf_stream));
   L->known_blocks = n_blocks;
   L->known_seq = L->scan_seq;
   L->recent.clear();
@@ -1066,7 +1066,7 @@ int vgx_submap_from_tsdf_layer(vgx_ctx ctx, vgx_tsdf_layer L, int32_t submap_id,
   int32_t nb = 0;
   int rc = vgx_tsdf_layer_stats(L, &nb, nullptr);
   if (rc != VGX_OK) return rc;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::mutex> lk(ctx->tsdf_mu);
   vgx_submap sm = new (std::nothrow) vgx_submap_s();
   if (!sm) return set_error(ctx, VGX_ERR_NOMEM, "vgx_submap_from_tsdf_layer: out of host memory");
   const TsdfLayerDev& d = L->dev;
@@ -1090,16 +1090,24 @@ int vgx_submap_from_tsdf_layer(vgx_ctx ctx, vgx_tsdf_layer L, int32_t submap_id,
       rc = set_error(ctx, VGX_ERR_NOMEM, "vgx_submap_from_tsdf_layer: device allocation failed");
     } else {
       hipError_t e = hipMemcpyAsync(sm->d_block_index, d.block_index, (size_t)nb * 12,
-                                    hipMemcpyDeviceToDevice, ctx->stream);
+                                    hipMemcpyDeviceToDevice, ctx->tsdf_stream);
       if (e == hipSuccess) {
         hipLaunchKernelGGL(tsdf_unpack_kernel, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0,
-                           ctx->stream, d.voxels, nvox, sm->d_tsdf_distance, sm->d_tsdf_weight);
+                           ctx->tsdf_stream, d.voxels, nvox, sm->d_tsdf_distance, sm->d_tsdf_weight);
         e = hipGetLastError();
       }
+      // finishSubmap(): the TSDF side hands the layer's voxels to the registration side -- the submap's own kernels run
+      // on the context's registration stream, behind an event on the TSDF stream
+      if (e == hipSuccess) e = hipEventRecord(ctx->ev_handover, ctx->tsdf_stream);
       if (e != hipSuccess)
         rc = set_error(ctx, VGX_ERR_HIP, std::string("vgx_submap_from_tsdf_layer: ") + hipGetErrorString(e));
     }
-    if (rc == VGX_OK) rc = launch_brickify(sm, 0);
+    if (rc == VGX_OK) {
+      std::lock_guard<std::mutex> reg(ctx->mu);  // (lock order: tsdf_mu, then mu)
+      if (hipStreamWaitEvent(ctx->stream, ctx->ev_handover, 0) != hipSuccess)
+        rc = set_error(ctx, VGX_ERR_HIP, "vgx_submap_from_tsdf_layer: hipStreamWaitEvent failed");
+      if (rc == VGX_OK) rc = launch_brickify(sm, 0);
+    }
   }
   if (rc != VGX_OK) {
     vgx_submap_destroy(sm);
@@ -1113,7 +1121,7 @@ int vgx_tsdf_integrator_create(vgx_ctx ctx, const vgx_tsdf_config* cfg, vgx_tsdf
                                vgx_tsdf_integrator* out) {
   if (!ctx || !cfg || !out) return VGX_ERR_INVALID;
   *out = nullptr;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::mutex> lk(ctx->tsdf_mu);
   if (layer && layer->ctx != ctx)
     return set_error(ctx, VGX_ERR_INVALID, "vgx_tsdf_integrator_create: layer of another context");
   VGX_HIP(ctx, hipSetDevice(ctx->device));
@@ -1145,7 +1153,7 @@ int vgx_tsdf_integrator_create(vgx_ctx ctx, const vgx_tsdf_config* cfg, vgx_tsdf
 int vgx_tsdf_integrator_destroy(vgx_tsdf_integrator I) {
   if (!I) return VGX_ERR_INVALID;
   (void)hipSetDevice(I->ctx->device);
-  (void)hipStreamSynchronize(I->ctx->stream);
+  (void)hipStreamSynchronize(I->ctx->tsdf_stream);
   void* ptrs[] = {I->dev.start_set, I->dev.observed_set, I->dev.n_updates, I->d_points, I->d_rgba, I->d_wg_stats,
                   I->d_mkeys[0], I->d_mkeys[1], I->d_midx[0], I->d_midx[1], I->d_mstart, I->d_mcounters, I->d_msort,
                   I->d_mrank, I->d_gpg, I->d_gcolor, I->d_gflags, I->d_gcount, I->d_okey[0], I->d_okey[1], I->d_oidx[0],
@@ -1174,10 +1182,10 @@ int vgx_tsdf_integrator_set_layer(vgx_tsdf_integrator I, vgx_tsdf_layer layer) {
 static int reset_set(vgx_ctx ctx, unsigned long long* set, unsigned long long* offset) {
   if (++(*offset) >= kFullResetThreshold) {
     const unsigned long long poison = ~0ull;
-    VGX_HIP(ctx, hipMemsetAsync(set, 0, ((size_t)1 << kSetBits) * 8, ctx->stream));
+    VGX_HIP(ctx, hipMemsetAsync(set, 0, ((size_t)1 << kSetBits) * 8, ctx->tsdf_stream));
     *offset = 0;
-    VGX_HIP(ctx, hipMemcpyAsync(set, &poison, 8, hipMemcpyHostToDevice, ctx->stream));
-    VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    VGX_HIP(ctx, hipMemcpyAsync(set, &poison, 8, hipMemcpyHostToDevice, ctx->tsdf_stream));
+    VGX_HIP(ctx, hipStreamSynchronize(ctx->tsdf_stream));
   }
   return VGX_OK;
 }
@@ -1196,7 +1204,7 @@ __global__ __launch_bounds__(256) void sorted_order_keys_kernel(const float* __r
 }
 
 // The scan's visiting order: *order = nullptr for "mixed" (the kernels compute it), else the sorted table.
-// The caller holds I->mu and ctx->mu.
+// The caller holds I->mu and ctx->tsdf_mu.
 static int visiting_order(vgx_tsdf_integrator I, const void* d_points, int64_t n, const uint32_t** order) {
   vgx_ctx ctx = I->ctx;
   *order = nullptr;
@@ -1205,7 +1213,7 @@ static int visiting_order(vgx_tsdf_integrator I, const void* d_points, int64_t n
     return set_error(ctx, VGX_ERR_INVALID, "vgx_tsdf_config.integration_order: neither VGX_TSDF_ORDER_MIXED nor VGX_TSDF_ORDER_SORTED");
   if (n >= (1ll << 32)) return set_error(ctx, VGX_ERR_UNSUPPORTED, "integration_order sorted: more than 2^32 points in a scan");
   if (n > I->order_cap) {
-    VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    VGX_HIP(ctx, hipStreamSynchronize(ctx->tsdf_stream));
     void* old[] = {I->d_okey[0], I->d_okey[1], I->d_oidx[0], I->d_oidx[1], I->d_osort};
     for (void* q : old)
       if (q) (void)hipFree(q);
@@ -1218,17 +1226,17 @@ static int visiting_order(vgx_tsdf_integrator I, const void* d_points, int64_t n
     }
     size_t bytes = 0;
     VGX_HIP(ctx, stable_sort_pairs(nullptr, bytes, I->d_okey[0], I->d_okey[1], I->d_oidx[0], I->d_oidx[1], (size_t)n, 32,
-                                   ctx->stream));
+                                   ctx->tsdf_stream));
     VGX_HIP(ctx, hipMalloc(&I->d_osort, std::max<size_t>(bytes, 16)));
     I->osort_bytes = bytes;
     I->order_cap = n;
   }
-  hipLaunchKernelGGL(sorted_order_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+  hipLaunchKernelGGL(sorted_order_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->tsdf_stream,
                      (const float*)d_points, (long long)n, I->d_okey[0], I->d_oidx[0]);
   VGX_HIP(ctx, hipGetLastError());
   size_t bytes = I->osort_bytes;
   VGX_HIP(ctx, stable_sort_pairs(I->d_osort, bytes, I->d_okey[0], I->d_okey[1], I->d_oidx[0], I->d_oidx[1], (size_t)n, 32,
-                                 ctx->stream));
+                                 ctx->tsdf_stream));
   *order = I->d_oidx[1];
   return VGX_OK;
 }
@@ -1237,7 +1245,7 @@ static int visiting_order(vgx_tsdf_integrator I, const void* d_points, int64_t n
 static int integrate_locked(vgx_tsdf_integrator I, const float T[7], const void* d_points, const void* d_rgba,
                             int64_t n, int32_t freespace, int64_t* n_updates) {
   vgx_ctx ctx = I->ctx;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::mutex> lk(ctx->tsdf_mu);
   if (!I->layer) return set_error(ctx, VGX_ERR_INVALID, "vgx_tsdf_integrate: no layer set");
   VGX_HIP(ctx, hipSetDevice(ctx->device));
   // integratePointCloud: reset both approximate sets every clear_checks_every_n_frames
@@ -1247,7 +1255,7 @@ static int integrate_locked(vgx_tsdf_integrator I, const float T[7], const void*
     if (rc == VGX_OK) rc = reset_set(ctx, I->dev.observed_set, &I->dev.observed_offset);
     if (rc != VGX_OK) return rc;
   }
-  if (n_updates) VGX_HIP(ctx, hipMemsetAsync(I->dev.n_updates, 0, 8 * kScanStatWords, ctx->stream));
+  if (n_updates) VGX_HIP(ctx, hipMemsetAsync(I->dev.n_updates, 0, 8 * kScanStatWords, ctx->tsdf_stream));
   if (n > 0) {
     // Every voxel a ray of this scan can touch lies within max_ray_length + truncation of the
     // sensor origin (a longer return is a clearing ray cut at max_ray_length, RayCaster [recalled]);
@@ -1287,7 +1295,7 @@ static int integrate_locked(vgx_tsdf_integrator I, const float T[7], const void*
       if (n_updates) {  // a counted scan: one row of statistics per workgroup
         const long long wgs = racing_scan_workgroups((long long)n, I->cloud_width);
         if (wgs > I->wg_stats_cap) {
-          VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+          VGX_HIP(ctx, hipStreamSynchronize(ctx->tsdf_stream));
           if (I->d_wg_stats) (void)hipFree(I->d_wg_stats);
           I->d_wg_stats = nullptr;
           I->wg_stats_cap = 0;
@@ -1297,7 +1305,7 @@ static int integrate_locked(vgx_tsdf_integrator I, const float T[7], const void*
         I->dev.wg_stats = I->d_wg_stats;
         I->wg_stats_rows = wgs;
       }
-      VGX_HIP(ctx, launch_racing_scan(ctx->stream, I->layer->dev, I->dev, T, (const float*)d_points, (const uint32_t*)d_rgba,
+      VGX_HIP(ctx, launch_racing_scan(ctx->tsdf_stream, I->layer->dev, I->dev, T, (const float*)d_points, (const uint32_t*)d_rgba,
                                       (long long)n, (int)freespace, n_updates != nullptr, I->cloud_width));
     } else {
       dim3 grid((unsigned)((n + 255) / 256)), block(256);
@@ -1306,11 +1314,11 @@ static int integrate_locked(vgx_tsdf_integrator I, const float T[7], const void*
         return e ? atoi(e) != 0 : true;
       }();
       if (pipelined)
-        hipLaunchKernelGGL(tsdf_integrate_kernel<true>, grid, block, 0, ctx->stream, I->layer->dev, I->dev,
+        hipLaunchKernelGGL(tsdf_integrate_kernel<true>, grid, block, 0, ctx->tsdf_stream, I->layer->dev, I->dev,
                            T[0], T[1], T[2], T[3], T[4], T[5], T[6], (const float*)d_points,
                            (const uint32_t*)d_rgba, (long long)n, (int)freespace);
       else
-        hipLaunchKernelGGL(tsdf_integrate_kernel<false>, grid, block, 0, ctx->stream, I->layer->dev, I->dev,
+        hipLaunchKernelGGL(tsdf_integrate_kernel<false>, grid, block, 0, ctx->tsdf_stream, I->layer->dev, I->dev,
                            T[0], T[1], T[2], T[3], T[4], T[5], T[6], (const float*)d_points,
                            (const uint32_t*)d_rgba, (long long)n, (int)freespace);
     }
@@ -1319,8 +1327,8 @@ static int integrate_locked(vgx_tsdf_integrator I, const float T[7], const void*
   }
   if (n_updates) {
     unsigned long long u = 0;
-    VGX_HIP(ctx, hipMemcpyAsync(&u, I->dev.n_updates, 8, hipMemcpyDeviceToHost, ctx->stream));
-    VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    VGX_HIP(ctx, hipMemcpyAsync(&u, I->dev.n_updates, 8, hipMemcpyDeviceToHost, ctx->tsdf_stream));
+    VGX_HIP(ctx, hipStreamSynchronize(ctx->tsdf_stream));
     *n_updates = (int64_t)u;
   }
   return VGX_OK;
@@ -1330,16 +1338,16 @@ static int integrate_locked(vgx_tsdf_integrator I, const float T[7], const void*
 static int merged_integrate_locked(vgx_tsdf_integrator I, const float T[7], const void* d_points, const void* d_rgba,
                                    int64_t n, int32_t freespace, int64_t* n_updates) {
   vgx_ctx ctx = I->ctx;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::mutex> lk(ctx->tsdf_mu);
   if (!I->layer) return set_error(ctx, VGX_ERR_INVALID, "vgx_tsdf_integrate_merged: no layer set");
   if (n > (int64_t)1 << 31) return set_error(ctx, VGX_ERR_UNSUPPORTED, "vgx_tsdf_integrate_merged: more than 2^31 points");
   VGX_HIP(ctx, hipSetDevice(ctx->device));
-  if (n_updates) VGX_HIP(ctx, hipMemsetAsync(I->dev.n_updates, 0, 8, ctx->stream));
+  if (n_updates) VGX_HIP(ctx, hipMemsetAsync(I->dev.n_updates, 0, 8, ctx->tsdf_stream));
   if (n > 0) {
     const unsigned long long* keys_sorted = nullptr;
     const unsigned int* idx_sorted = nullptr;
     if (n > I->merged_cap) {
-      VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      VGX_HIP(ctx, hipStreamSynchronize(ctx->tsdf_stream));
       void* old[] = {I->d_mkeys[0], I->d_mkeys[1], I->d_midx[0], I->d_midx[1], I->d_mstart, I->d_msort,
                      I->d_mrank, I->d_gpg, I->d_gcolor, I->d_gflags, I->d_gcount};
       for (void* q : old)
@@ -1361,11 +1369,11 @@ static int merged_integrate_locked(vgx_tsdf_integrator I, const float T[7], cons
       VGX_HIP(ctx, hipMalloc(&I->d_gcount, ((size_t)n + 1) * 4));
       if (!I->d_mcounters) {
         VGX_HIP(ctx, hipMalloc(&I->d_mcounters, 32));
-        VGX_HIP(ctx, hipMemsetAsync(I->d_mcounters, 0, 32, ctx->stream));  // ([5]: set by a scan, cleared by the same scan)
+        VGX_HIP(ctx, hipMemsetAsync(I->d_mcounters, 0, 32, ctx->tsdf_stream));  // ([5]: set by a scan, cleared by the same scan)
       }
       size_t bytes = 0;
       VGX_HIP(ctx, stable_sort_pairs_u64(nullptr, bytes, I->d_mkeys[0], I->d_mkeys[1], I->d_midx[0], I->d_midx[1], (size_t)n,
-                                         ctx->stream));
+                                         ctx->tsdf_stream));
       VGX_HIP(ctx, hipMalloc(&I->d_msort, std::max<size_t>(bytes, 16)));
       I->msort_bytes = bytes;
       I->merged_cap = n;
@@ -1382,14 +1390,14 @@ static int merged_integrate_locked(vgx_tsdf_integrator I, const float T[7], cons
     rc = det_counters(I, &scan_ctr);
     if (rc != VGX_OK) return rc;
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-    hipLaunchKernelGGL(merged_bundle_kernel, grid, block, 0, ctx->stream, c, I->layer->dev.voxel_size_inv, T[0], T[1],
+    hipLaunchKernelGGL(merged_bundle_kernel, grid, block, 0, ctx->tsdf_stream, c, I->layer->dev.voxel_size_inv, T[0], T[1],
                        T[2], T[3], T[4], T[5], T[6], (const float*)d_points, (long long)n, order, (int)freespace,
                        I->d_mkeys[0], I->d_midx[0], I->d_mcounters, I->d_gcount, scan_ctr);
     VGX_HIP(ctx, hipGetLastError());
     size_t bytes = I->msort_bytes;
     // stable: equal keys keep the visiting order they were written in
     VGX_HIP(ctx, stable_sort_pairs_u64(I->d_msort, bytes, I->d_mkeys[0], I->d_mkeys[1], I->d_midx[0], I->d_midx[1], (size_t)n,
-                                       ctx->stream));
+                                       ctx->tsdf_stream));
     keys_sorted = I->d_mkeys[1];
     idx_sorted = I->d_midx[1];
     {
@@ -1398,7 +1406,7 @@ static int merged_integrate_locked(vgx_tsdf_integrator I, const float T[7], cons
       TileChain chain;
       rc = det_next_chain(I, head_tiles, &chain);
       if (rc != VGX_OK) return rc;
-      hipLaunchKernelGGL(merged_heads_kernel, dim3(head_tiles), block, 0, ctx->stream, keys_sorted, (long long)n, chain, I->d_mstart,
+      hipLaunchKernelGGL(merged_heads_kernel, dim3(head_tiles), block, 0, ctx->tsdf_stream, keys_sorted, (long long)n, chain, I->d_mstart,
                          I->d_mcounters);
       VGX_HIP(ctx, hipGetLastError());
     }
@@ -1408,7 +1416,7 @@ static int merged_integrate_locked(vgx_tsdf_integrator I, const float T[7], cons
     const int lanes = I->merged_lanes;
     const unsigned work_groups = (unsigned)std::min<long long>(((long long)n * lanes + 255) / 256, (long long)ctx->cu_count * 16);
 #define VGX_LAUNCH_MERGE(L)                                                                                                        \
-    hipLaunchKernelGGL(merged_merge_kernel<L>, dim3(work_groups), block, 0, ctx->stream, c, I->layer->dev.voxel_size_inv, T[0],    \
+    hipLaunchKernelGGL(merged_merge_kernel<L>, dim3(work_groups), block, 0, ctx->tsdf_stream, c, I->layer->dev.voxel_size_inv, T[0],    \
                        T[1], T[2], T[3], T[4], T[5], T[6], (const float*)d_points, (const uint32_t*)d_rgba, keys_sorted, idx_sorted, \
                        I->d_mstart, I->d_mcounters, I->d_gpg, I->d_gcolor, I->d_gflags, I->d_gcount, I->d_mcounters + 5, scan_ctr)
     if (lanes == 4) VGX_LAUNCH_MERGE(4);
@@ -1429,8 +1437,8 @@ static int merged_integrate_locked(vgx_tsdf_integrator I, const float T[7], cons
   }
   if (n_updates) {  // an empty scan
     unsigned long long u = 0;
-    VGX_HIP(ctx, hipMemcpyAsync(&u, I->dev.n_updates, 8, hipMemcpyDeviceToHost, ctx->stream));
-    VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    VGX_HIP(ctx, hipMemcpyAsync(&u, I->dev.n_updates, 8, hipMemcpyDeviceToHost, ctx->tsdf_stream));
+    VGX_HIP(ctx, hipStreamSynchronize(ctx->tsdf_stream));
     *n_updates = (int64_t)u;
   }
   return VGX_OK;
@@ -1445,10 +1453,10 @@ int vgx_tsdf_integrate_merged_device(vgx_tsdf_integrator I, const float T[7], co
 
 static int stage_scan(vgx_tsdf_integrator I, const float* points, const uint8_t* rgba, int64_t n) {
   vgx_ctx ctx = I->ctx;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::mutex> lk(ctx->tsdf_mu);
   VGX_HIP(ctx, hipSetDevice(ctx->device));
   if (n > I->staging_cap) {
-    VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    VGX_HIP(ctx, hipStreamSynchronize(ctx->tsdf_stream));
     if (I->d_points) (void)hipFree(I->d_points);
     if (I->d_rgba) (void)hipFree(I->d_rgba);
     I->d_points = nullptr;
@@ -1459,9 +1467,9 @@ static int stage_scan(vgx_tsdf_integrator I, const float* points, const uint8_t*
     I->staging_cap = n;
   }
   if (n > 0) {
-    VGX_HIP(ctx, hipMemcpyAsync(I->d_points, points, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+    VGX_HIP(ctx, hipMemcpyAsync(I->d_points, points, (size_t)n * 12, hipMemcpyHostToDevice, ctx->tsdf_stream));
     if (rgba)
-      VGX_HIP(ctx, hipMemcpyAsync(I->d_rgba, rgba, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+      VGX_HIP(ctx, hipMemcpyAsync(I->d_rgba, rgba, (size_t)n * 4, hipMemcpyHostToDevice, ctx->tsdf_stream));
   }
   return VGX_OK;
 }
@@ -1503,11 +1511,11 @@ int vgx_tsdf_integrator_walk_stats(vgx_tsdf_integrator I, int64_t stats[7]) {
   if (!I || !stats) return VGX_ERR_INVALID;
   std::lock_guard<std::mutex> own(I->mu);
   vgx_ctx ctx = I->ctx;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::mutex> lk(ctx->tsdf_mu);
   VGX_HIP(ctx, hipSetDevice(ctx->device));
   unsigned long long u[kScanStatWords - 1] = {};
-  VGX_HIP(ctx, hipMemcpyAsync(u, I->dev.n_updates + 1, sizeof(u), hipMemcpyDeviceToHost, ctx->stream));
-  VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  VGX_HIP(ctx, hipMemcpyAsync(u, I->dev.n_updates + 1, sizeof(u), hipMemcpyDeviceToHost, ctx->tsdf_stream));
+  VGX_HIP(ctx, hipStreamSynchronize(ctx->tsdf_stream));
   for (int k = 0; k < kScanStatWords - 1; ++k) stats[k] = (int64_t)u[k];
   return VGX_OK;
 }
@@ -1518,7 +1526,7 @@ int vgx_tsdf_integrator_read_trace(vgx_tsdf_integrator I, int64_t* rows, int64_t
   if (!I || !n_workgroups || max_workgroups < 0) return VGX_ERR_INVALID;
   std::lock_guard<std::mutex> own(I->mu);
   vgx_ctx ctx = I->ctx;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::mutex> lk(ctx->tsdf_mu);
   VGX_HIP(ctx, hipSetDevice(ctx->device));
   *n_workgroups = I->wg_stats_rows;
   if (clock_khz) {
@@ -1528,8 +1536,8 @@ int vgx_tsdf_integrator_read_trace(vgx_tsdf_integrator I, int64_t* rows, int64_t
   }
   const long long take = I->wg_stats_rows < max_workgroups ? I->wg_stats_rows : max_workgroups;
   if (rows && take > 0) {
-    VGX_HIP(ctx, hipMemcpyAsync(rows, I->d_wg_stats, (size_t)take * kWgStatWords * 8, hipMemcpyDeviceToHost, ctx->stream));
-    VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    VGX_HIP(ctx, hipMemcpyAsync(rows, I->d_wg_stats, (size_t)take * kWgStatWords * 8, hipMemcpyDeviceToHost, ctx->tsdf_stream));
+    VGX_HIP(ctx, hipStreamSynchronize(ctx->tsdf_stream));
   }
   return VGX_OK;
 }

@@ -1117,7 +1117,7 @@ __global__ __launch_bounds__(256) void det_merged_walk_kernel(vgx_tsdf_config c,
 // ---------------------------------------------------------------------------------------------------
 int grow(vgx_ctx ctx, Buf& b, size_t bytes) {
   if (b.bytes >= bytes) return VGX_OK;
-  VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  VGX_HIP(ctx, hipStreamSynchronize(ctx->tsdf_stream));
   if (b.p) (void)hipFree(b.p);
   b.p = nullptr;
   b.bytes = 0;
@@ -1167,7 +1167,7 @@ struct PhaseClock {
 // a 4-byte device value into one of the pinned words behind the counters' mirror (valid after read_counters)
 int fetch_u32(vgx_ctx ctx, DetScratch* S, int word, const void* dev) {
   S->h_ctr[word] = 0ull;
-  VGX_HIP(ctx, hipMemcpyAsync(&S->h_ctr[word], dev, 4, hipMemcpyDeviceToHost, ctx->stream));
+  VGX_HIP(ctx, hipMemcpyAsync(&S->h_ctr[word], dev, 4, hipMemcpyDeviceToHost, ctx->tsdf_stream));
   return VGX_OK;
 }
 
@@ -1175,7 +1175,7 @@ int grow_zeroed(vgx_ctx ctx, Buf& b, size_t bytes) {
   if (b.bytes >= bytes) return VGX_OK;
   int rc = grow(ctx, b, bytes);
   if (rc != VGX_OK) return rc;
-  VGX_HIP(ctx, hipMemsetAsync(b.p, 0, b.bytes, ctx->stream));
+  VGX_HIP(ctx, hipMemsetAsync(b.p, 0, b.bytes, ctx->tsdf_stream));
   return VGX_OK;
 }
 
@@ -1193,7 +1193,7 @@ int wait_for_sweep(vgx_ctx ctx, DetScratch* S, unsigned long long seq, unsigned 
       __builtin_ia32_pause();
       continue;
     }
-    const hipError_t e = hipStreamQuery(ctx->stream);
+    const hipError_t e = hipStreamQuery(ctx->tsdf_stream);
     if (e == hipSuccess) {  // everything queued has run: the report is there, or it never will be
       const unsigned long long w2 = __atomic_load_n(S->h_flag, __ATOMIC_ACQUIRE);
       if ((w2 >> 2) >= seq) {
@@ -1213,11 +1213,11 @@ int sort_by_slot(vgx_ctx ctx, DetScratch* S, const uint32_t* keys, uint32_t* key
                  unsigned end_bit) {
   size_t bytes = 0;
   auto iota = rocprim::make_counting_iterator<uint32_t>(0u);
-  VGX_HIP(ctx, stable_sort_pairs(nullptr, bytes, keys, keys_sorted, iota, idx_sorted, n, end_bit, ctx->stream));
+  VGX_HIP(ctx, stable_sort_pairs(nullptr, bytes, keys, keys_sorted, iota, idx_sorted, n, end_bit, ctx->tsdf_stream));
   int rc = grow(ctx, S->tmp, bytes);
   if (rc != VGX_OK) return rc;
   bytes = S->tmp.bytes;
-  VGX_HIP(ctx, stable_sort_pairs(S->tmp.p, bytes, keys, keys_sorted, iota, idx_sorted, n, end_bit, ctx->stream));
+  VGX_HIP(ctx, stable_sort_pairs(S->tmp.p, bytes, keys, keys_sorted, iota, idx_sorted, n, end_bit, ctx->tsdf_stream));
   return VGX_OK;
 }
 
@@ -1226,7 +1226,7 @@ int next_chain(vgx_ctx ctx, DetScratch* S, uint32_t tiles, TileChain* ch) {
   int rc = grow_zeroed(ctx, S->tile_state, (size_t)tiles * 8);
   if (rc != VGX_OK) return rc;
   if (S->sweep_epoch >= kChainEpochMax) {  // (after 2^30 launches: start the tags over)
-    VGX_HIP(ctx, hipMemsetAsync(S->tile_state.p, 0, S->tile_state.bytes, ctx->stream));
+    VGX_HIP(ctx, hipMemsetAsync(S->tile_state.p, 0, S->tile_state.bytes, ctx->tsdf_stream));
     S->sweep_epoch = 0;
   }
   ++S->sweep_epoch;
@@ -1240,8 +1240,8 @@ int next_chain(vgx_ctx ctx, DetScratch* S, uint32_t tiles, TileChain* ch) {
 }
 
 int read_counters(vgx_ctx ctx, DetScratch* S) {
-  VGX_HIP(ctx, hipMemcpyAsync(S->h_ctr, S->d_ctr, kCtrCount * 8, hipMemcpyDeviceToHost, ctx->stream));
-  VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  VGX_HIP(ctx, hipMemcpyAsync(S->h_ctr, S->d_ctr, kCtrCount * 8, hipMemcpyDeviceToHost, ctx->tsdf_stream));
+  VGX_HIP(ctx, hipStreamSynchronize(ctx->tsdf_stream));
   return VGX_OK;
 }
 
@@ -1296,7 +1296,7 @@ static int det_commit(vgx_tsdf_integrator I, DetScratch* S, const float T[7], si
   vgx_ctx ctx = I->ctx;
   vgx_tsdf_layer layer = I->layer;
   const vgx_tsdf_config& c = I->dev.cfg;
-  hipStream_t st = ctx->stream;
+  hipStream_t st = ctx->tsdf_stream;
   size_t M = N;
   const uint32_t* c_idx = S->s_idx.as<uint32_t>();  // without a filter every sorted access is an update
   const uint32_t* c_key = S->s_key.as<uint32_t>();
@@ -1435,7 +1435,7 @@ int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points,
   vgx_ctx ctx = I->ctx;
   vgx_tsdf_layer layer = I->layer;
   const vgx_tsdf_config& c = I->dev.cfg;
-  hipStream_t st = ctx->stream;
+  hipStream_t st = ctx->tsdf_stream;
   if (n_updates) *n_updates = 0;
   if (n >= (1ll << 31)) return set_error(ctx, VGX_ERR_UNSUPPORTED, "TSDF reproducible mode: more than 2^31 points in a scan");
   DET_TRY(ensure_scratch(I));
@@ -1661,7 +1661,7 @@ int det_merged_commit(vgx_tsdf_integrator I, const float T[7], long long n, cons
                       const unsigned int* group_start, const unsigned int* counters, int64_t* n_updates) {
   vgx_ctx ctx = I->ctx;
   const vgx_tsdf_config& c = I->dev.cfg;
-  hipStream_t st = ctx->stream;
+  hipStream_t st = ctx->tsdf_stream;
   if (n_updates) *n_updates = 0;
   DET_TRY(ensure_scratch(I));
   DetScratch* S = I->det;
