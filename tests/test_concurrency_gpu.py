@@ -95,7 +95,7 @@ def test_scans_integrate_while_the_pose_graph_is_evaluated(capi):
         assert ctx.get_tsdf_stream() != ctx.get_stream() and ctx.get_tsdf_stream() != 0
         scans = _scans(200)
         subs, cfs, batch, pairs, guess = _graph(capi, ctx)
-        n_normal, n_dropin = 50, 10
+        n_normal, n_dropin = 300, 10
         # warm both sides (allocations, first-use initialisation)
         _integrate(capi, ctx, scans[:3])
         _evaluate(capi, batch, cfs, pairs, guess, 2, 2)
@@ -111,9 +111,13 @@ def test_scans_integrate_while_the_pose_graph_is_evaluated(capi):
         # ---- together, on two threads
         res, err = {}, []
 
+        took = {}
+
         def run(name, fn):
             try:
+                s0 = time.perf_counter()
                 res[name] = fn()
+                took[name] = time.perf_counter() - s0
             except BaseException as e:    # noqa: BLE001  (a failed assertion in a thread must fail the test)
                 err.append((name, repr(e)))
         ta = threading.Thread(target=run, args=("layer", lambda: _integrate(capi, ctx, scans)))
@@ -131,14 +135,14 @@ def test_scans_integrate_while_the_pose_graph_is_evaluated(capi):
         assert dropped_c == 0
         for x, y in zip(layer_serial, layer_conc):
             assert np.array_equal(x.view(np.uint8), y.view(np.uint8))
-        assert len(layer_serial[0]) > 50
+        assert len(layer_serial[0]) > 20
         for x, y in zip(blocks_serial, blocks_conc):
             assert np.array_equal(x.view(np.uint64), y.view(np.uint64))
         for (r0, a0, b0), (r1, a1, b1) in zip(rows_serial, rows_conc):
             assert np.array_equal(r0, r1) and np.array_equal(a0, a1) and np.array_equal(b0, b1)
         assert any(np.abs(b).max() > 0 for b in blocks_serial)
         print(f"serial: scans {t_a * 1e3:.1f} ms + evaluations {t_b * 1e3:.1f} ms = {(t_a + t_b) * 1e3:.1f} ms; "
-              f"concurrent: {t_both * 1e3:.1f} ms")
+              f"concurrent: {t_both * 1e3:.1f} ms (scans {took['layer'] * 1e3:.1f}, evaluations {took['reg'] * 1e3:.1f})")
         # ---- and an overlap: less than one after the other (the reproducible mode waits for the device several times
         # per scan -- the other side's kernels run meanwhile)
         assert t_both < 0.97 * (t_a + t_b), (t_a, t_b, t_both)
