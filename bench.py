@@ -969,7 +969,7 @@ def main():
         out["pipeline_config2"] = pipeline.run(capi, ctx, torch, n_submaps=30 if full else 10,
                                                scans_per_submap=100 if full else 30)
         out["pipeline_config2"]["cut"] = "full: 30 submaps x 100 scans" if full else \
-            "bounded: 10 submaps x 30 scans of the 30 x 100 session (python bench.py --pipeline runs all of it)"
+            "10 x 30 miniature of the 30 x 100 session (--pipeline runs all of it)"
         out["pipeline_config2"]["tsdf_mode"] = "racing (the default: a different legal interleaving every run)"
         # The racing TSDF mode moves the end state from run to run (xy RMSE 0.059 / 0.066 / 0.114 m for the
         # same inputs).  The same cut with the scans integrated in the REPRODUCIBLE mode gives the same maps and the

@@ -45,6 +45,8 @@ def _tsdf(t):
             "reproducible_bit_identical_to_oracle": (rm.get("parity_vs_oracle") or {}).get("bit_identical"),
             "sorted_order_bit_identical_to_oracle": (rm.get("parity_vs_oracle_sorted_order") or {}).get("bit_identical"),
             "cpu_Mpoints_per_s_1_core": cb.get("Mpoints_per_s"),
+            # the one-core rate the flag below is held against (the same scan sequence the replicas run, steady state)
+            "cpu_Mpoints_per_s_1_core_same_sequence": ac.get("one_core_same_sequence_Mpoints_per_s"),
             "cpu_Mpoints_per_s_all_cores": ac.get("Mpoints_per_s"), "cpu_cores": ac.get("cores"),
             "cpu_all_cores_at_most_cores_x_one": ac.get("at_most_cores_x_one_core")}
 
@@ -137,7 +139,7 @@ def compact(full, detail_path):
         out["config5"] = o
     c2 = d.get("pipeline_config2")
     if c2:
-        out["pipeline_config2"] = _pick(c2, ("submaps", "scans", "tsdf_integrate_ms_per_scan", "finish_submap_ms",
+        out["pipeline_config2"] = _pick(c2, ("cut", "submaps", "scans", "tsdf_integrate_ms_per_scan", "finish_submap_ms",
                                              "solves", "solve_ms_total", "xy_rmse_m_odometry_only",
                                              "xy_rmse_m_optimised", "dropped_updates"))
         rep = c2.get("reproducible_tsdf_mode") or {}

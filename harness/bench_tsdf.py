@@ -15,15 +15,33 @@ def _room_points(dirs, origin):
     return (dirs * t.min(1)[:, None]).astype(np.float32)
 
 
+def tsdf_sources_sha():
+    """sha256 over the TSDF sources the sort-based paths are made of (what profiles/tsdf_launches.sh records with a trace)"""
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for name in ("vgx_tsdf.hip", "vgx_tsdf_det.hip", "vgx_tsdf_internal.h"):
+        try:
+            h.update(open(os.path.join(root, "voxgraph_amd", "csrc", name), "rb").read())
+        except OSError:
+            return None
+    return h.hexdigest()[:16]
+
+
 def profiled_launches():
     """kernel launches per scan of the sort-based paths, from the committed rocprofv3 trace of the same sensor shapes
-    (profiles/r04b_tsdf_launches.txt, profiles/tsdf_launches.sh): {("fast" | "merged", "lidar" | "rgbd"): launches}"""
-    import os
+    (profiles/r05_tsdf_launches.txt, made by profiles/tsdf_launches.sh): {("fast" | "merged", "lidar" | "rgbd"): launches}
+    -- and only if the trace was taken on THESE sources (the script records their hash; ADVICE r4: a stale count divided
+    into a fresh time is a wrong microseconds-per-launch without notice).  Returns (counts, note)."""
     import re
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r04b_tsdf_launches.txt")
-    out, key = {}, None
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "profiles", "r05_tsdf_launches.txt")
+    out, key, sha = {}, None, None
     try:
         for line in open(path):
+            m = re.match(r"sources sha256: (\w+)", line)
+            if m:
+                sha = m.group(1)
             m = re.match(r"=== (fast|merged) det=\d (lidar|rgbd)", line)
             if m:
                 key = (m.group(1), m.group(2))
@@ -32,8 +50,11 @@ def profiled_launches():
                 out[key] = int(m.group(1))
                 key = None
     except OSError:
-        pass
-    return out
+        return {}, "no committed trace (profiles/r05_tsdf_launches.txt)"
+    now = tsdf_sources_sha()
+    if sha is None or now is None or sha != now:
+        return {}, f"the committed trace was taken on other sources (trace {sha}, these {now}): launch counts dropped"
+    return out, f"profiles/r05_tsdf_launches.txt, sources {sha}"
 
 
 def sensor_cases():
@@ -78,7 +99,7 @@ def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=8):
     from oracle import pyoracle as orc
     out = {}
     cases = sensor_cases()
-    launches = profiled_launches()
+    launches, launches_note = profiled_launches()
     for name, (dirs, vs, kw, bmin, bdim) in cases.items():
         sensor = "rgbd" if name.startswith("rgbd") else "lidar"
         poses, clouds = session_scans(dirs, scans)
@@ -393,6 +414,7 @@ def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=8):
                                                            # SURVEY 8d's pricing and is NOT what bounds it
                                                            "roofline": {"bound": "launch", "unit": "GB/s", "hbm_peak_GBs": HBM_PEAK_GBS,
                                                         "launches_per_scan_from_profiles": launches.get(("merged", sensor)),
+                                                        "launches_source": launches_note,
                                                         "us_per_launch": (merged_ms * 1e3 / launches[("merged", sensor)]
                                                                           if ("merged", sensor) in launches else None),
                                                         "bytes_per_launch": 16.0 * n_pts + 24.0 * merged_updates,
@@ -410,6 +432,7 @@ def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=8):
                                            # launch / latency bound like the merged integrator
                                            "roofline": {"bound": "launch",
                                                         "launches_per_scan_from_profiles": launches.get(("fast", sensor)),
+                                                        "launches_source": launches_note,
                                                         "us_per_launch": (det_ms * 1e3 / launches[("fast", sensor)]
                                                                           if ("fast", sensor) in launches else None),
                                                         "host_waits_per_scan": "2 (the count, the commit) + 1 per extra attempt; "

@@ -455,6 +455,10 @@ typedef struct vgx_tsdf_integrator_s* vgx_tsdf_integrator; /* voxblox::FastTsdfI
  * its own thread; integration_order_mode (voxgraph_mapper.yaml:29) is `integration_order` below. */
 #define VGX_TSDF_ORDER_MIXED 0  /* integration_order_mode "mixed" (voxblox's and voxgraph's default) */
 #define VGX_TSDF_ORDER_SORTED 1 /* "sorted": points visited by ascending squared norm of point_C    */
+/* ABI note: the struct grew at its END in rounds 3 (deterministic) and 4 (integration_order), and every field is
+ * validated (an integration_order that is neither value is refused with VGX_ERR_INVALID).  Fill it with
+ * vgx_tsdf_config_default() -- or zero it -- before setting fields; a caller compiled against an older header must be
+ * rebuilt (the library reads sizeof(vgx_tsdf_config) bytes). */
 typedef struct vgx_tsdf_config {
   float default_truncation_distance;    /* 0.1   */
   float max_weight;                     /* 10000 */

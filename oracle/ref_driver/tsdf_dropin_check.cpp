@@ -194,7 +194,18 @@ int main() {
           for (int q = 0; q < 4; ++q) cols.push_back((uint8_t)C(rng));
         }
       const float T[7] = {1, 0, 0, 0, 0.05f + 3.0f * scan, 0.02f, 0.03f};
-      gpu.integratePointCloud(T, pts.data(), cols.data(), (int64_t)pts.size() / 3);
+      // the reference's own call, with voxblox's types (pointcloud_integrator.cpp:83): Transformation, Pointcloud, Colors
+      {
+        voxblox::Transformation T_G_C(voxblox::Transformation::Rotation(T[0], T[1], T[2], T[3]),
+                                      voxblox::Transformation::Position(T[4], T[5], T[6]));
+        std::vector<voxblox::Point> pointcloud(pts.size() / 3);
+        std::vector<voxblox::Color> colors(pts.size() / 3);
+        for (size_t q = 0; q < pointcloud.size(); ++q) {
+          pointcloud[q] = voxblox::Point(pts[3 * q], pts[3 * q + 1], pts[3 * q + 2]);
+          colors[q].r = cols[4 * q]; colors[q].g = cols[4 * q + 1]; colors[q].b = cols[4 * q + 2]; colors[q].a = cols[4 * q + 3];
+        }
+        gpu.integratePointCloud(T_G_C, pointcloud, colors);
+      }
       orc_tsdf_integrate(oi, T, pts.data(), cols.data(), (int64_t)pts.size() / 3, 0);
       ++tot.scans;
     }

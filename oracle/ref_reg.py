@@ -13,7 +13,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_ref", "libref_reg.so")
+# VGX_REF_DIR: another build of the same driver (oracle/PIN.md: the reference sources against the REAL voxblox headers)
+_SO = os.path.join(os.environ.get("VGX_REF_DIR") or os.path.join(_HERE, "_ref"), "libref_reg.so")
 _LIB = None
 
 POINTS_ISOSURFACE, POINTS_VOXELS = 0, 1

@@ -8,6 +8,8 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 : > $OUT/tsdf_launches.txt
+# the sources this trace describes (harness/bench_tsdf.py profiled_launches drops the counts when they differ)
+echo "sources sha256: $(cd $REPO && python -c 'from harness.bench_tsdf import tsdf_sources_sha; print(tsdf_sources_sha())')" >> $OUT/tsdf_launches.txt
 for cfg in "fast 1 lidar det_points" "fast 1 rgbd det_points" "merged 0 lidar merged_bundle" "merged 0 rgbd merged_bundle"; do
   set -- $cfg
   rm -rf $OUT/prof_tl

@@ -87,7 +87,73 @@ def run(make_layer, make_integrator, kw, merged, scans):
     return {"updates": updates, "blocks": int(len(layer.download()[0])), "sha256": digest(layer.download())}
 
 
+CFG_FIELDS = ("default_truncation_distance", "max_weight", "voxel_carving_enabled", "min_ray_length_m", "max_ray_length_m",
+              "use_const_weight", "allow_clear", "use_weight_dropoff", "use_sparsity_compensation_factor",
+              "sparsity_compensation_factor", "start_voxel_subsampling_factor", "max_consecutive_ray_collisions",
+              "clear_checks_every_n_frames", "enable_anti_grazing", "integration_order")
+
+
+def dump_sessions(path):
+    """oracle/PIN.md: the sessions as one little-endian file for oracle/ref_driver/voxblox_tsdf_pin.cpp --
+    int32 n_sessions; per session: char name[64], float cfg[15] (CFG_FIELDS, voxblox defaults where a session sets
+    nothing; integration_order 0 mixed / 1 sorted), int32 merged, int32 n_scans; per scan: float T[7] (qw qx qy qz tx ty tz),
+    int32 n, float pts[n][3], uint8 rgba[n][4].  Voxel size 0.2, 16 voxels per side."""
+    import struct
+    from oracle import pyoracle as orc
+    with open(path, "wb") as f:
+        ss = sessions()
+        f.write(struct.pack("<i", len(ss)))
+        for name, kw, merged, scans in ss:
+            cfg = orc.tsdf_config(**oracle_kw(kw))
+            vals = [float(getattr(cfg, k)) if k != "integration_order" else float(kw.get("integration_order", 0)) for k in CFG_FIELDS]
+            f.write(name.encode().ljust(64, b"\0")[:64])
+            f.write(struct.pack("<15f", *vals))
+            f.write(struct.pack("<ii", int(merged), len(scans)))
+            for T, pts, col in scans:
+                f.write(np.asarray(T, F).tobytes())
+                f.write(struct.pack("<i", len(pts)))
+                f.write(np.ascontiguousarray(pts, F).tobytes())
+                f.write(np.ascontiguousarray(col, np.uint8).tobytes())
+    print("wrote", path)
+
+
+def compare_layers(directory):
+    """oracle/PIN.md: <directory>/<session>.layer.bin as voxblox_tsdf_pin wrote them (int32 n_blocks; per block int32
+    index[3], float distance[4096], float weight[4096], uint8 rgba[4096][4]; any block order) against the oracle's
+    layers, blocks matched by index.  Exit code 1 on the first session that differs."""
+    from oracle import pyoracle as orc
+    bad = 0
+    for name, kw, merged, scans in sessions():
+        layer = orc.TsdfLayer(0.2, 16)
+        integ = orc.FastTsdfIntegrator(orc.tsdf_config(**oracle_kw(kw)), layer)
+        for T, pts, col in scans:
+            (integ.integratePointCloudMerged if merged else integ.integratePointCloud)(T, pts, col)
+        bi, d, w, c = layer.download()
+        raw = open(os.path.join(directory, name + ".layer.bin"), "rb").read()
+        n = int(np.frombuffer(raw, np.int32, 1)[0])
+        rec = np.dtype([("index", np.int32, 3), ("d", F, 4096), ("w", F, 4096), ("c", np.uint8, (4096, 4))])
+        theirs = np.frombuffer(raw, rec, n, 4)
+        ours = {tuple(b): k for k, b in enumerate(bi)}
+        same_set = n == len(bi) and all(tuple(b) in ours for b in theirs["index"])
+        nd = nw = nc = 0
+        if same_set:
+            for b in theirs:
+                k = ours[tuple(b["index"])]
+                nd += int((b["d"].view(np.uint32) != d[k].view(np.uint32)).sum())
+                nw += int((b["w"].view(np.uint32) != w[k].view(np.uint32)).sum())
+                nc += int((b["c"] != c[k].reshape(4096, 4)).any(1).sum())
+        ok = same_set and nd == nw == nc == 0
+        bad += 0 if ok else 1
+        print(f"{name}: blocks voxblox {n} / oracle {len(bi)}, same block set {same_set}; voxels differing in distance {nd}, "
+              f"weight {nw}, colour {nc} -> {'IDENTICAL' if ok else 'DIFFERENT'}")
+    sys.exit(1 if bad else 0)
+
+
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--dump":
+        return dump_sessions(sys.argv[2])
+    if len(sys.argv) == 3 and sys.argv[1] == "--compare":
+        return compare_layers(sys.argv[2])
     from oracle import pyoracle as orc
     out = {}
     for name, kw, merged, scans in sessions():

@@ -148,3 +148,49 @@ def test_a_batch_refuses_submaps_of_different_layouts(capi):
     for o in cfs + [g0, g1]:
         o.destroy()
     ctx.close()
+
+
+def test_a_sampling_batch_falls_back_to_apron_bricks_when_the_quad_copy_does_not_fit():
+    """quad bricks on demand are the default for an all-sampling batch and cost 4.25 x the apron bricks per
+    reading submap.  When that allocation fails the batch must still be created -- on the apron bricks, with the same
+    results (the layout never shows in them) -- and the copies made for it so far must be given back.  The failure is
+    simulated (VGX_TEST_QUAD_ALLOC_FAILS_AFTER=1: the second quad allocation of the process fails), in a child process
+    because the switch is read once."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import numpy as np
+from oracle import synth
+from tests import helpers as H
+from voxgraph_amd import capi
+def world(sampling_bricks=None):
+    ctx = capi.Context(0)
+    if sampling_bricks is not None:
+        ctx.set_sampling_bricks(sampling_bricks)
+    ref, read = synth.config1_pair(asymmetric=True)
+    subs = [H.gpu_submap(capi, ctx, sm, k) for k, sm in enumerate((ref, read))]
+    for g in subs:
+        g.extract_voxel_points(1.0, 0.3, True)
+    return ctx, subs
+poses = np.array([[0.02, -0.01, 0.03, 0.01], [0.31, -0.2, 0.08, 0.12]])
+def run(ctx, subs):
+    cfg = capi.default_config(registration_point_type=capi.POINTS_VOXELS, sampling_ratio=0.3, sampler_seed=7)
+    cfs = [capi.RegistrationCostFunction(ctx, subs[a], subs[b], cfg) for a, b in ((0, 1), (1, 0))]
+    batch = capi.RegistrationBatch(ctx, cfs, [(0, 1), (1, 0)])      # two reading submaps: the second quad copy "fails"
+    layout = batch.brick_layout()
+    status, normal = batch.evaluate_normal(poses)
+    return layout, normal
+ctx, subs = world()
+layout, normal = run(ctx, subs)
+assert layout == capi.BRICKS_APRON, layout
+ctx2, subs2 = world(capi.SAMPLING_BRICKS_SAME)
+layout2, normal2 = run(ctx2, subs2)
+assert layout2 == capi.BRICKS_APRON and np.array_equal(normal, normal2) and np.abs(normal).max() > 0
+print("fallback ok")
+"""
+    env = dict(os.environ, VGX_TEST_QUAD_ALLOC_FAILS_AFTER="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "fallback ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+    assert "reads the apron bricks" in r.stderr

@@ -12,6 +12,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "voxgraph_amd.h"
 
@@ -86,6 +87,34 @@ class GpuFastTsdfIntegrator {
       throw std::runtime_error(std::string("vgx_tsdf_integrate: ") + vgx_last_error(ctx_));
   }
 
+  // The call voxgraph makes, with voxblox's own types (pointcloud_integrator.cpp:83, member type
+  // pointcloud_integrator.h:30):   integratePointCloud(T_submap_sensor, pointcloud, colors, freespace_points = false)
+  //   Transformation  kindr::minimal::QuatTransformationTemplate<float>: getRotation().{w,x,y,z}(), getPosition()[k]
+  //   Pointcloud      AlignedVector<Eigen::Vector3f>: contiguous 12-byte elements
+  //   Colors          AlignedVector<voxblox::Color>:  contiguous RGBA8; may be empty
+  // Templated (containers only: arrays take the overload above), so it compiles against the real headers and against
+  // the stand-ins of oracle/ref_shims alike.
+  template <class Transformation, class Pointcloud, class Colors, class = typename Pointcloud::value_type,
+            class = typename Colors::value_type>
+  void integratePointCloud(const Transformation& T_G_C, const Pointcloud& points_C, const Colors& colors,
+                           bool freespace_points = false) {
+    static_assert(sizeof(typename Pointcloud::value_type) == 12, "Pointcloud: three packed floats per point");
+    static_assert(sizeof(typename Colors::value_type) == 4, "Colors: RGBA8 per point");
+    if (!colors.empty() && colors.size() != points_C.size())
+      throw std::invalid_argument("integratePointCloud: colors and points differ in length");  // voxblox CHECK_EQ
+    const auto& q = T_G_C.getRotation();
+    const auto& t = T_G_C.getPosition();
+    const float T[7] = {(float)q.w(), (float)q.x(), (float)q.y(), (float)q.z(), (float)t[0], (float)t[1], (float)t[2]};
+    integratePointCloud(T, reinterpret_cast<const float*>(points_C.data()),
+                        colors.empty() ? nullptr : reinterpret_cast<const uint8_t*>(colors.data()), (int64_t)points_C.size(),
+                        freespace_points);
+  }
+  // an ORGANISED cloud's row length (sensor_msgs/PointCloud2.width, which voxgraph's callback has and voxblox's flat
+  // Pointcloud drops): vgx_tsdf_integrator_set_cloud_width; 0 = unorganised
+  void setCloudWidth(int32_t width) {
+    if (vgx_tsdf_integrator_set_cloud_width(integ_, width) != VGX_OK) throw std::invalid_argument("setCloudWidth: negative width");
+  }
+
  private:
   vgx_ctx ctx_;
   vgx_tsdf_integrator integ_ = nullptr;
@@ -115,6 +144,34 @@ class GpuMergedTsdfIntegrator {
     if (vgx_tsdf_integrate_merged(integ_, T_G_C, points_C, colors, n_points, freespace_points ? 1 : 0,
                                   nullptr) != VGX_OK)
       throw std::runtime_error(std::string("vgx_tsdf_integrate_merged: ") + vgx_last_error(ctx_));
+  }
+
+  // The call voxgraph makes, with voxblox's own types (pointcloud_integrator.cpp:83, member type
+  // pointcloud_integrator.h:30):   integratePointCloud(T_submap_sensor, pointcloud, colors, freespace_points = false)
+  //   Transformation  kindr::minimal::QuatTransformationTemplate<float>: getRotation().{w,x,y,z}(), getPosition()[k]
+  //   Pointcloud      AlignedVector<Eigen::Vector3f>: contiguous 12-byte elements
+  //   Colors          AlignedVector<voxblox::Color>:  contiguous RGBA8; may be empty
+  // Templated (containers only: arrays take the overload above), so it compiles against the real headers and against
+  // the stand-ins of oracle/ref_shims alike.
+  template <class Transformation, class Pointcloud, class Colors, class = typename Pointcloud::value_type,
+            class = typename Colors::value_type>
+  void integratePointCloud(const Transformation& T_G_C, const Pointcloud& points_C, const Colors& colors,
+                           bool freespace_points = false) {
+    static_assert(sizeof(typename Pointcloud::value_type) == 12, "Pointcloud: three packed floats per point");
+    static_assert(sizeof(typename Colors::value_type) == 4, "Colors: RGBA8 per point");
+    if (!colors.empty() && colors.size() != points_C.size())
+      throw std::invalid_argument("integratePointCloud: colors and points differ in length");  // voxblox CHECK_EQ
+    const auto& q = T_G_C.getRotation();
+    const auto& t = T_G_C.getPosition();
+    const float T[7] = {(float)q.w(), (float)q.x(), (float)q.y(), (float)q.z(), (float)t[0], (float)t[1], (float)t[2]};
+    integratePointCloud(T, reinterpret_cast<const float*>(points_C.data()),
+                        colors.empty() ? nullptr : reinterpret_cast<const uint8_t*>(colors.data()), (int64_t)points_C.size(),
+                        freespace_points);
+  }
+  // (the merged integrator ignores the hint) an ORGANISED cloud's row length (sensor_msgs/PointCloud2.width, which voxgraph's callback has and voxblox's flat
+  // Pointcloud drops): vgx_tsdf_integrator_set_cloud_width; 0 = unorganised
+  void setCloudWidth(int32_t width) {
+    if (vgx_tsdf_integrator_set_cloud_width(integ_, width) != VGX_OK) throw std::invalid_argument("setCloudWidth: negative width");
   }
 
  private:

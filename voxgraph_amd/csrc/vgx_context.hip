@@ -5,6 +5,8 @@
 #include <cstring>
 #include <numeric>
 
+#include <cstdlib>
+
 #include "vgx_internal.h"
 
 namespace vgx {
@@ -264,7 +266,11 @@ int vgx_submap_s::ensure_quad_grid(int which) {
   if ((unsigned long long)n_blocks * cells >= (1ull << 32))
     return set_error(ctx, VGX_ERR_UNSUPPORTED, "submap too large for 32-bit addressing of its quad bricks: " +
                                                    std::to_string(n_blocks) + " blocks");
-  if (hipMalloc(&g.d_quad, (size_t)n_blocks * cells * sizeof(float)) != hipSuccess) {
+  // (tests only: VGX_TEST_QUAD_ALLOC_FAILS_AFTER=k makes every allocation after the k-th fail, tests/test_brick_layout_gpu.py)
+  static const long fail_after = getenv("VGX_TEST_QUAD_ALLOC_FAILS_AFTER") ? atol(getenv("VGX_TEST_QUAD_ALLOC_FAILS_AFTER")) : -1;
+  static long made_so_far = 0;
+  const bool pretend_oom = fail_after >= 0 && made_so_far++ >= fail_after;
+  if (pretend_oom || hipMalloc(&g.d_quad, (size_t)n_blocks * cells * sizeof(float)) != hipSuccess) {
     (void)hipGetLastError();
     g.d_quad = nullptr;
     return set_error(ctx, VGX_ERR_NOMEM, "quad bricks for a sampling session: device allocation failed (" +

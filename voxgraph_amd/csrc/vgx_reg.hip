@@ -1885,11 +1885,34 @@ int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs, const int3
   for (int c = 0; c < n && quad_on_demand; ++c) quad_on_demand = regs[c]->sampling();
   if (quad_on_demand) {
     VGX_HIP(ctx, hipSetDevice(ctx->device));
-    for (int c = 0; c < n; ++c) {
-      const int rc_q = regs[c]->reading->ensure_quad_grid(regs[c]->cfg.use_esdf_distance ? 1 : 0);
-      if (rc_q != VGX_OK) return rc_q;
+    // Results never depend on the layout, so running out of memory for the second copy (4.25 x the apron bricks, kept for
+    // the submap's lifetime: ~340 MB per dense 256^3 submap) must not cost the batch: the copies made for THIS batch are
+    // given back and it reads the apron bricks everything else reads.
+    std::vector<std::pair<vgx_submap, int>> made;
+    for (int c = 0; c < n && quad_on_demand; ++c) {
+      const int which = regs[c]->cfg.use_esdf_distance ? 1 : 0;
+      const bool had = regs[c]->reading->grid[which].d_quad != nullptr;
+      const int rc_q = regs[c]->reading->ensure_quad_grid(which);
+      if (rc_q == VGX_OK) {
+        if (!had && regs[c]->reading->grid[which].d_quad) made.emplace_back(regs[c]->reading, which);
+        continue;
+      }
+      if (rc_q != VGX_ERR_NOMEM) return rc_q;
+      VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (the copies' kernels are in flight)
+      for (auto& m : made) {
+        (void)hipFree(m.first->grid[m.second].d_quad);
+        m.first->grid[m.second].d_quad = nullptr;
+      }
+      static bool told = false;
+      if (!told) {
+        told = true;
+        fprintf(stderr, "libvoxgraph_amd: no memory for the quad bricks of a sampling batch (%s); it reads the apron bricks "
+                        "instead -- same results, slower scattered evaluations\n", vgx_last_error(ctx));
+      }
+      set_error(ctx, VGX_OK, "no error");
+      quad_on_demand = false;
     }
-    layout = VGX_BRICKS_QUAD;
+    if (quad_on_demand) layout = VGX_BRICKS_QUAD;
   }
   vgx_reg_batch b = new (std::nothrow) vgx_reg_batch_s();
   if (!b) return set_error(ctx, VGX_ERR_NOMEM, "vgx_reg_batch_create: out of host memory");

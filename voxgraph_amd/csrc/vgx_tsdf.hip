@@ -1335,10 +1335,27 @@ static int integrate_locked(vgx_tsdf_integrator I, const float T[7], const void*
 }
 
 // MergedTsdfIntegrator::integratePointCloud with the scan already in device memory; the caller holds I->mu.
+static int merged_integrate_body(vgx_tsdf_integrator I, const float T[7], const void* d_points, const void* d_rgba,
+                                 int64_t n, int32_t freespace, int64_t* n_updates);
 static int merged_integrate_locked(vgx_tsdf_integrator I, const float T[7], const void* d_points, const void* d_rgba,
                                    int64_t n, int32_t freespace, int64_t* n_updates) {
   vgx_ctx ctx = I->ctx;
   std::lock_guard<std::mutex> lk(ctx->tsdf_mu);
+  const int rc = merged_integrate_body(I, T, d_points, d_rgba, n, freespace, n_updates);
+  if (rc != VGX_OK && I->d_mcounters) {
+    // a scan that stopped between its bundle and merge kernels would leave the "key corner" flag (counters[5]: set by
+    // the bundle kernel, cleared by the merge kernel of the same scan) for the NEXT scan to be refused by
+    const std::string why = vgx_last_error(ctx);
+    (void)hipMemsetAsync(I->d_mcounters + 5, 0, 4, ctx->tsdf_stream);
+    (void)hipGetLastError();
+    set_error(ctx, rc, why);
+  }
+  return rc;
+}
+
+static int merged_integrate_body(vgx_tsdf_integrator I, const float T[7], const void* d_points, const void* d_rgba,
+                                 int64_t n, int32_t freespace, int64_t* n_updates) {
+  vgx_ctx ctx = I->ctx;
   if (!I->layer) return set_error(ctx, VGX_ERR_INVALID, "vgx_tsdf_integrate_merged: no layer set");
   if (n > (int64_t)1 << 31) return set_error(ctx, VGX_ERR_UNSUPPORTED, "vgx_tsdf_integrate_merged: more than 2^31 points");
   VGX_HIP(ctx, hipSetDevice(ctx->device));

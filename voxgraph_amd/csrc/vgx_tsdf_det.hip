@@ -1290,6 +1290,22 @@ int det_next_chain(vgx_tsdf_integrator I, uint32_t tiles, TileChain* chain) {
 // ---- 3. the updates that happen, in sorted order -> compaction, new blocks, ordered application ----
 // (shared by both integrators: `update` says which of the N sorted accesses update their voxel; rays are
 // indexed by acc_ray, their point / weight / colour live in ray_pg / ray_color)
+// what a non-zero kCtrError means (vgx_tsdf_internal.h: 1-3 from the reproducible mode's kernels and the chained
+// prefix sums, 4-5 from the merged integrator's)
+static int det_error_code(vgx_ctx ctx, unsigned long long code) {
+  switch (code) {
+    case 0ull: return VGX_OK;
+    case 1ull: return set_error(ctx, VGX_ERR_UNSUPPORTED, "TSDF reproducible mode: a ray longer than 2^24 voxel steps");
+    case 2ull: return set_error(ctx, VGX_ERR_UNSUPPORTED, "TSDF reproducible mode: a voxel index beyond +-2^20 voxels of the layer origin");
+    case 3ull: return set_error(ctx, VGX_ERR_HIP, "TSDF reproducible mode: a tile of a chained kernel never reported (internal error)");
+    case kErrMergedRayTooLong: return set_error(ctx, VGX_ERR_UNSUPPORTED, "TSDF merged integrator: a ray longer than 2^24 voxel steps");
+    case kErrMergedKeyCorner:
+      return set_error(ctx, VGX_ERR_UNSUPPORTED,
+                       "TSDF merged integrator: a clearing point whose end voxel is 2^20 - 1 (mod 2^21) on all three axes cannot be keyed");
+    default: return set_error(ctx, VGX_ERR_HIP, "TSDF reproducible mode: unknown device error code " + std::to_string(code));
+  }
+}
+
 static int det_commit(vgx_tsdf_integrator I, DetScratch* S, const float T[7], size_t N,
                       const UpdateOp* update, bool update_set, bool ordered_blocks, const float4* ray_pg,
                       const uint32_t* ray_color, int64_t* n_updates, PhaseClock* pc = nullptr) {
@@ -1353,7 +1369,12 @@ static int det_commit(vgx_tsdf_integrator I, DetScratch* S, const float T[7], si
   }
   int32_t n_blocks_now = 0;
   if (M_dev && !ordered_blocks) DET_TRY(fetch_u32(ctx, S, kHostM, M_dev));  // (else: det_blocks_kernel left it in the counters)
-  if (M_dev || ordered_blocks) DET_TRY(read_counters(ctx, S));
+  if (M_dev || ordered_blocks) {
+    DET_TRY(read_counters(ctx, S));
+    // a look-back that timed out substituted a zero prefix (3), a walk left the +-2^20 band (2): the compaction
+    // would be wrong -- nothing is applied to the layer
+    if (S->h_ctr[kCtrError]) return det_error_code(ctx, S->h_ctr[kCtrError]);
+  }
   if (pc) pc->mark(4);
   if (ordered_blocks) {
     M = (size_t)S->h_ctr[kCtrM];
@@ -1515,8 +1536,7 @@ int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points,
     DET_TRY(read_counters(ctx, S));
     pc.mark(0);
     ++pc.attempts;
-    if (S->h_ctr[kCtrError])
-      return set_error(ctx, VGX_ERR_UNSUPPORTED, "TSDF reproducible mode: a ray longer than 2^24 voxel steps");
+    if (S->h_ctr[kCtrError]) return det_error_code(ctx, S->h_ctr[kCtrError]);
     const unsigned long long total = S->h_ctr[kCtrTotal];
     if (may_cap) {
       may_cap = false;
@@ -1648,9 +1668,7 @@ int det_integrate(vgx_tsdf_integrator I, const float T[7], const void* d_points,
   }
   if (range_error) {
     DET_TRY(read_counters(ctx, S));  // (also: what the sweeps queued ahead were still writing is off the stream)
-    if (S->h_ctr[kCtrError] == 3ull)
-      return set_error(ctx, VGX_ERR_HIP, "TSDF reproducible mode: a sweep's tile never reported (internal error)");
-    return set_error(ctx, VGX_ERR_UNSUPPORTED, "TSDF reproducible mode: a voxel index beyond +-2^20 voxels of the layer origin");
+    return det_error_code(ctx, S->h_ctr[kCtrError] ? S->h_ctr[kCtrError] : 2ull);
   }
   return det_commit(I, S, T, N, &update, true, true, S->ray_pg.as<float4>(), S->ray_color.as<uint32_t>(), n_updates,
                     &pc);
@@ -1680,11 +1698,8 @@ int det_merged_commit(vgx_tsdf_integrator I, const float T[7], long long n, cons
     VGX_HIP(ctx, hipGetLastError());
   }
   DET_TRY(read_counters(ctx, S));
-  if (S->h_ctr[kCtrError] == kErrMergedKeyCorner)  // (merged_bundle_kernel)
-    return set_error(ctx, VGX_ERR_UNSUPPORTED,
-                     "TSDF merged integrator: a clearing point whose end voxel is 2^20 - 1 (mod 2^21) on all three axes cannot be keyed");
-  if (S->h_ctr[kCtrError])  // (merged_merge_kernel: the fast path raises the same error for the same condition)
-    return set_error(ctx, VGX_ERR_UNSUPPORTED, "TSDF merged integrator: a ray longer than 2^24 voxel steps");
+  // (merged_bundle_kernel: the key corner; merged_merge_kernel: a ray too long; the chained prefix sums: 3)
+  if (S->h_ctr[kCtrError]) return det_error_code(ctx, S->h_ctr[kCtrError]);
   if (S->h_ctr[kCtrTotal] >= (1ull << 32) - 2)
     return set_error(ctx, VGX_ERR_UNSUPPORTED, "TSDF merged integrator: more than 2^32 voxel steps in a scan");
   const uint32_t total = (uint32_t)S->h_ctr[kCtrTotal];
@@ -1725,8 +1740,7 @@ int det_merged_commit(vgx_tsdf_integrator I, const float T[7], long long n, cons
     const double far = std::max(std::max(std::fabs((double)T[4]), std::fabs((double)T[5])), std::fabs((double)T[6])) + reach;
     if (!(far * (double)I->layer->dev.voxel_size_inv + 4.0 < (double)kVoxBias)) {
       DET_TRY(read_counters(ctx, S));
-      if (S->h_ctr[kCtrError])
-        return set_error(ctx, VGX_ERR_UNSUPPORTED, "TSDF merged integrator: a voxel index beyond +-2^20 voxels of the layer origin");
+      if (S->h_ctr[kCtrError]) return det_error_code(ctx, S->h_ctr[kCtrError]);
     }
   }
   // only anti-grazing removes updates; blocks in order of first update only in the reproducible mode
