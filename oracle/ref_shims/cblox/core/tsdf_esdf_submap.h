@@ -12,9 +12,8 @@
 #include "voxblox/core/tsdf_map.h"
 #include "voxblox/integrator/esdf_integrator.h"
 #include "voxblox/interpolator/interpolator.h"
+#include "cblox/core/common.h"
 namespace cblox {
-typedef unsigned int SubmapID;
-using voxblox::Transformation;
 
 class TsdfEsdfSubmap {
  public:

@@ -31,5 +31,8 @@ class CheckFailure {
 #define CHECK_GE(a, b) CHECK((a) >= (b))
 #define CHECK_GT(a, b) CHECK((a) > (b))
 #define CHECK_NOTNULL(p) (p)
+// LOG(FATAL) << ...: abort with the message (the only severity voxgraph's backend uses on these paths)
+#define VGX_SHIM_LOG_FATAL ::ref_shims::CheckFailure(__FILE__, __LINE__, "LOG(FATAL)").stream()
+#define LOG(severity) VGX_SHIM_LOG_##severity
 #define CHECK_NEAR(a, b, margin) CHECK(((a) - (b)) <= (margin) && ((b) - (a)) <= (margin))
 #endif

@@ -80,6 +80,7 @@ template <typename Scalar>
 class QuatTransformationTemplate {
  public:
   typedef Eigen::Matrix<Scalar, 3, 1> Position;
+  typedef Eigen::Matrix<Scalar, 3, 1> Vector3;
   typedef Eigen::Matrix<Scalar, 6, 1> Vector6;
   typedef RotationQuaternionTemplate<Scalar> Rotation;
 

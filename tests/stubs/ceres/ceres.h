@@ -1,12 +1,23 @@
 // Minimal stand-in for <ceres/ceres.h> (Ceres is not installed in this image): the
 // ceres::CostFunction / EvaluationCallback surface the adapters in voxgraph_amd/cpp/ touch, and a
 // small Problem / Solve with Ceres' calling conventions for end-to-end checks.  TEST ONLY.
+// Round 5: enough more of the interface (Problem::Options, local parameterizations, residual-block queries,
+// Covariance, NumericDiffCostFunction, Solver::Summary reports) for the reference's OWN callers -- pose_graph.cpp,
+// registration_constraint.cpp, node*.cpp, submap_registration_helper.cpp -- to compile against it
+// (oracle/ref_driver/callers_check.cpp).
 #ifndef TESTS_STUBS_CERES_CERES_H_
 #define TESTS_STUBS_CERES_CERES_H_
 #include <cmath>
 #include <cstdint>
+#include <deque>
+#include <string>
+#include <utility>
 #include <vector>
 namespace ceres {
+enum Ownership { DO_NOT_TAKE_OWNERSHIP, TAKE_OWNERSHIP };
+enum LinearSolverType { DENSE_NORMAL_CHOLESKY, DENSE_QR, SPARSE_NORMAL_CHOLESKY, DENSE_SCHUR, SPARSE_SCHUR, ITERATIVE_SCHUR, CGNR };
+enum NumericDiffMethodType { CENTRAL, FORWARD, RIDDERS };
+enum { DYNAMIC = -1 };
 class CostFunction {
  public:
   CostFunction() : num_residuals_(0) {}
@@ -65,42 +76,193 @@ class EvaluationCallback {
 // and a dense Levenberg-Marquardt loop with Ceres' acceptance / radius rules and default tolerances.
 // Jacobians of constant blocks are requested as nullptr, as Ceres does.
 class LossFunction;
-typedef int ResidualBlockId;
+struct ResidualBlock;
+typedef ResidualBlock* ResidualBlockId;   // (a pointer type, as in Ceres: voxgraph initialises its ids with nullptr)
+
+// ---- local parameterizations: Plus() only (the stub solver's step: x <- Plus(x, delta)) -------------------------------
+// voxgraph's are Identity(3) x AutoDiff<AngleLocalParameterization, 1, 1> (node_collection.cpp:7-11): the Jacobian of
+// Plus at delta = 0 is the identity for both, so the solver needs no ComputeJacobian.
+class LocalParameterization {
+ public:
+  virtual ~LocalParameterization() {}
+  virtual bool Plus(const double* x, const double* delta, double* x_plus_delta) const = 0;
+  virtual int GlobalSize() const = 0;
+  virtual int LocalSize() const = 0;
+};
+class IdentityParameterization : public LocalParameterization {
+ public:
+  explicit IdentityParameterization(int size) : size_(size) {}
+  bool Plus(const double* x, const double* delta, double* out) const override {
+    for (int i = 0; i < size_; ++i) out[i] = x[i] + delta[i];
+    return true;
+  }
+  int GlobalSize() const override { return size_; }
+  int LocalSize() const override { return size_; }
+
+ private:
+  int size_;
+};
+template <typename Functor, int kGlobalSize, int kLocalSize>
+class AutoDiffLocalParameterization : public LocalParameterization {
+ public:
+  AutoDiffLocalParameterization() : functor_(new Functor()) {}
+  explicit AutoDiffLocalParameterization(Functor* functor) : functor_(functor) {}
+  ~AutoDiffLocalParameterization() override { delete functor_; }
+  bool Plus(const double* x, const double* delta, double* out) const override { return (*functor_)(x, delta, out); }
+  int GlobalSize() const override { return kGlobalSize; }
+  int LocalSize() const override { return kLocalSize; }
+
+ private:
+  Functor* functor_;
+};
+class ProductParameterization : public LocalParameterization {
+ public:
+  ProductParameterization(LocalParameterization* a, LocalParameterization* b) : a_(a), b_(b) {}
+  ~ProductParameterization() override {
+    delete a_;
+    delete b_;
+  }
+  bool Plus(const double* x, const double* delta, double* out) const override {
+    return a_->Plus(x, delta, out) && b_->Plus(x + a_->GlobalSize(), delta + a_->LocalSize(), out + a_->GlobalSize());
+  }
+  int GlobalSize() const override { return a_->GlobalSize() + b_->GlobalSize(); }
+  int LocalSize() const override { return a_->LocalSize() + b_->LocalSize(); }
+
+ private:
+  LocalParameterization *a_, *b_;
+};
+
+struct CRSMatrix {};
+
+struct ResidualBlock {
+  CostFunction* cost;
+  int param[2];
+};
 
 class Problem {
  public:
+  struct Options {
+    Ownership cost_function_ownership = TAKE_OWNERSHIP;
+    Ownership loss_function_ownership = TAKE_OWNERSHIP;
+    Ownership local_parameterization_ownership = TAKE_OWNERSHIP;
+  };
+  struct EvaluateOptions {};
+  Problem() {}
+  explicit Problem(const Options& options) : options_(options) {}
+  Problem(const Problem&) = delete;
+  Problem& operator=(const Problem&) = delete;
   ~Problem() {
-    for (Block& b : blocks_) delete b.cost;  // TAKE_OWNERSHIP, Ceres' default
+    if (options_.cost_function_ownership == TAKE_OWNERSHIP)
+      for (Block& b : blocks_) delete b.cost;  // Ceres' default
+    // (local parameterizations: voxgraph keeps ownership, pose_graph.cpp:76-77; the stub never deletes them)
   }
   void AddParameterBlock(double* values, int size) { Index(values, size); }
   void SetParameterBlockConstant(double* values) { constant_[Index(values, 4)] = true; }
+  void SetParameterization(double* values, LocalParameterization* lp) { parameterization_[Index(values, lp->GlobalSize())] = lp; }
   ResidualBlockId AddResidualBlock(CostFunction* cost, LossFunction* /*loss*/, double* x0, double* x1) {
     Block b;
     b.cost = cost;
     b.param[0] = Index(x0, cost->parameter_block_sizes()[0]);
     b.param[1] = Index(x1, cost->parameter_block_sizes()[1]);
     blocks_.push_back(b);
-    return static_cast<ResidualBlockId>(blocks_.size()) - 1;
+    return &blocks_.back();
   }
   int NumResidualBlocks() const { return static_cast<int>(blocks_.size()); }
+  void GetResidualBlocks(std::vector<ResidualBlockId>* ids) const {
+    ids->clear();
+    for (const Block& b : blocks_) ids->push_back(const_cast<Block*>(&b));
+  }
+  void GetParameterBlocksForResidualBlock(const ResidualBlockId id, std::vector<double*>* out) const {
+    out->clear();
+    out->push_back(params_[static_cast<size_t>(id->param[0])]);
+    out->push_back(params_[static_cast<size_t>(id->param[1])]);
+  }
+  const CostFunction* GetCostFunctionForResidualBlock(const ResidualBlockId id) const { return id->cost; }
+  // cost and residuals at the current parameter values (gradient / jacobian: not provided by the stand-in)
+  bool Evaluate(const EvaluateOptions&, double* cost, std::vector<double>* residuals, std::vector<double>* gradient,
+                CRSMatrix* jacobian) {
+    if (gradient || jacobian) return false;
+    double c = 0;
+    if (residuals) residuals->clear();
+    for (Block& b : blocks_) {
+      std::vector<double> r(static_cast<size_t>(b.cost->num_residuals()));
+      double* params[2] = {params_[static_cast<size_t>(b.param[0])], params_[static_cast<size_t>(b.param[1])]};
+      if (!b.cost->Evaluate(params, r.data(), nullptr)) return false;
+      for (double v : r) c += 0.5 * v * v;
+      if (residuals) residuals->insert(residuals->end(), r.begin(), r.end());
+    }
+    if (cost) *cost = c;
+    return true;
+  }
 
   // (stub: the solver below reads these directly)
-  struct Block {
-    CostFunction* cost;
-    int param[2];
-  };
+  typedef ResidualBlock Block;
   int Index(double* values, int size) {
     for (size_t k = 0; k < params_.size(); ++k)
       if (params_[k] == values) return static_cast<int>(k);
     params_.push_back(values);
     sizes_.push_back(size);
     constant_.push_back(false);
+    parameterization_.push_back(nullptr);
     return static_cast<int>(params_.size()) - 1;
   }
-  std::vector<Block> blocks_;
+  Options options_;
+  std::deque<Block> blocks_;   // (stable addresses: ResidualBlockId points into it)
   std::vector<double*> params_;
   std::vector<int> sizes_;
   std::vector<bool> constant_;
+  std::vector<LocalParameterization*> parameterization_;
+};
+
+// ceres::Covariance: the interface only (pose_graph.cpp:118-165 compiles against it); Compute() reports failure
+class Covariance {
+ public:
+  struct Options {};
+  explicit Covariance(const Options&) {}
+  bool Compute(const std::vector<std::pair<const double*, const double*> >&, Problem*) { return false; }
+  bool GetCovarianceBlock(const double*, const double*, double*) const { return false; }
+};
+
+// NumericDiffCostFunction<Functor, CENTRAL, DYNAMIC, 4, 4>(functor, ownership, num_residuals)
+// (submap_registration_helper.cpp:54-57): residuals from functor->Evaluate, Jacobians by central differences
+template <typename Functor, NumericDiffMethodType kMethod, int kNumResiduals, int N0, int N1>
+class NumericDiffCostFunction : public CostFunction {
+ public:
+  NumericDiffCostFunction(Functor* functor, Ownership ownership, int num_residuals = kNumResiduals)
+      : functor_(functor), ownership_(ownership) {
+    set_num_residuals(num_residuals);
+    mutable_parameter_block_sizes()->push_back(N0);
+    mutable_parameter_block_sizes()->push_back(N1);
+  }
+  ~NumericDiffCostFunction() override {
+    if (ownership_ == TAKE_OWNERSHIP) delete functor_;
+  }
+  bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const override {
+    if (!functor_->Evaluate(parameters, residuals, nullptr)) return false;
+    if (!jacobians) return true;
+    const int n = num_residuals();
+    const int sizes[2] = {N0, N1};
+    std::vector<double> plus(static_cast<size_t>(n)), minus(static_cast<size_t>(n));
+    for (int b = 0; b < 2; ++b) {
+      if (!jacobians[b]) continue;
+      std::vector<double> x0(parameters[0], parameters[0] + N0), x1(parameters[1], parameters[1] + N1);
+      double* px[2] = {x0.data(), x1.data()};
+      for (int a = 0; a < sizes[b]; ++a) {
+        const double keep = px[b][a], h = 1e-6 * std::fmax(1.0, std::fabs(keep));
+        px[b][a] = keep + h;
+        if (!functor_->Evaluate(px, plus.data(), nullptr)) return false;
+        px[b][a] = keep - h;
+        if (!functor_->Evaluate(px, minus.data(), nullptr)) return false;
+        px[b][a] = keep;
+        for (int i = 0; i < n; ++i) jacobians[b][sizes[b] * i + a] = (plus[static_cast<size_t>(i)] - minus[static_cast<size_t>(i)]) / (2.0 * h);
+      }
+    }
+    return true;
+  }
+
+ private:
+  Functor* functor_;
+  Ownership ownership_;
 };
 
 struct Solver {
@@ -108,13 +270,21 @@ struct Solver {
     int max_num_iterations = 50;
     double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
     double initial_trust_region_radius = 1e4;
+    double max_solver_time_in_seconds = 1e9;   // (accepted, not enforced)
     int num_threads = 1;
+    LinearSolverType linear_solver_type = DENSE_QR;   // (accepted: the stand-in solves dense normal equations)
     EvaluationCallback* evaluation_callback = nullptr;
   };
   struct Summary {
     int num_iterations = 0, num_evaluations = 0;
     double initial_cost = 0, final_cost = 0;
     const char* termination = "";
+    bool IsSolutionUsable() const { return termination[0] == 'C' || termination[0] == 'N'; }  // CONVERGENCE / NO_CONVERGENCE
+    std::string BriefReport() const {
+      return std::string("stand-in Ceres: ") + termination + ", iterations " + std::to_string(num_iterations) +
+             ", cost " + std::to_string(initial_cost) + " -> " + std::to_string(final_cost);
+    }
+    std::string FullReport() const { return BriefReport(); }
   };
 };
 
@@ -197,6 +367,19 @@ inline void Solve(const Solver::Options& o, Problem* p, Solver::Summary* summary
       if (offset[k] >= 0)
         for (int a = 0; a < p->sizes_[k]; ++a) (*x)[static_cast<size_t>(offset[k] + a)] = p->params_[k][a];
   };
+  // x <- Plus(x, step) per parameter block (its local parameterization, or plain addition)
+  auto plus = [&](const std::vector<double>& x, const std::vector<double>& step, std::vector<double>* out) {
+    *out = x;
+    for (size_t k = 0; k < p->params_.size(); ++k) {
+      if (offset[k] < 0) continue;
+      const size_t o = static_cast<size_t>(offset[k]);
+      if (p->parameterization_[k]) {
+        p->parameterization_[k]->Plus(&x[o], &step[o], &(*out)[o]);
+      } else {
+        for (int a = 0; a < p->sizes_[k]; ++a) (*out)[o + static_cast<size_t>(a)] = x[o + static_cast<size_t>(a)] + step[o + static_cast<size_t>(a)];
+      }
+    }
+  };
   auto set = [&](const std::vector<double>& x) {
     for (size_t k = 0; k < p->params_.size(); ++k)
       if (offset[k] >= 0)
@@ -241,8 +424,8 @@ inline void Solve(const Solver::Options& o, Problem* p, Solver::Summary* summary
       s.termination = "CONVERGENCE (parameter)";
       break;
     }
-    std::vector<double> cand(x);
-    for (int i = 0; i < nf; ++i) cand[static_cast<size_t>(i)] += step[static_cast<size_t>(i)];
+    std::vector<double> cand;
+    plus(x, step, &cand);
     set(cand);
     double ncost = 0;
     if (!SolverImpl::Evaluate(o, p, offset, nf, &ncost, &ng, &nH)) {

@@ -1,0 +1,73 @@
+"""The reference's OWN callers on top of either cost function: pose_graph.cpp,
+constraint_collection.cpp, registration_constraint.cpp, node.cpp, node_collection.cpp, pose_4d.cpp and
+submap_registration_helper.cpp are compiled from /root/reference where they lie (oracle/Makefile: ref) -- once as they
+are, once with the ONE edit INTEGRATION.md section 3 shows applied by sed at build time
+(`new RegistrationCostFunction(` -> `voxgraph_amd::MakeGpuRegistrationCostFunction(`, gpu_submap_registry.h) -- and both
+binaries run PoseGraph::optimize() on a four-submap graph (kVoxels and mirrored kIsosurfacePoints constraints) and
+SubmapRegistrationHelper::testRegistration() (oracle/ref_driver/callers_check.cpp says what is NOT compiled from the
+reference: constraint.cpp's Eigen decompositions and the AutoDiff constraints, unused by this graph).  The solver behind
+ceres::Solve is the stand-in of tests/stubs/ceres (the real Ceres is absent from this image).
+
+Bar: the same final poses within 1 mm / 0.01 deg (north_star).  The binaries travel to the GPU box with the snapshot."""
+import math
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref", "callers_check_reference")
+GPU = os.path.join(ROOT, "oracle", "_ref", "callers_check_gpu")
+TRUTH = {10: (0.0, 0.0, 0.0, 0.0), 11: (1.3, 0.2, 0.02, 0.06), 12: (2.5, -0.1, 0.0, -0.05), 13: (3.4, 0.15, -0.03, 0.04)}
+
+
+def _run(binary):
+    r = subprocess.run([binary], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    poses = {(int(m.group(1)), int(m.group(2))): tuple(float(x) for x in m.group(3).split())
+             for m in re.finditer(r"POSE point_type=(\d) submap=(\d+) (.*)", r.stdout)}
+    solves = {int(m.group(1)): (int(m.group(2)), float(m.group(3)), float(m.group(4)))
+              for m in re.finditer(r"SOLVE point_type=(\d) iterations=(\d+) initial_cost=(\S+) final_cost=(\S+)", r.stdout)}
+    edges = {int(m.group(1)): float(m.group(2)) for m in re.finditer(r"EDGES point_type=(\d) sum_sq_residuals=(\S+)", r.stdout)}
+    m = re.search(r"HELPER usable=(\d) iterations=(\d+) final_cost=(\S+) pose (.*)", r.stdout)
+    helper = (int(m.group(1)), int(m.group(2)), float(m.group(3)), tuple(float(x) for x in m.group(4).split()))
+    assert len(poses) == 8 and len(solves) == 2 and len(edges) == 2
+    return poses, solves, edges, helper
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref/callers_check_reference not built (needs /root/reference)")
+def test_reference_callers_run_on_the_reference_cost_function():
+    """(no GPU needed) the reference's PoseGraph::optimize(), compiled from its sources, pulls the drifted graph back"""
+    poses, solves, edges, helper = _run(REF)
+    for pt in (0, 1):
+        its, c0, c1 = solves[pt]
+        assert c1 < 0.1 * c0 and its >= 1
+        for sid, want in TRUTH.items():
+            got = poses[(pt, sid)]
+            assert max(abs(a - b) for a, b in zip(got[:3], want[:3])) < 0.012 and abs(got[3] - want[3]) < 0.006, (pt, sid, got)
+        assert edges[pt] == pytest.approx(2.0 * c1, rel=1e-9)      # the edges' squared residuals ARE the cost
+    assert helper[0] == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(GPU)),
+                    reason="oracle/_ref/callers_check_* not built (needs /root/reference)")
+def test_pose_graph_optimize_gives_the_same_poses_on_the_gpu_cost_function():
+    ref_poses, ref_solves, ref_edges, ref_helper = _run(REF)
+    gpu_poses, gpu_solves, gpu_edges, gpu_helper = _run(GPU)
+    worst_m = worst_rad = 0.0
+    for key, want in ref_poses.items():
+        got = gpu_poses[key]
+        worst_m = max(worst_m, max(abs(a - b) for a, b in zip(got[:3], want[:3])))
+        worst_rad = max(worst_rad, abs(got[3] - want[3]))
+    worst_m = max(worst_m, max(abs(a - b) for a, b in zip(gpu_helper[3][:3], ref_helper[3][:3])))
+    worst_rad = max(worst_rad, abs(gpu_helper[3][3] - ref_helper[3][3]))
+    print(f"worst pose difference: {worst_m * 1e3:.6f} mm, {math.degrees(worst_rad):.6f} deg")
+    assert worst_m < 1e-3 and worst_rad < math.radians(0.01)
+    for pt in (0, 1):
+        assert gpu_solves[pt][0] == ref_solves[pt][0]                                  # the same iterations
+        assert gpu_solves[pt][1] == pytest.approx(ref_solves[pt][1], rel=1e-6)         # initial cost
+        assert gpu_solves[pt][2] == pytest.approx(ref_solves[pt][2], rel=1e-4)
+        assert gpu_edges[pt] == pytest.approx(ref_edges[pt], rel=1e-4)
+    assert gpu_helper[0] == ref_helper[0] == 1 and gpu_helper[1] == ref_helper[1]
