@@ -55,13 +55,15 @@ constexpr unsigned long long kEmptyKey = ~0ull;
 constexpr uint32_t kNil = 0xffffffffu;
 constexpr int kBias = 1 << 20;                // 21 bits per axis in a voxel key
 
-struct RayRec {           // a cast ray, as phase 1 leaves it
+struct RayRec {           // a cast ray: as phase 1 leaves it, and as a pass of the walk hands it on to the next
   int curr[3];
   int sign_bits;          // (sign + 1) of the three axes, two bits each
   float t_next[3], t_step[3];
-  uint32_t steps_lo, steps_hi;
+  uint32_t left_lo, left_hi;  // voxels of the walk not yet exchanged
   float gx, gy, gz, weight;
   uint32_t color;
+  int carry;              // observed voxels in a row so far
+  int rounds;             // rounds spent on it so far (statistics)
 };
 
 struct UpdateRec {        // one voxel step of one ray
@@ -109,7 +111,8 @@ __global__ __launch_bounds__(256) void tsdf_integrate_coop_kernel(TsdfLayerDev L
   __shared__ unsigned long long tkey[kTable];
   __shared__ uint32_t thead[kTable];
   __shared__ uint16_t occ[kMaxRecs];
-  __shared__ uint32_t sh_n_rays, sh_next_ray, sh_n_recs, sh_n_occ;
+  __shared__ uint16_t ray_list[2][256];   // the rays of the current pass / handed on to the next
+  __shared__ uint32_t sh_n_rays, sh_next_ray, sh_n_recs, sh_n_occ, sh_n_next;
 
   const vgx_tsdf_config& c = I.cfg;
   const int tid = (int)threadIdx.x, lane = tid & 63;
@@ -127,7 +130,9 @@ __global__ __launch_bounds__(256) void tsdf_integrate_coop_kernel(TsdfLayerDev L
     sh_next_ray = 0;
     sh_n_recs = 0;
     sh_n_occ = 0;
+    sh_n_next = 0;
   }
+  ray_list[0][tid] = (uint16_t)tid;
   __syncthreads();
 
   // ---------------------------------------------------------------- phase 1: validity, start set, ray set-up
@@ -190,8 +195,10 @@ __global__ __launch_bounds__(256) void tsdf_integrate_coop_kernel(TsdfLayerDev L
         r.sign_bits = (d.sign[0] + 1) | ((d.sign[1] + 1) << 2) | ((d.sign[2] + 1) << 4);
         r.t_next[0] = d.t_next[0]; r.t_next[1] = d.t_next[1]; r.t_next[2] = d.t_next[2];
         r.t_step[0] = d.t_step[0]; r.t_step[1] = d.t_step[1]; r.t_step[2] = d.t_step[2];
-        r.steps_lo = (uint32_t)(unsigned long long)d.steps;
-        r.steps_hi = (uint32_t)((unsigned long long)d.steps >> 32);
+        r.left_lo = (uint32_t)(unsigned long long)(d.steps + 1);   // the walk visits steps + 1 voxels
+        r.left_hi = (uint32_t)((unsigned long long)(d.steps + 1) >> 32);
+        r.carry = 0;
+        r.rounds = 0;
         r.gx = gx; r.gy = gy; r.gz = gz; r.weight = weight;
         r.color = rgba ? rgba[i] : 0u;
       }
@@ -210,13 +217,24 @@ __global__ __launch_bounds__(256) void tsdf_integrate_coop_kernel(TsdfLayerDev L
   }
 
   // ---------------------------------------------------------------- phases 2 + 3: walk in rounds, flush
-  // Lanes per ray: eight while the workgroup's rays all fit side by side (32 groups); a workgroup with more rays -- far
-  // walls, where every beam has its own start cell -- gives each ray fewer lanes rather than walking them 32 at a time
-  // (the unconditional window is mc + 1 = 3 steps with voxblox's default: four lanes lose little).
-  const int lpr = n_rays <= 32u ? 8 : (n_rays <= 64u ? 4 : (n_rays <= 128u ? 2 : 1));
-  const int j = lane & (lpr - 1);                   // this lane's step within the group's window
-  const int gb = lane & ~(lpr - 1);                 // first lane of the group
-  const uint32_t wmask = (1u << lpr) - 1u;
+  // Lanes per ray, chosen per PASS from the rays the pass starts with: eight while they all fit side by side (32 groups),
+  // four / two / one for more.  A pass with fewer than eight lanes per ray is short: after a few rounds a ray that is
+  // still walking is handed on, with its state, to the next pass -- most rays stop within their first three voxels, the
+  // few that walk on (a clear line of sight: up to max_ray_length / voxel_size steps) then get eight lanes and peeks
+  // instead of crawling one exchange per round while 250 lanes idle (the config-2 city scans: 60 % of the points cast a
+  // ray, the longest walks 110 voxels; 188 us per scan before this, profiles/r05_tsdf_racing.txt).
+  uint32_t n_list = n_rays;
+  int cur_list = 0;
+  int lpr = 8, j = 0, gb = 0, budget = 1 << 30;
+  uint32_t wmask = 0xffu;
+  auto choose_lanes = [&](uint32_t rays_in_pass) {
+    lpr = rays_in_pass <= 32u ? 8 : (rays_in_pass <= 64u ? 4 : (rays_in_pass <= 128u ? 2 : 1));
+    j = lane & (lpr - 1);                 // this lane's step within the group's window
+    gb = lane & ~(lpr - 1);               // first lane of the group
+    wmask = (1u << lpr) - 1u;
+    budget = lpr == 8 ? (1 << 30) : (lpr == 4 ? 2 : (lpr == 2 ? 3 : 4));   // rounds a ray gets in this pass
+  };
+  choose_lanes(n_list);
   // (a run of 2^24 observed voxels does not exist: the clamp only keeps mc + 1 - carry inside an int)
   const int mc = c.max_consecutive_ray_collisions < (1 << 24) ? c.max_consecutive_ray_collisions : (1 << 24);
   const int shift = L.vps_shift, vmask = L.vps - 1;
@@ -224,7 +242,7 @@ __global__ __launch_bounds__(256) void tsdf_integrate_coop_kernel(TsdfLayerDev L
   const float trunc = c.default_truncation_distance;
 
   // the group's ray (replicated over its lanes)
-  int ray = -1;
+  int ray = -1, ray_rounds = 0;
   int cur[3] = {0, 0, 0}, sg[3] = {0, 0, 0};
   float tn[3] = {0, 0, 0}, ts[3] = {0, 0, 0};
   long long steps_left = 0;   // voxels of the walk not yet exchanged (the walk visits steps + 1 voxels)
@@ -246,24 +264,24 @@ __global__ __launch_bounds__(256) void tsdf_integrate_coop_kernel(TsdfLayerDev L
     while (true) {
       const uint32_t pending = *(volatile uint32_t*)&sh_n_recs;
       // (A) a group without a ray takes the next one
-      if (ray < 0 && *(volatile uint32_t*)&sh_next_ray < n_rays) {
+      if (ray < 0 && *(volatile uint32_t*)&sh_next_ray < n_list) {
         uint32_t k = 0;
         if (j == 0) k = atomicAdd(&sh_next_ray, 1u);
         k = (uint32_t)__shfl((int)k, gb);
-        if (k < n_rays) {
-          const RayRec& q = rays[k];
-          ray = (int)k;
+        if (k < n_list) {
+          ray = (int)ray_list[cur_list][k];
+          const RayRec& q = rays[ray];
           cur[0] = q.curr[0]; cur[1] = q.curr[1]; cur[2] = q.curr[2];
           sg[0] = (q.sign_bits & 3) - 1; sg[1] = ((q.sign_bits >> 2) & 3) - 1; sg[2] = ((q.sign_bits >> 4) & 3) - 1;
           tn[0] = q.t_next[0]; tn[1] = q.t_next[1]; tn[2] = q.t_next[2];
           ts[0] = q.t_step[0]; ts[1] = q.t_step[1]; ts[2] = q.t_step[2];
-          const long long steps = (long long)(((unsigned long long)q.steps_hi << 32) | q.steps_lo);
-          steps_left = steps + 1;
-          carry = 0;
+          steps_left = (long long)(((unsigned long long)q.left_hi << 32) | q.left_lo);
+          carry = q.carry;
+          rounds = (unsigned long long)q.rounds;
           peekbits = 0;
           nvalid = 0;
           rgx = q.gx; rgy = q.gy; rgz = q.gz; rweight = q.weight; rcolor = q.color;
-          rounds = 0;
+          ray_rounds = 0;
         }
       }
       if (!__any(ray >= 0) || pending > (uint32_t)kFlushAt) break;
@@ -352,6 +370,19 @@ __global__ __launch_bounds__(256) void tsdf_integrate_coop_kernel(TsdfLayerDev L
           tn[0] = __shfl(t0, src); tn[1] = __shfl(t1, src); tn[2] = __shfl(t2, src);
           peekbits = pbits >> w;     // peeks of window positions w .. remaining - 1 become positions 0 ..
           nvalid = remaining - w;
+          if (++ray_rounds >= budget) {  // still walking at the end of a short pass: on to the next one, state and all
+            if (j == 0) {
+              RayRec& q = rays[ray];
+              q.curr[0] = cur[0]; q.curr[1] = cur[1]; q.curr[2] = cur[2];
+              q.t_next[0] = tn[0]; q.t_next[1] = tn[1]; q.t_next[2] = tn[2];
+              q.left_lo = (uint32_t)(unsigned long long)steps_left;
+              q.left_hi = (uint32_t)((unsigned long long)steps_left >> 32);
+              q.carry = carry;
+              q.rounds = (int)rounds;
+              ray_list[cur_list ^ 1][atomicAdd(&sh_n_next, 1u)] = (uint16_t)ray;
+            }
+            ray = -1;
+          }
         }
       }
       // (C) the round's surviving steps become records chained to their voxel
@@ -401,10 +432,23 @@ __global__ __launch_bounds__(256) void tsdf_integrate_coop_kernel(TsdfLayerDev L
         }
       }
     }
-    // (D) the workgroup meets: all rays handed out and finished?
-    const bool busy = ray >= 0 || sh_next_ray < n_rays;
-    all_done = __syncthreads_or(busy ? 1 : 0) == 0;
-    {
+    // (D) the workgroup meets: is this pass's list handed out and are its rays finished or handed on?  then the next pass
+    const bool busy = ray >= 0 || sh_next_ray < n_list;
+    const bool pass_done = __syncthreads_or(busy ? 1 : 0) == 0;
+    const uint32_t handed_on = sh_n_next, pending_now = sh_n_recs;
+    all_done = pass_done && handed_on == 0;
+    if (pass_done && !all_done) {
+      __syncthreads();  // (everybody has read the two counters)
+      if (tid == 0) {
+        sh_next_ray = 0;
+        sh_n_next = 0;
+      }
+      cur_list ^= 1;
+      n_list = handed_on;
+      choose_lanes(n_list);
+      __syncthreads();
+    }
+    if (all_done || pending_now > (uint32_t)kFlushAt) {
       if (tracing && tid == 0 && all_done) I.wg_stats[(size_t)blockIdx.x * kWgStatWords + 2] = wall_clock64();
       // ------------------------------------------------------------ phase 3: one lane per distinct voxel
       const uint32_t n_occ = sh_n_occ;
@@ -444,17 +488,54 @@ __global__ __launch_bounds__(256) void tsdf_integrate_coop_kernel(TsdfLayerDev L
           __syncthreads();
         }
       }
-      for (uint32_t o = (uint32_t)tid; o < n_occ && ablate < 1; o += 256) {
-        uint32_t my_retries = 0;
+      // A lane owns up to kFoldsPerLane voxels of the table (n_occ <= kMaxRecs = 3 x 256).  Their memory operations go
+      // out TOGETHER, stage by stage -- the two loads of all of them, then the compare-and-swaps of all of them, then the
+      // colour writes -- so a flush is three round trips whatever the number of voxels, not three per voxel.
+      constexpr int kFoldsPerLane = (kMaxRecs + 255) / 256;
+      uint32_t f_head[kFoldsPerLane], f_oc[kFoldsPerLane], f_col[kFoldsPerLane], f_retries[kFoldsPerLane];
+      unsigned long long f_old[kFoldsPerLane], f_want[kFoldsPerLane], f_prev[kFoldsPerLane];
+      size_t f_at[kFoldsPerLane];
+      bool f_on[kFoldsPerLane], f_blend[kFoldsPerLane];
+      // updateTsdfVoxel for every record of a chain in turn, on registers: {distance, weight} and colour after the chain
+      auto fold = [&](uint32_t head, unsigned long long old, uint32_t oc, unsigned long long* want, uint32_t* col_out, bool* blends) {
+        float d = __uint_as_float((unsigned)(old & 0xffffffffull)), W = __uint_as_float((unsigned)(old >> 32));
+        uint32_t col = oc;
+        bool any = false, any_blend = false;
+        for (uint32_t q = head; q != kNil; q = recs[q].next) {
+          const UpdateRec u = recs[q];
+          const float new_weight = W + u.w;
+          if (new_weight < 1e-6f) continue;  // kFloatEpsilon: the voxel is left alone
+          const float new_sdf = (u.sdf * u.w + d * W) / new_weight;
+          d = (new_sdf > 0.0f) ? fminf(trunc, new_sdf) : fmaxf(-trunc, new_sdf);
+          if (fabsf(u.sdf) < trunc) {
+            col = blended_color(col, u.color, W, u.w);
+            any_blend = true;
+          }
+          W = fminf(c.max_weight, new_weight);
+          any = true;
+        }
+        *want = pack_voxel(d, W);
+        *col_out = col;
+        *blends = any_blend;
+        return any;
+      };
+      // stage 0: which voxel, which block (a plain, cacheable look at the table first -- an entry >= 0 never changes inside
+      // a kernel; anything else -- free, being allocated, stale in this XCD's L2 -- goes through the atomic path)
+#pragma unroll
+      for (int e = 0; e < kFoldsPerLane; ++e) {
+        const uint32_t o = (uint32_t)tid + 256u * (uint32_t)e;
+        f_on[e] = o < n_occ && ablate < 1;
+        f_head[e] = kNil;
+        f_at[e] = 0;
+        f_retries[e] = 0;
+        if (!f_on[e]) continue;
         const uint32_t slot = occ[o] & 0x3ffu;
         const unsigned long long key = tkey[slot];
-        const uint32_t head = thead[slot];
+        f_head[e] = thead[slot];
         tkey[slot] = kEmptyKey;
         thead[slot] = kNil;
         const int kx = (int)((key >> 42) & 0x1fffffull) - kBias, ky = (int)((key >> 21) & 0x1fffffull) - kBias,
                   kz = (int)(key & 0x1fffffull) - kBias;
-        // the block: a plain (cacheable) look at the table first -- an entry >= 0 never changes inside a kernel, anything
-        // else (free, being allocated, stale in this XCD's L2) goes through the atomic path
         int bslot = -1;
         {
           const int bx = kx >> shift, by = ky >> shift, bz = kz >> shift;
@@ -464,68 +545,94 @@ __global__ __launch_bounds__(256) void tsdf_integrate_coop_kernel(TsdfLayerDev L
           if (bslot < 0) bslot = get_or_allocate_block(L, bx, by, bz);
         }
         uint32_t chain = 0;
-        for (uint32_t q = head; q != kNil; q = recs[q].next) ++chain;
+        for (uint32_t q = f_head[e]; q != kNil; q = recs[q].next) ++chain;
         if (bslot < 0) {
           st_dropped += chain;
+          f_on[e] = false;
           continue;
         }
         st_updates += chain;
-        const size_t at = (size_t)bslot * vps3 + (size_t)((kx & vmask) + L.vps * ((ky & vmask) + L.vps * (kz & vmask)));
-        unsigned long long* vaddr = &L.voxels[at];
-        uint32_t* caddr = &L.rgba[at];
-        unsigned long long old = __hip_atomic_load(vaddr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t oc = __hip_atomic_load(caddr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // updateTsdfVoxel for every record of the chain in turn, on registers
-        while (true) {
-          float d = __uint_as_float((unsigned)(old & 0xffffffffull)), W = __uint_as_float((unsigned)(old >> 32));
-          uint32_t col = oc;
-          bool any = false, any_blend = false;
-          for (uint32_t q = head; q != kNil; q = recs[q].next) {
-            const UpdateRec u = recs[q];
-            const float new_weight = W + u.w;
-            if (new_weight < 1e-6f) continue;  // kFloatEpsilon: the voxel is left alone
-            const float new_sdf = (u.sdf * u.w + d * W) / new_weight;
-            d = (new_sdf > 0.0f) ? fminf(trunc, new_sdf) : fmaxf(-trunc, new_sdf);
-            if (fabsf(u.sdf) < trunc) {
-              col = blended_color(col, u.color, W, u.w);
-              any_blend = true;
-            }
-            W = fminf(c.max_weight, new_weight);
-            any = true;
-          }
-          if (!any) break;
-          const unsigned long long prev = atomicCAS(vaddr, old, pack_voxel(d, W));
-          if (prev != old) {  // another workgroup got in between: fold again over what it left
-            old = prev;
-            if (STATS) ++st_retries;
-            ++my_retries;
-            continue;
-          }
-          if (any_blend) {
-            if (STATS) {
-              for (uint32_t q = head; q != kNil; q = recs[q].next) st_blends += fabsf(recs[q].sdf) < trunc ? 1u : 0u;
-            }
-            uint32_t prevc = atomicCAS(caddr, oc, col);
-            while (prevc != oc) {  // blend again over the colour found, with the weights this fold saw
-              oc = prevc;
-              float W2 = __uint_as_float((unsigned)(old >> 32));
-              col = oc;
-              for (uint32_t q = head; q != kNil; q = recs[q].next) {
-                const UpdateRec u = recs[q];
-                const float new_weight = W2 + u.w;
-                if (new_weight < 1e-6f) continue;
-                if (fabsf(u.sdf) < trunc) col = blended_color(col, u.color, W2, u.w);
-                W2 = fminf(c.max_weight, new_weight);
-              }
-              if (STATS) ++st_retries;
-              ++my_retries;
-              prevc = atomicCAS(caddr, oc, col);
-            }
-          }
-          break;
+        f_at[e] = (size_t)bslot * vps3 + (size_t)((kx & vmask) + L.vps * ((ky & vmask) + L.vps * (kz & vmask)));
+      }
+      // stage 1: the loads
+#pragma unroll
+      for (int e = 0; e < kFoldsPerLane; ++e) {
+        f_old[e] = 0ull;
+        f_oc[e] = 0u;
+        if (f_on[e]) {
+          f_old[e] = __hip_atomic_load(&L.voxels[f_at[e]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          f_oc[e] = __hip_atomic_load(&L.rgba[f_at[e]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (STATS) ++st_voxels;
-        my_retry_max = my_retries > my_retry_max ? my_retries : my_retry_max;
+      }
+      // stage 2: fold and publish, all of the lane's voxels together ...
+      bool f_done[kFoldsPerLane];
+#pragma unroll
+      for (int e = 0; e < kFoldsPerLane; ++e) {
+        f_done[e] = !f_on[e];
+        f_want[e] = 0ull;
+        f_col[e] = f_oc[e];
+        f_blend[e] = false;
+        if (f_on[e] && !fold(f_head[e], f_old[e], f_oc[e], &f_want[e], &f_col[e], &f_blend[e])) {
+          f_on[e] = false;  // every record of the chain left the voxel alone
+          f_done[e] = true;
+          if (STATS) ++st_voxels;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < kFoldsPerLane; ++e) {
+        f_prev[e] = f_old[e];
+        if (!f_done[e]) f_prev[e] = atomicCAS(&L.voxels[f_at[e]], f_old[e], f_want[e]);
+      }
+      // ... then those that found another workgroup's update in between, each on its own: folded again over what it left
+#pragma unroll
+      for (int e = 0; e < kFoldsPerLane; ++e) {
+        if (f_done[e]) continue;
+        while (f_prev[e] != f_old[e]) {
+          f_old[e] = f_prev[e];
+          ++f_retries[e];
+          if (STATS) ++st_retries;
+          if (!fold(f_head[e], f_old[e], f_oc[e], &f_want[e], &f_col[e], &f_blend[e])) {
+            f_on[e] = false;
+            break;
+          }
+          f_prev[e] = atomicCAS(&L.voxels[f_at[e]], f_old[e], f_want[e]);
+        }
+      }
+      // stage 3: colours.  A blend that leaves the colour as it was found needs no write (a scan without colours into a
+      // layer without colours: every fold): this update's colour is then ordered at its LOAD -- the colour word is its own
+      // atomic in any case, see the header comment -- and a third of a fold's round trips goes.
+      uint32_t f_prevc[kFoldsPerLane];
+#pragma unroll
+      for (int e = 0; e < kFoldsPerLane; ++e) {
+        f_prevc[e] = f_oc[e];
+        if (!f_on[e]) continue;
+        if (STATS) {
+          ++st_voxels;
+          if (f_blend[e])
+            for (uint32_t q = f_head[e]; q != kNil; q = recs[q].next) st_blends += fabsf(recs[q].sdf) < trunc ? 1u : 0u;
+        }
+        if (f_blend[e] && f_col[e] != f_oc[e]) f_prevc[e] = atomicCAS(&L.rgba[f_at[e]], f_oc[e], f_col[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < kFoldsPerLane; ++e) {
+        if (!f_on[e]) continue;
+        while (f_prevc[e] != f_oc[e]) {  // blend again over the colour found, with the weights this fold saw
+          f_oc[e] = f_prevc[e];
+          float W2 = __uint_as_float((unsigned)(f_old[e] >> 32));
+          uint32_t col = f_oc[e];
+          for (uint32_t q = f_head[e]; q != kNil; q = recs[q].next) {
+            const UpdateRec u = recs[q];
+            const float new_weight = W2 + u.w;
+            if (new_weight < 1e-6f) continue;
+            if (fabsf(u.sdf) < trunc) col = blended_color(col, u.color, W2, u.w);
+            W2 = fminf(c.max_weight, new_weight);
+          }
+          ++f_retries[e];
+          if (STATS) ++st_retries;
+          if (col == f_oc[e]) break;
+          f_prevc[e] = atomicCAS(&L.rgba[f_at[e]], f_oc[e], col);
+        }
+        my_retry_max = f_retries[e] > my_retry_max ? f_retries[e] : my_retry_max;
       }
       __syncthreads();
       if (tid == 0) {
