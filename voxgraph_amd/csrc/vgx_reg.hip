@@ -685,7 +685,7 @@ __global__ __launch_bounds__(kBlockThreads) void reg_eval_points_single_kernel(
 // ---------------------------------------------------------------------------
 // u = (jo0, jo1, jo2, jo3, je3, r): [J r]^T [J r] (9x9) is a signed
 // re-arrangement of the 21 unique products of u because je0..2 == -jo0..2.
-constexpr int kReduceIters = 20;  // a fused-pass tile of a large constraint = kTilePoints * kReduceIters residuals
+constexpr int kReduceIters = 10;  // a fused-pass tile of a large constraint = kTilePoints * kReduceIters residuals (round 4: 20)
 constexpr bool kNonTemporalLoads = false;  // A/B: VGX_NT_LOADS=1
 constexpr bool kNonTemporalStores = true;  // measured 6.08 -> 5.40 ms (profiles/ab_nt.sh, VGX_NT_STORES=0/1)
 constexpr int kMaxReduceIters = 64;
@@ -899,17 +899,47 @@ __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_ker
       accumulate21<ACC>(acc, u);
     }
   }
-  // every sum goes to LDS as soon as its wavefront tree is done (kept in an array until all 21 were reduced,
-  // the f64 copies spilled 8 registers to scratch in every tile's epilogue: 9 KB of scratch traffic per tile,
-  // a tenth of the bytes of the shipped configuration's 1.6 K-residual tiles)
+  // The tile's 21 sums over its 64 lanes: a reduce-SCATTER butterfly.  Every step halves the sums a lane still carries --
+  // it keeps one half, adds what its partner (lane ^ 32, 16, 8, 4, 2) sends of that half, and sends the other -- so 31
+  // f64 exchanges instead of 21 x 6, and lane pair (2 s, 2 s + 1) ends up with sum s.  The additions are the ones the
+  // plain butterfly makes for that sum, in the same pairing (a + b = b + a exactly): bit for bit the round-4 result.
+  // The epilogue was most of what a tile costs beyond its points (round 4: 10 Ki-residual tiles +4 % on one GPU against
+  // 20 Ki ones, the size a 1/8 shard wants -- VERDICT r4 item 6), and the f64 copies live together here only once the
+  // point loop's registers are dead.
   __shared__ double lds[kBlockThreads / 64][kPartialSize];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  {
+    const bool b5 = (lane & 32) != 0, b4 = (lane & 16) != 0, b3 = (lane & 8) != 0, b2 = (lane & 4) != 0, b1 = (lane & 2) != 0;
+    double r16[16];
 #pragma unroll
-  for (int k = 0; k < 21; ++k) {
-    double v = (double)acc[k];
+    for (int i = 0; i < 16; ++i) {  // sums i (kept by lanes with bit 5 clear) and 16 + i (bit 5 set); 21 .. 31 do not exist
+      const double lo = (double)acc[i], up = 16 + i < 21 ? (double)acc[16 + i < 21 ? 16 + i : 0] : 0.0;
+      const double keep = b5 ? up : lo, send = b5 ? lo : up;
+      r16[i] = keep + __shfl_xor(send, 32, 64);
+    }
+    double r8[8];
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    if (lane == 0) lds[wave][k] = v;
+    for (int i = 0; i < 8; ++i) {
+      const double keep = b4 ? r16[8 + i] : r16[i], send = b4 ? r16[i] : r16[8 + i];
+      r8[i] = keep + __shfl_xor(send, 16, 64);
+    }
+    double r4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const double keep = b3 ? r8[4 + i] : r8[i], send = b3 ? r8[i] : r8[4 + i];
+      r4[i] = keep + __shfl_xor(send, 8, 64);
+    }
+    double r2[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const double keep = b2 ? r4[2 + i] : r4[i], send = b2 ? r4[i] : r4[2 + i];
+      r2[i] = keep + __shfl_xor(send, 4, 64);
+    }
+    const double keep = b1 ? r2[1] : r2[0], send = b1 ? r2[0] : r2[1];
+    double v = keep + __shfl_xor(send, 2, 64);
+    v += __shfl_xor(v, 1, 64);
+    const int s = lane >> 1;   // = 16 b5 + 8 b4 + 4 b3 + 2 b2 + b1
+    if ((lane & 1) == 0 && s < 21) lds[wave][s] = v;
   }
   __syncthreads();
   if (threadIdx.x < 21) {
@@ -1928,15 +1958,15 @@ int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs, const int3
   b->row_offset.assign((size_t)n + 1, 0);
   std::vector<ConstraintDev> desc((size_t)n);
   std::vector<int32_t> tile_first((size_t)n + 1, 0), points_tile_first((size_t)n + 1, 0);
-  // Fused-pass tile size: a function of the constraint alone, so that its partial sums -- f32 running
-  // products inside a tile -- and therefore its 45 numbers are bit for bit the same whichever batch or
-  // shard it is evaluated in.  20 Ki residuals for large constraints (each tile ends in a 21 x f64
-  // wave + LDS reduction; measured flat between 12 and 32 Ki), a fifth of the constraint for smaller
-  // ones so that the launch still has many tiles per CU (shipped configuration, 8 K draws per
-  // constraint: 1.60 -> 1.40 ms).  NOT a fixed number of tiles per constraint
-  // that is a multiple of 8: tile t runs on XCD t % 8 and chunk culling is spatially structured, so
-  // with 16 tiles per constraint the same XCDs got the live tiles of every constraint (config 3
-  // 1.58 -> 1.77 ms).
+  // Fused-pass tile size: a function of the constraint alone, so that its partial sums -- f32 running products inside a
+  // tile -- and therefore its 45 numbers are bit for bit the same whichever batch or shard it is evaluated in.  10 Ki
+  // residuals for large constraints since round 5 (20 Ki before: a 1/8 shard of config 3 was 2.4 rounds of tiles on
+  // 256 CUs x 6 resident workgroups and its slowest CU decided -- profiles/r04_shard_balance.json: 0.61-0.71 of linear at
+  // N = 8 predicted; the smaller tile cost 4 % on one GPU until the tile's epilogue became a reduce-scatter butterfly,
+  // reg_eval_reduce_lean_kernel), a fifth of the constraint for smaller ones so that the launch still has many tiles per
+  // CU (shipped configuration, 8 K draws per constraint: 1.60 -> 1.40 ms).  NOT a fixed number of tiles per constraint
+  // that is a multiple of 8: tile t runs on XCD t % 8 and chunk culling is spatially structured, so with 16 tiles per
+  // constraint the same XCDs got the live tiles of every constraint (config 3 1.58 -> 1.77 ms).
   auto reduce_iters_of = [](int64_t n_residuals) {
     static const int forced = [] {
       const char* e = getenv("VGX_FUSED_TILE_ITERS");  // A/B switch
