@@ -131,45 +131,25 @@ __global__ __launch_bounds__(256) void atomic_chain_kernel(unsigned long long* _
 // read against the box it ran on and not only against the 8 TB/s of the data sheet.  One workgroup walks a contiguous
 // slice of both ranges; read_bytes == 0 is a pure fill, write_bytes == read_bytes a float4 copy.
 typedef float nt_float4 __attribute__((ext_vector_type(4)));
-// Grid-stride over max(n_read, n_write) float4 positions, four positions per thread in flight: the whole chip works
-// on one moving front of both ranges (2048 workgroups with a private slice each -- the first version -- reached only
-// 4.4 TB/s on a box where the headline kernel itself moved 6.5: 2048 far-apart streams fight over DRAM pages).
-// Position i reads float4 floor(i * n_read / N) when that index differs from the one of position i - 1, and likewise
-// writes: the shorter range is touched by an evenly spread subset of the lanes, consecutive among themselves.
+// ONE float4 position per thread, no loop, a grid of n / 256 workgroups: the shape that reaches the guide's 6.29 TB/s on
+// this part (profiles/probes/copy_probe.hip, round 5: copy 6.23-6.37 TB/s, fill 6.8 TB/s, against 4.8-5.3 TB/s for
+// grid-stride loops of 2048 to 65536 workgroups with 1 to 8 float4 in flight per thread, and 4.4 TB/s for a private
+// contiguous slice per workgroup -- both of which this kernel was, for a day).  Position i reads float4
+// floor(i * n_read / N) when that index differs from the one of position i - 1, and likewise writes: the shorter range is
+// touched by an evenly spread subset of the lanes, consecutive among themselves.
 __global__ __launch_bounds__(256) void stream_ceiling_kernel(const nt_float4* __restrict__ src, unsigned long long read_fp,
                                                             nt_float4* __restrict__ dst, unsigned long long write_fp,
                                                             unsigned long long n_pos) {
-  const unsigned long long stride = (unsigned long long)gridDim.x * 256ull;
-  nt_float4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-  for (unsigned long long i0 = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; i0 < n_pos; i0 += 4ull * stride) {
-    nt_float4 v[4];
-    bool rd[4], wr[4];
-    unsigned long long wi[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const unsigned long long i = i0 + (unsigned long long)k * stride;
-      const bool in = i < n_pos;
-      // 32.32 fixed point: index of position i in a range of n = fp * N / 2^32 items
-      const unsigned long long ri = (i * read_fp) >> 32, rp = i ? ((i - 1ull) * read_fp) >> 32 : ~0ull;
-      wi[k] = (i * write_fp) >> 32;
-      const unsigned long long wp = i ? ((i - 1ull) * write_fp) >> 32 : ~0ull;
-      rd[k] = in && read_fp != 0ull && ri != rp;
-      wr[k] = in && write_fp != 0ull && wi[k] != wp;
-      v[k] = acc;
-      if (rd[k]) v[k] = __builtin_nontemporal_load(&src[ri]);
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (wr[k]) {
-        nt_float4 o = v[k];
-        o.x += (float)k;
-        __builtin_nontemporal_store(o, &dst[wi[k]]);
-      } else if (rd[k]) {
-        acc += v[k];
-      }
-    }
-  }
-  if (acc.x == 1.2345e30f && dst) dst[0] = acc;  // keeps the read-only case's loads alive
+  const unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
+  if (i >= n_pos) return;
+  // 32.32 fixed point: index of position i in a range of n = fp * N / 2^32 items
+  const unsigned long long ri = (i * read_fp) >> 32, rp = i ? ((i - 1ull) * read_fp) >> 32 : ~0ull;
+  const unsigned long long wi = (i * write_fp) >> 32, wp = i ? ((i - 1ull) * write_fp) >> 32 : ~0ull;
+  const bool rd = read_fp != 0ull && ri != rp, wr = write_fp != 0ull && wi != wp;
+  nt_float4 v = {0.0f, 0.0f, 0.0f, (float)threadIdx.x};
+  if (rd) v = src[ri];
+  if (wr) __builtin_nontemporal_store(v, &dst[wi]);
+  else if (rd && v.x == 1.2345e30f) dst[0] = v;  // keeps a read-only position's load alive
 }
 
 }  // namespace vgx
@@ -221,10 +201,6 @@ extern "C" int vgx_bench_stream_ceiling(vgx_ctx ctx, const void* d_src, int64_t 
   hipEvent_t e[2];
   for (auto& ev : e) (void)hipEventCreate(&ev);
   int rc = VGX_OK;
-  // as many workgroups as the headline kernel keeps resident (8 per CU), each with a long contiguous slice
-  int cus = 256;
-  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
-  const dim3 grid((unsigned)(cus * 8)), block(256);
   float ms = 0.0f;
   const unsigned long long nr = (unsigned long long)read_bytes / 16, nw = (unsigned long long)write_bytes / 16;
   const unsigned long long n_pos = nr > nw ? nr : nw;
@@ -235,6 +211,7 @@ extern "C" int vgx_bench_stream_ceiling(vgx_ctx ctx, const void* d_src, int64_t 
     return (unsigned long long)(((unsigned __int128)nn << 32) / n_pos);
   };
   const unsigned long long rf = ratio(nr), wf = ratio(nw);
+  const dim3 grid((unsigned)((n_pos + 255ull) / 256ull)), block(256);
   hipLaunchKernelGGL(stream_ceiling_kernel, grid, block, 0, ctx->stream, (const nt_float4*)d_src, rf, (nt_float4*)d_dst, wf,
                      n_pos);  // warm
   (void)hipEventRecord(e[0], ctx->stream);
