@@ -24,7 +24,7 @@ import os
 import shutil
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL, FUSED, TSDF = "reg_eval_points_kernel", "reg_eval_reduce", "tsdf_integrate_kernel"
+KERNEL, FUSED, TSDF = "reg_eval_points_kernel", "reg_eval_reduce", "tsdf_integrate"   # (tsdf_integrate_coop_kernel since round 5)
 
 
 def rows(pattern):
