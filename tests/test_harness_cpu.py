@@ -248,3 +248,31 @@ def test_profiled_launch_counts_come_from_the_committed_trace():
         assert all(v > 5 for v in got.values())
     else:
         assert got == {} and ("other sources" in note or "no committed trace" in note), note
+
+
+def test_box_state_degrades_gracefully_without_a_gpu_and_the_line_carries_the_ceilings():
+    """harness/box_state.py (which box was it?) must never cost the line: without amdgpu in sysfs /
+    without rocm-smi it reports `available: False`; and harness/bench_line.py passes the same-run ceilings and the box's
+    clocks through to the compact line"""
+    from harness import bench_line, box_state
+    snap = box_state.snapshot()
+    assert set(snap) == {"sysfs", "rocm_smi"} and "available" in snap["sysfs"] and "available" in snap["rocm_smi"]
+    with box_state.Sampler(period_s=0.001) as s:
+        pass
+    assert "available" in s.summary()
+    full = {"metric": "m", "value": 1.0, "unit": "u", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": 1.0,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "w"},
+            "roofline": {"bound": "hbm", "achieved": 6750.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.84, "traffic": 3.0e10,
+                         "traffic_source": "profiles/hbm_traffic.json", "hbm_frac": 0.79, "copy_ceiling_GBs": 6315.0,
+                         "fill_ceiling_GBs": 6778.0, "kernel_shaped_ceiling_GBs": 6273.0, "frac_of_copy_ceiling": 1.07,
+                         "traffic_frac_of_copy_ceiling": 1.01, "frac_of_kernel_shaped_ceiling": 1.08, "kernel_ms": 4.7},
+            "box": {"before": {"sysfs": {"power_cap_W": 1400.0, "compute_partition": "SPX", "memory_partition": "NPS1"}},
+                    "during_timed_region": {"sclk_MHz": {"median": 2390.0}, "mclk_MHz": {"median": 2000.0},
+                                            "power_in_W": {"median": 1152.0}}}}
+    out, line = bench_line.compact(full, "bench_detail.json")
+    assert out["roofline"]["copy_ceiling_GBs"] == 6315.0 and out["roofline"]["traffic_frac_of_copy_ceiling"] == 1.01
+    assert out["roofline"]["traffic_source"] == "profiles/hbm_traffic.json"
+    assert out["box"] == {"sclk_MHz_during": 2390.0, "mclk_MHz_during": 2000.0, "power_W_during": 1152.0, "power_cap_W": 1400.0,
+                          "compute_partition": "SPX", "memory_partition": "NPS1"}
+    assert len(line) < bench_line.LINE_LIMIT
