@@ -34,7 +34,8 @@ def _tsdf(t):
     ac = cb.get("all_cores") or {}
     mg = t.get("merged_integrator") or {}
     rm = t.get("reproducible_mode") or {}
-    return {"ms_per_scan": t.get("ms_per_scan"), "Mpoints_per_s": t.get("Mpoints_per_s"),
+    return {"ms_per_scan": t.get("ms_per_scan"), "ms_per_scan_fresh_integrator": t.get("ms_per_scan_fresh_integrator"),
+            "integrator_age_scans": t.get("integrator_age_scans"), "Mpoints_per_s": t.get("Mpoints_per_s"),
             "Mvoxel_updates_per_s": t.get("Mvoxel_updates_per_s"), "dropped_updates": t.get("dropped_updates"),
             "roofline": _pick(rf, ("bound", "kernel", "kernel_ms", "one_point_scan_ms", "longest_walk_steps", "dependent_round_trips", "roundtrip_ns_unloaded",
                                    "latency_chain_ms", "atomic_peak_Gops", "atomic_achieved_Gops",
@@ -42,11 +43,12 @@ def _tsdf(t):
             "organised_cloud_ms_per_scan": (rf.get("organised_cloud") or {}).get("back_to_back_ms_per_scan"),
             "merged_ms_per_scan": mg.get("ms_per_scan"),
             "reproducible_ms_per_scan": rm.get("ms_per_scan"),
+            "reproducible_ms_per_scan_fresh_integrator": rm.get("ms_per_scan_fresh_integrator"),
             "reproducible_bit_identical_to_oracle": (rm.get("parity_vs_oracle") or {}).get("bit_identical"),
             "sorted_order_bit_identical_to_oracle": (rm.get("parity_vs_oracle_sorted_order") or {}).get("bit_identical"),
+            # one core and all cores run the same scan sequence through integrators as old as the GPU's
             "cpu_Mpoints_per_s_1_core": cb.get("Mpoints_per_s"),
-            # the one-core rate the flag below is held against (the same scan sequence the replicas run, steady state)
-            "cpu_Mpoints_per_s_1_core_same_sequence": ac.get("one_core_same_sequence_Mpoints_per_s"),
+            "cpu_Mpoints_per_s_1_core_fresh_integrator": cb.get("Mpoints_per_s_fresh_integrator"),
             "cpu_Mpoints_per_s_all_cores": ac.get("Mpoints_per_s"), "cpu_cores": ac.get("cores"),
             "cpu_all_cores_at_most_cores_x_one": ac.get("at_most_cores_x_one_core")}
 

@@ -93,7 +93,7 @@ class GpuFastTsdfIntegrator {
   //   Pointcloud      AlignedVector<Eigen::Vector3f>: contiguous 12-byte elements
   //   Colors          AlignedVector<voxblox::Color>:  contiguous RGBA8; may be empty
   // Templated (containers only: arrays take the overload above), so it compiles against the real headers and against
-  // the stand-ins of oracle/ref_shims alike.
+  // header stand-ins (the checker tree has a set) alike.
   template <class Transformation, class Pointcloud, class Colors, class = typename Pointcloud::value_type,
             class = typename Colors::value_type>
   void integratePointCloud(const Transformation& T_G_C, const Pointcloud& points_C, const Colors& colors,
@@ -152,7 +152,7 @@ class GpuMergedTsdfIntegrator {
   //   Pointcloud      AlignedVector<Eigen::Vector3f>: contiguous 12-byte elements
   //   Colors          AlignedVector<voxblox::Color>:  contiguous RGBA8; may be empty
   // Templated (containers only: arrays take the overload above), so it compiles against the real headers and against
-  // the stand-ins of oracle/ref_shims alike.
+  // header stand-ins (the checker tree has a set) alike.
   template <class Transformation, class Pointcloud, class Colors, class = typename Pointcloud::value_type,
             class = typename Colors::value_type>
   void integratePointCloud(const Transformation& T_G_C, const Pointcloud& points_C, const Colors& colors,
