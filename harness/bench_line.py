@@ -72,7 +72,8 @@ def compact(full, detail_path):
     out["box"] = {"sclk_MHz_during": (du.get("sclk_MHz") or {}).get("median"),
                   "mclk_MHz_during": (du.get("mclk_MHz") or {}).get("median"),
                   "power_W_during": (du.get("power_W") or du.get("power_in_W") or {}).get("median"),
-                  "power_cap_W": sy.get("power_cap_W"), "compute_partition": sy.get("compute_partition"),
+                  "power_cap_W": sy.get("power_cap_W"), "pci_bus_id": sy.get("pci_bus_id"), "vbios": sy.get("vbios"),
+                  "compute_partition": sy.get("compute_partition"),
                   "memory_partition": sy.get("memory_partition")}
     cb = d.get("cpu_baseline")
     if cb:
