@@ -267,12 +267,14 @@ def test_box_state_degrades_gracefully_without_a_gpu_and_the_line_carries_the_ce
                          "traffic_source": "profiles/hbm_traffic.json", "hbm_frac": 0.79, "copy_ceiling_GBs": 6315.0,
                          "fill_ceiling_GBs": 6778.0, "kernel_shaped_ceiling_GBs": 6273.0, "frac_of_copy_ceiling": 1.07,
                          "traffic_frac_of_copy_ceiling": 1.01, "frac_of_kernel_shaped_ceiling": 1.08, "kernel_ms": 4.7},
-            "box": {"before": {"sysfs": {"power_cap_W": 1400.0, "compute_partition": "SPX", "memory_partition": "NPS1"}},
+            "box": {"before": {"sysfs": {"power_cap_W": 1400.0, "compute_partition": "SPX", "memory_partition": "NPS1",
+                                         "pci_bus_id": "0000:0d:00.0", "vbios": "113-M355-01-1K1-030A"}},
                     "during_timed_region": {"sclk_MHz": {"median": 2390.0}, "mclk_MHz": {"median": 2000.0},
                                             "power_in_W": {"median": 1152.0}}}}
     out, line = bench_line.compact(full, "bench_detail.json")
     assert out["roofline"]["copy_ceiling_GBs"] == 6315.0 and out["roofline"]["traffic_frac_of_copy_ceiling"] == 1.01
     assert out["roofline"]["traffic_source"] == "profiles/hbm_traffic.json"
     assert out["box"] == {"sclk_MHz_during": 2390.0, "mclk_MHz_during": 2000.0, "power_W_during": 1152.0, "power_cap_W": 1400.0,
+                          "pci_bus_id": "0000:0d:00.0", "vbios": "113-M355-01-1K1-030A",
                           "compute_partition": "SPX", "memory_partition": "NPS1"}
     assert len(line) < bench_line.LINE_LIMIT
