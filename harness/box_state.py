@@ -147,8 +147,25 @@ def rocm_smi_state(timeout=25):
         return {"available": bool(txt), "raw": txt[-1500:], "stderr": r.stderr[-300:], "rc": r.returncode}
 
 
+def firmware_state(timeout=25):
+    """driver + firmware versions (MEC / RLC / SMC ...): cards of the pool differ by 20 % on one kernel at equal clocks, power
+    cap and copy ceiling (profiles/r05_headline_ab.txt addendum 3) -- the versions are what is left to compare"""
+    exe = "/opt/rocm/bin/rocm-smi" if os.path.exists("/opt/rocm/bin/rocm-smi") else "rocm-smi"
+    try:
+        r = subprocess.run([exe, "--showfwinfo", "--showdriverversion", "--json"], capture_output=True, text=True, timeout=timeout)
+        txt = r.stdout.strip()
+        data = json.loads(txt[txt.index("{"):])
+        card = data.get("card0") or next(iter(data.values()))
+        out = {"available": True, "card0": card}
+        if "system" in data:
+            out["system"] = data["system"]
+        return out
+    except Exception as e:   # noqa: BLE001  (a box without rocm-smi, an output that is not JSON: say so, do not fail a bench)
+        return {"available": False, "error": repr(e)[:200]}
+
+
 def snapshot(card_index=0):
-    return {"sysfs": sysfs_state(card_index), "rocm_smi": rocm_smi_state()}
+    return {"sysfs": sysfs_state(card_index), "rocm_smi": rocm_smi_state(), "firmware": firmware_state()}
 
 
 class Sampler:

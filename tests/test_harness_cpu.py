@@ -256,7 +256,7 @@ def test_box_state_degrades_gracefully_without_a_gpu_and_the_line_carries_the_ce
     clocks through to the compact line"""
     from harness import bench_line, box_state
     snap = box_state.snapshot()
-    assert set(snap) == {"sysfs", "rocm_smi"} and "available" in snap["sysfs"] and "available" in snap["rocm_smi"]
+    assert set(snap) == {"sysfs", "rocm_smi", "firmware"} and "available" in snap["firmware"] and "available" in snap["sysfs"] and "available" in snap["rocm_smi"]
     with box_state.Sampler(period_s=0.001) as s:
         pass
     assert "available" in s.summary()
