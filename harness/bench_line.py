@@ -60,12 +60,14 @@ def compact(full, detail_path):
             "vs_baseline", "dtype", "data")
     out = {k: d.get(k) for k in head}
     cfg = d.get("config") or {}
-    out["config"] = _pick(cfg, ("workload", "submaps", "constraints", "residuals_per_pass", "passes_per_step", "parallelism"))
+    out["config"] = _pick(cfg, ("workload", "submaps", "constraints", "residuals_per_pass", "passes_per_step", "parallelism",
+                                "output_placement"))
     rf = d.get("roofline") or {}
     out["roofline"] = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "hbm_frac",
                                  "contract_88B_frac", "copy_ceiling_GBs", "fill_ceiling_GBs", "kernel_shaped_ceiling_GBs",
                                  "frac_of_copy_ceiling", "traffic_frac_of_copy_ceiling", "frac_of_kernel_shaped_ceiling",
-                                 "kernel", "kernel_ms", "units_per_launch", "bytes_per_launch", "with_correspondence_frac"))
+                                 "kernel", "kernel_ms", "units_per_launch", "bytes_per_launch", "with_correspondence_frac",
+                                 "placement_ms_sets"))
     bx = d.get("box") or {}
     sy = (bx.get("before") or {}).get("sysfs") or {}
     du = bx.get("during_timed_region") or {}

@@ -297,6 +297,22 @@ VGX_API int vgx_reg_batch_evaluate_points(vgx_reg_batch batch,
                                           void* d_residuals, void* d_jac_ref,
                                           void* d_jac_read, int32_t* status);
 
+/* Placement by measurement.  WHERE the output arrays of the materialising pass lie in physical memory decides which of
+ * two speeds the kernel runs at -- 200 x 256^3 submaps, 1176 constraints: 4.4-4.7 ms or 5.3-5.7 ms per launch; about one
+ * array in four is a slow one, half of all sets of three; an array's own fill and read rates do not tell (measured:
+ * profiles/r05_headline_ab.txt, addendum 4).  The physical address is not the caller's to choose, but which of several
+ * allocations to keep is: given n_candidates device pointers for each array (each large enough for the batch; d_jac_ref /
+ * d_jac_read may be NULL as for the pass itself), this call times the batch's own launch -- one warm-up and `launches`
+ * timed launches per trial -- first on whole sets (the k-th candidate of each array), then array by array against the
+ * best combination so far, and returns in chosen[] the index to keep for residuals, jac_ref and jac_read.  ms_chosen
+ * (nullable): ms per launch of that combination.  ms_trials (nullable, [n_candidates * 4]): every trial in order -- the n
+ * sets, then jac_read's, jac_ref's and the residuals' candidates (-1 where a candidate needed no new trial).  The arrays
+ * are overwritten.  Synchronous.  4 candidates and 3 launches cost 13 trials of 4 launches. */
+VGX_API int vgx_reg_batch_choose_outputs(vgx_reg_batch batch, const double* poses, int32_t n_nodes,
+                                         int32_t n_candidates, void* const* d_residuals, void* const* d_jac_ref,
+                                         void* const* d_jac_read, int32_t launches, int32_t chosen[3],
+                                         float* ms_chosen, float* ms_trials);
+
 /* Fused pass: no per-point outputs.  Per constraint c, 45 f64:
  *   [0]      sum r^2
  *   [1..8]   J^T r      over the stacked parameters [ref(4), read(4)]

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Does the headline kernel's time go with WHERE its three output arrays lie physically?  One process, one batch, eight
+sets of (residuals, jac_ref, jac_read) allocated one after the other and all kept alive (so every set has its own physical
+pages), the kernel timed on each set three times round-robin.  VGX_LIB selects the build."""
+import os
+import sys
+import types
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from voxgraph_amd import capi  # noqa: E402
+import torch  # noqa: E402
+
+capi.load()
+ctx = capi.Context(0)
+a = types.SimpleNamespace(grid=[20, 10], block_dims=[16, 16, 16], block_min=[-8, -8, -4], voxel_size=0.2,
+                          truncation=0.6, esdf_max=2.0, pose_sigma=0.3, yaw_sigma=0.05, seed=2)
+true_poses, poses, pairs = bench.build_graph(a)
+subs = []
+for k in range(len(true_poses)):
+    sm = capi.Submap.synth_city(ctx, k, 0.2, 16, a.block_min, a.block_dims, 0.6, 2.0, 10.0, true_poses[k], 2)
+    sm.extract_voxel_points(1.0, 0.3, True)
+    sm.release_raw_layers()
+    subs.append(sm)
+cfg = capi.default_config(registration_point_type=capi.POINTS_VOXELS)
+cfs = [capi.RegistrationCostFunction(ctx, subs[i], subs[j], cfg) for i, j in pairs]
+batch = capi.RegistrationBatch(ctx, cfs, pairs)
+R = batch.num_residuals()
+sets = []
+for k in range(int(os.environ.get("VGX_PROBE_SETS", "8"))):
+    r = torch.empty(R, dtype=torch.float32, device="cuda"); jo = torch.empty((R, 4), dtype=torch.float32, device="cuda"); je = torch.empty((R, 4), dtype=torch.float32, device="cuda")
+    sets.append((r, jo, je))
+torch.cuda.synchronize()
+
+
+def timed(s, reps=10):
+    r, jo, je = s
+    for _ in range(2):
+        batch.evaluate_points(poses, r.data_ptr(), jo.data_ptr(), je.data_ptr())
+    ctx.synchronize()
+    ctx.timer_start()
+    for _ in range(reps):
+        batch.evaluate_points(poses, r.data_ptr(), jo.data_ptr(), je.data_ptr())
+    return ctx.timer_stop() / reps
+
+
+rows = [[] for _ in sets]
+for rnd in range(3):
+    for k, s in enumerate(sets):
+        rows[k].append(timed(s))
+def fill(tensor, nbytes):
+    return nbytes / capi.stream_ceiling_ms(ctx, 0, 0, tensor.data_ptr(), nbytes, 3) / 1e6
+
+
+def read(tensor, nbytes):
+    return nbytes / capi.stream_ceiling_ms(ctx, tensor.data_ptr(), nbytes, tensor.data_ptr(), 0, 3) / 1e6
+
+
+for k, (s, t) in enumerate(zip(sets, rows)):
+    f = [fill(s[0], 4 * R), fill(s[1], 16 * R), fill(s[2], 16 * R)]
+    g = [read(s[1], 16 * R), read(s[2], 16 * R)]
+    cp = 32.0 * R / capi.stream_ceiling_ms(ctx, s[1].data_ptr(), 16 * R, s[2].data_ptr(), 16 * R, 3) / 1e6
+    print("set %d  r %#x jo %#x je %#x   ms %s   fill r/jo/je %.0f %.0f %.0f  read jo/je %.0f %.0f  copy jo->je %.0f GB/s" % (
+        k, s[0].data_ptr(), s[1].data_ptr(), s[2].data_ptr(), " ".join("%.4f" % x for x in t), f[0], f[1], f[2], g[0], g[1], cp))
+# mixed sets: r/jo of one with je of another
+for (i, j) in ((0, 1), (1, 0), (2, 5), (5, 2)):
+    t = timed((sets[i][0], sets[i][1], sets[j][2]))
+    print("r, jo of set %d with je of set %d   ms %.4f" % (i, j, t))

@@ -318,6 +318,38 @@ def test_batch_points_match_per_constraint_oracle(capi, ctx, small_graph):
     batch.destroy()
 
 
+def test_choose_outputs_times_candidates_and_leaves_valid_rows(capi, ctx, small_graph):
+    """vgx_reg_batch_choose_outputs (placement by measurement): every trial is a real launch of the batch, the indices
+    it returns are candidates, and whichever arrays it picks hold the rows a plain evaluate_points writes"""
+    import torch
+    G = small_graph
+    batch = capi.RegistrationBatch(ctx, G["cfs"], G["pairs"])
+    R = batch.num_residuals()
+    n = 3
+    cand = [(_torch_buf(R, torch.float32), _torch_buf(4 * R, torch.float32), _torch_buf(4 * R, torch.float32)) for _ in range(n)]
+    ref = (_torch_buf(R, torch.float32), _torch_buf(4 * R, torch.float32), _torch_buf(4 * R, torch.float32))
+    torch.cuda.synchronize()
+    chosen, ms, trials = batch.choose_outputs(G["poses"], [c[0].data_ptr() for c in cand], [c[1].data_ptr() for c in cand],
+                                              [c[2].data_ptr() for c in cand], launches=2)
+    assert len(chosen) == 3 and all(0 <= k < n for k in chosen)
+    assert ms > 0 and len(trials) == 4 * n
+    assert all(t > 0 for t in trials[:n])                                   # the sets
+    for which in range(3):                                                  # then jac_read, jac_ref, residuals
+        block = trials[n + which * n: n + (which + 1) * n]
+        assert sum(1 for t in block if t == -1.0) == 1 and all(t > 0 or t == -1.0 for t in block)
+    assert ms <= min(t for t in trials if t > 0) * 1.006     # (a change is adopted only when it gains 0.5 %)
+    batch.evaluate_points(G["poses"], ref[0].data_ptr(), ref[1].data_ptr(), ref[2].data_ptr())
+    ctx.synchronize()
+    for which, k in enumerate(chosen):
+        assert torch.equal(cand[k][which], ref[which])
+    # without Jacobians: only the residual arrays are candidates
+    chosen2, ms2, trials2 = batch.choose_outputs(G["poses"], [c[0].data_ptr() for c in cand], None, None, launches=1)
+    assert 0 <= chosen2[0] < n and ms2 > 0
+    with pytest.raises(Exception):
+        batch.choose_outputs(G["poses"], [cand[0][0].data_ptr(), 0], None, None)
+    batch.destroy()
+
+
 def test_batch_normal_equations_and_assembly(capi, ctx, small_graph):
     import torch
     G = small_graph

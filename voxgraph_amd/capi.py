@@ -130,6 +130,8 @@ SIGNATURES = {
     "vgx_reg_batch_num_residuals": (C.c_int64, [vp]),
     "vgx_reg_batch_row_offsets": (C.c_int, [vp, i64p]),
     "vgx_reg_batch_evaluate_points": (C.c_int, [vp, f64p, C.c_int32, vp, vp, vp, i32p]),
+    "vgx_reg_batch_choose_outputs": (C.c_int, [vp, f64p, C.c_int32, C.c_int32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
+                                               C.c_int32, i32p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "vgx_reg_batch_evaluate_normal": (C.c_int, [vp, f64p, C.c_int32, vp, f64p, i32p]),
     "vgx_reg_batch_count_live": (C.c_int, [vp, f64p, C.c_int32, i64p, i64p]),
     "vgx_reg_batch_launch_order": (C.c_int, [vp, C.c_int32, i32p]),
@@ -505,6 +507,21 @@ class RegistrationBatch:
             vp(d_jac_ref) if d_jac_ref else None, vp(d_jac_read) if d_jac_read else None,
             _ptr(status, i32p)))
         return status[:self.n]
+
+    def choose_outputs(self, poses, d_residuals, d_jac_ref, d_jac_read, launches=3):
+        """vgx_reg_batch_choose_outputs: lists of candidate device pointers (d_jac_ref / d_jac_read may be None) ->
+        (chosen [3], ms per launch of the chosen combination, ms of every trial)"""
+        poses = _f64(poses).reshape(-1, 4)
+        n = len(d_residuals)
+        arr = lambda ps: (vp * n)(*[vp(int(x)) for x in ps]) if ps is not None else None
+        a_r, a_jr, a_je = arr(d_residuals), arr(d_jac_ref), arr(d_jac_read)
+        chosen = np.zeros(3, np.int32)
+        ms = C.c_float()
+        trials = (C.c_float * (4 * n))()
+        self.ctx.check(self.ctx.lib.vgx_reg_batch_choose_outputs(
+            self.h, _ptr(poses, f64p), poses.shape[0], n, a_r, a_jr, a_je, int(launches), _ptr(chosen, i32p),
+            C.byref(ms), trials))
+        return [int(x) for x in chosen], float(ms.value), [float(x) for x in trials]
 
     def evaluate_normal(self, poses, d_normal=None, to_host=True):
         poses = _f64(poses).reshape(-1, 4)

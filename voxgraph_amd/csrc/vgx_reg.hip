@@ -2239,6 +2239,94 @@ int vgx_reg_batch_evaluate_points(vgx_reg_batch b, const double* poses, int32_t 
   return VGX_OK;
 }
 
+// Placement by measurement (include/voxgraph_amd.h): which of the caller's candidate arrays the materialising pass runs
+// fastest on.  First whole sets (k-th candidate of each array), then array by array against the best combination so far.
+int vgx_reg_batch_choose_outputs(vgx_reg_batch b, const double* poses, int32_t n_nodes, int32_t n_candidates,
+                                 void* const* d_residuals, void* const* d_jac_ref, void* const* d_jac_read, int32_t launches,
+                                 int32_t chosen[3], float* ms_chosen, float* ms_trials) {
+  if (!b || !poses || !d_residuals || !chosen || n_candidates <= 0 || launches <= 0) return VGX_ERR_INVALID;
+  vgx_ctx ctx = b->ctx;
+  for (int k = 0; k < n_candidates; ++k)
+    if (!d_residuals[k] || (d_jac_ref && !d_jac_ref[k]) || (d_jac_read && !d_jac_read[k]))
+      return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_batch_choose_outputs: a candidate is NULL");
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    VGX_HIP(ctx, hipSetDevice(ctx->device));
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+      if (e0) (void)hipEventDestroy(e0);
+      return set_error(ctx, VGX_ERR_HIP, "vgx_reg_batch_choose_outputs: hipEventCreate failed");
+    }
+  }
+  int n_trials = 0;
+  auto trial = [&](int i, int j, int k, float* ms) -> int {
+    void* jr = d_jac_ref ? d_jac_ref[j] : nullptr;
+    void* je = d_jac_read ? d_jac_read[k] : nullptr;
+    int rc = vgx_reg_batch_evaluate_points(b, poses, n_nodes, d_residuals[i], jr, je, nullptr);  // warm-up (and first-use set-up)
+    if (rc != VGX_OK) return rc;
+    {
+      std::lock_guard<std::mutex> lk(ctx->mu);
+      VGX_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    }
+    for (int l = 0; l < launches && rc == VGX_OK; ++l)
+      rc = vgx_reg_batch_evaluate_points(b, poses, n_nodes, d_residuals[i], jr, je, nullptr);
+    if (rc != VGX_OK) return rc;
+    {
+      std::lock_guard<std::mutex> lk(ctx->mu);
+      VGX_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    }
+    VGX_HIP(ctx, hipEventSynchronize(e1));
+    float t = 0.0f;
+    VGX_HIP(ctx, hipEventElapsedTime(&t, e0, e1));
+    *ms = t / (float)launches;
+    if (ms_trials) ms_trials[n_trials] = *ms;
+    ++n_trials;
+    return VGX_OK;
+  };
+  int rc = VGX_OK;
+  float best = 0.0f;
+  int pick[3] = {0, 0, 0};
+  for (int s_ = 0; s_ < n_candidates && rc == VGX_OK; ++s_) {  // whole sets
+    float t = 0.0f;
+    rc = trial(s_, s_, s_, &t);
+    if (rc == VGX_OK && (s_ == 0 || t < best)) {
+      best = t;
+      pick[0] = pick[1] = pick[2] = s_;
+    }
+  }
+  // array by array (the larger ones first); a change is kept when it gains more than the measurement's own scatter
+  for (int which = 2; which >= 0 && rc == VGX_OK && n_candidates > 1; --which) {
+    if ((which == 1 && !d_jac_ref) || (which == 2 && !d_jac_read)) continue;
+    const int set_pick = pick[which];
+    for (int c = 0; c < n_candidates && rc == VGX_OK; ++c) {
+      if (c == set_pick) {  // (measured as part of its set, or since adopted)
+        if (ms_trials) ms_trials[n_trials] = -1.0f;
+        ++n_trials;
+        continue;
+      }
+      int q[3] = {pick[0], pick[1], pick[2]};
+      q[which] = c;
+      float t = 0.0f;
+      rc = trial(q[0], q[1], q[2], &t);
+      if (rc == VGX_OK && t < 0.995f * best) {
+        best = t;
+        pick[which] = c;
+      }
+    }
+  }
+  {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  }
+  if (rc != VGX_OK) return rc;
+  chosen[0] = pick[0];
+  chosen[1] = pick[1];
+  chosen[2] = pick[2];
+  if (ms_chosen) *ms_chosen = best;
+  return VGX_OK;
+}
+
 int vgx_reg_batch_evaluate_normal(vgx_reg_batch b, const double* poses, int32_t n_nodes,
                                   void* d_normal, double* normal_host, int32_t* status) {
   if (!b || !poses) return VGX_ERR_INVALID;
