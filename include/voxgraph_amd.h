@@ -287,11 +287,9 @@ VGX_API int vgx_reg_batch_row_offsets(vgx_reg_batch batch, int64_t* row_offset);
  * into DEVICE arrays stacked by row_offset: residuals[R], jac_ref[R][4],
  * jac_read[R][4].  poses: host [n_nodes][4] f64.  status[c] (host, nullable)
  * receives VGX_OK / VGX_EVALUATE_FALSE per constraint.  Asynchronous.
- * Alignment: 16 bytes is required (float4 stores); 4 KiB is what the kernel
- * wants -- a workgroup stores 16 KiB runs, and array bases off the 4 KiB grid
- * cost 10-20 % (measured: profiles/r05_headline_ab.txt, addendum 2).  hipMalloc
- * results are aligned far beyond that; arrays carved out of one allocation
- * should be rounded up to 4 KiB. */
+ * Alignment: 16 bytes is required (float4 stores); more buys nothing (measured
+ * with the placement held fixed: profiles/r05_points_placement.txt).  WHERE the
+ * arrays lie physically does matter: vgx_reg_batch_choose_outputs below. */
 VGX_API int vgx_reg_batch_evaluate_points(vgx_reg_batch batch,
                                           const double* poses, int32_t n_nodes,
                                           void* d_residuals, void* d_jac_ref,

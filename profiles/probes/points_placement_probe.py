@@ -29,7 +29,7 @@ batch = capi.RegistrationBatch(ctx, cfs, pairs)
 R = batch.num_residuals()
 sets = []
 for k in range(int(os.environ.get("VGX_PROBE_SETS", "8"))):
-    r = torch.empty(R, dtype=torch.float32, device="cuda"); jo = torch.empty((R, 4), dtype=torch.float32, device="cuda"); je = torch.empty((R, 4), dtype=torch.float32, device="cuda")
+    r = torch.empty(R + 4096, dtype=torch.float32, device="cuda"); jo = torch.empty((R + 4096, 4), dtype=torch.float32, device="cuda"); je = torch.empty((R + 4096, 4), dtype=torch.float32, device="cuda")
     sets.append((r, jo, je))
 torch.cuda.synchronize()
 
@@ -67,3 +67,25 @@ for k, (s, t) in enumerate(zip(sets, rows)):
 for (i, j) in ((0, 1), (1, 0), (2, 5), (5, 2)):
     t = timed((sets[i][0], sets[i][1], sets[j][2]))
     print("r, jo of set %d with je of set %d   ms %.4f" % (i, j, t))
+
+# alignment with the placement held fixed: the fastest set's arrays, the Jacobian arrays shifted by a few bytes inside their
+# own allocations (the same physical pages)
+best = min(range(len(sets)), key=lambda k: min(rows[k]))
+worst = max(range(len(sets)), key=lambda k: min(rows[k]))
+
+
+def timed_ptrs(rp, jop, jep, reps=10):
+    for _ in range(2):
+        batch.evaluate_points(poses, rp, jop, jep)
+    ctx.synchronize()
+    ctx.timer_start()
+    for _ in range(reps):
+        batch.evaluate_points(poses, rp, jop, jep)
+    return ctx.timer_stop() / reps
+
+
+for tag, k in (("fastest set", best), ("slowest set", worst)):
+    r, jo, je = sets[k]
+    for sh in (0, 256, 2048, 4096, 8192, 16384 + 2048):
+        print("%s (%d), jac_ref and jac_read + %5d B   ms %.4f" % (tag, k, sh, timed_ptrs(r.data_ptr(), jo.data_ptr() + sh, je.data_ptr() + sh)))
+    print("%s (%d), residuals + 1024 B                 ms %.4f" % (tag, k, timed_ptrs(r.data_ptr() + 1024, jo.data_ptr(), je.data_ptr())))
