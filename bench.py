@@ -350,7 +350,7 @@ def main():
 
     R_buf = max(R, fo["R"] if fo else 0)
     # Where the three row arrays lie in physical memory decides which of two speeds the materialising kernel runs at
-    # (4.4-4.7 or 5.3-5.7 ms on this workload; half of all allocations are slow ones: profiles/r05_headline_ab.txt
+    # (4.4-4.7 or 5.3-5.7 ms on this workload; half of all sets of three are slow ones: profiles/r05_points_placement.txt, r05_headline_ab.txt
     # addendum 4).  The library's answer is placement by measurement (vgx_reg_batch_choose_outputs): several
     # candidate allocations, the batch's own launch timed on them, the best array of each kind kept, the rest freed --
     # here, before anything is timed, as a caller that owns its row buffers would do once per batch.

@@ -296,9 +296,9 @@ VGX_API int vgx_reg_batch_evaluate_points(vgx_reg_batch batch,
                                           void* d_jac_read, int32_t* status);
 
 /* Placement by measurement.  WHERE the output arrays of the materialising pass lie in physical memory decides which of
- * two speeds the kernel runs at -- 200 x 256^3 submaps, 1176 constraints: 4.4-4.7 ms or 5.3-5.7 ms per launch; about one
- * array in four is a slow one, half of all sets of three; an array's own fill and read rates do not tell (measured:
- * profiles/r05_headline_ab.txt, addendum 4).  The physical address is not the caller's to choose, but which of several
+ * two speeds the kernel runs at -- 200 x 256^3 submaps, 1176 constraints: 4.4-4.7 ms or 5.3-5.7 ms per launch; about half
+ * of the sets of three an allocator hands out are slow ones, a matter of how the arrays lie relative to each other: every
+ * array's own fill and read rate is the same (measured: profiles/r05_points_placement.txt).  The physical address is not the caller's to choose, but which of several
  * allocations to keep is: given n_candidates device pointers for each array (each large enough for the batch; d_jac_ref /
  * d_jac_read may be NULL as for the pass itself), this call times the batch's own launch -- one warm-up and `launches`
  * timed launches per trial -- first on whole sets (the k-th candidate of each array), then array by array against the

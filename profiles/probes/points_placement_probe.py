@@ -61,6 +61,9 @@ for k, (s, t) in enumerate(zip(sets, rows)):
     f = [fill(s[0], 4 * R), fill(s[1], 16 * R), fill(s[2], 16 * R)]
     g = [read(s[1], 16 * R), read(s[2], 16 * R)]
     cp = 32.0 * R / capi.stream_ceiling_ms(ctx, s[1].data_ptr(), 16 * R, s[2].data_ptr(), 16 * R, 3) / 1e6
+    half = (8 * R) & ~15
+    self_copy = [2.0 * half / capi.stream_ceiling_ms(ctx, s[w].data_ptr(), half, s[w].data_ptr() + half, half, 3) / 1e6 for w in (1, 2)]
+    print("       first half -> second half of jo / of je (two streams inside ONE array): %.0f %.0f GB/s" % tuple(self_copy))
     print("set %d  r %#x jo %#x je %#x   ms %s   fill r/jo/je %.0f %.0f %.0f  read jo/je %.0f %.0f  copy jo->je %.0f GB/s" % (
         k, s[0].data_ptr(), s[1].data_ptr(), s[2].data_ptr(), " ".join("%.4f" % x for x in t), f[0], f[1], f[2], g[0], g[1], cp))
 # mixed sets: r/jo of one with je of another
