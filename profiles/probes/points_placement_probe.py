@@ -29,7 +29,8 @@ batch = capi.RegistrationBatch(ctx, cfs, pairs)
 R = batch.num_residuals()
 sets = []
 for k in range(int(os.environ.get("VGX_PROBE_SETS", "8"))):
-    r = torch.empty(R + 4096, dtype=torch.float32, device="cuda"); jo = torch.empty((R + 4096, 4), dtype=torch.float32, device="cuda"); je = torch.empty((R + 4096, 4), dtype=torch.float32, device="cuda")
+    SLACK = (1 << 30) // 16 + 4096      # rows of slack: the arrays can be shifted by up to 1 GiB inside their allocations
+    r = torch.empty(R + 4 * SLACK, dtype=torch.float32, device="cuda"); jo = torch.empty((R + SLACK, 4), dtype=torch.float32, device="cuda"); je = torch.empty((R + SLACK, 4), dtype=torch.float32, device="cuda")
     sets.append((r, jo, je))
 torch.cuda.synchronize()
 
@@ -68,6 +69,8 @@ for k, (s, t) in enumerate(zip(sets, rows)):
         k, s[0].data_ptr(), s[1].data_ptr(), s[2].data_ptr(), " ".join("%.4f" % x for x in t), f[0], f[1], f[2], g[0], g[1], cp))
 # mixed sets: r/jo of one with je of another
 for (i, j) in ((0, 1), (1, 0), (2, 5), (5, 2)):
+    if max(i, j) >= len(sets):
+        continue
     t = timed((sets[i][0], sets[i][1], sets[j][2]))
     print("r, jo of set %d with je of set %d   ms %.4f" % (i, j, t))
 
@@ -92,3 +95,12 @@ for tag, k in (("fastest set", best), ("slowest set", worst)):
     for sh in (0, 256, 2048, 4096, 8192, 16384 + 2048):
         print("%s (%d), jac_ref and jac_read + %5d B   ms %.4f" % (tag, k, sh, timed_ptrs(r.data_ptr(), jo.data_ptr() + sh, je.data_ptr() + sh)))
     print("%s (%d), residuals + 1024 B                 ms %.4f" % (tag, k, timed_ptrs(r.data_ptr() + 1024, jo.data_ptr(), je.data_ptr())))
+
+# larger shifts of ONE array inside its allocation: is the relation between the arrays periodic in their distance?
+for tag, k in (("slowest set", worst), ("fastest set", best)):
+    r, jo, je = sets[k]
+    for sh in (0, 64 << 10, 1 << 20, 2 << 20, 16 << 20, 128 << 20, 512 << 20, 1 << 30):
+        a = timed_ptrs(r.data_ptr(), jo.data_ptr(), je.data_ptr() + sh)
+        b = timed_ptrs(r.data_ptr(), jo.data_ptr() + sh, je.data_ptr())
+        c = timed_ptrs(r.data_ptr() + sh, jo.data_ptr(), je.data_ptr())
+        print("%s (%d), shift %10d B:  jac_read shifted %.4f   jac_ref shifted %.4f   residuals shifted %.4f" % (tag, k, sh, a, b, c))
