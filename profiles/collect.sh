@@ -21,7 +21,8 @@ export TMPDIR=/tmp
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_stats -o stats -- \
     python $REPO/bench.py --gpus 1 --steps 20 --warmup 5 --detail $OUT/prof_stats_detail.json > $OUT/prof_stats_bench.json 2> $OUT/prof_stats.err
-PMC_ARGS="--steps 3 --inner 1 --warmup 1 --no-cpu-baseline --no-solve --no-tsdf --no-config5 --no-config2 --no-fo-plain --no-multi-ctx --no-parity --calibrate"
+# (--placement-candidates 1: the counter passes keep the launch sequence summarize.py indexes -- no placement trials in front)
+PMC_ARGS="--placement-candidates 1 --steps 3 --inner 1 --warmup 1 --no-cpu-baseline --no-solve --no-tsdf --no-config5 --no-config2 --no-fo-plain --no-multi-ctx --no-parity --calibrate"
 REGEX="reg_eval_points|reg_eval_reduce"
 timeout 240 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum \
     --kernel-trace -f csv --kernel-include-regex "$REGEX" \
@@ -42,7 +43,7 @@ for c in rd write; do
 done
 timeout 240 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES \
     --kernel-trace -f csv --kernel-include-regex "reg_eval_points_kernel|reg_eval_reduce|tsdf_integrate|det_apply|det_sweep|det_ray" \
-    -d $OUT/prof_sq -o sq -- python $REPO/bench.py --steps 2 --inner 1 --warmup 1 --no-cpu-baseline --no-solve --no-shipped --no-config5 --no-config2 --no-multi-ctx --no-parity \
+    -d $OUT/prof_sq -o sq -- python $REPO/bench.py --placement-candidates 1 --steps 2 --inner 1 --warmup 1 --no-cpu-baseline --no-solve --no-shipped --no-config5 --no-config2 --no-multi-ctx --no-parity \
     > /dev/null 2> $OUT/prof_sq.err
 # un-profiled, the driver's EXACT command from the repo root (what BENCH_rNN.json will hold): stdout = the one
 # compact line (harness/bench_line.py), the full object in bench_detail.json next to bench.py
