@@ -43,6 +43,13 @@ VGX_API int vgx_synth_city_scan(vgx_ctx ctx, const double sensor_pose[4], int32_
 VGX_API int vgx_bench_atomic_roundtrip(vgx_ctx ctx, int64_t table_bytes, int32_t waves, int32_t chain,
                                        float* ns_per_step);
 
+/* Device memory whose physical pages are deliberately out of order: an address range reserved through the virtual-memory
+ * API, one physical allocation per chunk_bytes (rounded up to the allocation granularity), mapped in a shuffled order
+ * (seed 0: in order).  For the placement experiments of profiles/r05_points_placement.txt.  Freed with
+ * vgx_bench_free_scattered only. */
+VGX_API int vgx_bench_alloc_scattered(vgx_ctx ctx, int64_t bytes, int64_t chunk_bytes, uint32_t seed, void** d_ptr);
+VGX_API int vgx_bench_free_scattered(vgx_ctx ctx, void* d_ptr);
+
 /* Same-run memory ceiling for the REG rooflines (bench.py `roofline.copy_ceiling_GBs`): `launches` launches that stream
  * read_bytes in (float4 loads from d_src) and write_bytes out (non-temporal float4 stores to d_dst) -- both DEVICE
  * pointers, sizes multiples of 16; read_bytes == write_bytes is a float4 copy, read_bytes == 0 a fill.  Returns the

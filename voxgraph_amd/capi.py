@@ -115,6 +115,8 @@ SIGNATURES = {
                                       C.c_uint32, vp]),
     "vgx_bench_atomic_roundtrip": (C.c_int, [vp, C.c_int64, C.c_int32, C.c_int32, f32p]),
     "vgx_bench_stream_ceiling": (C.c_int, [vp, vp, C.c_int64, vp, C.c_int64, C.c_int32, f32p]),
+    "vgx_bench_alloc_scattered": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_uint32, C.POINTER(vp)]),
+    "vgx_bench_free_scattered": (C.c_int, [vp, vp]),
     "vgx_tsdf_integrator_walk_stats": (C.c_int, [vp, i64p]),
     "vgx_tsdf_integrator_read_trace": (C.c_int, [vp, i64p, C.c_int64, i64p, i64p]),
     "vgx_tsdf_integrator_set_speculation": (C.c_int, [vp, C.c_int32, C.c_int64]),
@@ -667,6 +669,17 @@ def atomic_roundtrip_ns(ctx, table_bytes=8 << 20, waves=1, chain=2000):
     out = C.c_float()
     ctx.check(ctx.lib.vgx_bench_atomic_roundtrip(ctx.h, table_bytes, waves, chain, C.byref(out)))
     return out.value
+
+
+def alloc_scattered(ctx, nbytes, chunk_bytes, seed):
+    """bench tooling (vgx_bench_alloc_scattered): device pointer of a range whose physical chunks are mapped in shuffled order"""
+    out = vp()
+    ctx.check(ctx.lib.vgx_bench_alloc_scattered(ctx.h, int(nbytes), int(chunk_bytes), int(seed), C.byref(out)))
+    return int(out.value)
+
+
+def free_scattered(ctx, ptr):
+    ctx.check(ctx.lib.vgx_bench_free_scattered(ctx.h, vp(int(ptr))))
 
 
 def stream_ceiling_ms(ctx, d_src, read_bytes, d_dst, write_bytes, launches=5):

@@ -2,7 +2,11 @@
 // the device so that BASELINE config 3 (200 submaps @ 256^3 = 3.4 G voxels) is
 // practical.  Bit-for-bit mirror of synth.city_sdf / synth.make_submap (checked
 // in tests/test_synth_scene.py).  Not part of the reference's interface.
+#include <algorithm>
 #include <cmath>
+#include <map>
+#include <mutex>
+#include <vector>
 
 #include "vgx_internal.h"
 #include "voxgraph_amd_bench.h"
@@ -315,5 +319,98 @@ extern "C" int vgx_synth_city_submap(vgx_ctx ctx, int32_t submap_id, float voxel
     return rc;
   }
   *out = sm;
+  return VGX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// vgx_bench_alloc_scattered: device memory whose PHYSICAL pages are deliberately out of order.  The materialising pass runs
+// at 4.4 ms on arrays whose pages happen to lie scattered, at 5.4 ms on others and at 7.1 ms on arrays that are one physical
+// run (profiles/r05_points_placement.txt); this allocator makes the scattered case on purpose: an address range reserved
+// through the virtual-memory API, one physical allocation per `chunk_bytes`, mapped in a shuffled order (seed 0: in order).
+namespace {
+struct ScatteredRange {
+  size_t bytes = 0;
+  std::vector<hipMemGenericAllocationHandle_t> handles;
+};
+std::mutex g_scattered_mu;
+std::map<void*, ScatteredRange> g_scattered;
+}  // namespace
+
+extern "C" int vgx_bench_alloc_scattered(vgx_ctx ctx, int64_t bytes, int64_t chunk_bytes, uint32_t seed, void** out) {
+  if (!ctx || !out || bytes <= 0 || chunk_bytes <= 0) return VGX_ERR_INVALID;
+  *out = nullptr;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  VGX_HIP(ctx, hipSetDevice(ctx->device));
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = ctx->device;
+  size_t gran = 0;
+  VGX_HIP(ctx, hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+  if (gran == 0) gran = 2u << 20;
+  const size_t chunk = ((size_t)chunk_bytes + gran - 1) / gran * gran;
+  const size_t n = ((size_t)bytes + chunk - 1) / chunk;
+  const size_t total = n * chunk;
+  void* base = nullptr;
+  VGX_HIP(ctx, hipMemAddressReserve(&base, total, gran, nullptr, 0));
+  ScatteredRange range;
+  range.bytes = total;
+  int rc = VGX_OK;
+  for (size_t i = 0; i < n && rc == VGX_OK; ++i) {
+    hipMemGenericAllocationHandle_t h;
+    if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) rc = VGX_ERR_NOMEM;
+    else range.handles.push_back(h);
+  }
+  std::vector<size_t> perm(n);
+  for (size_t i = 0; i < n; ++i) perm[i] = i;
+  if (seed != 0u) {  // Fisher-Yates on a 64-bit LCG
+    unsigned long long state = 0x9E3779B97F4A7C15ull ^ ((unsigned long long)seed * 0xD1B54A32D192ED03ull);
+    for (size_t i = n; i > 1; --i) {
+      state = state * 6364136223846793005ull + 1442695040888963407ull;
+      std::swap(perm[i - 1], perm[(size_t)((state >> 33) % i)]);
+    }
+  }
+  size_t mapped = 0;
+  for (size_t i = 0; i < n && rc == VGX_OK; ++i) {
+    if (hipMemMap((char*)base + i * chunk, chunk, 0, range.handles[perm[i]], 0) != hipSuccess) rc = VGX_ERR_HIP;
+    else mapped = i + 1;
+  }
+  if (rc == VGX_OK) {
+    hipMemAccessDesc desc = {};
+    desc.location = prop.location;
+    desc.flags = hipMemAccessFlagsProtReadWrite;
+    if (hipMemSetAccess(base, total, &desc, 1) != hipSuccess) rc = VGX_ERR_HIP;
+  }
+  if (rc != VGX_OK) {
+    (void)hipGetLastError();
+    if (mapped) (void)hipMemUnmap(base, mapped * chunk);
+    for (auto h : range.handles) (void)hipMemRelease(h);
+    (void)hipMemAddressFree(base, total);
+    return set_error(ctx, rc, "vgx_bench_alloc_scattered: the virtual-memory API refused (reserve / create / map / set access)");
+  }
+  {
+    std::lock_guard<std::mutex> g(g_scattered_mu);
+    g_scattered[base] = std::move(range);
+  }
+  *out = base;
+  return VGX_OK;
+}
+
+extern "C" int vgx_bench_free_scattered(vgx_ctx ctx, void* ptr) {
+  if (!ctx || !ptr) return VGX_ERR_INVALID;
+  ScatteredRange range;
+  {
+    std::lock_guard<std::mutex> g(g_scattered_mu);
+    auto it = g_scattered.find(ptr);
+    if (it == g_scattered.end()) return set_error(ctx, VGX_ERR_INVALID, "vgx_bench_free_scattered: not a scattered range");
+    range = std::move(it->second);
+    g_scattered.erase(it);
+  }
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  VGX_HIP(ctx, hipSetDevice(ctx->device));
+  VGX_HIP(ctx, hipDeviceSynchronize());
+  (void)hipMemUnmap(ptr, range.bytes);
+  for (auto h : range.handles) (void)hipMemRelease(h);
+  (void)hipMemAddressFree(ptr, range.bytes);
   return VGX_OK;
 }
