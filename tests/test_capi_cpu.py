@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(capi):
     # benchmark tooling lives in its own header, not in the drop-in boundary
     boundary = _declared_symbols(("voxgraph_amd.h",))
     assert not [n for n in boundary if "synth" in n]
-    assert sorted(set(declared) - set(boundary)) == ["vgx_bench_atomic_roundtrip", "vgx_bench_stream_ceiling", "vgx_synth_city_scan",
+    assert sorted(set(declared) - set(boundary)) == ["vgx_bench_alloc_scattered", "vgx_bench_atomic_roundtrip", "vgx_bench_free_scattered", "vgx_bench_stream_ceiling", "vgx_synth_city_scan",
                                                      "vgx_synth_city_submap", "vgx_tsdf_integrator_read_trace", "vgx_tsdf_integrator_set_speculation",
                                                      "vgx_tsdf_integrator_walk_stats"]
 
