@@ -262,8 +262,11 @@ def test_box_state_degrades_gracefully_without_a_gpu_and_the_line_carries_the_ce
     assert "available" in s.summary()
     full = {"metric": "m", "value": 1.0, "unit": "u", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": 1.0,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "w"},
-            "roofline": {"bound": "hbm", "achieved": 6750.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.84, "traffic": 3.0e10,
+            "config": {"workload": "w", "output_placement": "row arrays: the fastest of 4 allocations of each kind"},
+            "tsdf": {"lidar_64x1024": {"ms_per_scan": 0.021, "ms_per_scan_fresh_integrator": 0.044, "integrator_age_scans": 100,
+                                       "reproducible_mode": {"ms_per_scan": 0.25, "ms_per_scan_fresh_integrator": 0.31},
+                                       "cpu_baseline": {"Mpoints_per_s": 70.0, "Mpoints_per_s_fresh_integrator": 54.0}}},
+            "roofline": {"bound": "hbm", "achieved": 6750.0, "placement_ms_sets": [5.59, 4.36, 4.36, 4.43], "peak": 8000.0, "unit": "GB/s", "frac": 0.84, "traffic": 3.0e10,
                          "traffic_source": "profiles/hbm_traffic.json", "hbm_frac": 0.79, "copy_ceiling_GBs": 6315.0,
                          "fill_ceiling_GBs": 6778.0, "kernel_shaped_ceiling_GBs": 6273.0, "frac_of_copy_ceiling": 1.07,
                          "traffic_frac_of_copy_ceiling": 1.01, "frac_of_kernel_shaped_ceiling": 1.08, "kernel_ms": 4.7},
@@ -277,4 +280,11 @@ def test_box_state_degrades_gracefully_without_a_gpu_and_the_line_carries_the_ce
     assert out["box"] == {"sclk_MHz_during": 2390.0, "mclk_MHz_during": 2000.0, "power_W_during": 1152.0, "power_cap_W": 1400.0,
                           "pci_bus_id": "0000:0d:00.0", "vbios": "113-M355-01-1K1-030A",
                           "compute_partition": "SPX", "memory_partition": "NPS1"}
+    # the two findings of round 5's end travel in the line: what the candidate placements of the row arrays cost, and
+    # the session-old integrator's TSDF figures next to the fresh one's
+    assert out["roofline"]["placement_ms_sets"] == [5.59, 4.36, 4.36, 4.43] and "fastest of 4" in out["config"]["output_placement"]
+    t = out["tsdf"]["lidar"]
+    assert (t["ms_per_scan"], t["ms_per_scan_fresh_integrator"], t["integrator_age_scans"]) == (0.021, 0.044, 100)
+    assert (t["reproducible_ms_per_scan"], t["reproducible_ms_per_scan_fresh_integrator"]) == (0.25, 0.31)
+    assert (t["cpu_Mpoints_per_s_1_core"], t["cpu_Mpoints_per_s_1_core_fresh_integrator"]) == (70.0, 54.0)
     assert len(line) < bench_line.LINE_LIMIT
