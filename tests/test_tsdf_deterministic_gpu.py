@@ -105,6 +105,46 @@ def test_dense_lidar_scans_are_the_single_thread_result_bit_for_bit(capi, ctx):
         o.destroy()
 
 
+def test_a_session_old_integrator_is_the_oracles_bit_for_bit_and_does_less_work(capi, ctx):
+    """The reference keeps ONE FastTsdfIntegrator for the whole mapping session and points it at every new submap's layer
+    (pointcloud_integrator.cpp:66-75), and voxblox's ApproxHashSet never forgets between its 10 000-scan resets: the mark
+    scan N leaves at slot (hash + N) reads as "present" for the voxel with hash - k in scan N + k, so marks of earlier scans
+    cut later scans' rays short (DESIGN.md 3 "The integrator's age"; what bench.py's TSDF figures are measured with).
+    Four submaps of ten scans each through one integrator: the reproducible mode's layer and update count are the oracle's
+    at every scan of every submap -- the artefact included -- and the same ten scans cost fewer voxel updates in the
+    fourth submap than in the first."""
+    vs, vps = 0.2, 16
+    ocfg = orc.voxgraph_tsdf_config()
+    gcfg = capi.voxgraph_tsdf_config(deterministic=1)
+    scans = []
+    for k in range(10):
+        origin = np.array([0.02 * k - 1.0, -0.005 * k + 0.5, 0.001 * k + 0.3], F)
+        scans.append((np.r_[np.array([1, 0, 0, 0], F), origin].astype(F), _lidar_scan(512, 32, 40 + k, origin=origin.astype(np.float64))))
+    ol, gl = orc.TsdfLayer(vs, vps), capi.TsdfLayer(ctx, vs, vps)
+    oi, gi = orc.FastTsdfIntegrator(ocfg, ol), capi.FastTsdfIntegrator(ctx, gcfg, gl)
+    updates = []
+    old_layers = []
+    for submap in range(4):
+        if submap:                     # a new submap: a fresh layer, the SAME integrator
+            old_layers.append(gl)
+            ol, gl = orc.TsdfLayer(vs, vps), capi.TsdfLayer(ctx, vs, vps)
+            oi.setLayer(ol)
+            gi.setLayer(gl)
+        per = []
+        for k, (T, pts) in enumerate(scans):
+            a = oi.integratePointCloud(T, pts)
+            b = gi.integratePointCloud(T, pts)
+            assert a == b, (submap, k, a, b)
+            per.append(a)
+        _assert_layers_identical(ol, gl, f"submap {submap}")
+        updates.append(sum(per[1:]))
+    print("voxel updates of scans 1..9, submap by submap:", updates)
+    assert updates[3] < updates[0], updates      # the same scans, an older integrator: rays stop earlier
+    assert gl.stats()[1] == 0
+    for o in [gi, gl] + old_layers:
+        o.destroy()
+
+
 def test_rgbd_fullsize_scans_bit_for_bit(capi, ctx):
     """BASELINE config 4: 640 x 480 depth images at 0.05 m voxels, truncation 0.15 m, 5 m rays, 1/z^2
     weights (voxblox's default), three consecutive frames from a slowly moving camera."""
