@@ -484,8 +484,9 @@ def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=8):
                                                         "launches_source": launches_note,
                                                         "us_per_launch": (det_ms * 1e3 / launches[("fast", sensor)]
                                                                           if ("fast", sensor) in launches else None),
-                                                        "host_waits_per_scan": "2 (the count, the commit) + 1 per extra attempt; "
-                                                                               "the sweeps report through a pinned word"},
+                                                        "host_waits_per_scan": "2 (the count, the commit) + 1 per extra attempt, each a "
+                                                                               "poll of pinned report words behind a one-workgroup "
+                                                                               "kernel; the sweeps report through a pinned word"},
                                            "voxel_updates_per_scan": det_updates,
                                            "over_racing_kernel": det_ms / (ms / timed),
                                            "parity_vs_oracle": det_parity,

@@ -87,6 +87,11 @@ struct DetScratch {
   unsigned long long* h_flag = nullptr;
   unsigned long long* d_flag = nullptr;  // the same word as the device addresses it
   unsigned long long flag_seq = 0;
+  // the counters' way to the host (read_counters): a one-workgroup kernel stores them into pinned, coherent words and
+  // then a sequence number, the host polls that number -- no copy engine, no stream synchronisation (round 5)
+  unsigned long long* h_report = nullptr;
+  unsigned long long* d_report = nullptr;  // the same words as the device addresses them
+  unsigned long long report_seq = 0;
   bool start_capped = false;  // the previous scan's complete walks were too many to write out: count capped at once
   long long ext_points = -1;  // ext[] holds the previous scan's marks for a scan of this many points (-1: nothing to keep)
 };
@@ -107,6 +112,7 @@ void det_scratch_free(DetScratch* s) {
   if (s->d_ctr) (void)hipFree(s->d_ctr);
   if (s->h_ctr) (void)hipHostFree(s->h_ctr);
   if (s->h_flag) (void)hipHostFree(s->h_flag);
+  if (s->h_report) (void)hipHostFree(s->h_report);
   delete s;
 }
 
@@ -1239,9 +1245,51 @@ int next_chain(vgx_ctx ctx, DetScratch* S, uint32_t tiles, TileChain* ch) {
   return VGX_OK;
 }
 
+constexpr int kReportWords = 32;  // [0] sequence number, [2 .. 2 + kCtrCount) the counters
+static_assert(2 + kCtrCount <= kReportWords, "the report holds every counter");
+
+__global__ __launch_bounds__(64) void det_report_kernel(const unsigned long long* __restrict__ ctr,
+                                                       unsigned long long* __restrict__ host_words, unsigned long long seq) {
+  const int i = (int)threadIdx.x;
+  if (i < kCtrCount)
+    __hip_atomic_store(&host_words[2 + i], __hip_atomic_load(&ctr[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();
+  __syncthreads();
+  if (i == 0) __hip_atomic_store(&host_words[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// The scan's counters on the host, and everything queued before this call finished.  Through the pinned report words:
+// one tiny kernel behind the producers and a poll (a few microseconds after the producer ends) instead of a copy through
+// the blit path and a stream synchronisation (20-45 us of bubble per read-back in profiles/r05_tsdf_launches.txt, two per
+// scan).  VGX_DET_REPORT=0: the copy + synchronise of rounds 3-4 (A/B aid; also the fallback without pinned memory).
 int read_counters(vgx_ctx ctx, DetScratch* S) {
-  VGX_HIP(ctx, hipMemcpyAsync(S->h_ctr, S->d_ctr, kCtrCount * 8, hipMemcpyDeviceToHost, ctx->tsdf_stream));
-  VGX_HIP(ctx, hipStreamSynchronize(ctx->tsdf_stream));
+  static const bool by_report = !(getenv("VGX_DET_REPORT") && atoi(getenv("VGX_DET_REPORT")) == 0);
+  if (!by_report || !S->h_report) {
+    VGX_HIP(ctx, hipMemcpyAsync(S->h_ctr, S->d_ctr, kCtrCount * 8, hipMemcpyDeviceToHost, ctx->tsdf_stream));
+    VGX_HIP(ctx, hipStreamSynchronize(ctx->tsdf_stream));
+    return VGX_OK;
+  }
+  const unsigned long long seq = ++S->report_seq;
+  hipLaunchKernelGGL(det_report_kernel, dim3(1), dim3(64), 0, ctx->tsdf_stream, S->d_ctr, S->d_report, seq);
+  VGX_HIP(ctx, hipGetLastError());
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 1;; ++spins) {
+    if (__atomic_load_n(&S->h_report[0], __ATOMIC_ACQUIRE) >= seq) break;
+    if (spins % 8192u != 0) {
+      __builtin_ia32_pause();
+      continue;
+    }
+    const hipError_t e = hipStreamQuery(ctx->tsdf_stream);
+    if (e == hipSuccess) {  // everything queued has run: the report is there, or it never will be
+      if (__atomic_load_n(&S->h_report[0], __ATOMIC_ACQUIRE) >= seq) break;
+      return set_error(ctx, VGX_ERR_HIP, "TSDF reproducible mode: the counters' report never arrived (internal error)");
+    }
+    if (e != hipErrorNotReady) VGX_HIP(ctx, e);
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30))
+      return set_error(ctx, VGX_ERR_HIP, "TSDF reproducible mode: no report of the counters within 30 s");
+  }
+  for (int i = 0; i < kCtrCount; ++i) S->h_ctr[i] = __atomic_load_n(&S->h_report[2 + i], __ATOMIC_RELAXED);
   return VGX_OK;
 }
 
@@ -1271,6 +1319,19 @@ static int ensure_scratch(vgx_tsdf_integrator I) {
     dp = S->h_flag;  // (unified addressing: the same pointer)
   }
   S->d_flag = (unsigned long long*)dp;
+  // the counters' report words: coherent or nothing (read_counters then copies and synchronises as before)
+  if (hipHostMalloc((void**)&S->h_report, kReportWords * 8, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+    (void)hipGetLastError();
+    S->h_report = nullptr;
+  } else {
+    for (int i = 0; i < kReportWords; ++i) S->h_report[i] = 0ull;
+    void* rp = nullptr;
+    if (hipHostGetDevicePointer(&rp, S->h_report, 0) != hipSuccess || !rp) {
+      (void)hipGetLastError();
+      rp = S->h_report;
+    }
+    S->d_report = (unsigned long long*)rp;
+  }
   return VGX_OK;
 }
 
