@@ -111,6 +111,7 @@ def multi_context_child(args, n_devices, timeout_s=240):
         detail = os.path.join(tmp, "inprocess.json")
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(n_devices), "--inprocess", "--no-cpu-baseline", "--no-tsdf",
                "--no-solve", "--no-config5", "--no-config2", "--no-parity", "--no-full-overlap", "--no-shipped",
+               "--placement-candidates", "1",      # (only the child's multi_context block is used)
                "--steps", str(max(min(args.steps, 5), 1)), "--warmup", "1", "--inner", str(args.inner),
                "--grid", *map(str, args.grid), "--block-dims", *map(str, args.block_dims), "--block-min", *map(str, args.block_min),
                "--voxel-size", str(args.voxel_size), "--truncation", str(args.truncation), "--esdf-max", str(args.esdf_max),
