@@ -167,7 +167,7 @@ def main():
                     help="full-overlap workload: perturbed duplicates per submap (config 3 has ~6 "
                          "constraints per reference submap)")
     ap.add_argument("--no-full-overlap", action="store_true")
-    ap.add_argument("--placement-candidates", type=int, default=4,
+    ap.add_argument("--placement-candidates", type=int, default=6,
                     help="allocations of each row array the materialising kernel is timed on before the timed region; the "
                          "fastest of each kind is kept (vgx_reg_batch_choose_outputs; 1 = take what the allocator gives)")
     ap.add_argument("--no-fo-plain", action="store_true",
