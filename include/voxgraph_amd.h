@@ -295,6 +295,17 @@ VGX_API int vgx_reg_batch_evaluate_points(vgx_reg_batch batch,
                                           void* d_residuals, void* d_jac_ref,
                                           void* d_jac_read, int32_t* status);
 
+/* The same pass into ONE output stream: an array of tile blocks, one block per rows_per_block (1024) consecutive residuals
+ * of a constraint -- block = [residual f32 x 1024][jac_ref f32x4 x 1024][jac_read f32x4 x 1024], 36 KiB, every constraint
+ * padded to whole blocks (its last block's unused rows are not written).  Residual k of constraint c is row k % 1024 of
+ * block first_block[c] + k / 1024.  For consumers that live on the device and do not need three Ceres-shaped arrays: one
+ * write front instead of three (profiles/r05_points_placement.txt says what three cost on an unlucky placement).
+ * vgx_reg_batch_blocked_layout: bytes = size of the array; first_block (nullable) = [n + 1]. */
+VGX_API int vgx_reg_batch_blocked_layout(vgx_reg_batch batch, int64_t* bytes, int32_t* rows_per_block,
+                                         int64_t* first_block);
+VGX_API int vgx_reg_batch_evaluate_points_blocked(vgx_reg_batch batch, const double* poses, int32_t n_nodes,
+                                                  void* d_blocks, int32_t* status);
+
 /* Placement by measurement.  WHERE the output arrays of the materialising pass lie in physical memory decides which of
  * two speeds the kernel runs at -- 200 x 256^3 submaps, 1176 constraints: 4.4-4.7 ms or 5.3-5.7 ms per launch; about half
  * of the sets of three an allocator hands out are slow ones, a matter of how the arrays lie relative to each other: every

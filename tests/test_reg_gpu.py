@@ -350,6 +350,45 @@ def test_choose_outputs_times_candidates_and_leaves_valid_rows(capi, ctx, small_
     batch.destroy()
 
 
+def test_blocked_output_layout_holds_the_same_rows(capi, ctx, small_graph):
+    """vgx_reg_batch_evaluate_points_blocked: ONE array of 36 KiB tile blocks ([r x 1024][jac_ref x 1024][jac_read x 1024],
+    every constraint padded to whole blocks) instead of three arrays -- the same kernel, so the same values bit for bit;
+    rows of a constraint's last block beyond its residuals are not written"""
+    import torch
+    G = small_graph
+    batch = capi.RegistrationBatch(ctx, G["cfs"], G["pairs"])
+    R = batch.num_residuals()
+    ro = batch.row_offsets()
+    nbytes, rows, first = batch.blocked_layout()
+    assert rows == 1024 and nbytes == int(first[-1]) * rows * 36
+    assert all(first[c + 1] - first[c] == -(-(ro[c + 1] - ro[c]) // rows) for c in range(len(G["pairs"])))
+    r, jo, je = _torch_buf(R, torch.float32), _torch_buf(4 * R, torch.float32), _torch_buf(4 * R, torch.float32)
+    blocks = torch.full((nbytes // 4,), float("nan"), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    st0 = batch.evaluate_points(G["poses"], r.data_ptr(), jo.data_ptr(), je.data_ptr())
+    st1 = batch.evaluate_points_blocked(G["poses"], blocks.data_ptr())
+    ctx.synchronize()
+    assert np.array_equal(st0, st1)
+    r, jo, je = r.cpu().numpy(), jo.cpu().numpy().reshape(R, 4), je.cpu().numpy().reshape(R, 4)
+    B = blocks.cpu().numpy().reshape(-1, 9 * rows)
+    written = 0
+    for c in range(len(G["pairs"])):
+        n = int(ro[c + 1] - ro[c])
+        for k0 in range(0, n, rows):
+            blk = B[int(first[c]) + k0 // rows]
+            m = min(rows, n - k0)
+            s = slice(int(ro[c]) + k0, int(ro[c]) + k0 + m)
+            assert np.array_equal(blk[:m].view(np.uint32), r[s].view(np.uint32))
+            assert np.array_equal(blk[rows:rows + 4 * rows].reshape(rows, 4)[:m].view(np.uint32), jo[s].view(np.uint32))
+            assert np.array_equal(blk[5 * rows:].reshape(rows, 4)[:m].view(np.uint32), je[s].view(np.uint32))
+            assert np.isnan(blk[m:rows]).all() and np.isnan(blk[rows:5 * rows].reshape(rows, 4)[m:]).all()   # padding untouched
+            written += m
+    assert written == R
+    with pytest.raises(Exception):
+        batch.evaluate_points_blocked(G["poses"], blocks.data_ptr() + 4)     # not 16-byte aligned
+    batch.destroy()
+
+
 def test_batch_normal_equations_and_assembly(capi, ctx, small_graph):
     import torch
     G = small_graph

@@ -132,6 +132,8 @@ SIGNATURES = {
     "vgx_reg_batch_num_residuals": (C.c_int64, [vp]),
     "vgx_reg_batch_row_offsets": (C.c_int, [vp, i64p]),
     "vgx_reg_batch_evaluate_points": (C.c_int, [vp, f64p, C.c_int32, vp, vp, vp, i32p]),
+    "vgx_reg_batch_blocked_layout": (C.c_int, [vp, C.POINTER(C.c_int64), i32p, C.POINTER(C.c_int64)]),
+    "vgx_reg_batch_evaluate_points_blocked": (C.c_int, [vp, f64p, C.c_int32, vp, i32p]),
     "vgx_reg_batch_choose_outputs": (C.c_int, [vp, f64p, C.c_int32, C.c_int32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
                                                C.c_int32, i32p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "vgx_reg_batch_evaluate_normal": (C.c_int, [vp, f64p, C.c_int32, vp, f64p, i32p]),
@@ -508,6 +510,21 @@ class RegistrationBatch:
             self.h, _ptr(poses, f64p), poses.shape[0], vp(d_residuals),
             vp(d_jac_ref) if d_jac_ref else None, vp(d_jac_read) if d_jac_read else None,
             _ptr(status, i32p)))
+        return status[:self.n]
+
+    def blocked_layout(self):
+        """vgx_reg_batch_blocked_layout -> (bytes, rows per block, first_block [n + 1])"""
+        nbytes, rows = C.c_int64(), C.c_int32()
+        first = np.zeros(self.n + 1, np.int64)
+        self.ctx.check(self.ctx.lib.vgx_reg_batch_blocked_layout(self.h, C.byref(nbytes), C.byref(rows),
+                                                                 first.ctypes.data_as(C.POINTER(C.c_int64))))
+        return int(nbytes.value), int(rows.value), first
+
+    def evaluate_points_blocked(self, poses, d_blocks):
+        poses = _f64(poses).reshape(-1, 4)
+        status = np.zeros(max(self.n, 1), np.int32)
+        self.ctx.check(self.ctx.lib.vgx_reg_batch_evaluate_points_blocked(self.h, _ptr(poses, f64p), poses.shape[0], vp(d_blocks),
+                                                                          _ptr(status, i32p)))
         return status[:self.n]
 
     def choose_outputs(self, poses, d_residuals, d_jac_ref, d_jac_read, launches=3):

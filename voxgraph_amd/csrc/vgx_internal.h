@@ -114,6 +114,7 @@ struct alignas(16) ConstraintDev {
   const float4* chunk_bounds; // bounding spheres of consecutive kChunkPoints-point chunks
   int64_t n;                // num_residuals
   int64_t row0;             // first output row (stacked outputs)
+  int64_t prow0;            // ... with every constraint padded to whole tiles: the blocked output layout (batch only)
   int32_t tile_points;      // batch: residuals per fused-pass tile of this constraint (all but its last tile)
   double factor;            // N / sum(w)                              (.cpp:274)
   double no_corr_cost;      // config.no_correspondence_cost

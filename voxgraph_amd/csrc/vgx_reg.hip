@@ -655,13 +655,27 @@ __global__ __launch_bounds__(kBlockThreads) void reg_eval_points_kernel(
     const ConstraintDev* __restrict__ cons, const PosePack* __restrict__ packs,
     const Tile* __restrict__ tiles, const unsigned char* __restrict__ tile_dead, int n_tiles,
     OUT* __restrict__ residuals, typename Out4<OUT>::type* __restrict__ jac_ref,
-    typename Out4<OUT>::type* __restrict__ jac_read) {
+    typename Out4<OUT>::type* __restrict__ jac_read, int blocked) {
   int t = swizzle_tile(blockIdx.x, n_tiles);
   if (t >= n_tiles) return;
   const Tile tile = tiles[t];
   const int dead = tile_dead[t];
-  reg_eval_points_body<VPS, LAYOUT, OUT, PPT, NT, NTL>(cons[tile.constraint], packs[tile.constraint], tile, dead,
-                                                       residuals, jac_ref, jac_read);
+  const ConstraintDev& C = cons[tile.constraint];
+  if (blocked) {
+    // ONE output stream (vgx_reg_batch_evaluate_points_blocked): `residuals` is the base of an array of tile blocks,
+    // block = [r x kTilePoints][jac_ref x kTilePoints][jac_read x kTilePoints], one per tile of every constraint padded to
+    // whole tiles.  The three pointers are re-based so that the body's [row0 + start + local] lands inside this tile's block.
+    using O4 = typename Out4<OUT>::type;
+    constexpr long long kBlockBytes = (long long)(PPT * kBlockThreads) * (long long)(sizeof(OUT) + 2 * sizeof(O4));
+    const long long first = C.row0 + tile.start;
+    char* blk = reinterpret_cast<char*>(residuals) + ((C.prow0 + tile.start) / (PPT * kBlockThreads)) * kBlockBytes;
+    OUT* r_t = reinterpret_cast<OUT*>(blk) - first;
+    O4* jr_t = reinterpret_cast<O4*>(blk + (long long)(PPT * kBlockThreads) * (long long)sizeof(OUT)) - first;
+    O4* je_t = reinterpret_cast<O4*>(blk + (long long)(PPT * kBlockThreads) * (long long)(sizeof(OUT) + sizeof(O4))) - first;
+    reg_eval_points_body<VPS, LAYOUT, OUT, PPT, NT, NTL>(C, packs[tile.constraint], tile, dead, r_t, jr_t, je_t);
+    return;
+  }
+  reg_eval_points_body<VPS, LAYOUT, OUT, PPT, NT, NTL>(C, packs[tile.constraint], tile, dead, residuals, jac_ref, jac_read);
 }
 
 // drop-in form (one constraint per Evaluate): descriptor and pose pack travel as kernel
@@ -1443,7 +1457,7 @@ static void apply_swizzle_env() {
 template <typename OUT>
 static void launch_points(vgx_ctx ctx, int vps, int layout, const ConstraintDev* d_desc, const PosePack* d_pack,
                           const Tile* d_tiles, unsigned char* d_tile_dead, int n_tiles, void* res, void* jr,
-                          void* je) {
+                          void* je, bool blocked = false) {
   if (n_tiles <= 0) return;
   apply_swizzle_env();
   hipLaunchKernelGGL(reg_points_tile_dead_kernel<kPointsPerThread>, dim3((n_tiles + 255) / 256), dim3(256), 0,
@@ -1460,7 +1474,7 @@ static void launch_points(vgx_ctx ctx, int vps, int layout, const ConstraintDev*
   }();
 #define VGX_LAUNCH_POINTS(VPS, LAYOUT, NT, NTL)                                                             \
   hipLaunchKernelGGL((reg_eval_points_kernel<VPS, LAYOUT, OUT, kPointsPerThread, NT, NTL>), grid, block, 0, \
-                     ctx->stream, d_desc, d_pack, d_tiles, d_tile_dead, n_tiles, (OUT*)res, (O4*)jr, (O4*)je)
+                     ctx->stream, d_desc, d_pack, d_tiles, d_tile_dead, n_tiles, (OUT*)res, (O4*)jr, (O4*)je, blocked ? 1 : 0)
   if (layout == 0) {  // apron bricks: the A/B switches of the non-temporal hints live here
     if (vps == 16) {
       if (nt && ntl) VGX_LAUNCH_POINTS(16, 0, true, true);
@@ -1537,6 +1551,7 @@ vgx::ConstraintDev vgx_reg_s::describe() const {
   c.chunk_bounds = ps.d_chunk_bounds;
   c.n = num_residuals;
   c.row0 = 0;
+  c.prow0 = 0;
   // RCF:274: num_residuals / summed_reference_weight; sampled points weigh 1
   if (cfg.sampling_ratio != -1.0f) {
     c.factor = 1.0;
@@ -1986,6 +2001,7 @@ int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs, const int3
       }
     }
     desc[(size_t)c].row0 = b->row_offset[(size_t)c];
+    desc[(size_t)c].prow0 = (int64_t)b->tiles.size() * kTilePoints;  // (the tiles so far are whole ones or a constraint's last)
     b->row_offset[(size_t)c + 1] = b->row_offset[(size_t)c] + regs[c]->num_residuals;
     std::vector<Tile> t = make_tiles(c, regs[c]->num_residuals, kTilePoints);
     points_tile_first[(size_t)c] = (int32_t)b->tiles.size();
@@ -2235,6 +2251,47 @@ int vgx_reg_batch_evaluate_points(vgx_reg_batch b, const double* poses, int32_t 
   }
   launch_points<float>(ctx, b->regs[0]->reading->vps, b->layout, b->d_desc, b->d_pack, b->d_tiles, b->d_tile_dead,
                        (int)b->tiles.size(), d_residuals, d_jac_ref, d_jac_read);
+  VGX_HIP(ctx, hipGetLastError());
+  return VGX_OK;
+}
+
+// The materialising pass into ONE array of tile blocks (include/voxgraph_amd.h): the same kernel, its three output pointers
+// re-based per tile.
+int vgx_reg_batch_blocked_layout(vgx_reg_batch b, int64_t* bytes, int32_t* rows_per_block, int64_t* first_block) {
+  if (!b) return VGX_ERR_INVALID;
+  if (bytes) *bytes = (int64_t)b->tiles.size() * kTilePoints * 36;
+  if (rows_per_block) *rows_per_block = kTilePoints;
+  if (first_block) {
+    int64_t blk = 0;
+    for (int c = 0; c < b->n; ++c) {
+      first_block[c] = blk;
+      blk += (b->regs[(size_t)c]->num_residuals + kTilePoints - 1) / kTilePoints;
+    }
+    first_block[b->n] = blk;
+  }
+  return VGX_OK;
+}
+
+int vgx_reg_batch_evaluate_points_blocked(vgx_reg_batch b, const double* poses, int32_t n_nodes, void* d_blocks,
+                                          int32_t* status) {
+  if (!b || !poses) return VGX_ERR_INVALID;
+  vgx_ctx ctx = b->ctx;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!d_blocks) return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_batch_evaluate_points_blocked: blocks == NULL");
+  if (((uintptr_t)d_blocks & 15u) != 0)
+    return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_batch_evaluate_points_blocked: blocks must be 16-byte aligned");
+  VGX_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = batch_begin(b);
+  if (rc == VGX_OK) rc = batch_upload_packs(b, poses, n_nodes, status);
+  if (rc != VGX_OK) return rc;
+  if (b->n == 0) return VGX_OK;
+  if (!b->points_order_made && !b->tiles.empty()) {
+    rc = apply_launch_order(b, b->tiles, b->d_tiles, b->host_points_tile_first, /*points_pass=*/true);
+    if (rc != VGX_OK) return rc;
+    b->points_order_made = true;
+  }
+  launch_points<float>(ctx, b->regs[0]->reading->vps, b->layout, b->d_desc, b->d_pack, b->d_tiles, b->d_tile_dead,
+                       (int)b->tiles.size(), d_blocks, d_blocks, d_blocks, /*blocked=*/true);
   VGX_HIP(ctx, hipGetLastError());
   return VGX_OK;
 }
