@@ -362,11 +362,15 @@ def main():
     torch.cuda.synchronize()
     placement = {"candidates": n_cand, "chosen": [0, 0, 0], "ms_chosen": None, "ms_trials": None}
     if n_cand > 1 and R > 0:
-        chosen, ms_chosen, ms_trials = batch.choose_outputs(poses, [c_[0].data_ptr() for c_ in cand], [c_[1].data_ptr() for c_ in cand],
-                                                            [c_[2].data_ptr() for c_ in cand], launches=3)
-        placement.update(chosen=chosen, ms_chosen=ms_chosen, ms_trials=ms_trials, ms_sets=ms_trials[:n_cand],
-                         what="vgx_reg_batch_choose_outputs: sets first, then jac_read / jac_ref / residuals array by array "
-                              "(-1: no new trial needed); ms per launch, 3 launches per trial")
+        try:
+            chosen, ms_chosen, ms_trials = batch.choose_outputs(poses, [c_[0].data_ptr() for c_ in cand], [c_[1].data_ptr() for c_ in cand],
+                                                                [c_[2].data_ptr() for c_ in cand], launches=3)
+            placement.update(chosen=chosen, ms_chosen=ms_chosen, ms_trials=ms_trials, ms_sets=ms_trials[:n_cand],
+                             what="vgx_reg_batch_choose_outputs: sets first, then jac_read / jac_ref / residuals array by array "
+                                  "(-1: no new trial needed); ms per launch, 3 launches per trial")
+        except Exception as e:   # noqa: BLE001  (the selection is an optimisation: without it the first set is used, and the line says so)
+            placement.update(candidates=1, error=repr(e)[:300])
+            print(f"bench.py: placement selection failed, using the first allocation: {e!r}", file=sys.stderr)
     residuals, jac_ref, jac_read = cand[placement["chosen"][0]][0], cand[placement["chosen"][1]][1], cand[placement["chosen"][2]][2]
     del cand
     torch.cuda.empty_cache()
