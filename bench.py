@@ -477,6 +477,24 @@ def main():
     mix_ms = capi.stream_ceiling_ms(ctx, jac_ref.data_ptr(), rd, jac_read.data_ptr(), n16, 3)
     ceil_after["kernel_shaped_GBs"] = (rd + n16) / (mix_ms * 1e-3) / 1e9
     ceil_after["kernel_shaped_read_fraction"] = rd / max(rd + n16, 1)
+    # the placement-proof entry point on the same workload, same run: ONE array of tile blocks (one write front,
+    # vgx_reg_batch_evaluate_points_blocked) -- what a device-resident consumer gets without choosing anything
+    blocked_ms = None
+    if R > 0:
+        try:
+            nbytes_blk, _rows, _first = batch.blocked_layout()
+            blocks = torch.empty(nbytes_blk // 4, dtype=torch.float32, device="cuda")
+            for _ in range(2):
+                batch.evaluate_points_blocked(poses, blocks.data_ptr())
+            torch.cuda.synchronize()
+            ctx.timer_start()
+            for _ in range(10):
+                batch.evaluate_points_blocked(poses, blocks.data_ptr())
+            blocked_ms = ctx.timer_stop() / 10
+            del blocks
+            torch.cuda.empty_cache()
+        except Exception as e:   # noqa: BLE001
+            print(f"bench.py: blocked-layout timing skipped: {e!r}", file=sys.stderr)
 
     # ---- full-overlap workload, timed the same way (HIP events on the kernel's stream) ----
     fo_out = None
@@ -613,6 +631,21 @@ def main():
             assembler.destroy()
         if world == 1 and ref_cost is not None:
             out["cost_vs_materialised"] = abs(out["cost"] - ref_cost) / max(ref_cost, 1e-30)
+        # the cost-only pass (vgx_reg_batch_evaluate_cost): what Ceres asks for at every trial step (`jacobians == nullptr`,
+        # registration_cost_function.cpp:179) -- the same tiles, one running sum per lane; its costs must be the full
+        # pass's costs bit for bit
+        d_cost = torch.zeros(max(bt.n, 1), dtype=torch.float64, device="cuda")
+        for _ in range(2):
+            bt.evaluate_cost(ps, d_cost=d_cost.data_ptr(), to_host=False)
+        torch.cuda.synchronize()
+        ctx.timer_start()
+        for _ in range(n_f):
+            bt.evaluate_cost(ps, d_cost=d_cost.data_ptr(), to_host=False)
+        out["cost_only_ms"] = ctx.timer_stop() / n_f
+        _, normal = bt.evaluate_normal(ps)
+        out["cost_only_equals_full_pass_cost"] = bool(np.array_equal(d_cost.cpu().numpy()[:bt.n].view(np.uint64),
+                                                                     normal[:, 0].copy().view(np.uint64)))
+        out["cost_only_kernels"] = "reg_eval_reduce_lean_kernel<cost only> + reg_finalize_cost_kernel"
         return out
 
     fused = None
@@ -891,6 +924,19 @@ def main():
                          "kernel": "reg_eval_points_kernel<16,float,4>",
                          "output_placement": placement,
                          "placement_ms_sets": placement.get("ms_sets"),
+                         # What a caller gets WITHOUT choosing: `frac` above is the kernel on the arrays
+                         # vgx_reg_batch_choose_outputs picked among the candidates; the same bytes over the FIRST
+                         # candidate set's time (what the allocator hands out), over the MEDIAN set's, and over the
+                         # placement-proof blocked entry point's (one write front, nothing to choose), all same run
+                         "frac_first_allocation": (bytes_conservative / (placement["ms_sets"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                         if placement.get("ms_sets") else achieved / HBM_PEAK_GBS,
+                         "frac_median_allocation": (bytes_conservative / (float(np.median(placement["ms_sets"])) * 1e-3) / 1e9
+                                                    / HBM_PEAK_GBS) if placement.get("ms_sets") else achieved / HBM_PEAK_GBS,
+                         "frac_blocked_layout": (bytes_conservative / (blocked_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if blocked_ms else None,
+                         "blocked_layout_ms": blocked_ms,
+                         "frac_note": "frac: arrays selected among the candidates; frac_first / frac_median_allocation: the "
+                                      "first / median candidate set (3-launch trials of the selection); frac_blocked_layout: "
+                                      "vgx_reg_batch_evaluate_points_blocked, placement-proof",
                          "kernel_ms": kernel_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
                          "bytes_per_unit": BYTES_PER_EVAL, "bytes_per_unit_without_correspondence": BYTES_NO_CORR,
                          "bytes_per_unit_culled": BYTES_OUT,

@@ -67,7 +67,8 @@ def compact(full, detail_path):
                                  "contract_88B_frac", "copy_ceiling_GBs", "fill_ceiling_GBs", "kernel_shaped_ceiling_GBs",
                                  "frac_of_copy_ceiling", "traffic_frac_of_copy_ceiling", "frac_of_kernel_shaped_ceiling",
                                  "kernel", "kernel_ms", "units_per_launch", "bytes_per_launch", "with_correspondence_frac",
-                                 "placement_ms_sets"))
+                                 "placement_ms_sets", "frac_first_allocation", "frac_median_allocation", "frac_blocked_layout",
+                                 "blocked_layout_ms"))
     bx = d.get("box") or {}
     sy = (bx.get("before") or {}).get("sysfs") or {}
     du = bx.get("during_timed_region") or {}
@@ -97,14 +98,16 @@ def compact(full, detail_path):
         out[k] = d.get(k)
     f = d.get("fused")
     out["fused"] = _pick(f, ("value", "ms_per_step", "stream_ms_per_step", "hbm_frac", "algorithmic_GBs",
-                             "cost_vs_materialised", "allreduce_bytes")) if f else None
+                             "cost_vs_materialised", "allreduce_bytes", "cost_only_ms",
+                             "cost_only_equals_full_pass_cost")) if f else None
     fo = d.get("roofline_full_overlap")
     if fo:
         o = _pick(fo, ("kernel_ms", "frac", "hbm_frac", "value", "with_correspondence_frac"))
         if fo.get("plain_order"):
             o["plain_order"] = _pick(fo["plain_order"], ("kernel_ms", "frac", "hbm_frac"))
         if fo.get("fused"):
-            o["fused"] = _pick(fo["fused"], ("ms_per_step", "stream_ms_per_step", "hbm_frac", "cost_vs_materialised"))
+            o["fused"] = _pick(fo["fused"], ("ms_per_step", "stream_ms_per_step", "hbm_frac", "cost_vs_materialised",
+                                             "cost_only_ms", "cost_only_equals_full_pass_cost"))
         out["roofline_full_overlap"] = o
     sh = d.get("shipped_config")
     if sh:

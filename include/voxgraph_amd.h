@@ -316,7 +316,11 @@ VGX_API int vgx_reg_batch_evaluate_points_blocked(vgx_reg_batch batch, const dou
  * best combination so far, and returns in chosen[] the index to keep for residuals, jac_ref and jac_read.  ms_chosen
  * (nullable): ms per launch of that combination.  ms_trials (nullable, [n_candidates * 4]): every trial in order -- the n
  * sets, then jac_read's, jac_ref's and the residuals' candidates (-1 where a candidate needed no new trial).  The arrays
- * are overwritten.  Synchronous.  4 candidates and 3 launches cost 13 trials of 4 launches. */
+ * are overwritten.  Synchronous.  4 candidates and 3 launches cost 13 trials of 4 launches.
+ * REFUSED (VGX_ERR_INVALID) for a batch with sampling constraints: every trial is launches + 1 evaluations of the batch,
+ * and an evaluation of a sampling batch DRAWS -- it would leave every reference point set's std::mt19937 dozens of
+ * evaluations further on and break "one evaluation of the batch = one Evaluate of every constraint in list order".  Where
+ * the arrays lie does not depend on which points are drawn: choose with an all-points batch of the same sizes. */
 VGX_API int vgx_reg_batch_choose_outputs(vgx_reg_batch batch, const double* poses, int32_t n_nodes,
                                          int32_t n_candidates, void* const* d_residuals, void* const* d_jac_ref,
                                          void* const* d_jac_read, int32_t launches, int32_t chosen[3],
@@ -333,6 +337,23 @@ VGX_API int vgx_reg_batch_evaluate_normal(vgx_reg_batch batch,
                                           const double* poses, int32_t n_nodes,
                                           void* d_normal, double* normal_host,
                                           int32_t* status);
+
+/* Fused pass, COST ONLY: per constraint c one f64, sum r^2 -- element [0] of vgx_reg_batch_evaluate_normal's block at the
+ * same poses, BIT FOR BIT (the same f32 operations in the same order, the same reduction tree; all-points batches -- a
+ * sampling batch draws anew, see below).  The reference does no Jacobian work when Ceres passes `jacobians == nullptr`
+ * (registration_cost_function.cpp:179), and Ceres' Levenberg-Marquardt evaluates every TRIAL step that way
+ * (pose_graph.cpp:90-101): this is that evaluation for the whole constraint list -- no gradient, no pose-Jacobian
+ * products, one running sum per lane instead of 21, nothing to compress afterwards.
+ * d_cost: DEVICE pointer [n] f64 (nullable); cost_host: host [n] (nullable; implies a stream synchronisation).
+ * Deterministic.
+ * SAMPLING constraints (sampling_ratio != -1): EVERY evaluation of a batch -- points, normal or cost -- is one Evaluate of
+ * every constraint in list order and DRAWS its points from the reference point sets' engines, as every call of the
+ * reference's Evaluate does (registration_cost_function.cpp:113-122): a cost-only evaluation followed by a full one at the
+ * same poses sees two different draws, exactly like Ceres on the reference.  A caller that serves a second request at
+ * an unchanged point from what it cached (the C++ adapters, when Ceres says new_evaluation_point == false and what it
+ * asks for is cached) does NOT redraw where the reference would: fewer draws, each still a legal one. */
+VGX_API int vgx_reg_batch_evaluate_cost(vgx_reg_batch batch, const double* poses, int32_t n_nodes, void* d_cost,
+                                        double* cost_host, int32_t* status);
 
 /* Measurement aid for the fused pass: the number of residuals whose registration points the
  * fused kernel actually reads at these poses, i.e. the points of every 512-point chunk whose
@@ -449,6 +470,10 @@ VGX_API int vgx_reg_multi_evaluate_fused(vgx_reg_multi multi, const double* pose
  * [n][45] normal blocks in the caller's constraint order; needs no reduction at all. */
 VGX_API int vgx_reg_multi_evaluate_normal(vgx_reg_multi multi, const double* poses, int32_t n_nodes,
                                           double* normal_host /* [n][45] */, int32_t* status);
+/* ... and its cost-only form (vgx_reg_batch_evaluate_cost on every context's share): cost_host[c] = element [0] of the
+ * block above, bit for bit, in the caller's constraint order. */
+VGX_API int vgx_reg_multi_evaluate_cost(vgx_reg_multi multi, const double* poses, int32_t n_nodes,
+                                        double* cost_host /* [n] */, int32_t* status);
 
 /* ---- overlap detection (callers' side of REG) -------------------------- */
 /* VoxgraphSubmap::getSubmapFrameSurfaceObb (voxgraph_submap.cpp:280-321): box around the

@@ -1,8 +1,10 @@
 /*
- * voxgraph_amd_bench.h -- benchmark / test tooling exported by libvoxgraph_amd.so that is NOT part
- * of the drop-in boundary (include/voxgraph_amd.h): synthetic scenes generated on the device so that
- * bench.py and the tests can fill 200 submaps of 256^3 voxels without a host round trip.  Nothing in
- * the reference corresponds to these entry points and an integration never calls them.
+ * voxgraph_amd_bench.h -- benchmark / test tooling, exported by libvoxgraph_amd_bench.so (csrc/bench/; it links
+ * the product library libvoxgraph_amd.so, which carries none of this): synthetic scenes generated on the device so that
+ * bench.py and the tests can fill 200 submaps of 256^3 voxels without a host round trip, memory and atomic ceilings for
+ * the rooflines, and the TSDF integrator's diagnostics -- among them the racing kernel's EVENT LOG, which
+ * tests/test_tsdf_replay_gpu.py replays through the oracle.  Nothing in the reference corresponds to these entry
+ * points and an integration never calls them.
  */
 #ifndef VOXGRAPH_AMD_BENCH_H_
 #define VOXGRAPH_AMD_BENCH_H_
@@ -80,6 +82,33 @@ VGX_API int vgx_tsdf_integrator_read_trace(vgx_tsdf_integrator integrator, int64
  * further attempt.  Defaults 32 and 8 Mi.  The integrated layer does NOT depend on either value -- the tests use
  * small ones so that small scans exercise the extension logic (tests/test_tsdf_deterministic_gpu.py). */
 VGX_API int vgx_tsdf_integrator_set_speculation(vgx_tsdf_integrator integrator, int32_t depth, int64_t threshold);
+
+/* ---- the racing TSDF kernel's event log ----------------------------------------------------------------------------
+ * After vgx_tsdf_integrator_set_event_trace(integrator, capacity_words > 0) every racing scan of the integrator runs the
+ * logging instantiation of the shipped kernel (the same template, csrc/vgx_tsdf_coop_kernel.h: same decisions, other
+ * timing) and appends events to a log of capacity_words 64-bit words; 0 restores the shipped launcher and frees the log.
+ * An event is a run of words, the kind in the low byte of the first:
+ *   1  start-set exchange   {1, point, value written, value returned}
+ *   2  start-set skip       {2, point, value, the point of the lane to the left}   (same value as the left neighbour:
+ *                            no exchange -- it would have found its own value)
+ *   3  a cast ray           {3 | bad << 8, point, voxels its walk visits, 0}       (bad: NaN ray ends, never walked)
+ *   4  observed-set exchange {4 | step << 8, point, value written, value returned}  (step: 0 = the walk's first voxel)
+ *   5  a per-voxel fold     {5 | n << 8 | flags << 40, voxel key, word folded over, word published, colour folded over |
+ *                            colour left << 32, voxel's index in the pool, then n records: point | step << 32, in the
+ *                            order updateTsdfVoxel was applied}      voxel key: 21 bits per axis biased by 2^20, x highest;
+ *                            word: distance bits | weight bits << 32; flags: 1 published (a compare-and-swap from the
+ *                            one word to the other succeeded; else every record left the voxel alone and the two words
+ *                            are equal), 2 the colour was written (compare-and-swap likewise), 4 some record blended
+ * Peeks (plain loads that only choose which exchanges to issue) are not events. */
+VGX_API int vgx_tsdf_integrator_set_event_trace(vgx_tsdf_integrator integrator, int64_t capacity_words);
+/* Copies the log out (header stripped) and empties it.  *lost: events that did not fit.  A log longer than max_words:
+ * VGX_ERR_INVALID with *n_words = what is needed, nothing emptied. */
+VGX_API int vgx_tsdf_integrator_read_event_trace(vgx_tsdf_integrator integrator, uint64_t* words, int64_t max_words,
+                                                 int64_t* n_words, int64_t* lost);
+/* The two approximate sets as they are now (2^20 words each; either may be NULL); state[0], [1]: the offsets the last
+ * scan's values carried, state[2]: scans since the sets were last reset (clear_checks_every_n_frames). */
+VGX_API int vgx_tsdf_integrator_download_sets(vgx_tsdf_integrator integrator, uint64_t* start_set, uint64_t* observed_set,
+                                              int64_t state[3]);
 
 #ifdef __cplusplus
 }

@@ -286,6 +286,26 @@ class TsdfConfig(C.Structure):
                 ("enable_anti_grazing", C.c_int)]
 
 
+class ReplayLayer(C.Structure):
+    """orc_replay_layer (oracle/tsdf_replay.h): the arrays of a layer download"""
+    _fields_ = [("n_blocks", C.c_int32), ("block_index", c_i32p), ("distance", c_f32p), ("weight", c_f32p), ("rgba", c_u8p)]
+
+
+class ReplayReport(C.Structure):
+    """orc_replay_report (oracle/tsdf_replay.h)"""
+    _names = ("points", "valid_points", "start_exchanges", "start_skips", "rays_cast", "rays_bad", "observed_exchanges",
+              "overrun_exchanges", "rays_with_overrun", "max_overrun", "rays_stopped_early", "rays_walked_to_end",
+              "required_updates", "fold_events", "folds_published", "folds_left_alone", "fold_records", "longest_fold",
+              "colour_writes", "start_slots_touched", "observed_slots_touched", "voxels_touched", "voxels_with_several_links",
+              "new_blocks", "errors")
+    _fields_ = [(k, C.c_int64) for k in _names] + [("first_error", C.c_char * 400)]
+
+    def as_dict(self):
+        d = {k: int(getattr(self, k)) for k in self._names}
+        d["first_error"] = self.first_error.decode(errors="replace")
+        return d
+
+
 _tsdf_bound = False
 
 
@@ -310,6 +330,18 @@ def _tsdf_lib():
         L.orc_tsdf_merged_integrate.restype = C.c_int64
         L.orc_tsdf_integrate_sequence.argtypes = [C.c_void_p, C.c_int, c_f32p, c_f32p, C.c_int64, C.c_int]
         L.orc_tsdf_integrate_sequence.restype = C.c_int64
+        c_u64p = C.POINTER(C.c_uint64)
+        L.orc_tsdf_integrator_set_log.argtypes = [C.c_void_p, c_u64p, C.c_int64]
+        L.orc_tsdf_integrator_set_log.restype = None
+        L.orc_tsdf_integrator_log_words.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        L.orc_tsdf_integrator_log_words.restype = C.c_int64
+        L.orc_tsdf_integrator_download_sets.argtypes = [C.c_void_p, c_u64p, c_u64p, c_u64p]
+        L.orc_tsdf_integrator_download_sets.restype = None
+        L.orc_tsdf_replay_check.argtypes = [C.POINTER(TsdfConfig), C.c_float, C.c_int, c_f32p, c_f32p, c_u8p, C.c_int64, C.c_int,
+                                            C.c_uint64, C.c_uint64, c_u64p, c_u64p, c_u64p, c_u64p,
+                                            C.POINTER(ReplayLayer), C.POINTER(ReplayLayer), c_u64p, C.c_int64,
+                                            C.POINTER(ReplayReport)]
+        L.orc_tsdf_replay_check.restype = C.c_int64
         _tsdf_bound = True
     return L
 
@@ -375,6 +407,26 @@ class FastTsdfIntegrator:
         col = None if colors is None else np.ascontiguousarray(colors, np.uint8).reshape(-1, 4)
         return _tsdf_lib().orc_tsdf_integrate(self.h, _p(T, c_f32p), _p(pts, c_f32p),
                                               _p(col, c_u8p), pts.shape[0], int(freespace_points))
+
+    def set_log(self, capacity_words):
+        """scans from now on append their events (the racing kernel's log format) to a buffer of that many words; 0: off"""
+        self._log = np.zeros(int(capacity_words), np.uint64) if capacity_words else None
+        _tsdf_lib().orc_tsdf_integrator_set_log(self.h, _p(self._log, C.POINTER(C.c_uint64)), int(capacity_words))
+
+    def read_log(self):
+        """-> (the words logged since set_log / the last read_log, events lost); empties the log"""
+        lost = C.c_int64()
+        n = _tsdf_lib().orc_tsdf_integrator_log_words(self.h, C.byref(lost))
+        out = self._log[:n].copy()
+        _tsdf_lib().orc_tsdf_integrator_set_log(self.h, _p(self._log, C.POINTER(C.c_uint64)), len(self._log))
+        return out, int(lost.value)
+
+    def download_sets(self):
+        """-> (start set, observed set: uint64[2^20] each, (start offset, observed offset))"""
+        a, b, o = np.zeros(1 << 20, np.uint64), np.zeros(1 << 20, np.uint64), np.zeros(2, np.uint64)
+        u = C.POINTER(C.c_uint64)
+        _tsdf_lib().orc_tsdf_integrator_download_sets(self.h, _p(a, u), _p(b, u), _p(o, u))
+        return a, b, (int(o[0]), int(o[1]))
 
     def integrate_sequence(self, poses, clouds, repeats=1):
         """`repeats` passes over the scans (poses [k][7], clouds [k][n][3]) inside ONE foreign call (no
@@ -459,3 +511,33 @@ def isosurface_points(voxel_size, vps, block_index, tsdf_distance, tsdf_weight, 
     xyz, d, w = np.zeros((n, 3), np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
     L.orc_isosurface_points(*args, _p(xyz, c_f32p), _p(d, c_f32p), _p(w, c_f32p))
     return xyz, d, w
+
+
+def tsdf_replay_check(config, voxel_size, vps, T_G_C, points_C, colors, freespace_points, offsets, sets_pre, sets_post,
+                      layer_pre, layer_post, trace):
+    """oracle/tsdf_replay.h: is `trace` (one racing scan's event log) a legal interleaving of the sequential integrator's
+    steps?  offsets = (start, observed) offsets of the scan's values; sets_* = (start set, observed set); layer_* = the
+    four arrays of a layer download.  Returns the report as a dict (errors == 0: legal)."""
+    u64p = C.POINTER(C.c_uint64)
+    T = _f32(T_G_C)
+    pts = _f32(points_C).reshape(-1, 3)
+    col = None if colors is None else np.ascontiguousarray(colors, np.uint8).reshape(-1, 4)
+    keep = []
+
+    def layer(arrs):
+        bi, d, w, c = arrs
+        bi = np.ascontiguousarray(bi, np.int32).reshape(-1, 3)
+        d, w = _f32(d), _f32(w)
+        c = np.ascontiguousarray(c, np.uint8)
+        keep.extend((bi, d, w, c))
+        return ReplayLayer(len(bi), _p(bi, c_i32p), _p(d, c_f32p), _p(w, c_f32p), _p(c, c_u8p))
+
+    pre, post = layer(layer_pre), layer(layer_post)
+    sets = [np.ascontiguousarray(x, np.uint64) for x in (*sets_pre, *sets_post)]
+    tr = np.ascontiguousarray(trace, np.uint64)
+    rep = ReplayReport()
+    _tsdf_lib().orc_tsdf_replay_check(C.byref(config), float(np.float32(voxel_size)), int(vps), _p(T, c_f32p), _p(pts, c_f32p),
+                                      _p(col, c_u8p), pts.shape[0], int(freespace_points), int(offsets[0]), int(offsets[1]),
+                                      _p(sets[0], u64p), _p(sets[2], u64p), _p(sets[1], u64p), _p(sets[3], u64p),
+                                      C.byref(pre), C.byref(post), _p(tr, u64p), len(tr), C.byref(rep))
+    return rep.as_dict()

@@ -9,21 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-static const float kCoordinateEpsilon = 1e-6f; /* voxblox::kCoordinateEpsilon */
-
-/* getGridIndexFromPoint's static_cast<IndexElement>(std::floor(x)) [recalled].  The reference's cast is undefined
- * for NaN and beyond the integer range; here -- and in the product, csrc/vgx_tsdf_internal.h grid_index -- it is
- * DEFINED: NaN -> 0, saturating at the 32-bit limits (a point 2^31 voxels away is a driver's "no return" code, not
- * a measurement; NaN points pass isPointValid in the reference too).  Everything within +-2^31 voxels: the cast. */
-static int64_t grid_index(float x) {
-  x = floorf(x);
-  if (!(x == x)) return 0;
-  if (x >= 2147483648.0f) return 2147483647;
-  if (x < -2147483648.0f) return -2147483647 - 1;
-  return (int64_t)x;
-}
-static const float kFloatEpsilon = 1e-6f;      /* voxblox::kFloatEpsilon */
-static const float kEpsilon = 1e-6f;           /* voxblox::kEpsilon */
+#include "tsdf_oracle_impl.h" /* the per-point / per-voxel steps, shared with the replay checker (tsdf_replay.c) */
 
 void orc_tsdf_config_default(orc_tsdf_config* c) {
   c->default_truncation_distance = 0.1f;
@@ -166,13 +152,17 @@ static void approx_set_reset(approx_set* s) {
   }
 }
 
-/* LongIndexHash: static_cast<unsigned int>(x + y*17191 + z*17191^2) on int64 */
-static uint64_t long_index_hash(const int64_t idx[3]) {
-  int64_t v = idx[0] + idx[1] * 17191 + idx[2] * (int64_t)(17191 * 17191);
-  return (uint64_t)(uint32_t)v;
+/* replaceHash: true if the slot did NOT already hold this hash */
+static int approx_set_exchange(approx_set* s, const int64_t idx[3], uint64_t* value, uint64_t* returned) {
+  uint64_t v = long_index_hash(idx) + s->offset;
+  uint64_t* slot = &s->slots[v & ORC_SET_MASK];
+  uint64_t old = *slot;
+  *slot = v;
+  *value = v;
+  *returned = old;
+  return old != v;
 }
 
-/* replaceHash: true if the slot did NOT already hold this hash */
 static int approx_set_replace(approx_set* s, const int64_t idx[3]) {
   uint64_t v = long_index_hash(idx) + s->offset;
   uint64_t* slot = &s->slots[v & ORC_SET_MASK];
@@ -181,11 +171,16 @@ static int approx_set_replace(approx_set* s, const int64_t idx[3]) {
   return old != v;
 }
 
+static uint64_t pack_voxel_key(const int64_t v[3], int clearing);
+
 /* ---- integrator ----------------------------------------------------------- */
 struct orc_tsdf_integrator {
   orc_tsdf_config cfg;
   orc_tsdf_layer* layer;
   approx_set start_set, observed_set;
+  /* optional event log of the scans to come, in the racing kernel's format (tsdf_replay.h; orc_tsdf_integrator_set_log) */
+  uint64_t* log;
+  int64_t log_cap, log_n, log_lost;
   int64_t reset_counter; /* function-static in voxblox */
 };
 
@@ -207,69 +202,6 @@ void orc_tsdf_integrator_destroy(orc_tsdf_integrator* I) {
 
 void orc_tsdf_integrator_set_layer(orc_tsdf_integrator* I, orc_tsdf_layer* layer) {
   I->layer = layer;
-}
-
-/* Eigen _transformVector + translation (kindr::minimal transform) */
-static void transform_point(const float T[7], const float v[3], float out[3]) {
-  float w = T[0], x = T[1], y = T[2], z = T[3];
-  float uv[3] = {y * v[2] - z * v[1], z * v[0] - x * v[2], x * v[1] - y * v[0]};
-  uv[0] += uv[0];
-  uv[1] += uv[1];
-  uv[2] += uv[2];
-  float c[3] = {y * uv[2] - z * uv[1], z * uv[0] - x * uv[2], x * uv[1] - y * uv[0]};
-  out[0] = (v[0] + w * uv[0] + c[0]) + T[4];
-  out[1] = (v[1] + w * uv[1] + c[1]) + T[5];
-  out[2] = (v[2] + w * uv[2] + c[2]) + T[6];
-}
-
-static float norm3(const float v[3]) { return sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
-
-static int signum(float x) { return (x > 0.0f) - (x < 0.0f); }
-
-/* updateTsdfVoxel + computeDistance + blendTwoColors */
-static void update_voxel(orc_tsdf_integrator* I, const float origin[3], const float point_G[3],
-                         const int64_t gidx[3], const uint8_t color[4], float weight,
-                         float* v_dist, float* v_weight, uint8_t* v_rgba) {
-  const orc_tsdf_config* c = &I->cfg;
-  const float vs = I->layer->voxel_size;
-  float voxel_center[3], v_voxel_origin[3], v_point_origin[3];
-  for (int a = 0; a < 3; ++a) {
-    /* getCenterPointFromGridIndex: (idx + 0.5) * grid_size, double product -> f32 */
-    voxel_center[a] = (float)(((double)(float)gidx[a] + 0.5) * (double)vs);
-    v_voxel_origin[a] = voxel_center[a] - origin[a];
-    v_point_origin[a] = point_G[a] - origin[a];
-  }
-  float dist_G = norm3(v_point_origin);
-  float dot = v_voxel_origin[0] * v_point_origin[0] + v_voxel_origin[1] * v_point_origin[1] +
-              v_voxel_origin[2] * v_point_origin[2];
-  float dist_G_V = dot / dist_G;
-  float sdf = dist_G - dist_G_V;
-
-  float updated_weight = weight;
-  const float dropoff_epsilon = vs;
-  if (c->use_weight_dropoff && sdf < -dropoff_epsilon) {
-    updated_weight = weight * (c->default_truncation_distance + sdf) /
-                     (c->default_truncation_distance - dropoff_epsilon);
-    updated_weight = fmaxf(updated_weight, 0.0f);
-  }
-  if (c->use_sparsity_compensation_factor) {
-    if (fabsf(sdf) < c->default_truncation_distance)
-      updated_weight *= c->sparsity_compensation_factor;
-  }
-  const float new_weight = *v_weight + updated_weight;
-  if (new_weight < kFloatEpsilon) return;
-  const float new_sdf = (sdf * updated_weight + *v_dist * *v_weight) / new_weight;
-  if (fabsf(sdf) < c->default_truncation_distance) {
-    float first_weight = *v_weight, second_weight = updated_weight;
-    float total = first_weight + second_weight;
-    first_weight /= total;
-    second_weight /= total;
-    for (int k = 0; k < 4; ++k)
-      v_rgba[k] = (uint8_t)roundf((float)v_rgba[k] * first_weight + (float)color[k] * second_weight);
-  }
-  *v_dist = (new_sdf > 0.0f) ? fminf(c->default_truncation_distance, new_sdf)
-                             : fmaxf(-c->default_truncation_distance, new_sdf);
-  *v_weight = fminf(c->max_weight, new_weight);
 }
 
 /* ---- ThreadSafeIndex [recalled, voxblox utils/ thread-safe index]: the order points are visited in ------ */
@@ -317,6 +249,60 @@ static int64_t* visiting_order(int mode, const float* points_C, int64_t n) {
   return order;
 }
 
+/* ---- the single thread's own event log: the same events, in the same format, the racing kernel logs
+ * (include/voxgraph_amd_bench.h) -- every update its own one-record fold.  A sequential run is one legal interleaving, so
+ * tsdf_replay.c must accept it; tests/test_tsdf_replay_cpu.py checks that, and that it rejects the log once tampered with. */
+void orc_tsdf_integrator_set_log(orc_tsdf_integrator* I, uint64_t* buffer, int64_t capacity_words) {
+  I->log = buffer;
+  I->log_cap = buffer ? capacity_words : 0;
+  I->log_n = 0;
+  I->log_lost = 0;
+}
+
+int64_t orc_tsdf_integrator_log_words(const orc_tsdf_integrator* I, int64_t* lost) {
+  if (lost) *lost = I->log_lost;
+  return I->log_n;
+}
+
+void orc_tsdf_integrator_download_sets(const orc_tsdf_integrator* I, uint64_t* start_set, uint64_t* observed_set,
+                                       uint64_t offsets[2]) {
+  if (start_set) memcpy(start_set, I->start_set.slots, ORC_SET_SIZE * sizeof(uint64_t));
+  if (observed_set) memcpy(observed_set, I->observed_set.slots, ORC_SET_SIZE * sizeof(uint64_t));
+  if (offsets) {
+    offsets[0] = I->start_set.offset;
+    offsets[1] = I->observed_set.offset;
+  }
+}
+
+static uint64_t* log_reserve(orc_tsdf_integrator* I, int64_t words) {
+  if (!I->log) return NULL;
+  if (I->log_n + words > I->log_cap) {
+    ++I->log_lost;
+    return NULL;
+  }
+  uint64_t* w = I->log + I->log_n;
+  I->log_n += words;
+  return w;
+}
+
+static void log4(orc_tsdf_integrator* I, uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
+  uint64_t* w = log_reserve(I, 4);
+  if (w) {
+    w[0] = a; w[1] = b; w[2] = c; w[3] = d;
+  }
+}
+
+static uint64_t log_word(float d, float w) {
+  uint32_t a, b;
+  memcpy(&a, &d, 4);
+  memcpy(&b, &w, 4);
+  return (uint64_t)a | ((uint64_t)b << 32);
+}
+
+static uint32_t log_rgba(const uint8_t* c) {
+  return (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16) | ((uint32_t)c[3] << 24);
+}
+
 int64_t orc_tsdf_integrate(orc_tsdf_integrator* I, const float T_G_C[7], const float* points_C,
                            const uint8_t* rgba, int64_t n, int freespace_points) {
   const orc_tsdf_config* c = &I->cfg;
@@ -338,86 +324,40 @@ int64_t orc_tsdf_integrate(orc_tsdf_integrator* I, const float T_G_C[7], const f
     const int64_t pi = order[seq];
     const float* point_C = &points_C[3 * pi];
     const uint8_t* color = rgba ? &rgba[4 * pi] : zero_color;
-    /* isPointValid */
-    int is_clearing;
-    const float ray_distance = norm3(point_C);
-    if (ray_distance < c->min_ray_length_m) {
-      continue;
-    } else if (ray_distance > c->max_ray_length_m) {
-      if (c->allow_clear || freespace_points) is_clearing = 1; else continue;
-    } else {
-      is_clearing = freespace_points;
-    }
+    int is_clearing = 0;
+    if (!point_is_valid(c, point_C, freespace_points, &is_clearing)) continue;
     float point_G[3];
     transform_point(T_G_C, point_C, point_G);
     /* start-voxel dedup on a grid start_voxel_subsampling_factor times finer */
     int64_t gidx[3];
-    const float sub_inv = c->start_voxel_subsampling_factor * vsi;
-    for (int a = 0; a < 3; ++a) gidx[a] = grid_index(point_G[a] * sub_inv + kCoordinateEpsilon);
-    if (!approx_set_replace(&I->start_set, gidx)) continue;
-
-    /* RayCaster(origin, point_G, is_clearing, carving, max_ray, voxel_size_inv, trunc, false) */
-    float d[3] = {point_G[0] - origin[0], point_G[1] - origin[1], point_G[2] - origin[2]};
-    float len = norm3(d);
-    float unit_ray[3] = {d[0] / len, d[1] / len, d[2] / len};
-    float ray_start[3], ray_end[3];
-    const float trunc = c->default_truncation_distance;
-    if (is_clearing) {
-      float ray_length = fminf(fmaxf(len - trunc, 0.0f), c->max_ray_length_m);
-      for (int a = 0; a < 3; ++a) {
-        ray_end[a] = origin[a] + unit_ray[a] * ray_length;
-        ray_start[a] = c->voxel_carving_enabled ? origin[a] : ray_end[a];
-      }
+    start_cell(c, vsi, point_G, gidx);
+    if (!I->log) {
+      if (!approx_set_replace(&I->start_set, gidx)) continue;
     } else {
-      for (int a = 0; a < 3; ++a) {
-        ray_end[a] = point_G[a] + unit_ray[a] * trunc;
-        ray_start[a] = c->voxel_carving_enabled ? origin[a] : (point_G[a] - unit_ray[a] * trunc);
-      }
+      uint64_t value, returned;
+      const int is_new = approx_set_exchange(&I->start_set, gidx, &value, &returned);
+      log4(I, 1, (uint64_t)pi, value, returned);
+      if (!is_new) continue;
     }
-    /* cast_from_origin == false: setupRayCaster(end_scaled, start_scaled) */
-    float start_scaled[3], end_scaled[3];
-    for (int a = 0; a < 3; ++a) {
-      start_scaled[a] = ray_end[a] * vsi;
-      end_scaled[a] = ray_start[a] * vsi;
-    }
-    int64_t curr[3], ray_length_in_steps = 0;
-    int step_sign[3];
-    float t_to_next[3], t_step[3];
-    int bad = 0;
-    for (int a = 0; a < 3; ++a)
-      if (isnan(start_scaled[a]) || isnan(end_scaled[a])) bad = 1;
-    if (bad) continue;
-    for (int a = 0; a < 3; ++a) {
-      curr[a] = grid_index(start_scaled[a] + kCoordinateEpsilon);
-      int64_t end_index = grid_index(end_scaled[a] + kCoordinateEpsilon);
-      int64_t diff = end_index - curr[a];
-      ray_length_in_steps += diff < 0 ? -diff : diff;
-      float ray_scaled = end_scaled[a] - start_scaled[a];
-      step_sign[a] = signum(ray_scaled);
-      float corrected_step = (float)(step_sign[a] > 0 ? step_sign[a] : 0);
-      float start_scaled_shifted = start_scaled[a] - (float)curr[a];
-      float distance_to_boundary = corrected_step - start_scaled_shifted;
-      /* voxblox divides by ray_scaled unguarded; a component that is exactly 0
-       * never advances here (t = +inf) instead of producing NaN */
-      if (ray_scaled == 0.0f) {
-        t_to_next[a] = INFINITY;
-        t_step[a] = INFINITY;
-      } else {
-        t_to_next[a] = distance_to_boundary / ray_scaled;
-        t_step[a] = (float)step_sign[a] / ray_scaled;
-      }
-    }
-    int64_t consecutive_ray_collisions = 0;
-    for (int64_t current_step = 0; current_step <= ray_length_in_steps; ++current_step) {
-      int64_t v[3] = {curr[0], curr[1], curr[2]};
-      /* advance (minCoeff: first minimum) */
-      int t_min_idx = 0;
-      if (t_to_next[1] < t_to_next[t_min_idx]) t_min_idx = 1;
-      if (t_to_next[2] < t_to_next[t_min_idx]) t_min_idx = 2;
-      curr[t_min_idx] += step_sign[t_min_idx];
-      t_to_next[t_min_idx] += t_step[t_min_idx];
 
-      if (!approx_set_replace(&I->observed_set, v)) {
+    orc_ray ray;
+    fast_ray_setup(c, vsi, origin, point_G, is_clearing, &ray);
+    if (I->log) log4(I, 3 | (ray.bad ? 0x100u : 0u), (uint64_t)pi, ray.bad ? 0 : (uint64_t)(ray.ray_length_in_steps + 1), 0);
+    if (ray.bad) continue;
+    int64_t consecutive_ray_collisions = 0;
+    for (int64_t current_step = 0; current_step <= ray.ray_length_in_steps; ++current_step) {
+      int64_t v[3];
+      ray_next(&ray, v);
+
+      int is_new;
+      if (!I->log) {
+        is_new = approx_set_replace(&I->observed_set, v);
+      } else {
+        uint64_t value, returned;
+        is_new = approx_set_exchange(&I->observed_set, v, &value, &returned);
+        log4(I, 4 | ((uint64_t)current_step << 8), (uint64_t)pi, value, returned);
+      }
+      if (!is_new) {
         ++consecutive_ray_collisions;
       } else {
         consecutive_ray_collisions = 0;
@@ -437,17 +377,26 @@ int64_t orc_tsdf_integrate(orc_tsdf_integrator* I, const float T_G_C[7], const f
       int slot = layer_get_or_allocate(L, b[0], b[1], b[2]);
       size_t lin = (size_t)lv[0] + (size_t)vps * ((size_t)lv[1] + (size_t)vps * (size_t)lv[2]);
       size_t at = (size_t)slot * L->nvox + lin;
-      /* getVoxelWeight */
-      float weight;
-      if (c->use_const_weight) {
-        weight = 1.0f;
-      } else {
-        float dist_z = fabsf(point_C[2]);
-        weight = dist_z > kEpsilon ? 1.0f / (dist_z * dist_z) : 0.0f;
-      }
-      update_voxel(I, origin, point_G, v, color, weight, &L->distance[at], &L->weight[at],
+      const uint64_t word_before = log_word(L->distance[at], L->weight[at]);
+      const uint32_t colour_before = log_rgba(&L->rgba[4 * at]);
+      update_voxel(c, L->voxel_size, origin, point_G, v, color, point_weight(c, point_C), &L->distance[at], &L->weight[at],
                    &L->rgba[4 * at]);
       ++updates;
+      if (I->log) {
+        uint64_t* w = log_reserve(I, 7);
+        if (w) {
+          const uint64_t word_after = log_word(L->distance[at], L->weight[at]);
+          const uint32_t colour_after = log_rgba(&L->rgba[4 * at]);
+          const uint64_t flags = (word_after != word_before ? 1u : 0u) | (colour_after != colour_before ? 2u : 0u);
+          w[0] = 5 | (1ull << 8) | (flags << 40);
+          w[1] = pack_voxel_key(v, 0);
+          w[2] = word_before;
+          w[3] = word_after;
+          w[4] = (uint64_t)colour_before | ((uint64_t)colour_after << 32);
+          w[5] = (uint64_t)at;
+          w[6] = (uint64_t)pi | ((uint64_t)current_step << 32);
+        }
+      }
     }
   }
   free(order);
@@ -639,7 +588,7 @@ int64_t orc_tsdf_merged_integrate(orc_tsdf_integrator* I, const float T_G_C[7], 
       int slot = layer_get_or_allocate(L, b[0], b[1], b[2]);
       size_t lin = (size_t)lv[0] + (size_t)vps * ((size_t)lv[1] + (size_t)vps * (size_t)lv[2]);
       size_t at = (size_t)slot * L->nvox + lin;
-      update_voxel(I, origin, point_G, v, merged_color, merged_weight, &L->distance[at], &L->weight[at],
+      update_voxel(c, L->voxel_size, origin, point_G, v, merged_color, merged_weight, &L->distance[at], &L->weight[at],
                    &L->rgba[4 * at]);
       ++updates;
     }

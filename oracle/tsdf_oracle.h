@@ -91,6 +91,15 @@ int64_t orc_tsdf_merged_integrate(orc_tsdf_integrator* I, const float T_G_C[7],
                                   const float* points_C, const uint8_t* rgba, int64_t n,
                                   int freespace_points);
 
+/* The single thread's own event log, in the racing kernel's format (include/voxgraph_amd_bench.h "event log"; every
+ * update its own one-record fold): scans from now on append to buffer[0 .. capacity_words) (NULL: off).  For
+ * tsdf_replay.h's checker: a sequential run is one legal interleaving. */
+void orc_tsdf_integrator_set_log(orc_tsdf_integrator* I, uint64_t* buffer, int64_t capacity_words);
+int64_t orc_tsdf_integrator_log_words(const orc_tsdf_integrator* I, int64_t* lost);
+/* the two approximate sets as they are (2^20 words each, either may be NULL) and their offsets */
+void orc_tsdf_integrator_download_sets(const orc_tsdf_integrator* I, uint64_t* start_set, uint64_t* observed_set,
+                                       uint64_t offsets[2]);
+
 #ifdef __cplusplus
 }
 #endif

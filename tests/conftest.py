@@ -36,8 +36,8 @@ def _gfx950_present():
 _ORDER = [
     # 1. REG hot path, bit-exact against the oracle / the reference's own source
     "test_reg_gpu", "test_fullsize_gpu", "test_batch_sampling_gpu", "test_dropin_cpp_gpu", "test_brick_layout_gpu",
-    # 2. TSDF: the order-independent (bit-exact) cases and the reproducible mode
-    "test_tsdf_deterministic_gpu", "test_tsdf_gpu", "test_tsdf_merged_gpu", "test_tsdf_dropin_gpu",
+    # 2. TSDF: the reproducible mode, the racing mode replayed event by event, the order-independent (bit-exact) cases
+    "test_tsdf_deterministic_gpu", "test_tsdf_replay_gpu", "test_tsdf_gpu", "test_tsdf_merged_gpu", "test_tsdf_dropin_gpu",
     # 3. producers either side of the path, bit-exact
     "test_overlap_gpu", "test_iso_gpu", "test_esdf_gpu", "test_mapfile_gpu",
     # 4. boundary, adapters, sharding, error paths

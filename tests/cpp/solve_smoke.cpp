@@ -120,6 +120,14 @@ int main() {
     ceres::Solve(o2, &problem, &summary);
     report("batched", summary, b);
     for (int k = 0; k < 4; ++k) end[1][k] = b[k];
+    // every trial step was a cost-only evaluation (registration_cost_function.cpp:179: no Jacobian work when Ceres passes
+    // none) and took the cost-only route; every accepted step's Jacobians one full pass at the same point
+    std::printf("batched: %d cost-only evaluations by the solver, %ld through vgx_reg_batch_evaluate_cost; %d with Jacobians, %ld "
+                "full passes\n", summary.num_cost_only_evaluations, batch.cost_only_evaluations(),
+                summary.num_jacobian_evaluations, batch.full_evaluations());
+    if (summary.num_cost_only_evaluations < 1 || batch.cost_only_evaluations() != summary.num_cost_only_evaluations ||
+        batch.full_evaluations() != summary.num_jacobian_evaluations)
+      return std::printf("FAIL: cost-only evaluations did not take the cost-only route\n"), 1;
   }
   // ---- 3. two contexts ----------------------------------------------------------------------------------------
   {
@@ -139,6 +147,8 @@ int main() {
     ceres::Solve(o3, &problem, &summary);
     report("multi", summary, b);
     for (int k = 0; k < 4; ++k) end[2][k] = b[k];
+    if (batch.cost_only_evaluations() != summary.num_cost_only_evaluations || batch.full_evaluations() != summary.num_jacobian_evaluations)
+      return std::printf("FAIL: multi: cost-only evaluations did not take the cost-only route\n"), 1;
   }
   // ---- same end pose on every route: 1 mm / 0.01 degree -------------------------------------------------------
   double worst_xyz = 0, worst_yaw = 0, from_truth = 0;

@@ -276,7 +276,8 @@ struct Solver {
     EvaluationCallback* evaluation_callback = nullptr;
   };
   struct Summary {
-    int num_iterations = 0, num_evaluations = 0;
+    int num_iterations = 0, num_evaluations = 0;   // evaluations: cost-only + with Jacobians
+    int num_cost_only_evaluations = 0, num_jacobian_evaluations = 0;
     double initial_cost = 0, final_cost = 0;
     const char* termination = "";
     bool IsSolutionUsable() const { return termination[0] == 'C' || termination[0] == 'N'; }  // CONVERGENCE / NO_CONVERGENCE
@@ -290,9 +291,11 @@ struct Solver {
 
 struct SolverImpl {
   // cost = 0.5 sum r^2; g = J^T r; H = J^T J over the free parameters (dense)
+  // new_evaluation_point: false when the parameters are where the previous evaluation left them (Ceres evaluates the
+  // Jacobians of a step it has just accepted on a cost-only evaluation that way)
   static bool Evaluate(const Solver::Options& o, Problem* p, const std::vector<int>& offset, int nf, double* cost,
-                       std::vector<double>* g, std::vector<double>* H) {
-    if (o.evaluation_callback) o.evaluation_callback->PrepareForEvaluation(true, true);
+                       std::vector<double>* g, std::vector<double>* H, bool new_evaluation_point = true) {
+    if (o.evaluation_callback) o.evaluation_callback->PrepareForEvaluation(true, new_evaluation_point);
     *cost = 0;
     g->assign(static_cast<size_t>(nf), 0.0);
     H->assign(static_cast<size_t>(nf) * nf, 0.0);
@@ -319,6 +322,20 @@ struct SolverImpl {
             }
           }
       }
+    }
+    return true;
+  }
+  // cost only, as Ceres' trust-region loop evaluates every trial step: `jacobians == nullptr` for every block, the
+  // callback told so beforehand (ProgramEvaluator: PrepareForEvaluation(jacobian != nullptr || gradient != nullptr, ...))
+  static bool EvaluateCost(const Solver::Options& o, Problem* p, double* cost) {
+    if (o.evaluation_callback) o.evaluation_callback->PrepareForEvaluation(false, true);
+    *cost = 0;
+    for (Problem::Block& b : p->blocks_) {
+      const int nr = b.cost->num_residuals();
+      std::vector<double> r(static_cast<size_t>(nr));
+      double* params[2] = {p->params_[static_cast<size_t>(b.param[0])], p->params_[static_cast<size_t>(b.param[1])]};
+      if (!b.cost->Evaluate(params, r.data(), nullptr)) return false;
+      for (int i = 0; i < nr; ++i) *cost += 0.5 * r[static_cast<size_t>(i)] * r[static_cast<size_t>(i)];
     }
     return true;
   }
@@ -392,7 +409,7 @@ inline void Solve(const Solver::Options& o, Problem* p, Solver::Summary* summary
   double cost = 0;
   s.termination = "FAILURE";
   if (!SolverImpl::Evaluate(o, p, offset, nf, &cost, &g, &H)) return;
-  s.num_evaluations = 1;
+  s.num_evaluations = s.num_jacobian_evaluations = 1;
   s.initial_cost = s.final_cost = cost;
   double radius = o.initial_trust_region_radius, decrease = 2.0;
   s.termination = "NO_CONVERGENCE";
@@ -427,15 +444,24 @@ inline void Solve(const Solver::Options& o, Problem* p, Solver::Summary* summary
     std::vector<double> cand;
     plus(x, step, &cand);
     set(cand);
+    // the trial step: its cost alone (TrustRegionMinimizer: evaluator->Evaluate(x_candidate, &cost, nullptr, nullptr, nullptr))
     double ncost = 0;
-    if (!SolverImpl::Evaluate(o, p, offset, nf, &ncost, &ng, &nH)) {
+    if (!SolverImpl::EvaluateCost(o, p, &ncost)) {
       set(x);
       return;
     }
     ++s.num_evaluations;
+    ++s.num_cost_only_evaluations;
     const double rho = model > 0 ? (cost - ncost) / model : -1.0;
     if (rho > 1e-3) {
       const double rel = std::fabs(cost - ncost) / std::fmax(cost, 1e-300);
+      // accepted: gradient and Jacobian at the point just evaluated (EvaluateGradientAndJacobian(new_evaluation_point = false))
+      if (!SolverImpl::Evaluate(o, p, offset, nf, &ncost, &ng, &nH, /*new_evaluation_point=*/false)) {
+        set(x);
+        return;
+      }
+      ++s.num_evaluations;
+      ++s.num_jacobian_evaluations;
       x = cand;
       cost = ncost;
       g = ng;

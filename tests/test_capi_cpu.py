@@ -25,25 +25,38 @@ def _declared_symbols(headers=("voxgraph_amd.h", "voxgraph_amd_bench.h")):
 
 def test_library_exports_every_declared_symbol(capi):
     lib = capi.load()
-    declared = _declared_symbols()
-    assert len(declared) >= 30
-    for name in declared:
-        assert hasattr(lib, name), f"{name} declared in voxgraph_amd.h but not exported"
-    # and the ctypes table covers the headers exactly
-    assert sorted(capi.SIGNATURES) == declared
-    # benchmark tooling lives in its own header, not in the drop-in boundary
     boundary = _declared_symbols(("voxgraph_amd.h",))
-    assert not [n for n in boundary if "synth" in n]
-    assert sorted(set(declared) - set(boundary)) == ["vgx_bench_alloc_scattered", "vgx_bench_atomic_roundtrip", "vgx_bench_free_scattered", "vgx_bench_stream_ceiling", "vgx_synth_city_scan",
-                                                     "vgx_synth_city_submap", "vgx_tsdf_integrator_read_trace", "vgx_tsdf_integrator_set_speculation",
-                                                     "vgx_tsdf_integrator_walk_stats"]
+    tooling = _declared_symbols(("voxgraph_amd_bench.h",))
+    assert len(boundary) >= 30 and not set(boundary) & set(tooling)
+    for name in boundary + tooling:
+        assert hasattr(lib, name), f"{name} declared in include/ but not exported"
+    # the ctypes tables cover the two headers exactly
+    assert sorted(capi.SIGNATURES) == boundary
+    assert sorted(capi.BENCH_SIGNATURES) == tooling
+    # benchmark / test tooling lives in its own header AND its own library: the product library carries none of it
+    assert not [n for n in boundary if "synth" in n or "bench" in n]
+    product = _exported(capi.LIB_PATH)
+    assert not set(tooling) & set(product), sorted(set(tooling) & set(product))
+    assert set(tooling) <= set(_exported(capi.BENCH_LIB_PATH))
+    assert tooling == ["vgx_bench_alloc_scattered", "vgx_bench_atomic_roundtrip", "vgx_bench_free_scattered", "vgx_bench_stream_ceiling",
+                       "vgx_synth_city_scan", "vgx_synth_city_submap", "vgx_tsdf_integrator_download_sets",
+                       "vgx_tsdf_integrator_read_event_trace", "vgx_tsdf_integrator_read_trace", "vgx_tsdf_integrator_set_event_trace",
+                       "vgx_tsdf_integrator_set_speculation", "vgx_tsdf_integrator_walk_stats"]
+
+
+def _exported(path):
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path]).decode()
+    return [l.split()[-1] for l in out.splitlines() if " T " in l]
 
 
 def test_only_c_abi_symbols_are_exported(capi):
-    out = subprocess.check_output(["nm", "-D", "--defined-only", capi.LIB_PATH]).decode()
-    names = [l.split()[-1] for l in out.splitlines() if " T " in l]
-    assert names and all(n.startswith("vgx_") for n in names), [n for n in names
-                                                               if not n.startswith("vgx_")][:5]
+    """the product library exports the boundary header's symbols and three C-linkage hooks for the tooling library
+    (csrc/vgx_internal.h), nothing else -- no C++ names; the tooling library exports its header's symbols only"""
+    names = _exported(capi.LIB_PATH)
+    boundary = _declared_symbols(("voxgraph_amd.h",))
+    hooks = ["vgx_internal_build_block_lut", "vgx_internal_launch_brickify", "vgx_internal_set_error"]
+    assert sorted(names) == sorted(boundary + hooks), sorted(set(names) ^ set(boundary + hooks))
+    assert sorted(_exported(capi.BENCH_LIB_PATH)) == _declared_symbols(("voxgraph_amd_bench.h",))
 
 
 def test_product_does_not_link_or_reference_the_oracle(capi):

@@ -348,6 +348,16 @@ def test_choose_outputs_times_candidates_and_leaves_valid_rows(capi, ctx, small_
     with pytest.raises(Exception):
         batch.choose_outputs(G["poses"], [cand[0][0].data_ptr(), 0], None, None)
     batch.destroy()
+    # a SAMPLING batch is refused: its trial evaluations would advance the reference point sets' engines
+    scfg = capi.default_config(registration_point_type=capi.POINTS_VOXELS, sampling_ratio=0.5)
+    scfs = [capi.RegistrationCostFunction(ctx, G["gs"][a], G["gs"][b], scfg) for a, b in G["pairs"]]
+    sbatch = capi.RegistrationBatch(ctx, scfs, G["pairs"])
+    with pytest.raises(Exception, match="sampling"):
+        sbatch.choose_outputs(G["poses"], [c[0].data_ptr() for c in cand], [c[1].data_ptr() for c in cand],
+                              [c[2].data_ptr() for c in cand], launches=1)
+    sbatch.destroy()
+    for cf in scfs:
+        cf.destroy()
 
 
 def test_blocked_output_layout_holds_the_same_rows(capi, ctx, small_graph):
@@ -387,6 +397,47 @@ def test_blocked_output_layout_holds_the_same_rows(capi, ctx, small_graph):
     with pytest.raises(Exception):
         batch.evaluate_points_blocked(G["poses"], blocks.data_ptr() + 4)     # not 16-byte aligned
     batch.destroy()
+
+
+def test_cost_only_pass_is_the_full_pass_cost_bit_for_bit(capi, ctx, small_graph):
+    """vgx_reg_batch_evaluate_cost (what Ceres asks for at every trial step: `jacobians == nullptr`,
+    registration_cost_function.cpp:179): the same f32 operations in the same order through the same reduction tree, so the
+    cost a step is accepted on is the very number the full evaluation at that point reports -- and within 1e-6 of the
+    oracle's; with a no-correspondence cost, on the device, reproducibly, and interleaved with full passes"""
+    import torch
+    G = small_graph
+    batch = capi.RegistrationBatch(ctx, G["cfs"], G["pairs"])
+    rng = np.random.default_rng(2)
+    for trial in range(4):
+        poses = G["poses"] + (rng.normal(0, [0.1, 0.1, 0.05, 0.02], G["poses"].shape) if trial else 0)
+        st_n, normal = batch.evaluate_normal(poses)
+        st_c, cost = batch.evaluate_cost(poses)
+        assert np.array_equal(st_n, st_c)
+        assert np.array_equal(cost.view(np.uint64), normal[:, 0].copy().view(np.uint64)), (trial, cost, normal[:, 0])
+        _, cost2 = batch.evaluate_cost(poses)
+        assert np.array_equal(cost.view(np.uint64), cost2.view(np.uint64))
+    for c, (a, b) in enumerate(G["pairs"]):
+        xyz, dist, w = G["pts"][a]
+        ok, want, _, _ = orc.reg_evaluate_normal(G["layers"][b], xyz, dist, w, poses[a], poses[b])
+        assert abs(cost[c] - want) <= 1e-6 * want
+    # into a caller's device array, nothing brought to the host
+    d_cost = torch.full((batch.n,), float("nan"), dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    batch.evaluate_cost(poses, d_cost=d_cost.data_ptr(), to_host=False)
+    ctx.synchronize()
+    assert np.array_equal(d_cost.cpu().numpy().view(np.uint64), cost.view(np.uint64))
+    batch.destroy()
+    # no_correspondence_cost != 0: misses count (RCF:165-166), nothing is culled
+    cfs = [capi.RegistrationCostFunction(ctx, G["gs"][a], G["gs"][b],
+                                         capi.default_config(registration_point_type=capi.POINTS_VOXELS, no_correspondence_cost=0.3))
+           for a, b in G["pairs"]]
+    b2 = capi.RegistrationBatch(ctx, cfs, G["pairs"])
+    _, normal = b2.evaluate_normal(poses)
+    _, cost = b2.evaluate_cost(poses)
+    assert np.array_equal(cost.view(np.uint64), normal[:, 0].copy().view(np.uint64)) and np.all(cost > 0)
+    b2.destroy()
+    for cf in cfs:
+        cf.destroy()
 
 
 def test_batch_normal_equations_and_assembly(capi, ctx, small_graph):

@@ -12,6 +12,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # VGX_LIB: an alternative build of the same library (A/B scripts under profiles/ only)
 LIB_PATH = os.environ.get("VGX_LIB") or os.path.join(_HERE, "lib", "libvoxgraph_amd.so")
+# test / benchmark tooling (include/voxgraph_amd_bench.h), built next to it from csrc/bench/
+BENCH_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), os.path.basename(LIB_PATH).replace("libvoxgraph_amd", "libvoxgraph_amd_bench", 1))
 
 OK = 0
 EVALUATE_FALSE = 1
@@ -108,18 +110,6 @@ SIGNATURES = {
     "vgx_submap_release_raw_layers": (C.c_int, [vp]),
     "vgx_submap_download_layers": (C.c_int, [vp, f32p, f32p, f32p, u8p]),
     "vgx_submap_block_index": (C.c_int, [vp, i32p]),
-    "vgx_synth_city_submap": (C.c_int, [vp, C.c_int32, C.c_float, C.c_int32, i32p, i32p, C.c_float,
-                                        C.c_float, C.c_float, f64p, C.c_uint32, C.c_int32,
-                                        C.POINTER(vp)]),
-    "vgx_synth_city_scan": (C.c_int, [vp, f64p, C.c_int32, C.c_int32, C.c_float, C.c_float,
-                                      C.c_uint32, vp]),
-    "vgx_bench_atomic_roundtrip": (C.c_int, [vp, C.c_int64, C.c_int32, C.c_int32, f32p]),
-    "vgx_bench_stream_ceiling": (C.c_int, [vp, vp, C.c_int64, vp, C.c_int64, C.c_int32, f32p]),
-    "vgx_bench_alloc_scattered": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_uint32, C.POINTER(vp)]),
-    "vgx_bench_free_scattered": (C.c_int, [vp, vp]),
-    "vgx_tsdf_integrator_walk_stats": (C.c_int, [vp, i64p]),
-    "vgx_tsdf_integrator_read_trace": (C.c_int, [vp, i64p, C.c_int64, i64p, i64p]),
-    "vgx_tsdf_integrator_set_speculation": (C.c_int, [vp, C.c_int32, C.c_int64]),
     "vgx_reg_config_default": (None, [C.POINTER(RegConfig)]),
     "vgx_reg_create": (C.c_int, [vp, vp, vp, C.POINTER(RegConfig), C.POINTER(vp)]),
     "vgx_reg_destroy": (C.c_int, [vp]),
@@ -132,6 +122,7 @@ SIGNATURES = {
     "vgx_reg_batch_num_residuals": (C.c_int64, [vp]),
     "vgx_reg_batch_row_offsets": (C.c_int, [vp, i64p]),
     "vgx_reg_batch_evaluate_points": (C.c_int, [vp, f64p, C.c_int32, vp, vp, vp, i32p]),
+    "vgx_reg_batch_evaluate_cost": (C.c_int, [vp, f64p, C.c_int32, vp, f64p, i32p]),
     "vgx_reg_batch_blocked_layout": (C.c_int, [vp, C.POINTER(C.c_int64), i32p, C.POINTER(C.c_int64)]),
     "vgx_reg_batch_evaluate_points_blocked": (C.c_int, [vp, f64p, C.c_int32, vp, i32p]),
     "vgx_reg_batch_choose_outputs": (C.c_int, [vp, f64p, C.c_int32, C.c_int32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
@@ -156,6 +147,7 @@ SIGNATURES = {
     "vgx_reg_multi_shard_of": (C.c_int, [vp, i32p]),
     "vgx_reg_multi_evaluate_fused": (C.c_int, [vp, f64p, C.c_int32, f64p, i32p]),
     "vgx_reg_multi_evaluate_normal": (C.c_int, [vp, f64p, C.c_int32, f64p, i32p]),
+    "vgx_reg_multi_evaluate_cost": (C.c_int, [vp, f64p, C.c_int32, f64p, i32p]),
     "vgx_reg_compress_normal": (C.c_int, [f64p, f64p, f64p]),
     "vgx_submap_surface_obb": (C.c_int, [vp, f32p, f32p]),
     "vgx_submap_mission_surface_aabb": (C.c_int, [vp, f64p, f32p, f32p]),
@@ -188,6 +180,25 @@ SIGNATURES = {
                                      C.POINTER(MapFileSubmapData)]),
 }
 
+# every symbol include/voxgraph_amd_bench.h declares (libvoxgraph_amd_bench.so: test and benchmark tooling)
+BENCH_SIGNATURES = {
+    "vgx_synth_city_submap": (C.c_int, [vp, C.c_int32, C.c_float, C.c_int32, i32p, i32p, C.c_float,
+                                        C.c_float, C.c_float, f64p, C.c_uint32, C.c_int32,
+                                        C.POINTER(vp)]),
+    "vgx_synth_city_scan": (C.c_int, [vp, f64p, C.c_int32, C.c_int32, C.c_float, C.c_float,
+                                      C.c_uint32, vp]),
+    "vgx_bench_atomic_roundtrip": (C.c_int, [vp, C.c_int64, C.c_int32, C.c_int32, f32p]),
+    "vgx_bench_stream_ceiling": (C.c_int, [vp, vp, C.c_int64, vp, C.c_int64, C.c_int32, f32p]),
+    "vgx_bench_alloc_scattered": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_uint32, C.POINTER(vp)]),
+    "vgx_bench_free_scattered": (C.c_int, [vp, vp]),
+    "vgx_tsdf_integrator_walk_stats": (C.c_int, [vp, i64p]),
+    "vgx_tsdf_integrator_read_trace": (C.c_int, [vp, i64p, C.c_int64, i64p, i64p]),
+    "vgx_tsdf_integrator_set_speculation": (C.c_int, [vp, C.c_int32, C.c_int64]),
+    "vgx_tsdf_integrator_set_event_trace": (C.c_int, [vp, C.c_int64]),
+    "vgx_tsdf_integrator_read_event_trace": (C.c_int, [vp, C.POINTER(C.c_uint64), C.c_int64, i64p, i64p]),
+    "vgx_tsdf_integrator_download_sets": (C.c_int, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), i64p]),
+}
+
 _lib = None
 
 
@@ -217,13 +228,38 @@ def load():
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
         _share_hip_runtime_with_torch()
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)   # (the tooling library resolves its undefined symbols in it)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)     # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        _lib = lib
+        _lib = _Libraries(lib)
     return _lib
+
+
+class _Libraries:
+    """The product library, plus -- bound at the first use of one of its symbols -- the tooling library: tests and bench.py
+    call both through `ctx.lib`; an integration loads libvoxgraph_amd.so alone."""
+
+    def __init__(self, product):
+        self.product = product
+        self.tooling = None
+
+    def __getattr__(self, name):
+        if name in SIGNATURES:
+            return getattr(self.product, name)
+        if name in BENCH_SIGNATURES:
+            if self.tooling is None:
+                if not os.path.exists(BENCH_LIB_PATH):
+                    raise ImportError(f"{BENCH_LIB_PATH} is missing: build it with __graft_entry__.build()")
+                tooling = C.CDLL(BENCH_LIB_PATH)
+                for sym, (res, args) in BENCH_SIGNATURES.items():
+                    fn = getattr(tooling, sym)
+                    fn.restype = res
+                    fn.argtypes = args
+                self.tooling = tooling
+            return getattr(self.tooling, name)
+        raise AttributeError(name)
 
 
 class VgxError(RuntimeError):
@@ -551,6 +587,16 @@ class RegistrationBatch:
             _ptr(host, f64p), _ptr(status, i32p)))
         return status[:self.n], host
 
+    def evaluate_cost(self, poses, d_cost=None, to_host=True):
+        """cost-only fused pass (vgx_reg_batch_evaluate_cost): -> (status, cost[n] f64 or None)"""
+        poses = _f64(poses).reshape(-1, 4)
+        status = np.zeros(max(self.n, 1), np.int32)
+        host = np.zeros(self.n, np.float64) if to_host else None
+        self.ctx.check(self.ctx.lib.vgx_reg_batch_evaluate_cost(
+            self.h, _ptr(poses, f64p), poses.shape[0], vp(d_cost) if d_cost else None,
+            _ptr(host, f64p), _ptr(status, i32p)))
+        return status[:self.n], host
+
     def count_live(self, poses, unique=False):
         """residuals whose points the fused pass reads at these poses (chunk culling applied);
         with unique=True also the number of distinct points behind them"""
@@ -672,6 +718,14 @@ class RegistrationMulti:
         out = np.zeros((self.n, NORMAL_SIZE))
         status = np.zeros(max(self.n, 1), np.int32)
         self.ctxs[0].check(self.ctxs[0].lib.vgx_reg_multi_evaluate_normal(
+            self.h, _ptr(poses, f64p), poses.shape[0], _ptr(out, f64p), _ptr(status, i32p)))
+        return out, status[:self.n]
+
+    def evaluate_cost(self, poses):
+        poses = _f64(poses).reshape(-1, 4)
+        out = np.zeros(self.n)
+        status = np.zeros(max(self.n, 1), np.int32)
+        self.ctxs[0].check(self.ctxs[0].lib.vgx_reg_multi_evaluate_cost(
             self.h, _ptr(poses, f64p), poses.shape[0], _ptr(out, f64p), _ptr(status, i32p)))
         return out, status[:self.n]
 
@@ -903,6 +957,27 @@ class FastTsdfIntegrator:
         self.ctx.check(self.ctx.lib.vgx_tsdf_integrator_walk_stats(self.h, out))
         names = ("longest_chain", "exchanges", "colour_blends", "peeks", "voxel_folds", "cas_retries", "overrun_exchanges")
         return {k: int(v) for k, v in zip(names, out)}
+
+    def set_event_trace(self, capacity_words):
+        """test tooling: racing scans from now on run the event-logging form of the shipped kernel (0: off)"""
+        self.ctx.check(self.ctx.lib.vgx_tsdf_integrator_set_event_trace(self.h, int(capacity_words)))
+        self._trace_cap = int(capacity_words)
+
+    def read_event_trace(self):
+        """-> (uint64 words of the log since the last read, events lost to a full log); empties the log"""
+        buf = np.zeros(self._trace_cap, np.uint64)
+        n, lost = C.c_int64(), C.c_int64()
+        self.ctx.check(self.ctx.lib.vgx_tsdf_integrator_read_event_trace(
+            self.h, _ptr(buf, C.POINTER(C.c_uint64)), len(buf), C.byref(n), C.byref(lost)))
+        return buf[:n.value].copy(), int(lost.value)
+
+    def download_sets(self):
+        """-> (start set, observed set: uint64[2^20] each, (start offset, observed offset, scans since the last reset))"""
+        a, b = np.zeros(1 << 20, np.uint64), np.zeros(1 << 20, np.uint64)
+        st = (C.c_int64 * 3)()
+        self.ctx.check(self.ctx.lib.vgx_tsdf_integrator_download_sets(
+            self.h, _ptr(a, C.POINTER(C.c_uint64)), _ptr(b, C.POINTER(C.c_uint64)), st))
+        return a, b, tuple(int(x) for x in st)
 
     def destroy(self):
         if self.h:

@@ -14,11 +14,18 @@
 // normal equations of its N-residual original (vgx_reg_compress_normal): legitimate
 // because the reference attaches no robust loss to registration constraints
 // (registration_constraint.cpp:10, constraint.h:34).
+//
+// Ceres' `evaluate_jacobians` is honoured (the reference does no Jacobian work when `jacobians == nullptr`,
+// registration_cost_function.cpp:179, and Levenberg-Marquardt evaluates every trial step that way): a cost-only
+// request runs the cost-only pass (vgx_reg_batch_evaluate_cost: one sum per constraint, no gradient, nothing to
+// compress) and every block answers with the residual vector (sqrt(cost), 0, ..., 0) -- all Ceres reads there is its
+// squared norm, and that cost is, bit for bit, the one the full evaluation at the same point reports.
 #ifndef VOXGRAPH_AMD_CPP_GPU_REGISTRATION_BATCH_H_
 #define VOXGRAPH_AMD_CPP_GPU_REGISTRATION_BATCH_H_
 
 #include <ceres/ceres.h>
 
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <stdexcept>
@@ -36,20 +43,42 @@ class GpuRegistrationBlocks : public ceres::EvaluationCallback {
  public:
   // ceres::EvaluationCallback: the user's parameter blocks already hold the point to
   // evaluate when this is called.
-  void PrepareForEvaluation(bool /*evaluate_jacobians*/, bool new_evaluation_point) override {
+  //
+  // new_evaluation_point == false: what is cached answers if it holds what is asked for -- the Jacobians of a step
+  // Ceres has just accepted on its cost are NOT in a cost-only cache and are evaluated then, at the same point.  With
+  // SAMPLING constraints that second evaluation draws anew (as every Evaluate of the reference does), and a request
+  // the cache can answer does not draw where the reference would: fewer draws, each a legal one (include/voxgraph_amd.h,
+  // vgx_reg_batch_evaluate_cost).
+  void PrepareForEvaluation(bool evaluate_jacobians, bool new_evaluation_point) override {
     if (!finalized_) throw std::logic_error("GpuRegistrationBatch: Finalize() was not called");
-    if (!new_evaluation_point && valid_) return;
+    if (!new_evaluation_point && valid_ && (have_jacobians_ || !evaluate_jacobians)) return;
     for (size_t k = 0; k < nodes_.size(); ++k) std::memcpy(&poses_[4 * k], nodes_[k], 4 * sizeof(double));
-    EvaluateNormals(poses_.data(), static_cast<int32_t>(nodes_.size()), normal_.data(), status_.data());
-    for (size_t c = 0; c < regs_.size(); ++c)
-      vgx_reg_compress_normal(&normal_[45 * c], &compressed_r_[9 * c], &compressed_j_[72 * c]);
+    if (evaluate_jacobians) {
+      EvaluateNormals(poses_.data(), static_cast<int32_t>(nodes_.size()), normal_.data(), status_.data());
+      for (size_t c = 0; c < regs_.size(); ++c)
+        vgx_reg_compress_normal(&normal_[45 * c], &compressed_r_[9 * c], &compressed_j_[72 * c]);
+      ++full_evaluations_;
+    } else {
+      EvaluateCosts(poses_.data(), static_cast<int32_t>(nodes_.size()), cost_.data(), status_.data());
+      for (size_t c = 0; c < regs_.size(); ++c) {
+        double* r = &compressed_r_[9 * c];
+        r[0] = std::sqrt(cost_[c] > 0.0 ? cost_[c] : 0.0);
+        for (int m = 1; m < 9; ++m) r[m] = 0.0;
+      }
+      ++cost_only_evaluations_;
+    }
+    have_jacobians_ = evaluate_jacobians;
     valid_ = true;
   }
 
   int num_constraints() const { return static_cast<int>(regs_.size()); }
+  // evaluations so far by route: the full fused pass (normal equations, compressed) / the cost-only pass
+  long full_evaluations() const { return full_evaluations_; }
+  long cost_only_evaluations() const { return cost_only_evaluations_; }
 
  protected:
   virtual void EvaluateNormals(const double* poses, int32_t n_nodes, double* normal, int32_t* status) = 0;
+  virtual void EvaluateCosts(const double* poses, int32_t n_nodes, double* cost, int32_t* status) = 0;
 
   ceres::CostFunction* AddBlock(vgx_reg reg, const double* pose_reference, const double* pose_reading) {
     if (finalized_) throw std::logic_error("GpuRegistrationBatch: AddConstraint after Finalize");
@@ -62,6 +91,7 @@ class GpuRegistrationBlocks : public ceres::EvaluationCallback {
   void FinalizeBlocks() {
     const size_t n = regs_.size();
     normal_.assign(n * 45, 0.0);
+    cost_.assign(n, 0.0);
     status_.assign(n, 0);
     compressed_r_.assign(n * 9, 0.0);
     compressed_j_.assign(n * 72, 0.0);
@@ -81,6 +111,9 @@ class GpuRegistrationBlocks : public ceres::EvaluationCallback {
                   double** jacobians) const override {
       const GpuRegistrationBlocks& o = *owner_;
       if (!o.valid_) return false;
+      // (Ceres announces what it will ask for: PrepareForEvaluation(jacobian != nullptr || gradient != nullptr, ...).  A
+      // caller that asks a cost-only evaluation for Jacobians broke that contract: an evaluation failure, not a guess.)
+      if (jacobians && !o.have_jacobians_) return false;
       if (o.status_[static_cast<size_t>(index_)] == VGX_EVALUATE_FALSE) return false;  // .cpp:273
       std::memcpy(residuals, &o.compressed_r_[9 * static_cast<size_t>(index_)], 9 * sizeof(double));
       if (jacobians) {
@@ -109,10 +142,12 @@ class GpuRegistrationBlocks : public ceres::EvaluationCallback {
 
   std::vector<const double*> nodes_;
   std::map<const double*, int32_t> node_of_;
-  std::vector<double> poses_, normal_, compressed_r_, compressed_j_;
+  std::vector<double> poses_, normal_, cost_, compressed_r_, compressed_j_;
   std::vector<int32_t> status_;
   bool finalized_ = false;
   bool valid_ = false;
+  bool have_jacobians_ = false;   // the cache holds the compressed Jacobians (else residual-only blocks of a cost-only pass)
+  long full_evaluations_ = 0, cost_only_evaluations_ = 0;
 };
 
 // One GPU.
@@ -143,6 +178,10 @@ class GpuRegistrationBatch : public GpuRegistrationBlocks {
   void EvaluateNormals(const double* poses, int32_t n_nodes, double* normal, int32_t* status) override {
     if (vgx_reg_batch_evaluate_normal(batch_, poses, n_nodes, nullptr, normal, status) != VGX_OK)
       throw std::runtime_error(std::string("vgx_reg_batch_evaluate_normal: ") + vgx_last_error(ctx_));
+  }
+  void EvaluateCosts(const double* poses, int32_t n_nodes, double* cost, int32_t* status) override {
+    if (vgx_reg_batch_evaluate_cost(batch_, poses, n_nodes, nullptr, cost, status) != VGX_OK)
+      throw std::runtime_error(std::string("vgx_reg_batch_evaluate_cost: ") + vgx_last_error(ctx_));
   }
 
  private:

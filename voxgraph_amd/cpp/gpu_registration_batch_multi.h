@@ -83,6 +83,10 @@ class GpuRegistrationBatchMulti : public GpuRegistrationBlocks {
     if (vgx_reg_multi_evaluate_normal(multi_, poses, n_nodes, normal, status) != VGX_OK)
       throw std::runtime_error(std::string("vgx_reg_multi_evaluate_normal: ") + vgx_last_error(gpus_[0]));
   }
+  void EvaluateCosts(const double* poses, int32_t n_nodes, double* cost, int32_t* status) override {
+    if (vgx_reg_multi_evaluate_cost(multi_, poses, n_nodes, cost, status) != VGX_OK)
+      throw std::runtime_error(std::string("vgx_reg_multi_evaluate_cost: ") + vgx_last_error(gpus_[0]));
+  }
 
  private:
   std::vector<vgx_ctx> gpus_;

@@ -698,3 +698,10 @@ int vgx_submap_download_points(vgx_submap sm, int32_t point_type, float* xyz, fl
 }
 
 }  // extern "C"
+
+// the three hooks of the tooling library (vgx_internal.h)
+extern "C" {
+int vgx_internal_set_error(vgx_ctx ctx, int code, const char* msg) { return vgx::set_error(ctx, code, msg ? msg : ""); }
+int vgx_internal_launch_brickify(vgx_submap sm, int which) { return vgx::launch_brickify(sm, which); }
+int vgx_internal_build_block_lut(vgx_submap sm) { return vgx::build_block_lut(sm); }
+}

@@ -363,7 +363,11 @@ struct vgx_reg_batch_s {
 // helpers
 // ---------------------------------------------------------------------------
 namespace vgx {
+#ifndef VGX_TOOLING_LIBRARY
 int set_error(vgx_ctx ctx, int code, const std::string& msg);
+#else
+inline int set_error(vgx_ctx ctx, int code, const std::string& msg);
+#endif
 
 // Scope-bound device scratch: freed on every exit path (the VGX_HIP macro returns early).
 struct DeviceScratch {
@@ -391,8 +395,13 @@ void set_global_error(const std::string& msg);
   } while (0)
 
 // kernels' launch wrappers implemented in the .hip files
+#ifndef VGX_TOOLING_LIBRARY
 int launch_brickify(vgx_submap sm, int which);
 int build_block_lut(vgx_submap sm);
+#else
+inline int launch_brickify(vgx_submap sm, int which);
+inline int build_block_lut(vgx_submap sm);
+#endif
 int build_chunk_bounds(vgx_ctx ctx, PointSet& ps);
 // frees a point set's device arrays and leaves it empty (present = false) with a new version
 void reset_point_set(PointSet& ps);
@@ -405,5 +414,24 @@ constexpr int kBlockThreads = 256;
 constexpr int kPointsPerThread = 4;  // measured 5.09-5.28 / 5.06-5.12 / 5.77-5.79 ms at 2 / 4 / 8 (config 3)
 constexpr int kTilePoints = kBlockThreads * kPointsPerThread;
 }  // namespace vgx
+
+// The library is built with -fvisibility=hidden: the C ABI of include/voxgraph_amd.h is what it exports -- plus these three
+// hooks, C linkage like everything else, for libvoxgraph_amd_bench.so alone (csrc/bench/: scene generators, memory
+// ceilings, the racing TSDF kernel's event log: test and benchmark tooling built from these same internal headers, kept
+// out of the product library).  In no public header; vgx_context.hip defines them on vgx::set_error / launch_brickify /
+// build_block_lut.
+extern "C" {
+VGX_API int vgx_internal_set_error(vgx_ctx ctx, int code, const char* msg);
+VGX_API int vgx_internal_launch_brickify(vgx_submap sm, int which);
+VGX_API int vgx_internal_build_block_lut(vgx_submap sm);
+}
+#ifdef VGX_TOOLING_LIBRARY
+// inside the tooling library the internal names resolve to the hooks
+namespace vgx {
+inline int set_error(vgx_ctx ctx, int code, const std::string& msg) { return vgx_internal_set_error(ctx, code, msg.c_str()); }
+inline int launch_brickify(vgx_submap sm, int which) { return vgx_internal_launch_brickify(sm, which); }
+inline int build_block_lut(vgx_submap sm) { return vgx_internal_build_block_lut(sm); }
+}  // namespace vgx
+#endif
 
 #endif

@@ -130,7 +130,7 @@ struct vgx_reg_multi_s {
   uint64_t generation = 0;
   int pending = 0;
   bool quit = false;
-  int mode = 0;                    // 0 fused, 1 per-constraint normal blocks to the host
+  int mode = 0;                    // 0 fused, 1 per-constraint normal blocks to the host, 2 per-constraint costs to the host
   const double* poses = nullptr;
   int32_t n_nodes = 0;
   // context 0: the complete [n][45] array (gathered from the shards), the list's node structure, the fused
@@ -158,9 +158,13 @@ static void run_shard(vgx_reg_multi_s* m, vgx_reg_multi_s::Shard& s) {
     if (s.rc == VGX_OK && (hipSetDevice(s.ctx->device) != hipSuccess ||
                            hipEventRecord(s.done, s.ctx->stream) != hipSuccess))
       s.rc = VGX_ERR_HIP;
-  } else {
+  } else if (m->mode == 1) {
     s.rc = vgx_reg_batch_evaluate_normal(s.batch, m->poses, m->n_nodes, nullptr, nl ? s.h_normal : nullptr,
                                          nl ? s.status.data() : nullptr);
+  } else {
+    // cost only (vgx_reg_multi_evaluate_cost): the shard's costs into the first n_local doubles of its pinned block array
+    s.rc = vgx_reg_batch_evaluate_cost(s.batch, m->poses, m->n_nodes, nullptr, nl ? s.h_normal : nullptr,
+                                       nl ? s.status.data() : nullptr);
   }
 }
 
@@ -492,6 +496,26 @@ int vgx_reg_multi_evaluate_normal(vgx_reg_multi m, const double* poses, int32_t 
     for (size_t c = 0; c < s->global.size(); ++c) {
       std::memcpy(normal_host + (size_t)s->global[c] * kNormalSize, s->h_normal + c * kNormalSize,
                   kNormalSize * sizeof(double));
+      if (status) status[s->global[c]] = s->status[c];
+    }
+  return VGX_OK;
+}
+
+// The cost-only evaluation (vgx_reg_batch_evaluate_cost) of every context's share: cost_host[c] in the caller's
+// constraint order, element 0 of vgx_reg_multi_evaluate_normal's blocks bit for bit; no reduction either.
+int vgx_reg_multi_evaluate_cost(vgx_reg_multi m, const double* poses, int32_t n_nodes, double* cost_host, int32_t* status) {
+  if (!m || !poses || !cost_host || n_nodes <= 0) return VGX_ERR_INVALID;
+  std::lock_guard<std::mutex> call(m->call_mu);
+  vgx_ctx ctx0 = m->shards[0]->ctx;
+  int rc = dispatch(m, 2, poses, n_nodes);
+  if (rc != VGX_OK) {
+    for (auto& s : m->shards)
+      if (s->rc != VGX_OK) return set_error(ctx0, s->rc, std::string("vgx_reg_multi: shard failed: ") + vgx_last_error(s->ctx));
+    return rc;
+  }
+  for (auto& s : m->shards)
+    for (size_t c = 0; c < s->global.size(); ++c) {
+      cost_host[s->global[c]] = s->h_normal[c];
       if (status) status[s->global[c]] = s->status[c];
     }
   return VGX_OK;

@@ -782,10 +782,24 @@ __device__ __forceinline__ void accumulate21(ACC acc[21], const float u[6]) {
     for (int b = a; b < 6; ++b, ++k) acc[k] = x[a] * x[b] + acc[k];
 }
 
+// product 20 of accumulate21 (u[5] * u[5]) by itself: the cost-only pass's running sum
+template <typename ACC>
+__device__ __forceinline__ void accumulate_square(ACC& acc, float r) {
+#pragma clang fp contract(fast)
+  const ACC x = (ACC)r;
+  acc = x * x + acc;
+}
+
 // Tiles are launched in an XCD-aware order (make_xcd_order); every tile still writes its partial
 // sums into the slot it has in its constraint's own contiguous range (tile_first[c] + k-th tile of
 // c), so the order in which a constraint's partials are summed never changes.
-template <int VPS, int LAYOUT, int PPT, typename ACC, int WAVES>
+// COST_ONLY (vgx_reg_batch_evaluate_cost; registration_cost_function.cpp:179: the reference does no Jacobian work when
+// `jacobians == nullptr`, and Ceres' Levenberg-Marquardt evaluates every trial step that way): the same walk over the
+// same tiles with ONE running sum per lane -- the squared residual, the same f32 operations in the same order as product
+// 20 of the full pass, reduced through the same tree -- so the cost it returns is the full pass's cost BIT FOR BIT, and a
+// step accepted on the one is judged on the other's number.  No gradient, no pose-Jacobian products, a sixth of the
+// accumulator registers, a one-sum epilogue.
+template <int VPS, int LAYOUT, int PPT, typename ACC, int WAVES, bool COST_ONLY = false>
 __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_kernel(
     const ConstraintDev* __restrict__ cons, const PosePack* __restrict__ packs,
     const Tile* __restrict__ tiles, int n_tiles, const int32_t* __restrict__ tile_first,
@@ -810,9 +824,10 @@ __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_ker
   if ((int)threadIdx.x < n_chunks)
     s_live[threadIdx.x] = !(bounds && chunk_outside(g, P, bounds[chunk0 + threadIdx.x]));
   __syncthreads();
-  ACC acc[21];
+  constexpr int kAcc = COST_ONLY ? 1 : 21;
+  ACC acc[kAcc];
 #pragma unroll
-  for (int k = 0; k < 21; ++k) acc[k] = (ACC)0;
+  for (int k = 0; k < kAcc; ++k) acc[k] = (ACC)0;
   const float nc = (float)C.no_corr_cost;
   const bool grid_empty = g.bricks == nullptr;
 
@@ -910,8 +925,24 @@ __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_ker
       for (int k = 0; k < 5; ++k) u[k] = ok ? u[k] : 0.0f;
       // RCF:165-166: w * no_correspondence_cost with zero Jacobian rows
       u[5] = ok ? u[5] : ((count_misses && in_range) ? w[j] * nc : 0.0f);
-      accumulate21<ACC>(acc, u);
+      if (COST_ONLY) accumulate_square<ACC>(acc[0], u[5]);   // (the five Jacobian entries are dead code here)
+      else accumulate21<ACC>(acc, u);
     }
+  }
+  if (COST_ONLY) {
+    // the one sum over the 64 lanes (the pairing the reduce-scatter below uses for every sum: partners 32, 16, 8, 4, 2, 1
+    // apart, a + b = b + a exactly), over the four wavefronts in the same order, into slot 20 of the tile's partials
+    __shared__ double lds1[kBlockThreads / 64];
+    double v = (double)acc[0];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) lds1[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const size_t slot = (size_t)tile_first[tile.constraint] + (size_t)(tile.start / C.tile_points);
+      partials[slot * kPartialSize + 20] = ((lds1[0] + lds1[1]) + lds1[2]) + lds1[3];
+    }
+    return;
   }
   // The tile's 21 sums over its 64 lanes: a reduce-SCATTER butterfly.  Every step halves the sums a lane still carries --
   // it keeps one half, adds what its partner (lane ^ 32, 16, 8, 4, 2) sends of that half, and sends the other -- so 31
@@ -1362,6 +1393,25 @@ __global__ __launch_bounds__(256) void reg_finalize_kernel(const ConstraintDev* 
       v = sgn[p] * sgn[q] * S(map[p], map[q]);
     }
     normal[(size_t)c * kNormalSize + k] = v * f2;
+  }
+}
+
+// The cost-only pass's finalize: slot 20 of the constraint's tile partials summed in reg_finalize_kernel's order (12
+// strided groups, then the groups in order) and scaled by (N / sum w)^2 -- element 0 of the 45-block, bit for bit.
+__global__ __launch_bounds__(64) void reg_finalize_cost_kernel(const ConstraintDev* __restrict__ cons, int n,
+                                                              const int32_t* __restrict__ tile_first,
+                                                              const double* __restrict__ partials, double* __restrict__ cost) {
+  constexpr int G = 12;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 4), grp = threadIdx.x & 15;   // 16 lanes per constraint, 12 of them sum
+  double v = 0.0;
+  if (c < n && grp < G)
+    for (int t = tile_first[c] + grp; t < tile_first[c + 1]; t += G) v += partials[(size_t)t * kPartialSize + 20];
+  double total = 0.0;
+#pragma unroll
+  for (int g = 0; g < G; ++g) total += __shfl(v, (int)(threadIdx.x & ~15u) + g, 64);
+  if (c < n && grp == 0) {
+    const double f = cons[c].factor;
+    cost[c] = total * (f * f);
   }
 }
 
@@ -2303,6 +2353,13 @@ int vgx_reg_batch_choose_outputs(vgx_reg_batch b, const double* poses, int32_t n
                                  int32_t chosen[3], float* ms_chosen, float* ms_trials) {
   if (!b || !poses || !d_residuals || !chosen || n_candidates <= 0 || launches <= 0) return VGX_ERR_INVALID;
   vgx_ctx ctx = b->ctx;
+  // Every trial is launches + 1 evaluations of the batch, and an evaluation of a SAMPLING batch draws: it would leave every
+  // reference point set's std::mt19937 dozens of evaluations further on, silently -- "one evaluation of the batch = one
+  // Evaluate of every constraint in list order" would no longer describe what the caller's next evaluation returns.  The
+  // placement of the row arrays does not depend on which points are drawn: choose with an all-points batch of the same sizes.
+  if (b->any_sampling)
+    return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_batch_choose_outputs: a sampling batch (its trial evaluations would advance the "
+                                           "sampling engines); choose the arrays with an all-points batch of the same sizes");
   for (int k = 0; k < n_candidates; ++k)
     if (!d_residuals[k] || (d_jac_ref && !d_jac_ref[k]) || (d_jac_read && !d_jac_read[k]))
       return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_batch_choose_outputs: a candidate is NULL");
@@ -2384,23 +2441,18 @@ int vgx_reg_batch_choose_outputs(vgx_reg_batch b, const double* poses, int32_t n
   return VGX_OK;
 }
 
-int vgx_reg_batch_evaluate_normal(vgx_reg_batch b, const double* poses, int32_t n_nodes,
-                                  void* d_normal, double* normal_host, int32_t* status) {
-  if (!b || !poses) return VGX_ERR_INVALID;
+}  // extern "C"
+
+// The fused pass's tile kernel (every solver evaluation): all 21 sums per tile, or -- cost_only -- the squared residual
+// alone.  The caller holds ctx->mu and has uploaded the pose packs.
+template <bool COST_ONLY>
+static int launch_fused_tiles(vgx_reg_batch b) {
   vgx_ctx ctx = b->ctx;
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  vgx_reg_batch ex = b;
-  VGX_HIP(ctx, hipSetDevice(ctx->device));
-  int rc = batch_begin(b);
-  if (rc == VGX_OK) rc = batch_upload_packs(b, poses, n_nodes, status);
-  if (rc != VGX_OK) return rc;
-  if (b->n == 0) return VGX_OK;
-  double* out = d_normal ? (double*)d_normal : b->d_normal;
-  const int n_tiles = (int)ex->reduce_tiles.size();
-  if (!ex->launch_order_made && n_tiles > 0) {
-    rc = apply_launch_order(b, ex->reduce_tiles, ex->d_reduce_tiles, ex->host_tile_first, /*points_pass=*/false);
+  const int n_tiles = (int)b->reduce_tiles.size();
+  if (!b->launch_order_made && n_tiles > 0) {
+    int rc = apply_launch_order(b, b->reduce_tiles, b->d_reduce_tiles, b->host_tile_first, /*points_pass=*/false);
     if (rc != VGX_OK) return rc;
-    ex->launch_order_made = true;
+    b->launch_order_made = true;
   }
   static const int variant = [] {
     const char* e = getenv("VGX_FUSED_KERNEL");  // A/B switch (profiles/ab_fused2.sh)
@@ -2409,9 +2461,9 @@ int vgx_reg_batch_evaluate_normal(vgx_reg_batch b, const double* poses, int32_t 
   if (n_tiles > 0) {
     dim3 grid(n_tiles), block(kBlockThreads);
     const int vps = b->regs[0]->reading->vps;
-#define VGX_LAUNCH_LEAN(VPS, LAYOUT, PPT, ACC, W)                                                             \
-  hipLaunchKernelGGL((reg_eval_reduce_lean_kernel<VPS, LAYOUT, PPT, ACC, W>), grid, block, 0, ctx->stream,  \
-                     b->d_desc, b->d_pack, ex->d_reduce_tiles, n_tiles, b->d_tile_first, b->d_partials)
+#define VGX_LAUNCH_LEAN(VPS, LAYOUT, PPT, ACC, W)                                                                       \
+  hipLaunchKernelGGL((reg_eval_reduce_lean_kernel<VPS, LAYOUT, PPT, ACC, W, COST_ONLY>), grid, block, 0, ctx->stream,  \
+                     b->d_desc, b->d_pack, b->d_reduce_tiles, n_tiles, b->d_tile_first, b->d_partials)
 #define VGX_LEAN_CASE(CODE, PPT, ACC, W)                                  \
   case CODE:                                                              \
     if (vps == 16) VGX_LAUNCH_LEAN(16, 0, PPT, ACC, W);                   \
@@ -2423,6 +2475,12 @@ int vgx_reg_batch_evaluate_normal(vgx_reg_batch b, const double* poses, int32_t 
     } else if (b->layout == 2) {
       if (vps == 16) VGX_LAUNCH_LEAN(16, 2, 2, float, 6);
       else VGX_LAUNCH_LEAN(8, 2, 2, float, 6);
+    } else if (COST_ONLY) {
+      // one variant: with a single accumulator the register budget no longer chooses between them (the cost is the same
+      // bits as any f32-accumulating variant's; VGX_FUSED_KERNEL=421, the f64 one, has no cost-only twin)
+      if (variant == 421) return set_error(ctx, VGX_ERR_INVALID, "VGX_FUSED_KERNEL=421 (f64 accumulators) has no cost-only form");
+      if (vps == 16) VGX_LAUNCH_LEAN(16, 0, 2, float, 6);
+      else VGX_LAUNCH_LEAN(8, 0, 2, float, 6);
     } else
     switch (variant) {
       VGX_LEAN_CASE(421, 2, double, 4);
@@ -2438,12 +2496,58 @@ int vgx_reg_batch_evaluate_normal(vgx_reg_batch b, const double* poses, int32_t 
 #undef VGX_LAUNCH_LEAN
     VGX_HIP(ctx, hipGetLastError());
   }
+  return VGX_OK;
+}
+
+extern "C" {
+
+int vgx_reg_batch_evaluate_normal(vgx_reg_batch b, const double* poses, int32_t n_nodes,
+                                  void* d_normal, double* normal_host, int32_t* status) {
+  if (!b || !poses) return VGX_ERR_INVALID;
+  vgx_ctx ctx = b->ctx;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  VGX_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = batch_begin(b);
+  if (rc == VGX_OK) rc = batch_upload_packs(b, poses, n_nodes, status);
+  if (rc != VGX_OK) return rc;
+  if (b->n == 0) return VGX_OK;
+  double* out = d_normal ? (double*)d_normal : b->d_normal;
+  rc = launch_fused_tiles<false>(b);
+  if (rc != VGX_OK) return rc;
   hipLaunchKernelGGL(reg_finalize_kernel, dim3(b->n), dim3(256), 0, ctx->stream, b->d_desc,
                      b->d_tile_first, b->d_partials, out);
   VGX_HIP(ctx, hipGetLastError());
   if (normal_host) {
     VGX_HIP(ctx, hipMemcpyAsync(normal_host, out, (size_t)b->n * kNormalSize * sizeof(double),
                                 hipMemcpyDeviceToHost, ctx->stream));
+    VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return VGX_OK;
+}
+
+// One evaluation of every constraint's COST alone (include/voxgraph_amd.h): what Ceres asks for at every trial step
+// (`jacobians == nullptr`, registration_cost_function.cpp:179).  cost[c] = r^T r of constraint c, already scaled by
+// (N / sum w)^2: element 0 of vgx_reg_batch_evaluate_normal's 45-block at the same poses, bit for bit.
+int vgx_reg_batch_evaluate_cost(vgx_reg_batch b, const double* poses, int32_t n_nodes, void* d_cost, double* cost_host,
+                                int32_t* status) {
+  if (!b || !poses) return VGX_ERR_INVALID;
+  vgx_ctx ctx = b->ctx;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  VGX_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = batch_begin(b);
+  if (rc == VGX_OK) rc = batch_upload_packs(b, poses, n_nodes, status);
+  if (rc != VGX_OK) return rc;
+  if (b->n == 0) return VGX_OK;
+  // (the internal [n][45] array's first n doubles when the caller passes no device array: a cost-only evaluation
+  // invalidates nothing the caller can see -- vgx_reg_batch_evaluate_normal rewrites the array before anyone reads it)
+  double* out = d_cost ? (double*)d_cost : b->d_normal;
+  rc = launch_fused_tiles<true>(b);
+  if (rc != VGX_OK) return rc;
+  hipLaunchKernelGGL(reg_finalize_cost_kernel, dim3((unsigned)((b->n + 3) / 4)), dim3(64), 0, ctx->stream, b->d_desc, (int)b->n,
+                     b->d_tile_first, b->d_partials, out);
+  VGX_HIP(ctx, hipGetLastError());
+  if (cost_host) {
+    VGX_HIP(ctx, hipMemcpyAsync(cost_host, out, (size_t)b->n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
   return VGX_OK;

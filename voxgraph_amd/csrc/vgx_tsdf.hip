@@ -28,7 +28,6 @@
 #include <rocprim/rocprim.hpp>  // device radix sort (MergedTsdfIntegrator's bundleRays)
 
 #include "vgx_tsdf_internal.h"
-#include "voxgraph_amd_bench.h"  // vgx_tsdf_integrator_walk_stats
 
 #pragma clang fp contract(off)
 
@@ -1154,7 +1153,7 @@ int vgx_tsdf_integrator_destroy(vgx_tsdf_integrator I) {
   if (!I) return VGX_ERR_INVALID;
   (void)hipSetDevice(I->ctx->device);
   (void)hipStreamSynchronize(I->ctx->tsdf_stream);
-  void* ptrs[] = {I->dev.start_set, I->dev.observed_set, I->dev.n_updates, I->d_points, I->d_rgba, I->d_wg_stats,
+  void* ptrs[] = {I->dev.start_set, I->dev.observed_set, I->dev.n_updates, I->d_points, I->d_rgba, I->d_wg_stats, I->d_trace,
                   I->d_mkeys[0], I->d_mkeys[1], I->d_midx[0], I->d_midx[1], I->d_mstart, I->d_mcounters, I->d_msort,
                   I->d_mrank, I->d_gpg, I->d_gcolor, I->d_gflags, I->d_gcount, I->d_okey[0], I->d_okey[1], I->d_oidx[0],
                   I->d_oidx[1], I->d_osort};
@@ -1305,7 +1304,7 @@ static int integrate_locked(vgx_tsdf_integrator I, const float T[7], const void*
         I->dev.wg_stats = I->d_wg_stats;
         I->wg_stats_rows = wgs;
       }
-      VGX_HIP(ctx, launch_racing_scan(ctx->tsdf_stream, I->layer->dev, I->dev, T, (const float*)d_points, (const uint32_t*)d_rgba,
+      VGX_HIP(ctx, (I->racing_launch ? I->racing_launch : launch_racing_scan)(ctx->tsdf_stream, I->layer->dev, I->dev, T, (const float*)d_points, (const uint32_t*)d_rgba,
                                       (long long)n, (int)freespace, n_updates != nullptr, I->cloud_width));
     } else {
       dim3 grid((unsigned)((n + 255) / 256)), block(256);
@@ -1508,55 +1507,6 @@ int vgx_tsdf_integrate_device(vgx_tsdf_integrator I, const float T[7], const voi
   if (!I || !T || n < 0 || (n > 0 && !d_points)) return VGX_ERR_INVALID;
   std::lock_guard<std::mutex> own(I->mu);
   return integrate_locked(I, T, d_points, d_rgba, n, freespace, n_updates);
-}
-
-// test tooling (include/voxgraph_amd_bench.h): the reproducible mode's bounded speculation.  A scan whose complete
-// walks exceed `threshold` steps is written out `depth` steps per ray at first and extended where a ray ran on;
-// defaults 32 and 8 Mi.  Results do not depend on either (vgx_tsdf_det.hip); small values make small test scans
-// go through the extension, the marks kept between scans and the warm second attempt.
-int vgx_tsdf_integrator_set_speculation(vgx_tsdf_integrator I, int32_t depth, int64_t threshold) {
-  if (!I || depth < 1 || threshold < 0 || threshold >= (1ll << 32)) return VGX_ERR_INVALID;
-  std::lock_guard<std::mutex> own(I->mu);
-  I->det_cap = (uint32_t)depth;
-  I->det_cap_threshold = (uint32_t)threshold;
-  return VGX_OK;
-}
-
-// bench header: what the rays of the last COUNTED racing scan did (n_updates != NULL resets the statistics before the
-// scan and makes the kernel gather them): see include/voxgraph_amd_bench.h for the seven numbers
-int vgx_tsdf_integrator_walk_stats(vgx_tsdf_integrator I, int64_t stats[7]) {
-  if (!I || !stats) return VGX_ERR_INVALID;
-  std::lock_guard<std::mutex> own(I->mu);
-  vgx_ctx ctx = I->ctx;
-  std::lock_guard<std::mutex> lk(ctx->tsdf_mu);
-  VGX_HIP(ctx, hipSetDevice(ctx->device));
-  unsigned long long u[kScanStatWords - 1] = {};
-  VGX_HIP(ctx, hipMemcpyAsync(u, I->dev.n_updates + 1, sizeof(u), hipMemcpyDeviceToHost, ctx->tsdf_stream));
-  VGX_HIP(ctx, hipStreamSynchronize(ctx->tsdf_stream));
-  for (int k = 0; k < kScanStatWords - 1; ++k) stats[k] = (int64_t)u[k];
-  return VGX_OK;
-}
-
-// bench header: the rows the workgroups of the last counted racing scan left (stamps + work counts)
-int vgx_tsdf_integrator_read_trace(vgx_tsdf_integrator I, int64_t* rows, int64_t max_workgroups, int64_t* n_workgroups,
-                                   int64_t* clock_khz) {
-  if (!I || !n_workgroups || max_workgroups < 0) return VGX_ERR_INVALID;
-  std::lock_guard<std::mutex> own(I->mu);
-  vgx_ctx ctx = I->ctx;
-  std::lock_guard<std::mutex> lk(ctx->tsdf_mu);
-  VGX_HIP(ctx, hipSetDevice(ctx->device));
-  *n_workgroups = I->wg_stats_rows;
-  if (clock_khz) {
-    int khz = 100000;
-    (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device);
-    *clock_khz = khz;
-  }
-  const long long take = I->wg_stats_rows < max_workgroups ? I->wg_stats_rows : max_workgroups;
-  if (rows && take > 0) {
-    VGX_HIP(ctx, hipMemcpyAsync(rows, I->d_wg_stats, (size_t)take * kWgStatWords * 8, hipMemcpyDeviceToHost, ctx->tsdf_stream));
-    VGX_HIP(ctx, hipStreamSynchronize(ctx->tsdf_stream));
-  }
-  return VGX_OK;
 }
 
 int vgx_tsdf_integrate(vgx_tsdf_integrator I, const float T[7], const float* points, const uint8_t* rgba,

@@ -34,6 +34,10 @@ struct TsdfIntegratorDev {
   unsigned long long start_offset, observed_offset;
   unsigned long long* n_updates;  // [kScanStatWords]: voxel updates, then the walk statistics of a counted scan
   unsigned long long* wg_stats;   // counted scans of the cooperative kernel: [workgroups][kWgStatWords]
+  // the event log of a traced racing scan (vgx_tsdf_coop_kernel.h; null in every scan of the product library: the
+  // logging instantiations of the kernel live in libvoxgraph_amd_bench.so, vgx_tsdf_integrator_set_event_trace)
+  unsigned long long* trace;
+  unsigned long long trace_words;
 };
 // a workgroup's row: 0..3 wall_clock64 at its start / rays queued / walk done / end, 4 rays, 5 rounds, 6 per-voxel folds,
 // 7 longest chain of repeated folds, 8..15 what reduce_wg_stats_kernel sums into n_updates[0..7]
@@ -422,6 +426,11 @@ struct vgx_tsdf_integrator_s {
   unsigned long long* d_wg_stats = nullptr;  // counted racing scans: one row per workgroup (grown on demand)
   long long wg_stats_cap = 0, wg_stats_rows = 0;
   int cloud_width = 0;  // vgx_tsdf_integrator_set_cloud_width: points per row of the scans to come (0: unorganised)
+  // the racing scan's launcher: vgx::launch_racing_scan unless the diagnostics library installed its event-logging twin
+  // (same kernel template, TRACE = true; include/voxgraph_amd_bench.h vgx_tsdf_integrator_set_event_trace)
+  hipError_t (*racing_launch)(hipStream_t, const vgx::TsdfLayerDev&, const vgx::TsdfIntegratorDev&, const float*, const float*,
+                              const uint32_t*, long long, int, bool, int) = nullptr;
+  unsigned long long* d_trace = nullptr;   // owned by the integrator once set (freed with it)
   vgx::DetScratch* det = nullptr;  // reproducible mode's buffers (vgx_tsdf_det.hip), grown on demand
   // reproducible mode, bounded speculation (vgx_tsdf_det.hip det_count_kernel): a scan whose complete walks are more
   // than det_cap_threshold steps is written out det_cap steps deep at first.  Nothing but time depends on either;
@@ -451,7 +460,11 @@ void tsdf_request_readback(vgx_tsdf_layer L);
 hipError_t launch_racing_scan(hipStream_t stream, const TsdfLayerDev& L, const TsdfIntegratorDev& I, const float T[7],
                               const float* d_points, const uint32_t* d_rgba, long long n, int freespace, bool stats,
                               int cloud_width);
-long long racing_scan_workgroups(long long n, int cloud_width);
+inline long long racing_scan_workgroups(long long n, int cloud_width) {
+  if (cloud_width > 0 && n % cloud_width == 0)
+    return (long long)((cloud_width + 15) / 16) * ((n / cloud_width + 15) / 16);
+  return (n + 255) / 256;
+}
 // vgx_tsdf_det.hip: one scan in the reproducible mode (vgx_tsdf_config.deterministic); the caller
 // holds the integrator's and the context's locks, the approximate sets have been reset for the scan
 // `order`: order[seq] = index of the point visited seq-th (integration_order "sorted"), nullptr = "mixed"
