@@ -1024,7 +1024,11 @@ def main():
         out["cpu_baseline"] = None
     # second hot path (does not shard: replicas only) -- rank 0, N = 1
     if rank == 0 and world == 1 and not args.no_tsdf:
-        out["tsdf"] = tsdf_bench(capi, ctx, torch)
+        # (thread B of `tsdf.*.latency_under_solve_us`: one fused solver evaluation of the config-3 graph, looped)
+        def solver_step():
+            batch.evaluate_normal(poses, to_host=True)     # (waits for the registration stream alone, as a solver does)
+        out["tsdf"] = tsdf_bench(capi, ctx, torch, solver_step=None if args.no_fused else solver_step,
+                                 solver_ms_alone=(fused or {}).get("stream_ms_per_step"))
         out["finish_submap"] = finish_bench(capi, ctx, args, true_poses)
     # config 5 (every rank takes part: its constraints are sharded like config 3's)
     if not args.no_config5:

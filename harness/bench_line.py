@@ -26,6 +26,17 @@ def _r(x, digits=6):
     return x
 
 
+def _latency(l):
+    """per-scan submit -> complete while a solve runs on the same context: {p50, p99} (+ the scans alone, the cadence)"""
+    if not l:
+        return None
+    if l.get("error"):
+        return {"error": l["error"][:120]}
+    return {"p50": l.get("p50"), "p99": l.get("p99"), "alone_p50": (l.get("alone") or {}).get("p50"),
+            "alone_p99": (l.get("alone") or {}).get("p99"), "cadence_Hz": l.get("cadence_Hz"),
+            "stream_priorities": l.get("stream_priorities")}
+
+
 def _tsdf(t):
     if not t:
         return None
@@ -41,6 +52,7 @@ def _tsdf(t):
                                    "latency_chain_ms", "atomic_peak_Gops", "atomic_achieved_Gops",
                                    "atomic_throughput_ms", "achieved", "peak", "unit", "frac", "hbm_frac")),
             "organised_cloud_ms_per_scan": (rf.get("organised_cloud") or {}).get("back_to_back_ms_per_scan"),
+            "latency_under_solve_us": _latency(t.get("latency_under_solve_us")),
             "merged_ms_per_scan": mg.get("ms_per_scan"),
             "reproducible_ms_per_scan": rm.get("ms_per_scan"),
             "reproducible_ms_per_scan_fresh_integrator": rm.get("ms_per_scan_fresh_integrator"),

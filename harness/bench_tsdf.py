@@ -94,7 +94,7 @@ def session_scans(dirs, scans):
 AGE_PASSES = 4   # untimed sessions before the timed one (steady from ~80 scans: profiles/r05_tsdf_age.txt)
 
 
-def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=8):
+def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=8, solver_step=None, solver_ms_alone=None):
     """Second hot path (TSDF): whole scans resident in HBM, one integratePointCloud per
     scan into the active layer, HIP-event timed.  Two sensor shapes from BASELINE.json:
     RGB-D 640x480 @ 0.05 m voxels (config 4) and OS1-64-shaped LiDAR 64x1024 @ 0.20 m with
@@ -161,6 +161,21 @@ def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=8):
             grew = max(grew, layer_s.growths() - g0)
         gc.enable()
         ms = float(np.median(session_ms))
+        # what a scan costs the mapping thread while the pose graph is being optimised on the same context
+        # (voxgraph_mapper.cpp:218-238): racing scans at the sensor's cadence, thread B looping solver evaluations
+        latency = None
+        if solver_step is not None:
+            from harness.bench_latency import latency_block
+            lay_l = new_layer()
+            integ.setLayer(lay_l)
+            hz, n_lat = (30.0, 45) if sensor == "rgbd" else (10.0, 25)
+            try:
+                latency = latency_block(capi, ctx, torch, integ, poses, dev, n_pts, hz, n_lat, solver_step, solver_ms_alone)
+            except Exception as e:   # noqa: BLE001
+                latency = {"error": repr(e)[:300]}
+            ctx.synchronize()
+            integ.setLayer(layer_s)
+            lay_l.destroy()
         # second pass: voxel updates per scan (the count needs a sync per scan) and, with the stream
         # drained around every launch, the duration of each scan's kernel by itself (HIP events)
         layer2 = new_layer()
@@ -413,6 +428,7 @@ def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=8):
         timed = scans - 1
         alg_bytes_scan = 16.0 * n_pts + 24.0 * updates / timed
         out[name] = {"points_per_scan": n_pts, "scans_timed": timed, "ms_per_scan": ms / timed,
+                     "latency_under_solve_us": latency,
                      "ms_per_scan_fresh_integrator": ms_fresh / timed, "integrator_age_scans": integrator_age,
                      "ms_per_scan_of_each_timed_session": [x / timed for x in session_ms],
                      "protocol": f"one integrator for the session (pointcloud_integrator.cpp:66-75): {integrator_age} scans old "

@@ -70,15 +70,33 @@ VGX_API const char* vgx_last_error(vgx_ctx ctx);
  * runs (the reference finishes a submap on the thread that integrates).  Any entry point may be called from any
  * thread; calls on one side are serialised among themselves (except the drop-in vgx_reg_evaluate, which overlaps on up
  * to eight evaluation streams).  DEVICE pointers handed to vgx_tsdf_integrate*_device must be ready with respect to the
- * TSDF stream (complete, or produced on / ordered before vgx_ctx_get_tsdf_stream()).
+ * TSDF stream (complete, produced on / ordered before vgx_ctx_get_tsdf_stream(), or ordered behind their producer with
+ * vgx_ctx_tsdf_wait_for_stream).  NOTE for callers that set the context's stream to their own (vgx_ctx_set_stream) and
+ * produce scan points on it: since round 5 scans do NOT run on that stream -- order them with
+ * vgx_ctx_tsdf_wait_for_stream(ctx, NULL) before the vgx_tsdf_integrate*_device call, or hand the same stream to
+ * vgx_ctx_set_tsdf_stream as well.
+ *
+ * PRIORITY.  The TSDF side goes first: the context's own TSDF stream is created with the device's highest stream
+ * priority and its own registration stream with the lowest, so that a scan (one short kernel the sensor's cadence waits
+ * for) is dispatched as workgroups of a running solver evaluation (thousands, which nobody waits for one by one) retire
+ * instead of behind all of them -- voxgraph optimises in the background of its mapping thread
+ * (voxgraph_mapper.cpp:218-238).  Measured per-scan latency under a running solve: bench.py
+ * `tsdf.*.latency_under_solve_us`, profiles/r06_scan_latency.txt.  Streams handed in by the caller keep the priority
+ * the caller gave them.  vgx_ctx_stream_priorities: 1 when the own streams were created that way (0: the device offers
+ * one level only, or VGX_STREAM_PRIORITY=0 in the environment -- A/B aid).
  *
  * vgx_ctx_set_stream: launch the registration side on an existing hipStream_t (e.g. the caller's PyTorch stream);
  * vgx_ctx_set_tsdf_stream: the same for the TSDF side (waits for what that side has queued so far).  NULL restores
- * the context's own stream.  vgx_ctx_synchronize waits for both. */
+ * the context's own stream.  vgx_ctx_synchronize waits for both, vgx_ctx_synchronize_tsdf for the TSDF side alone (the
+ * mapping thread's "is my scan in?", whatever the solver has queued).  vgx_ctx_tsdf_wait_for_stream: the TSDF stream
+ * waits ON THE DEVICE for what producer_stream (NULL: the context's registration stream) holds at the time of the call. */
 VGX_API int vgx_ctx_set_stream(vgx_ctx ctx, void* hip_stream);
 VGX_API void* vgx_ctx_get_stream(vgx_ctx ctx);
 VGX_API int vgx_ctx_set_tsdf_stream(vgx_ctx ctx, void* hip_stream);
 VGX_API void* vgx_ctx_get_tsdf_stream(vgx_ctx ctx);
+VGX_API int vgx_ctx_synchronize_tsdf(vgx_ctx ctx);
+VGX_API int vgx_ctx_tsdf_wait_for_stream(vgx_ctx ctx, void* producer_stream);
+VGX_API int vgx_ctx_stream_priorities(vgx_ctx ctx);
 /* How the sampling grids of the submaps created on this context FROM NOW ON are laid out in HBM (set it
  * once, before the first submap; a batch refuses to mix layouts).  Results never depend on it.
  *   VGX_BRICKS_APRON (default)  17^3 floats per block; fewest bytes: fastest where every registration

@@ -89,6 +89,9 @@ SIGNATURES = {
     "vgx_ctx_set_tsdf_stream": (C.c_int, [vp, vp]),
     "vgx_ctx_get_tsdf_stream": (vp, [vp]),
     "vgx_ctx_synchronize": (C.c_int, [vp]),
+    "vgx_ctx_synchronize_tsdf": (C.c_int, [vp]),
+    "vgx_ctx_tsdf_wait_for_stream": (C.c_int, [vp, vp]),
+    "vgx_ctx_stream_priorities": (C.c_int, [vp]),
     "vgx_ctx_set_brick_layout": (C.c_int, [vp, C.c_int32]),
     "vgx_ctx_set_sampling_bricks": (C.c_int, [vp, C.c_int32]),
     "vgx_ctx_timer_start": (C.c_int, [vp]),
@@ -310,6 +313,17 @@ class Context:
 
     def synchronize(self):
         self.check(self.lib.vgx_ctx_synchronize(self.h))
+
+    def synchronize_tsdf(self):
+        """waits for the TSDF side alone (a scan is in), whatever the registration side has queued"""
+        self.check(self.lib.vgx_ctx_synchronize_tsdf(self.h))
+
+    def tsdf_wait_for_stream(self, producer_stream=None):
+        """the TSDF stream waits on the device for what producer_stream (None: the registration stream) holds now"""
+        self.check(self.lib.vgx_ctx_tsdf_wait_for_stream(self.h, vp(int(producer_stream)) if producer_stream else None))
+
+    def stream_priorities(self):
+        return bool(self.lib.vgx_ctx_stream_priorities(self.h))
 
     def set_brick_layout(self, layout):
         """BRICKS_APRON (default) or BRICKS_QUAD, for the submaps created from now on"""

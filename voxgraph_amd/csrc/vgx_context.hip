@@ -329,9 +329,21 @@ int vgx_ctx_create(int device, vgx_ctx* out) {
   if (!ctx) return set_error(nullptr, VGX_ERR_NOMEM, "vgx_ctx_create: out of host memory");
   ctx->device = device;
   ctx->cu_count = prop.multiProcessorCount;
+  // Who goes first when both sides have work: the TSDF side.  A scan is one short kernel (tens of microseconds) that the
+  // sensor's cadence waits for; a solver evaluation is thousands of workgroups that nobody waits for individually
+  // (voxgraph_mapper.cpp:218-238: optimisation runs in the background of the mapping thread).  So the TSDF stream is
+  // created with the device's highest priority and the registration stream with its lowest: the scan's workgroups are
+  // dispatched as soon as workgroups of the evaluation retire instead of queueing behind all of them
+  // (profiles/r06_scan_latency.txt: per-scan latency under a running solve with and without).  VGX_STREAM_PRIORITY=0: both
+  // at the default priority (A/B aid).
+  int prio_least = 0, prio_greatest = 0;
+  const char* prio_env = getenv("VGX_STREAM_PRIORITY");
+  const bool use_prio = !(prio_env && atoi(prio_env) == 0) && hipSetDevice(device) == hipSuccess &&
+                        hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) == hipSuccess;
+  ctx->stream_priorities = use_prio && prio_least != prio_greatest;
   if (hipSetDevice(device) != hipSuccess ||
-      hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&ctx->tsdf_own_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithPriority(&ctx->own_stream, hipStreamNonBlocking, ctx->stream_priorities ? prio_least : 0) != hipSuccess ||
+      hipStreamCreateWithPriority(&ctx->tsdf_own_stream, hipStreamNonBlocking, ctx->stream_priorities ? prio_greatest : 0) != hipSuccess ||
       hipEventCreate(&ctx->ev_start) != hipSuccess ||
       hipEventCreate(&ctx->ev_stop) != hipSuccess ||
       hipEventCreate(&ctx->ev_tsdf_start) != hipSuccess ||
@@ -434,19 +446,60 @@ int vgx_ctx_synchronize(vgx_ctx ctx) {
   return VGX_OK;
 }
 
+// the TSDF side alone: the mapping thread's "is my scan in?" without waiting for a solver evaluation on the other stream
+int vgx_ctx_synchronize_tsdf(vgx_ctx ctx) {
+  if (!ctx) return VGX_ERR_INVALID;
+  hipStream_t st;
+  {
+    std::lock_guard<std::mutex> lk(ctx->tsdf_mu);
+    st = ctx->tsdf_stream;
+  }
+  VGX_HIP(ctx, hipStreamSynchronize(st));
+  return VGX_OK;
+}
+
+// The TSDF stream waits, on the device, for what `producer_stream` holds now (NULL: the context's registration stream): a
+// caller whose scan points are PRODUCED on another stream (a driver, PyTorch, the registration side) orders its
+// vgx_tsdf_integrate*_device calls behind that producer without a host synchronisation.
+int vgx_ctx_tsdf_wait_for_stream(vgx_ctx ctx, void* producer_stream) {
+  if (!ctx) return VGX_ERR_INVALID;
+  hipStream_t producer = (hipStream_t)producer_stream;
+  if (!producer) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    producer = ctx->stream;
+  }
+  std::lock_guard<std::mutex> lk(ctx->tsdf_mu);
+  VGX_HIP(ctx, hipSetDevice(ctx->device));
+  hipEvent_t ev = nullptr;
+  VGX_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  hipError_t e = hipEventRecord(ev, producer);
+  if (e == hipSuccess) e = hipStreamWaitEvent(ctx->tsdf_stream, ev, 0);
+  (void)hipEventDestroy(ev);   // (destroyed once the wait has consumed it: HIP defers the release)
+  VGX_HIP(ctx, e);
+  return VGX_OK;
+}
+
+int vgx_ctx_stream_priorities(vgx_ctx ctx) { return ctx && ctx->stream_priorities ? 1 : 0; }
+
 // The timer brackets BOTH streams of the context (registration side and TSDF side): elapsed = the longer of the two
 // start-to-stop intervals, i.e. the time until everything enqueued in between is done, whichever stream it went to.
 int vgx_ctx_timer_start(vgx_ctx ctx) {
   if (!ctx) return VGX_ERR_INVALID;
   VGX_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
-  VGX_HIP(ctx, hipEventRecord(ctx->ev_tsdf_start, ctx->tsdf_stream));
+  {
+    std::lock_guard<std::mutex> lk(ctx->tsdf_mu);
+    VGX_HIP(ctx, hipEventRecord(ctx->ev_tsdf_start, ctx->tsdf_stream));
+  }
   return VGX_OK;
 }
 
 int vgx_ctx_timer_stop(vgx_ctx ctx, float* elapsed_ms) {
   if (!ctx || !elapsed_ms) return VGX_ERR_INVALID;
   VGX_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
-  VGX_HIP(ctx, hipEventRecord(ctx->ev_tsdf_stop, ctx->tsdf_stream));
+  {
+    std::lock_guard<std::mutex> lk(ctx->tsdf_mu);
+    VGX_HIP(ctx, hipEventRecord(ctx->ev_tsdf_stop, ctx->tsdf_stream));
+  }
   VGX_HIP(ctx, hipEventSynchronize(ctx->ev_stop));
   VGX_HIP(ctx, hipEventSynchronize(ctx->ev_tsdf_stop));
   float a = 0.0f, b = 0.0f;

@@ -154,6 +154,7 @@ struct Context {
   // Lock order where both are taken: integrator -> tsdf_mu -> mu.
   hipStream_t tsdf_own_stream = nullptr;
   hipStream_t tsdf_stream = nullptr;
+  bool stream_priorities = false;  // own streams: TSDF side at the device's highest priority, registration side at its lowest
   hipEvent_t ev_tsdf_start = nullptr, ev_tsdf_stop = nullptr, ev_handover = nullptr;
   std::mutex tsdf_mu;
   std::mutex err_mu;       // guards last_error only (set_error is called with and without `mu`)
