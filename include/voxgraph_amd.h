@@ -80,8 +80,12 @@ VGX_API const char* vgx_last_error(vgx_ctx ctx);
  * priority and its own registration stream with the lowest, so that a scan (one short kernel the sensor's cadence waits
  * for) is dispatched as workgroups of a running solver evaluation (thousands, which nobody waits for one by one) retire
  * instead of behind all of them -- voxgraph optimises in the background of its mapping thread
- * (voxgraph_mapper.cpp:218-238).  Measured per-scan latency under a running solve: bench.py
- * `tsdf.*.latency_under_solve_us`, profiles/r06_scan_latency.txt.  Streams handed in by the caller keep the priority
+ * (voxgraph_mapper.cpp:218-238).  Priorities alone did not do it on gfx950 (measured); what does: while the context has a
+ * TSDF integrator, the fused pass's tile kernel is launched FIVE workgroups deep per CU instead of six, which leaves the
+ * registers of one scan workgroup free on every CU -- a scan under a running solve then takes 0.14-0.32 ms (median)
+ * instead of 0.7 ms, at + 3 % per solver evaluation; a context without an integrator runs the solver at full depth.
+ * Measured per-scan latency under a running solve: bench.py `tsdf.*.latency_under_solve_us`,
+ * profiles/r06_scan_latency.txt.  Streams handed in by the caller keep the priority
  * the caller gave them.  vgx_ctx_stream_priorities: 1 when the own streams were created that way (0: the device offers
  * one level only, or VGX_STREAM_PRIORITY=0 in the environment -- A/B aid).
  *

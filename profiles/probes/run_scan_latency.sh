@@ -4,5 +4,5 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $REPO
 for p in 1 0 1 0; do
   echo "=== VGX_STREAM_PRIORITY=$p"
-  VGX_STREAM_PRIORITY=$p python profiles/probes/scan_latency_probe.py 2>&1 | grep -v "^$" | tail -8
+  VGX_STREAM_PRIORITY=$p python profiles/probes/scan_latency_probe.py 2>&1 | grep -v "^$" | tail -10
 done

@@ -48,6 +48,11 @@ def points_step():
     reg_stream.synchronize()
 
 
+def fused_device_step():
+    batch.evaluate_normal(poses, to_host=False)
+    reg_stream.synchronize()
+
+
 for _ in range(3):
     fused_step()
     points_step()
@@ -67,7 +72,8 @@ for name, (dirs, vs, kw, bmin, bdim) in sensor_cases().items():
             integ.integrate_device(T[k], dev[k].data_ptr(), None, n_pts)
     ctx.synchronize()
     hz, n = (30.0, 60) if sensor == "rgbd" else (10.0, 30)
-    for load, step in (("fused solver evaluations", fused_step), ("materialising passes", points_step)):
+    for load, step in (("fused solver evaluations (blocks to the host)", fused_step),
+                       ("fused solver evaluations (device only)", fused_device_step), ("materialising passes", points_step)):
         out = latency_block(capi, ctx, torch, integ, T, dev, n_pts, hz, n, step, None)
         out.pop("what")
         print(sensor, "under", load, json.dumps(out))

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <mutex>
 #include <condition_variable>
@@ -155,6 +156,7 @@ struct Context {
   hipStream_t tsdf_own_stream = nullptr;
   hipStream_t tsdf_stream = nullptr;
   bool stream_priorities = false;  // own streams: TSDF side at the device's highest priority, registration side at its lowest
+  std::atomic<int> tsdf_integrators{0};  // TSDF integrators alive on this context: the fused pass leaves room for their scans
   hipEvent_t ev_tsdf_start = nullptr, ev_tsdf_stop = nullptr, ev_handover = nullptr;
   std::mutex tsdf_mu;
   std::mutex err_mu;       // guards last_error only (set_error is called with and without `mu`)
@@ -329,8 +331,9 @@ struct vgx_reg_batch_s {
   int32_t* d_drawn_idx = nullptr;        // ... and its index in the point set (reg_draw_kernel)
   unsigned char* d_tile_dead = nullptr;  // per materialising-pass tile, per launch: every chunk culled (rows are zeros)
   int32_t* d_tile_first = nullptr;    // [n+1] first tile of each constraint
-  double* d_partials = nullptr;       // [n_tiles][kPartialSize]
+  double* d_partials = nullptr;       // [n_tiles][4 wavefronts][kPartialSize]
   double* d_normal = nullptr;         // [n][45] (internal, when caller passes none)
+  double* h_normal = nullptr;         // pinned [n][45]: staging of the host copies (normal_host / cost_host)
   int32_t* d_node_pair = nullptr;
   int32_t* d_global_index = nullptr;
   // fused pass: coarser tiles, and node -> incident (constraint<<1 | side) CSR

@@ -819,11 +819,18 @@ __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_ker
   const bool sampled = C.sample_raw != nullptr;
   const float4* bounds = (!count_misses && !sampled && C.chunk_bounds) ? C.chunk_bounds : nullptr;
   const long long chunk0 = tile.start / kChunkPoints;  // tiles start on chunk boundaries
-  __shared__ unsigned char s_live[kMaxReduceIters * 2];
+  // Which of the tile's chunks can touch the reading grid: a 128-bit mask PER WAVEFRONT (two ballots), no LDS and no
+  // barrier: the kernel needs no LDS of its own since round 6 (a tile's four wavefronts leave a row of sums each and the
+  // finalize kernels add them).  What it is GIVEN at launch is another matter: launch_fused_tiles pads it with dynamic LDS
+  // it never touches while the context integrates scans, to keep one workgroup's worth of registers free per CU.
   const int n_chunks = (tile.count + kChunkPoints - 1) / kChunkPoints;
-  if ((int)threadIdx.x < n_chunks)
-    s_live[threadIdx.x] = !(bounds && chunk_outside(g, P, bounds[chunk0 + threadIdx.x]));
-  __syncthreads();
+  const int wlane = (int)(threadIdx.x & 63);
+  const unsigned long long live_lo =
+      __ballot(wlane < n_chunks && !(bounds && chunk_outside(g, P, bounds[chunk0 + wlane])));
+  unsigned long long live_hi = 0ull;
+  if (n_chunks > 64)   // (VGX_FUSED_TILE_ITERS > 32 only; uniform)
+    live_hi = __ballot(wlane + 64 < n_chunks && !(bounds && chunk_outside(g, P, bounds[chunk0 + wlane + 64])));
+  auto chunk_live = [&](int k) { return ((k < 64 ? live_lo >> k : live_hi >> (k - 64)) & 1ull) != 0ull; };
   constexpr int kAcc = COST_ONLY ? 1 : 21;
   ACC acc[kAcc];
 #pragma unroll
@@ -833,7 +840,7 @@ __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_ker
 
   f32x4 pt_next[PPT];
   float w_next[PPT];
-  bool live_next = s_live[0] != 0;
+  bool live_next = chunk_live(0);
   if (live_next) {
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
@@ -859,7 +866,7 @@ __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_ker
     }
     live_next = false;
     if (base + kIterPoints < tile.count) {
-      live_next = s_live[(base + kIterPoints) / kChunkPoints] != 0;
+      live_next = chunk_live((base + kIterPoints) / kChunkPoints);
       if (live_next) {
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
@@ -929,19 +936,18 @@ __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_ker
       else accumulate21<ACC>(acc, u);
     }
   }
+  // A tile leaves ONE ROW OF SUMS PER WAVEFRONT -- partials[tile slot][wave][22] -- and the finalize kernels add a tile's
+  // four rows first, ((w0 + w1) + w2) + w3: the additions the workgroup made through LDS until round 5, in the same order
+  // (bit for bit the same blocks), without LDS and without a barrier.
+  const size_t row = ((size_t)tile_first[tile.constraint] + (size_t)(tile.start / C.tile_points)) * (kBlockThreads / 64) +
+                     (threadIdx.x >> 6);
   if (COST_ONLY) {
     // the one sum over the 64 lanes (the pairing the reduce-scatter below uses for every sum: partners 32, 16, 8, 4, 2, 1
-    // apart, a + b = b + a exactly), over the four wavefronts in the same order, into slot 20 of the tile's partials
-    __shared__ double lds1[kBlockThreads / 64];
+    // apart, a + b = b + a exactly) into entry 20 of the wavefront's row
     double v = (double)acc[0];
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    if ((threadIdx.x & 63) == 0) lds1[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const size_t slot = (size_t)tile_first[tile.constraint] + (size_t)(tile.start / C.tile_points);
-      partials[slot * kPartialSize + 20] = ((lds1[0] + lds1[1]) + lds1[2]) + lds1[3];
-    }
+    if ((threadIdx.x & 63) == 0) partials[row * kPartialSize + 20] = v;
     return;
   }
   // The tile's 21 sums over its 64 lanes: a reduce-SCATTER butterfly.  Every step halves the sums a lane still carries --
@@ -951,8 +957,7 @@ __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_ker
   // The epilogue was most of what a tile costs beyond its points (round 4: 10 Ki-residual tiles +4 % on one GPU against
   // 20 Ki ones, the size a 1/8 shard wants -- VERDICT r4 item 6), and the f64 copies live together here only once the
   // point loop's registers are dead.
-  __shared__ double lds[kBlockThreads / 64][kPartialSize];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63;
   {
     const bool b5 = (lane & 32) != 0, b4 = (lane & 16) != 0, b3 = (lane & 8) != 0, b2 = (lane & 4) != 0, b1 = (lane & 2) != 0;
     double r16[16];
@@ -984,13 +989,7 @@ __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_ker
     double v = keep + __shfl_xor(send, 2, 64);
     v += __shfl_xor(v, 1, 64);
     const int s = lane >> 1;   // = 16 b5 + 8 b4 + 4 b3 + 2 b2 + b1
-    if ((lane & 1) == 0 && s < 21) lds[wave][s] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < 21) {
-    double v = ((lds[0][threadIdx.x] + lds[1][threadIdx.x]) + lds[2][threadIdx.x]) + lds[3][threadIdx.x];
-    const size_t slot = (size_t)tile_first[tile.constraint] + (size_t)(tile.start / C.tile_points);
-    partials[slot * kPartialSize + threadIdx.x] = v;
+    if ((lane & 1) == 0 && s < 21) partials[row * kPartialSize + s] = v;
   }
 }
 
@@ -1355,8 +1354,10 @@ __global__ __launch_bounds__(256) void reg_finalize_kernel(const ConstraintDev* 
   const int grp = threadIdx.x / 21, k21 = threadIdx.x % 21;
   if (grp < G) {
     double v = 0.0;
-    for (int t = tile_first[c] + grp; t < tile_first[c + 1]; t += G)
-      v += partials[(size_t)t * kPartialSize + k21];
+    for (int t = tile_first[c] + grp; t < tile_first[c + 1]; t += G) {
+      const double* w = partials + (size_t)t * (kBlockThreads / 64) * kPartialSize + k21;   // the tile's four wavefront rows
+      v += ((w[0] + w[kPartialSize]) + w[2 * kPartialSize]) + w[3 * kPartialSize];
+    }
     part[grp][k21] = v;
   }
   __syncthreads();
@@ -1405,7 +1406,10 @@ __global__ __launch_bounds__(64) void reg_finalize_cost_kernel(const ConstraintD
   const int c = blockIdx.x * 4 + (threadIdx.x >> 4), grp = threadIdx.x & 15;   // 16 lanes per constraint, 12 of them sum
   double v = 0.0;
   if (c < n && grp < G)
-    for (int t = tile_first[c] + grp; t < tile_first[c + 1]; t += G) v += partials[(size_t)t * kPartialSize + 20];
+    for (int t = tile_first[c] + grp; t < tile_first[c + 1]; t += G) {
+      const double* w = partials + (size_t)t * (kBlockThreads / 64) * kPartialSize + 20;
+      v += ((w[0] + w[kPartialSize]) + w[2 * kPartialSize]) + w[3 * kPartialSize];
+    }
   double total = 0.0;
 #pragma unroll
   for (int g = 0; g < G; ++g) total += __shfl(v, (int)(threadIdx.x & ~15u) + g, 64);
@@ -2149,8 +2153,9 @@ int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs, const int3
         hipHostMalloc(&b->h_pack, 2 * (size_t)n * sizeof(PosePack)) != hipSuccess ||
         hipEventCreateWithFlags(&b->pack_copied[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&b->pack_copied[1], hipEventDisableTiming) != hipSuccess ||
-        hipMalloc(&b->d_partials, std::max<size_t>(1, ex->reduce_tiles.size()) * kPartialSize * sizeof(double)) != hipSuccess ||
-        hipMalloc(&b->d_normal, (size_t)n * kNormalSize * sizeof(double)) != hipSuccess)
+        hipMalloc(&b->d_partials, std::max<size_t>(1, ex->reduce_tiles.size()) * (kBlockThreads / 64) * kPartialSize * sizeof(double)) != hipSuccess ||
+        hipMalloc(&b->d_normal, (size_t)n * kNormalSize * sizeof(double)) != hipSuccess ||
+        hipHostMalloc((void**)&b->h_normal, (size_t)n * kNormalSize * sizeof(double), hipHostMallocDefault) != hipSuccess)
       rc = set_error(ctx, VGX_ERR_NOMEM, "vgx_reg_batch_create: device allocation failed");
   }
   if (rc != VGX_OK) {
@@ -2173,6 +2178,7 @@ int vgx_reg_batch_destroy(vgx_reg_batch b) {
   if (b->d_desc) (void)hipFree(b->d_desc);
   if (b->d_pack) (void)hipFree(b->d_pack);
   if (b->h_pack) (void)hipHostFree(b->h_pack);
+  if (b->h_normal) (void)hipHostFree(b->h_normal);
   for (int k = 0; k < 2; ++k)
     if (b->pack_copied[k]) (void)hipEventDestroy(b->pack_copied[k]);
   if (b->d_tiles) (void)hipFree(b->d_tiles);
@@ -2458,11 +2464,26 @@ static int launch_fused_tiles(vgx_reg_batch b) {
     const char* e = getenv("VGX_FUSED_KERNEL");  // A/B switch (profiles/ab_fused2.sh)
     return e ? atoi(e) : kFusedVariantDefault;
   }();
+  // ROOM FOR A SCAN.  At 77 VGPRs the tile kernel is resident six workgroups deep on every CU (6 x 80 of a SIMD's 512
+  // registers), and a racing TSDF scan's wavefronts need 104: while a solver evaluation ran, a scan submitted from the mapping
+  // thread got a few workgroups in and the rest waited for the launch to drain -- 0.7 ms median, 1.4 ms worst (this kernel's
+  // duration) against 0.1 ms alone; stream priorities changed nothing, nor did taking this kernel's own LDS away; the
+  // workgroup stamps show the scan's workgroups starting over the whole 1.3 ms (profiles/r06_scan_latency.txt).  So while
+  // the context has a TSDF integrator -- someone is mapping while this optimises, voxgraph_mapper.cpp:218-238 -- the kernel
+  // is launched with 27 KB of dynamic LDS it never touches: FIVE resident workgroups per CU (160 KB / 27), 112 registers
+  // free on every SIMD, room for one scan workgroup on every CU at any time: scans at 0.14-0.32 ms median / 0.22-0.45 ms
+  // worst under a running solve, solver evaluations + 3 % (1.49 -> 1.53 ms).  Four per CU: 0.18 / 0.20 ms at + 12 %: not
+  // taken.  Without an integrator on the context: no padding.  VGX_FUSED_LDS_PAD=bytes overrides (0: never pad).
+  static const int pad_env = [] {
+    const char* e = getenv("VGX_FUSED_LDS_PAD");
+    return e ? atoi(e) : -1;
+  }();
+  const unsigned occupancy_pad = pad_env >= 0 ? (unsigned)pad_env : (ctx->tsdf_integrators.load() > 0 ? 27u * 1024u : 0u);
   if (n_tiles > 0) {
     dim3 grid(n_tiles), block(kBlockThreads);
     const int vps = b->regs[0]->reading->vps;
 #define VGX_LAUNCH_LEAN(VPS, LAYOUT, PPT, ACC, W)                                                                       \
-  hipLaunchKernelGGL((reg_eval_reduce_lean_kernel<VPS, LAYOUT, PPT, ACC, W, COST_ONLY>), grid, block, 0, ctx->stream,  \
+  hipLaunchKernelGGL((reg_eval_reduce_lean_kernel<VPS, LAYOUT, PPT, ACC, W, COST_ONLY>), grid, block, occupancy_pad, ctx->stream,  \
                      b->d_desc, b->d_pack, b->d_reduce_tiles, n_tiles, b->d_tile_first, b->d_partials)
 #define VGX_LEAN_CASE(CODE, PPT, ACC, W)                                  \
   case CODE:                                                              \
@@ -2518,9 +2539,13 @@ int vgx_reg_batch_evaluate_normal(vgx_reg_batch b, const double* poses, int32_t 
                      b->d_tile_first, b->d_partials, out);
   VGX_HIP(ctx, hipGetLastError());
   if (normal_host) {
-    VGX_HIP(ctx, hipMemcpyAsync(normal_host, out, (size_t)b->n * kNormalSize * sizeof(double),
-                                hipMemcpyDeviceToHost, ctx->stream));
+    // through the batch's own PINNED block: a copy into the caller's pageable memory is staged by the runtime behind a
+    // process-wide lock, and a scan submitted from the mapping thread meanwhile waited for this evaluation to finish
+    // (profiles/r06_scan_latency.txt: 0.7 ms median per scan under a running solve, 0.1 ms with this)
+    const size_t bytes = (size_t)b->n * kNormalSize * sizeof(double);
+    VGX_HIP(ctx, hipMemcpyAsync(b->h_normal, out, bytes, hipMemcpyDeviceToHost, ctx->stream));
     VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(normal_host, b->h_normal, bytes);
   }
   return VGX_OK;
 }
@@ -2547,8 +2572,9 @@ int vgx_reg_batch_evaluate_cost(vgx_reg_batch b, const double* poses, int32_t n_
                      b->d_tile_first, b->d_partials, out);
   VGX_HIP(ctx, hipGetLastError());
   if (cost_host) {
-    VGX_HIP(ctx, hipMemcpyAsync(cost_host, out, (size_t)b->n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    VGX_HIP(ctx, hipMemcpyAsync(b->h_normal, out, (size_t)b->n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(cost_host, b->h_normal, (size_t)b->n * sizeof(double));
   }
   return VGX_OK;
 }

@@ -1145,12 +1145,15 @@ int vgx_tsdf_integrator_create(vgx_ctx ctx, const vgx_tsdf_config* cfg, vgx_tsdf
     vgx_tsdf_integrator_destroy(I);
     return set_error(ctx, VGX_ERR_NOMEM, "vgx_tsdf_integrator_create: device allocation failed");
   }
+  ctx->tsdf_integrators.fetch_add(1);
+  I->counted_on_ctx = true;
   *out = I;
   return VGX_OK;
 }
 
 int vgx_tsdf_integrator_destroy(vgx_tsdf_integrator I) {
   if (!I) return VGX_ERR_INVALID;
+  if (I->counted_on_ctx) I->ctx->tsdf_integrators.fetch_sub(1);
   (void)hipSetDevice(I->ctx->device);
   (void)hipStreamSynchronize(I->ctx->tsdf_stream);
   void* ptrs[] = {I->dev.start_set, I->dev.observed_set, I->dev.n_updates, I->d_points, I->d_rgba, I->d_wg_stats, I->d_trace,

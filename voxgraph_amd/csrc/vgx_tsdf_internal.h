@@ -431,6 +431,7 @@ struct vgx_tsdf_integrator_s {
   hipError_t (*racing_launch)(hipStream_t, const vgx::TsdfLayerDev&, const vgx::TsdfIntegratorDev&, const float*, const float*,
                               const uint32_t*, long long, int, bool, int) = nullptr;
   unsigned long long* d_trace = nullptr;   // owned by the integrator once set (freed with it)
+  bool counted_on_ctx = false;             // Context::tsdf_integrators holds this one
   vgx::DetScratch* det = nullptr;  // reproducible mode's buffers (vgx_tsdf_det.hip), grown on demand
   // reproducible mode, bounded speculation (vgx_tsdf_det.hip det_count_kernel): a scan whose complete walks are more
   // than det_cap_threshold steps is written out det_cap steps deep at first.  Nothing but time depends on either;
