@@ -28,6 +28,8 @@ constexpr FloatingPoint kCoordinateEpsilon = 1e-6;
 
 struct Color {
   uint8_t r = 0, g = 0, b = 0, a = 0;
+  Color() {}
+  Color(uint8_t r_, uint8_t g_, uint8_t b_, uint8_t a_ = 255) : r(r_), g(g_), b(b_), a(a_) {}
 };
 
 // floor(p * inv + eps) per axis
