@@ -48,6 +48,7 @@ class Layer {
     blocks_.emplace(index, block);
     return block;
   }
+  size_t getNumberOfAllocatedBlocks() const { return blocks_.size(); }
   void getAllAllocatedBlocks(BlockIndexList* out) const {
     out->clear();
     for (const auto& kv : blocks_) out->push_back(kv.first);
