@@ -30,12 +30,12 @@ def tsdf_sources_sha():
 
 def profiled_launches():
     """kernel launches per scan of the sort-based paths, from the committed rocprofv3 trace of the same sensor shapes
-    (profiles/r05_tsdf_launches.txt, made by profiles/tsdf_launches.sh): {("fast" | "merged", "lidar" | "rgbd"): launches}
+    (profiles/r06_tsdf_launches.txt, made by profiles/tsdf_launches.sh): {("fast" | "merged", "lidar" | "rgbd"): launches}
     -- and only if the trace was taken on THESE sources (the script records their hash; ADVICE r4: a stale count divided
     into a fresh time is a wrong microseconds-per-launch without notice).  Returns (counts, note)."""
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    path = os.path.join(root, "profiles", "r05_tsdf_launches.txt")
+    path = os.path.join(root, "profiles", "r06_tsdf_launches.txt")
     out, key, sha = {}, None, None
     try:
         for line in open(path):
@@ -50,11 +50,11 @@ def profiled_launches():
                 out[key] = int(m.group(1))
                 key = None
     except OSError:
-        return {}, "no committed trace (profiles/r05_tsdf_launches.txt)"
+        return {}, "no committed trace (profiles/r06_tsdf_launches.txt)"
     now = tsdf_sources_sha()
     if sha is None or now is None or sha != now:
         return {}, f"the committed trace was taken on other sources (trace {sha}, these {now}): launch counts dropped"
-    return out, f"profiles/r05_tsdf_launches.txt, sources {sha}"
+    return out, f"profiles/r06_tsdf_launches.txt, sources {sha}"
 
 
 def sensor_cases():

@@ -35,11 +35,18 @@ def rows(pattern):
     return out
 
 
-def dispatches(prefix, kernel):
-    """[{counter: value, "grid": n}] per dispatch of `kernel`, in dispatch order"""
+def is_cost_only(name):
+    """the cost-only instantiation of the fused tile kernel (round 6): reg_eval_reduce_lean_kernel<..., true>"""
+    import re
+    return bool(re.search(r"reg_eval_reduce_lean_kernel<[^>]*true>", name))
+
+
+def dispatches(prefix, kernel, cost_only=False):
+    """[{counter: value, "grid": n}] per dispatch of `kernel`, in dispatch order (cost_only: that instantiation alone,
+    else every other one)"""
     d = {}
     for x in rows(f"{prefix}/**/*counter_collection.csv"):
-        if kernel in x.get("Kernel_Name", ""):
+        if kernel in x.get("Kernel_Name", "") and is_cost_only(x.get("Kernel_Name", "")) == cost_only:
             e = d.setdefault(int(x["Dispatch_Id"]), {"grid": int(x["Grid_Size"])})
             e[x["Counter_Name"]] = float(x["Counter_Value"])
     return [d[k] for k in sorted(d)]
@@ -69,12 +76,12 @@ def mean(v):
     return sum(v) / len(v) if v else None
 
 
-def by_grid(trace, kernel):
+def by_grid(trace, kernel, cost_only=False):
     """kernel-trace rows of one kernel grouped per grid size, in order of first appearance:
     [(grid, [duration_ns, ...])]"""
     g = collections.OrderedDict()
     for x in trace:
-        if kernel in x.get("Kernel_Name", ""):
+        if kernel in x.get("Kernel_Name", "") and is_cost_only(x.get("Kernel_Name", "")) == cost_only:
             g.setdefault(int(x["Grid_Size_X"]), []).append(int(x["End_Timestamp"]) - int(x["Start_Timestamp"]))
     return list(g.items())
 
@@ -139,6 +146,9 @@ def main():
         pw[nm] = entry(durs, grid=grid)
     if bench and "config3_fused" in pw:
         pw["config3_fused"]["bench_stream_ms_per_step_incl_finalize_assemble"] = bench["fused"]["stream_ms_per_step"]
+    # the cost-only instantiation (vgx_reg_batch_evaluate_cost), same grids in the same order
+    for (grid, durs), nm in zip(by_grid(trace, FUSED, cost_only=True), ["config3_fused_cost_only", "full_overlap_fused_cost_only"]):
+        pw[nm] = entry(durs, grid=grid)
     # the bench's own TSDF section only: the config-2 session that follows integrates scans of the
     # same size (synth_city_scan_kernel marks where it starts)
     cut = next((i for i, x in enumerate(trace) if "synth_city_scan" in x.get("Kernel_Name", "")), len(trace))
