@@ -5,12 +5,17 @@
 // Covariance, NumericDiffCostFunction, Solver::Summary reports) for the reference's OWN callers -- pose_graph.cpp,
 // registration_constraint.cpp, node*.cpp, submap_registration_helper.cpp -- to compile against it
 // (oracle/ref_driver/callers_check.cpp).
+// Round 6: Jet + a real AutoDiffCostFunction (the reference's relative_pose_cost_function_inl.h, i.e. its odometry /
+// loop-closure / absolute-pose constraints, now compile and differentiate against it), and a solver loop that
+// evaluates trial steps cost-only (`jacobians == nullptr`) as Ceres' trust-region minimizer does.
 #ifndef TESTS_STUBS_CERES_CERES_H_
 #define TESTS_STUBS_CERES_CERES_H_
 #include <cmath>
 #include <cstdint>
 #include <deque>
+#include <ostream>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 namespace ceres {
@@ -48,16 +53,144 @@ class SizedCostFunction : public CostFunction {
 inline double cos(double x) { return std::cos(x); }
 inline double sin(double x) { return std::sin(x); }
 inline double floor(double x) { return std::floor(x); }
-// AutoDiffCostFunction: residuals through the functor with T = double; no Jets here, so
-// Jacobians cannot be produced (Evaluate returns false if they are requested)
+
+// ---- ceres::Jet: first-order forward-mode dual numbers (value a + N partial derivatives v), what
+// AutoDiffCostFunction feeds a functor.  Only the operations voxgraph's functors use
+// (relative_pose_cost_function_inl.h, normalize_angle.h, angle_local_parameterization.h): + - * /, comparisons on the
+// value, cos, sin, floor (piecewise constant: zero derivative, as in Ceres), abs, streaming.
+template <typename T, int N>
+struct Jet {
+  T a;
+  T v[N];
+  Jet() : a() {
+    for (int k = 0; k < N; ++k) v[k] = T();
+  }
+  template <typename U, typename = typename std::enable_if<std::is_arithmetic<U>::value>::type>
+  Jet(const U& value) : a(static_cast<T>(value)) {  // NOLINT (implicit: T(0), static_cast<T>(double), 2.0 * x)
+    for (int k = 0; k < N; ++k) v[k] = T();
+  }
+  Jet(const T& value, int k_one) : a(value) {
+    for (int k = 0; k < N; ++k) v[k] = k == k_one ? T(1) : T();
+  }
+  Jet& operator+=(const Jet& y) { return *this = *this + y; }
+  Jet& operator-=(const Jet& y) { return *this = *this - y; }
+  Jet& operator*=(const Jet& y) { return *this = *this * y; }
+  Jet& operator/=(const Jet& y) { return *this = *this / y; }
+};
+template <typename T, int N>
+Jet<T, N> operator+(const Jet<T, N>& x, const Jet<T, N>& y) {
+  Jet<T, N> r;
+  r.a = x.a + y.a;
+  for (int k = 0; k < N; ++k) r.v[k] = x.v[k] + y.v[k];
+  return r;
+}
+template <typename T, int N>
+Jet<T, N> operator-(const Jet<T, N>& x, const Jet<T, N>& y) {
+  Jet<T, N> r;
+  r.a = x.a - y.a;
+  for (int k = 0; k < N; ++k) r.v[k] = x.v[k] - y.v[k];
+  return r;
+}
+template <typename T, int N>
+Jet<T, N> operator-(const Jet<T, N>& x) {
+  Jet<T, N> r;
+  r.a = -x.a;
+  for (int k = 0; k < N; ++k) r.v[k] = -x.v[k];
+  return r;
+}
+template <typename T, int N>
+Jet<T, N> operator*(const Jet<T, N>& x, const Jet<T, N>& y) {
+  Jet<T, N> r;
+  r.a = x.a * y.a;
+  for (int k = 0; k < N; ++k) r.v[k] = x.a * y.v[k] + x.v[k] * y.a;
+  return r;
+}
+template <typename T, int N>
+Jet<T, N> operator/(const Jet<T, N>& x, const Jet<T, N>& y) {
+  Jet<T, N> r;
+  const T inv = T(1) / y.a;
+  r.a = x.a * inv;
+  for (int k = 0; k < N; ++k) r.v[k] = (x.v[k] - r.a * y.v[k]) * inv;
+  return r;
+}
+#define VGX_JET_MIXED(op)                                                                                     \
+  template <typename T, int N, typename U, typename = typename std::enable_if<std::is_arithmetic<U>::value>::type> \
+  Jet<T, N> operator op(const Jet<T, N>& x, const U& s) { return x op Jet<T, N>(s); }                        \
+  template <typename T, int N, typename U, typename = typename std::enable_if<std::is_arithmetic<U>::value>::type> \
+  Jet<T, N> operator op(const U& s, const Jet<T, N>& y) { return Jet<T, N>(s) op y; }
+VGX_JET_MIXED(+)
+VGX_JET_MIXED(-)
+VGX_JET_MIXED(*)
+VGX_JET_MIXED(/)
+#undef VGX_JET_MIXED
+#define VGX_JET_COMPARE(op)                                                                       \
+  template <typename T, int N>                                                                    \
+  bool operator op(const Jet<T, N>& x, const Jet<T, N>& y) { return x.a op y.a; }                 \
+  template <typename T, int N, typename U, typename = typename std::enable_if<std::is_arithmetic<U>::value>::type> \
+  bool operator op(const Jet<T, N>& x, const U& s) { return x.a op static_cast<T>(s); }           \
+  template <typename T, int N, typename U, typename = typename std::enable_if<std::is_arithmetic<U>::value>::type> \
+  bool operator op(const U& s, const Jet<T, N>& y) { return static_cast<T>(s) op y.a; }
+VGX_JET_COMPARE(<)
+VGX_JET_COMPARE(<=)
+VGX_JET_COMPARE(>)
+VGX_JET_COMPARE(>=)
+VGX_JET_COMPARE(==)
+VGX_JET_COMPARE(!=)
+#undef VGX_JET_COMPARE
+template <typename T, int N>
+Jet<T, N> cos(const Jet<T, N>& x) {
+  Jet<T, N> r;
+  r.a = std::cos(x.a);
+  const T d = -std::sin(x.a);
+  for (int k = 0; k < N; ++k) r.v[k] = d * x.v[k];
+  return r;
+}
+template <typename T, int N>
+Jet<T, N> sin(const Jet<T, N>& x) {
+  Jet<T, N> r;
+  r.a = std::sin(x.a);
+  const T d = std::cos(x.a);
+  for (int k = 0; k < N; ++k) r.v[k] = d * x.v[k];
+  return r;
+}
+template <typename T, int N>
+Jet<T, N> floor(const Jet<T, N>& x) {
+  return Jet<T, N>(std::floor(x.a));
+}
+template <typename T, int N>
+Jet<T, N> abs(const Jet<T, N>& x) {
+  return x.a < T(0) ? -x : x;
+}
+template <typename T, int N>
+std::ostream& operator<<(std::ostream& os, const Jet<T, N>& x) {
+  os << "[" << x.a << " ;";
+  for (int k = 0; k < N; ++k) os << " " << x.v[k];
+  return os << "]";
+}
+
+// AutoDiffCostFunction<Functor, kNumResiduals, N0, N1>: the functor with T = double when no Jacobian is asked for, with
+// T = Jet<double, N0 + N1> otherwise (parameter k of block b carries the unit derivative N0 * b + k): residual i's
+// partial derivatives are row i of the two Jacobian blocks, row-major -- Ceres' contract.
 template <typename Functor, int kNumResiduals, int N0, int N1>
 class AutoDiffCostFunction : public SizedCostFunction<kNumResiduals, N0, N1> {
  public:
   explicit AutoDiffCostFunction(Functor* functor) : functor_(functor) {}
   ~AutoDiffCostFunction() override { delete functor_; }
   bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const override {
-    if (jacobians) return false;
-    return (*functor_)(parameters[0], parameters[1], residuals);
+    if (!jacobians) return (*functor_)(parameters[0], parameters[1], residuals);
+    typedef Jet<double, N0 + N1> J;
+    J x0[N0], x1[N1], y[kNumResiduals];
+    for (int k = 0; k < N0; ++k) x0[k] = J(parameters[0][k], k);
+    for (int k = 0; k < N1; ++k) x1[k] = J(parameters[1][k], N0 + k);
+    if (!(*functor_)(x0, x1, y)) return false;
+    for (int i = 0; i < kNumResiduals; ++i) {
+      residuals[i] = y[i].a;
+      if (jacobians[0])
+        for (int k = 0; k < N0; ++k) jacobians[0][i * N0 + k] = y[i].v[k];
+      if (jacobians[1])
+        for (int k = 0; k < N1; ++k) jacobians[1][i * N1 + k] = y[i].v[N0 + k];
+    }
+    return true;
   }
 
  private:

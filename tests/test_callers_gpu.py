@@ -1,12 +1,14 @@
-"""The reference's OWN callers on top of either cost function (VERDICT r4 item 4): pose_graph.cpp,
-constraint_collection.cpp, registration_constraint.cpp, node.cpp, node_collection.cpp, pose_4d.cpp and
-submap_registration_helper.cpp are compiled from /root/reference where they lie (oracle/Makefile: ref) -- once as they
-are, once with the ONE edit INTEGRATION.md section 3 shows applied by sed at build time
+"""The reference's OWN callers on top of either cost function (VERDICT r4 item 4, r5 item 4): pose_graph.cpp,
+constraint_collection.cpp, constraint.cpp, relative_pose_constraint.cpp, absolute_pose_constraint.cpp (with
+relative_pose_cost_function_inl.h differentiated by Jets), registration_constraint.cpp, node.cpp, node_collection.cpp,
+pose_4d.cpp and submap_registration_helper.cpp are compiled from /root/reference where they lie (oracle/Makefile: ref)
+-- once as they are, once with the ONE edit INTEGRATION.md section 3 shows applied by sed at build time
 (`new RegistrationCostFunction(` -> `voxgraph_amd::MakeGpuRegistrationCostFunction(`, gpu_submap_registry.h) -- and both
-binaries run PoseGraph::optimize() on a four-submap graph (kVoxels and mirrored kIsosurfacePoints constraints) and
-SubmapRegistrationHelper::testRegistration() (oracle/ref_driver/callers_check.cpp says what is NOT compiled from the
-reference: constraint.cpp's Eigen decompositions and the AutoDiff constraints, unused by this graph).  The solver behind
-ceres::Solve is the stand-in of tests/stubs/ceres (the real Ceres is absent from this image).
+binaries run PoseGraph::optimize() on a four-submap graph as voxgraph builds it (kVoxels and mirrored kIsosurfacePoints
+registration constraints, odometry edges with the shipped information matrix, a semi-definite height measurement),
+SubmapRegistrationHelper::testRegistration(), and the alignment problem of map_evaluation.cpp:116-161 (restated: that
+file is a ROS node).  No hand-written stand-in for reference code is left in oracle/ref_driver/callers_check.cpp.  The
+solver behind ceres::Solve is the stand-in of tests/stubs/ceres (the real Ceres is absent from this image).
 
 Bar: the same final poses within 1 mm / 0.01 deg (north_star).  The binaries travel to the GPU box with the snapshot."""
 import math
@@ -32,14 +34,17 @@ def _run(binary):
     edges = {int(m.group(1)): float(m.group(2)) for m in re.finditer(r"EDGES point_type=(\d) sum_sq_residuals=(\S+)", r.stdout)}
     m = re.search(r"HELPER usable=(\d) iterations=(\d+) final_cost=(\S+) pose (.*)", r.stdout)
     helper = (int(m.group(1)), int(m.group(2)), float(m.group(3)), tuple(float(x) for x in m.group(4).split()))
+    m = re.search(r"ALIGN iterations=(\d+) final_cost=(\S+) pose (.*)", r.stdout)
+    align = (int(m.group(1)), float(m.group(2)), tuple(float(x) for x in m.group(3).split()))
     assert len(poses) == 8 and len(solves) == 2 and len(edges) == 2
-    return poses, solves, edges, helper
+    return poses, solves, edges, helper, align
 
 
 @pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref/callers_check_reference not built (needs /root/reference)")
 def test_reference_callers_run_on_the_reference_cost_function():
     """(no GPU needed) the reference's PoseGraph::optimize(), compiled from its sources, pulls the drifted graph back"""
-    poses, solves, edges, helper = _run(REF)
+    poses, solves, edges, helper, align = _run(REF)
+    assert max(abs(a - b) for a, b in zip(align[2][:3], TRUTH[11][:3])) < 0.012 and abs(align[2][3] - TRUTH[11][3]) < 0.006, align
     for pt in (0, 1):
         its, c0, c1 = solves[pt]
         assert c1 < 0.1 * c0 and its >= 1
@@ -54,8 +59,8 @@ def test_reference_callers_run_on_the_reference_cost_function():
 @pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(GPU)),
                     reason="oracle/_ref/callers_check_* not built (needs /root/reference)")
 def test_pose_graph_optimize_gives_the_same_poses_on_the_gpu_cost_function():
-    ref_poses, ref_solves, ref_edges, ref_helper = _run(REF)
-    gpu_poses, gpu_solves, gpu_edges, gpu_helper = _run(GPU)
+    ref_poses, ref_solves, ref_edges, ref_helper, ref_align = _run(REF)
+    gpu_poses, gpu_solves, gpu_edges, gpu_helper, gpu_align = _run(GPU)
     worst_m = worst_rad = 0.0
     for key, want in ref_poses.items():
         got = gpu_poses[key]
@@ -63,6 +68,9 @@ def test_pose_graph_optimize_gives_the_same_poses_on_the_gpu_cost_function():
         worst_rad = max(worst_rad, abs(got[3] - want[3]))
     worst_m = max(worst_m, max(abs(a - b) for a, b in zip(gpu_helper[3][:3], ref_helper[3][:3])))
     worst_rad = max(worst_rad, abs(gpu_helper[3][3] - ref_helper[3][3]))
+    worst_m = max(worst_m, max(abs(a - b) for a, b in zip(gpu_align[2][:3], ref_align[2][:3])))
+    worst_rad = max(worst_rad, abs(gpu_align[2][3] - ref_align[2][3]))
+    assert gpu_align[0] == ref_align[0] and gpu_align[1] == pytest.approx(ref_align[1], rel=1e-4)
     print(f"worst pose difference: {worst_m * 1e3:.6f} mm, {math.degrees(worst_rad):.6f} deg")
     assert worst_m < 1e-3 and worst_rad < math.radians(0.01)
     for pt in (0, 1):
