@@ -47,6 +47,11 @@ timeout 240 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIV
     > /dev/null 2> $OUT/prof_sq.err
 # un-profiled, the driver's EXACT command from the repo root (what BENCH_rNN.json will hold): stdout = the one
 # compact line (harness/bench_line.py), the full object in bench_detail.json next to bench.py
+# gpurun brings at most 64 MiB of gpurun_out/ back: the traces compress 15-20 x (summarize.py reads .csv.gz), and the
+# kernel traces of the counter passes (summarize.py reads their counter_collection only) go
+find $OUT/prof_* -name "*.csv" -size +1M -exec gzip -9 {} \;
+find $OUT/prof_rd $OUT/prof_fetch $OUT/prof_write $OUT/prof_rd_plain $OUT/prof_write_plain $OUT/prof_sq -name "*kernel_trace.csv*" -delete 2>/dev/null
+du -sh $OUT
 cd $REPO
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/driver_cmd.out 2> $OUT/driver_cmd.err
 cp bench_detail.json $OUT/bench_full.json

@@ -28,9 +28,13 @@ KERNEL, FUSED, TSDF = "reg_eval_points_kernel", "reg_eval_reduce", "tsdf_integra
 
 
 def rows(pattern):
+    """csv rows of every file matching the pattern under gpurun_out/ (collect.sh gzips the large traces: gpurun brings at
+    most 64 MiB back)"""
+    import gzip
     out = []
-    for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", pattern), recursive=True)):
-        with open(f, newline="") as fh:
+    for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", pattern), recursive=True) +
+                    glob.glob(os.path.join(ROOT, "gpurun_out", pattern + ".gz"), recursive=True)):
+        with (gzip.open(f, "rt", newline="") if f.endswith(".gz") else open(f, newline="")) as fh:
             out += list(csv.DictReader(fh))
     return out
 
