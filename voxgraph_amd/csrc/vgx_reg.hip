@@ -124,6 +124,20 @@ __device__ __forceinline__ const VGX_GLOBAL T* as_global(const T* p) {
 template <int VPS>
 __device__ __forceinline__ void locate_axis(float p, const GridDev& g, int& blk, int& vox,
                                             float& delta) {
+#ifdef VGX_LOCATE_UPPER_BOUND
+  // EXPERIMENT ONLY (profiles/r06_locate_upper_bound.txt; `make SUFFIX=_fastloc EXTRA=-DVGX_LOCATE_UPPER_BOUND`): the
+  // cheapest conceivable point location -- one fma, one floor, shifts; no guard, offsets NOT the reference's bits -- to
+  // bound from above what a guarded two-speed locate_axis could gain.  Never shipped.
+  {
+    const float t = fmaf(p, g.voxel_size_inv, -0.5f);
+    const float fl = floorf(t);
+    const int gi = (int)fl;
+    blk = gi >> (VPS == 16 ? 4 : 3);
+    vox = gi & (VPS - 1);
+    delta = t - fl;
+    return;
+  }
+#endif
   blk = (int)floorf(p * g.block_size_inv + 1e-6f);
   float origin = (float)blk * g.block_size;
   int v = (int)floorf((p - origin) * g.voxel_size_inv + 1e-6f);
