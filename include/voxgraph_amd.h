@@ -367,7 +367,9 @@ VGX_API int vgx_reg_batch_evaluate_normal(vgx_reg_batch batch,
  * (pose_graph.cpp:90-101): this is that evaluation for the whole constraint list -- no gradient, no pose-Jacobian
  * products, one running sum per lane instead of 21, nothing to compress afterwards.
  * d_cost: DEVICE pointer [n] f64 (nullable); cost_host: host [n] (nullable; implies a stream synchronisation).
- * Deterministic.
+ * With d_cost == NULL the batch's internal block array serves as scratch: the blocks a previous
+ * vgx_reg_batch_evaluate_normal(d_normal == NULL) left there (what vgx_reg_batch_assemble / _scatter_normal read when
+ * THEY are given NULL) are gone -- evaluate the blocks again before assembling.  Deterministic.
  * SAMPLING constraints (sampling_ratio != -1): EVERY evaluation of a batch -- points, normal or cost -- is one Evaluate of
  * every constraint in list order and DRAWS its points from the reference point sets' engines, as every call of the
  * reference's Evaluate does (registration_cost_function.cpp:113-122): a cost-only evaluation followed by a full one at the

@@ -154,6 +154,81 @@ def test_scans_integrate_while_the_pose_graph_is_evaluated(capi):
         ctx.close()
 
 
+def test_racing_scans_under_a_running_solve_are_legal_interleavings_and_get_in(capi):
+    """The DEFAULT mode under the reference's defining overlap: racing scans -- one launch each -- on
+    thread A while thread B loops fused solver evaluations on the same context.  Every scan's event log is replayed
+    through the oracle (tests/test_tsdf_replay_gpu.py's checker: 0 violations allowed), the solver's blocks stay
+    bit-identical to the serial run, and -- the fused passes run five workgroups deep while the context has an
+    integrator -- a scan submitted under the solver completes well inside the fused kernel's duration."""
+    from oracle import pyoracle as orc
+    import torch
+    ctx = capi.Context(0)
+    try:
+        subs, cfs, batch, pairs, guess = _graph(capi, ctx, n_sub=8)
+        scans = _scans(24, n_az=1024, n_el=64)
+        ocfg, gcfg = orc.voxgraph_tsdf_config(), capi.voxgraph_tsdf_config()
+        layer = capi.TsdfLayer(ctx, 0.2, 16)
+        integ = capi.FastTsdfIntegrator(ctx, gcfg, layer)
+        _, serial = batch.evaluate_normal(guess, to_host=True)
+        stop, err, done = threading.Event(), [], [0]
+
+        def solver():
+            try:
+                while not stop.is_set():
+                    _, blocks = batch.evaluate_normal(guess, to_host=True)
+                    assert np.array_equal(blocks.view(np.uint64), serial.view(np.uint64))
+                    done[0] += 1
+            except BaseException as e:    # noqa: BLE001
+                err.append(repr(e))
+        th = threading.Thread(target=solver)
+        th.start()
+        time.sleep(0.05)
+        try:
+            # ---- replayed scans (the logging instantiation of the shipped kernel), the solver running
+            integ.set_event_trace(8 << 20)
+            totals = dict(scans=0, exchanges=0, updates=0, overrun=0)
+            for T, pts in scans[:12]:
+                s0, o0, _ = integ.download_sets()
+                l0 = layer.download()
+                n_upd = integ.integratePointCloud(T, pts)
+                trace, lost = integ.read_event_trace()
+                s1, o1, (off_s, off_o, _) = integ.download_sets()
+                rep = orc.tsdf_replay_check(ocfg, 0.2, 16, T, pts, None, False, (off_s, off_o), (s0, o0), (s1, o1), l0,
+                                            layer.download(), trace)
+                assert lost == 0 and rep["errors"] == 0, rep["first_error"]
+                assert rep["required_updates"] == n_upd
+                totals["scans"] += 1
+                totals["exchanges"] += rep["observed_exchanges"]
+                totals["updates"] += n_upd
+                totals["overrun"] += rep["overrun_exchanges"]
+            integ.set_event_trace(0)
+            # ---- latency of the shipped (unlogged) kernel under the solver: submit -> complete on the TSDF stream alone
+            dev = [torch.from_numpy(p).cuda() for _, p in scans]
+            torch.cuda.synchronize()
+            lat = []
+            for k, (T, pts) in enumerate(scans):
+                time.sleep(0.004)
+                t0 = time.perf_counter()
+                integ.integrate_device(T, dev[k].data_ptr(), None, len(pts))
+                ctx.synchronize_tsdf()
+                lat.append((time.perf_counter() - t0) * 1e6)
+        finally:
+            stop.set()
+            th.join(timeout=120)
+        assert not err, err
+        assert done[0] > 10 and layer.stats()[1] == 0
+        lat = np.sort(np.array(lat))
+        print(f"racing scans under a running solve: {totals}; {done[0]} solver evaluations meanwhile; scan latency p50 "
+              f"{np.median(lat):.0f} us, max {lat[-1]:.0f} us")
+        # (a generous bar: the probe measures 0.2-0.4 ms; before the fused passes left room it was 0.7 ms median on the big
+        # graph -- here the solver's kernel is short, so the bar only says "does not wait for whole evaluations")
+        assert np.median(lat) < 2000
+        for o in [integ, layer, batch] + cfs + subs:
+            o.destroy()
+    finally:
+        ctx.close()
+
+
 def test_finish_submap_hands_over_across_the_two_streams(capi):
     """vgx_submap_from_tsdf_layer right behind the last scan, no host synchronisation in between: the registration side's
     kernels (brick building, ESDF, point extraction) must see the layer as the TSDF stream left it"""
