@@ -117,6 +117,8 @@ def main():
                 assert np.array_equal(tjo[:n].cpu().numpy(), jo0.astype(F)), "batch jac_ref rows"
                 assert np.array_equal(tje[:n].cpu().numpy(), je0.astype(F)), "batch jac_read rows"
                 st2, normal = batch.evaluate_normal(poses)
+                st3, cost = batch.evaluate_cost(poses)        # (round 6) the cost-only pass: the full pass's cost bit for bit
+                assert np.array_equal(cost.view(np.uint64), normal[:, 0].copy().view(np.uint64)), ("cost-only", cost, normal[:, 0])
                 J = np.concatenate([jo0, je0], axis=1)
                 want = np.r_[float(r0 @ r0), J.T @ r0, (J.T @ J)[np.triu_indices(8)]]
                 for lo, hi in ((0, 1), (1, 9), (9, 45)):

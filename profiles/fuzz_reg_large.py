@@ -74,6 +74,8 @@ def main():
             st = batch.evaluate_points(poses, tr.data_ptr(), tjo.data_ptr(), tje.data_ptr())
             ctx.synchronize()
             _, normal = batch.evaluate_normal(poses)
+            _, cost_only = batch.evaluate_cost(poses)     # (round 6) bit for bit the full pass's cost
+            assert np.array_equal(cost_only.view(np.uint64), normal[:, 0].copy().view(np.uint64)), "cost-only pass"
             r, jo, je = tr.cpu().numpy(), tjo.cpu().numpy(), tje.cpu().numpy()
             for c, (a, b) in enumerate(pairs):
                 xyz, dist, w = pts[a]
