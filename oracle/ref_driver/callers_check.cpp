@@ -249,6 +249,40 @@ int main() {
     if (!(summary.final_cost < 0.2 * summary.initial_cost)) rc = 1;
   }
 #ifdef VGX_CALLERS_GPU
+  // GpuSubmapRegistry: a cached upload is believed only while its owner lives and its stamp is unchanged
+  {
+    voxgraph_amd::GpuSubmapRegistry& registry = voxgraph_amd::GpuSubmapRegistry::instance();
+    const size_t size_before = registry.size();
+    VoxgraphSubmap::ConstPtr kept = submaps[3];
+    const vgx_submap first = registry.handleOf(kept);
+    const vgx_submap again = registry.handleOf(kept);                 // same object, same stamp: the cached upload
+    // the same object FINISHED AGAIN with another block in its layers: the stamp changes, the upload must be redone
+    {
+      voxblox::BlockIndex extra;
+      extra[0] = 7; extra[1] = 7; extra[2] = 7;
+      submaps[3]->getTsdfMapPtr()->getTsdfLayerPtr()->allocateBlockPtrByIndex(extra);
+      std::ostringstream sink;
+      std::streambuf* old = std::cout.rdbuf(sink.rdbuf());
+      submaps[3]->finishSubmap();
+      std::cout.rdbuf(old);
+    }
+    const long stale_before = registry.staleReplaced();
+    const vgx_submap refreshed = registry.handleOf(kept);
+    const long stale_after = registry.staleReplaced();
+    // a submap that dies without release(): its entry is swept at the next call
+    size_t size_with_temp = 0;
+    {
+      const double pose[4] = {9.0, 9.0, 0.0, 0.0};
+      VoxgraphSubmap::ConstPtr temp = make_submap(99, pose, 0.1f, 16, 1, 0.3f, 1.0f);
+      (void)registry.handleOf(temp);
+      size_with_temp = registry.size();
+    }
+    (void)registry.handleOf(kept);
+    std::printf("REGISTRY cached=%d stamp_change_reuploaded=%d stale_replaced=%ld size_before=%zu size_with_temp=%zu size_after_sweep=%zu\n",
+                (int)(first == again), (int)(refreshed != nullptr), stale_after - stale_before, size_before, size_with_temp,
+                registry.size());
+    if (first != again || stale_after - stale_before != 1 || size_with_temp != size_before + 1 || registry.size() != size_before) rc = 1;
+  }
   voxgraph_amd::GpuSubmapRegistry::instance().clear();
   vgx_ctx_destroy(ctx);
 #endif

@@ -61,6 +61,14 @@ def test_reference_callers_run_on_the_reference_cost_function():
 def test_pose_graph_optimize_gives_the_same_poses_on_the_gpu_cost_function():
     ref_poses, ref_solves, ref_edges, ref_helper, ref_align = _run(REF)
     gpu_poses, gpu_solves, gpu_edges, gpu_helper, gpu_align = _run(GPU)
+    # GpuSubmapRegistry: the cached upload is reused for the same object and stamp, redone when the object is
+    # finished again (stamp change), and an entry whose owner died without release() is swept
+    out = subprocess.run([GPU], capture_output=True, text=True, timeout=600).stdout
+    m = re.search(r"REGISTRY cached=(\d) stamp_change_reuploaded=(\d) stale_replaced=(\d+) size_before=(\d+) size_with_temp=(\d+) "
+                  r"size_after_sweep=(\d+)", out)
+    assert m, out[-1500:]
+    cached, reup, stale, before, with_temp, after = (int(x) for x in m.groups())
+    assert cached == 1 and reup == 1 and stale == 1 and with_temp == before + 1 and after == before
     worst_m = worst_rad = 0.0
     for key, want in ref_poses.items():
         got = gpu_poses[key]

@@ -259,3 +259,43 @@ def test_finish_submap_hands_over_across_the_two_streams(capi):
         assert np.array_equal(x0, x1) and np.array_equal(d0, d1) and np.array_equal(w0, w1)
     finally:
         ctx.close()
+
+
+def test_scans_produced_on_another_stream_are_ordered_by_tsdf_wait_for_stream(capi):
+    """vgx_ctx_tsdf_wait_for_stream: scan points PRODUCED on another stream (here PyTorch's: a long matrix
+    product queued in front of the copy, so that the points land late) and integrated on the TSDF stream with no host
+    synchronisation in between -- the device-side wait must order the integration behind the producer: the same layer as
+    with a synchronise after every scan"""
+    import torch
+    ctx = capi.Context(0)
+    try:
+        scans = _scans(6, n_az=512, n_el=32)
+        pinned = [torch.from_numpy(p).pin_memory() for _, p in scans]
+        ballast = torch.randn((4096, 4096), device="cuda")
+        producer = torch.cuda.current_stream()
+
+        def run(sync_every_scan):
+            layer = capi.TsdfLayer(ctx, 0.2, 16)
+            integ = capi.FastTsdfIntegrator(ctx, capi.voxgraph_tsdf_config(deterministic=1), layer)
+            bufs = [torch.zeros((len(p), 3), dtype=torch.float32, device="cuda") for _, p in scans]
+            torch.cuda.synchronize()
+            ctx.synchronize()
+            for k, (T, pts) in enumerate(scans):
+                for _ in range(4):
+                    ballast @ ballast                                   # a few milliseconds of work in front of the copy
+                bufs[k].copy_(pinned[k], non_blocking=True)
+                if sync_every_scan:
+                    producer.synchronize()
+                else:
+                    ctx.tsdf_wait_for_stream(producer.cuda_stream)      # the TSDF stream waits, on the device
+                integ.integrate_device(T, bufs[k].data_ptr(), None, len(pts))
+            out = layer.download()
+            for o in (integ, layer):
+                o.destroy()
+            return out
+        want, got = run(True), run(False)
+        assert len(want[0]) > 20
+        for x, y in zip(want, got):
+            assert np.array_equal(x.view(np.uint8), y.view(np.uint8))
+    finally:
+        ctx.close()
