@@ -93,7 +93,8 @@ VGX_API const char* vgx_last_error(vgx_ctx ctx);
  * vgx_ctx_set_tsdf_stream: the same for the TSDF side (waits for what that side has queued so far).  NULL restores
  * the context's own stream.  vgx_ctx_synchronize waits for both, vgx_ctx_synchronize_tsdf for the TSDF side alone (the
  * mapping thread's "is my scan in?", whatever the solver has queued).  vgx_ctx_tsdf_wait_for_stream: the TSDF stream
- * waits ON THE DEVICE for what producer_stream (NULL: the context's registration stream) holds at the time of the call. */
+ * waits ON THE DEVICE for what producer_stream (NULL: the context's registration stream) holds at the time of the call
+ * (HIP's legacy default stream, whose handle IS NULL, cannot be named here: produce on a created stream). */
 VGX_API int vgx_ctx_set_stream(vgx_ctx ctx, void* hip_stream);
 VGX_API void* vgx_ctx_get_stream(vgx_ctx ctx);
 VGX_API int vgx_ctx_set_tsdf_stream(vgx_ctx ctx, void* hip_stream);

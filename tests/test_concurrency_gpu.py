@@ -272,7 +272,7 @@ def test_scans_produced_on_another_stream_are_ordered_by_tsdf_wait_for_stream(ca
         scans = _scans(6, n_az=512, n_el=32)
         pinned = [torch.from_numpy(p).pin_memory() for _, p in scans]
         ballast = torch.randn((4096, 4096), device="cuda")
-        producer = torch.cuda.current_stream()
+        producer = torch.cuda.Stream()                                  # (a named stream: NULL means "the registration stream")
 
         def run(sync_every_scan):
             layer = capi.TsdfLayer(ctx, 0.2, 16)
@@ -281,9 +281,10 @@ def test_scans_produced_on_another_stream_are_ordered_by_tsdf_wait_for_stream(ca
             torch.cuda.synchronize()
             ctx.synchronize()
             for k, (T, pts) in enumerate(scans):
-                for _ in range(4):
-                    ballast @ ballast                                   # a few milliseconds of work in front of the copy
-                bufs[k].copy_(pinned[k], non_blocking=True)
+                with torch.cuda.stream(producer):
+                    for _ in range(4):
+                        ballast @ ballast                               # a few milliseconds of work in front of the copy
+                    bufs[k].copy_(pinned[k], non_blocking=True)
                 if sync_every_scan:
                     producer.synchronize()
                 else:
