@@ -31,6 +31,13 @@ def test_tsdf_random_configurations_bit_identical_to_the_oracle():
     assert _run("fuzz_tsdf", 25, 300) == 0
 
 
+def test_racing_tsdf_random_configurations_replay_as_legal_interleavings():
+    """the racing (default) mode by trace and replay: 12 random integrator configurations x 4 scans (unorganised and
+    organised clouds incl. ragged tiles, counted and uncounted kernels, colours, free-space scans); the long runs
+    (1360 scans, 59 M exchanges, 0 violations) are recorded in profiles/README.md"""
+    assert _run("fuzz_replay", 12, 300) == 0
+
+
 def test_reg_random_constraints_equal_the_oracle():
     """drop-in f64 rows, batched f32 rows, fused sums, voxel-point and isosurface producers: 60 random submap pairs"""
     assert _run("fuzz_reg", 60, 300) == 0
