@@ -75,6 +75,13 @@ def test_two_contexts_sum_to_the_unsharded_buffer(capi, world):
     normal, status = multi.evaluate_normal(poses)
     assert np.all(status == 0)
     assert np.array_equal(normal, normal0)         # a constraint's tile size is a function of the constraint alone
+    # the cost-only pass on every context's share (vgx_reg_multi_evaluate_cost, what Ceres asks for at trial steps): element 0
+    # of those blocks bit for bit, in the caller's order, and the single batch's cost-only pass says the same
+    cost, status = multi.evaluate_cost(poses)
+    assert np.all(status == 0)
+    assert np.array_equal(cost.view(np.uint64), normal0[:, 0].copy().view(np.uint64))
+    _, cost0 = single.evaluate_cost(poses)
+    assert np.array_equal(cost.view(np.uint64), cost0.view(np.uint64))
     # bitwise reproducible, evaluation after evaluation (fixed-order reduction, no atomics)
     for _ in range(3):
         f2, _ = multi.evaluate_fused(poses)
