@@ -1,9 +1,10 @@
 // oracle/PIN.md: voxblox's OWN Fast / Merged TSDF integrators on the sessions of tests/golden/make_tsdf_golden.py
-// (TEST INFRASTRUCTURE; built by `make -C oracle pin VOXBLOX=...` only -- it needs the real voxblox sources, which this
-// image does not have, so this file has NEVER BEEN COMPILED: it is written against voxblox's public API as recalled --
-// TsdfIntegratorBase::Config, FastTsdfIntegrator / MergedTsdfIntegrator(config, Layer<TsdfVoxel>*),
-// integratePointCloud(T_G_C, points_C, colors, freespace_points), Layer::getAllAllocatedBlocks / getBlockByIndex,
-// Block::getVoxelByLinearIndex -- and the first thing to do with a checkout is to make it build).
+// (TEST INFRASTRUCTURE; built by `make -C oracle pin VOXBLOX=...`).  It needs the real voxblox sources, which this image
+// does not have: it is written against voxblox's public API as recalled -- TsdfIntegratorBase::Config,
+// FastTsdfIntegrator / MergedTsdfIntegrator(config, Layer<TsdfVoxel>*), integratePointCloud(T_G_C, points_C, colors,
+// freespace_points), Layer::getAllAllocatedBlocks / getBlockByIndex, Block::getVoxelByLinearIndex.  Since round 6 it is at
+// least COMPILED AND RUN by `make -C oracle pin-dryrun` against a fake checkout whose tsdf_integrator.{h,cc} wrap the oracle
+// (oracle/pin_dryrun/README.md); against the real headers the first thing to do is still to make it build.
 //
 //   voxblox_tsdf_pin sessions.bin out_dir
 // reads the sessions (format: make_tsdf_golden.py dump_sessions), integrates each with integrator_threads = 1 in the
