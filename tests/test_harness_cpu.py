@@ -231,14 +231,14 @@ def test_parity_gate_picks_culled_and_live_constraints():
 
 def test_profiled_launch_counts_come_from_the_committed_trace():
     """bench.py's `tsdf.*.{reproducible_mode,merged_integrator}.roofline.launches_per_scan_from_profiles`: parsed from
-    profiles/r05_tsdf_launches.txt (rocprofv3 kernel trace of one scan of each sort-based path, tsdf_launches.sh) -- and
+    profiles/r06_tsdf_launches.txt (rocprofv3 kernel trace of one scan of each sort-based path, tsdf_launches.sh) -- and
     only while that trace describes the sources in the tree: the script records a hash of the TSDF sources,
     a mismatch drops the counts instead of dividing a fresh time by a stale number"""
     import os
     from harness import bench_tsdf
     got, note = bench_tsdf.profiled_launches()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    path = os.path.join(root, "profiles", "r05_tsdf_launches.txt")
+    path = os.path.join(root, "profiles", "r06_tsdf_launches.txt")
     recorded = [l.split()[-1] for l in open(path) if l.startswith("sources sha256:")] if os.path.exists(path) else []
     if recorded and recorded[0] == bench_tsdf.tsdf_sources_sha():
         assert set(got) == {("fast", "lidar"), ("fast", "rgbd"), ("merged", "lidar"), ("merged", "rgbd")}, note
