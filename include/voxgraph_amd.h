@@ -154,6 +154,11 @@ VGX_API int vgx_submap_create(vgx_ctx ctx, int32_t submap_id, float voxel_size,
                               const float* esdf_distance,
                               const uint8_t* esdf_observed,
                               vgx_submap* out);
+/* Lifetimes follow the reference's ownership: a RegistrationCostFunction holds VoxgraphSubmap::ConstPtr to both submaps
+ * (registration_cost_function.h), a ceres::Problem owns its cost functions.  So destroying a submap that cost functions
+ * were built on is DEFERRED to the destruction of the last of them (the call returns VGX_OK at once and the handle must
+ * not be used again by the caller); likewise vgx_reg_destroy on a cost function that batches still list is carried out
+ * by the last vgx_reg_batch_destroy.  Contexts are not counted: destroy a context last. */
 VGX_API int vgx_submap_destroy(vgx_submap submap);
 VGX_API int32_t vgx_submap_id(vgx_submap submap);
 VGX_API int32_t vgx_submap_num_blocks(vgx_submap submap);

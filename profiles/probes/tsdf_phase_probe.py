@@ -47,11 +47,17 @@ for name, (dirs, vs, kw, bmin, bdim) in sensor_cases().items():
         ctx.timer_start()
         integ.integrate_device(T[k], dev[k].data_ptr(), None, n_pts)
         unc.append(ctx.timer_stop() * 1e3)
+    ctx.synchronize()
+    ctx.timer_start()
+    for _ in range(5):
+        for k in range(20):
+            integ.integrate_device(T[k], dev[k].data_ptr(), None, n_pts)
+    b2b = ctx.timer_stop() * 1e3 / 100
     r = np.concatenate(rows)
     p1, walk, fold, life = r[:, 1] - r[:, 0], r[:, 2] - r[:, 1], r[:, 3] - r[:, 2], r[:, 3] - r[:, 0]
     span = [x[:, 3].max() - x[:, 0].min() for x in rows]
     q = lambda a: "%.1f / %.1f / %.1f" % (np.median(a), np.percentile(a, 90), a.max())
-    print(f"{name}: kernel (hip events) counted {np.median(kern):.1f} us, uncounted {np.median(unc):.1f} us; span first start -> last end "
+    print(f"{name}: kernel (hip events) counted {np.median(kern):.1f} us, uncounted {np.median(unc):.1f} us, back to back {b2b:.1f} us; span first start -> last end "
           f"{np.median(span):.1f} us; per workgroup (median / p90 / max, us): phase 1 {q(p1)}, walk {q(walk)}, folds {q(fold)}, "
           f"whole {q(life)}; rays per workgroup {q(r[:, 4])}, rounds {q(r[:, 5])}, folds {q(r[:, 6])}")
     integ.destroy()

@@ -741,3 +741,34 @@ def test_hip_path_matches_the_reference_source_golden(capi, ctx, golden_dir, cas
     assert exact == len(gold["perturbations"])
     for o in (cf, g_ref, g_read):
         o.destroy()
+
+
+def test_a_submap_outlives_the_cost_functions_built_on_it(capi, ctx):
+    """Lifetimes as the reference's: RegistrationCostFunction holds VoxgraphSubmap::ConstPtr to both submaps and the
+    ceres::Problem owns its cost functions, so vgx_submap_destroy on a submap cost functions were built on -- what
+    GpuSubmapRegistry does to a stale upload -- and vgx_reg_destroy on a cost function a batch lists are DEFERRED to the
+    last user's destruction (include/voxgraph_amd.h): evaluations in between are the ones from before, bit for bit."""
+    import torch
+    sm, _ = synth.config1_pair()
+    a, b = H.gpu_submap(capi, ctx, sm, 31), H.gpu_submap(capi, ctx, sm, 32)
+    a.extract_voxel_points()
+    cf = capi.RegistrationCostFunction(ctx, a, b, capi.default_config(registration_point_type=capi.POINTS_VOXELS))
+    cf2 = capi.RegistrationCostFunction(ctx, a, a, capi.default_config(registration_point_type=capi.POINTS_VOXELS))
+    ref_pose, read_pose = np.array([0.02, -0.01, 0.03, 0.01]), np.array([0.07, 0.03, -0.02, 0.04])
+    ok, r0, jo0, je0 = _gpu_eval(cf, ref_pose, read_pose)
+    assert ok
+    batch = capi.RegistrationBatch(ctx, [cf, cf2], [[0, 1], [0, 1]])
+    _, n0 = batch.evaluate_normal(np.stack([ref_pose, read_pose]))
+    # the owners let go in the "wrong" order: submaps first, then the cost functions, the batch last
+    a.destroy()
+    b.destroy()
+    junk = [torch.full((1 << 22,), 7.0, device="cuda") for _ in range(8)]  # whatever was freed would be handed out again
+    torch.cuda.synchronize()
+    ok, r1, jo1, je1 = _gpu_eval(cf, ref_pose, read_pose)
+    assert ok and np.array_equal(r0, r1) and np.array_equal(jo0, jo1) and np.array_equal(je0, je1)
+    cf.destroy()
+    cf2.destroy()
+    _, n1 = batch.evaluate_normal(np.stack([ref_pose, read_pose]))
+    assert np.array_equal(n0, n1) and np.abs(n0).sum() > 0
+    batch.destroy()   # -> the two cost functions -> the two submaps
+    del junk

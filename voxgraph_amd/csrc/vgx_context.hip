@@ -304,6 +304,13 @@ vgx::GridDev vgx_submap_s::grid_dev(int which) const {
 // ---------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------
+namespace vgx {
+std::mutex& lifetime_mu() {
+  static std::mutex mu;
+  return mu;
+}
+}  // namespace vgx
+
 extern "C" {
 
 int vgx_ctx_create(int device, vgx_ctx* out) {
@@ -613,6 +620,14 @@ int vgx_submap_block_index(vgx_submap sm, int32_t* block_index) {
 
 int vgx_submap_destroy(vgx_submap sm) {
   if (!sm) return VGX_ERR_INVALID;
+  {
+    // cost functions still read this submap's bricks and points: the last of them to go frees it
+    std::lock_guard<std::mutex> lk(vgx::lifetime_mu());
+    if (sm->users > 0) {
+      sm->destroy_requested = true;
+      return VGX_OK;
+    }
+  }
   (void)hipSetDevice(sm->ctx->device);
   vgx_submap_release_raw_layers(sm);
   if (sm->d_lut) (void)hipFree(sm->d_lut);

@@ -284,6 +284,11 @@ struct vgx_submap_s {
   int32_t* d_iso_block_index = nullptr;    // [isosurface_blocks.size()][3]
   vgx::GridDev grid_dev(int which) const;
   int ensure_quad_grid(int which);  // apron bricks -> quad bricks, once (vgx_context.hip)
+  // Lifetime (guarded by vgx::lifetime_mu()): cost functions made from this submap.  vgx_submap_destroy while users > 0
+  // only records the request; the last vgx_reg_destroy carries it out (the reference's cost function holds
+  // VoxgraphSubmap::ConstPtr: registration_cost_function.h -- a submap outlives every cost function built on it).
+  int users = 0;
+  bool destroy_requested = false;
 };
 
 struct vgx_reg_s {
@@ -307,6 +312,10 @@ struct vgx_reg_s {
   bool sampling() const { return cfg.sampling_ratio != -1.0f; }
   bool points_current() const;  // the reference submap still holds the points this was built on
   vgx::ConstraintDev describe() const;
+  // Lifetime (vgx::lifetime_mu()): batches that list this cost function; vgx_reg_destroy while users > 0 is deferred to
+  // the last vgx_reg_batch_destroy (ceres::Problem owns its cost functions for as long as it evaluates them).
+  int users = 0;
+  bool destroy_requested = false;
 };
 
 struct vgx_reg_batch_s {
@@ -361,6 +370,7 @@ struct vgx_reg_batch_s {
   uint32_t* d_raw = nullptr;       // all engine outputs of one evaluation
   void* d_stream_jobs = nullptr;   // device copy of {state*, out*, count} per job
   bool any_sampling = false;
+  bool holds_regs = false;         // regs[*]->users were incremented (vgx_reg_batch_create succeeded)
 };
 
 // ---------------------------------------------------------------------------
@@ -372,6 +382,9 @@ int set_error(vgx_ctx ctx, int code, const std::string& msg);
 #else
 inline int set_error(vgx_ctx ctx, int code, const std::string& msg);
 #endif
+
+// the one lock behind the users / destroy_requested fields of submaps and cost functions (vgx_context.hip)
+std::mutex& lifetime_mu();
 
 // Scope-bound device scratch: freed on every exit path (the VGX_HIP macro returns early).
 struct DeviceScratch {

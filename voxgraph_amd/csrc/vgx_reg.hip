@@ -1778,18 +1778,43 @@ int vgx_reg_create(vgx_ctx ctx, vgx_submap reference, vgx_submap reading, const 
       return set_error(ctx, VGX_ERR_HIP, std::string("vgx_reg_create: sampler tables: ") + hipGetErrorString(e));
     }
   }
+  {
+    std::lock_guard<std::mutex> lt(lifetime_mu());
+    ++reference->users;
+    ++reading->users;
+  }
   *out = r;
   return VGX_OK;
 }
 
 int vgx_reg_destroy(vgx_reg r) {
   if (!r) return VGX_ERR_INVALID;
+  {
+    std::lock_guard<std::mutex> lt(lifetime_mu());
+    if (r->users > 0) {  // a batch still lists it: the last vgx_reg_batch_destroy comes back here
+      r->destroy_requested = true;
+      return VGX_OK;
+    }
+  }
   (void)hipSetDevice(r->ctx->device);
   (void)hipStreamSynchronize(r->ctx->stream);
   if (r->d_sample_raw) (void)hipFree(r->d_sample_raw);
   if (r->h_sample_raw) (void)hipHostFree(r->h_sample_raw);
   if (r->rng.d_state) (void)hipFree(r->rng.d_state);
+  // the submaps this cost function kept alive (vgx_submap_destroy was called on them while it existed)
+  vgx_submap orphan[2] = {nullptr, nullptr};
+  {
+    std::lock_guard<std::mutex> lt(lifetime_mu());
+    vgx_submap both[2] = {r->reference, r->reading};
+    for (int k = 0; k < 2; ++k) {
+      vgx_submap sm = both[k];
+      if (--sm->users == 0 && sm->destroy_requested) orphan[k] = sm;
+    }
+    if (orphan[0] == orphan[1]) orphan[1] = nullptr;  // a submap registered against itself
+  }
   delete r;
+  for (int k = 0; k < 2; ++k)
+    if (orphan[k]) (void)vgx_submap_destroy(orphan[k]);
   return VGX_OK;
 }
 
@@ -2176,6 +2201,11 @@ int vgx_reg_batch_create(vgx_ctx ctx, int32_t n, const vgx_reg* regs, const int3
     vgx_reg_batch_destroy(b);
     return rc;
   }
+  {
+    std::lock_guard<std::mutex> lt(lifetime_mu());
+    for (vgx_reg r : b->regs) ++r->users;
+    b->holds_regs = true;
+  }
   *out = b;
   return VGX_OK;
 }
@@ -2184,6 +2214,13 @@ int vgx_reg_batch_destroy(vgx_reg_batch b) {
   if (!b) return VGX_ERR_INVALID;
   (void)hipSetDevice(b->ctx->device);
   (void)hipStreamSynchronize(b->ctx->stream);
+  std::vector<vgx_reg> orphans;  // cost functions destroyed by their owner while this batch listed them
+  if (b->holds_regs) {
+    std::lock_guard<std::mutex> lt(lifetime_mu());
+    for (vgx_reg r : b->regs)
+      if (--r->users == 0 && r->destroy_requested) orphans.push_back(r);
+  }
+  for (vgx_reg r : orphans) (void)vgx_reg_destroy(r);
   if (b->d_raw) (void)hipFree(b->d_raw);
   if (b->d_stream_jobs) (void)hipFree(b->d_stream_jobs);
   if (b->d_node_first) (void)hipFree(b->d_node_first);
