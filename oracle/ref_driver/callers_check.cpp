@@ -27,8 +27,9 @@
 // consecutive submaps with the shipped information matrix (voxgraph_mapper.yaml:41-47: 1, 1, 2500, 2500; the measured
 // relative pose carries a small error, as odometry does), and a HEIGHT measurement on the last submap (absolute pose
 // against the mission frame, semi-definite information: measurement_templates.cpp:27-29 -- the LDLT branch of
-// constraint.cpp).  They perturb the poses, call PoseGraph::optimize() and SubmapRegistrationHelper::testRegistration(),
-// run the map-evaluation alignment, and print the poses: tests/test_callers_gpu.py requires them within 1 mm / 0.01 deg
+// constraint.cpp).  They perturb the poses, call PoseGraph::optimize(), getVisualizationEdges(), getEdgeCovarianceMap(), the
+// two-stage optimize(true) / optimize() of pose_graph_interface.cpp:182-191 and SubmapRegistrationHelper::testRegistration(),
+// run the map-evaluation alignment, and print the poses and covariance blocks: tests/test_callers_gpu.py requires them within 1 mm / 0.01 deg
 // of each other (north_star's solve tolerance).
 #include <cmath>
 #include <cstdio>
@@ -112,6 +113,64 @@ std::shared_ptr<VoxgraphSubmap> make_submap(unsigned id, const double pose[4], f
 }
 }  // namespace
 
+// The four-submap graph as voxgraph builds it (see the header comment), poses starting from truth + drift
+void fill_graph(voxgraph::PoseGraph& graph, const std::vector<std::shared_ptr<VoxgraphSubmap>>& submaps, int point_type,
+                const double truth[4][4], const double drift[4][4]) {
+  for (unsigned k = 0; k < 4; ++k) {
+    voxgraph::SubmapNode::Config node;
+    node.submap_id = 10 + k;
+    node.set_constant = k == 0;   // pose_graph_interface.cpp:30-32
+    double start[4];
+    for (int a = 0; a < 4; ++a) start[a] = truth[k][a] + drift[k][a];
+    node.T_mission_node_initial = pose_of(start);
+    graph.addSubmapNode(node);
+  }
+  for (unsigned a = 0; a < 4; ++a)
+    for (unsigned b = a + 1; b < 4 && b <= a + 2; ++b) {
+      voxgraph::RegistrationConstraint::Config c;
+      c.first_submap_id = 10 + a;
+      c.second_submap_id = 10 + b;
+      c.first_submap_ptr = submaps[a];
+      c.second_submap_ptr = submaps[b];
+      c.information_matrix.setIdentity();
+      c.registration.registration_point_type = static_cast<VoxgraphSubmap::RegistrationPointType>(point_type);
+      c.registration.sampling_ratio = -1;
+      graph.addRegistrationConstraint(c);
+    }
+  // odometry edges between consecutive submaps (pose_graph_interface.cpp:41-66), shipped information matrix
+  for (unsigned a = 0; a + 1 < 4; ++a) {
+    voxgraph::RelativePoseConstraint::Config c;
+    c.origin_submap_id = 10 + a;
+    c.destination_submap_id = 11 + a;
+    double measured[4];   // the true relative pose seen through a little odometry error
+    const voxblox::Transformation T_ab = pose_of(truth[a]).inverse() * pose_of(truth[a + 1]);
+    const voxblox::Transformation::Vector6 rel = T_ab.log();
+    measured[0] = rel[0] + 0.004 * (a + 1); measured[1] = rel[1] - 0.003; measured[2] = rel[2] + 0.001; measured[3] = rel[5] + 0.001;
+    c.T_origin_destination = pose_of(measured);
+    c.information_matrix.setZero();
+    c.information_matrix(0, 0) = 1.0; c.information_matrix(1, 1) = 1.0;
+    c.information_matrix(2, 2) = 2500.0; c.information_matrix(3, 3) = 2500.0;
+    graph.addRelativePoseConstraint(c);
+  }
+  // a height measurement on the last submap: z only, against the mission frame (semi-definite: constraint.cpp's LDLT branch)
+  {
+    voxgraph::ReferenceFrameNode::Config frame;
+    frame.reference_frame_id = 0;
+    frame.set_constant = true;
+    frame.T_mission_node_initial = voxblox::Transformation();
+    graph.addReferenceFrameNode(frame);
+    voxgraph::AbsolutePoseConstraint::Config c;
+    c.reference_frame_id = 0;
+    c.submap_id = 13;
+    double at[4] = {0.0, 0.0, truth[3][2] + 0.001, 0.0};
+    c.T_ref_submap = pose_of(at);
+    c.information_matrix.setZero();
+    c.information_matrix(2, 2) = 2500.0;
+    c.allow_semi_definite_information_matrix = true;
+    graph.addAbsolutePoseConstraint(c);
+  }
+}
+
 int main() {
 #ifdef VGX_CALLERS_GPU
   vgx_ctx ctx = nullptr;
@@ -133,59 +192,7 @@ int main() {
   int rc = 0;
   for (int point_type = 1; point_type >= 0; --point_type) {   // kVoxels, then kIsosurfacePoints (mirrored: pose_graph.cpp:62-71)
     voxgraph::PoseGraph graph;
-    for (unsigned k = 0; k < 4; ++k) {
-      voxgraph::SubmapNode::Config node;
-      node.submap_id = 10 + k;
-      node.set_constant = k == 0;   // pose_graph_interface.cpp:30-32
-      double start[4];
-      for (int a = 0; a < 4; ++a) start[a] = truth[k][a] + drift[k][a];
-      node.T_mission_node_initial = pose_of(start);
-      graph.addSubmapNode(node);
-    }
-    for (unsigned a = 0; a < 4; ++a)
-      for (unsigned b = a + 1; b < 4 && b <= a + 2; ++b) {
-        voxgraph::RegistrationConstraint::Config c;
-        c.first_submap_id = 10 + a;
-        c.second_submap_id = 10 + b;
-        c.first_submap_ptr = submaps[a];
-        c.second_submap_ptr = submaps[b];
-        c.information_matrix.setIdentity();
-        c.registration.registration_point_type = static_cast<VoxgraphSubmap::RegistrationPointType>(point_type);
-        c.registration.sampling_ratio = -1;
-        graph.addRegistrationConstraint(c);
-      }
-    // odometry edges between consecutive submaps (pose_graph_interface.cpp:41-66), shipped information matrix
-    for (unsigned a = 0; a + 1 < 4; ++a) {
-      voxgraph::RelativePoseConstraint::Config c;
-      c.origin_submap_id = 10 + a;
-      c.destination_submap_id = 11 + a;
-      double measured[4];   // the true relative pose seen through a little odometry error
-      const voxblox::Transformation T_ab = pose_of(truth[a]).inverse() * pose_of(truth[a + 1]);
-      const voxblox::Transformation::Vector6 rel = T_ab.log();
-      measured[0] = rel[0] + 0.004 * (a + 1); measured[1] = rel[1] - 0.003; measured[2] = rel[2] + 0.001; measured[3] = rel[5] + 0.001;
-      c.T_origin_destination = pose_of(measured);
-      c.information_matrix.setZero();
-      c.information_matrix(0, 0) = 1.0; c.information_matrix(1, 1) = 1.0;
-      c.information_matrix(2, 2) = 2500.0; c.information_matrix(3, 3) = 2500.0;
-      graph.addRelativePoseConstraint(c);
-    }
-    // a height measurement on the last submap: z only, against the mission frame (semi-definite: constraint.cpp's LDLT branch)
-    {
-      voxgraph::ReferenceFrameNode::Config frame;
-      frame.reference_frame_id = 0;
-      frame.set_constant = true;
-      frame.T_mission_node_initial = voxblox::Transformation();
-      graph.addReferenceFrameNode(frame);
-      voxgraph::AbsolutePoseConstraint::Config c;
-      c.reference_frame_id = 0;
-      c.submap_id = 13;
-      double at[4] = {0.0, 0.0, truth[3][2] + 0.001, 0.0};
-      c.T_ref_submap = pose_of(at);
-      c.information_matrix.setZero();
-      c.information_matrix(2, 2) = 2500.0;
-      c.allow_semi_definite_information_matrix = true;
-      graph.addAbsolutePoseConstraint(c);
-    }
+    fill_graph(graph, submaps, point_type, truth, drift);
     std::ostringstream sink;  // optimize() prints the solver report
     std::streambuf* old = std::cout.rdbuf(sink.rdbuf());
     graph.optimize();
@@ -203,6 +210,53 @@ int main() {
     double edge_sum = 0;
     for (const auto& e : graph.getVisualizationEdges()) edge_sum += e.residual;
     std::printf("EDGES point_type=%d sum_sq_residuals=%.9e\n", point_type, edge_sum);
+    // PoseGraph::getEdgeCovarianceMap (pose_graph.cpp:117-163; asked for by loop_closure_edge_server.cpp:46 through
+    // pose_graph_interface.cpp:207-218 for every overlapping pair): ceres::Covariance over the problem optimize() left,
+    // i.e. one more evaluation of every cost function WITH Jacobians at the final poses
+    {
+      voxgraph::PoseGraph::EdgeCovarianceMap cov;
+      for (unsigned a = 0; a < 4; ++a)
+        for (unsigned b = a + 1; b < 4 && b <= a + 2; ++b)
+          cov.emplace(voxgraph::SubmapIdPair(10 + a, 10 + b), voxgraph::PoseGraph::EdgeCovarianceMatrix::Zero());
+      const bool ok = graph.getEdgeCovarianceMap(&cov);
+      std::printf("COVARIANCE point_type=%d ok=%d pairs=%zu\n", point_type, (int)ok, cov.size());
+      if (!ok) rc = 1;
+      for (const auto& kv : cov) {
+        std::printf("COV point_type=%d pair=%u,%u", point_type, kv.first.first, kv.first.second);
+        for (int i = 0; i < 4; ++i)
+          for (int j = 0; j < 4; ++j) std::printf(" %.12e", kv.second(i, j));
+        std::printf("\n");
+      }
+    }
+    // The two-stage optimisation after a loop closure (pose_graph_interface.cpp:182-191): first WITHOUT the registration
+    // constraints (optimize(true): constraint_collection.cpp skips them), then with all of them.  The loop closure ties the
+    // last submap to the first (pose_graph_interface.cpp:68-92); a fresh graph, poses starting from the drift again.
+    if (point_type == 1) {
+      voxgraph::PoseGraph graph;
+      fill_graph(graph, submaps, point_type, truth, drift);
+      voxgraph::RelativePoseConstraint::Config c;
+      c.origin_submap_id = 10;
+      c.destination_submap_id = 13;
+      const voxblox::Transformation T_ab = pose_of(truth[0]).inverse() * pose_of(truth[3]);
+      const voxblox::Transformation::Vector6 rel = T_ab.log();
+      double measured[4] = {rel[0] - 0.002, rel[1] + 0.002, rel[2], rel[5] - 0.0005};
+      c.T_origin_destination = pose_of(measured);
+      c.information_matrix.setIdentity();
+      graph.addRelativePoseConstraint(c);
+      std::ostringstream sink2;
+      std::streambuf* old2 = std::cout.rdbuf(sink2.rdbuf());
+      graph.optimize(true);
+      const auto first = graph.getSolverSummaries().back();
+      graph.optimize();
+      std::cout.rdbuf(old2);
+      const auto second = graph.getSolverSummaries().back();
+      std::printf("TWOSTAGE iterations=%d,%d final_cost=%.9e,%.9e\n", first.num_iterations, second.num_iterations, first.final_cost,
+                  second.final_cost);
+      for (const auto& kv : graph.getSubmapPoses()) {
+        const voxblox::Transformation::Vector6 v = kv.second.log();
+        std::printf("POSE2 submap=%u %.9f %.9f %.9f %.9f\n", kv.first, (double)v[0], (double)v[1], (double)v[2], (double)v[5]);
+      }
+    }
   }
   // SubmapRegistrationHelper::testRegistration (submap_registration_helper.cpp:15-71): reading submap 1 against submap 0
   {

@@ -7,7 +7,8 @@
 // (oracle/ref_driver/callers_check.cpp).
 // Round 6: Jet + a real AutoDiffCostFunction (the reference's relative_pose_cost_function_inl.h, i.e. its odometry /
 // loop-closure / absolute-pose constraints, now compile and differentiate against it), and a solver loop that
-// evaluates trial steps cost-only (`jacobians == nullptr`) as Ceres' trust-region minimizer does.
+// evaluates trial steps cost-only (`jacobians == nullptr`) as Ceres' trust-region minimizer does; ceres::Covariance
+// computes (dense (J^T J)^-1 over the free blocks) instead of reporting failure: PoseGraph::getEdgeCovarianceMap runs.
 #ifndef TESTS_STUBS_CERES_CERES_H_
 #define TESTS_STUBS_CERES_CERES_H_
 #include <cmath>
@@ -347,15 +348,6 @@ class Problem {
   std::vector<LocalParameterization*> parameterization_;
 };
 
-// ceres::Covariance: the interface only (pose_graph.cpp:118-165 compiles against it); Compute() reports failure
-class Covariance {
- public:
-  struct Options {};
-  explicit Covariance(const Options&) {}
-  bool Compute(const std::vector<std::pair<const double*, const double*> >&, Problem*) { return false; }
-  bool GetCovarianceBlock(const double*, const double*, double*) const { return false; }
-};
-
 // NumericDiffCostFunction<Functor, CENTRAL, DYNAMIC, 4, 4>(functor, ownership, num_residuals)
 // (submap_registration_helper.cpp:54-57): residuals from functor->Evaluate, Jacobians by central differences
 template <typename Functor, NumericDiffMethodType kMethod, int kNumResiduals, int N0, int N1>
@@ -501,6 +493,67 @@ struct SolverImpl {
     }
     return true;
   }
+};
+
+// ceres::Covariance (pose_graph.cpp:117-163): dense stand-in -- (J^T J)^-1 over the free parameter blocks at the current
+// parameter values, Jacobians requested from every cost function exactly as an evaluation with Jacobians requests them.
+// Ceres (covariance_impl.cc) fails on a rank-deficient Jacobian unless told otherwise, as a failed Cholesky does here;
+// a constant block has zero covariance; the local parameterizations voxgraph uses (identity, angle wrap: node.cpp) have
+// identity Jacobians, so the tangent-space lift is the identity.  A block that was not requested is not served.
+class Covariance {
+ public:
+  struct Options {};
+  explicit Covariance(const Options&) {}
+  bool Compute(const std::vector<std::pair<const double*, const double*> >& blocks, Problem* p) {
+    problem_ = p;
+    requested_ = blocks;
+    offset_.assign(p->params_.size(), -1);
+    nf_ = 0;
+    for (size_t k = 0; k < p->params_.size(); ++k)
+      if (!p->constant_[k]) {
+        offset_[k] = nf_;
+        nf_ += p->sizes_[k];
+      }
+    Solver::Options o;
+    double cost = 0;
+    std::vector<double> g, H;
+    if (!SolverImpl::Evaluate(o, p, offset_, nf_, &cost, &g, &H)) return false;
+    inverse_.assign(static_cast<size_t>(nf_) * nf_, 0.0);
+    const std::vector<double> no_damping(static_cast<size_t>(nf_), 0.0);
+    std::vector<double> e(static_cast<size_t>(nf_)), x;
+    for (int i = 0; i < nf_; ++i) {
+      e.assign(static_cast<size_t>(nf_), 0.0);
+      e[static_cast<size_t>(i)] = -1.0;   // SolveDamped solves H x = -g
+      if (!SolverImpl::SolveDamped(H, no_damping, e, nf_, &x)) return false;
+      for (int j = 0; j < nf_; ++j) inverse_[static_cast<size_t>(j) * nf_ + i] = x[static_cast<size_t>(j)];
+    }
+    return true;
+  }
+  bool GetCovarianceBlock(const double* a, const double* b, double* out) const {
+    if (!problem_) return false;
+    bool asked = false;
+    for (const auto& r : requested_) asked = asked || (r.first == a && r.second == b) || (r.first == b && r.second == a);
+    int ka = -1, kb = -1;
+    for (size_t k = 0; k < problem_->params_.size(); ++k) {
+      if (problem_->params_[k] == a) ka = static_cast<int>(k);
+      if (problem_->params_[k] == b) kb = static_cast<int>(k);
+    }
+    if (!asked || ka < 0 || kb < 0) return false;
+    const int na = problem_->sizes_[static_cast<size_t>(ka)], nb = problem_->sizes_[static_cast<size_t>(kb)];
+    for (int i = 0; i < na; ++i)
+      for (int j = 0; j < nb; ++j) {
+        const int oa = offset_[static_cast<size_t>(ka)], ob = offset_[static_cast<size_t>(kb)];
+        out[i * nb + j] = (oa < 0 || ob < 0) ? 0.0 : inverse_[static_cast<size_t>(oa + i) * nf_ + static_cast<size_t>(ob + j)];
+      }
+    return true;
+  }
+
+ private:
+  Problem* problem_ = nullptr;
+  std::vector<std::pair<const double*, const double*> > requested_;
+  std::vector<int> offset_;
+  int nf_ = 0;
+  std::vector<double> inverse_;
 };
 
 inline void Solve(const Solver::Options& o, Problem* p, Solver::Summary* summary) {
