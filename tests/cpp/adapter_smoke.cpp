@@ -121,17 +121,31 @@ int main() {
     for (int k2 = 0; k2 < 8; ++k2)
       if (std::fabs(g_c[k2] - g_full[k2]) > 1e-6 * (std::fabs(g_full[k2]) + 1e-3 * cost_full))
         return fail("compressed gradient");
-    // moving a pose and re-preparing changes the block; without new_evaluation_point it is cached
+    // without new_evaluation_point, at the same poses, the cache answers (no pass is run) ...
     double before = rc[8];
-    read_pose[0] += 0.05;
+    const long passes = batch.full_evaluations() + batch.cost_only_evaluations();
     cb.PrepareForEvaluation(false, false);
-    block->Evaluate(params, rc, nullptr);
-    if (rc[8] != before) return fail("cache");
-    cb.PrepareForEvaluation(false, true);
-    block->Evaluate(params, rc, nullptr);
+    if (!block->Evaluate(params, rc, nullptr) || rc[8] != before || batch.full_evaluations() + batch.cost_only_evaluations() != passes)
+      return fail("cache");
+    // ... but never for another point: a pose moved WITHOUT an announcement (Problem::Evaluate and Covariance::Compute do
+    // not call the callback of Solver::Options) is noticed by the block itself, which has the batch evaluated there
+    read_pose[0] += 0.05;
+    if (!block->Evaluate(params, rc, nullptr)) return fail("unannounced evaluation");
     double c2 = 0;
     for (int m = 0; m < 9; ++m) c2 += rc[m] * rc[m];
-    if (std::fabs(c2 - cost_c) < 1e-9 * cost_c) return fail("re-evaluation");
+    if (std::fabs(c2 - cost_c) < 1e-9 * cost_c || batch.unannounced_evaluations() != 1) return fail("stale cache served");
+    // the announced (cost-only) re-evaluation at that point gives the same cost
+    cb.PrepareForEvaluation(false, true);
+    double rc2[9], c3 = 0;
+    if (!block->Evaluate(params, rc2, nullptr)) return fail("re-evaluation");
+    for (int m = 0; m < 9; ++m) c3 += rc2[m] * rc2[m];
+    if (std::fabs(c3 - c2) > 1e-6 * c2) return fail("re-evaluation: another cost");
+    // parameters that are neither the cached point nor what the user's blocks hold: an evaluation failure, not a guess
+    {
+      double elsewhere[4] = {read_pose[0] + 1.0, read_pose[1], read_pose[2], read_pose[3]};
+      const double* p2[2] = {params[0] == read_pose ? elsewhere : params[0], params[1] == read_pose ? elsewhere : params[1]};
+      if (block->Evaluate(p2, rc2, nullptr)) return fail("a value for parameters nobody holds");
+    }
     read_pose[0] -= 0.05;
     std::printf("batched Ceres path ok: cost %.6f == %.6f\n", cost_c, cost_full);
     // ---- the same two constraints sharded over two contexts (one device here; one per GPU
@@ -164,7 +178,8 @@ int main() {
         if (r_s[q] != r_m[q]) return fail("multi block differs from the single-GPU block");
       for (int q = 0; q < 36; ++q)
         if (j_s0[q] != j_m0[q] || j_s1[q] != j_m1[q]) return fail("multi Jacobian differs");
-      if (!block2->Evaluate(params, r_s, nullptr) || !m2->Evaluate(params, r_m, nullptr)) return fail("multi block 2");
+      double* params_mirrored[2] = {read_pose, ref_pose};   // block2 / m2 were added with the blocks in this order
+      if (!block2->Evaluate(params_mirrored, r_s, nullptr) || !m2->Evaluate(params_mirrored, r_m, nullptr)) return fail("multi block 2");
       for (int q = 0; q < 9; ++q)
         if (r_s[q] != r_m[q]) return fail("multi block 2 differs");
       double two_poses[8];

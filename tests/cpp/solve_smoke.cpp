@@ -89,6 +89,25 @@ int main() {
   ceres::Solver::Options options;                       // pose_graph.cpp:90-97 (tolerances: Ceres defaults)
   options.max_num_iterations = 50;
   double end[3][4];
+  // what Ceres evaluates WITHOUT announcing it to an evaluation callback (the callback sits in Solver::Options): a
+  // residual-only Problem::Evaluate (PoseGraph::getVisualizationEdges, pose_graph.cpp:173-174) and Covariance::Compute
+  // (getEdgeCovarianceMap, pose_graph.cpp:140) -- at the final point, and at a point no solver evaluation saw
+  double final_cost_again[3] = {0, 0, 0}, probe_cost[3] = {0, 0, 0}, covariance[3][16];
+  const double probe_offset[4] = {0.02, -0.015, 0.01, 0.004};
+  auto unannounced = [&](int route, ceres::Problem* problem, double* b) -> bool {
+    bool ok = problem->Evaluate(ceres::Problem::EvaluateOptions(), &final_cost_again[route], nullptr, nullptr, nullptr);
+    double keep[4];
+    for (int k = 0; k < 4; ++k) keep[k] = b[k], b[k] = end[0][k] + probe_offset[k];   // the same point on every route
+    ok = ok && problem->Evaluate(ceres::Problem::EvaluateOptions(), &probe_cost[route], nullptr, nullptr, nullptr);
+    for (int k = 0; k < 4; ++k) b[k] = end[0][k];
+    ceres::Covariance::Options covariance_options;
+    ceres::Covariance cov(covariance_options);
+    std::vector<std::pair<const double*, const double*> > blocks;
+    blocks.emplace_back(b, b);
+    ok = ok && cov.Compute(blocks, problem) && cov.GetCovarianceBlock(b, b, covariance[route]);
+    for (int k = 0; k < 4; ++k) b[k] = keep[k];
+    return ok;
+  };
   // ---- 1. drop-in cost functions -----------------------------------------------------------------------
   {
     double a[4], b[4];
@@ -102,6 +121,8 @@ int main() {
     report("drop-in", summary, b);
     for (int k = 0; k < 4; ++k) end[0][k] = b[k];
     if (!(summary.final_cost < 0.05 * summary.initial_cost)) return std::printf("FAIL: drop-in did not converge\n"), 1;
+    if (!unannounced(0, &problem, b)) return std::printf("FAIL: drop-in: Problem::Evaluate / Covariance failed\n"), 1;
+    if (std::fabs(final_cost_again[0] - summary.final_cost) > 1e-9 * summary.final_cost) return std::printf("FAIL: drop-in: cost at the final point\n"), 1;
   }
   // ---- 2. batched evaluation callback ----------------------------------------------------------------------
   {
@@ -128,6 +149,15 @@ int main() {
     if (summary.num_cost_only_evaluations < 1 || batch.cost_only_evaluations() != summary.num_cost_only_evaluations ||
         batch.full_evaluations() != summary.num_jacobian_evaluations)
       return std::printf("FAIL: cost-only evaluations did not take the cost-only route\n"), 1;
+    // Unannounced evaluations: the blocks notice that their parameters are not the cached point's (or that Jacobians are
+    // asked of a cost-only cache) and have the batch evaluated where the user's parameter blocks are
+    if (!unannounced(1, &problem, b)) return std::printf("FAIL: batched: Problem::Evaluate / Covariance failed\n"), 1;
+    std::printf("batched: %ld evaluations the blocks asked for themselves (Problem::Evaluate x 2, Covariance::Compute)\n",
+                batch.unannounced_evaluations());
+    if (std::fabs(final_cost_again[1] - summary.final_cost) > 1e-9 * summary.final_cost)
+      return std::printf("FAIL: batched: Problem::Evaluate after the solve is not the final cost (%.9e vs %.9e): a stale cache\n",
+                         final_cost_again[1], summary.final_cost), 1;
+    if (batch.unannounced_evaluations() < 2) return std::printf("FAIL: batched: no unannounced evaluation was noticed\n"), 1;
   }
   // ---- 3. two contexts ----------------------------------------------------------------------------------------
   {
@@ -149,6 +179,20 @@ int main() {
     for (int k = 0; k < 4; ++k) end[2][k] = b[k];
     if (batch.cost_only_evaluations() != summary.num_cost_only_evaluations || batch.full_evaluations() != summary.num_jacobian_evaluations)
       return std::printf("FAIL: multi: cost-only evaluations did not take the cost-only route\n"), 1;
+    if (!unannounced(2, &problem, b)) return std::printf("FAIL: multi: Problem::Evaluate / Covariance failed\n"), 1;
+    if (std::fabs(final_cost_again[2] - summary.final_cost) > 1e-9 * summary.final_cost) return std::printf("FAIL: multi: stale cache\n"), 1;
+  }
+  // ---- the unannounced evaluations agree across the routes (the compressed blocks have the originals' normal equations) ----
+  {
+    double worst_cost = 0, worst_cov = 0, cov_scale = 0;
+    for (int k = 0; k < 16; ++k) cov_scale = std::fmax(cov_scale, std::fabs(covariance[0][k]));
+    for (int r = 1; r < 3; ++r) {
+      worst_cost = std::fmax(worst_cost, std::fabs(probe_cost[r] - probe_cost[0]) / probe_cost[0]);
+      for (int k = 0; k < 16; ++k) worst_cov = std::fmax(worst_cov, std::fabs(covariance[r][k] - covariance[0][k]) / cov_scale);
+    }
+    std::printf("unannounced evaluations: cost at a point no solve saw %.9e (routes agree to %.1e), covariance of the free pose "
+                "(routes agree to %.1e of its largest entry %.3e)\n", probe_cost[0], worst_cost, worst_cov, cov_scale);
+    if (!(probe_cost[0] > 0) || worst_cost > 1e-5 || !(cov_scale > 0) || worst_cov > 1e-4) return std::printf("FAIL: unannounced evaluations disagree\n"), 1;
   }
   // ---- same end pose on every route: 1 mm / 0.01 degree -------------------------------------------------------
   double worst_xyz = 0, worst_yaw = 0, from_truth = 0;

@@ -20,6 +20,15 @@
 // request runs the cost-only pass (vgx_reg_batch_evaluate_cost: one sum per constraint, no gradient, nothing to
 // compress) and every block answers with the residual vector (sqrt(cost), 0, ..., 0) -- all Ceres reads there is its
 // squared norm, and that cost is, bit for bit, the one the full evaluation at the same point reports.
+//
+// Evaluations Ceres does NOT announce (round 6): with the callback in Solver::Options (the Ceres the reference builds
+// against) only ceres::Solve calls PrepareForEvaluation -- Problem::Evaluate (PoseGraph::getVisualizationEdges,
+// pose_graph.cpp:173-174) and Covariance::Compute (getEdgeCovarianceMap, :140) evaluate the blocks without it, possibly
+// right after a solve whose last announced point was a REJECTED step.  A block therefore checks the `parameters` it is
+// handed against the poses its cache was computed at (bit compare, 8 doubles) and, on a mismatch or when Jacobians are
+// asked of a cost-only cache, has the batch evaluated again at the point the user's parameter blocks hold -- which is
+// where Ceres evaluates in both cases.  If the parameters are not what the user's blocks hold either (an evaluation at
+// explicitly passed parameter values), the block reports an evaluation failure rather than a value for another point.
 #ifndef VOXGRAPH_AMD_CPP_GPU_REGISTRATION_BATCH_H_
 #define VOXGRAPH_AMD_CPP_GPU_REGISTRATION_BATCH_H_
 
@@ -28,6 +37,7 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -50,8 +60,25 @@ class GpuRegistrationBlocks : public ceres::EvaluationCallback {
   // the cache can answer does not draw where the reference would: fewer draws, each a legal one (include/voxgraph_amd.h,
   // vgx_reg_batch_evaluate_cost).
   void PrepareForEvaluation(bool evaluate_jacobians, bool new_evaluation_point) override {
+    std::lock_guard<std::mutex> lk(mu_);
+    Prepare(evaluate_jacobians, new_evaluation_point);
+  }
+
+  int num_constraints() const { return static_cast<int>(regs_.size()); }
+  // evaluations so far by route: the full fused pass (normal equations, compressed) / the cost-only pass
+  long full_evaluations() const { return full_evaluations_; }
+  long cost_only_evaluations() const { return cost_only_evaluations_; }
+  // evaluations a block asked for itself because its parameters were not the cached point's (see the header comment)
+  long unannounced_evaluations() const { return unannounced_evaluations_; }
+
+ protected:
+  virtual void EvaluateNormals(const double* poses, int32_t n_nodes, double* normal, int32_t* status) = 0;
+  virtual void EvaluateCosts(const double* poses, int32_t n_nodes, double* cost, int32_t* status) = 0;
+
+ private:
+  void Prepare(bool evaluate_jacobians, bool new_evaluation_point) {   // (mu_ held)
     if (!finalized_) throw std::logic_error("GpuRegistrationBatch: Finalize() was not called");
-    if (!new_evaluation_point && valid_ && (have_jacobians_ || !evaluate_jacobians)) return;
+    if (!new_evaluation_point && valid_ && (have_jacobians_ || !evaluate_jacobians) && PosesCurrent()) return;
     for (size_t k = 0; k < nodes_.size(); ++k) std::memcpy(&poses_[4 * k], nodes_[k], 4 * sizeof(double));
     if (evaluate_jacobians) {
       EvaluateNormals(poses_.data(), static_cast<int32_t>(nodes_.size()), normal_.data(), status_.data());
@@ -70,16 +97,23 @@ class GpuRegistrationBlocks : public ceres::EvaluationCallback {
     have_jacobians_ = evaluate_jacobians;
     valid_ = true;
   }
-
-  int num_constraints() const { return static_cast<int>(regs_.size()); }
-  // evaluations so far by route: the full fused pass (normal equations, compressed) / the cost-only pass
-  long full_evaluations() const { return full_evaluations_; }
-  long cost_only_evaluations() const { return cost_only_evaluations_; }
+  // the user's parameter blocks still hold the poses the cache was computed at
+  bool PosesCurrent() const {
+    for (size_t k = 0; k < nodes_.size(); ++k)
+      if (std::memcmp(&poses_[4 * k], nodes_[k], 4 * sizeof(double)) != 0) return false;
+    return true;
+  }
+  // the cache answers block `index` for these parameters
+  bool Serves(int index, double const* const* parameters, bool jacobians) const {
+    if (!valid_ || (jacobians && !have_jacobians_)) return false;
+    for (int side = 0; side < 2; ++side)
+      if (std::memcmp(parameters[side], &poses_[4 * static_cast<size_t>(node_pair_[2 * static_cast<size_t>(index) + side])],
+                      4 * sizeof(double)) != 0)
+        return false;
+    return true;
+  }
 
  protected:
-  virtual void EvaluateNormals(const double* poses, int32_t n_nodes, double* normal, int32_t* status) = 0;
-  virtual void EvaluateCosts(const double* poses, int32_t n_nodes, double* cost, int32_t* status) = 0;
-
   ceres::CostFunction* AddBlock(vgx_reg reg, const double* pose_reference, const double* pose_reading) {
     if (finalized_) throw std::logic_error("GpuRegistrationBatch: AddConstraint after Finalize");
     regs_.push_back(reg);
@@ -106,14 +140,17 @@ class GpuRegistrationBlocks : public ceres::EvaluationCallback {
   // The 9-residual stand-in for one RegistrationCostFunction.
   class Block : public ceres::SizedCostFunction<9, 4, 4> {
    public:
-    Block(const GpuRegistrationBlocks* owner, int index) : owner_(owner), index_(index) {}
-    bool Evaluate(double const* const* /*parameters*/, double* residuals,
+    Block(GpuRegistrationBlocks* owner, int index) : owner_(owner), index_(index) {}
+    bool Evaluate(double const* const* parameters, double* residuals,
                   double** jacobians) const override {
-      const GpuRegistrationBlocks& o = *owner_;
-      if (!o.valid_) return false;
-      // (Ceres announces what it will ask for: PrepareForEvaluation(jacobian != nullptr || gradient != nullptr, ...).  A
-      // caller that asks a cost-only evaluation for Jacobians broke that contract: an evaluation failure, not a guess.)
-      if (jacobians && !o.have_jacobians_) return false;
+      GpuRegistrationBlocks& o = *owner_;
+      std::lock_guard<std::mutex> lk(o.mu_);   // (Ceres evaluates blocks from several threads: pose_graph.cpp:96)
+      if (!o.Serves(index_, parameters, jacobians != nullptr)) {
+        // not announced (Problem::Evaluate, Covariance::Compute; see the header comment): the point in the user's blocks
+        o.Prepare(jacobians != nullptr || o.have_jacobians_, /*new_evaluation_point=*/true);
+        ++o.unannounced_evaluations_;
+        if (!o.Serves(index_, parameters, jacobians != nullptr)) return false;  // parameters from somewhere else: no guess
+      }
       if (o.status_[static_cast<size_t>(index_)] == VGX_EVALUATE_FALSE) return false;  // .cpp:273
       std::memcpy(residuals, &o.compressed_r_[9 * static_cast<size_t>(index_)], 9 * sizeof(double));
       if (jacobians) {
@@ -127,7 +164,7 @@ class GpuRegistrationBlocks : public ceres::EvaluationCallback {
     }
 
    private:
-    const GpuRegistrationBlocks* owner_;
+    GpuRegistrationBlocks* owner_;
     int index_;
   };
 
@@ -147,7 +184,8 @@ class GpuRegistrationBlocks : public ceres::EvaluationCallback {
   bool finalized_ = false;
   bool valid_ = false;
   bool have_jacobians_ = false;   // the cache holds the compressed Jacobians (else residual-only blocks of a cost-only pass)
-  long full_evaluations_ = 0, cost_only_evaluations_ = 0;
+  long full_evaluations_ = 0, cost_only_evaluations_ = 0, unannounced_evaluations_ = 0;
+  std::mutex mu_;   // the cache: PrepareForEvaluation / a block's own refresh write it, every block's Evaluate reads it
 };
 
 // One GPU.
