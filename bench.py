@@ -495,6 +495,31 @@ def main():
             torch.cuda.empty_cache()
         except Exception as e:   # noqa: BLE001
             print(f"bench.py: blocked-layout timing skipped: {e!r}", file=sys.stderr)
+    # the same pass in Ceres' own types (vgx_reg_batch_evaluate_points_f64: f64 rows, 72 B written per row -- SURVEY.md
+    # 8d's "124 B" variant, reported alongside, never instead); its f32 rounding must be the timed pass's rows
+    f64_rows_ms, f64_rows_match = None, None
+    if R > 0 and world == 1:
+        try:
+            r64 = torch.empty(R, dtype=torch.float64, device="cuda")
+            jo64 = torch.empty((R, 4), dtype=torch.float64, device="cuda")
+            je64 = torch.empty((R, 4), dtype=torch.float64, device="cuda")
+            for _ in range(2):
+                batch.evaluate_points_f64(poses, r64.data_ptr(), jo64.data_ptr(), je64.data_ptr())
+            torch.cuda.synchronize()
+            ctx.timer_start()
+            for _ in range(10):
+                batch.evaluate_points_f64(poses, r64.data_ptr(), jo64.data_ptr(), je64.data_ptr())
+            f64_rows_ms = ctx.timer_stop() / 10
+            # (the ceiling launches above wrote over the f32 arrays: the f32 pass once more, then the comparison)
+            batch.evaluate_points(poses, residuals.data_ptr(), jac_ref.data_ptr(), jac_read.data_ptr())
+            torch.cuda.synchronize()
+            f64_rows_match = bool(torch.equal(r64.float().view(torch.int32), residuals[:R].view(torch.int32))
+                                  and torch.equal(jo64.float().view(torch.int32), jac_ref[:R].view(torch.int32))
+                                  and torch.equal(je64.float().view(torch.int32), jac_read[:R].view(torch.int32)))
+            del r64, jo64, je64
+            torch.cuda.empty_cache()
+        except Exception as e:   # noqa: BLE001
+            print(f"bench.py: f64-rows timing skipped: {e!r}", file=sys.stderr)
 
     # ---- full-overlap workload, timed the same way (HIP events on the kernel's stream) ----
     fo_out = None
@@ -934,6 +959,11 @@ def main():
                                                     / HBM_PEAK_GBS) if placement.get("ms_sets") else achieved / HBM_PEAK_GBS,
                          "frac_blocked_layout": (bytes_conservative / (blocked_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if blocked_ms else None,
                          "blocked_layout_ms": blocked_ms,
+                         # f64 rows (Ceres' types; 36 more bytes written per row): ms, fraction of peak by its own bytes,
+                         # and whether every value's f32 rounding is the timed f32 pass's value
+                         "f64_rows_ms": f64_rows_ms,
+                         "f64_rows_frac": ((bytes_conservative + 36.0 * R) / (f64_rows_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if f64_rows_ms else None,
+                         "f64_rows_round_to_the_f32_rows": f64_rows_match,
                          "frac_note": "frac: arrays selected among the candidates; frac_first / frac_median_allocation: the "
                                       "first / median candidate set (3-launch trials of the selection); frac_blocked_layout: "
                                       "vgx_reg_batch_evaluate_points_blocked, placement-proof",

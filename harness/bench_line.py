@@ -80,7 +80,7 @@ def compact(full, detail_path):
                                  "frac_of_copy_ceiling", "traffic_frac_of_copy_ceiling", "frac_of_kernel_shaped_ceiling",
                                  "kernel", "kernel_ms", "units_per_launch", "bytes_per_launch", "with_correspondence_frac",
                                  "placement_ms_sets", "frac_first_allocation", "frac_median_allocation", "frac_blocked_layout",
-                                 "blocked_layout_ms"))
+                                 "blocked_layout_ms", "f64_rows_ms", "f64_rows_frac", "f64_rows_round_to_the_f32_rows"))
     bx = d.get("box") or {}
     sy = (bx.get("before") or {}).get("sysfs") or {}
     du = bx.get("during_timed_region") or {}

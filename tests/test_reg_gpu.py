@@ -399,6 +399,48 @@ def test_blocked_output_layout_holds_the_same_rows(capi, ctx, small_graph):
     batch.destroy()
 
 
+def test_batched_f64_rows_are_the_reference_f64_rows(capi, ctx, small_graph):
+    """vgx_reg_batch_evaluate_points_f64: the materialising pass in Ceres' own types (SURVEY.md 8d's 124-byte variant) -- every
+    f64 EQUAL to the oracle's (which is pinned to the reference's own source: tests/test_ref_pin.py) and to the drop-in
+    vgx_reg_evaluate's for the same constraint; its f32 rounding is the f32 pass's row, bit for bit; a null Jacobian block
+    is honoured; a misaligned Jacobian array is refused"""
+    import torch
+    G = small_graph
+    batch = capi.RegistrationBatch(ctx, G["cfs"], G["pairs"])
+    ro, R = batch.row_offsets(), batch.num_residuals()
+    r, jo, je = _torch_buf(R, torch.float64), _torch_buf(4 * R, torch.float64), _torch_buf(4 * R, torch.float64)
+    r32, jo32, je32 = _torch_buf(R, torch.float32), _torch_buf(4 * R, torch.float32), _torch_buf(4 * R, torch.float32)
+    torch.cuda.synchronize()
+    st = batch.evaluate_points_f64(G["poses"], r.data_ptr(), jo.data_ptr(), je.data_ptr())
+    st32 = batch.evaluate_points(G["poses"], r32.data_ptr(), jo32.data_ptr(), je32.data_ptr())
+    ctx.synchronize()
+    assert np.all(st == 0) and np.array_equal(st, st32)
+    rr, jjo, jje = r.cpu().numpy(), jo.cpu().numpy().reshape(R, 4), je.cpu().numpy().reshape(R, 4)
+    assert np.array_equal(rr.astype(F).view(np.uint32), r32.cpu().numpy().view(np.uint32))
+    assert np.array_equal(jjo.astype(F).view(np.uint32), jo32.cpu().numpy().reshape(R, 4).view(np.uint32))
+    assert np.array_equal(jje.astype(F).view(np.uint32), je32.cpu().numpy().reshape(R, 4).view(np.uint32))
+    rows = 0
+    for c, (a, b) in enumerate(G["pairs"]):
+        xyz, dist, w = G["pts"][a]
+        ok0, r0, jo0, je0 = orc.reg_evaluate(G["layers"][b], xyz, dist, w, G["poses"][a], G["poses"][b])
+        s = slice(ro[c], ro[c + 1])
+        assert ok0 and np.array_equal(rr[s], r0) and np.array_equal(jjo[s], jo0) and np.array_equal(jje[s], je0), c
+        ok1, r1, jo1, je1 = _gpu_eval(G["cfs"][c], G["poses"][a], G["poses"][b])
+        assert ok1 and np.array_equal(rr[s], r1) and np.array_equal(jjo[s], jo1) and np.array_equal(jje[s], je1), c
+        rows += len(r0)
+    assert rows == R and np.count_nonzero(jjo) > 0
+    # jacobians[0] == nullptr (a constant block, pose_graph_interface.cpp:30-32): residuals and the other block as before
+    je2 = _torch_buf(4 * R, torch.float64)
+    r2 = _torch_buf(R, torch.float64)
+    torch.cuda.synchronize()
+    batch.evaluate_points_f64(G["poses"], r2.data_ptr(), None, je2.data_ptr())
+    ctx.synchronize()
+    assert np.array_equal(r2.cpu().numpy(), rr) and np.array_equal(je2.cpu().numpy().reshape(R, 4), jje)
+    with pytest.raises(Exception, match="aligned"):
+        batch.evaluate_points_f64(G["poses"], r.data_ptr(), jo.data_ptr() + 16, je.data_ptr())
+    batch.destroy()
+
+
 def test_cost_only_pass_is_the_full_pass_cost_bit_for_bit(capi, ctx, small_graph):
     """vgx_reg_batch_evaluate_cost (what Ceres asks for at every trial step: `jacobians == nullptr`,
     registration_cost_function.cpp:179): the same f32 operations in the same order through the same reduction tree, so the

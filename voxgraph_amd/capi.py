@@ -125,6 +125,7 @@ SIGNATURES = {
     "vgx_reg_batch_num_residuals": (C.c_int64, [vp]),
     "vgx_reg_batch_row_offsets": (C.c_int, [vp, i64p]),
     "vgx_reg_batch_evaluate_points": (C.c_int, [vp, f64p, C.c_int32, vp, vp, vp, i32p]),
+    "vgx_reg_batch_evaluate_points_f64": (C.c_int, [vp, f64p, C.c_int32, vp, vp, vp, i32p]),
     "vgx_reg_batch_evaluate_cost": (C.c_int, [vp, f64p, C.c_int32, vp, f64p, i32p]),
     "vgx_reg_batch_blocked_layout": (C.c_int, [vp, C.POINTER(C.c_int64), i32p, C.POINTER(C.c_int64)]),
     "vgx_reg_batch_evaluate_points_blocked": (C.c_int, [vp, f64p, C.c_int32, vp, i32p]),
@@ -557,6 +558,16 @@ class RegistrationBatch:
         poses = _f64(poses).reshape(-1, 4)
         status = np.zeros(max(self.n, 1), np.int32)
         self.ctx.check(self.ctx.lib.vgx_reg_batch_evaluate_points(
+            self.h, _ptr(poses, f64p), poses.shape[0], vp(d_residuals),
+            vp(d_jac_ref) if d_jac_ref else None, vp(d_jac_read) if d_jac_read else None,
+            _ptr(status, i32p)))
+        return status[:self.n]
+
+    def evaluate_points_f64(self, poses, d_residuals, d_jac_ref, d_jac_read):
+        """vgx_reg_batch_evaluate_points_f64: the same rows as f64 (Ceres' own types) into device arrays"""
+        poses = _f64(poses).reshape(-1, 4)
+        status = np.zeros(max(self.n, 1), np.int32)
+        self.ctx.check(self.ctx.lib.vgx_reg_batch_evaluate_points_f64(
             self.h, _ptr(poses, f64p), poses.shape[0], vp(d_residuals),
             vp(d_jac_ref) if d_jac_ref else None, vp(d_jac_read) if d_jac_read else None,
             _ptr(status, i32p)))

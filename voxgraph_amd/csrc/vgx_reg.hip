@@ -1543,7 +1543,11 @@ static void launch_points(vgx_ctx ctx, int vps, int layout, const ConstraintDev*
 #define VGX_LAUNCH_POINTS(VPS, LAYOUT, NT, NTL)                                                             \
   hipLaunchKernelGGL((reg_eval_points_kernel<VPS, LAYOUT, OUT, kPointsPerThread, NT, NTL>), grid, block, 0, \
                      ctx->stream, d_desc, d_pack, d_tiles, d_tile_dead, n_tiles, (OUT*)res, (O4*)jr, (O4*)je, blocked ? 1 : 0)
-  if (layout == 0) {  // apron bricks: the A/B switches of the non-temporal hints live here
+  if (sizeof(OUT) == 8) {
+    // f64 rows (vgx_reg_batch_evaluate_points_f64): apron bricks with the default hints only (the caller checked the layout)
+    if (vps == 16) VGX_LAUNCH_POINTS(16, 0, kNonTemporalStores, kNonTemporalLoads);
+    else VGX_LAUNCH_POINTS(8, 0, kNonTemporalStores, kNonTemporalLoads);
+  } else if (layout == 0) {  // apron bricks: the A/B switches of the non-temporal hints live here
     if (vps == 16) {
       if (nt && ntl) VGX_LAUNCH_POINTS(16, 0, true, true);
       else if (nt) VGX_LAUNCH_POINTS(16, 0, true, false);
@@ -2358,6 +2362,33 @@ int vgx_reg_batch_evaluate_points(vgx_reg_batch b, const double* poses, int32_t 
   }
   launch_points<float>(ctx, b->regs[0]->reading->vps, b->layout, b->d_desc, b->d_pack, b->d_tiles, b->d_tile_dead,
                        (int)b->tiles.size(), d_residuals, d_jac_ref, d_jac_read);
+  VGX_HIP(ctx, hipGetLastError());
+  return VGX_OK;
+}
+
+// The materialising pass in Ceres' own types: f64 rows, every value the reference's f64 (include/voxgraph_amd.h).
+int vgx_reg_batch_evaluate_points_f64(vgx_reg_batch b, const double* poses, int32_t n_nodes, void* d_residuals,
+                                      void* d_jac_ref, void* d_jac_read, int32_t* status) {
+  if (!b || !poses) return VGX_ERR_INVALID;
+  vgx_ctx ctx = b->ctx;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!d_residuals) return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_batch_evaluate_points_f64: residuals == NULL");
+  if (((uintptr_t)d_jac_ref | (uintptr_t)d_jac_read) & 31u)
+    return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_batch_evaluate_points_f64: Jacobian arrays must be 32-byte aligned (one row)");
+  if (b->n > 0 && b->layout != VGX_BRICKS_APRON)
+    return set_error(ctx, VGX_ERR_UNSUPPORTED, "vgx_reg_batch_evaluate_points_f64: apron bricks only (the default layout)");
+  VGX_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = batch_begin(b);
+  if (rc == VGX_OK) rc = batch_upload_packs(b, poses, n_nodes, status);
+  if (rc != VGX_OK) return rc;
+  if (b->n == 0) return VGX_OK;
+  if (!b->points_order_made && !b->tiles.empty()) {
+    rc = apply_launch_order(b, b->tiles, b->d_tiles, b->host_points_tile_first, /*points_pass=*/true);
+    if (rc != VGX_OK) return rc;
+    b->points_order_made = true;
+  }
+  launch_points<double>(ctx, b->regs[0]->reading->vps, b->layout, b->d_desc, b->d_pack, b->d_tiles, b->d_tile_dead,
+                        (int)b->tiles.size(), d_residuals, d_jac_ref, d_jac_read);
   VGX_HIP(ctx, hipGetLastError());
   return VGX_OK;
 }
