@@ -45,12 +45,19 @@ def is_cost_only(name):
     return bool(re.search(r"reg_eval_reduce_lean_kernel<[^>]*true>", name))
 
 
+def is_f64_rows(name):
+    """the OUT = double instantiation of the materialising kernel (vgx_reg_batch_evaluate_points_f64 and the drop-in
+    vgx_reg_evaluate): kept apart from the f32 headline kernel, whose name and grids it shares"""
+    import re
+    return bool(re.search(r"reg_eval_points(_single)?_kernel<\d+, \d+, double", name))
+
+
 def dispatches(prefix, kernel, cost_only=False):
     """[{counter: value, "grid": n}] per dispatch of `kernel`, in dispatch order (cost_only: that instantiation alone,
     else every other one)"""
     d = {}
     for x in rows(f"{prefix}/**/*counter_collection.csv"):
-        if kernel in x.get("Kernel_Name", "") and is_cost_only(x.get("Kernel_Name", "")) == cost_only:
+        if kernel in x.get("Kernel_Name", "") and is_cost_only(x.get("Kernel_Name", "")) == cost_only and not is_f64_rows(x.get("Kernel_Name", "")):
             e = d.setdefault(int(x["Dispatch_Id"]), {"grid": int(x["Grid_Size"])})
             e[x["Counter_Name"]] = float(x["Counter_Value"])
     return [d[k] for k in sorted(d)]
@@ -80,12 +87,13 @@ def mean(v):
     return sum(v) / len(v) if v else None
 
 
-def by_grid(trace, kernel, cost_only=False):
+def by_grid(trace, kernel, cost_only=False, f64_rows=False):
     """kernel-trace rows of one kernel grouped per grid size, in order of first appearance:
     [(grid, [duration_ns, ...])]"""
     g = collections.OrderedDict()
     for x in trace:
-        if kernel in x.get("Kernel_Name", "") and is_cost_only(x.get("Kernel_Name", "")) == cost_only:
+        if (kernel in x.get("Kernel_Name", "") and is_cost_only(x.get("Kernel_Name", "")) == cost_only
+                and is_f64_rows(x.get("Kernel_Name", "")) == f64_rows):
             g.setdefault(int(x["Grid_Size_X"]), []).append(int(x["End_Timestamp"]) - int(x["Start_Timestamp"]))
     return list(g.items())
 
@@ -135,6 +143,10 @@ def main():
             pw["full_overlap_points_plain_order"] = entry(durs[half:], plain, grid=pts[1][0])
             durs = durs[:half]
         pw["full_overlap_points"] = entry(durs, fo_b["kernel_ms"], grid=pts[1][0])
+    # the f64-rows instantiation (vgx_reg_batch_evaluate_points_f64) on config 3's grid: two warm-up launches, then the timed ten
+    for grid, durs in by_grid(trace, "reg_eval_points_kernel<", f64_rows=True)[:1]:
+        f64_ms = ((bench or {}).get("roofline") or {}).get("f64_rows_ms")
+        pw["config3_points_f64_rows"] = entry(durs[2:] if len(durs) > 2 else durs, f64_ms, grid=grid)
     red = by_grid(trace, FUSED)
     # grids in order of first appearance in bench.py: config 3, full overlap, shipped (sampled), the two
     # shards of the in-process multi-context section, config 5
