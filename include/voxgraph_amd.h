@@ -326,8 +326,7 @@ VGX_API int vgx_reg_batch_evaluate_points(vgx_reg_batch batch,
 /* The same pass in Ceres' own types: residuals[R] and jac_*[R][4] as F64, every value the f64 the reference's Evaluate writes
  * (registration_cost_function.cpp:163-166, 254-267, scaled as :274-291) -- what vgx_reg_evaluate returns for one constraint,
  * for the whole list in one launch and left on the device (72 B per row written instead of 36: SURVEY.md 8d's "124 B"
- * variant).  Same arguments and status as vgx_reg_batch_evaluate_points; jac_* 32-byte aligned (one row); the default
- * (apron) brick layout only. */
+ * variant).  Same arguments and status as vgx_reg_batch_evaluate_points; jac_* 32-byte aligned (one row). */
 VGX_API int vgx_reg_batch_evaluate_points_f64(vgx_reg_batch batch, const double* poses /* [n_nodes][4] */, int32_t n_nodes,
                                               void* d_residuals, void* d_jac_ref, void* d_jac_read, int32_t* status);
 

@@ -106,6 +106,21 @@ def test_batched_sampling_follows_the_shared_sampler_streams(capi, ctx, graph, m
             # f32 outputs of the same f64 values: exact
             assert np.array_equal(r[s], r0.astype(F)), (call, c)
             assert np.array_equal(jo[s], jo0.astype(F)) and np.array_equal(je[s], je0.astype(F)), (call, c)
+    # the same pass in Ceres' own types (vgx_reg_batch_evaluate_points_f64) is one more evaluation of the batch: it draws
+    # on, and every f64 is the oracle's
+    import torch
+    R = batch.num_residuals()
+    r64 = torch.full((R,), float("nan"), dtype=torch.float64, device="cuda:0")
+    jo64 = torch.full((R, 4), float("nan"), dtype=torch.float64, device="cuda:0")
+    je64 = torch.full((R, 4), float("nan"), dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    assert np.all(batch.evaluate_points_f64(poses, r64.data_ptr(), jo64.data_ptr(), je64.data_ptr()) == 0)
+    ctx.synchronize()
+    r64, jo64, je64 = r64.cpu().numpy(), jo64.cpu().numpy(), je64.cpu().numpy()
+    for c in range(len(PAIRS)):
+        r0, jo0, je0 = oracle_rows(c)
+        s = slice(ro[c], ro[c + 1])
+        assert np.array_equal(r64[s], r0) and np.array_equal(jo64[s], jo0) and np.array_equal(je64[s], je0), c
     # a drop-in Evaluate in between continues the SAME stream on the host ...
     c = 1
     n = cfs[c].num_residuals()

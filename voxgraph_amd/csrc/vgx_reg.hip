@@ -1543,8 +1543,8 @@ static void launch_points(vgx_ctx ctx, int vps, int layout, const ConstraintDev*
 #define VGX_LAUNCH_POINTS(VPS, LAYOUT, NT, NTL)                                                             \
   hipLaunchKernelGGL((reg_eval_points_kernel<VPS, LAYOUT, OUT, kPointsPerThread, NT, NTL>), grid, block, 0, \
                      ctx->stream, d_desc, d_pack, d_tiles, d_tile_dead, n_tiles, (OUT*)res, (O4*)jr, (O4*)je, blocked ? 1 : 0)
-  if (sizeof(OUT) == 8) {
-    // f64 rows (vgx_reg_batch_evaluate_points_f64): apron bricks with the default hints only (the caller checked the layout)
+  if (sizeof(OUT) == 8 && layout == 0) {
+    // f64 rows (vgx_reg_batch_evaluate_points_f64): the default hints only (no A/B switches)
     if (vps == 16) VGX_LAUNCH_POINTS(16, 0, kNonTemporalStores, kNonTemporalLoads);
     else VGX_LAUNCH_POINTS(8, 0, kNonTemporalStores, kNonTemporalLoads);
   } else if (layout == 0) {  // apron bricks: the A/B switches of the non-temporal hints live here
@@ -2375,8 +2375,6 @@ int vgx_reg_batch_evaluate_points_f64(vgx_reg_batch b, const double* poses, int3
   if (!d_residuals) return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_batch_evaluate_points_f64: residuals == NULL");
   if (((uintptr_t)d_jac_ref | (uintptr_t)d_jac_read) & 31u)
     return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_batch_evaluate_points_f64: Jacobian arrays must be 32-byte aligned (one row)");
-  if (b->n > 0 && b->layout != VGX_BRICKS_APRON)
-    return set_error(ctx, VGX_ERR_UNSUPPORTED, "vgx_reg_batch_evaluate_points_f64: apron bricks only (the default layout)");
   VGX_HIP(ctx, hipSetDevice(ctx->device));
   int rc = batch_begin(b);
   if (rc == VGX_OK) rc = batch_upload_packs(b, poses, n_nodes, status);
