@@ -738,8 +738,8 @@ constexpr bool kBallotSkip = VGX_BALLOT_SKIP != 0;
 // transform and Interpolator::setIndexes/getQVector (locate_stage1: which cell a point falls in,
 // and its fractional offsets, bit for bit) -- and evaluates everything that is a smooth function of
 // (8 neighbours, offsets) in the cheapest association:
-//   * trilinear value and gradient as 7 + 6 nested lerps with FMAs (22 VALU instead of the
-//     interp_table_ product, q-vector and three 4-term gradient rows: ~78),
+//   * the gradient as RCF:204-205's combination of the interp_table_ coefficients in nine FMAs (round 6; nested lerps over
+//     the neighbours before: see eval_point_lean),
 //   * the f64 detour of RCF:183-202 (doubles rounded into a float matrix) stays in f32,
 //   * validity from the interpolated value itself: every neighbour enters it, so it is NaN exactly
 //     when a neighbour is the NaN sentinel,
@@ -756,20 +756,22 @@ constexpr bool kBallotSkip = VGX_BALLOT_SKIP != 0;
 // ACC = float keeps the 21 running products in f32 per thread across a tile (<= 2 * kMaxReduceIters
 // terms), widened to f64 for the wave / workgroup / constraint reduction: half the accumulator
 // registers and no f64 FMA in the loop.  Fixed order throughout => bitwise reproducible.
-__device__ __forceinline__ bool eval_point_lean(const float d[8], bool have, float Dx, float Dy, float Dz,
+__device__ __forceinline__ bool eval_point_lean(const float c[8], bool have, float Dx, float Dy, float Dz,
                                                 float value, float inv_f, const PosePack& P, float xi, float yi,
                                                 float d_ref, float w, float u[6]) {
 #pragma clang fp contract(fast)
-  // neighbour k = 4 x + 2 y + z
-  const float a0 = d[4] - d[0], a1 = d[5] - d[1], a2 = d[6] - d[2], a3 = d[7] - d[3];
-  const float v0 = Dx * a0 + d[0], v1 = Dx * a1 + d[1], v2 = Dx * a2 + d[2], v3 = Dx * a3 + d[3];
-  const float b0 = v2 - v0, b1 = v3 - v1;
-  const float u0 = Dy * b0 + v0, u1 = Dy * b1 + v1;
-  const float ax0 = Dy * (a2 - a0) + a0, ax1 = Dy * (a3 - a1) + a1;
-  const float gz = u1 - u0;
+  // c = interp_table_ * distances^T, as interpolated_value made it (the reference's own coefficients, RCF:158): the
+  // gradient is RCF:204-205's combination of them -- (c1 + c4 y + c6 z + c7 yz, c2 + c4 x + c5 z + c7 xz, c3 + c5 y +
+  // c6 x + c7 xy) -- in nine FMAs.  Until round 6 the gradient came from a chain of nested lerps over the eight
+  // neighbours (22 operations): its y and z components were differences of INTERPOLATED VALUES, i.e. carried an error of
+  // an ulp of the distance (~1e-8 m) into a gradient of a few millimetres per voxel -- 2e-6 of it, which a constraint
+  // with a dozen correspondences showed in its J^T r (profiles/fuzz_reg.py seed 300290: 1.27e-6 of the largest entry).
+  // The coefficients are differences of neighbours throughout, as in the reference.
+  const float q4 = Dx * Dy, q5 = Dy * Dz, q6 = Dz * Dx;
+  const float gx = q5 * c[7] + (Dz * c[6] + (Dy * c[4] + c[1]));
+  const float gy = q6 * c[7] + (Dz * c[5] + (Dx * c[4] + c[2]));
+  const float gz = q4 * c[7] + (Dx * c[6] + (Dy * c[5] + c[3]));
   const float val = value;  // the reference's association (interpolated_value), computed by the caller
-  const float gx = Dz * (ax1 - ax0) + ax0;
-  const float gy = Dz * (b1 - b0) + b0;
   const float s = -w * inv_f;
   const float h0 = s * gx, h1 = s * gy, h2 = s * gz;
   const float mo3 = xi * P.sin_emo - yi * P.cos_emo;
@@ -940,7 +942,7 @@ __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_ker
       float c_[8];
       const float value = interpolated_value(d[j], loc[j].Dx, loc[j].Dy, loc[j].Dz, c_[0], c_[1], c_[2], c_[3], c_[4],
                                              c_[5], c_[6], c_[7]);
-      const bool ok = eval_point_lean(d[j], have[j], loc[j].Dx, loc[j].Dy, loc[j].Dz, value, g.voxel_size_inv, P,
+      const bool ok = eval_point_lean(c_, have[j], loc[j].Dx, loc[j].Dy, loc[j].Dz, value, g.voxel_size_inv, P,
                                       pt[j].x, pt[j].y, pt[j].w, w[j], u) && in_range;
 #pragma unroll
       for (int k = 0; k < 5; ++k) u[k] = ok ? u[k] : 0.0f;
