@@ -772,17 +772,36 @@ __device__ __forceinline__ bool eval_point_lean(const float c[8], bool have, flo
   const float gy = q6 * c[7] + (Dz * c[5] + (Dx * c[4] + c[2]));
   const float gz = q4 * c[7] + (Dx * c[6] + (Dy * c[5] + c[3]));
   const float val = value;  // the reference's association (interpolated_value), computed by the caller
+  const bool ok = have && (val == val);  // NaN sentinel among the neighbours <=> NaN value
+  // What is accumulated is NOT u = (jo0, jo1, jo2, jo3, je3, r) itself but v = (h0, h1, h2, a, b, r) with
+  //   h = -w / voxel_size * gradient,   a = h0 x_i + h1 y_i,   b = h1 x_i - h0 y_i,
+  // of which u is a LINEAR function with per-constraint coefficients (RCF:214-239 regrouped):
+  //   jo0 = cos_e h0 - sin_e h1,  jo1 = sin_e h0 + cos_e h1,  jo2 = h2,
+  //   jo3 = sin_emo a + cos_emo b,  je3 = k1 h0 + k2 h1 - jo3
+  // so the 21 sums of products of u are T (sums of products of v) T^T with a constant 6 x 6 matrix T: reg_finalize_kernel
+  // applies it once per constraint in f64 (lean_basis) instead of every point paying ten operations for it.  Lanes
+  // without a correspondence carry zeros: the selects sit on the gradient (3) and the residual (1).
   const float s = -w * inv_f;
-  const float h0 = s * gx, h1 = s * gy, h2 = s * gz;
-  const float mo3 = xi * P.sin_emo - yi * P.cos_emo;
-  const float mo7 = xi * P.cos_emo + yi * P.sin_emo;
-  u[0] = h0 * P.cos_e - h1 * P.sin_e;
-  u[1] = h0 * P.sin_e + h1 * P.cos_e;
+  const float h0 = ok ? s * gx : 0.0f, h1 = ok ? s * gy : 0.0f, h2 = ok ? s * gz : 0.0f;
+  u[0] = h0;
+  u[1] = h1;
   u[2] = h2;
-  u[3] = h0 * mo3 + h1 * mo7;
-  u[4] = h0 * (P.k1 - mo3) + h1 * (P.k2 - mo7);
+  u[3] = h0 * xi + h1 * yi;
+  u[4] = h1 * xi - h0 * yi;
   u[5] = (d_ref - val) * w;
-  return have && (val == val);  // NaN sentinel among the neighbours <=> NaN value
+  return ok;
+}
+
+// u = T v (see eval_point_lean): row i of T, from the pose pack's own f32 values
+__device__ __forceinline__ void lean_basis(const PosePack& P, double T[6][6]) {
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) T[i][j] = 0.0;
+  T[0][0] = (double)P.cos_e;  T[0][1] = -(double)P.sin_e;
+  T[1][0] = (double)P.sin_e;  T[1][1] = (double)P.cos_e;
+  T[2][2] = 1.0;
+  T[3][3] = (double)P.sin_emo;  T[3][4] = (double)P.cos_emo;
+  T[4][0] = (double)P.k1;  T[4][1] = (double)P.k2;  T[4][3] = -(double)P.sin_emo;  T[4][4] = -(double)P.cos_emo;
+  T[5][5] = 1.0;
 }
 
 template <typename ACC>
@@ -942,11 +961,10 @@ __global__ __launch_bounds__(kBlockThreads, WAVES) void reg_eval_reduce_lean_ker
       float c_[8];
       const float value = interpolated_value(d[j], loc[j].Dx, loc[j].Dy, loc[j].Dz, c_[0], c_[1], c_[2], c_[3], c_[4],
                                              c_[5], c_[6], c_[7]);
-      const bool ok = eval_point_lean(c_, have[j], loc[j].Dx, loc[j].Dy, loc[j].Dz, value, g.voxel_size_inv, P,
-                                      pt[j].x, pt[j].y, pt[j].w, w[j], u) && in_range;
-#pragma unroll
-      for (int k = 0; k < 5; ++k) u[k] = ok ? u[k] : 0.0f;
-      // RCF:165-166: w * no_correspondence_cost with zero Jacobian rows
+      const bool ok = eval_point_lean(c_, have[j] && in_range, loc[j].Dx, loc[j].Dy, loc[j].Dz, value, g.voxel_size_inv, P,
+                                      pt[j].x, pt[j].y, pt[j].w, w[j], u);
+      // (u[0..4] are zeros without a correspondence: eval_point_lean)  RCF:165-166: w * no_correspondence_cost with zero
+      // Jacobian rows
       u[5] = ok ? u[5] : ((count_misses && in_range) ? w[j] * nc : 0.0f);
       if (COST_ONLY) accumulate_square<ACC>(acc[0], u[5]);   // (the five Jacobian entries are dead code here)
       else accumulate21<ACC>(acc, u);
@@ -1360,6 +1378,7 @@ static bool make_xcd_order(const std::vector<ConstraintDev>& desc, const std::ve
 // group order: a fixed tree) and expand the 21 products into
 // [cost, J^T r (8), upper J^T J (36)].
 __global__ __launch_bounds__(256) void reg_finalize_kernel(const ConstraintDev* __restrict__ cons,
+                                                          const PosePack* __restrict__ packs,
                                                           const int32_t* __restrict__ tile_first,
                                                           const double* __restrict__ partials,
                                                           double* __restrict__ normal) {
@@ -1383,6 +1402,38 @@ __global__ __launch_bounds__(256) void reg_finalize_kernel(const ConstraintDev* 
     for (int g = 0; g < G; ++g) v += part[g][threadIdx.x];
     s[threadIdx.x] = v;
   }
+  __syncthreads();
+  // the sums are of products of v = (h0, h1, h2, a, b, r): into products of u = T v (eval_point_lean, lean_basis), in f64,
+  // every entry by the same fixed loop: sum_u(i, j) = sum_p sum_q T[i][p] T[j][q] sum_v(p, q).  Entry (5, 5) -- the cost --
+  // is untouched (row 5 of T is e_5): the cost-only pass's number, bit for bit.
+  __shared__ double su[21];
+  if (threadIdx.x < 21) {
+    double T[6][6];
+    lean_basis(packs[c], T);
+    int i = 0, rem = (int)threadIdx.x;
+    while (rem >= 6 - i) {
+      rem -= 6 - i;
+      ++i;
+    }
+    const int j = i + rem;
+    auto Sv = [&](int a, int b) {
+      const int lo = a < b ? a : b, hi = a < b ? b : a;
+      return s[lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo)];
+    };
+    double acc = 0.0;
+    if (i == 5 && j == 5) {
+      acc = Sv(5, 5);
+    } else {
+      for (int p = 0; p < 6; ++p)
+        for (int q = 0; q < 6; ++q) {
+          const double t = T[i][p] * T[j][q];
+          if (t != 0.0) acc += t * Sv(p, q);
+        }
+    }
+    su[threadIdx.x] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x < 21) s[threadIdx.x] = su[threadIdx.x];
   __syncthreads();
   if (threadIdx.x < kNormalSize) {
     const int map[8] = {0, 1, 2, 3, 0, 1, 2, 4};
@@ -2617,7 +2668,7 @@ int vgx_reg_batch_evaluate_normal(vgx_reg_batch b, const double* poses, int32_t 
   double* out = d_normal ? (double*)d_normal : b->d_normal;
   rc = launch_fused_tiles<false>(b);
   if (rc != VGX_OK) return rc;
-  hipLaunchKernelGGL(reg_finalize_kernel, dim3(b->n), dim3(256), 0, ctx->stream, b->d_desc,
+  hipLaunchKernelGGL(reg_finalize_kernel, dim3(b->n), dim3(256), 0, ctx->stream, b->d_desc, b->d_pack,
                      b->d_tile_first, b->d_partials, out);
   VGX_HIP(ctx, hipGetLastError());
   if (normal_host) {
