@@ -11,7 +11,8 @@ import numpy as np
 
 def _percentiles(us):
     a = np.sort(np.asarray(us, np.float64))
-    return {"p50": float(np.percentile(a, 50)), "p99": float(np.percentile(a, 99)), "max": float(a[-1]), "scans": int(len(a))}
+    return {"p50": float(np.percentile(a, 50)), "p90": float(np.percentile(a, 90)), "p99": float(np.percentile(a, 99)), "max": float(a[-1]),
+            "scans": int(len(a)), "over_1ms": int((a > 1000.0).sum())}
 
 
 def scan_latency(capi, ctx, torch, integ, T_list, d_clouds, n_points, hz, n_scans, solver_step=None):

@@ -32,7 +32,8 @@ def _latency(l):
         return None
     if l.get("error"):
         return {"error": l["error"][:120]}
-    return {"p50": l.get("p50"), "p99": l.get("p99"), "alone_p50": (l.get("alone") or {}).get("p50"),
+    return {"p50": l.get("p50"), "p90": l.get("p90"), "p99": l.get("p99"), "over_1ms": l.get("over_1ms"), "scans": l.get("scans"),
+            "alone_p50": (l.get("alone") or {}).get("p50"),
             "alone_p99": (l.get("alone") or {}).get("p99"), "cadence_Hz": l.get("cadence_Hz"),
             "stream_priorities": l.get("stream_priorities")}
 

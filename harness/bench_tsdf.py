@@ -168,7 +168,7 @@ def tsdf_bench(capi, ctx, torch, scans=20, cpu_scans=8, solver_step=None, solver
             from harness.bench_latency import latency_block
             lay_l = new_layer()
             integ.setLayer(lay_l)
-            hz, n_lat = (30.0, 45) if sensor == "rgbd" else (10.0, 25)
+            hz, n_lat = (30.0, 90) if sensor == "rgbd" else (10.0, 40)   # 3 s / 4 s of sensor time (p99 of 45 scans was its maximum)
             try:
                 latency = latency_block(capi, ctx, torch, integ, poses, dev, n_pts, hz, n_lat, solver_step, solver_ms_alone)
             except Exception as e:   # noqa: BLE001

@@ -72,6 +72,20 @@ for name, (dirs, vs, kw, bmin, bdim) in sensor_cases().items():
             integ.integrate_device(T[k], dev[k].data_ptr(), None, n_pts)
     ctx.synchronize()
     hz, n = (30.0, 60) if sensor == "rgbd" else (10.0, 30)
+    if os.environ.get("VGX_LAT_TAIL"):
+        # the tail by itself: many scans at a faster cadence under the host-blocking fused evaluations; every scan above 1 ms
+        # with its index (is it the first ones?  periodic?  how often?)
+        from harness.bench_latency import scan_latency
+        n_tail = int(os.environ["VGX_LAT_TAIL"])
+        for rep in range(2):
+            lat, evals = scan_latency(capi, ctx, torch, integ, T, dev, n_pts, 4 * hz, n_tail, fused_step)
+            a_ = np.asarray(lat)
+            print(sensor, "tail", json.dumps({"scans": n_tail, "cadence_Hz": 4 * hz, "p50": float(np.percentile(a_, 50)), "p99": float(np.percentile(a_, 99)),
+                                              "max": float(a_.max()), "over_1ms": [(int(i), round(float(a_[i]))) for i in np.nonzero(a_ > 1000)[0]],
+                                              "solver_evaluations": evals}))
+        integ.destroy()
+        layer.destroy()
+        continue
     for load, step in (("fused solver evaluations (blocks to the host)", fused_step),
                        ("fused solver evaluations (device only)", fused_device_step), ("materialising passes", points_step)):
         out = latency_block(capi, ctx, torch, integ, T, dev, n_pts, hz, n, step, None)
