@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Differential fuzzing of the device ESDF (vgx_submap_generate_esdf, voxgraph_submap.cpp:86) against oracle/esdf_oracle.c (the
+restated voxblox queue): random small submaps (8 / 16 voxels per side, spheres + ground, blocks dropped at random, TSDF noise,
+unobserved shells), random EsdfIntegrator settings (max / default / min distance).  The device result is the EXACT fixed point
+of the propagation, the queue stops at improvements below min_diff_m = 1 mm, so the contract is: observed masks equal; fixed-band
+voxels the TSDF's values; the sign of every observed voxel the TSDF's; |gpu| <= |oracle| + 1e-6 and |gpu - oracle| < 2.5 mm;
+the device layer satisfies the fixed-point equation to 1e-6 (tests/test_esdf_gpu.py's checker).
+    gpurun -- 'SEEDS=200 python profiles/fuzz_esdf.py'"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+F = np.float32
+
+
+def main():
+    from oracle import pyoracle as orc
+    from oracle import synth
+    from tests.test_esdf_gpu import _check_fixed_point
+    from voxgraph_amd import capi
+    capi.load()
+    ctx = capi.Context(0)
+    n_seeds, first = int(os.environ.get("SEEDS", "100")), int(os.environ.get("FIRST", "0"))
+    done, worst, worst_fp, voxels = 0, 0.0, 0.0, 0
+    for seed in range(first, first + n_seeds):
+        rng = np.random.default_rng(seed)
+        vps = int(rng.choice([8, 16]))
+        vs = float(rng.choice([0.05, 0.1, 0.2]))
+        dims = tuple(int(x) for x in rng.integers(1, 5, 3))
+        ext = np.array(dims) * vps * vs
+        c = rng.uniform(0.2, 0.8, 3) * ext
+        sdf = synth.sphere_ground_sdf(tuple(c), float(rng.uniform(0.2, 0.6) * ext.min()), float(rng.uniform(0.1, 0.4) * ext[2]))
+        sm = synth.make_submap(sdf, vs, vps, tuple(int(x) for x in rng.integers(-2, 2, 3)), dims, trunc=3 * vs, esdf_max=10 * vs,
+                               drop_empty_blocks=bool(rng.integers(0, 2)))
+        if len(sm.block_index) == 0:
+            continue
+        td = sm.tsdf_distance.copy()
+        if rng.integers(0, 2):
+            td = np.clip(td + rng.normal(0, 0.02 * vs, td.shape).astype(F), -3 * vs, 3 * vs).astype(F)
+        tw = sm.tsdf_weight.copy()
+        if rng.integers(0, 2):
+            tw = np.where(rng.uniform(size=tw.shape) < 0.03, 0, tw).astype(F)       # holes in the observed region
+        max_d = float(rng.choice([2.0, 6 * vs, 12 * vs]))
+        kw = dict(max_distance_m=max_d, default_distance_m=float(rng.choice([max_d, 2.0])), min_distance_m=float(rng.choice([0.2, vs, 2 * vs])))
+        what = dict(seed=seed, vps=vps, vs=vs, dims=dims, blocks=len(sm.block_index), **kw)
+        g = capi.Submap(ctx, 0, vs, vps, sm.block_index, td, tw, None, None)
+        try:
+            g.generate_esdf(capi.esdf_config(**kw))
+            _, _, ed, eo = g.download_layers(vps)
+            od, oo, _ = orc.esdf_from_tsdf(vs, vps, sm.block_index, td, tw, orc.esdf_config(**kw))
+            assert np.array_equal(eo, oo), "observed masks"
+            obs = oo.astype(bool)
+            fixed = (tw >= 1e-6) & (np.abs(td) < kw["min_distance_m"])
+            assert np.array_equal(ed[fixed], td[fixed]), "fixed band"
+            assert np.array_equal(np.sign(ed[obs]), np.sign(td[obs])), "signs"
+            if obs.any():
+                diff = np.abs(ed - od)[obs]
+                assert diff.max() < 2.5e-3, ("distance", float(diff.max()))
+                assert np.all(np.abs(ed[obs]) <= np.abs(od[obs]) + 1e-6), "device above the queue's value"
+                worst = max(worst, float(diff.max()))
+                try:
+                    err, n_free = _check_fixed_point(sm.block_index, td, ed, eo, vs, vps, kw["min_distance_m"], kw["max_distance_m"],
+                                                     kw["default_distance_m"])
+                except ValueError:          # (no observed voxel outside the fixed band: nothing propagates)
+                    err, n_free = 0.0, 0
+                assert err < 1e-6, ("fixed point", err)
+                worst_fp = max(worst_fp, err)
+                voxels += int(obs.sum())
+        except AssertionError as e:
+            print("MISMATCH", what, str(e)[:300])
+            return 1
+        finally:
+            g.destroy()
+        done += 1
+    print("no mismatch in %d submaps (%d observed voxels): worst |device - queue| %.2e m (bar 2.5e-3), worst fixed-point residual %.1e" %
+          (done, voxels, worst, worst_fp))
+    ctx.close()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -773,21 +773,23 @@ __device__ __forceinline__ bool eval_point_lean(const float c[8], bool have, flo
   const float gz = q4 * c[7] + (Dx * c[6] + (Dy * c[5] + c[3]));
   const float val = value;  // the reference's association (interpolated_value), computed by the caller
   const bool ok = have && (val == val);  // NaN sentinel among the neighbours <=> NaN value
-  // What is accumulated is NOT u = (jo0, jo1, jo2, jo3, je3, r) itself but v = (h0, h1, h2, a, b, r) with
-  //   h = -w / voxel_size * gradient,   a = h0 x_i + h1 y_i,   b = h1 x_i - h0 y_i,
-  // of which u is a LINEAR function with per-constraint coefficients (RCF:214-239 regrouped):
-  //   jo0 = cos_e h0 - sin_e h1,  jo1 = sin_e h0 + cos_e h1,  jo2 = h2,
-  //   jo3 = sin_emo a + cos_emo b,  je3 = k1 h0 + k2 h1 - jo3
-  // so the 21 sums of products of u are T (sums of products of v) T^T with a constant 6 x 6 matrix T: reg_finalize_kernel
-  // applies it once per constraint in f64 (lean_basis) instead of every point paying ten operations for it.  Lanes
-  // without a correspondence carry zeros: the selects sit on the gradient (3) and the residual (1).
+  // What is accumulated is NOT u = (jo0, jo1, jo2, jo3, je3, r) itself but v = (h0, h1, h2, jo3, je3, r), h = -w / voxel_size *
+  // gradient: (jo0, jo1) is (h0, h1) turned by the reading submap's yaw (RCF:214-218) -- a rotation the constraint's every point
+  // shares, so reg_finalize_kernel applies it ONCE, in f64, to the sums of products (lean_basis: sum_u = T sum_v T^T with an
+  // orthogonal T: nothing is amplified) instead of every point paying four operations for it.  jo3 and je3 are formed per point
+  // as before: expressing them too through per-constraint constants (two point moments a = h0 x + h1 y, b = h1 x - h0 y) was
+  // built and measured -- six more operations saved, -1 % -- and dropped: je3 = k . h - jo3 then comes out of the sums as a
+  // difference of terms up to 25 x its size, and the large-constraint fuzzer's worst J^T J entry went from 2.9e-7 to 7.5e-7 of
+  // the largest (profiles/r06_fused_gradient.txt).  Lanes without a correspondence carry zeros: the selects sit on the gradient.
   const float s = -w * inv_f;
   const float h0 = ok ? s * gx : 0.0f, h1 = ok ? s * gy : 0.0f, h2 = ok ? s * gz : 0.0f;
+  const float mo3 = xi * P.sin_emo - yi * P.cos_emo;
+  const float mo7 = xi * P.cos_emo + yi * P.sin_emo;
   u[0] = h0;
   u[1] = h1;
   u[2] = h2;
-  u[3] = h0 * xi + h1 * yi;
-  u[4] = h1 * xi - h0 * yi;
+  u[3] = h0 * mo3 + h1 * mo7;
+  u[4] = h0 * (P.k1 - mo3) + h1 * (P.k2 - mo7);
   u[5] = (d_ref - val) * w;
   return ok;
 }
@@ -795,13 +797,9 @@ __device__ __forceinline__ bool eval_point_lean(const float c[8], bool have, flo
 // u = T v (see eval_point_lean): row i of T, from the pose pack's own f32 values
 __device__ __forceinline__ void lean_basis(const PosePack& P, double T[6][6]) {
   for (int i = 0; i < 6; ++i)
-    for (int j = 0; j < 6; ++j) T[i][j] = 0.0;
+    for (int j = 0; j < 6; ++j) T[i][j] = i == j ? 1.0 : 0.0;
   T[0][0] = (double)P.cos_e;  T[0][1] = -(double)P.sin_e;
   T[1][0] = (double)P.sin_e;  T[1][1] = (double)P.cos_e;
-  T[2][2] = 1.0;
-  T[3][3] = (double)P.sin_emo;  T[3][4] = (double)P.cos_emo;
-  T[4][0] = (double)P.k1;  T[4][1] = (double)P.k2;  T[4][3] = -(double)P.sin_emo;  T[4][4] = -(double)P.cos_emo;
-  T[5][5] = 1.0;
 }
 
 template <typename ACC>
@@ -1403,7 +1401,7 @@ __global__ __launch_bounds__(256) void reg_finalize_kernel(const ConstraintDev* 
     s[threadIdx.x] = v;
   }
   __syncthreads();
-  // the sums are of products of v = (h0, h1, h2, a, b, r): into products of u = T v (eval_point_lean, lean_basis), in f64,
+  // the sums are of products of v = (h0, h1, h2, jo3, je3, r): into products of u = T v (eval_point_lean, lean_basis), in f64,
   // every entry by the same fixed loop: sum_u(i, j) = sum_p sum_q T[i][p] T[j][q] sum_v(p, q).  Entry (5, 5) -- the cost --
   // is untouched (row 5 of T is e_5): the cost-only pass's number, bit for bit.
   __shared__ double su[21];
