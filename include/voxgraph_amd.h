@@ -634,8 +634,12 @@ VGX_API int vgx_tsdf_integrator_set_cloud_width(vgx_tsdf_integrator integrator, 
 /* integratePointCloud(T_G_C, points_C, colors, freespace_points)
  * (pointcloud_integrator.cpp:83).  T_G_C = {qw,qx,qy,qz, tx,ty,tz} f32
  * (voxblox::Transformation); points_C [n][3] sensor frame; rgba [n][4] or NULL.
- * Host pointers; returns after the scan is integrated.  n_updates (nullable)
- * receives the number of voxel updates performed. */
+ * Host pointers (pageable is fine: the arrays are read before the call returns, through pinned staging buffers of the
+ * integrator's own, and are the caller's again afterwards).  n_updates == NULL -- what voxblox's void call corresponds to:
+ * the call returns with the scan QUEUED on the context's TSDF stream; the layer is the device's, and every reader of it
+ * (vgx_tsdf_layer_download / _stats, vgx_submap_from_tsdf_layer, the next scan) is ordered behind the scan on that stream;
+ * vgx_ctx_synchronize_tsdf waits for it explicitly.  n_updates != NULL: a COUNTED scan -- the call waits for it and
+ * returns the number of voxel updates performed (a slower kernel instantiation: diagnostics, tests). */
 VGX_API int vgx_tsdf_integrate(vgx_tsdf_integrator integrator, const float T_G_C[7],
                                const float* points_C, const uint8_t* rgba, int64_t n,
                                int32_t freespace_points, int64_t* n_updates);

@@ -105,6 +105,31 @@ def test_dense_lidar_scans_are_the_single_thread_result_bit_for_bit(capi, ctx):
         o.destroy()
 
 
+def test_the_void_call_returns_with_the_scan_queued_and_its_arrays_consumed(capi, ctx):
+    """vgx_tsdf_integrate(n_updates = NULL) -- voxblox's void integratePointCloud -- reads the caller's (pageable) arrays through
+    the integrator's two pinned staging buffers and returns with the scan QUEUED: the caller may scribble over the arrays at
+    once, call again at once (several scans in flight: the staging buffers alternate), change the scan's size; every reader of
+    the layer is ordered behind the scans.  Reproducible mode, so the layer must be the oracle's bit for bit."""
+    vs, vps = 0.2, 16
+    ol, gl = orc.TsdfLayer(vs, vps), capi.TsdfLayer(ctx, vs, vps)
+    oi = orc.FastTsdfIntegrator(orc.voxgraph_tsdf_config(), ol)
+    gi = capi.FastTsdfIntegrator(ctx, capi.voxgraph_tsdf_config(deterministic=1), gl)
+    rng = np.random.default_rng(11)
+    for k in range(7):
+        origin = np.array([0.3 * k - 0.8, -0.2 * k + 0.4, 0.02 * k], F)
+        pts = _lidar_scan(512 if k % 3 else 768, 32, 40 + k, origin=origin.astype(np.float64))   # (sizes change: buffers regrow)
+        T = np.r_[np.array([1, 0, 0, 0], F), origin].astype(F)
+        col = rng.integers(0, 256, (len(pts), 4)).astype(np.uint8)
+        oi.integratePointCloud(T, pts.copy(), col.copy())
+        assert gi.integratePointCloud(T, pts, col, count=False) == 0      # (nothing counted, nothing waited for)
+        pts[:] = np.nan                                                    # the arrays are the caller's again
+        col[:] = 255
+    _assert_layers_identical(ol, gl, "after seven queued scans")
+    assert gl.stats()[1] == 0
+    for o in (gi, gl):
+        o.destroy()
+
+
 def test_a_session_old_integrator_is_the_oracles_bit_for_bit_and_does_less_work(capi, ctx):
     """The reference keeps ONE FastTsdfIntegrator for the whole mapping session and points it at every new submap's layer
     (pointcloud_integrator.cpp:66-75), and voxblox's ApproxHashSet never forgets between its 10 000-scan resets: the mark

@@ -917,14 +917,15 @@ class FastTsdfIntegrator:
         self.ctx.check(self.ctx.lib.vgx_tsdf_integrator_set_layer(self.h, layer.h))
         self.layer = layer
 
-    def integratePointCloud(self, T_G_C, points_C, colors=None, freespace_points=False):
+    def integratePointCloud(self, T_G_C, points_C, colors=None, freespace_points=False, count=True):
+        """count=False: n_updates == NULL, voxblox's void call -- uncounted, returns with the scan queued"""
         T = _f32(T_G_C)
         pts = _f32(points_C).reshape(-1, 3)
         col = None if colors is None else np.ascontiguousarray(colors, np.uint8).reshape(-1, 4)
         n = C.c_int64()
         self.ctx.check(self.ctx.lib.vgx_tsdf_integrate(self.h, _ptr(T, f32p), _ptr(pts, f32p),
                                                        _ptr(col, u8p), pts.shape[0],
-                                                       int(freespace_points), C.byref(n)))
+                                                       int(freespace_points), C.byref(n) if count else None))
         return n.value
 
     def integratePointCloudMerged(self, T_G_C, points_C, colors=None, freespace_points=False):

@@ -1162,6 +1162,10 @@ int vgx_tsdf_integrator_destroy(vgx_tsdf_integrator I) {
                   I->d_oidx[1], I->d_osort};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  for (int k = 0; k < 2; ++k) {
+    if (I->h_stage[k]) (void)hipHostFree(I->h_stage[k]);
+    if (I->stage_uploaded[k]) (void)hipEventDestroy(I->stage_uploaded[k]);
+  }
   if (I->det) det_scratch_free(I->det);
   delete I;
   return VGX_OK;
@@ -1486,9 +1490,46 @@ static int stage_scan(vgx_tsdf_integrator I, const float* points, const uint8_t*
     I->staging_cap = n;
   }
   if (n > 0) {
-    VGX_HIP(ctx, hipMemcpyAsync(I->d_points, points, (size_t)n * 12, hipMemcpyHostToDevice, ctx->tsdf_stream));
-    if (rgba)
-      VGX_HIP(ctx, hipMemcpyAsync(I->d_rgba, rgba, (size_t)n * 4, hipMemcpyHostToDevice, ctx->tsdf_stream));
+    // Through pinned memory, two buffers in turn: the caller's arrays are read HERE (a host copy), the upload and the scan
+    // run behind the call.  (Straight from pageable memory the runtime stages the copy itself and the call waits for it.)
+    if (n > I->h_stage_cap) {
+      VGX_HIP(ctx, hipStreamSynchronize(ctx->tsdf_stream));
+      for (int k = 0; k < 2; ++k) {
+        if (I->h_stage[k]) (void)hipHostFree(I->h_stage[k]);
+        I->h_stage[k] = nullptr;
+      }
+      I->h_stage_cap = 0;
+      bool ok = true;
+      for (int k = 0; k < 2 && ok; ++k) {
+        ok = hipHostMalloc((void**)&I->h_stage[k], (size_t)n * 16, hipHostMallocDefault) == hipSuccess;
+        if (ok && !I->stage_uploaded[k]) ok = hipEventCreateWithFlags(&I->stage_uploaded[k], hipEventDisableTiming) == hipSuccess;
+      }
+      if (ok) {
+        I->h_stage_cap = n;
+      } else {  // no pinned memory to be had: the pageable path below
+        (void)hipGetLastError();
+        for (int k = 0; k < 2; ++k) {
+          if (I->h_stage[k]) (void)hipHostFree(I->h_stage[k]);
+          I->h_stage[k] = nullptr;
+        }
+      }
+    }
+    if (I->h_stage_cap >= n) {
+      const int k = I->stage_turn;
+      I->stage_turn ^= 1;
+      VGX_HIP(ctx, hipEventSynchronize(I->stage_uploaded[k]));   // (the upload that last read this buffer: two scans ago)
+      char* h = I->h_stage[k];
+      std::memcpy(h, points, (size_t)n * 12);
+      if (rgba) std::memcpy(h + (size_t)n * 12, rgba, (size_t)n * 4);
+      VGX_HIP(ctx, hipMemcpyAsync(I->d_points, h, (size_t)n * 12, hipMemcpyHostToDevice, ctx->tsdf_stream));
+      if (rgba) VGX_HIP(ctx, hipMemcpyAsync(I->d_rgba, h + (size_t)n * 12, (size_t)n * 4, hipMemcpyHostToDevice, ctx->tsdf_stream));
+      VGX_HIP(ctx, hipEventRecord(I->stage_uploaded[k], ctx->tsdf_stream));
+    } else {
+      VGX_HIP(ctx, hipMemcpyAsync(I->d_points, points, (size_t)n * 12, hipMemcpyHostToDevice, ctx->tsdf_stream));
+      if (rgba)
+        VGX_HIP(ctx, hipMemcpyAsync(I->d_rgba, rgba, (size_t)n * 4, hipMemcpyHostToDevice, ctx->tsdf_stream));
+      VGX_HIP(ctx, hipStreamSynchronize(ctx->tsdf_stream));   // the caller's arrays are his again when the call returns
+    }
   }
   return VGX_OK;
 }
@@ -1499,10 +1540,8 @@ int vgx_tsdf_integrate_merged(vgx_tsdf_integrator I, const float T[7], const flo
   std::lock_guard<std::mutex> own(I->mu);
   int rc = stage_scan(I, points, rgba, n);
   if (rc != VGX_OK) return rc;
-  int64_t upd = 0;
-  rc = merged_integrate_locked(I, T, I->d_points, rgba ? I->d_rgba : nullptr, n, freespace, &upd);
-  if (n_updates) *n_updates = upd;
-  return rc;
+  // (n_updates == NULL: nothing is counted and nothing is waited for -- the call returns with the scan queued)
+  return merged_integrate_locked(I, T, I->d_points, rgba ? I->d_rgba : nullptr, n, freespace, n_updates);
 }
 
 int vgx_tsdf_integrate_device(vgx_tsdf_integrator I, const float T[7], const void* d_points,
@@ -1520,10 +1559,10 @@ int vgx_tsdf_integrate(vgx_tsdf_integrator I, const float T[7], const float* poi
   std::lock_guard<std::mutex> own(I->mu);
   int rc = stage_scan(I, points, rgba, n);
   if (rc != VGX_OK) return rc;
-  int64_t upd = 0;
-  rc = integrate_locked(I, T, I->d_points, rgba ? I->d_rgba : nullptr, n, freespace, &upd);
-  if (n_updates) *n_updates = upd;
-  return rc;
+  // n_updates == NULL (what GpuFastTsdfIntegrator::integratePointCloud passes: voxblox's call returns nothing): an uncounted
+  // scan, and the call returns with it QUEUED -- the points have been read, the layer is the device's and every reader of it
+  // (download, finish, the next scan) is ordered behind the scan on the TSDF stream.  With a count the call waits for it.
+  return integrate_locked(I, T, I->d_points, rgba ? I->d_rgba : nullptr, n, freespace, n_updates);
 }
 
 }  // extern "C"

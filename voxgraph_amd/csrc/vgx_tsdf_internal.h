@@ -408,6 +408,13 @@ struct vgx_tsdf_integrator_s {
   float* d_points = nullptr;  // staging for host-pointer scans
   uint32_t* d_rgba = nullptr;
   long long staging_cap = 0;
+  // ... and its host side: two pinned buffers ([n x 12 B points][n x 4 B colours]) filled in turn, so that the caller's
+  // (pageable) arrays are consumed when vgx_tsdf_integrate returns while the upload and the scan run behind it; an event per
+  // buffer says when its upload has finished and the buffer may be filled again
+  char* h_stage[2] = {nullptr, nullptr};
+  hipEvent_t stage_uploaded[2] = {nullptr, nullptr};
+  long long h_stage_cap = 0;
+  int stage_turn = 0;
   std::mutex mu;  // one scan at a time per integrator: the staging buffers belong to the scan in flight
   // MergedTsdfIntegrator scratch (grown on demand): sort keys / point indices (double-buffered),
   // group starts, {groups, surface entries} counters, radix-sort workspace
