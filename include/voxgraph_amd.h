@@ -362,6 +362,18 @@ VGX_API int vgx_reg_batch_choose_outputs(vgx_reg_batch batch, const double* pose
                                          void* const* d_jac_read, int32_t launches, int32_t chosen[3],
                                          float* ms_chosen, float* ms_trials);
 
+/* The same, with the arrays the library's own: allocates n_candidates (1..16) sets of the row arrays the batch needs (f32:
+ * residuals [R], jac_* [R][4]; want_jac_* = 0 leaves that array out), chooses among them as vgx_reg_batch_choose_outputs does
+ * (3 launches per trial), frees the unchosen ones and returns the three pointers to keep -- one call instead of "allocate a
+ * few, choose, free the rest"; transient memory n_candidates x 36 B x R (fewer sets are tried when the device runs out).  A
+ * sampling batch gets the first set untimed (its trial evaluations would advance the engines).  ms_chosen (nullable): ms per
+ * launch on the arrays returned (0 when nothing was timed).  Release them with vgx_reg_batch_free_outputs while the batch
+ * lives (it waits for the batch's stream first). */
+VGX_API int vgx_reg_batch_alloc_outputs(vgx_reg_batch batch, const double* poses, int32_t n_nodes, int32_t n_candidates,
+                                        int32_t want_jac_ref, int32_t want_jac_read, void** d_residuals, void** d_jac_ref,
+                                        void** d_jac_read, float* ms_chosen);
+VGX_API int vgx_reg_batch_free_outputs(vgx_reg_batch batch, void* d_residuals, void* d_jac_ref, void* d_jac_read);
+
 /* Fused pass: no per-point outputs.  Per constraint c, 45 f64:
  *   [0]      sum r^2
  *   [1..8]   J^T r      over the stacked parameters [ref(4), read(4)]

@@ -360,6 +360,38 @@ def test_choose_outputs_times_candidates_and_leaves_valid_rows(capi, ctx, small_
         cf.destroy()
 
 
+def test_alloc_outputs_returns_chosen_arrays_of_the_library(capi, ctx, small_graph):
+    """vgx_reg_batch_alloc_outputs: the library allocates the candidate sets, chooses among them by timing the batch's own launch
+    (vgx_reg_batch_choose_outputs), frees the rest and hands back three arrays: they hold the rows any other arrays would; a
+    missing Jacobian block is left out; released with vgx_reg_batch_free_outputs"""
+    import ctypes
+    import torch
+    G = small_graph
+    batch = capi.RegistrationBatch(ctx, G["cfs"], G["pairs"])
+    R = batch.num_residuals()
+    r, jo, je = _torch_buf(R, torch.float32), _torch_buf(4 * R, torch.float32), _torch_buf(4 * R, torch.float32)
+    torch.cuda.synchronize()
+    batch.evaluate_points(G["poses"], r.data_ptr(), jo.data_ptr(), je.data_ptr())
+    pr, pjo, pje, ms = batch.alloc_outputs(G["poses"], n_candidates=3)
+    assert pr and pjo and pje and ms > 0 and pr % 16 == 0 and pjo % 16 == 0 and pje % 16 == 0
+    batch.evaluate_points(G["poses"], pr, pjo, pje)
+    ctx.synchronize()
+    got = [torch.empty(n, dtype=torch.float32, device="cuda") for n in (R, 4 * R, 4 * R)]
+    hip = ctypes.CDLL("libamdhip64.so")
+    for dst, src, n in zip(got, (pr, pjo, pje), (R, 4 * R, 4 * R)):
+        assert hip.hipMemcpy(ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(src), ctypes.c_size_t(4 * n), 3) == 0   # device to device
+    torch.cuda.synchronize()
+    for a, b in zip(got, (r, jo, je)):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    batch.free_outputs(pr, pjo, pje)
+    pr2, pjo2, pje2, _ = batch.alloc_outputs(G["poses"], n_candidates=2, want_jac_ref=False)     # a constant block: no array for it
+    assert pr2 and not pjo2 and pje2
+    batch.evaluate_points(G["poses"], pr2, None, pje2)
+    ctx.synchronize()
+    batch.free_outputs(pr2, 0, pje2)
+    batch.destroy()
+
+
 def test_blocked_output_layout_holds_the_same_rows(capi, ctx, small_graph):
     """vgx_reg_batch_evaluate_points_blocked: ONE array of 36 KiB tile blocks ([r x 1024][jac_ref x 1024][jac_read x 1024],
     every constraint padded to whole blocks) instead of three arrays -- the same kernel, so the same values bit for bit;

@@ -131,6 +131,9 @@ SIGNATURES = {
     "vgx_reg_batch_evaluate_points_blocked": (C.c_int, [vp, f64p, C.c_int32, vp, i32p]),
     "vgx_reg_batch_choose_outputs": (C.c_int, [vp, f64p, C.c_int32, C.c_int32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
                                                C.c_int32, i32p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "vgx_reg_batch_alloc_outputs": (C.c_int, [vp, f64p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp), C.POINTER(vp),
+                                              C.POINTER(vp), C.POINTER(C.c_float)]),
+    "vgx_reg_batch_free_outputs": (C.c_int, [vp, vp, vp, vp]),
     "vgx_reg_batch_evaluate_normal": (C.c_int, [vp, f64p, C.c_int32, vp, f64p, i32p]),
     "vgx_reg_batch_count_live": (C.c_int, [vp, f64p, C.c_int32, i64p, i64p]),
     "vgx_reg_batch_launch_order": (C.c_int, [vp, C.c_int32, i32p]),
@@ -602,6 +605,19 @@ class RegistrationBatch:
             self.h, _ptr(poses, f64p), poses.shape[0], n, a_r, a_jr, a_je, int(launches), _ptr(chosen, i32p),
             C.byref(ms), trials))
         return [int(x) for x in chosen], float(ms.value), [float(x) for x in trials]
+
+    def alloc_outputs(self, poses, n_candidates=4, want_jac_ref=True, want_jac_read=True):
+        """vgx_reg_batch_alloc_outputs -> (residuals, jac_ref, jac_read device pointers (0 where not wanted), ms per launch)"""
+        poses = _f64(poses).reshape(-1, 4)
+        r, jo, je, ms = vp(), vp(), vp(), C.c_float()
+        self.ctx.check(self.ctx.lib.vgx_reg_batch_alloc_outputs(self.h, _ptr(poses, f64p), poses.shape[0], int(n_candidates),
+                                                                int(want_jac_ref), int(want_jac_read), C.byref(r), C.byref(jo),
+                                                                C.byref(je), C.byref(ms)))
+        return (r.value or 0), (jo.value or 0), (je.value or 0), float(ms.value)
+
+    def free_outputs(self, r, jo, je):
+        self.ctx.check(self.ctx.lib.vgx_reg_batch_free_outputs(self.h, vp(r) if r else None, vp(jo) if jo else None,
+                                                               vp(je) if je else None))
 
     def evaluate_normal(self, poses, d_normal=None, to_host=True):
         poses = _f64(poses).reshape(-1, 4)

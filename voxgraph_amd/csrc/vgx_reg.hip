@@ -2578,6 +2578,72 @@ int vgx_reg_batch_choose_outputs(vgx_reg_batch b, const double* poses, int32_t n
   return VGX_OK;
 }
 
+// Row arrays chosen for their placement, allocated and released by the library (include/voxgraph_amd.h): n_candidates
+// allocations of each array, vgx_reg_batch_choose_outputs over them, the unchosen ones freed.
+int vgx_reg_batch_alloc_outputs(vgx_reg_batch b, const double* poses, int32_t n_nodes, int32_t n_candidates, int32_t want_jac_ref,
+                                int32_t want_jac_read, void** d_residuals, void** d_jac_ref, void** d_jac_read, float* ms_chosen) {
+  if (!b || !poses || !d_residuals || n_candidates <= 0 || n_candidates > 16 || (want_jac_ref && !d_jac_ref) ||
+      (want_jac_read && !d_jac_read))
+    return VGX_ERR_INVALID;
+  vgx_ctx ctx = b->ctx;
+  *d_residuals = nullptr;
+  if (d_jac_ref) *d_jac_ref = nullptr;
+  if (d_jac_read) *d_jac_read = nullptr;
+  const size_t rows = (size_t)std::max<int64_t>(b->row_offset.back(), 1);
+  void* cand[3][16] = {};
+  const size_t bytes[3] = {rows * 4, rows * 16, rows * 16};
+  const bool want[3] = {true, want_jac_ref != 0, want_jac_read != 0};
+  int have = 0, rc = VGX_OK;
+  {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    VGX_HIP(ctx, hipSetDevice(ctx->device));
+    for (; have < n_candidates; ++have) {
+      bool ok = true;
+      for (int a = 0; a < 3 && ok; ++a)
+        if (want[a]) ok = hipMalloc(&cand[a][have], bytes[a]) == hipSuccess;
+      if (!ok) {  // out of memory: choose among the complete sets there are (at least one is needed)
+        (void)hipGetLastError();
+        for (int a = 0; a < 3; ++a)
+          if (cand[a][have]) (void)hipFree(cand[a][have]), cand[a][have] = nullptr;
+        break;
+      }
+    }
+  }
+  if (have == 0) return set_error(ctx, VGX_ERR_NOMEM, "vgx_reg_batch_alloc_outputs: no memory for one set of row arrays");
+  int32_t chosen[3] = {0, 0, 0};
+  // (a sampling batch cannot be timed without advancing its engines -- vgx_reg_batch_choose_outputs refuses it: the first
+  // set is kept as it is; a batch without rows has nothing to time)
+  if (have > 1 && !b->any_sampling && b->row_offset.back() > 0)
+    rc = vgx_reg_batch_choose_outputs(b, poses, n_nodes, have, cand[0], want[1] ? cand[1] : nullptr, want[2] ? cand[2] : nullptr, 3,
+                                      chosen, ms_chosen, nullptr);
+  else if (ms_chosen)
+    *ms_chosen = 0.0f;
+  {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int a = 0; a < 3; ++a)
+      for (int k = 0; k < have; ++k)
+        if (cand[a][k] && (rc != VGX_OK || k != chosen[a])) (void)hipFree(cand[a][k]);
+  }
+  if (rc != VGX_OK) return rc;
+  *d_residuals = cand[0][chosen[0]];
+  if (want[1]) *d_jac_ref = cand[1][chosen[1]];
+  if (want[2]) *d_jac_read = cand[2][chosen[2]];
+  return VGX_OK;
+}
+
+int vgx_reg_batch_free_outputs(vgx_reg_batch b, void* d_residuals, void* d_jac_ref, void* d_jac_read) {
+  if (!b) return VGX_ERR_INVALID;
+  vgx_ctx ctx = b->ctx;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (void* p : {d_residuals, d_jac_ref, d_jac_read})
+    if (p) (void)hipFree(p);
+  return VGX_OK;
+}
+
 }  // extern "C"
 
 // The fused pass's tile kernel (every solver evaluation): all 21 sums per tile, or -- cost_only -- the squared residual
