@@ -224,11 +224,14 @@ __global__ __launch_bounds__(256) void iso_pass_kernel(IsoParams p, int32_t* __r
                                                       const int64_t* __restrict__ offsets,
                                                       float4* __restrict__ xyzd,
                                                       float* __restrict__ weight,
-                                                      unsigned char* __restrict__ block_has_vertex) {
+                                                      unsigned char* __restrict__ block_has_vertex,
+                                                      const int32_t* __restrict__ block_list) {
   constexpr int EDGES = VPS * VPS * VPS * 3;
   __shared__ IsoTile<VPS> tile;
   __shared__ int s_wave[4];
-  const int b = blockIdx.x;
+  // passes 1-3 run on the blocks pass 0 found candidates in only (block_list; a block without a sign-changing edge of a
+  // fully observed cell owns no vertex: most blocks of a submap)
+  const int b = block_list ? block_list[blockIdx.x] : (int)blockIdx.x;
   iso_load_tile<VPS>(p, b, tile);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -299,14 +302,16 @@ __global__ __launch_bounds__(256) void iso_pass_kernel(IsoParams p, int32_t* __r
 
 template <int MODE>
 static void launch_iso(vgx_submap sm, const IsoParams& p, int32_t* counts, const int64_t* offsets,
-                       float4* xyzd, float* weight, unsigned char* has) {
+                       float4* xyzd, float* weight, unsigned char* has, const int32_t* block_list = nullptr, int n_list = 0) {
   hipStream_t st = sm->ctx->stream;
+  const int grid = block_list ? n_list : sm->n_blocks;
+  if (grid <= 0) return;
   if (sm->vps == 16)
-    hipLaunchKernelGGL((iso_pass_kernel<16, MODE>), dim3(sm->n_blocks), dim3(256), 0, st, p, counts,
-                       offsets, xyzd, weight, has);
+    hipLaunchKernelGGL((iso_pass_kernel<16, MODE>), dim3(grid), dim3(256), 0, st, p, counts,
+                       offsets, xyzd, weight, has, block_list);
   else
-    hipLaunchKernelGGL((iso_pass_kernel<8, MODE>), dim3(sm->n_blocks), dim3(256), 0, st, p, counts,
-                       offsets, xyzd, weight, has);
+    hipLaunchKernelGGL((iso_pass_kernel<8, MODE>), dim3(grid), dim3(256), 0, st, p, counts,
+                       offsets, xyzd, weight, has, block_list);
 }
 
 }  // namespace vgx
@@ -375,8 +380,13 @@ extern "C" int vgx_submap_extract_isosurface_points(vgx_submap sm, double min_vo
     fetch_counts();
   }
   int64_t candidates = 0;
+  std::vector<int32_t> active;   // blocks with candidates, in block order
+  int32_t* d_active = nullptr;
   if (rc == VGX_OK)
-    for (int b = 0; b < nb; ++b) candidates += counts[(size_t)b];
+    for (int b = 0; b < nb; ++b) {
+      candidates += counts[(size_t)b];
+      if (counts[(size_t)b] > 0) active.push_back(b);
+    }
   if (rc == VGX_OK && candidates > 0) {
     unsigned long long cap = 1024;
     while (cap < 2ull * (unsigned long long)candidates) cap <<= 1;
@@ -387,11 +397,14 @@ extern "C" int vgx_submap_extract_isosurface_points(vgx_submap sm, double min_vo
       hipError_t e = hipMemsetAsync(p.keys, 0xff, cap * 8, ctx->stream);
       if (e == hipSuccess) e = hipMemsetAsync(p.ids, 0xff, cap * 8, ctx->stream);
       if (e == hipSuccess) e = hipMemsetAsync(d_has, 0, (size_t)nb, ctx->stream);
+      if (e == hipSuccess) e = hipMemsetAsync(d_counts, 0, (size_t)nb * 4, ctx->stream);   // (pass 2 writes the active blocks' only)
+      if (e == hipSuccess) e = hipMalloc(&d_active, active.size() * 4);
+      if (e == hipSuccess) e = hipMemcpyAsync(d_active, active.data(), active.size() * 4, hipMemcpyHostToDevice, ctx->stream);
       if (e != hipSuccess) fail(e);
     }
     if (rc == VGX_OK) {
-      launch_iso<1>(sm, p, d_counts, nullptr, nullptr, nullptr, nullptr);
-      launch_iso<2>(sm, p, d_counts, nullptr, nullptr, nullptr, nullptr);
+      launch_iso<1>(sm, p, d_counts, nullptr, nullptr, nullptr, nullptr, d_active, (int)active.size());
+      launch_iso<2>(sm, p, d_counts, nullptr, nullptr, nullptr, nullptr, d_active, (int)active.size());
       fetch_counts();
     }
     if (rc == VGX_OK) {
@@ -405,7 +418,7 @@ extern "C" int vgx_submap_extract_isosurface_points(vgx_submap sm, double min_vo
         } else {
           hipError_t e = hipMemcpyAsync(d_offsets, offsets.data(), ((size_t)nb + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
           if (e == hipSuccess) {
-            launch_iso<3>(sm, p, d_counts, d_offsets, ps.d_xyzd, ps.d_weight, d_has);
+            launch_iso<3>(sm, p, d_counts, d_offsets, ps.d_xyzd, ps.d_weight, d_has, d_active, (int)active.size());
             e = hipGetLastError();
           }
           // sum of weights (RCF:124) and the isosurface block list
@@ -430,6 +443,7 @@ extern "C" int vgx_submap_extract_isosurface_points(vgx_submap sm, double min_vo
   if (p.keys) (void)hipFree(p.keys);
   if (p.ids) (void)hipFree(p.ids);
   if (d_counts) (void)hipFree(d_counts);
+  if (d_active) (void)hipFree(d_active);
   if (d_offsets) (void)hipFree(d_offsets);
   if (d_has) (void)hipFree(d_has);
   if (rc == VGX_OK) rc = build_chunk_bounds(ctx, ps);
