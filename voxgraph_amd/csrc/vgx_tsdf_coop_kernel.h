@@ -62,15 +62,15 @@ constexpr unsigned long long kEmptyKey = ~0ull;
 constexpr uint32_t kNil = 0xffffffffu;
 constexpr int kBias = 1 << 20;                // 21 bits per axis in a voxel key
 
-struct RayRec {           // a cast ray: as phase 1 leaves it, and as a pass of the walk hands it on to the next
+struct RayRec {           // a cast ray: as phase 1 leaves it, and as a pass of the walk hands it on to the next (52 bytes)
   int curr[3];
-  int sign_bits;          // (sign + 1) of the three axes, two bits each
+  uint32_t sign_carry;    // (sign + 1) of the three axes, two bits each (bits 0-5); observed voxels in a row so far << 8
   float t_next[3], t_step[3];
   uint32_t left_lo, left_hi;  // voxels of the walk not yet exchanged
-  float gx, gy, gz, weight;
-  uint32_t color;
-  int carry;              // observed voxels in a row so far
-  int rounds;             // rounds spent on it so far (statistics)
+  uint32_t point;         // the point the ray belongs to: its end point, weight and colour are made again from it when a group
+                          // takes the ray (round 6: 24 bytes less per ray -- with them 256 rays + the tables take 40.5 KB of
+                          // LDS and FOUR workgroups fit a CU's 160 KB instead of three, which a depth image's 1200 workgroups
+                          // are short of)
 };
 
 struct UpdateRec {        // one voxel step of one ray
@@ -141,6 +141,7 @@ __global__ __launch_bounds__(256) void tsdf_integrate_coop_kernel(TsdfLayerDev L
   __shared__ uint16_t occ[kMaxRecs];
   __shared__ uint16_t ray_list[2][256];   // the rays of the current pass / handed on to the next
   __shared__ uint32_t sh_n_rays, sh_next_ray, sh_n_recs, sh_n_occ, sh_n_next;
+  __shared__ uint32_t ray_rounds_s[STATS ? 256 : 1];   // counted scans only: rounds a handed-on ray has spent so far
   // TRACE only: which point a queued ray belongs to and how many voxels its walk visits; which (point, step) a record is
   __shared__ uint32_t ray_point[TRACE ? 256 : 1];
   __shared__ unsigned long long ray_total[TRACE ? 256 : 1];
@@ -227,21 +228,13 @@ __global__ __launch_bounds__(256) void tsdf_integrate_coop_kernel(TsdfLayerDev L
     if (cast) {
       const RayDda d = ray_setup(c, L.voxel_size_inv, tx, ty, tz, gx, gy, gz, is_clearing, false);
       cast = !d.bad;
-      float weight = 1.0f;  // getVoxelWeight
-      if (!c.use_const_weight) {
-        const float dist_z = fabsf(pz);
-        weight = dist_z > 1e-6f ? 1.0f / (dist_z * dist_z) : 0.0f;
-      }
       r.curr[0] = d.curr[0]; r.curr[1] = d.curr[1]; r.curr[2] = d.curr[2];
-      r.sign_bits = (d.sign[0] + 1) | ((d.sign[1] + 1) << 2) | ((d.sign[2] + 1) << 4);
+      r.sign_carry = (uint32_t)((d.sign[0] + 1) | ((d.sign[1] + 1) << 2) | ((d.sign[2] + 1) << 4));   // carry 0
       r.t_next[0] = d.t_next[0]; r.t_next[1] = d.t_next[1]; r.t_next[2] = d.t_next[2];
       r.t_step[0] = d.t_step[0]; r.t_step[1] = d.t_step[1]; r.t_step[2] = d.t_step[2];
       r.left_lo = (uint32_t)(unsigned long long)(d.steps + 1);   // the walk visits steps + 1 voxels
       r.left_hi = (uint32_t)((unsigned long long)(d.steps + 1) >> 32);
-      r.carry = 0;
-      r.rounds = 0;
-      r.gx = gx; r.gy = gy; r.gz = gz; r.weight = weight;
-      r.color = rgba ? rgba[i] : 0u;
+      r.point = (uint32_t)i;
       if (TRACE) trace4(I, kEvRay | (d.bad ? 0x100ull : 0ull), (unsigned long long)i, (unsigned long long)(d.steps + 1), 0ull);
     }
     const unsigned long long m = __ballot(cast);
@@ -251,6 +244,7 @@ __global__ __launch_bounds__(256) void tsdf_integrate_coop_kernel(TsdfLayerDev L
     if (cast) {
       const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
       rays[slot] = r;
+      if (STATS) ray_rounds_s[slot] = 0u;
       if (TRACE) {
         ray_point[slot] = (uint32_t)i;
         ray_total[slot] = ((unsigned long long)r.left_hi << 32) | r.left_lo;
@@ -321,15 +315,27 @@ __global__ __launch_bounds__(256) void tsdf_integrate_coop_kernel(TsdfLayerDev L
           ray = (int)ray_list[cur_list][k];
           const RayRec& q = rays[ray];
           cur[0] = q.curr[0]; cur[1] = q.curr[1]; cur[2] = q.curr[2];
-          sg[0] = (q.sign_bits & 3) - 1; sg[1] = ((q.sign_bits >> 2) & 3) - 1; sg[2] = ((q.sign_bits >> 4) & 3) - 1;
+          sg[0] = (int)(q.sign_carry & 3u) - 1; sg[1] = (int)((q.sign_carry >> 2) & 3u) - 1; sg[2] = (int)((q.sign_carry >> 4) & 3u) - 1;
           tn[0] = q.t_next[0]; tn[1] = q.t_next[1]; tn[2] = q.t_next[2];
           ts[0] = q.t_step[0]; ts[1] = q.t_step[1]; ts[2] = q.t_step[2];
           steps_left = (long long)(((unsigned long long)q.left_hi << 32) | q.left_lo);
-          carry = q.carry;
-          rounds = (unsigned long long)q.rounds;
+          carry = (int)(q.sign_carry >> 8);
+          rounds = STATS ? (unsigned long long)ray_rounds_s[ray] : 0ull;
           peekbits = 0;
           nvalid = 0;
-          rgx = q.gx; rgy = q.gy; rgz = q.gz; rweight = q.weight; rcolor = q.color;
+          {
+            // the ray's end point, weight and colour again from its point (the loads are in flight beside the round's
+            // exchanges: they are first needed for the update terms)
+            const size_t pi = (size_t)q.point;
+            const float px = points_C[3 * pi], py = points_C[3 * pi + 1], pz_ = points_C[3 * pi + 2];
+            transform_point(qw, qx, qy, qz, tx, ty, tz, px, py, pz_, rgx, rgy, rgz);
+            rweight = 1.0f;  // getVoxelWeight
+            if (!c.use_const_weight) {
+              const float dist_z = fabsf(pz_);
+              rweight = dist_z > 1e-6f ? 1.0f / (dist_z * dist_z) : 0.0f;
+            }
+            rcolor = rgba ? rgba[pi] : 0u;
+          }
           ray_rounds = 0;
           if (TRACE) {
             rpoint = ray_point[ray];
@@ -436,8 +442,8 @@ __global__ __launch_bounds__(256) void tsdf_integrate_coop_kernel(TsdfLayerDev L
               q.t_next[0] = tn[0]; q.t_next[1] = tn[1]; q.t_next[2] = tn[2];
               q.left_lo = (uint32_t)(unsigned long long)steps_left;
               q.left_hi = (uint32_t)((unsigned long long)steps_left >> 32);
-              q.carry = carry;
-              q.rounds = (int)rounds;
+              q.sign_carry = (q.sign_carry & 0xffu) | ((uint32_t)carry << 8);
+              if (STATS) ray_rounds_s[ray] = (uint32_t)rounds;
               ray_list[cur_list ^ 1][atomicAdd(&sh_n_next, 1u)] = (uint16_t)ray;
             }
             ray = -1;
