@@ -330,6 +330,20 @@ VGX_API int vgx_reg_batch_evaluate_points(vgx_reg_batch batch,
 VGX_API int vgx_reg_batch_evaluate_points_f64(vgx_reg_batch batch, const double* poses /* [n_nodes][4] */, int32_t n_nodes,
                                               void* d_residuals, void* d_jac_ref, void* d_jac_read, int32_t* status);
 
+/* The same rows KEPT BY THE BATCH, and one constraint's slice of them fetched to the host -- SURVEY.md 8b's "vgx_reg_fetch(h,
+ * residuals, jac_ref, jac_read) for the cached per-constraint slice": ONE launch per solver evaluation, and every residual block
+ * still the reference's own N-residual block (f64, Ceres layout, every value the reference's: a ceres::LossFunction or a
+ * covariance estimate sees exactly what RegistrationCostFunction::Evaluate would have given it), where the drop-in
+ * vgx_reg_evaluate is one launch per block.  evaluate_rows_f64: want_jac_* = 0 leaves that block's Jacobians out (Ceres passes
+ * jacobians == NULL, or the block is constant); the arrays are the batch's own (72 B per row, allocated at first use, with a
+ * pinned host mirror filled by one copy per evaluation while they are below 2 GiB).  fetch_rows_f64(c, ...): any output may
+ * be NULL; waits for the evaluation; VGX_ERR_INVALID without one, or for a Jacobian block it was not asked for.
+ * voxgraph_amd/cpp/gpu_registration_rows.h is the ceres::EvaluationCallback built on the pair. */
+VGX_API int vgx_reg_batch_evaluate_rows_f64(vgx_reg_batch batch, const double* poses /* [n_nodes][4] */, int32_t n_nodes,
+                                            int32_t want_jac_ref, int32_t want_jac_read, int32_t* status);
+VGX_API int vgx_reg_batch_fetch_rows_f64(vgx_reg_batch batch, int32_t constraint, double* residuals, double* jac_ref,
+                                         double* jac_read);
+
 
 /* The same pass into ONE output stream: an array of tile blocks, one block per rows_per_block (1024) consecutive residuals
  * of a constraint -- block = [residual f32 x 1024][jac_ref f32x4 x 1024][jac_read f32x4 x 1024], 36 KiB, every constraint

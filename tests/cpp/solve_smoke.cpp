@@ -5,7 +5,9 @@
 //      residuals and Jacobians back over PCIe on every Evaluate),
 //   2. batched: voxgraph_amd::GpuRegistrationBatch as Solver::Options::evaluation_callback, one fused
 //      GPU pass per solver evaluation, each constraint a 9-residual block with the same normal equations,
-//   3. multi-GPU: voxgraph_amd::GpuRegistrationBatchMulti over two contexts (one device here).
+//   3. multi-GPU: voxgraph_amd::GpuRegistrationBatchMulti over two contexts (one device here),
+//   4. rows: voxgraph_amd::GpuRegistrationRows -- the reference's own N-residual blocks, all of them evaluated by one launch per
+//      solver evaluation and fetched slice by slice (SURVEY 8b's vgx_reg_fetch): the drop-in route's VALUES, so its very path.
 // The three routes minimise the same objective, so they must end in the same pose: within 1 mm and
 // 0.01 degree of each other (north_star's end-pose tolerance), and at the true pose within a fraction
 // of a voxel.  Ceres itself is absent from this image: tests/stubs/ceres/ceres.h supplies Problem /
@@ -18,6 +20,7 @@
 #include "gpu_registration_batch.h"
 #include "gpu_registration_batch_multi.h"
 #include "gpu_registration_cost_function.h"
+#include "gpu_registration_rows.h"
 
 namespace {
 float scene_sdf(float x, float y, float z) {
@@ -88,11 +91,13 @@ int main() {
   cfg.registration_point_type = VGX_POINTS_VOXELS;
   ceres::Solver::Options options;                       // pose_graph.cpp:90-97 (tolerances: Ceres defaults)
   options.max_num_iterations = 50;
-  double end[3][4];
+  double end[4][4];
+  int dropin_iterations = 0;
+  double dropin_final_cost = 0;
   // what Ceres evaluates WITHOUT announcing it to an evaluation callback (the callback sits in Solver::Options): a
   // residual-only Problem::Evaluate (PoseGraph::getVisualizationEdges, pose_graph.cpp:173-174) and Covariance::Compute
   // (getEdgeCovarianceMap, pose_graph.cpp:140) -- at the final point, and at a point no solver evaluation saw
-  double final_cost_again[3] = {0, 0, 0}, probe_cost[3] = {0, 0, 0}, covariance[3][16];
+  double final_cost_again[4] = {0, 0, 0, 0}, probe_cost[4] = {0, 0, 0, 0}, covariance[4][16];
   const double probe_offset[4] = {0.02, -0.015, 0.01, 0.004};
   auto unannounced = [&](int route, ceres::Problem* problem, double* b) -> bool {
     bool ok = problem->Evaluate(ceres::Problem::EvaluateOptions(), &final_cost_again[route], nullptr, nullptr, nullptr);
@@ -120,6 +125,8 @@ int main() {
     ceres::Solve(options, &problem, &summary);
     report("drop-in", summary, b);
     for (int k = 0; k < 4; ++k) end[0][k] = b[k];
+    dropin_iterations = summary.num_iterations;
+    dropin_final_cost = summary.final_cost;
     if (!(summary.final_cost < 0.05 * summary.initial_cost)) return std::printf("FAIL: drop-in did not converge\n"), 1;
     if (!unannounced(0, &problem, b)) return std::printf("FAIL: drop-in: Problem::Evaluate / Covariance failed\n"), 1;
     if (std::fabs(final_cost_again[0] - summary.final_cost) > 1e-9 * summary.final_cost) return std::printf("FAIL: drop-in: cost at the final point\n"), 1;
@@ -181,6 +188,41 @@ int main() {
       return std::printf("FAIL: multi: cost-only evaluations did not take the cost-only route\n"), 1;
     if (!unannounced(2, &problem, b)) return std::printf("FAIL: multi: Problem::Evaluate / Covariance failed\n"), 1;
     if (std::fabs(final_cost_again[2] - summary.final_cost) > 1e-9 * summary.final_cost) return std::printf("FAIL: multi: stale cache\n"), 1;
+  }
+  // ---- 4. the reference's own blocks, one launch per evaluation ---------------------------------------------
+  {
+    double a[4], b[4];
+    for (int k = 0; k < 4; ++k) a[k] = a_true[k], b[k] = b_start[k];
+    voxgraph_amd::GpuRegistrationCostFunction ab(ctx, A, B, cfg), ba(ctx, B, A, cfg);
+    voxgraph_amd::GpuRegistrationRows rows(ctx);
+    ceres::Problem problem;
+    ceres::CostFunction* f_ab = rows.AddConstraint(ab.handle(), a, b);
+    ceres::CostFunction* f_ba = rows.AddConstraint(ba.handle(), b, a);
+    if (f_ab->num_residuals() != ab.num_residuals() || f_ba->num_residuals() != ba.num_residuals())
+      return std::printf("FAIL: rows: block sizes\n"), 1;
+    problem.AddResidualBlock(f_ab, nullptr, a, b);
+    problem.AddResidualBlock(f_ba, nullptr, b, a);
+    rows.Finalize();
+    problem.SetParameterBlockConstant(a);
+    ceres::Solver::Options o4 = options;
+    o4.evaluation_callback = &rows;
+    ceres::Solver::Summary summary;
+    ceres::Solve(o4, &problem, &summary);
+    report("rows", summary, b);
+    for (int k = 0; k < 4; ++k) end[3][k] = b[k];
+    std::printf("rows: %d solver evaluations, %ld launches of the batch\n", summary.num_evaluations, rows.evaluations());
+    // the drop-in route's values => its iterations, its cost, its end pose, to the last bit
+    if (summary.num_iterations != dropin_iterations || summary.final_cost != dropin_final_cost)
+      return std::printf("FAIL: rows: not the drop-in route's path (%d iterations, cost %.17g against %d, %.17g)\n", summary.num_iterations,
+                         summary.final_cost, dropin_iterations, dropin_final_cost), 1;
+    for (int k = 0; k < 4; ++k)
+      if (end[3][k] != end[0][k]) return std::printf("FAIL: rows: end pose differs from the drop-in route's\n"), 1;
+    if (rows.evaluations() > summary.num_evaluations) return std::printf("FAIL: rows: more launches than evaluations\n"), 1;
+    if (!unannounced(3, &problem, b)) return std::printf("FAIL: rows: Problem::Evaluate / Covariance failed\n"), 1;
+    if (final_cost_again[3] != summary.final_cost || probe_cost[3] != probe_cost[0])
+      return std::printf("FAIL: rows: unannounced evaluations are not the drop-in route's values\n"), 1;
+    for (int k = 0; k < 16; ++k)
+      if (covariance[3][k] != covariance[0][k]) return std::printf("FAIL: rows: covariance differs from the drop-in route's\n"), 1;
   }
   // ---- the unannounced evaluations agree across the routes (the compressed blocks have the originals' normal equations) ----
   {

@@ -473,6 +473,34 @@ def test_batched_f64_rows_are_the_reference_f64_rows(capi, ctx, small_graph):
     batch.destroy()
 
 
+def test_rows_kept_by_the_batch_and_fetched_per_constraint(capi, ctx, small_graph):
+    """vgx_reg_batch_evaluate_rows_f64 + vgx_reg_batch_fetch_rows_f64 (SURVEY.md 8b's vgx_reg_fetch): one launch for the whole
+    list, every constraint's slice the drop-in vgx_reg_evaluate's values bit for bit; a Jacobian block that was not asked for is
+    refused; so is a fetch without an evaluation"""
+    G = small_graph
+    batch = capi.RegistrationBatch(ctx, G["cfs"], G["pairs"])
+    with pytest.raises(Exception, match="no rows evaluation"):
+        batch.fetch_rows_f64(0, G["cfs"][0].num_residuals())
+    for poses in (G["poses"], G["poses"] + 0.01):
+        assert np.all(batch.evaluate_rows_f64(poses) == 0)
+        for c, (a, b) in enumerate(G["pairs"]):
+            n = G["cfs"][c].num_residuals()
+            r, jo, je = batch.fetch_rows_f64(c, n)
+            ok1, r1, jo1, je1 = _gpu_eval(G["cfs"][c], poses[a], poses[b])
+            assert ok1 and np.array_equal(r, r1) and np.array_equal(jo, jo1) and np.array_equal(je, je1), c
+    # jacobians == nullptr (a cost-only evaluation): residuals alone; a Jacobian fetch is then an error, not stale numbers
+    assert np.all(batch.evaluate_rows_f64(G["poses"], want_jac_ref=False, want_jac_read=False) == 0)
+    n0 = G["cfs"][0].num_residuals()
+    r, _, _ = batch.fetch_rows_f64(0, n0, want_jac_ref=False, want_jac_read=False)
+    a, b = G["pairs"][0]
+    assert np.array_equal(r, _gpu_eval(G["cfs"][0], G["poses"][a], G["poses"][b])[1])
+    with pytest.raises(Exception, match="no such Jacobian"):
+        batch.fetch_rows_f64(0, n0)
+    with pytest.raises(Exception):
+        batch.fetch_rows_f64(len(G["pairs"]), 1)
+    batch.destroy()
+
+
 def test_cost_only_pass_is_the_full_pass_cost_bit_for_bit(capi, ctx, small_graph):
     """vgx_reg_batch_evaluate_cost (what Ceres asks for at every trial step: `jacobians == nullptr`,
     registration_cost_function.cpp:179): the same f32 operations in the same order through the same reduction tree, so the

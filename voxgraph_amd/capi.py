@@ -126,6 +126,8 @@ SIGNATURES = {
     "vgx_reg_batch_row_offsets": (C.c_int, [vp, i64p]),
     "vgx_reg_batch_evaluate_points": (C.c_int, [vp, f64p, C.c_int32, vp, vp, vp, i32p]),
     "vgx_reg_batch_evaluate_points_f64": (C.c_int, [vp, f64p, C.c_int32, vp, vp, vp, i32p]),
+    "vgx_reg_batch_evaluate_rows_f64": (C.c_int, [vp, f64p, C.c_int32, C.c_int32, C.c_int32, i32p]),
+    "vgx_reg_batch_fetch_rows_f64": (C.c_int, [vp, C.c_int32, f64p, f64p, f64p]),
     "vgx_reg_batch_evaluate_cost": (C.c_int, [vp, f64p, C.c_int32, vp, f64p, i32p]),
     "vgx_reg_batch_blocked_layout": (C.c_int, [vp, C.POINTER(C.c_int64), i32p, C.POINTER(C.c_int64)]),
     "vgx_reg_batch_evaluate_points_blocked": (C.c_int, [vp, f64p, C.c_int32, vp, i32p]),
@@ -575,6 +577,22 @@ class RegistrationBatch:
             vp(d_jac_ref) if d_jac_ref else None, vp(d_jac_read) if d_jac_read else None,
             _ptr(status, i32p)))
         return status[:self.n]
+
+    def evaluate_rows_f64(self, poses, want_jac_ref=True, want_jac_read=True):
+        """vgx_reg_batch_evaluate_rows_f64: f64 rows kept by the batch -> status per constraint"""
+        poses = _f64(poses).reshape(-1, 4)
+        status = np.zeros(max(self.n, 1), np.int32)
+        self.ctx.check(self.ctx.lib.vgx_reg_batch_evaluate_rows_f64(self.h, _ptr(poses, f64p), poses.shape[0], int(want_jac_ref),
+                                                                    int(want_jac_read), _ptr(status, i32p)))
+        return status[:self.n]
+
+    def fetch_rows_f64(self, c, n, want_jac_ref=True, want_jac_read=True):
+        """vgx_reg_batch_fetch_rows_f64: constraint c's slice (n = its residuals) -> (residuals, jac_ref or None, jac_read or None)"""
+        r = np.full(n, np.nan)
+        jo = np.full((n, 4), np.nan) if want_jac_ref else None
+        je = np.full((n, 4), np.nan) if want_jac_read else None
+        self.ctx.check(self.ctx.lib.vgx_reg_batch_fetch_rows_f64(self.h, int(c), _ptr(r, f64p), _ptr(jo, f64p), _ptr(je, f64p)))
+        return r, jo, je
 
     def blocked_layout(self):
         """vgx_reg_batch_blocked_layout -> (bytes, rows per block, first_block [n + 1])"""

@@ -371,6 +371,12 @@ struct vgx_reg_batch_s {
   void* d_stream_jobs = nullptr;   // device copy of {state*, out*, count} per job
   bool any_sampling = false;
   bool holds_regs = false;         // regs[*]->users were incremented (vgx_reg_batch_create succeeded)
+  // vgx_reg_batch_evaluate_rows_f64 / _fetch_rows_f64: f64 rows the batch keeps itself (allocated at first use), and -- while
+  // they are small enough (kRowsMirrorLimit) -- their pinned host mirror, filled by ONE device-to-host copy per evaluation
+  double* d_rows[3] = {nullptr, nullptr, nullptr};   // residuals [R], jac_ref [R][4], jac_read [R][4]
+  char* h_rows = nullptr;                            // [R x 8][R x 32][R x 32] pinned, or NULL (too large: fetches copy slices)
+  bool rows_have[3] = {false, false, false};         // what the last rows evaluation produced
+  bool rows_mirrored = false;                        // the mirror holds the last evaluation (its copy may still be in flight)
 };
 
 // ---------------------------------------------------------------------------

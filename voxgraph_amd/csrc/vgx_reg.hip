@@ -2276,6 +2276,9 @@ int vgx_reg_batch_destroy(vgx_reg_batch b) {
       if (--r->users == 0 && r->destroy_requested) orphans.push_back(r);
   }
   for (vgx_reg r : orphans) (void)vgx_reg_destroy(r);
+  for (int a = 0; a < 3; ++a)
+    if (b->d_rows[a]) (void)hipFree(b->d_rows[a]);
+  if (b->h_rows) (void)hipHostFree(b->h_rows);
   if (b->d_raw) (void)hipFree(b->d_raw);
   if (b->d_stream_jobs) (void)hipFree(b->d_stream_jobs);
   if (b->d_node_first) (void)hipFree(b->d_node_first);
@@ -2439,6 +2442,73 @@ int vgx_reg_batch_evaluate_points_f64(vgx_reg_batch b, const double* poses, int3
   launch_points<double>(ctx, b->regs[0]->reading->vps, b->layout, b->d_desc, b->d_pack, b->d_tiles, b->d_tile_dead,
                         (int)b->tiles.size(), d_residuals, d_jac_ref, d_jac_read);
   VGX_HIP(ctx, hipGetLastError());
+  return VGX_OK;
+}
+
+// One evaluation of every constraint as f64 rows KEPT BY THE BATCH, and the slice of one constraint fetched to the host:
+// SURVEY.md 8b's "vgx_reg_fetch(h, residuals, jac_ref, jac_read) for the cached per-constraint slice" (include/voxgraph_amd.h).
+constexpr int64_t kRowsMirrorLimit = (int64_t)2 << 30;   // bytes of rows up to which a pinned host mirror is kept
+
+int vgx_reg_batch_evaluate_rows_f64(vgx_reg_batch b, const double* poses, int32_t n_nodes, int32_t want_jac_ref,
+                                    int32_t want_jac_read, int32_t* status) {
+  if (!b || !poses) return VGX_ERR_INVALID;
+  vgx_ctx ctx = b->ctx;
+  const int64_t R = b->row_offset.back();
+  {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    VGX_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bytes[3] = {(size_t)std::max<int64_t>(R, 1) * 8, (size_t)std::max<int64_t>(R, 1) * 32, (size_t)std::max<int64_t>(R, 1) * 32};
+    const bool want[3] = {true, want_jac_ref != 0, want_jac_read != 0};
+    for (int a = 0; a < 3; ++a)
+      if (want[a] && !b->d_rows[a] && hipMalloc(&b->d_rows[a], bytes[a]) != hipSuccess) {
+        (void)hipGetLastError();
+        return set_error(ctx, VGX_ERR_NOMEM, "vgx_reg_batch_evaluate_rows_f64: no device memory for the batch's own rows");
+      }
+    if (!b->h_rows && R > 0 && R * 72 <= kRowsMirrorLimit &&
+        hipHostMalloc((void**)&b->h_rows, (size_t)R * 72, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();   // no pinned memory: fetches copy their slices from the device
+      b->h_rows = nullptr;
+    }
+    b->rows_mirrored = false;
+  }
+  int rc = vgx_reg_batch_evaluate_points_f64(b, poses, n_nodes, b->d_rows[0], want_jac_ref ? b->d_rows[1] : nullptr,
+                                             want_jac_read ? b->d_rows[2] : nullptr, status);
+  if (rc != VGX_OK) return rc;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  b->rows_have[0] = true;
+  b->rows_have[1] = want_jac_ref != 0;
+  b->rows_have[2] = want_jac_read != 0;
+  if (b->h_rows && R > 0) {   // the whole evaluation in (up to) three copies behind the kernel: every fetch is a host copy
+    VGX_HIP(ctx, hipMemcpyAsync(b->h_rows, b->d_rows[0], (size_t)R * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (b->rows_have[1])
+      VGX_HIP(ctx, hipMemcpyAsync(b->h_rows + (size_t)R * 8, b->d_rows[1], (size_t)R * 32, hipMemcpyDeviceToHost, ctx->stream));
+    if (b->rows_have[2])
+      VGX_HIP(ctx, hipMemcpyAsync(b->h_rows + (size_t)R * 40, b->d_rows[2], (size_t)R * 32, hipMemcpyDeviceToHost, ctx->stream));
+    b->rows_mirrored = true;
+  }
+  return VGX_OK;
+}
+
+int vgx_reg_batch_fetch_rows_f64(vgx_reg_batch b, int32_t c, double* residuals, double* jac_ref, double* jac_read) {
+  if (!b || c < 0 || c >= b->n) return VGX_ERR_INVALID;
+  vgx_ctx ctx = b->ctx;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!b->rows_have[0]) return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_batch_fetch_rows_f64: no rows evaluation to fetch from");
+  if ((jac_ref && !b->rows_have[1]) || (jac_read && !b->rows_have[2]))
+    return set_error(ctx, VGX_ERR_INVALID, "vgx_reg_batch_fetch_rows_f64: the last rows evaluation was asked for no such Jacobian block");
+  VGX_HIP(ctx, hipSetDevice(ctx->device));
+  VGX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the pass (and the mirror's copies) behind it
+  const int64_t R = b->row_offset.back(), r0 = b->row_offset[(size_t)c], n = b->row_offset[(size_t)c + 1] - r0;
+  if (n <= 0) return VGX_OK;
+  if (b->rows_mirrored) {
+    if (residuals) std::memcpy(residuals, b->h_rows + (size_t)r0 * 8, (size_t)n * 8);
+    if (jac_ref) std::memcpy(jac_ref, b->h_rows + (size_t)R * 8 + (size_t)r0 * 32, (size_t)n * 32);
+    if (jac_read) std::memcpy(jac_read, b->h_rows + (size_t)R * 40 + (size_t)r0 * 32, (size_t)n * 32);
+    return VGX_OK;
+  }
+  if (residuals) VGX_HIP(ctx, hipMemcpy(residuals, b->d_rows[0] + r0, (size_t)n * 8, hipMemcpyDeviceToHost));
+  if (jac_ref) VGX_HIP(ctx, hipMemcpy(jac_ref, b->d_rows[1] + 4 * r0, (size_t)n * 32, hipMemcpyDeviceToHost));
+  if (jac_read) VGX_HIP(ctx, hipMemcpy(jac_read, b->d_rows[2] + 4 * r0, (size_t)n * 32, hipMemcpyDeviceToHost));
   return VGX_OK;
 }
 
