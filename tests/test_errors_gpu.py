@@ -235,3 +235,39 @@ def test_round2_entry_points_reject_bad_arguments(capi, ctx):
     assert capi.lpt_shards([], 3).shape == (0,)
     for obj in (integ, layer):
         obj.destroy()
+
+
+def test_round6_entry_points_reject_bad_arguments(capi, ctx):
+    """status codes, never a crash: f64 rows, rows kept by the batch + fetch, library-allocated outputs, the void TSDF call;
+    an EMPTY batch goes through every one of them"""
+    import ctypes as C
+    lib = ctx.lib
+    poses = np.zeros((2, 4))
+    pp = poses.ctypes.data_as(capi.f64p)
+    empty = capi.RegistrationBatch(ctx, [], np.zeros((0, 2), np.int32))
+    r, jo, je, ms = empty.alloc_outputs(poses, n_candidates=2)          # nothing to time: the first set, untimed
+    assert r and jo and je and ms == 0.0
+    assert empty.evaluate_points_f64(poses, r, jo, je).shape == (0,)
+    empty.free_outputs(r, jo, je)
+    assert empty.evaluate_rows_f64(poses).shape == (0,)
+    assert lib.vgx_reg_batch_fetch_rows_f64(empty.h, 0, None, None, None) == capi.ERR_INVALID      # no such constraint
+    out = [capi.vp(), capi.vp(), capi.vp()]
+    for bad_n in (0, 17, -1):
+        assert lib.vgx_reg_batch_alloc_outputs(empty.h, pp, 2, bad_n, 1, 1, C.byref(out[0]), C.byref(out[1]), C.byref(out[2]), None) == capi.ERR_INVALID
+    assert lib.vgx_reg_batch_alloc_outputs(empty.h, pp, 2, 2, 1, 1, C.byref(out[0]), None, C.byref(out[2]), None) == capi.ERR_INVALID   # wanted, nowhere to put it
+    assert lib.vgx_reg_batch_alloc_outputs(None, pp, 2, 2, 0, 0, C.byref(out[0]), None, None, None) == capi.ERR_INVALID
+    assert lib.vgx_reg_batch_evaluate_points_f64(empty.h, pp, 2, None, None, None, None) == capi.ERR_INVALID                           # residuals == NULL
+    assert lib.vgx_reg_batch_evaluate_rows_f64(None, pp, 2, 1, 1, None) == capi.ERR_INVALID
+    assert lib.vgx_reg_batch_evaluate_rows_f64(empty.h, None, 2, 1, 1, None) == capi.ERR_INVALID
+    assert lib.vgx_reg_batch_free_outputs(None, None, None, None) == capi.ERR_INVALID
+    empty.destroy()
+    # the void TSDF call (n_updates == NULL): NULL points with n > 0 and a negative n are refused, an empty scan is legal
+    layer = capi.TsdfLayer(ctx, 0.1, 16)
+    integ = capi.FastTsdfIntegrator(ctx, capi.tsdf_config(), layer)
+    T = np.array([1, 0, 0, 0, 0, 0, 0], F)
+    assert lib.vgx_tsdf_integrate(integ.h, T.ctypes.data_as(capi.f32p), None, None, 5, 0, None) == capi.ERR_INVALID
+    assert lib.vgx_tsdf_integrate(integ.h, T.ctypes.data_as(capi.f32p), None, None, -1, 0, None) == capi.ERR_INVALID
+    assert integ.integratePointCloud(T, np.zeros((0, 3), F), count=False) == 0
+    assert integ.integratePointCloud(T, np.full((100, 3), 0.001, F), count=False) == 0 and layer.stats() == (0, 0)
+    for obj in (integ, layer):
+        obj.destroy()
