@@ -4,7 +4,8 @@ restated voxblox queue): random small submaps (8 / 16 voxels per side, spheres +
 unobserved shells), random EsdfIntegrator settings (max / default / min distance).  The device result is the EXACT fixed point
 of the propagation, the queue stops at improvements below min_diff_m = 1 mm, so the contract is: observed masks equal; fixed-band
 voxels the TSDF's values; the sign of every observed voxel the TSDF's; |gpu| <= |oracle| + 1e-6 and |gpu - oracle| < 2.5 mm;
-the device layer satisfies the fixed-point equation to 1e-6 (tests/test_esdf_gpu.py's checker).
+the device layer satisfies the fixed-point equation to 1e-6 (tests/test_esdf_gpu.py's checker).  One stated exception: voxels on the
+max_distance_m frontier when default_distance_m lies beyond it (see below), counted.
     gpurun -- 'SEEDS=200 python profiles/fuzz_esdf.py'"""
 import os
 import sys
@@ -24,7 +25,7 @@ def main():
     capi.load()
     ctx = capi.Context(0)
     n_seeds, first = int(os.environ.get("SEEDS", "100")), int(os.environ.get("FIRST", "0"))
-    done, worst, worst_fp, voxels = 0, 0.0, 0.0, 0
+    done, worst, worst_fp, voxels, frontier = 0, 0.0, 0.0, 0, 0
     for seed in range(first, first + n_seeds):
         rng = np.random.default_rng(seed)
         vps = int(rng.choice([8, 16]))
@@ -57,10 +58,21 @@ def main():
             assert np.array_equal(ed[fixed], td[fixed]), "fixed band"
             assert np.array_equal(np.sign(ed[obs]), np.sign(td[obs])), "signs"
             if obs.any():
-                diff = np.abs(ed - od)[obs]
-                assert diff.max() < 2.5e-3, ("distance", float(diff.max()))
-                assert np.all(np.abs(ed[obs]) <= np.abs(od[obs]) + 1e-6), "device above the queue's value"
-                worst = max(worst, float(diff.max()))
+                # The frontier of max_distance_m when default_distance_m lies beyond it (not voxblox's defaults, 2 m / 2 m): a voxel is
+                # reached only from a neighbour whose |distance| < max_distance_m, so where that neighbour sits within the queue's 1 mm
+                # slack of the limit one side propagates (max + a step) and the other leaves the default -- a difference of
+                # default - max, by construction of the two algorithms (seed 5840).  Counted, and required to be exactly that case.
+                step_max = float(np.float32(np.sqrt(np.float32(3.0))) * np.float32(vs))
+                a_d, a_o = np.abs(ed), np.abs(od)
+                lo, hi = kw["max_distance_m"] - 2.5e-3, kw["max_distance_m"] + step_max + 1e-6
+                frontier_v = obs & (kw["default_distance_m"] > kw["max_distance_m"]) & (
+                    ((a_o == F(kw["default_distance_m"])) & (a_d > lo) & (a_d <= hi)) | ((a_d == F(kw["default_distance_m"])) & (a_o > lo) & (a_o <= hi)))
+                frontier += int((frontier_v & (np.abs(ed - od) >= 2.5e-3)).sum())
+                cmp_ = obs & ~frontier_v
+                diff = np.abs(ed - od)[cmp_]
+                assert diff.size == 0 or diff.max() < 2.5e-3, ("distance", float(diff.max()))
+                assert np.all(np.abs(ed[cmp_]) <= np.abs(od[cmp_]) + 1e-6), "device above the queue's value"
+                worst = max(worst, float(diff.max()) if diff.size else 0.0)
                 try:
                     err, n_free = _check_fixed_point(sm.block_index, td, ed, eo, vs, vps, kw["min_distance_m"], kw["max_distance_m"],
                                                      kw["default_distance_m"])
@@ -75,8 +87,9 @@ def main():
         finally:
             g.destroy()
         done += 1
-    print("no mismatch in %d submaps (%d observed voxels): worst |device - queue| %.2e m (bar 2.5e-3), worst fixed-point residual %.1e" %
-          (done, voxels, worst, worst_fp))
+    print("no mismatch in %d submaps (%d observed voxels): worst |device - queue| %.2e m (bar 2.5e-3), worst fixed-point residual %.1e; "
+          "%d voxels on the max-distance frontier with one side at the default (default > max configurations only)" %
+          (done, voxels, worst, worst_fp, frontier))
     ctx.close()
     return 0
 
