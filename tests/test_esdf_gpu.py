@@ -132,3 +132,41 @@ def test_esdf_fullsize_256_against_analytic_scene(capi, ctx):
     assert np.array_equal(np.sign(ed[sel]), np.sign(analytic[sel]))
     assert over.min() > -0.15 and np.percentile(over, 99) < 0.2 and np.median(np.abs(over)) < 0.03
     g.destroy()
+
+
+def test_the_max_distance_frontier_when_the_default_lies_beyond_it(capi, ctx):
+    """Outside voxblox's defaults (max_distance_m = default_distance_m = 2 m) the two algorithms have ONE discontinuity: a voxel is
+    reached only from a neighbour whose |distance| < max_distance_m, so where that neighbour lies within the queue's 1 mm slack
+    (min_diff_m) of the limit, the exact fixed point propagates (max + a step) and the queue leaves the default -- or the other
+    way round.  Found by profiles/fuzz_esdf.py (seed 5840: this scene); everything else agrees within 2.5 mm as everywhere."""
+    rng = np.random.default_rng(5840)
+    vps = int(rng.choice([8, 16])); vs = float(rng.choice([0.05, 0.1, 0.2]))
+    dims = tuple(int(x) for x in rng.integers(1, 5, 3)); ext = np.array(dims) * vps * vs
+    c = rng.uniform(0.2, 0.8, 3) * ext
+    sdf = synth.sphere_ground_sdf(tuple(c), float(rng.uniform(0.2, 0.6) * ext.min()), float(rng.uniform(0.1, 0.4) * ext[2]))
+    sm = synth.make_submap(sdf, vs, vps, tuple(int(x) for x in rng.integers(-2, 2, 3)), dims, trunc=3 * vs, esdf_max=10 * vs,
+                           drop_empty_blocks=bool(rng.integers(0, 2)))
+    td = sm.tsdf_distance.copy()
+    if rng.integers(0, 2):
+        td = np.clip(td + rng.normal(0, 0.02 * vs, td.shape).astype(F), -3 * vs, 3 * vs).astype(F)
+    tw = sm.tsdf_weight.copy()
+    if rng.integers(0, 2):
+        tw = np.where(rng.uniform(size=tw.shape) < 0.03, 0, tw).astype(F)
+    max_d = float(rng.choice([2.0, 6 * vs, 12 * vs]))
+    kw = dict(max_distance_m=max_d, default_distance_m=float(rng.choice([max_d, 2.0])), min_distance_m=float(rng.choice([0.2, vs, 2 * vs])))
+    assert kw["default_distance_m"] > kw["max_distance_m"]                       # the configuration the finding needs
+    g = capi.Submap(ctx, 0, vs, vps, sm.block_index, td, tw, None, None)
+    g.generate_esdf(capi.esdf_config(**kw))
+    _, _, ed, eo = g.download_layers(vps)
+    od, oo, _ = orc.esdf_from_tsdf(vs, vps, sm.block_index, td, tw, orc.esdf_config(**kw))
+    assert np.array_equal(eo, oo)
+    obs = oo.astype(bool)
+    far = obs & (np.abs(ed - od) >= 2.5e-3)
+    assert 1 <= int(far.sum()) <= 3                                              # (one voxel on this scene)
+    step_max = float(np.float32(np.sqrt(np.float32(3.0))) * np.float32(vs))
+    for d_dev, d_q in zip(np.abs(ed[far]), np.abs(od[far])):
+        at_default, other = (d_q, d_dev) if d_q == F(kw["default_distance_m"]) else (d_dev, d_q)
+        assert at_default == F(kw["default_distance_m"]) and kw["max_distance_m"] - 2.5e-3 < other <= kw["max_distance_m"] + step_max + 1e-6
+    err, _ = _check_fixed_point(sm.block_index, td, ed, eo, vs, vps, kw["min_distance_m"], kw["max_distance_m"], kw["default_distance_m"])
+    assert err < 1e-6                                                            # the device layer IS the recurrence's fixed point
+    g.destroy()
