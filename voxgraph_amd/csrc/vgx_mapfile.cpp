@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <array>
+#include <exception>
 #include <map>
 #include <string>
 #include <vector>
@@ -90,6 +91,13 @@ double number(Reader& r, int wire_type) {
   return 0.0;
 }
 
+// number() -> integer without undefined behaviour on what a corrupt file can hold (NaN, infinities, 1e300): out of range = `bad`
+int64_t to_int(double v, int64_t lo, int64_t hi, int64_t bad) {
+  if (!(v >= (double)lo && v <= (double)hi)) return bad;
+  return (int64_t)v;
+}
+constexpr int kMaxVoxelsPerSide = 256;   // (voxblox: 8 / 16 / 32; a header beyond this is not a map)
+
 struct Writer {
   std::vector<uint8_t> b;
   void varint(uint64_t v) {
@@ -159,7 +167,7 @@ bool parse_block(const uint8_t* p, size_t n, BlockHeader* h, std::vector<uint32_
     const uint64_t key = r.varint();
     const int field = (int)(key >> 3), wt = (int)(key & 7);
     if (!r.ok) break;
-    if (field == kBlockVoxelsPerSide) h->vps = (int)number(r, wt);
+    if (field == kBlockVoxelsPerSide) h->vps = (int)to_int(number(r, wt), 1, kMaxVoxelsPerSide, 0);
     else if (field == kBlockVoxelSize) h->voxel_size = number(r, wt);
     else if (field == kBlockOriginX) h->origin[0] = number(r, wt);
     else if (field == kBlockOriginY) h->origin[1] = number(r, wt);
@@ -187,7 +195,10 @@ bool parse_block(const uint8_t* p, size_t n, BlockHeader* h, std::vector<uint32_
 // Layer::computeBlockIndexFromOrigin [recalled]: round(origin / block_size)
 void block_index_of(const BlockHeader& h, int32_t out[3]) {
   const double bs = h.voxel_size * h.vps;
-  for (int a = 0; a < 3; ++a) out[a] = (int32_t)std::llround(h.origin[a] / bs);
+  for (int a = 0; a < 3; ++a) {
+    const double q = h.origin[a] / bs;   // (a corrupt origin: NaN, infinity, 1e300 -> block 0, never an out-of-range conversion)
+    out[a] = (q > -2147483000.0 && q < 2147483000.0) ? (int32_t)std::llround(q) : 0;
+  }
 }
 
 bool read_message(Reader& r, BlockRef* ref, const uint8_t* base) {
@@ -219,8 +230,8 @@ bool index_collection(vgx_map_file f) {
     const uint64_t key = head.varint();
     const int field = (int)(key >> 3), wt = (int)(key & 7);
     if (field == kCollectionVoxelSize) voxel_size = number(head, wt);
-    else if (field == kCollectionVoxelsPerSide) vps = (int)number(head, wt);
-    else if (field == kCollectionNumSubmaps) n_submaps = (uint64_t)number(head, wt);
+    else if (field == kCollectionVoxelsPerSide) vps = (int)to_int(number(head, wt), 1, kMaxVoxelsPerSide, 0);
+    else if (field == kCollectionNumSubmaps) n_submaps = (uint64_t)to_int(number(head, wt), 0, (int64_t)1 << 40, 0);
     else head.skip(wt);
   }
   if (!head.ok || vps <= 0 || !(voxel_size > 0)) return false;
@@ -235,9 +246,9 @@ bool index_collection(vgx_map_file f) {
     while (!sh.done()) {
       const uint64_t key = sh.varint();
       const int field = (int)(key >> 3), wt = (int)(key & 7);
-      if (field == kSubmapId) e.info.id = (int64_t)number(sh, wt);
-      else if (field == kSubmapNumBlocks) n_tsdf = (uint64_t)number(sh, wt);
-      else if (field == kSubmapNumEsdfBlocks) n_esdf = (uint64_t)number(sh, wt);
+      if (field == kSubmapId) e.info.id = to_int(number(sh, wt), INT64_MIN / 2, INT64_MAX / 2, 0);
+      else if (field == kSubmapNumBlocks) n_tsdf = (uint64_t)to_int(number(sh, wt), 0, (int64_t)1 << 40, 0);
+      else if (field == kSubmapNumEsdfBlocks) n_esdf = (uint64_t)to_int(number(sh, wt), 0, (int64_t)1 << 40, 0);
       else if (field == kSubmapTransform && wt == 2) {
         Reader t = sh.sub();
         while (!t.done()) {
@@ -283,7 +294,7 @@ bool index_layer(vgx_map_file f) {
     const uint64_t key = head.varint();
     const int field = (int)(key >> 3), wt = (int)(key & 7);
     if (field == kLayerVoxelSize) e.info.voxel_size = number(head, wt);
-    else if (field == kLayerVoxelsPerSide) e.info.voxels_per_side = (int32_t)number(head, wt);
+    else if (field == kLayerVoxelsPerSide) e.info.voxels_per_side = (int32_t)to_int(number(head, wt), 1, kMaxVoxelsPerSide, 0);
     else if (field == kLayerType && wt == 2) {
       Reader s = head.sub();
       type.assign((const char*)s.p, (size_t)(s.end - s.p));
@@ -454,13 +465,22 @@ int vgx_map_file_load_submap(vgx_ctx ctx, vgx_map_file f, int32_t index, vgx_sub
     return fail(f, "vgx_map_file_load_submap: an ESDF-only layer file cannot become a submap");
   const size_t vox = (size_t)e.info.voxels_per_side * e.info.voxels_per_side * e.info.voxels_per_side;
   const size_t nb = e.tsdf.size();
-  std::vector<int32_t> bi(3 * nb);
-  std::vector<float> td(nb * vox), tw(nb * vox), ed;
+  if (nb > (size_t)INT32_MAX) return fail(f, "vgx_map_file_load_submap: more blocks than a submap can hold");
+  std::vector<int32_t> bi;
+  std::vector<float> td, tw, ed;
   std::vector<uint8_t> eo;
   const bool has_esdf = !e.esdf.empty();
-  if (has_esdf) {
-    ed.resize(nb * vox);
-    eo.resize(nb * vox);
+  try {   // (sizes are the file's claims: no exception may cross the C boundary)
+    bi.resize(3 * nb);
+    td.resize(nb * vox);
+    tw.resize(nb * vox);
+    if (has_esdf) {
+      ed.resize(nb * vox);
+      eo.resize(nb * vox);
+    }
+  } catch (const std::exception&) {
+    f->error = "vgx_map_file_load_submap: out of host memory for the submap the file describes";
+    return VGX_ERR_NOMEM;
   }
   int rc = vgx_map_file_read_submap(f, index, bi.data(), td.data(), tw.data(), nullptr,
                                     has_esdf ? ed.data() : nullptr, has_esdf ? eo.data() : nullptr);
